@@ -1,0 +1,294 @@
+"""ctypes binding of the C ABI in include/hfnet_hip.h (libhfnet_hip.so).
+
+Thin plumbing for tests / bench: every call goes through the same `extern "C"` entry points a
+C++ SLAM build would bind.  There is no CPU fallback: without the built library
+or without a GPU these calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhfnet_hip.so")
+
+DESC_DIM = 256
+OK, ERR_INVALID_ARG, ERR_WRONG_MODE, ERR_SHAPE, ERR_DEVICE, ERR_IO, ERR_CAPACITY = range(7)
+MODE_LOCAL_AND_GLOBAL, MODE_LOCAL, MODE_LOCAL_AND_INTERMEDIATE, MODE_INTERMEDIATE_TO_GLOBAL = 0, 1, 2, 3
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4"), ("octave", "<i4")])
+
+# every symbol include/hfnet_hip.h declares (checked by tests/test_abi.py against the header text)
+SYMBOLS = [
+    "hfnet_last_error", "hfnet_abi_version", "hfnet_device_count",
+    "hfnet_engine_create", "hfnet_engine_destroy", "hfnet_engine_info", "hfnet_engine_synchronize",
+    "hfnet_model_create", "hfnet_model_destroy", "hfnet_model_is_valid", "hfnet_model_mode",
+    "hfnet_model_detect", "hfnet_model_detect_global", "hfnet_model_tap",
+    "hfnet_extractor_create", "hfnet_extractor_destroy", "hfnet_extractor_tables",
+    "hfnet_extractor_extract", "hfnet_extractor_extract_batch",
+    "hfnet_descriptor_distance", "hfnet_match_search_by_bow", "hfnet_match_search_for_triangulation",
+    "hfnet_db_create", "hfnet_db_destroy", "hfnet_db_add", "hfnet_db_erase", "hfnet_db_clear", "hfnet_db_query",
+    "hfnet_profile_enable", "hfnet_profile_reset", "hfnet_profile_count", "hfnet_profile_get",
+]
+
+
+class HfnetError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"hfnet status {status}: {msg}")
+        self.status = status
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m hfnet_slam_amd.build` (there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.hfnet_last_error.restype = C.c_char_p
+        for s in SYMBOLS:
+            getattr(L, s)  # AttributeError if the library does not export it
+        for s in ("hfnet_engine_destroy", "hfnet_model_destroy", "hfnet_extractor_destroy", "hfnet_db_destroy"):
+            getattr(L, s).restype = None
+            getattr(L, s).argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return lib().hfnet_last_error().decode()
+
+
+def _chk(status: int) -> None:
+    if status != OK:
+        raise HfnetError(status, last_error())
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def device_count() -> int:
+    return int(lib().hfnet_device_count())
+
+
+class Engine:
+    def __init__(self, weights_path: str, device: int = 0):
+        self.h = C.c_void_p()
+        _chk(lib().hfnet_engine_create(int(device), weights_path.encode(), C.byref(self.h)))
+        q = lambda w: lib().hfnet_engine_info(self.h, w)
+        self.stem_out, self.c_local, self.c_global, self.n_clusters, self.global_dim, self.device = (q(i) for i in range(6))
+
+    def close(self):
+        if self.h:
+            lib().hfnet_engine_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _chk(lib().hfnet_engine_synchronize(self.h))
+
+    # ---- Matcher ---------------------------------------------------------------------------
+    def descriptor_distance(self, a, b) -> float:
+        a = np.ascontiguousarray(a, np.float32).ravel(); b = np.ascontiguousarray(b, np.float32).ravel()
+        out = C.c_float(0)
+        _chk(lib().hfnet_descriptor_distance(self.h, _p(a), _p(b), a.size, C.byref(out)))
+        return out.value
+
+    def search_by_bow(self, q, t, th_low: float = 0.6):
+        q = np.ascontiguousarray(q, np.float32); t = np.ascontiguousarray(t, np.float32)
+        dim = q.shape[1] if q.ndim == 2 and q.shape[0] else t.shape[1]
+        match = np.full((q.shape[0],), -2, np.int32); dist = np.zeros((q.shape[0],), np.float32)
+        n = C.c_int(-1)
+        _chk(lib().hfnet_match_search_by_bow(self.h, _p(q), q.shape[0], _p(t), t.shape[0], dim, C.c_float(th_low),
+                                             _p(match), _p(dist), C.byref(n), 0))
+        return n.value, match, dist
+
+    def search_for_triangulation(self, d1, d2, th_high: float = 0.75):
+        d1 = np.ascontiguousarray(d1, np.float32); d2 = np.ascontiguousarray(d2, np.float32)
+        dim = d1.shape[1] if d1.ndim == 2 and d1.shape[0] else d2.shape[1]
+        match = np.full((d1.shape[0],), -2, np.int32)
+        n = C.c_int(-1)
+        _chk(lib().hfnet_match_search_for_triangulation(self.h, _p(d1), d1.shape[0], _p(d2), d2.shape[0], dim,
+                                                        C.c_float(th_high), _p(match), C.byref(n), 0))
+        return n.value, match
+
+    # ---- profiling -------------------------------------------------------------------------
+    def profile_enable(self, on: bool):
+        _chk(lib().hfnet_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        _chk(lib().hfnet_profile_reset(self.h))
+
+    def profile(self):
+        """{name: (launches, total_ms)}"""
+        out = {}
+        for i in range(lib().hfnet_profile_count(self.h)):
+            name = C.create_string_buffer(64); n = C.c_int(0); ms = C.c_double(0)
+            _chk(lib().hfnet_profile_get(self.h, i, name, 64, C.byref(n), C.byref(ms)))
+            out[name.value.decode()] = (n.value, ms.value)
+        return out
+
+
+class Model:
+    """== one BaseModel instance (include/Extractors/BaseModel.h:38-54)."""
+
+    def __init__(self, engine: Engine, mode: int, height: int, width: int, max_keypoints: int = 1000):
+        self.engine, self.mode, self.height, self.width, self.max_keypoints = engine, mode, height, width, max_keypoints
+        self.h = C.c_void_p()
+        _chk(lib().hfnet_model_create(engine.h, mode, height, width, max_keypoints, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().hfnet_model_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def is_valid(self) -> bool:
+        return bool(lib().hfnet_model_is_valid(self.h))
+
+    def detect(self, img: np.ndarray, n_keypoints: int, threshold: float, with_aux=None):
+        """Returns (status, kps, desc, aux).  status != OK mirrors the reference's `return false`."""
+        img = np.asarray(img)
+        if img.dtype != np.uint8 or img.ndim != 2 or img.strides[1] != 1:
+            img = np.ascontiguousarray(img, np.uint8)
+        kps = np.zeros((max(n_keypoints, 1),), KP_DTYPE)
+        desc = np.zeros((max(n_keypoints, 1), DESC_DIM), np.float32)
+        if with_aux is None:
+            with_aux = self.mode != MODE_LOCAL
+        aux = None
+        if with_aux:
+            if self.mode == MODE_LOCAL_AND_INTERMEDIATE:
+                aux = np.zeros((self.height // 8, self.width // 8, self.engine.c_local), np.float32)
+            else:
+                aux = np.zeros((self.engine.global_dim,), np.float32)
+        n = C.c_int(0)
+        st = lib().hfnet_model_detect(self.h, _p(img), img.strides[0], n_keypoints, C.c_float(threshold), _p(kps), _p(desc),
+                                      _p(aux), C.byref(n))
+        return st, kps[:n.value].copy(), desc[:n.value].copy(), aux
+
+    def detect_global(self, intermediate: np.ndarray):
+        x = np.ascontiguousarray(intermediate, np.float32)
+        g = np.zeros((self.engine.global_dim,), np.float32)
+        st = lib().hfnet_model_detect_global(self.h, _p(x), _p(g))
+        return st, g
+
+    def tap(self, tap_id: int, shape=None) -> np.ndarray:
+        cap = 1 << 26
+        buf = np.empty((cap,), np.float32)
+        cnt = C.c_size_t(0)
+        _chk(lib().hfnet_model_tap(self.h, tap_id, _p(buf), C.c_size_t(cap), C.byref(cnt)))
+        out = buf[:cnt.value].copy()
+        return out.reshape(shape) if shape is not None else out
+
+
+class Extractor:
+    """== HFextractor (include/Extractors/HFextractor.h) over the engine's per-level models."""
+
+    def __init__(self, engine: Engine, width: int, height: int, n_features=1000, threshold=0.01, scale_factor=1.2,
+                 n_levels=4, max_batch=1):
+        self.engine, self.width, self.height, self.n_features, self.n_levels, self.max_batch = \
+            engine, width, height, n_features, n_levels, max_batch
+        self.h = C.c_void_p()
+        _chk(lib().hfnet_extractor_create(engine.h, width, height, n_features, C.c_float(threshold), C.c_float(scale_factor),
+                                          n_levels, max_batch, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().hfnet_extractor_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def tables(self):
+        sf = np.zeros(self.n_levels, np.float32)
+        fpl, lw, lh = (np.zeros(self.n_levels, np.int32) for _ in range(3))
+        _chk(lib().hfnet_extractor_tables(self.h, _p(sf), _p(fpl), _p(lw), _p(lh)))
+        return sf, fpl, lw, lh
+
+    def extract(self, img: np.ndarray):
+        """HFextractor::operator().  Returns (n, kps, desc, global, n_per_level)."""
+        img = np.asarray(img)
+        if img.dtype != np.uint8 or img.ndim != 2 or img.strides[1] != 1:
+            img = np.ascontiguousarray(img, np.uint8)
+        kps = np.zeros((self.n_features,), KP_DTYPE)
+        desc = np.zeros((self.n_features, DESC_DIM), np.float32)
+        g = np.zeros((self.engine.global_dim,), np.float32)
+        npl = np.zeros((self.n_levels,), np.int32)
+        n = C.c_int(0)
+        _chk(lib().hfnet_extractor_extract(self.h, _p(img), img.strides[0], _p(kps), _p(desc), _p(g), C.byref(n), _p(npl)))
+        return n.value, kps[:max(n.value, 0)].copy(), desc[:max(n.value, 0)].copy(), g, npl
+
+    def extract_batch(self, imgs: np.ndarray):
+        """imgs: [F, H, W] uint8 (host).  Returns (n[F], kps[F, n_features], desc[F, n_features, 256], global[F, G])."""
+        imgs = np.ascontiguousarray(imgs, np.uint8)
+        f = imgs.shape[0]
+        kps = np.zeros((f, self.n_features), KP_DTYPE)
+        desc = np.zeros((f, self.n_features, DESC_DIM), np.float32)
+        g = np.zeros((f, self.engine.global_dim), np.float32)
+        n = np.zeros((f,), np.int32)
+        _chk(lib().hfnet_extractor_extract_batch(self.h, f, _p(imgs), imgs.strides[1], C.c_size_t(imgs.strides[0]), _p(kps), _p(desc),
+                                                 _p(g), _p(n), 0))
+        return n, kps, desc, g
+
+    def extract_batch_device(self, n_frames, d_images, row_stride, frame_stride, d_kps, d_desc, d_global, d_n):
+        """All pointers are raw device addresses (ints); only enqueues work on the engine's GPU."""
+        _chk(lib().hfnet_extractor_extract_batch(self.h, int(n_frames), C.c_void_p(d_images), int(row_stride), C.c_size_t(frame_stride),
+                                                 C.c_void_p(d_kps), C.c_void_p(d_desc), C.c_void_p(d_global), C.c_void_p(d_n), 1))
+
+
+class Database:
+    """== the descriptor store + linear scans of KeyFrameDatabase (src/KeyFrameDatabase.cc:75-104,170-197)."""
+
+    def __init__(self, engine: Engine, capacity: int, dim: int = 4096):
+        self.engine, self.capacity, self.dim = engine, capacity, dim
+        self.h = C.c_void_p()
+        _chk(lib().hfnet_db_create(engine.h, capacity, dim, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().hfnet_db_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add(self, slot: int, desc: np.ndarray):
+        d = np.ascontiguousarray(desc, np.float32).ravel()
+        assert d.size == self.dim
+        _chk(lib().hfnet_db_add(self.h, int(slot), _p(d)))
+
+    def erase(self, slot: int):
+        _chk(lib().hfnet_db_erase(self.h, int(slot)))
+
+    def clear(self):
+        _chk(lib().hfnet_db_clear(self.h))
+
+    def query(self, q: np.ndarray, mode: int = 0, want_scores=False):
+        q = np.ascontiguousarray(q, np.float32).ravel()
+        assert q.size == self.dim
+        slot = np.zeros((self.capacity,), np.int32); score = np.zeros((self.capacity,), np.float32)
+        n = C.c_int(0); best = C.c_float(0)
+        scores = np.zeros((self.capacity,), np.float32) if want_scores else None
+        _chk(lib().hfnet_db_query(self.h, _p(q), mode, _p(slot), _p(score), C.byref(n), C.byref(best), _p(scores)))
+        return slot[:n.value].copy(), score[:n.value].copy(), best.value, scores

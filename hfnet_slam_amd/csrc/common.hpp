@@ -1,0 +1,131 @@
+// common.hpp -- shared declarations of the HIP library (host side).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/hfnet_hip.h"
+
+namespace hfnet {
+
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define HF_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            ::hfnet::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+            return HFNET_ERR_DEVICE;                                                              \
+        }                                                                                         \
+    } while (0)
+
+#define HF_TRY(expr)                      \
+    do {                                  \
+        int s__ = (expr);                 \
+        if (s__ != HFNET_OK) return s__;  \
+    } while (0)
+
+// ---- device channel layout ------------------------------------------------------------------
+// Activations that feed an MFMA convolution are stored with the channels of every group of 8
+// permuted: physical slot p of a group holds logical channel {0,2,4,6,1,3,5,7}[p].  A lane of
+// v_mfma_f32_32x32x2_f32 then loads 4 consecutive floats (lanes 0-31: slots 0-3, lanes 32-63:
+// slots 4-7) and four back-to-back MFMAs consume logical channels (0,1), (2,3), (4,5), (6,7) --
+// the accumulation order of the oracle -- without any in-register shuffling.
+inline int logical_of_phys(int p) { const int r = p & 7; return (p & ~7) | (r < 4 ? 2 * r : 2 * (r - 4) + 1); }
+inline int phys_of_logical(int i) { return (i & ~7) | ((i & 1) << 2) | ((i & 7) >> 1); }
+
+inline int same_out(int in, int stride) { return (in + stride - 1) / stride; }
+inline int same_pad_before(int in, int k, int stride) {
+    const int o = same_out(in, stride);
+    int total = (o - 1) * stride + k - in;
+    if (total < 0) total = 0;
+    return total / 2;
+}
+inline int cv_round(float v) { return (int)lrintf(v); }
+
+// ---- geometry handed to spatial kernels (by value) --------------------------------------------
+struct LevelGeom {
+    int H, W;            // input rows / cols
+    int Ho, Wo;          // output rows / cols
+    int pt, pl;          // padding before (top / left)
+    long long in_off;    // first input pixel of this level's frame 0 in the layer's input tensor
+    long long out_off;   // first output pixel of this level's frame 0 in the output tensor
+};
+struct Geom {
+    int n_levels;
+    int batch;           // frames per level; image id = level * batch + frame
+    LevelGeom lv[HFNET_MAX_LEVELS];
+};
+
+// u8 source images of every level (pyramid): frame f of level l starts at ptr[l] + f * frame_stride[l]
+struct ImageSet {
+    const uint8_t* ptr[HFNET_MAX_LEVELS];
+    long long frame_stride[HFNET_MAX_LEVELS];
+    int row_stride[HFNET_MAX_LEVELS];
+};
+
+// ---- weights ------------------------------------------------------------------------------------
+struct HostTensor { std::string name; int ndim; int dims[4]; const float* data; };
+
+struct WeightFile {
+    std::vector<unsigned char> blob;
+    std::vector<HostTensor> tensors;
+    int load(const char* path);
+    const HostTensor* find(const std::string& name) const;
+};
+
+// one convolution packed for the MFMA kernels
+struct ConvPack {
+    int taps = 1;        // 1 (1x1) or 9 (3x3)
+    int cin = 0;         // channels per tap (multiple of 8)
+    int n = 0;           // valid output columns
+    int nt_total = 0;    // 32-wide column tiles (padded to a multiple of nt_per_block)
+    int nt_per_block = 1;
+    float* w = nullptr;      // device: [taps*cin/8][nt_total][64][4]
+    float* scale = nullptr;  // device: [nt_total*32]
+    float* shift = nullptr;  // device: [nt_total*32]
+};
+struct DwPack { int c = 0; float* w = nullptr; float* scale = nullptr; float* shift = nullptr; };  // [9][C] phys
+struct BlockPack { int cin, expand, stride, cout, residual, has_expand; ConvPack ex; DwPack dw; ConvPack pr; };
+
+struct DeviceWeights {
+    int stem_out = 0, c_local = 0, c_global = 0, n_clusters = 0, global_dim = 0, det_hidden = 0;
+    float* stem_w = nullptr;      // [9][stem_out] phys order
+    float* stem_scale = nullptr;
+    float* stem_shift = nullptr;
+    BlockPack blocks[17];
+    ConvPack desc1, desc2, det1, det2, memb;
+    float* clusters = nullptr;    // [K][D] logical
+    float* fc_wt = nullptr;       // [global_dim][K*D]  (transposed for coalesced tree256 dot products)
+    float* fc_b = nullptr;
+    std::vector<void*> allocations;
+    int build(const WeightFile& wf);
+    void release();
+};
+
+// ---- profiling ------------------------------------------------------------------------------------
+struct Profiler {
+    bool enabled = false;
+    struct Rec { hipEvent_t a, b; int id; };
+    std::vector<std::string> names;
+    std::vector<int> launches;
+    std::vector<double> total_ms;
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    int id_of(const char* name);
+    void begin(const char* name, hipStream_t s);
+    void end(hipStream_t s);
+    void flush();
+    void reset();
+};
+
+}  // namespace hfnet

@@ -1,0 +1,883 @@
+// engine.hip -- network plan / forward pass over a ragged [level][frame] batch, and the objects
+// behind the C ABI.  Host code; every kernel lives in kernels_*.hip.
+//
+// Reference call stack this replaces:
+//   HFextractor::operator() -> ComputePyramid -> per level BaseModel::Detect
+//     -> Mat2Tensor, session Run / executeV2, GetLocalFeaturesFromTensor   (src/Extractors/*.cc)
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace hfnet {
+
+// ------------------------------------------------------------------------------------ memory
+int DevMem::ensure(size_t n) {
+    if (n <= bytes) return HFNET_OK;
+    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    HF_HIP(hipMalloc(&p, n));
+    bytes = n;
+    return HFNET_OK;
+}
+void DevMem::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+Engine::~Engine() {
+    (void)hipSetDevice(device);
+    prof.flush();
+    for (auto ev : prof.pool) (void)hipEventDestroy(ev);
+    for (DevMem* m : {&m_a, &m_b, &m_s, &m_qn, &m_tn, &m_key, &m_i0, &m_i1, &m_f0, &m_cnt}) m->release();
+    w.release();
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+template <class T>
+static int dalloc(std::vector<void*>& allocs, T** out, size_t count) {
+    void* p = nullptr;
+    HF_HIP(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    allocs.push_back(p);
+    *out = (T*)p;
+    return HFNET_OK;
+}
+
+#define HF_LAUNCH(eng, strm, name, call)                                                   \
+    do {                                                                                   \
+        hipError_t er__;                                                                   \
+        if ((eng)->prof.enabled) {                                                         \
+            std::lock_guard<std::mutex> lk__((eng)->prof_mu);                              \
+            (eng)->prof.begin(name, strm);                                                 \
+            er__ = (call);                                                                 \
+            (eng)->prof.end(strm);                                                         \
+        } else {                                                                           \
+            er__ = (call);                                                                 \
+        }                                                                                  \
+        if (er__ != hipSuccess) {                                                          \
+            set_error("launch %s failed: %s", name, hipGetErrorString(er__));              \
+            return HFNET_ERR_DEVICE;                                                       \
+        }                                                                                  \
+    } while (0)
+
+// ------------------------------------------------------------------------------------ Net
+static int layer_channels(const DeviceWeights& w, int layer) { return layer == 1 ? w.stem_out : w.blocks[layer - 2].cout; }
+
+static void compute_offsets(Net& n, int batch) {
+    const NetConfig& c = n.cfg;
+    for (int L = 1; L <= 18; ++L) {
+        long long off = 0;
+        const int nl = (L <= 7) ? c.n_levels : 1;
+        for (int l = 0; l < HFNET_MAX_LEVELS + 1; ++l) n.pix[L][l] = 0;
+        for (int l = 0; l < nl; ++l) { n.pix[L][l] = off; off += (long long)batch * n.lp[l].h[L] * n.lp[l].w[L]; }
+        for (int l = nl; l <= HFNET_MAX_LEVELS; ++l) n.pix[L][l] = off;
+    }
+    long long oi = 0, oc = 0;
+    for (int l = 0; l < c.n_levels; ++l) {
+        n.pix_img[l] = oi; oi += (long long)batch * n.lp[l].Hc * n.lp[l].Wc;
+        n.pix_cell[l] = oc; oc += (long long)batch * n.lp[l].h[7] * n.lp[l].w[7];
+    }
+    for (int l = c.n_levels; l <= HFNET_MAX_LEVELS; ++l) { n.pix_img[l] = oi; n.pix_cell[l] = oc; }
+}
+
+int Net::build(Engine* eng, const NetConfig& c) {
+    e = eng;
+    cfg = c;
+    const DeviceWeights& w = e->w;
+    if (c.n_levels < 1 || c.n_levels > HFNET_MAX_LEVELS || c.batch < 1) { set_error("net: bad level / batch count"); return HFNET_ERR_INVALID_ARG; }
+    if (c.from_intermediate && (c.n_levels != 1 || !c.global)) { set_error("net: intermediate input needs one level and the global head"); return HFNET_ERR_INVALID_ARG; }
+    for (int l = 0; l < c.n_levels; ++l) {
+        LevelPlan& p = lp[l];
+        p = LevelPlan();
+        p.W = c.width[l]; p.H = c.height[l];
+        int first = 1;
+        if (c.from_intermediate) {
+            p.h[7] = p.H; p.w[7] = p.W; first = 8;
+        } else {
+            p.Hc = p.H / 8 * 8; p.Wc = p.W / 8 * 8;
+            if (p.Hc < 8 || p.Wc < 8) { set_error("net: level %d image %dx%d too small", l, p.W, p.H); return HFNET_ERR_SHAPE; }
+        }
+        for (int L = first; L <= 18; ++L) {
+            const int stride = L == 1 ? 2 : w.blocks[L - 2].stride;
+            const int ih = L == 1 ? p.Hc : p.h[L - 1], iw = L == 1 ? p.Wc : p.w[L - 1];
+            p.h[L] = same_out(ih, stride); p.w[L] = same_out(iw, stride);
+            p.pt[L] = same_pad_before(ih, 3, stride); p.pl[L] = same_pad_before(iw, 3, stride);
+        }
+        if (!c.from_intermediate && (p.h[7] != p.Hc / 8 || p.w[7] != p.Wc / 8)) { set_error("net: unexpected layer_7 size"); return HFNET_ERR_SHAPE; }
+    }
+    compute_offsets(*this, c.batch);
+    HF_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    const int first_layer = c.from_intermediate ? 7 : 1;
+    const int last_layer = c.global ? 18 : 7;
+    size_t exp_max = 0, dw_max = 0;
+    for (int L = first_layer; L <= last_layer; ++L) {
+        HF_TRY(dalloc(allocs, &act[L], (size_t)pix[L][HFNET_MAX_LEVELS] * layer_channels(w, L)));
+        if (L >= 2 && L > first_layer) {
+            const BlockPack& b = w.blocks[L - 2];
+            exp_max = std::max(exp_max, (size_t)pix[L - 1][HFNET_MAX_LEVELS] * b.expand);
+            dw_max = std::max(dw_max, (size_t)pix[L][HFNET_MAX_LEVELS] * b.expand);
+        }
+    }
+    // layers 8.. only cover level 0, but their input (layer 7) buffer spans all levels: size by level-0 pixels
+    HF_TRY(dalloc(allocs, &exp_buf, exp_max));
+    HF_TRY(dalloc(allocs, &dw_buf, dw_max));
+    if (c.local) {
+        const size_t pc = (size_t)pix_cell[HFNET_MAX_LEVELS], pi = (size_t)pix_img[HFNET_MAX_LEVELS];
+        HF_TRY(dalloc(allocs, &desc_hidden, pc * HFNET_DESC_DIM));
+        HF_TRY(dalloc(allocs, &desc_raw, pc * HFNET_DESC_DIM));
+        HF_TRY(dalloc(allocs, &desc_norm, pc * HFNET_DESC_DIM));
+        HF_TRY(dalloc(allocs, &det_hidden, pc * w.det_hidden));
+        HF_TRY(dalloc(allocs, &logits, pc * 65));
+        HF_TRY(dalloc(allocs, &dense, pi));
+        HF_TRY(dalloc(allocs, &nms, pi));
+        cand_stride = 0;
+        for (int l = 0; l < c.n_levels; ++l) cand_stride = std::max(cand_stride, (long long)lp[l].Hc * lp[l].Wc);
+        const size_t images = (size_t)c.n_levels * c.batch;
+        HF_TRY(dalloc(allocs, &cand, images * (size_t)cand_stride));
+        HF_TRY(dalloc(allocs, &counters, images));
+        HF_TRY(dalloc(allocs, &kps_level, images * (size_t)c.max_keypoints));
+        HF_TRY(dalloc(allocs, &n_level, images));
+    }
+    if (c.global) {
+        const size_t pg = (size_t)c.batch * lp[0].h[18] * lp[0].w[18];
+        const size_t N = (size_t)w.n_clusters * w.c_global;
+        HF_TRY(dalloc(allocs, &memb, pg * w.n_clusters));
+        HF_TRY(dalloc(allocs, &vlad_raw, (size_t)c.batch * N));
+        HF_TRY(dalloc(allocs, &vlad_tap, (size_t)c.batch * N));
+        HF_TRY(dalloc(allocs, &vlad_out, (size_t)c.batch * N));
+        HF_TRY(dalloc(allocs, &fc_raw, (size_t)c.batch * w.global_dim));
+        HF_TRY(dalloc(allocs, &global_out, (size_t)c.batch * w.global_dim));
+    }
+    HF_TRY(dalloc(allocs, &inter_logical, (size_t)c.batch * lp[0].h[7] * lp[0].w[7] * w.c_local));
+    return HFNET_OK;
+}
+
+void Net::release() {
+    for (void* p : allocs) (void)hipFree(p);
+    allocs.clear();
+    if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+}
+
+// layer_in == 0: the cropped input image
+Geom Net::geom(int layer_in, int layer_out, int first_level, int n_used) const {
+    Geom g;
+    std::memset(&g, 0, sizeof g);
+    g.n_levels = n_used;
+    g.batch = cfg.batch;
+    for (int i = 0; i < n_used; ++i) {
+        const int l = first_level + i;
+        const LevelPlan& p = lp[l];
+        LevelGeom& v = g.lv[i];
+        v.H = layer_in == 0 ? p.Hc : p.h[layer_in];
+        v.W = layer_in == 0 ? p.Wc : p.w[layer_in];
+        v.Ho = p.h[layer_out]; v.Wo = p.w[layer_out];
+        v.pt = p.pt[layer_out]; v.pl = p.pl[layer_out];
+        v.in_off = layer_in == 0 ? 0 : pix[layer_in][l];
+        v.out_off = pix[layer_out][l];
+    }
+    return g;
+}
+
+static int run_block(Net& n, int L, int n_used) {   // layer L = block L-2, input act[L-1]
+    Engine* e = n.e;
+    const BlockPack& b = e->w.blocks[L - 2];
+    const long long p_in = n.pix[L - 1][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
+    const long long p_out = n.pix[L][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
+    const float* src = n.act[L - 1];
+    if (b.has_expand) {
+        HF_LAUNCH(e, n.stream, "pointwise_expand", launch_pointwise(n.act[L - 1], b.ex, nullptr, n.exp_buf, p_in, 1, n.stream));
+        src = n.exp_buf;
+    }
+    const Geom g = n.geom(L - 1, L, 0, n_used);
+    HF_LAUNCH(e, n.stream, b.stride == 1 ? "depthwise_s1" : "depthwise_s2", launch_depthwise(src, b.dw, b.stride, n.dw_buf, g, n.stream));
+    HF_LAUNCH(e, n.stream, "pointwise_project",
+              launch_pointwise(n.dw_buf, b.pr, b.residual ? n.act[L - 1] : nullptr, n.act[L], p_out, 0, n.stream));
+    return HFNET_OK;
+}
+
+int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget) {
+    const DeviceWeights& w = e->w;
+    const int NL = cfg.n_levels;
+    if (!cfg.from_intermediate) {
+        const Geom gs = geom(0, 1, 0, NL);
+        HF_LAUNCH(e, stream, "stem", launch_stem(imgs, w.stem_w, w.stem_scale, w.stem_shift, w.stem_out, act[1], gs, stream));
+        for (int L = 2; L <= 7; ++L) HF_TRY(run_block(*this, L, NL));
+    }
+    if (cfg.local) {
+        const long long pc = pix_cell[HFNET_MAX_LEVELS];
+        Geom gh = geom(7, 7, 0, NL);
+        for (int l = 0; l < NL; ++l) { gh.lv[l].pt = gh.lv[l].pl = 1; gh.lv[l].out_off = pix_cell[l]; }
+        HF_LAUNCH(e, stream, "conv3x3_desc", launch_conv3x3(act[7], w.desc1, desc_hidden, 1, gh, stream));
+        HF_LAUNCH(e, stream, "pointwise_desc", launch_pointwise(desc_hidden, w.desc2, nullptr, desc_raw, pc, 0, stream));
+        HF_LAUNCH(e, stream, "l2norm_desc", launch_l2norm256(desc_raw, desc_norm, pc, stream));
+        HF_LAUNCH(e, stream, "conv3x3_det", launch_conv3x3(act[7], w.det1, det_hidden, 1, gh, stream));
+        HF_LAUNCH(e, stream, "pointwise_det", launch_pointwise(det_hidden, w.det2, nullptr, logits, pc, 0, stream));
+        Geom gd = geom(7, 7, 0, NL);
+        for (int l = 0; l < NL; ++l) { gd.lv[l].Ho = lp[l].Hc; gd.lv[l].Wo = lp[l].Wc; gd.lv[l].in_off = pix_cell[l]; gd.lv[l].out_off = pix_img[l]; }
+        HF_LAUNCH(e, stream, "softmax_d2s", launch_softmax_d2s(logits, 65, dense, gd, stream));
+        Geom gn = gd;
+        for (int l = 0; l < NL; ++l) { gn.lv[l].H = lp[l].Hc; gn.lv[l].W = lp[l].Wc; gn.lv[l].in_off = pix_img[l]; }
+        HF_HIP(hipMemsetAsync(counters, 0, sizeof(unsigned int) * (size_t)NL * cfg.batch, stream));
+        HF_LAUNCH(e, stream, "nms", launch_nms(dense, nms, cand, counters, cand_stride, threshold, gn, stream));
+        HF_LAUNCH(e, stream, "topk", launch_topk(cand, counters, cand_stride, budget, kps_level, cfg.max_keypoints, n_level, gn, stream));
+    }
+    if (cfg.global) {
+        for (int L = 8; L <= 18; ++L) HF_TRY(run_block(*this, L, 1));
+        const int P = lp[0].h[18] * lp[0].w[18];
+        HF_LAUNCH(e, stream, "pointwise_memberships", launch_pointwise(act[18], w.memb, nullptr, memb, (long long)cfg.batch * P, 0, stream));
+        HF_LAUNCH(e, stream, "softmax_memberships", launch_softmax_rows(memb, (long long)cfg.batch * P, w.n_clusters, w.n_clusters, stream));
+        HF_LAUNCH(e, stream, "vlad", launch_vlad(act[18], memb, w.clusters, vlad_tap, vlad_out, vlad_raw, cfg.batch, P, w.c_global, w.n_clusters, stream));
+        HF_LAUNCH(e, stream, "fc_l2", launch_fc_l2(vlad_out, w.fc_wt, w.fc_b, fc_raw, global_out, cfg.batch, w.n_clusters * w.c_global, w.global_dim, stream));
+    }
+    return HFNET_OK;
+}
+
+int Net::tap(int id, std::vector<float>& out) {
+    const DeviceWeights& w = e->w;
+    const float* src = nullptr;
+    size_t count = 0;
+    int permute_c = 0;
+    const long long pc = pix_cell[HFNET_MAX_LEVELS], pi = pix_img[HFNET_MAX_LEVELS];
+    if (id >= 0 && id <= 17) {
+        const int L = id + 1;
+        if (!act[L]) { set_error("tap %d not computed by this model", id); return HFNET_ERR_INVALID_ARG; }
+        src = act[L]; permute_c = layer_channels(w, L); count = (size_t)pix[L][HFNET_MAX_LEVELS] * permute_c;
+    } else if (id == 18 && cfg.local) { src = desc_hidden; permute_c = HFNET_DESC_DIM; count = (size_t)pc * HFNET_DESC_DIM; }
+    else if (id == 19 && cfg.local) { src = desc_raw; count = (size_t)pc * HFNET_DESC_DIM; }
+    else if (id == 20 && cfg.local) { src = det_hidden; permute_c = w.det_hidden; count = (size_t)pc * w.det_hidden; }
+    else if (id == 21 && cfg.local) { src = logits; count = (size_t)pc * 65; }
+    else if (id == 22 && cfg.local) { src = dense; count = (size_t)pi; }
+    else if (id == 23 && cfg.global) { src = memb; count = (size_t)cfg.batch * lp[0].h[18] * lp[0].w[18] * w.n_clusters; }
+    else if (id == 24 && cfg.global) { src = vlad_tap; count = (size_t)cfg.batch * w.n_clusters * w.c_global; }
+    else if (id == 25 && cfg.local) { src = nms; count = (size_t)pi; }
+    else if (id == 26 && cfg.local) { src = desc_norm; count = (size_t)pc * HFNET_DESC_DIM; }
+    else { set_error("unknown or unavailable tap %d", id); return HFNET_ERR_INVALID_ARG; }
+    out.resize(count);
+    if (permute_c) {
+        float* tmp = nullptr;
+        HF_HIP(hipMalloc((void**)&tmp, count * sizeof(float)));
+        hipError_t er = launch_permute_channels(src, tmp, (long long)(count / permute_c), permute_c, 1, stream);
+        if (er == hipSuccess) er = hipMemcpyAsync(out.data(), tmp, count * sizeof(float), hipMemcpyDeviceToHost, stream);
+        if (er == hipSuccess) er = hipStreamSynchronize(stream);
+        (void)hipFree(tmp);
+        if (er != hipSuccess) { set_error("tap copy failed: %s", hipGetErrorString(er)); return HFNET_ERR_DEVICE; }
+    } else {
+        HF_HIP(hipMemcpyAsync(out.data(), src, count * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HF_HIP(hipStreamSynchronize(stream));
+    }
+    return HFNET_OK;
+}
+
+// ------------------------------------------------------------------------------------ tables
+// HFextractor ctor (HFextractor.cc:82-119) and ComputePyramid sizes (:159-166)
+static void extractor_tables(int nfeatures, int nlevels, float scale_factor, int width, int height, float* sf, int* fpl, int* lw, int* lh) {
+    sf[0] = 1.0f;
+    for (int i = 1; i < nlevels; ++i) sf[i] = sf[i - 1] * scale_factor;
+    for (int i = 0; i < nlevels; ++i) {
+        const float inv = 1.0f / sf[i];
+        lw[i] = i == 0 ? width : cv_round((float)width * inv);
+        lh[i] = i == 0 ? height : cv_round((float)height * inv);
+    }
+    if (nlevels == 1) { fpl[0] = nfeatures; return; }
+    const float factor = 1.0f / scale_factor;
+    float desired = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; ++l) {
+        fpl[l] = cv_round(desired);
+        sum += fpl[l];
+        desired *= factor;
+    }
+    fpl[nlevels - 1] = std::max(nfeatures - sum, 0);
+}
+
+static short sat_short(float v) { const int i = cv_round(v); return (short)std::min(std::max(i, -32768), 32767); }
+
+// coefficient tables of cv::resize(INTER_LINEAR) for CV_8U (OpenCV 4.2 imgproc/src/resize.cpp)
+static void resize_tables(int sw, int sh, int dw, int dh, std::vector<int>& xofs, std::vector<short>& ialpha, std::vector<int>& yofs,
+                          std::vector<short>& ibeta) {
+    const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);
+    xofs.resize(dw); ialpha.resize(2 * dw); yofs.resize(dh); ibeta.resize(2 * dh);
+    for (int dx = 0; dx < dw; ++dx) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        ialpha[2 * dx] = sat_short((1.f - fx) * 2048.f);
+        ialpha[2 * dx + 1] = sat_short(fx * 2048.f);
+    }
+    for (int dy = 0; dy < dh; ++dy) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        const int sy = (int)floorf(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        ibeta[2 * dy] = sat_short((1.f - fy) * 2048.f);
+        ibeta[2 * dy + 1] = sat_short(fy * 2048.f);
+    }
+}
+
+}  // namespace hfnet
+
+// ================================================================================================ C ABI
+using namespace hfnet;
+
+#define API_GUARD(ptr, what)                                               \
+    do {                                                                   \
+        if (!(ptr)) { set_error(what " is null"); return HFNET_ERR_INVALID_ARG; } \
+    } while (0)
+
+extern "C" {
+
+const char* hfnet_last_error(void) { return get_error(); }
+int hfnet_abi_version(void) { return HFNET_ABI_VERSION; }
+
+int hfnet_device_count(void) {
+    int n = 0;
+    const hipError_t er = hipGetDeviceCount(&n);
+    if (er != hipSuccess || n <= 0) { set_error("no HIP device visible (%s)", hipGetErrorString(er)); return 0; }
+    return n;
+}
+
+int hfnet_engine_create(int device, const char* weights_path, hfnet_engine** out) {
+    API_GUARD(out, "out");
+    *out = nullptr;
+    API_GUARD(weights_path, "weights_path");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible: libhfnet_hip needs a gfx950 GPU"); return HFNET_ERR_DEVICE; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (0..%d)", device, ndev - 1); return HFNET_ERR_INVALID_ARG; }
+    HF_HIP(hipSetDevice(device));
+    WeightFile wf;
+    HF_TRY(wf.load(weights_path));
+    std::unique_ptr<hfnet_engine> e(new hfnet_engine());
+    e->impl.device = device;
+    HF_HIP(hipStreamCreateWithFlags(&e->impl.stream, hipStreamNonBlocking));
+    HF_TRY(e->impl.w.build(wf));
+    HF_HIP(hipDeviceSynchronize());
+    *out = e.release();
+    return HFNET_OK;
+}
+
+void hfnet_engine_destroy(hfnet_engine* e) { delete e; }
+
+int hfnet_engine_info(const hfnet_engine* e, int what) {
+    if (!e) return -1;
+    const DeviceWeights& w = e->impl.w;
+    switch (what) {
+        case 0: return w.stem_out;
+        case 1: return w.c_local;
+        case 2: return w.c_global;
+        case 3: return w.n_clusters;
+        case 4: return w.global_dim;
+        case 5: return e->impl.device;
+        default: return -1;
+    }
+}
+
+int hfnet_engine_synchronize(hfnet_engine* e) {
+    API_GUARD(e, "engine");
+    HF_HIP(hipSetDevice(e->impl.device));
+    HF_HIP(hipDeviceSynchronize());
+    return HFNET_OK;
+}
+
+// ---------------------------------------------------------------------------------------- BaseModel
+int hfnet_model_create(hfnet_engine* e, hfnet_mode mode, int height, int width, int max_keypoints, hfnet_model** out) {
+    API_GUARD(out, "out");
+    *out = nullptr;
+    API_GUARD(e, "engine");
+    if (mode < HFNET_IMAGE_TO_LOCAL_AND_GLOBAL || mode > HFNET_INTERMEDIATE_TO_GLOBAL) { set_error("unknown mode %d", (int)mode); return HFNET_ERR_INVALID_ARG; }
+    if (height <= 0 || width <= 0) { set_error("bad input shape %dx%d", width, height); return HFNET_ERR_SHAPE; }
+    if (max_keypoints < 1) max_keypoints = 1;
+    if (max_keypoints > HFNET_MAX_KEYPOINTS) { set_error("max_keypoints %d > %d", max_keypoints, HFNET_MAX_KEYPOINTS); return HFNET_ERR_CAPACITY; }
+    HF_HIP(hipSetDevice(e->impl.device));
+    std::unique_ptr<hfnet_model> m(new hfnet_model());
+    m->eng = e; m->mode = mode; m->height = height; m->width = width; m->max_keypoints = max_keypoints;
+    NetConfig c;
+    c.n_levels = 1; c.width[0] = width; c.height[0] = height; c.batch = 1; c.max_keypoints = max_keypoints;
+    c.local = mode != HFNET_INTERMEDIATE_TO_GLOBAL;
+    c.global = mode == HFNET_IMAGE_TO_LOCAL_AND_GLOBAL || mode == HFNET_INTERMEDIATE_TO_GLOBAL;
+    c.from_intermediate = mode == HFNET_INTERMEDIATE_TO_GLOBAL;
+    HF_TRY(m->net.build(&e->impl, c));
+    if (c.local) {
+        HF_TRY(dalloc(m->net.allocs, &m->d_image, (size_t)height * width));
+        HF_TRY(dalloc(m->net.allocs, &m->d_kps, (size_t)max_keypoints));
+        HF_TRY(dalloc(m->net.allocs, &m->d_desc, (size_t)max_keypoints * HFNET_DESC_DIM));
+        HF_TRY(dalloc(m->net.allocs, &m->d_n, 2));
+    }
+    m->valid = true;
+    *out = m.release();
+    return HFNET_OK;
+}
+
+void hfnet_model_destroy(hfnet_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->eng->impl.device);
+    delete m;
+}
+
+int hfnet_model_is_valid(const hfnet_model* m) { return m && m->valid ? 1 : 0; }
+int hfnet_model_mode(const hfnet_model* m) { return m ? (int)m->mode : -1; }
+
+int hfnet_model_detect(hfnet_model* m, const uint8_t* image, int row_stride, int n_keypoints, float threshold, hfnet_keypoint* kps,
+                       float* local_desc, float* aux, int* n_out) {
+    API_GUARD(m, "model");
+    if (n_out) *n_out = 0;
+    if (!m->valid) { set_error("model is not valid"); return HFNET_ERR_INVALID_ARG; }
+    if (m->mode == HFNET_INTERMEDIATE_TO_GLOBAL) { set_error("Detect(image, ...) called on an IntermediateToGlobal model"); return HFNET_ERR_WRONG_MODE; }
+    if ((m->mode == HFNET_IMAGE_TO_LOCAL) != (aux == nullptr)) {
+        // the 5-argument overload only exists for kImageToLocal, the 6-argument one for the other two (HFNetTFModelV2.cc:65,81)
+        set_error("Detect overload does not match the model mode"); return HFNET_ERR_WRONG_MODE; }
+    API_GUARD(image, "image"); API_GUARD(kps, "kps"); API_GUARD(local_desc, "local_desc"); API_GUARD(n_out, "n_out");
+    if (row_stride < m->width) { set_error("row_stride %d < width %d", row_stride, m->width); return HFNET_ERR_SHAPE; }
+    if (n_keypoints < 0 || n_keypoints > m->max_keypoints) { set_error("n_keypoints %d outside [0, %d]", n_keypoints, m->max_keypoints); return HFNET_ERR_CAPACITY; }
+    std::lock_guard<std::mutex> lk(m->mu);
+    Net& net = m->net;
+    HF_HIP(hipSetDevice(m->eng->impl.device));
+    HF_HIP(hipMemcpy2DAsync(m->d_image, m->width, image, row_stride, m->width, m->height, hipMemcpyHostToDevice, net.stream));
+    ImageSet imgs;
+    std::memset(&imgs, 0, sizeof imgs);
+    imgs.ptr[0] = m->d_image; imgs.row_stride[0] = m->width; imgs.frame_stride[0] = (long long)m->width * m->height;
+    TopkBudget budget;
+    std::memset(&budget, 0, sizeof budget);
+    budget.k[0] = n_keypoints;
+    HF_TRY(net.forward(imgs, threshold, budget));
+    SampleArgs sa;
+    std::memset(&sa, 0, sizeof sa);
+    sa.desc_map = net.desc_norm; sa.kps_in = net.kps_level; sa.n_in = net.n_level; sa.kps_stride = net.cfg.max_keypoints;
+    sa.kps_out = m->d_kps; sa.desc_out = m->d_desc; sa.n_out_frame = m->d_n; sa.n_out_level = nullptr;
+    sa.out_frame_stride = m->max_keypoints; sa.scale_factor[0] = 1.0f; sa.set_octave = 0;
+    Geom gs = net.geom(7, 7, 0, 1);
+    gs.lv[0].H = net.lp[0].Hc; gs.lv[0].W = net.lp[0].Wc; gs.lv[0].Ho = net.lp[0].h[7]; gs.lv[0].Wo = net.lp[0].w[7];
+    gs.lv[0].in_off = net.pix_cell[0];
+    HF_LAUNCH(&m->eng->impl, net.stream, "sample", launch_sample(sa, gs, net.stream));
+    int n = 0;
+    HF_HIP(hipMemcpyAsync(&n, m->d_n, sizeof(int), hipMemcpyDeviceToHost, net.stream));
+    if (m->mode == HFNET_IMAGE_TO_LOCAL_AND_GLOBAL) {
+        HF_HIP(hipMemcpyAsync(aux, net.global_out, sizeof(float) * m->eng->impl.w.global_dim, hipMemcpyDeviceToHost, net.stream));
+    } else if (m->mode == HFNET_IMAGE_TO_LOCAL_AND_INTERMEDIATE) {
+        const long long P = (long long)net.lp[0].h[7] * net.lp[0].w[7];
+        const int C = m->eng->impl.w.c_local;
+        HF_LAUNCH(&m->eng->impl, net.stream, "permute", launch_permute_channels(net.act[7], net.inter_logical, P, C, 1, net.stream));
+        HF_HIP(hipMemcpyAsync(aux, net.inter_logical, sizeof(float) * P * C, hipMemcpyDeviceToHost, net.stream));
+    }
+    HF_HIP(hipStreamSynchronize(net.stream));
+    if (n > 0) {
+        HF_HIP(hipMemcpyAsync(kps, m->d_kps, sizeof(hfnet_keypoint) * n, hipMemcpyDeviceToHost, net.stream));
+        HF_HIP(hipMemcpyAsync(local_desc, m->d_desc, sizeof(float) * HFNET_DESC_DIM * n, hipMemcpyDeviceToHost, net.stream));
+        HF_HIP(hipStreamSynchronize(net.stream));
+    }
+    *n_out = n;
+    return HFNET_OK;
+}
+
+int hfnet_model_detect_global(hfnet_model* m, const float* intermediate, float* global_desc) {
+    API_GUARD(m, "model");
+    if (!m->valid) { set_error("model is not valid"); return HFNET_ERR_INVALID_ARG; }
+    if (m->mode != HFNET_INTERMEDIATE_TO_GLOBAL) { set_error("Detect(intermediate, global) called on an image model"); return HFNET_ERR_WRONG_MODE; }
+    API_GUARD(intermediate, "intermediate"); API_GUARD(global_desc, "global_desc");
+    std::lock_guard<std::mutex> lk(m->mu);
+    Net& net = m->net;
+    Engine& eng = m->eng->impl;
+    HF_HIP(hipSetDevice(eng.device));
+    const long long P = (long long)m->height * m->width;
+    const int C = eng.w.c_local;
+    HF_HIP(hipMemcpyAsync(net.inter_logical, intermediate, sizeof(float) * P * C, hipMemcpyHostToDevice, net.stream));
+    HF_LAUNCH(&eng, net.stream, "permute", launch_permute_channels(net.inter_logical, net.act[7], P, C, 0, net.stream));
+    ImageSet imgs;
+    std::memset(&imgs, 0, sizeof imgs);
+    TopkBudget budget;
+    std::memset(&budget, 0, sizeof budget);
+    HF_TRY(net.forward(imgs, 0.f, budget));
+    HF_HIP(hipMemcpyAsync(global_desc, net.global_out, sizeof(float) * eng.w.global_dim, hipMemcpyDeviceToHost, net.stream));
+    HF_HIP(hipStreamSynchronize(net.stream));
+    return HFNET_OK;
+}
+
+int hfnet_model_tap(hfnet_model* m, int tap, float* out, size_t capacity, size_t* count) {
+    API_GUARD(m, "model"); API_GUARD(out, "out"); API_GUARD(count, "count");
+    std::lock_guard<std::mutex> lk(m->mu);
+    HF_HIP(hipSetDevice(m->eng->impl.device));
+    std::vector<float> v;
+    HF_TRY(m->net.tap(tap, v));
+    *count = v.size();
+    if (v.size() > capacity) { set_error("tap %d needs %zu floats, buffer holds %zu", tap, v.size(), capacity); return HFNET_ERR_CAPACITY; }
+    std::memcpy(out, v.data(), v.size() * sizeof(float));
+    return HFNET_OK;
+}
+
+// ---------------------------------------------------------------------------------------- HFextractor
+int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_features, float threshold, float scale_factor, int n_levels,
+                           int max_batch, hfnet_extractor** out) {
+    API_GUARD(out, "out");
+    *out = nullptr;
+    API_GUARD(e, "engine");
+    if (n_levels < 1 || n_levels > HFNET_MAX_LEVELS) { set_error("n_levels %d outside [1, %d]", n_levels, HFNET_MAX_LEVELS); return HFNET_ERR_INVALID_ARG; }
+    if (width <= 0 || height <= 0 || n_features < 1 || max_batch < 1 || !(scale_factor >= 1.0f)) { set_error("bad extractor parameters"); return HFNET_ERR_INVALID_ARG; }
+    if (n_features > HFNET_MAX_KEYPOINTS) { set_error("n_features %d > %d", n_features, HFNET_MAX_KEYPOINTS); return HFNET_ERR_CAPACITY; }
+    HF_HIP(hipSetDevice(e->impl.device));
+    std::unique_ptr<hfnet_extractor> x(new hfnet_extractor());
+    x->eng = e; x->width = width; x->height = height; x->n_features = n_features; x->n_levels = n_levels; x->max_batch = max_batch;
+    x->threshold = threshold; x->scale_factor = scale_factor;
+    extractor_tables(n_features, n_levels, scale_factor, width, height, x->scale_factors, x->features_per_level, x->level_w, x->level_h);
+    {   // the per-level model shapes of InitAllModels (BaseModel.cc:33-63) must agree with the pyramid sizes
+        float scale = 1.0f;
+        for (int l = 0; l < n_levels; ++l) {
+            const int mh = cv_round(height * scale), mw = cv_round(width * scale);
+            if (mh != x->level_h[l] || mw != x->level_w[l]) {
+                set_error("level %d: pyramid size %dx%d differs from the model shape %dx%d the reference would build", l, x->level_w[l], x->level_h[l], mw, mh);
+                return HFNET_ERR_SHAPE; }
+            scale /= scale_factor;
+        }
+    }
+    NetConfig c;
+    c.n_levels = n_levels; c.batch = max_batch; c.local = true; c.global = true; c.from_intermediate = false;
+    c.max_keypoints = 1;
+    for (int l = 0; l < n_levels; ++l) { c.width[l] = x->level_w[l]; c.height[l] = x->level_h[l]; c.max_keypoints = std::max(c.max_keypoints, x->features_per_level[l]); }
+    HF_TRY(x->net.build(&e->impl, c));
+    for (int l = 0; l < n_levels; ++l) {
+        HF_TRY(dalloc(x->allocs, &x->d_pyr[l], (size_t)max_batch * x->level_w[l] * x->level_h[l]));
+        if (l == 0) continue;
+        std::vector<int> xofs, yofs;
+        std::vector<short> ia, ib;
+        resize_tables(x->level_w[l - 1], x->level_h[l - 1], x->level_w[l], x->level_h[l], xofs, ia, yofs, ib);
+        HF_TRY(dalloc(x->allocs, &x->d_xofs[l], xofs.size()));
+        HF_TRY(dalloc(x->allocs, &x->d_ialpha[l], ia.size()));
+        HF_TRY(dalloc(x->allocs, &x->d_yofs[l], yofs.size()));
+        HF_TRY(dalloc(x->allocs, &x->d_ibeta[l], ib.size()));
+        HF_HIP(hipMemcpy(x->d_xofs[l], xofs.data(), xofs.size() * sizeof(int), hipMemcpyHostToDevice));
+        HF_HIP(hipMemcpy(x->d_ialpha[l], ia.data(), ia.size() * sizeof(short), hipMemcpyHostToDevice));
+        HF_HIP(hipMemcpy(x->d_yofs[l], yofs.data(), yofs.size() * sizeof(int), hipMemcpyHostToDevice));
+        HF_HIP(hipMemcpy(x->d_ibeta[l], ib.data(), ib.size() * sizeof(short), hipMemcpyHostToDevice));
+    }
+    HF_TRY(dalloc(x->allocs, &x->d_kps, (size_t)max_batch * n_features));
+    HF_TRY(dalloc(x->allocs, &x->d_desc, (size_t)max_batch * n_features * HFNET_DESC_DIM));
+    HF_TRY(dalloc(x->allocs, &x->d_n, (size_t)max_batch));
+    HF_TRY(dalloc(x->allocs, &x->d_n_level, (size_t)max_batch * n_levels));
+    *out = x.release();
+    return HFNET_OK;
+}
+
+void hfnet_extractor_destroy(hfnet_extractor* x) {
+    if (!x) return;
+    (void)hipSetDevice(x->eng->impl.device);
+    for (void* p : x->allocs) (void)hipFree(p);
+    delete x;
+}
+
+int hfnet_extractor_tables(const hfnet_extractor* x, float* scale_factors, int* features_per_level, int* level_width, int* level_height) {
+    API_GUARD(x, "extractor");
+    for (int l = 0; l < x->n_levels; ++l) {
+        if (scale_factors) scale_factors[l] = x->scale_factors[l];
+        if (features_per_level) features_per_level[l] = x->features_per_level[l];
+        if (level_width) level_width[l] = x->level_w[l];
+        if (level_height) level_height[l] = x->level_h[l];
+    }
+    return HFNET_OK;
+}
+
+// one chunk of nb <= max_batch frames; all pointers device pointers except when host_* is given
+static int extract_chunk(hfnet_extractor* x, int nb, const uint8_t* d_images, int row_stride, long long frame_stride, hfnet_keypoint* d_kps,
+                         float* d_desc, float* d_global, int* d_n, int* d_n_level) {
+    Net& net = x->net;
+    Engine& eng = x->eng->impl;
+    if (net.cfg.batch != nb) { net.cfg.batch = nb; compute_offsets(net, nb); }
+    ImageSet imgs;
+    std::memset(&imgs, 0, sizeof imgs);
+    imgs.ptr[0] = d_images; imgs.row_stride[0] = row_stride; imgs.frame_stride[0] = frame_stride;
+    for (int l = 1; l < x->n_levels; ++l) {
+        const int sw = x->level_w[l - 1], sh = x->level_h[l - 1], dw = x->level_w[l], dh = x->level_h[l];
+        HF_LAUNCH(&eng, net.stream, "pyramid_resize",
+                  launch_resize_u8(imgs.ptr[l - 1], sw, sh, imgs.row_stride[l - 1], imgs.frame_stride[l - 1], x->d_pyr[l], dw, dh, dw,
+                                   (long long)dw * dh, x->d_xofs[l], x->d_ialpha[l], x->d_yofs[l], x->d_ibeta[l], nb, net.stream));
+        imgs.ptr[l] = x->d_pyr[l]; imgs.row_stride[l] = dw; imgs.frame_stride[l] = (long long)dw * dh;
+    }
+    TopkBudget budget;
+    std::memset(&budget, 0, sizeof budget);
+    for (int l = 0; l < x->n_levels; ++l) budget.k[l] = x->features_per_level[l];
+    HF_TRY(net.forward(imgs, x->threshold, budget));
+    SampleArgs sa;
+    std::memset(&sa, 0, sizeof sa);
+    sa.desc_map = net.desc_norm; sa.kps_in = net.kps_level; sa.n_in = net.n_level; sa.kps_stride = net.cfg.max_keypoints;
+    sa.kps_out = d_kps; sa.desc_out = d_desc; sa.n_out_frame = d_n; sa.n_out_level = d_n_level;
+    sa.out_frame_stride = x->n_features; sa.set_octave = 1;
+    for (int l = 0; l < x->n_levels; ++l) sa.scale_factor[l] = x->scale_factors[l];
+    Geom gs = net.geom(7, 7, 0, x->n_levels);
+    for (int l = 0; l < x->n_levels; ++l) {
+        gs.lv[l].H = net.lp[l].Hc; gs.lv[l].W = net.lp[l].Wc; gs.lv[l].Ho = net.lp[l].h[7]; gs.lv[l].Wo = net.lp[l].w[7];
+        gs.lv[l].in_off = net.pix_cell[l];
+    }
+    HF_LAUNCH(&eng, net.stream, "sample", launch_sample(sa, gs, net.stream));
+    if (d_global)
+        HF_HIP(hipMemcpyAsync(d_global, net.global_out, sizeof(float) * (size_t)nb * eng.w.global_dim, hipMemcpyDeviceToDevice, net.stream));
+    return HFNET_OK;
+}
+
+int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_t* images, int row_stride, size_t frame_stride,
+                                  hfnet_keypoint* kps, float* local_desc, float* global_desc, int* n_out, int on_device) {
+    API_GUARD(x, "extractor");
+    if (n_frames < 0) { set_error("n_frames < 0"); return HFNET_ERR_INVALID_ARG; }
+    if (n_frames == 0) return HFNET_OK;
+    API_GUARD(images, "images"); API_GUARD(kps, "kps"); API_GUARD(local_desc, "local_desc"); API_GUARD(n_out, "n_out");
+    if (row_stride < x->width || frame_stride < (size_t)row_stride * x->height) { set_error("bad image strides"); return HFNET_ERR_SHAPE; }
+    std::lock_guard<std::mutex> lk(x->mu);
+    Engine& eng = x->eng->impl;
+    HF_HIP(hipSetDevice(eng.device));
+    hipStream_t st = x->net.stream;
+    const int G = eng.w.global_dim;
+    for (int f0 = 0; f0 < n_frames; f0 += x->max_batch) {
+        const int nb = std::min(x->max_batch, n_frames - f0);
+        if (on_device) {
+            HF_TRY(extract_chunk(x, nb, images + (size_t)f0 * frame_stride, row_stride, (long long)frame_stride, kps + (size_t)f0 * x->n_features,
+                                 local_desc + (size_t)f0 * x->n_features * HFNET_DESC_DIM, global_desc ? global_desc + (size_t)f0 * G : nullptr,
+                                 n_out + f0, nullptr));
+        } else {
+            for (int f = 0; f < nb; ++f)
+                HF_HIP(hipMemcpy2DAsync(x->d_pyr[0] + (size_t)f * x->width * x->height, x->width, images + (size_t)(f0 + f) * frame_stride, row_stride,
+                                        x->width, x->height, hipMemcpyHostToDevice, st));
+            HF_TRY(extract_chunk(x, nb, x->d_pyr[0], x->width, (long long)x->width * x->height, x->d_kps, x->d_desc, nullptr, x->d_n, x->d_n_level));
+            HF_HIP(hipMemcpyAsync(n_out + f0, x->d_n, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+            if (global_desc) HF_HIP(hipMemcpyAsync(global_desc + (size_t)f0 * G, x->net.global_out, sizeof(float) * (size_t)nb * G, hipMemcpyDeviceToHost, st));
+            HF_HIP(hipStreamSynchronize(st));
+            for (int f = 0; f < nb; ++f) {
+                const int n = n_out[f0 + f];
+                if (n <= 0) continue;
+                HF_HIP(hipMemcpyAsync(kps + (size_t)(f0 + f) * x->n_features, x->d_kps + (size_t)f * x->n_features, sizeof(hfnet_keypoint) * n, hipMemcpyDeviceToHost, st));
+                HF_HIP(hipMemcpyAsync(local_desc + (size_t)(f0 + f) * x->n_features * HFNET_DESC_DIM, x->d_desc + (size_t)f * x->n_features * HFNET_DESC_DIM,
+                                      sizeof(float) * HFNET_DESC_DIM * n, hipMemcpyDeviceToHost, st));
+            }
+            HF_HIP(hipStreamSynchronize(st));
+        }
+    }
+    return HFNET_OK;
+}
+
+int hfnet_extractor_extract(hfnet_extractor* x, const uint8_t* image, int row_stride, hfnet_keypoint* kps, float* local_desc,
+                            float* global_desc, int* n_out, int* n_per_level) {
+    if (n_out) *n_out = -1;
+    API_GUARD(x, "extractor"); API_GUARD(n_out, "n_out");
+    if (!image) { set_error("empty image"); return HFNET_ERR_INVALID_ARG; }   // HFextractor.cc:145 returns -1
+    int n = 0;
+    HF_TRY(hfnet_extractor_extract_batch(x, 1, image, row_stride, (size_t)row_stride * x->height, kps, local_desc, global_desc, &n, 0));
+    *n_out = n;
+    if (n_per_level) {
+        std::lock_guard<std::mutex> lk(x->mu);
+        HF_HIP(hipMemcpy(n_per_level, x->d_n_level, sizeof(int) * x->n_levels, hipMemcpyDeviceToHost));
+    }
+    return HFNET_OK;
+}
+
+// ---------------------------------------------------------------------------------------- Matcher
+static int stage_rows(Engine& e, DevMem& m, const float* src, size_t count, int on_device, const float** out) {
+    if (on_device) { *out = src; return HFNET_OK; }
+    HF_TRY(m.ensure(std::max<size_t>(count, 1) * sizeof(float)));
+    if (count) HF_HIP(hipMemcpyAsync(m.p, src, count * sizeof(float), hipMemcpyHostToDevice, e.stream));
+    *out = m.as<float>();
+    return HFNET_OK;
+}
+
+int hfnet_descriptor_distance(hfnet_engine* eh, const float* a, const float* b, int dim, float* out) {
+    API_GUARD(eh, "engine"); API_GUARD(a, "a"); API_GUARD(b, "b"); API_GUARD(out, "out");
+    if (dim <= 0) { set_error("dim <= 0"); return HFNET_ERR_INVALID_ARG; }
+    Engine& e = eh->impl;
+    std::lock_guard<std::mutex> lk(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    const float *da, *db;
+    HF_TRY(stage_rows(e, e.m_a, a, dim, 0, &da));
+    HF_TRY(stage_rows(e, e.m_b, b, dim, 0, &db));
+    HF_TRY(e.m_f0.ensure(sizeof(float)));
+    HF_LAUNCH(&e, e.stream, "descriptor_distance", launch_descriptor_distance(da, db, dim, e.m_f0.as<float>(), e.stream));
+    HF_HIP(hipMemcpyAsync(out, e.m_f0.p, sizeof(float), hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));
+    return HFNET_OK;
+}
+
+int hfnet_match_search_by_bow(hfnet_engine* eh, const float* query, int n_query, const float* train, int n_train, int dim, float th_low,
+                              int32_t* match_q2t, float* dist, int* n_matches, int on_device) {
+    API_GUARD(eh, "engine"); API_GUARD(match_q2t, "match_q2t"); API_GUARD(dist, "dist"); API_GUARD(n_matches, "n_matches");
+    if (n_query < 0 || n_train < 0 || dim <= 0 || dim % 8) { set_error("bad matcher sizes (dim must be a multiple of 8)"); return HFNET_ERR_INVALID_ARG; }
+    if ((n_query && !query) || (n_train && !train)) { set_error("null descriptor matrix"); return HFNET_ERR_INVALID_ARG; }
+    Engine& e = eh->impl;
+    std::lock_guard<std::mutex> lk(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    if (n_query == 0) { if (!on_device) *n_matches = 0; else HF_HIP(hipMemsetAsync(n_matches, 0, sizeof(int), e.stream)); return HFNET_OK; }
+    const float *dq, *dt;
+    HF_TRY(stage_rows(e, e.m_a, query, (size_t)n_query * dim, on_device, &dq));
+    HF_TRY(stage_rows(e, e.m_b, train, (size_t)n_train * dim, on_device, &dt));
+    HF_TRY(e.m_s.ensure(sizeof(float) * std::max<size_t>((size_t)n_query * n_train, 1)));
+    HF_TRY(e.m_qn.ensure(sizeof(float) * n_query));
+    HF_TRY(e.m_tn.ensure(sizeof(float) * std::max(n_train, 1)));
+    HF_TRY(e.m_key.ensure(sizeof(unsigned long long) * ((size_t)n_query + 1)));
+    int32_t* d_match = match_q2t; float* d_dist = dist; int* d_cnt = n_matches;
+    if (!on_device) {
+        HF_TRY(e.m_i0.ensure(sizeof(int32_t) * n_query)); HF_TRY(e.m_f0.ensure(sizeof(float) * n_query)); HF_TRY(e.m_cnt.ensure(sizeof(int)));
+        d_match = e.m_i0.as<int32_t>(); d_dist = e.m_f0.as<float>(); d_cnt = e.m_cnt.as<int>();
+    }
+    HF_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int), e.stream));
+    // St[t][q] = train . query  (rows of St are contiguous in q for the train pass)
+    HF_LAUNCH(&e, e.stream, "match_gemm", launch_gemm_abt(dt, n_train, dq, n_query, dim, e.m_s.as<float>(), e.stream));
+    HF_LAUNCH(&e, e.stream, "match_bow_select",
+              launch_bow_select(dq, n_query, dt, n_train, dim, e.m_s.as<float>(), e.m_qn.as<float>(), e.m_tn.as<float>(),
+                                e.m_key.as<unsigned long long>(), th_low, d_match, d_dist, d_cnt, e.stream));
+    if (!on_device) {
+        HF_HIP(hipMemcpyAsync(match_q2t, d_match, sizeof(int32_t) * n_query, hipMemcpyDeviceToHost, e.stream));
+        HF_HIP(hipMemcpyAsync(dist, d_dist, sizeof(float) * n_query, hipMemcpyDeviceToHost, e.stream));
+        HF_HIP(hipMemcpyAsync(n_matches, d_cnt, sizeof(int), hipMemcpyDeviceToHost, e.stream));
+        HF_HIP(hipStreamSynchronize(e.stream));
+    }
+    return HFNET_OK;
+}
+
+int hfnet_match_search_for_triangulation(hfnet_engine* eh, const float* d1, int n1, const float* d2, int n2, int dim, float th_high,
+                                         int32_t* match12, int* n_matches, int on_device) {
+    API_GUARD(eh, "engine"); API_GUARD(match12, "match12"); API_GUARD(n_matches, "n_matches");
+    if (n1 < 0 || n2 < 0 || dim <= 0 || dim % 8) { set_error("bad matcher sizes (dim must be a multiple of 8)"); return HFNET_ERR_INVALID_ARG; }
+    if ((n1 && !d1) || (n2 && !d2)) { set_error("null descriptor matrix"); return HFNET_ERR_INVALID_ARG; }
+    Engine& e = eh->impl;
+    std::lock_guard<std::mutex> lk(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    if (n1 == 0) { if (!on_device) *n_matches = 0; else HF_HIP(hipMemsetAsync(n_matches, 0, sizeof(int), e.stream)); return HFNET_OK; }
+    const float *da, *db;
+    HF_TRY(stage_rows(e, e.m_a, d1, (size_t)n1 * dim, on_device, &da));
+    HF_TRY(stage_rows(e, e.m_b, d2, (size_t)n2 * dim, on_device, &db));
+    HF_TRY(e.m_s.ensure(sizeof(float) * std::max<size_t>((size_t)n1 * n2, 1)));
+    HF_TRY(e.m_i1.ensure(sizeof(int) * std::max(n2, 1)));
+    int32_t* d_match = match12; int* d_cnt = n_matches;
+    if (!on_device) {
+        HF_TRY(e.m_i0.ensure(sizeof(int32_t) * n1)); HF_TRY(e.m_cnt.ensure(sizeof(int)));
+        d_match = e.m_i0.as<int32_t>(); d_cnt = e.m_cnt.as<int>();
+    }
+    HF_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int), e.stream));
+    HF_LAUNCH(&e, e.stream, "match_gemm", launch_gemm_abt(da, n1, db, n2, dim, e.m_s.as<float>(), e.stream));
+    const float threshold = (float)(-0.5 * th_high * th_high + 1);   // Matcher.cc:851
+    HF_LAUNCH(&e, e.stream, "match_tri_select", launch_tri_select(e.m_s.as<float>(), n1, n2, threshold, e.m_i1.as<int>(), d_match, d_cnt, e.stream));
+    if (!on_device) {
+        HF_HIP(hipMemcpyAsync(match12, d_match, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, e.stream));
+        HF_HIP(hipMemcpyAsync(n_matches, d_cnt, sizeof(int), hipMemcpyDeviceToHost, e.stream));
+        HF_HIP(hipStreamSynchronize(e.stream));
+    }
+    return HFNET_OK;
+}
+
+// ---------------------------------------------------------------------------------------- KeyFrameDatabase
+int hfnet_db_create(hfnet_engine* eh, int capacity, int dim, hfnet_db** out) {
+    API_GUARD(out, "out");
+    *out = nullptr;
+    API_GUARD(eh, "engine");
+    if (capacity < 1 || dim < 256 || dim % 256) { set_error("db: capacity >= 1 and dim a multiple of 256 required"); return HFNET_ERR_INVALID_ARG; }
+    HF_HIP(hipSetDevice(eh->impl.device));
+    std::unique_ptr<hfnet_db> db(new hfnet_db());
+    db->eng = eh; db->capacity = capacity; db->dim = dim;
+    HF_HIP(hipMalloc((void**)&db->d_db, sizeof(float) * (size_t)capacity * dim));
+    HF_HIP(hipMalloc((void**)&db->d_occ, (size_t)capacity));
+    HF_HIP(hipMalloc((void**)&db->d_q, sizeof(float) * dim));
+    HF_HIP(hipMalloc((void**)&db->d_scores, sizeof(float) * capacity));
+    HF_HIP(hipMalloc((void**)&db->d_cand_score, sizeof(float) * capacity));
+    HF_HIP(hipMalloc((void**)&db->d_cand_slot, sizeof(int32_t) * capacity));
+    HF_HIP(hipMalloc((void**)&db->d_best, sizeof(float)));
+    HF_HIP(hipMalloc((void**)&db->d_n, sizeof(int)));
+    HF_HIP(hipMalloc((void**)&db->d_best_bits, sizeof(unsigned int)));
+    HF_HIP(hipMemset(db->d_occ, 0, (size_t)capacity));
+    *out = db.release();
+    return HFNET_OK;
+}
+
+void hfnet_db_destroy(hfnet_db* db) {
+    if (!db) return;
+    (void)hipSetDevice(db->eng->impl.device);
+    for (void* p : {(void*)db->d_db, (void*)db->d_occ, (void*)db->d_q, (void*)db->d_scores, (void*)db->d_cand_score, (void*)db->d_cand_slot,
+                    (void*)db->d_best, (void*)db->d_n, (void*)db->d_best_bits})
+        if (p) (void)hipFree(p);
+    delete db;
+}
+
+int hfnet_db_add(hfnet_db* db, int slot, const float* descriptor) {
+    API_GUARD(db, "db"); API_GUARD(descriptor, "descriptor");
+    if (slot < 0 || slot >= db->capacity) { set_error("db: slot %d outside [0, %d)", slot, db->capacity); return HFNET_ERR_CAPACITY; }
+    std::lock_guard<std::mutex> lk(db->mu);
+    Engine& e = db->eng->impl;
+    HF_HIP(hipSetDevice(e.device));
+    HF_HIP(hipMemcpy(db->d_db + (size_t)slot * db->dim, descriptor, sizeof(float) * db->dim, hipMemcpyHostToDevice));
+    HF_HIP(hipMemset(db->d_occ + slot, 1, 1));
+    return HFNET_OK;
+}
+
+int hfnet_db_erase(hfnet_db* db, int slot) {
+    API_GUARD(db, "db");
+    if (slot < 0 || slot >= db->capacity) { set_error("db: slot %d outside [0, %d)", slot, db->capacity); return HFNET_ERR_CAPACITY; }
+    std::lock_guard<std::mutex> lk(db->mu);
+    HF_HIP(hipSetDevice(db->eng->impl.device));
+    HF_HIP(hipMemset(db->d_occ + slot, 0, 1));
+    return HFNET_OK;
+}
+
+int hfnet_db_clear(hfnet_db* db) {
+    API_GUARD(db, "db");
+    std::lock_guard<std::mutex> lk(db->mu);
+    HF_HIP(hipSetDevice(db->eng->impl.device));
+    HF_HIP(hipMemset(db->d_occ, 0, (size_t)db->capacity));
+    return HFNET_OK;
+}
+
+int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slot, float* cand_score, int* n_cand, float* best_score,
+                   float* scores_all) {
+    API_GUARD(db, "db"); API_GUARD(query, "query"); API_GUARD(cand_slot, "cand_slot"); API_GUARD(cand_score, "cand_score"); API_GUARD(n_cand, "n_cand");
+    if (mode != 0 && mode != 1) { set_error("db: mode must be 0 or 1"); return HFNET_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> lk(db->mu);   // KeyFrameDatabase.cc:82 holds mMutex over the scan
+    Engine& e = db->eng->impl;
+    std::lock_guard<std::mutex> lk2(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    HF_HIP(hipMemcpyAsync(db->d_q, query, sizeof(float) * db->dim, hipMemcpyHostToDevice, e.stream));
+    HF_HIP(hipMemsetAsync(db->d_best_bits, 0, sizeof(unsigned int), e.stream));
+    HF_LAUNCH(&e, e.stream, "db_scores", launch_db_scores(db->d_q, db->d_db, db->d_occ, db->capacity, db->dim, db->d_scores, db->d_best_bits, e.stream));
+    HF_LAUNCH(&e, e.stream, "db_filter", launch_db_filter(db->d_scores, db->capacity, mode, db->d_best_bits, db->d_cand_slot, db->d_cand_score, db->d_n, db->d_best, e.stream));
+    int n = 0;
+    float best = 0.f;
+    HF_HIP(hipMemcpyAsync(&n, db->d_n, sizeof(int), hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipMemcpyAsync(&best, db->d_best, sizeof(float), hipMemcpyDeviceToHost, e.stream));
+    if (scores_all) HF_HIP(hipMemcpyAsync(scores_all, db->d_scores, sizeof(float) * db->capacity, hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));
+    if (n > 0) {
+        HF_HIP(hipMemcpyAsync(cand_slot, db->d_cand_slot, sizeof(int32_t) * n, hipMemcpyDeviceToHost, e.stream));
+        HF_HIP(hipMemcpyAsync(cand_score, db->d_cand_score, sizeof(float) * n, hipMemcpyDeviceToHost, e.stream));
+        HF_HIP(hipStreamSynchronize(e.stream));
+    }
+    *n_cand = n;
+    if (best_score) *best_score = best;
+    return HFNET_OK;
+}
+
+// ---------------------------------------------------------------------------------------- profiling
+int hfnet_profile_enable(hfnet_engine* e, int on) {
+    API_GUARD(e, "engine");
+    std::lock_guard<std::mutex> lk(e->impl.prof_mu);
+    if (!on) e->impl.prof.flush();
+    e->impl.prof.enabled = on != 0;
+    return HFNET_OK;
+}
+int hfnet_profile_reset(hfnet_engine* e) {
+    API_GUARD(e, "engine");
+    std::lock_guard<std::mutex> lk(e->impl.prof_mu);
+    e->impl.prof.reset();
+    return HFNET_OK;
+}
+int hfnet_profile_count(hfnet_engine* e) {
+    if (!e) return 0;
+    std::lock_guard<std::mutex> lk(e->impl.prof_mu);
+    e->impl.prof.flush();
+    return (int)e->impl.prof.names.size();
+}
+int hfnet_profile_get(hfnet_engine* e, int i, char* name, int name_cap, int* launches, double* total_ms) {
+    API_GUARD(e, "engine");
+    std::lock_guard<std::mutex> lk(e->impl.prof_mu);
+    Profiler& p = e->impl.prof;
+    p.flush();
+    if (i < 0 || i >= (int)p.names.size()) { set_error("profile index %d out of range", i); return HFNET_ERR_INVALID_ARG; }
+    if (name && name_cap > 0) { std::strncpy(name, p.names[i].c_str(), (size_t)name_cap - 1); name[name_cap - 1] = 0; }
+    if (launches) *launches = p.launches[i];
+    if (total_ms) *total_ms = p.total_ms[i];
+    return HFNET_OK;
+}
+
+}  // extern "C"

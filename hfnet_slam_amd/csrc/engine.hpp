@@ -1,0 +1,124 @@
+// engine.hpp -- host-side objects behind the C ABI (include/hfnet_hip.h).
+#pragma once
+#include "kernels.hpp"
+
+#include <memory>
+
+namespace hfnet {
+
+struct DevMem {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t n);   // grow-only
+    void release();
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct Engine {
+    int device = 0;
+    hipStream_t stream = nullptr;   // matcher / database work
+    DeviceWeights w;
+    Profiler prof;
+    std::mutex mu;                  // engine-level scratch + stream
+    std::mutex prof_mu;
+    DevMem m_a, m_b, m_s, m_qn, m_tn, m_key, m_i0, m_i1, m_f0, m_cnt;   // matcher scratch
+    ~Engine();
+};
+
+// per-level spatial plan of the network for one input size
+struct LevelPlan {
+    int H = 0, W = 0;        // raw image
+    int Hc = 0, Wc = 0;      // cropped to multiples of 8 (hf_net.py:188-190)
+    int h[19] = {0}, w[19] = {0};   // output rows / cols of layer_1 .. layer_18 (index = layer)
+    int pt[19] = {0}, pl[19] = {0}; // 'SAME' padding before, of the 3x3 conv in that layer
+};
+
+struct NetConfig {
+    int n_levels = 1;
+    int width[HFNET_MAX_LEVELS] = {0}, height[HFNET_MAX_LEVELS] = {0};
+    int batch = 1;
+    bool local = true;          // run the local heads + keypoint selection
+    bool global = false;        // run layers 8..18 + NetVLAD on level 0
+    bool from_intermediate = false;   // input is the layer_7 map (mode IntermediateToGlobal)
+    int max_keypoints = 1000;   // per image
+};
+
+// The network over a ragged batch: [level][frame] images, all levels in every launch.
+struct Net {
+    Engine* e = nullptr;
+    NetConfig cfg;
+    hipStream_t stream = nullptr;
+    LevelPlan lp[HFNET_MAX_LEVELS];
+    long long pix[19][HFNET_MAX_LEVELS + 1];   // pixel offset of level l (frame 0) in layer L's tensor; [n_levels] = total
+    long long pix_img[HFNET_MAX_LEVELS + 1];   // same for the cropped full-resolution maps
+    long long pix_cell[HFNET_MAX_LEVELS + 1];  // same for the H/8 x W/8 maps
+    std::vector<void*> allocs;
+    float* act[19] = {nullptr};                // layer outputs (device layout)
+    float *exp_buf = nullptr, *dw_buf = nullptr;
+    float *desc_hidden = nullptr, *desc_raw = nullptr, *desc_norm = nullptr, *det_hidden = nullptr, *logits = nullptr;
+    float *dense = nullptr, *nms = nullptr;
+    unsigned long long* cand = nullptr;
+    unsigned int* counters = nullptr;
+    long long cand_stride = 0;
+    hfnet_keypoint* kps_level = nullptr;       // [image][max_keypoints]
+    int* n_level = nullptr;                    // [image]
+    float *memb = nullptr, *vlad_raw = nullptr, *vlad_tap = nullptr, *vlad_out = nullptr, *fc_raw = nullptr, *global_out = nullptr;
+    float* inter_logical = nullptr;            // level-0 layer_7 map in logical order [batch x hd x wd x C]
+    int build(Engine* eng, const NetConfig& c);
+    void release();
+    Geom geom(int layer_in, int layer_out, int first_level, int n_levels_used) const;
+    // enqueue the whole forward pass; imgs: per-level u8 sources (ignored when from_intermediate)
+    int forward(const ImageSet& imgs, float threshold, const TopkBudget& budget);
+    int tap(int id, std::vector<float>& out);
+    ~Net() { release(); }
+};
+
+}  // namespace hfnet
+
+// ---- C ABI objects ------------------------------------------------------------------------------
+struct hfnet_engine { hfnet::Engine impl; };
+
+struct hfnet_model {
+    hfnet_engine* eng = nullptr;
+    hfnet_mode mode = HFNET_IMAGE_TO_LOCAL;
+    int height = 0, width = 0, max_keypoints = 0;
+    bool valid = false;
+    hfnet::Net net;
+    uint8_t* d_image = nullptr;          // [H x W]
+    hfnet_keypoint* d_kps = nullptr;     // [max_keypoints]
+    float* d_desc = nullptr;             // [max_keypoints x 256]
+    int* d_n = nullptr;
+    std::mutex mu;
+};
+
+struct hfnet_extractor {
+    hfnet_engine* eng = nullptr;
+    int width = 0, height = 0, n_features = 0, n_levels = 0, max_batch = 0;
+    float threshold = 0.f, scale_factor = 1.f;
+    float scale_factors[HFNET_MAX_LEVELS];
+    int features_per_level[HFNET_MAX_LEVELS], level_w[HFNET_MAX_LEVELS], level_h[HFNET_MAX_LEVELS];
+    hfnet::Net net;
+    std::vector<void*> allocs;
+    uint8_t* d_pyr[HFNET_MAX_LEVELS] = {nullptr};   // level l >= 1: [max_batch][h][w]; level 0: staging for host input
+    int* d_xofs[HFNET_MAX_LEVELS] = {nullptr};
+    short* d_ialpha[HFNET_MAX_LEVELS] = {nullptr};
+    int* d_yofs[HFNET_MAX_LEVELS] = {nullptr};
+    short* d_ibeta[HFNET_MAX_LEVELS] = {nullptr};
+    hfnet_keypoint* d_kps = nullptr;     // [max_batch][n_features]
+    float* d_desc = nullptr;             // [max_batch][n_features][256]
+    int* d_n = nullptr;                  // [max_batch]
+    int* d_n_level = nullptr;            // [max_batch][n_levels]
+    std::mutex mu;
+};
+
+struct hfnet_db {
+    hfnet_engine* eng = nullptr;
+    int capacity = 0, dim = 0;
+    float* d_db = nullptr;
+    unsigned char* d_occ = nullptr;
+    float *d_q = nullptr, *d_scores = nullptr, *d_cand_score = nullptr, *d_best = nullptr;
+    int32_t* d_cand_slot = nullptr;
+    int* d_n = nullptr;
+    unsigned int* d_best_bits = nullptr;
+    std::mutex mu;
+};

@@ -1,0 +1,86 @@
+// kernels.hpp -- launchers of every gfx950 kernel (definitions in kernels_*.hip).
+// All launchers enqueue on `s` and return hipGetLastError().
+#pragma once
+#include "common.hpp"
+
+namespace hfnet {
+
+// ---- kernels_conv.hip ---------------------------------------------------------------------------
+// u8 pyramid level -> level (cv::resize INTER_LINEAR, HFextractor.cc:159-173); tables built on host
+hipError_t launch_resize_u8(const uint8_t* src, int sw, int sh, int s_row, long long s_frame,
+                            uint8_t* dst, int dw, int dh, int d_row, long long d_frame,
+                            const int* xofs, const short* ialpha, const int* yofs, const short* ibeta,
+                            int batch, hipStream_t s);
+// image prep + stem conv 3x3/2 + BN + ReLU6 (HFNetTFModelV2.cc:204-208, layers.py:6-7, hf_net.py:30,188-190)
+hipError_t launch_stem(const ImageSet& imgs, const float* w, const float* scale, const float* shift, int cout,
+                       float* out, const Geom& g, hipStream_t s);
+// 1x1 convolution on the matrix cores: out[P x n] = epilogue(A[P x cin] * W)
+hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* residual, float* out, long long P,
+                            int relu6, hipStream_t s);
+// dense 3x3 stride-1 convolution (implicit GEMM on the matrix cores), per-image tiles
+hipError_t launch_conv3x3(const float* A, const ConvPack& cp, float* out, int relu6, const Geom& g, hipStream_t s);
+// depthwise 3x3 (stride 1 / 2) + BN + ReLU6
+hipError_t launch_depthwise(const float* in, const DwPack& dp, int stride, float* out, const Geom& g, hipStream_t s);
+// channel-order conversion between the device layout and NHWC logical order (boundary tensors)
+hipError_t launch_permute_channels(const float* in, float* out, long long P, int C, int to_logical, hipStream_t s);
+
+// ---- kernels_detect.hip -------------------------------------------------------------------------
+// softmax(65) -> drop dustbin -> depth_to_space(8) (hf_net.py:88-93); logits row stride ld
+hipError_t launch_softmax_d2s(const float* logits, int ld, float* dense, const Geom& g, hipStream_t s);
+// simple_nms(radius 4, 2 iterations) (layers.py:10-32) + candidate emission (score >= threshold,
+// HFNetTFModelV2.cc:127-140).  counters: one uint per image, zeroed by the caller.
+hipError_t launch_nms(const float* dense, float* nms, unsigned long long* cand, unsigned int* counters,
+                      long long cand_stride, float threshold, const Geom& g, hipStream_t s);
+// top-K of the candidates in canonical order (HFNetTFModelV2.cc:144-151); writes level-resolution
+// keypoints {x, y, response, octave=0} and the per-image count
+struct TopkBudget { int k[HFNET_MAX_LEVELS]; };
+hipError_t launch_topk(const unsigned long long* cand, const unsigned int* counters, long long cand_stride,
+                       const TopkBudget& kmax_per_level, hfnet_keypoint* kps, long long kps_stride, int* n_out,
+                       const Geom& g, hipStream_t s);
+// per-pixel L2 normalisation of the dense descriptor map (hf_net.py:80)
+hipError_t launch_l2norm256(const float* in, float* out, long long P, hipStream_t s);
+// bilinear Resampler + cv::normalize + keypoint rescale / concat (HFNetTFModelV2.cc:153-167,
+// BaseModel.cc:491-562, HFextractor.cc:267-281)
+struct SampleArgs {
+    const float* desc_map;        // normalised, [pixels x 256]
+    const hfnet_keypoint* kps_in; // per image slot of kps_stride entries (level coordinates)
+    const int* n_in;              // per image count
+    long long kps_stride;
+    hfnet_keypoint* kps_out;      // per frame: out_frame_stride entries, levels concatenated
+    float* desc_out;              // per frame: out_frame_stride x 256
+    int* n_out_frame;             // per frame total (may be null)
+    int* n_out_level;             // per frame x level counts (may be null)
+    long long out_frame_stride;
+    float scale_factor[HFNET_MAX_LEVELS];  // pt *= scale_factor[level]; octave = level
+    int set_octave;               // 0: single model (octave stays 0, no rescale)
+};
+hipError_t launch_sample(const SampleArgs& a, const Geom& g, hipStream_t s);
+
+// ---- kernels_global.hip -------------------------------------------------------------------------
+hipError_t launch_softmax_rows(float* x, long long rows, int n, int ld, hipStream_t s);
+// NetVLAD aggregation + intra-normalisation + both L2 normalisations (layers.py:77-97)
+hipError_t launch_vlad(const float* feat /*phys layout [frames x P x D]*/, const float* memb /*[frames x P x K]*/,
+                       const float* clusters, float* vlad_tap /*[frames x K*D] or null*/, float* out /*[frames x K*D]*/,
+                       float* scratch /*[frames x K*D]*/, int frames, int P, int D, int K, hipStream_t s);
+// dimensionality reduction: FC (tree256 dot products) + bias + L2 normalise (layers.py:98-108)
+hipError_t launch_fc_l2(const float* x, const float* wt, const float* bias, float* y_raw, float* out, int frames,
+                        int n_in, int n_out, hipStream_t s);
+
+// ---- kernels_match.hip --------------------------------------------------------------------------
+// S[n1 x n2] = D1 * D2^T, fused multiply-add chain over k = 0..dim-1 (Matcher.cc:845-849)
+hipError_t launch_gemm_abt(const float* d1, int n1, const float* d2, int n2, int dim, float* S, hipStream_t s);
+// SearchForTriangulation selection (Matcher.cc:851-889)
+hipError_t launch_tri_select(const float* S, int n1, int n2, float threshold, int* col_best, int32_t* match12,
+                             int* n_matches, hipStream_t s);
+// BFMatcher(NORM_L2, crossCheck) + distance < th_low (Matcher.cc:229-260)
+hipError_t launch_bow_select(const float* q, int nq, const float* t, int nt, int dim, const float* S /*[nq x nt]*/,
+                             float* qnorm, float* tnorm, unsigned long long* qkey, float th_low, int32_t* match_q2t,
+                             float* dist, int* n_matches, hipStream_t s);
+hipError_t launch_descriptor_distance(const float* a, const float* b, int dim, float* out, hipStream_t s);
+// KeyFrameDatabase scan (KeyFrameDatabase.cc:86-104, 178-197)
+hipError_t launch_db_scores(const float* q, const float* db, const unsigned char* occupied, int n, int dim, float* scores,
+                            unsigned int* best_bits, hipStream_t s);
+hipError_t launch_db_filter(const float* scores, int n, int mode, const unsigned int* best_bits, int32_t* cand_slot,
+                            float* cand_score, int* n_cand, float* best, hipStream_t s);
+
+}  // namespace hfnet

@@ -1,0 +1,316 @@
+// kernels_match.hip -- brute-force descriptor matching and the keyframe-database scan.
+//
+//   Matcher::SearchForTriangulation  src/Matcher.cc:845-889   (dot-product GEMM + mutual arg-max)
+//   Matcher::SearchByBoW x2           src/Matcher.cc:229-260, 574-618 (cv::BFMatcher L2 crossCheck)
+//   Matcher::DescriptorDistance       src/Matcher.cc:1893-1900
+//   KeyFrameDatabase scans            src/KeyFrameDatabase.cc:86-104, 178-197
+#include "kernels.hpp"
+
+#include <cfloat>
+
+namespace hfnet {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// =========================================================================== S = D1 * D2^T
+// One wave per 32x32 tile of S on v_mfma_f32_32x32x2_f32; each accumulator is the fused
+// multiply-add chain over k = 0, 1, 2, ... (the oracle's order).  Rows are in logical order here, so
+// every lane loads the 8 consecutive k of its row and the two half-waves pick even / odd k.
+__global__ __launch_bounds__(256) void k_gemm_abt(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int dim,
+                                                  float* __restrict__ S) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
+    const int row0 = (blockIdx.y * 4 + wave) * 32, col0 = blockIdx.x * 32;
+    if (row0 >= n1) return;
+    const float* ap = d1 + (long long)min(row0 + r, n1 - 1) * dim;
+    const float* bp = d2 + (long long)min(col0 + r, n2 - 1) * dim;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int k = 0; k < dim; k += 8) {
+        const f32x4 a0 = *(const f32x4*)(ap + k), a1 = *(const f32x4*)(ap + k + 4);
+        const f32x4 b0 = *(const f32x4*)(bp + k), b1 = *(const f32x4*)(bp + k + 4);
+        const float av0 = half ? a0[1] : a0[0], av1 = half ? a0[3] : a0[2], av2 = half ? a1[1] : a1[0], av3 = half ? a1[3] : a1[2];
+        const float bv0 = half ? b0[1] : b0[0], bv1 = half ? b0[3] : b0[2], bv2 = half ? b1[1] : b1[0], bv3 = half ? b1[3] : b1[2];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av2, bv2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av3, bv3, acc, 0, 0, 0);
+    }
+    const int col = col0 + r;
+    if (col >= n2) return;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        if (row < n1) S[(long long)row * n2 + col] = acc[reg];
+    }
+}
+
+hipError_t launch_gemm_abt(const float* d1, int n1, const float* d2, int n2, int dim, float* S, hipStream_t s) {
+    if (n1 <= 0 || n2 <= 0) return hipSuccess;
+    if (dim % 8) return hipErrorInvalidValue;
+    dim3 grid((n2 + 31) / 32, (n1 + 127) / 128);
+    hipLaunchKernelGGL(k_gemm_abt, grid, dim3(256), 0, s, d1, n1, d2, n2, dim, S);
+    return hipGetLastError();
+}
+
+// =========================================================================== SearchForTriangulation
+// column pass: first arg-max over rows with value > threshold (Matcher.cc:877-889)
+__global__ __launch_bounds__(256) void k_col_argmax(const float* __restrict__ S, int n1, int n2, float threshold, int* __restrict__ col_best) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n2) return;
+    float best = threshold;
+    int bi = -1;
+    for (int i = 0; i < n1; ++i) {
+        const float d = S[(long long)i * n2 + j];
+        if (d > best) { best = d; bi = i; }
+    }
+    col_best[j] = bi;
+}
+// row pass: first arg-max over columns with value > threshold, then the cross-check (Matcher.cc:860-893)
+__global__ __launch_bounds__(256) void k_row_match(const float* __restrict__ S, int n1, int n2, float threshold, const int* __restrict__ col_best,
+                                                   int32_t* __restrict__ match12, int* __restrict__ n_matches) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n1) return;
+    const int lane = threadIdx.x & 63;
+    float best = threshold;
+    int bj = 0x7fffffff;
+    for (int j = lane; j < n2; j += 64) {
+        const float d = S[(long long)i * n2 + j];
+        if (d > best) { best = d; bj = j; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oj = __shfl_xor(bj, off, 64);
+        if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+    }
+    if (lane == 0) {
+        int m = -1;
+        if (bj != 0x7fffffff && col_best[bj] == i) { m = bj; atomicAdd(n_matches, 1); }
+        match12[i] = m;
+    }
+}
+
+hipError_t launch_tri_select(const float* S, int n1, int n2, float threshold, int* col_best, int32_t* match12, int* n_matches,
+                             hipStream_t s) {
+    if (n1 <= 0) return hipSuccess;
+    if (n2 > 0) hipLaunchKernelGGL(k_col_argmax, dim3((n2 + 255) / 256), dim3(256), 0, s, S, n1, n2, threshold, col_best);
+    hipLaunchKernelGGL(k_row_match, dim3((n1 + 3) / 4), dim3(256), 0, s, S, n1, n2, threshold, col_best, match12, n_matches);
+    return hipGetLastError();
+}
+
+// =========================================================================== SearchByBoW (BFMatcher)
+// cv::BFMatcher(NORM_L2, crossCheck=true) == batchDistance(K=1, crosscheck): every train row picks its
+// nearest query (first minimum); a query is matched to the nearest train row that picked it.
+// Distances are OpenCV's: sqrt(normL2Sqr), generic 4-way unrolled order  s += v0^2+v1^2+v2^2+v3^2.
+// The MFMA dot products St[t][q] only pre-select: every query whose |t|^2+|q|^2-2St lies within a
+// rigorous rounding band of the column minimum is re-evaluated in the exact form, in ascending q.
+__global__ __launch_bounds__(256) void k_row_sumsq(const float* __restrict__ x, int n, int dim, float* __restrict__ out, unsigned int* __restrict__ maxbits) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    float p = 0.0f;
+    for (int k = lane; k < dim; k += 64) { const float v = x[(long long)i * dim + k]; p = fmaf(v, v, p); }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);
+    if (lane == 0) { out[i] = p; if (maxbits) atomicMax(maxbits, __float_as_uint(p)); }
+}
+
+// exact OpenCV L2 between rows a and b (dim == 256): lane g computes group g, lanes then add in order
+__device__ __forceinline__ float cv_l2_wave256(const float* a, const float* b, int lane) {
+    const f32x4 av = *(const f32x4*)(a + lane * 4), bv = *(const f32x4*)(b + lane * 4);
+    const float v0 = av[0] - bv[0], v1 = av[1] - bv[1], v2 = av[2] - bv[2], v3 = av[3] - bv[3];
+    const float gsum = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+    float s = 0.0f;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) s += __shfl(gsum, i, 64);
+    return sqrtf(s);
+}
+// general dim (multiple of 4): groups are strided over the lanes, accumulated in group order
+__device__ float cv_l2_wave(const float* a, const float* b, int dim, int lane) {
+    float s = 0.0f;
+    for (int g0 = 0; g0 < dim / 4; g0 += 64) {
+        const int gidx = g0 + lane;
+        float gsum = 0.0f;
+        if (gidx < dim / 4) {
+            const f32x4 av = *(const f32x4*)(a + gidx * 4), bv = *(const f32x4*)(b + gidx * 4);
+            const float v0 = av[0] - bv[0], v1 = av[1] - bv[1], v2 = av[2] - bv[2], v3 = av[3] - bv[3];
+            gsum = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+        }
+        const int cnt = min(64, dim / 4 - g0);
+        for (int i = 0; i < cnt; ++i) s += __shfl(gsum, i, 64);
+    }
+    return sqrtf(s);
+}
+
+__global__ __launch_bounds__(256) void k_bow_train_pass(const float* __restrict__ q, int nq, const float* __restrict__ t, int nt, int dim,
+                                                        const float* __restrict__ St /*[nt x nq]*/, const float* __restrict__ qn,
+                                                        const float* __restrict__ tn, const unsigned int* __restrict__ qn_maxbits,
+                                                        unsigned long long* __restrict__ qkey) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= nt) return;
+    const int lane = threadIdx.x & 63;
+    const float* srow = St + (long long)j * nq;
+    const float tnj = tn[j];
+    float amin = FLT_MAX;
+    for (int i = lane; i < nq; i += 64) amin = fminf(amin, (qn[i] + tnj) - 2.0f * srow[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amin = fminf(amin, __shfl_xor(amin, off, 64));
+    const float band = 1e-3f * (tnj + __uint_as_float(*qn_maxbits)) + 1e-30f;
+    float bd = FLT_MAX;
+    int bi = -1;
+    const float* trow = t + (long long)j * dim;
+    for (int i0 = 0; i0 < nq; i0 += 64) {
+        const int i = i0 + lane;
+        const bool c = i < nq && ((qn[i] + tnj) - 2.0f * srow[i]) <= amin + band;
+        unsigned long long mask = __ballot(c);
+        while (mask) {
+            const int b = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int qi = i0 + b;
+            const float d = (dim == 256) ? cv_l2_wave256(trow, q + (long long)qi * dim, lane) : cv_l2_wave(trow, q + (long long)qi * dim, dim, lane);
+            if (d < bd) { bd = d; bi = qi; }
+        }
+    }
+    if (lane == 0 && bi >= 0)
+        atomicMin(&qkey[bi], ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned int)j);
+}
+
+__global__ __launch_bounds__(256) void k_bow_finalize(const unsigned long long* __restrict__ qkey, int nq, float th_low,
+                                                      int32_t* __restrict__ match_q2t, float* __restrict__ dist, int* __restrict__ n_matches) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    const unsigned long long k = qkey[i];
+    int m = -1;
+    float d = FLT_MAX;
+    if (k != ~0ull) {
+        d = __uint_as_float((unsigned int)(k >> 32));
+        if (d < th_low) { m = (int)(unsigned int)k; atomicAdd(n_matches, 1); }
+    }
+    match_q2t[i] = m;
+    dist[i] = d;
+}
+
+__global__ void k_fill_u64(unsigned long long* p, long long n, unsigned long long v) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+hipError_t launch_bow_select(const float* q, int nq, const float* t, int nt, int dim, const float* St, float* qnorm, float* tnorm,
+                             unsigned long long* qkey, float th_low, int32_t* match_q2t, float* dist, int* n_matches, hipStream_t s) {
+    if (nq <= 0) return hipSuccess;
+    if (dim % 4) return hipErrorInvalidValue;
+    // qkey[nq] is followed by one extra 64-bit word used for the max query norm bits
+    unsigned int* maxbits = (unsigned int*)(qkey + nq);
+    hipLaunchKernelGGL(k_fill_u64, dim3((nq + 255) / 256), dim3(256), 0, s, qkey, (long long)nq, ~0ull);
+    hipLaunchKernelGGL(k_fill_u64, dim3(1), dim3(256), 0, s, qkey + nq, 1ll, 0ull);
+    hipLaunchKernelGGL(k_row_sumsq, dim3((nq + 3) / 4), dim3(256), 0, s, q, nq, dim, qnorm, maxbits);
+    if (nt > 0) {
+        hipLaunchKernelGGL(k_row_sumsq, dim3((nt + 3) / 4), dim3(256), 0, s, t, nt, dim, tnorm, (unsigned int*)nullptr);
+        hipLaunchKernelGGL(k_bow_train_pass, dim3((nt + 3) / 4), dim3(256), 0, s, q, nq, t, nt, dim, St, qnorm, tnorm, maxbits, qkey);
+    }
+    hipLaunchKernelGGL(k_bow_finalize, dim3((nq + 255) / 256), dim3(256), 0, s, qkey, nq, th_low, match_q2t, dist, n_matches);
+    return hipGetLastError();
+}
+
+// =========================================================================== DescriptorDistance
+// (des1 - des2).norm() in tree256 order; one wave
+__device__ __forceinline__ float tree256_wave4(f32x4 p) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = p[j] + __shfl_xor(p[j], off, 64);
+    }
+    const float a = p[0] + p[2], b = p[1] + p[3];
+    return a + b;
+}
+__device__ __forceinline__ float sumsq_diff_tree256_wave(const float* a, const float* b, int dim, int lane) {
+    f32x4 p = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < dim; k += 256) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = k + lane * 4 + c;
+            if (i < dim) { const float d = a[i] - b[i]; p[c] = fmaf(d, d, p[c]); }
+        }
+    }
+    return tree256_wave4(p);
+}
+__global__ __launch_bounds__(64) void k_descriptor_distance(const float* a, const float* b, int dim, float* out) {
+    const float ss = sumsq_diff_tree256_wave(a, b, dim, threadIdx.x);
+    if (threadIdx.x == 0) *out = sqrtf(ss);
+}
+hipError_t launch_descriptor_distance(const float* a, const float* b, int dim, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_descriptor_distance, dim3(1), dim3(64), 0, s, a, b, dim, out);
+    return hipGetLastError();
+}
+
+// =========================================================================== keyframe database scan
+// score = max(0, 1 - ||q - d||) for every occupied slot; one wave per slot, 16-byte coalesced loads
+// (HBM-bound: dim*4 bytes per slot); the best score is tracked with an atomic max on the float bits.
+__global__ __launch_bounds__(256) void k_db_scores(const float* __restrict__ q, const float* __restrict__ db, const unsigned char* __restrict__ occupied,
+                                                   int n, int dim, float* __restrict__ scores, unsigned int* __restrict__ best_bits) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    if (!occupied[i]) { if (lane == 0) scores[i] = -1.0f; return; }
+    const float* d = db + (long long)i * dim;
+    f32x4 p = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < dim; k += 256) {
+        const f32x4 qv = *(const f32x4*)(q + k + lane * 4), dv = *(const f32x4*)(d + k + lane * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float df = qv[c] - dv[c]; p[c] = fmaf(df, df, p[c]); }
+    }
+    const float ss = tree256_wave4(p);
+    if (lane == 0) {
+        const float sc = 1 - sqrtf(ss);
+        const float score = sc > 0.f ? sc : 0.f;
+        scores[i] = score;
+        atomicMax(best_bits, __float_as_uint(score));
+    }
+}
+
+// keep slots with score > 0.8*best (mode 0) / > max(0.5, 0.8*best) (mode 1), ascending slot order
+__global__ __launch_bounds__(1024) void k_db_filter(const float* __restrict__ scores, int n, int mode, const unsigned int* __restrict__ best_bits,
+                                                    int32_t* __restrict__ cand_slot, float* __restrict__ cand_score, int* __restrict__ n_cand,
+                                                    float* __restrict__ best_out) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const float best = __uint_as_float(*best_bits);
+    float min_score = best * 0.8f;
+    if (mode == 1) min_score = fmaxf(0.5f, min_score);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        const float sc = i < n ? scores[i] : -1.0f;
+        const bool keep = i < n && sc > min_score;
+        const unsigned long long mask = __ballot(keep);
+        const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(mask);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        if (keep) { const int o = base + woff + prefix; cand_slot[o] = i; cand_score[o] = sc; }
+        __syncthreads();
+        if (tid == 0) { int tot = 0; for (int w = 0; w < 16; ++w) tot += wsum[w]; base += tot; }
+        __syncthreads();
+    }
+    if (tid == 0) { *n_cand = base; *best_out = best; }
+}
+
+hipError_t launch_db_scores(const float* q, const float* db, const unsigned char* occupied, int n, int dim, float* scores,
+                            unsigned int* best_bits, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (dim % 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_db_scores, dim3((n + 3) / 4), dim3(256), 0, s, q, db, occupied, n, dim, scores, best_bits);
+    return hipGetLastError();
+}
+hipError_t launch_db_filter(const float* scores, int n, int mode, const unsigned int* best_bits, int32_t* cand_slot, float* cand_score,
+                            int* n_cand, float* best, hipStream_t s) {
+    hipLaunchKernelGGL(k_db_filter, dim3(1), dim3(1024), 0, s, scores, n, mode, best_bits, cand_slot, cand_score, n_cand, best);
+    return hipGetLastError();
+}
+
+}  // namespace hfnet

@@ -1,0 +1,303 @@
+// weights.cpp -- "HFNETW1" container reader, BatchNorm folding and packing of every convolution
+// into the layout the gfx950 kernels consume.  Host code only.
+//
+// What the reference does at this point: parse HF-Net.onnx / load the SavedModel and let the
+// runtime lay weights out (src/Extractors/HFNetRTModel.cc:208-254, HFNetTFModelV2.cc:180-202).
+// Tensor names / layouts: hfnet_slam_amd/weights.py.
+#include "common.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <fstream>
+
+namespace hfnet {
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+// ------------------------------------------------------------------------------------ container
+#pragma pack(push, 1)
+struct RawEntry { char name[96]; uint32_t ndim; uint32_t dims[4]; uint32_t pad; uint64_t offset; uint64_t nbytes; };
+#pragma pack(pop)
+static_assert(sizeof(RawEntry) == 136, "container entry layout");
+
+int WeightFile::load(const char* path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) { set_error("cannot open weight container '%s'", path ? path : "(null)"); return HFNET_ERR_IO; }
+    const std::streamsize sz = f.tellg();
+    f.seekg(0);
+    blob.resize((size_t)sz);
+    if (!f.read((char*)blob.data(), sz)) { set_error("short read on '%s'", path); return HFNET_ERR_IO; }
+    if (sz < 16 || std::memcmp(blob.data(), "HFNETW1\0", 8) != 0) { set_error("'%s' is not an HFNETW1 container", path); return HFNET_ERR_IO; }
+    uint32_t n;
+    std::memcpy(&n, blob.data() + 8, 4);
+    if (16 + (size_t)n * sizeof(RawEntry) > blob.size()) { set_error("'%s': truncated table", path); return HFNET_ERR_IO; }
+    tensors.clear();
+    for (uint32_t i = 0; i < n; ++i) {
+        RawEntry e;
+        std::memcpy(&e, blob.data() + 16 + (size_t)i * sizeof(RawEntry), sizeof e);
+        if (e.ndim > 4 || e.offset + e.nbytes > blob.size() || (e.offset & 3)) { set_error("'%s': bad entry %u", path, i); return HFNET_ERR_IO; }
+        HostTensor t;
+        e.name[95] = 0;
+        t.name = e.name;
+        t.ndim = (int)e.ndim;
+        size_t count = 1;
+        for (int d = 0; d < 4; ++d) { t.dims[d] = (int)e.dims[d]; if (d < t.ndim) count *= e.dims[d]; }
+        if (count * 4 != e.nbytes) { set_error("'%s': entry %s size mismatch", path, e.name); return HFNET_ERR_IO; }
+        t.data = (const float*)(blob.data() + e.offset);
+        tensors.push_back(t);
+    }
+    return HFNET_OK;
+}
+
+const HostTensor* WeightFile::find(const std::string& name) const {
+    for (const auto& t : tensors) if (t.name == name) return &t;
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------ packing
+namespace {
+
+struct Folded { std::vector<float> scale, shift; };
+
+// slim.batch_norm (inference) as y = fma(x, scale, shift); the same float expression as the
+// oracle (oracle/hfnet_oracle.c fold_bn): scale = gamma / sqrt(var + 1e-3), shift = beta - mean*scale
+int fold_bn(const WeightFile& wf, const std::string& scope, int c, Folded& out) {
+    const HostTensor* g = wf.find(scope + "/BatchNorm/gamma");
+    const HostTensor* b = wf.find(scope + "/BatchNorm/beta");
+    const HostTensor* m = wf.find(scope + "/BatchNorm/moving_mean");
+    const HostTensor* v = wf.find(scope + "/BatchNorm/moving_variance");
+    if (!g || !b || !m || !v || g->dims[0] != c) { set_error("weights: BatchNorm of '%s' missing or mis-sized", scope.c_str()); return HFNET_ERR_IO; }
+    out.scale.resize(c);
+    out.shift.resize(c);
+    for (int i = 0; i < c; ++i) {
+        const float s = g->data[i] / sqrtf(v->data[i] + 1e-3f);
+        const float ms = m->data[i] * s;
+        out.scale[i] = s;
+        out.shift[i] = b->data[i] - ms;
+    }
+    return HFNET_OK;
+}
+
+int choose_nt(int tiles) {
+    int best = 1;
+    double best_cost = 1e30;
+    for (int nt = 8; nt >= 1; --nt) {
+        const int padded = (tiles + nt - 1) / nt * nt;
+        const double cost = padded * (1.0 + 0.5 / nt);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = nt; }
+    }
+    return best;
+}
+
+}  // namespace
+
+static int upload(DeviceWeights& dw, const std::vector<float>& h, float** out) {
+    void* p = nullptr;
+    HF_HIP(hipMalloc(&p, h.size() * sizeof(float)));
+    dw.allocations.push_back(p);
+    HF_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = (float*)p;
+    return HFNET_OK;
+}
+
+// W: HWIO [taps][cin][n] in logical channel order.  Input channels are consumed in the physical
+// order of common.hpp; output columns are emitted in physical order when `out_phys`.
+static int pack_conv(DeviceWeights& dw, const float* W, int taps, int cin, int n, const float* scale_l,
+                     const float* shift_l, bool out_phys, ConvPack& cp) {
+    if (cin % 8 != 0 || (out_phys && n % 8 != 0)) { set_error("pack_conv: channel count not a multiple of 8 (cin=%d n=%d)", cin, n); return HFNET_ERR_IO; }
+    cp.taps = taps; cp.cin = cin; cp.n = n;
+    const int tiles = (n + 31) / 32;
+    cp.nt_per_block = choose_nt(tiles);
+    cp.nt_total = (tiles + cp.nt_per_block - 1) / cp.nt_per_block * cp.nt_per_block;
+    const int KQ = taps * cin / 8;
+    std::vector<float> w((size_t)KQ * cp.nt_total * 64 * 4, 0.f), sc((size_t)cp.nt_total * 32, 0.f), sh((size_t)cp.nt_total * 32, 0.f);
+    for (int kq = 0; kq < KQ; ++kq) {
+        const int tap = (kq * 8) / cin, c0 = (kq * 8) % cin;
+        for (int nt = 0; nt < cp.nt_total; ++nt)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int half = lane >> 5, j = nt * 32 + (lane & 31);
+                if (j >= n) continue;
+                const int nl = out_phys ? logical_of_phys(j) : j;
+                for (int t = 0; t < 4; ++t) {
+                    const int cl = c0 + 2 * t + half;   // logical input channel of MFMA t, k = half
+                    w[(((size_t)kq * cp.nt_total + nt) * 64 + lane) * 4 + t] = W[((size_t)tap * cin + cl) * n + nl];
+                }
+            }
+    }
+    for (int j = 0; j < n; ++j) {
+        const int nl = out_phys ? logical_of_phys(j) : j;
+        sc[j] = scale_l[nl];
+        sh[j] = shift_l[nl];
+    }
+    HF_TRY(upload(dw, w, &cp.w));
+    HF_TRY(upload(dw, sc, &cp.scale));
+    HF_TRY(upload(dw, sh, &cp.shift));
+    return HFNET_OK;
+}
+
+static int pack_conv_bn(DeviceWeights& dw, const WeightFile& wf, const std::string& scope, bool out_phys, ConvPack& cp, int* n_out) {
+    const HostTensor* w = wf.find(scope + "/weights");
+    if (!w || w->ndim != 4) { set_error("weights: '%s/weights' missing", scope.c_str()); return HFNET_ERR_IO; }
+    const int taps = w->dims[0] * w->dims[1], cin = w->dims[2], n = w->dims[3];
+    Folded f;
+    HF_TRY(fold_bn(wf, scope, n, f));
+    if (n_out) *n_out = n;
+    return pack_conv(dw, w->data, taps, cin, n, f.scale.data(), f.shift.data(), out_phys, cp);
+}
+
+// 1x1 conv with biases and no normaliser (hf_net.py:66-72): y = acc + b == fma(acc, 1, b)
+static int pack_conv_bias(DeviceWeights& dw, const WeightFile& wf, const std::string& scope, ConvPack& cp, int* n_out) {
+    const HostTensor* w = wf.find(scope + "/weights");
+    const HostTensor* b = wf.find(scope + "/biases");
+    if (!w || !b || w->ndim != 4) { set_error("weights: '%s' missing", scope.c_str()); return HFNET_ERR_IO; }
+    const int n = w->dims[3];
+    std::vector<float> ones((size_t)n, 1.0f);
+    if (n_out) *n_out = n;
+    return pack_conv(dw, w->data, w->dims[0] * w->dims[1], w->dims[2], n, ones.data(), b->data, false, cp);
+}
+
+static int pack_dw(DeviceWeights& dw, const WeightFile& wf, const std::string& scope, DwPack& dp) {
+    const HostTensor* w = wf.find(scope + "/depthwise_weights");
+    if (!w || w->ndim != 4 || w->dims[0] != 3 || w->dims[1] != 3) { set_error("weights: '%s/depthwise_weights' missing", scope.c_str()); return HFNET_ERR_IO; }
+    const int c = w->dims[2];
+    if (c % 8) { set_error("depthwise '%s': %d channels not a multiple of 8", scope.c_str(), c); return HFNET_ERR_IO; }
+    Folded f;
+    HF_TRY(fold_bn(wf, scope, c, f));
+    std::vector<float> wp((size_t)9 * c), sc(c), sh(c);
+    for (int p = 0; p < c; ++p) {
+        const int l = logical_of_phys(p);
+        for (int t = 0; t < 9; ++t) wp[(size_t)t * c + p] = w->data[(size_t)t * c + l];
+        sc[p] = f.scale[l];
+        sh[p] = f.shift[l];
+    }
+    dp.c = c;
+    HF_TRY(upload(dw, wp, &dp.w));
+    HF_TRY(upload(dw, sc, &dp.scale));
+    HF_TRY(upload(dw, sh, &dp.shift));
+    return HFNET_OK;
+}
+
+static const int kStrides[17] = {1, 2, 1, 2, 1, 1, 2, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1};  // hf_net.py:31-50
+
+int DeviceWeights::build(const WeightFile& wf) {
+    {   // stem: 3x3 s2, 1 -> stem_out (hf_net.py:30)
+        const HostTensor* w = wf.find("MobilenetV2/Conv/weights");
+        if (!w || w->ndim != 4 || w->dims[0] != 3 || w->dims[1] != 3 || w->dims[2] != 1) { set_error("weights: stem conv missing"); return HFNET_ERR_IO; }
+        stem_out = w->dims[3];
+        if (stem_out % 8 || stem_out > 64) { set_error("stem width %d unsupported", stem_out); return HFNET_ERR_IO; }
+        Folded f;
+        HF_TRY(fold_bn(wf, "MobilenetV2/Conv", stem_out, f));
+        std::vector<float> wp((size_t)9 * stem_out), sc(stem_out), sh(stem_out);
+        for (int p = 0; p < stem_out; ++p) {
+            const int l = logical_of_phys(p);
+            for (int t = 0; t < 9; ++t) wp[(size_t)t * stem_out + p] = w->data[(size_t)t * stem_out + l];
+            sc[p] = f.scale[l];
+            sh[p] = f.shift[l];
+        }
+        HF_TRY(upload(*this, wp, &stem_w));
+        HF_TRY(upload(*this, sc, &stem_scale));
+        HF_TRY(upload(*this, sh, &stem_shift));
+    }
+    int cin = stem_out;
+    for (int i = 0; i < 17; ++i) {
+        BlockPack& b = blocks[i];
+        const std::string scope = i == 0 ? std::string("MobilenetV2/expanded_conv") : "MobilenetV2/expanded_conv_" + std::to_string(i);
+        b.cin = cin;
+        b.stride = kStrides[i];
+        b.has_expand = wf.find(scope + "/expand/weights") != nullptr;
+        b.expand = cin;
+        if (b.has_expand) HF_TRY(pack_conv_bn(*this, wf, scope + "/expand", true, b.ex, &b.expand));
+        HF_TRY(pack_dw(*this, wf, scope + "/depthwise", b.dw));
+        if (b.dw.c != b.expand) { set_error("block %d: depthwise width %d != expansion %d", i, b.dw.c, b.expand); return HFNET_ERR_IO; }
+        HF_TRY(pack_conv_bn(*this, wf, scope + "/project", true, b.pr, &b.cout));
+        if (b.pr.cin != b.expand || (b.has_expand && b.ex.cin != cin)) { set_error("block %d: channel mismatch", i); return HFNET_ERR_IO; }
+        b.residual = (b.stride == 1 && b.cin == b.cout);   // conv_blocks.py:304-311
+        cin = b.cout;
+    }
+    c_local = blocks[5].cout;    // layer_7
+    c_global = blocks[16].cout;  // layer_18
+    int n = 0;
+    HF_TRY(pack_conv_bn(*this, wf, "local_head/descriptor/Conv", true, desc1, &n));
+    if (n != HFNET_DESC_DIM || desc1.cin != c_local) { set_error("descriptor head shape mismatch"); return HFNET_ERR_IO; }
+    HF_TRY(pack_conv_bias(*this, wf, "local_head/descriptor/Conv_1", desc2, &n));
+    if (n != HFNET_DESC_DIM) { set_error("descriptor dim %d != 256", n); return HFNET_ERR_IO; }
+    HF_TRY(pack_conv_bn(*this, wf, "local_head/detector/Conv", true, det1, &det_hidden));
+    HF_TRY(pack_conv_bias(*this, wf, "local_head/detector/Conv_1", det2, &n));
+    if (n != 65 || det2.cin != det_hidden) { set_error("detector head shape mismatch"); return HFNET_ERR_IO; }
+    HF_TRY(pack_conv_bn(*this, wf, "global_head/vlad/memberships", false, memb, &n_clusters));
+    if (memb.cin != c_global) { set_error("memberships conv width mismatch"); return HFNET_ERR_IO; }
+    const HostTensor* cl = wf.find("global_head/vlad/clusters");
+    const HostTensor* fw = wf.find("global_head/dimensionality_reduction/weights");
+    const HostTensor* fb = wf.find("global_head/dimensionality_reduction/biases");
+    if (!cl || !fw || !fb || cl->dims[0] != n_clusters || cl->dims[1] != c_global || fw->dims[0] != n_clusters * c_global) {
+        set_error("weights: global head tensors missing or mis-sized"); return HFNET_ERR_IO; }
+    global_dim = fw->dims[1];
+    {
+        std::vector<float> c(cl->data, cl->data + (size_t)n_clusters * c_global);
+        HF_TRY(upload(*this, c, &clusters));
+        const size_t N = (size_t)n_clusters * c_global, G = (size_t)global_dim;
+        std::vector<float> t(N * G);
+        for (size_t i = 0; i < N; ++i)
+            for (size_t j = 0; j < G; ++j) t[j * N + i] = fw->data[i * G + j];
+        HF_TRY(upload(*this, t, &fc_wt));
+        std::vector<float> b(fb->data, fb->data + G);
+        HF_TRY(upload(*this, b, &fc_b));
+    }
+    return HFNET_OK;
+}
+
+void DeviceWeights::release() {
+    for (void* p : allocations) (void)hipFree(p);
+    allocations.clear();
+}
+
+// ------------------------------------------------------------------------------------ profiler
+int Profiler::id_of(const char* name) {
+    for (size_t i = 0; i < names.size(); ++i) if (names[i] == name) return (int)i;
+    names.emplace_back(name);
+    launches.push_back(0);
+    total_ms.push_back(0.0);
+    return (int)names.size() - 1;
+}
+void Profiler::begin(const char* name, hipStream_t s) {
+    if (!enabled) return;
+    Rec r;
+    r.id = id_of(name);
+    auto take = [&]() { hipEvent_t e; if (!pool.empty()) { e = pool.back(); pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
+    r.a = take();
+    r.b = take();
+    (void)hipEventRecord(r.a, s);
+    pending.push_back(r);
+}
+void Profiler::end(hipStream_t s) {
+    if (!enabled || pending.empty()) return;
+    (void)hipEventRecord(pending.back().b, s);
+}
+void Profiler::flush() {
+    for (auto& r : pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            launches[r.id] += 1;
+            total_ms[r.id] += ms;
+        }
+        pool.push_back(r.a);
+        pool.push_back(r.b);
+    }
+    pending.clear();
+}
+void Profiler::reset() {
+    flush();
+    names.clear();
+    launches.clear();
+    total_ms.clear();
+}
+
+}  // namespace hfnet

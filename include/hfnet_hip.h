@@ -1,0 +1,160 @@
+/*
+ * hfnet_hip.h -- C ABI of the MI355X-native HF-Net feature front end (libhfnet_hip.so).
+ *
+ * Drop-in boundary for the feature front end of LiuLimingCode/HFNet_SLAM: every entry point
+ * below replaces one reference interface (cited as path:line under /root/reference).  Plain
+ * pointers and sizes only; caller-owned buffers; no memory owned by the library crosses the
+ * boundary; nothing here throws or exits (the reference's factory exit(-1)s on a bad model,
+ * src/Extractors/BaseModel.cc:119-125 -- the caller of this ABI decides instead).
+ *
+ * All entry points return HFNET_OK (0) or an error code; hfnet_last_error() gives the text for
+ * the calling thread.  Objects are internally serialised per object (the reference enters its
+ * shared global model from two SLAM threads without a lock, Tracking.cc:2026 /
+ * LocalMapping.cc:367); different objects may be used concurrently from different threads.
+ *
+ * Numeric contract: fp32 end to end (f32 MFMA, fused multiply-add chains in the order fixed by
+ * the CPU oracle, oracle/hfnet_oracle.h) -- keypoint coordinates / match indices / candidate
+ * indices are bit-exact against the oracle, float outputs are bit-exact or within 1e-6 abs.
+ */
+#ifndef HFNET_HIP_H
+#define HFNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HFNET_ABI_VERSION 1
+#define HFNET_DESC_DIM 256          /* local descriptor length  (HFNetTFModelV2.cc:153)            */
+#define HFNET_MAX_LEVELS 8
+#define HFNET_MAX_KEYPOINTS 8192    /* per image and call; mono init asks for 5*nFeatures (Tracking.cc:693) */
+
+typedef enum {
+    HFNET_OK = 0,
+    HFNET_ERR_INVALID_ARG = 1,
+    HFNET_ERR_WRONG_MODE = 2,       /* == the reference's `return false` on a mode mismatch (HFNetTFModelV2.cc:65,81,92) */
+    HFNET_ERR_SHAPE = 3,            /* input size differs from the size given at construction (HFNetTFModelV2.cc:103)  */
+    HFNET_ERR_DEVICE = 4,           /* HIP runtime error / no gfx950 device                                           */
+    HFNET_ERR_IO = 5,               /* weight container missing or malformed                                           */
+    HFNET_ERR_CAPACITY = 6
+} hfnet_status;
+
+/* include/Extractors/BaseModel.h:16-21 */
+typedef enum {
+    HFNET_IMAGE_TO_LOCAL_AND_GLOBAL = 0,
+    HFNET_IMAGE_TO_LOCAL = 1,
+    HFNET_IMAGE_TO_LOCAL_AND_INTERMEDIATE = 2,
+    HFNET_INTERMEDIATE_TO_GLOBAL = 3
+} hfnet_mode;
+
+/* The cv::KeyPoint fields the path writes (HFNetTFModelV2.cc:122-138, HFextractor.cc:272-279):
+ * pt.x, pt.y, response, octave; angle is always 0. */
+typedef struct { float x, y, response; int32_t octave; } hfnet_keypoint;
+
+typedef struct hfnet_engine hfnet_engine;        /* one GPU: weights resident in HBM, streams, scratch */
+typedef struct hfnet_model hfnet_model;          /* == one BaseModel instance (fixed input shape + mode) */
+typedef struct hfnet_extractor hfnet_extractor;  /* == one HFextractor (pyramid + per-level budget)      */
+typedef struct hfnet_db hfnet_db;                /* == KeyFrameDatabase's descriptor store + scan        */
+
+const char* hfnet_last_error(void);
+int hfnet_abi_version(void);
+/* number of visible HIP devices; HFNET_ERR_DEVICE text in hfnet_last_error() when none */
+int hfnet_device_count(void);
+
+/* ---- engine: model files + device (replaces LoadHFNetTRModel / LoadSavedModel,
+ *      src/Extractors/HFNetRTModel.cc:208-254, HFNetTFModelV2.cc:180-202) ------------------------ */
+int hfnet_engine_create(int device, const char* weights_path, hfnet_engine** out);
+void hfnet_engine_destroy(hfnet_engine* e);
+/* what: 0 stem channels, 1 local (intermediate) channels, 2 global-branch channels,
+ *       3 NetVLAD clusters, 4 global descriptor length (4096), 5 device ordinal */
+int hfnet_engine_info(const hfnet_engine* e, int what);
+int hfnet_engine_synchronize(hfnet_engine* e);
+
+/* ---- BaseModel (include/Extractors/BaseModel.h:38-54; ctor HFNetTFModelV2.cc:12-60) ----------- */
+/* height/width: the input image for image modes; for HFNET_INTERMEDIATE_TO_GLOBAL the
+ * intermediate map's H/8 x W/8 (BaseModel.cc:70).  max_keypoints bounds nKeypointsNum. */
+int hfnet_model_create(hfnet_engine* e, hfnet_mode mode, int height, int width, int max_keypoints,
+                       hfnet_model** out);
+void hfnet_model_destroy(hfnet_model* m);
+int hfnet_model_is_valid(const hfnet_model* m);                 /* BaseModel::IsValid            */
+int hfnet_model_mode(const hfnet_model* m);
+/* BaseModel::Detect(image, kps, local, global, N, thr)  and  Detect(image, kps, local, N, thr)
+ * (HFNetTFModelV2.cc:62-87).  image: 8-bit gray, `row_stride` bytes between rows.
+ * kps / local_desc: caller buffers for n_keypoints rows (local_desc is n x 256 floats).
+ * aux: mode LOCAL_AND_GLOBAL -> global descriptor (global_dim floats);
+ *      mode LOCAL_AND_INTERMEDIATE -> intermediate map (H/8 x W/8 x local_channels floats, NHWC);
+ *      mode LOCAL -> must be NULL.   Keypoint order is the oracle's canonical order. */
+int hfnet_model_detect(hfnet_model* m, const uint8_t* image, int row_stride, int n_keypoints,
+                       float threshold, hfnet_keypoint* kps, float* local_desc, float* aux, int* n_out);
+/* BaseModel::Detect(intermediate, global) (HFNetTFModelV2.cc:89-98) */
+int hfnet_model_detect_global(hfnet_model* m, const float* intermediate, float* global_desc);
+/* Diagnostics: copy an intermediate tensor of the last detect call to the host (logical channel
+ * order, NHWC).  tap ids as in oracle/hfnet_oracle.h (HFO_TAP_*), plus 25 = scores after NMS,
+ * 26 = normalised dense descriptor map.  *count receives the number of floats written. */
+int hfnet_model_tap(hfnet_model* m, int tap, float* out, size_t capacity, size_t* count);
+
+/* ---- HFextractor (include/Extractors/HFextractor.h:26-27; src/Extractors/HFextractor.cc:82-284;
+ *      model set-up mirrors InitAllModels, BaseModel.cc:24-93) ----------------------------------- */
+int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_features, float threshold,
+                           float scale_factor, int n_levels, int max_batch, hfnet_extractor** out);
+void hfnet_extractor_destroy(hfnet_extractor* x);
+/* tables HFextractor computes in its ctor: scale factors, per-level budget, per-level size */
+int hfnet_extractor_tables(const hfnet_extractor* x, float* scale_factors, int* features_per_level,
+                           int* level_width, int* level_height);
+/* HFextractor::operator()(image, keypoints, localDescriptors, globalDescriptors).  Returns the
+ * number of keypoints through *n_out (-1 with HFNET_ERR_INVALID_ARG on a bad image, as the
+ * reference returns -1, HFextractor.cc:145).  kps / local_desc hold n_features rows. */
+int hfnet_extractor_extract(hfnet_extractor* x, const uint8_t* image, int row_stride,
+                            hfnet_keypoint* kps, float* local_desc, float* global_desc,
+                            int* n_out, int* n_per_level /* n_levels or NULL */);
+/* Batched form (independent frames, BASELINE config 4): images are n_frames buffers of
+ * height x row_stride bytes, `frame_stride` bytes apart; outputs are n_frames slots of n_features
+ * rows each.  `on_device` != 0: every pointer is a device pointer on the engine's GPU and the call
+ * only enqueues work on the engine stream (use hfnet_engine_synchronize). */
+int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_t* images,
+                                  int row_stride, size_t frame_stride, hfnet_keypoint* kps,
+                                  float* local_desc, float* global_desc, int* n_out, int on_device);
+
+/* ---- Matcher brute-force bodies (src/Matcher.cc) ------------------------------------------------ */
+/* Matcher::DescriptorDistance (Matcher.cc:1893-1900) */
+int hfnet_descriptor_distance(hfnet_engine* e, const float* a, const float* b, int dim, float* out);
+/* SearchByBoW body (Matcher.cc:229-260, 574-618): cv::BFMatcher(NORM_L2, crossCheck=true).match
+ * followed by distance < th_low.  match_q2t[i] = train row matched to query row i or -1.
+ * Rows are `dim` floats, contiguous.  on_device as above. */
+int hfnet_match_search_by_bow(hfnet_engine* e, const float* query, int n_query, const float* train,
+                              int n_train, int dim, float th_low, int32_t* match_q2t, float* dist,
+                              int* n_matches, int on_device);
+/* SearchForTriangulation body (Matcher.cc:845-889): S = D1 * D2^T, threshold 1 - th_high^2 / 2,
+ * row arg-max (strict >) + column cross-check.  match12[i] = row of d2 or -1. */
+int hfnet_match_search_for_triangulation(hfnet_engine* e, const float* d1, int n1, const float* d2,
+                                         int n2, int dim, float th_high, int32_t* match12,
+                                         int* n_matches, int on_device);
+
+/* ---- KeyFrameDatabase scan (src/KeyFrameDatabase.cc:75-104, 170-197) --------------------------- */
+int hfnet_db_create(hfnet_engine* e, int capacity, int dim, hfnet_db** out);
+void hfnet_db_destroy(hfnet_db* db);
+/* KeyFrameDatabase::add / erase: slot ids are managed by the caller (mirrored on the KeyFrame) */
+int hfnet_db_add(hfnet_db* db, int slot, const float* descriptor);
+int hfnet_db_erase(hfnet_db* db, int slot);
+int hfnet_db_clear(hfnet_db* db);
+/* mode 0: DetectNBestCandidates filter (score > 0.8 * best);
+ * mode 1: DetectRelocalizationCandidates filter (score > max(0.5, 0.8 * best)).
+ * score = max(0, 1 - ||q - d||).  cand_slot / cand_score: caller buffers of `capacity` entries,
+ * filled in ascending slot order; scores_all (may be NULL): one score per slot, -1 for empty. */
+int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slot, float* cand_score,
+                   int* n_cand, float* best_score, float* scores_all);
+
+/* ---- measurement hooks (bench.py: HIP events on the engine stream around every launch) -------- */
+int hfnet_profile_enable(hfnet_engine* e, int on);
+int hfnet_profile_reset(hfnet_engine* e);
+/* number of distinct kernels seen since reset */
+int hfnet_profile_count(hfnet_engine* e);
+/* i-th kernel: name (<= 63 chars), launches, total milliseconds */
+int hfnet_profile_get(hfnet_engine* e, int i, char* name, int name_cap, int* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HFNET_HIP_H */

@@ -56,6 +56,7 @@ struct hfo_model {
     hfo_convbn desc1; const float* desc2_w; const float* desc2_b;
     hfo_convbn det1;  const float* det2_w;  const float* det2_b;
     hfo_convbn memb;  const float* clusters; const float* fc_w; const float* fc_b;
+    float* fc_wt;   /* [global_dim][K*D] transposed copy, built on first use */
 };
 
 static const int k_strides[HFO_NBLOCKS] = {1, 2, 1, 2, 1, 1, 2, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1}; /* hf_net.py:31-50 */
@@ -153,6 +154,18 @@ hfo_model* hfo_model_load(const char* path) {
     return m;
 }
 
+static const float* fc_weights_t(const hfo_model* cm) {
+    hfo_model* m = (hfo_model*)cm;
+#pragma omp critical(hfo_fc_wt)
+    if (!m->fc_wt) {
+        const int N = m->n_clusters * m->c_global, G = m->global_dim;
+        float* t = (float*)malloc(sizeof(float) * (size_t)N * G);
+        for (int i = 0; i < N; ++i) for (int j = 0; j < G; ++j) t[(size_t)j * N + i] = m->fc_w[(size_t)i * G + j];
+        m->fc_wt = t;
+    }
+    return m->fc_wt;
+}
+
 static void free_convbn(hfo_convbn* c) { free(c->scale); free(c->shift); }
 
 void hfo_model_free(hfo_model* m) {
@@ -160,7 +173,7 @@ void hfo_model_free(hfo_model* m) {
     free_convbn(&m->stem);
     for (int i = 0; i < HFO_NBLOCKS; ++i) { free_convbn(&m->blocks[i].ex); free_convbn(&m->blocks[i].dw); free_convbn(&m->blocks[i].pr); }
     free_convbn(&m->desc1); free_convbn(&m->det1); free_convbn(&m->memb);
-    free(m->blob); free(m);
+    free(m->fc_wt); free(m->blob); free(m);
 }
 
 int hfo_model_info(const hfo_model* m, int what) {
@@ -215,6 +228,14 @@ static float sumsq_diff_tree256(const float* a, const float* b, int n) {
     float p[256];
     for (int i = 0; i < 256; ++i) p[i] = 0.0f;
     for (int i = 0; i < n; ++i) { float d = a[i] - b[i]; p[i & 255] = fmaf(d, d, p[i & 255]); }
+    for (int off = 128; off >= 1; off >>= 1) for (int i = 0; i < off; ++i) p[i] = p[i] + p[i + off];
+    return p[0];
+}
+
+static float dot_tree256(const float* a, const float* b, int n) {
+    float p[256];
+    for (int i = 0; i < 256; ++i) p[i] = 0.0f;
+    for (int i = 0; i < n; ++i) p[i & 255] = fmaf(a[i], b[i], p[i & 255]);
     for (int off = 128; off >= 1; off >>= 1) for (int i = 0; i < off; ++i) p[i] = p[i] + p[i + off];
     return p[0];
 }
@@ -403,20 +424,10 @@ static void global_head(const hfo_model* m, const float* feat, int h, int w, flo
     l2_normalize_vec(v, K * D);                                     /* layers.py:92 (flatten is K-major) */
     tap_copy(taps, HFO_TAP_VLAD, v, (size_t)K * D);
     l2_normalize_vec(v, K * D);                                     /* layers.py:97 */
-    const int G = m->global_dim, N = K * D;
-#pragma omp parallel
-    {
-        float* acc = (float*)malloc(sizeof(float) * 256);
-#pragma omp for schedule(static)
-        for (int j0 = 0; j0 < G; j0 += 256) {
-            int jn = G - j0 < 256 ? G - j0 : 256;
-            for (int j = 0; j < jn; ++j) acc[j] = 0.0f;
-            for (int i = 0; i < N; ++i) { float a = v[i]; const float* wr = m->fc_w + (size_t)i * G + j0;
-                                          for (int j = 0; j < jn; ++j) acc[j] = fmaf(a, wr[j], acc[j]); }
-            for (int j = 0; j < jn; ++j) out[j0 + j] = acc[j] + m->fc_b[j0 + j];
-        }
-        free(acc);
-    }
+    const int G = m->global_dim, N = K * D;                         /* layers.py:99-107: x @ W + b, tree256 order */
+    const float* wt = fc_weights_t(m);
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < G; ++j) out[j] = dot_tree256(v, wt + (size_t)j * N, N) + m->fc_b[j];
     l2_normalize_vec(out, G);                                       /* layers.py:108 */
     free(mem); free(v);
 }

@@ -20,7 +20,8 @@
  *     multiply-add per term, terms in (ky, kx, cin) order; epilogue y = fma(acc, scale, shift).
  *   - short sums (softmax over 65 / 32 channels, NetVLAD over pixels, intra-norm over K):
  *     left to right.
- *   - long sums (L2 norms over 256 / 4096 / 7680 elements, descriptor distances): "tree256" --
+ *   - long vector reductions (L2 norms over 256 / 4096 / 7680 elements, descriptor distances, the
+ *     7680 -> 4096 dimensionality-reduction matmul): "tree256" --
  *     256 interleaved partial sums (element i goes to partial i % 256, in increasing i) followed
  *     by a binary tree (stride 128, 64, ..., 1).
  *   - exp() in the softmaxes is hfo_expf below (Cephes-style polynomial, the same family Eigen's

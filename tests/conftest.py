@@ -1,0 +1,64 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def weights_path(tmp_path_factory):
+    from hfnet_slam_amd import weights
+    p = str(tmp_path_factory.mktemp("w") / "synthetic_seed7.hfw")
+    weights.save(p, weights.synthetic_weights(7))
+    return p
+
+
+@pytest.fixture(scope="session")
+def weights_ties_path(tmp_path_factory):
+    """detector gain 4: the softmax saturates to exactly 1.0 in many cells -> response ties"""
+    from hfnet_slam_amd import weights
+    p = str(tmp_path_factory.mktemp("w") / "synthetic_seed7_gain4.hfw")
+    weights.save(p, weights.synthetic_weights(7, detector_gain=4.0))
+    return p
+
+
+@pytest.fixture(scope="session")
+def oracle_model(weights_path):
+    from oracle import oracle as O
+    O.build()
+    return O.Model(weights_path)
+
+
+@pytest.fixture(scope="session")
+def engine(weights_path):
+    from hfnet_slam_amd import capi
+    if capi.device_count() < 1:
+        pytest.fail("GPU test selected but no HIP device is visible: " + capi.last_error())
+    e = capi.Engine(weights_path, 0)
+    yield e
+    e.close()
+
+
+def synth_image(h, w, seed, kind="uniform"):
+    """(i) iid uniform; (ii) 'natural-ish' = 6 octaves of bilinear-upsampled noise"""
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        return rng.integers(0, 256, (h, w), dtype=np.uint8)
+    acc = np.zeros((h, w), np.float64)
+    for o in range(6):
+        gh, gw = max(2, h >> (6 - o)), max(2, w >> (6 - o))
+        g = rng.uniform(0, 1, (gh + 1, gw + 1))
+        ys = np.linspace(0, gh - 1e-6, h); xs = np.linspace(0, gw - 1e-6, w)
+        y0 = ys.astype(int); x0 = xs.astype(int); fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+        a = g[y0][:, x0]; b = g[y0][:, x0 + 1]; c = g[y0 + 1][:, x0]; d = g[y0 + 1][:, x0 + 1]
+        acc += (a * (1 - fy) * (1 - fx) + b * (1 - fy) * fx + c * fy * (1 - fx) + d * fy * fx) * (0.5 ** (5 - o))
+    acc = (acc - acc.min()) / (acc.max() - acc.min())
+    return np.clip(acc * 255.0, 0, 255).astype(np.uint8)

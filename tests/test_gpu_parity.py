@@ -1,0 +1,236 @@
+"""HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs -- `-m gpu`.
+
+Bar: keypoints / indices bit-exact; float tensors bit-exact where the HIP kernels follow the
+oracle's accumulation order (everything here), reported with np.array_equal so that any drift
+shows up as a failure rather than hiding inside a tolerance."""
+import numpy as np
+import pytest
+
+from conftest import synth_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq(name, a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    assert a.shape == b.shape, f"{name}: shape {a.shape} vs {b.shape}"
+    if not np.array_equal(a, b):
+        d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+        raise AssertionError(f"{name}: {np.count_nonzero(a != b)} of {a.size} elements differ, max |d| = {d.max():.3e} "
+                             f"at {np.unravel_index(d.argmax(), d.shape)} (ref scale {np.abs(b).max():.3e})")
+
+
+SIZES = [(64, 96), (120, 160), (133, 171)]   # the last one exercises the crop to multiples of 8 and odd strides
+
+
+@pytest.mark.parametrize("hw", SIZES)
+def test_layer_taps_bit_exact(engine, oracle_model, hw):
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    h, w = hw
+    img = synth_image(h, w, 1000 + h)
+    m = capi.Model(engine, capi.MODE_LOCAL_AND_GLOBAL, h, w, 500)
+    st, kps, desc, glob = m.detect(img, 300, 0.01)
+    assert st == capi.OK, capi.last_error()
+    taps = [O.TAP_STEM] + [O.TAP_BLOCK0 + i for i in range(17)] + [O.TAP_DESC_HIDDEN, O.TAP_DESC_RAW, O.TAP_DET_HIDDEN,
+                                                                    O.TAP_LOGITS, O.TAP_SCORES_DENSE, O.TAP_MEMBERSHIPS, O.TAP_VLAD]
+    ref = oracle_model.run_local(img, want_global=True, taps=taps)
+    for t in taps:
+        _eq(f"tap {t}", m.tap(t, ref["taps"][t].shape), ref["taps"][t])
+    _eq("scores_nms", m.tap(25, ref["scores_nms"].shape), ref["scores_nms"])
+    _eq("desc_map", m.tap(26, ref["desc_map"].shape), ref["desc_map"])
+    _eq("global", glob, ref["global"])
+    ok, rk, rd, rg = oracle_model.detect(img, O.MODE_LOCAL_AND_GLOBAL, 300, 0.01)
+    assert ok
+    assert len(kps) == len(rk)
+    for f in ("x", "y", "response", "octave"):
+        _eq(f"kps.{f}", kps[f], rk[f])
+    _eq("local descriptors", desc, rd)
+    _eq("global (detect)", glob, rg)
+    m.close()
+
+
+def test_modes_and_overloads(engine, oracle_model):
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    h, w = 96, 128
+    img = synth_image(h, w, 5)
+    # kImageToLocal: 5-argument overload only
+    m = capi.Model(engine, capi.MODE_LOCAL, h, w, 200)
+    assert m.is_valid()
+    st, kps, desc, _ = m.detect(img, 150, 0.01)
+    assert st == capi.OK
+    ok, rk, rd, _ = oracle_model.detect(img, O.MODE_LOCAL, 150, 0.01)
+    _eq("kps", kps, rk); _eq("desc", desc, rd)
+    st, *_ = m.detect(img, 150, 0.01, with_aux=True)       # 6-argument overload on a kImageToLocal model -> false
+    assert st == capi.ERR_WRONG_MODE
+    st, _ = m.detect_global(np.zeros((h // 8, w // 8, engine.c_local), np.float32))
+    assert st == capi.ERR_WRONG_MODE
+    m.close()
+    # kImageToLocalAndIntermediate + kIntermediateToGlobal == the TF wiring (BaseModel.cc:42-44,73-77)
+    mi = capi.Model(engine, capi.MODE_LOCAL_AND_INTERMEDIATE, h, w, 200)
+    st, kps, desc, inter = mi.detect(img, 150, 0.01)
+    assert st == capi.OK
+    ok, rk, rd, rinter = oracle_model.detect(img, O.MODE_LOCAL_AND_INTERMEDIATE, 150, 0.01)
+    _eq("kps", kps, rk); _eq("desc", desc, rd); _eq("intermediate", inter, rinter)
+    st, *_ = mi.detect(img, 150, 0.01, with_aux=False)
+    assert st == capi.ERR_WRONG_MODE
+    mg = capi.Model(engine, capi.MODE_INTERMEDIATE_TO_GLOBAL, h // 8, w // 8, 1)
+    st, g = mg.detect_global(inter)
+    assert st == capi.OK
+    ok, rg = oracle_model.detect_global(rinter)
+    _eq("global from intermediate", g, rg)
+    st, *_ = mg.detect(img, 10, 0.01)
+    assert st == capi.ERR_WRONG_MODE
+    # and it equals the one-shot LocalAndGlobal descriptor
+    ml = capi.Model(engine, capi.MODE_LOCAL_AND_GLOBAL, h, w, 200)
+    st, _, _, g2 = ml.detect(img, 150, 0.01)
+    _eq("global split == fused", g, g2)
+    for x in (mi, mg, ml):
+        x.close()
+
+
+def test_detect_edge_cases(engine, oracle_model):
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    h, w = 72, 104
+    m = capi.Model(engine, capi.MODE_LOCAL, h, w, 400)
+    # fewer candidates than requested (scan order is kept), zero requested, huge threshold, strided ROI input
+    img = synth_image(h, w, 77)
+    for nk, thr in ((400, 0.01), (0, 0.01), (50, 0.999999), (400, 0.2), (1, 0.0)):
+        st, kps, desc, _ = m.detect(img, nk, thr)
+        assert st == capi.OK, capi.last_error()
+        ok, rk, rd, _ = oracle_model.detect(img, O.MODE_LOCAL, nk, thr)
+        assert len(kps) == len(rk), (nk, thr, len(kps), len(rk))
+        _eq(f"kps n={nk} thr={thr}", kps, rk); _eq("desc", desc, rd)
+    big = synth_image(h + 10, w + 24, 78)
+    roi = big[5:5 + h, 8:8 + w]
+    st, kps, desc, _ = m.detect(roi, 100, 0.01)
+    ok, rk, rd, _ = oracle_model.detect(np.ascontiguousarray(roi), O.MODE_LOCAL, 100, 0.01)
+    _eq("roi kps", kps, rk); _eq("roi desc", desc, rd)
+    # constant image: every score equal -> nothing is suppressed, all H'*W' pixels are candidates (tie-break only)
+    const = np.full((h, w), 131, np.uint8)
+    st, kps, desc, _ = m.detect(const, 300, 0.01)
+    ok, rk, rd, _ = oracle_model.detect(const, O.MODE_LOCAL, 300, 0.01)
+    _eq("const kps", kps, rk); _eq("const desc", desc, rd)
+    # capacity / shape errors
+    st, *_ = m.detect(img, 401, 0.01)
+    assert st == capi.ERR_CAPACITY
+    m.close()
+
+
+def test_response_ties(weights_ties_path):
+    """saturated detector: many responses are exactly 1.0, selection is decided by the index tie-break"""
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    e = capi.Engine(weights_ties_path, 0)
+    om = O.Model(weights_ties_path)
+    h, w = 160, 200
+    img = synth_image(h, w, 2024)
+    m = capi.Model(e, capi.MODE_LOCAL, h, w, 300)
+    st, kps, desc, _ = m.detect(img, 120, 0.01)
+    ok, rk, rd, _ = om.detect(img, O.MODE_LOCAL, 120, 0.01)
+    assert np.sum(rk["response"] == rk["response"][0]) > 1, "fixture no longer produces ties"
+    _eq("kps", kps, rk); _eq("desc", desc, rd)
+    m.close(); e.close()
+
+
+@pytest.mark.parametrize("cfg", [(160, 120, 300, 3), (200, 152, 500, 4), (96, 96, 64, 1)])
+def test_extractor_matches_oracle(engine, oracle_model, cfg):
+    from hfnet_slam_amd import capi
+    w, h, nf, nl = cfg
+    x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, nl, max_batch=2)
+    sf, fpl, lw, lh = x.tables()
+    from oracle import oracle as O
+    rsf, rfpl, rlw, rlh = O.extractor_tables(nf, nl, 1.2, w, h)
+    _eq("scale factors", sf, rsf); _eq("budget", fpl, rfpl); _eq("level w", lw, rlw); _eq("level h", lh, rlh)
+    imgs = np.stack([synth_image(h, w, 300 + i, "natural" if i else "uniform") for i in range(3)])
+    n, kps, desc, g, npl = x.extract(imgs[0])
+    rn, rk, rd, rg, rnpl = oracle_model.extract(imgs[0], nf, 0.01, nl, 1.2)
+    assert n == rn
+    _eq("n per level", npl, rnpl); _eq("kps", kps, rk); _eq("desc", desc, rd); _eq("global", g, rg)
+    # batched (3 frames through a max_batch=2 extractor -> two chunks)
+    nb, kb, db, gb = x.extract_batch(imgs)
+    for i in range(3):
+        rn, rk, rd, rg, _ = oracle_model.extract(imgs[i], nf, 0.01, nl, 1.2)
+        assert nb[i] == rn
+        _eq(f"batch kps {i}", kb[i, :rn], rk); _eq(f"batch desc {i}", db[i, :rn], rd); _eq(f"batch global {i}", gb[i], rg)
+    x.close()
+
+
+def _unit_rows(rng, n, d=256):
+    a = rng.standard_normal((n, d)).astype(np.float32)
+    return (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.parametrize("n1,n2,sigma", [(300, 280, 0.02), (257, 129, 0.045), (33, 1000, 0.02), (1, 1, 0.0), (40, 0, 0.0)])
+def test_matchers(engine, n1, n2, sigma):
+    """planted permutation: B = normalise(A[pi] + sigma * g)"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    a = _unit_rows(rng, n1)
+    if n2:
+        perm = np.random.default_rng(12).permutation(max(n1, n2))[:n2] % n1
+        b = a[perm] + sigma * rng.standard_normal((n2, 256)).astype(np.float32)
+        b = (b / np.linalg.norm(b, axis=1, keepdims=True)).astype(np.float32)
+    else:
+        b = np.zeros((0, 256), np.float32)
+    n, m, d = engine.search_by_bow(a, b, 0.6)
+    rn, rm, rd = O.search_by_bow(a, b, 0.6)
+    assert n == rn
+    _eq("bow match", m, rm); _eq("bow dist", d, rd)
+    n, m = engine.search_for_triangulation(a, b, 0.75)
+    rn, rm = O.search_for_triangulation(a, b, 0.75)
+    assert n == rn
+    _eq("triangulation match", m, rm)
+
+
+def test_matcher_duplicates_and_ties(engine):
+    """exact duplicates -> equal distances: first-minimum rules decide"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    a = _unit_rows(rng, 64)
+    a[10] = a[3]; a[40] = a[3]
+    b = np.concatenate([a[:32], a[3:4], a[3:4]]).copy()
+    n, m, d = engine.search_by_bow(a, b, 0.6)
+    rn, rm, rd = O.search_by_bow(a, b, 0.6)
+    assert n == rn
+    _eq("bow match", m, rm); _eq("bow dist", d, rd)
+    n, m = engine.search_for_triangulation(a, b, 0.75)
+    rn, rm = O.search_for_triangulation(a, b, 0.75)
+    assert n == rn
+    _eq("tri match", m, rm)
+    x, y = a[0], a[1]
+    assert engine.descriptor_distance(x, y) == O.descriptor_distance(x, y)
+
+
+def test_database(engine):
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    rng = np.random.default_rng(13)
+    cap, dim, n = 700, 4096, 520
+    rows = _unit_rows(rng, n, dim)
+    db = capi.Database(engine, cap, dim)
+    slots = np.random.default_rng(14).permutation(cap)[:n]
+    for s, r in zip(slots, rows):
+        db.add(int(s), r)
+    dense = np.zeros((cap, dim), np.float32); dense[slots] = rows
+    occ = np.zeros(cap, bool); occ[slots] = True
+    for trial, sig in enumerate((0.002, 0.01, 0.05)):
+        q = rows[7 * trial + 1] + sig * rng.standard_normal(dim).astype(np.float32)
+        q = (q / np.linalg.norm(q)).astype(np.float32)
+        for mode in (0, 1):
+            cs, sc, best, scores = db.query(q, mode, want_scores=True)
+            ref = O.db_scores(q, dense)
+            _eq("scores", scores[occ], ref[occ])
+            assert np.all(scores[~occ] == -1.0)
+            ridx, rbest = O.db_candidates(np.where(occ, ref, -1.0).astype(np.float32), mode)
+            assert best == rbest
+            _eq("candidates", cs, ridx); _eq("candidate scores", sc, ref[ridx])
+    db.erase(int(slots[1]))
+    cs, sc, best, scores = db.query(rows[1], 0, want_scores=True)
+    assert scores[slots[1]] == -1.0 and slots[1] not in cs
+    db.clear()
+    cs, sc, best, _ = db.query(rows[1], 0)
+    assert len(cs) == 0 and best == 0.0
+    db.close()
