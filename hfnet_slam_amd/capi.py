@@ -29,7 +29,7 @@ SYMBOLS = [
     "hfnet_extractor_extract", "hfnet_extractor_extract_batch",
     "hfnet_descriptor_distance", "hfnet_match_search_by_bow", "hfnet_match_search_for_triangulation",
     "hfnet_db_create", "hfnet_db_destroy", "hfnet_db_add", "hfnet_db_erase", "hfnet_db_clear", "hfnet_db_query",
-    "hfnet_profile_enable", "hfnet_profile_reset", "hfnet_profile_count", "hfnet_profile_get",
+    "hfnet_profile_enable", "hfnet_profile_reset", "hfnet_profile_filter", "hfnet_profile_count", "hfnet_profile_get",
 ]
 
 
@@ -124,6 +124,9 @@ class Engine:
     # ---- profiling -------------------------------------------------------------------------
     def profile_enable(self, on: bool):
         _chk(lib().hfnet_profile_enable(self.h, int(on)))
+
+    def profile_filter(self, name):
+        _chk(lib().hfnet_profile_filter(self.h, name.encode() if name else None))
 
     def profile_reset(self):
         _chk(lib().hfnet_profile_reset(self.h))

@@ -115,6 +115,8 @@ struct DeviceWeights {
 // ---- profiling ------------------------------------------------------------------------------------
 struct Profiler {
     bool enabled = false;
+    bool active = false;       // the last begin() recorded an event pair
+    std::string filter;        // empty = all kernels
     struct Rec { hipEvent_t a, b; int id; };
     std::vector<std::string> names;
     std::vector<int> launches;

@@ -185,13 +185,17 @@ static int run_block(Net& n, int L, int n_used) {   // layer L = block L-2, inpu
     const long long p_in = n.pix[L - 1][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
     const long long p_out = n.pix[L][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
     const float* src = n.act[L - 1];
+    char nm[3][32];
+    snprintf(nm[0], sizeof nm[0], "expand_L%02d", L);
+    snprintf(nm[1], sizeof nm[1], "depthwise_L%02d", L);
+    snprintf(nm[2], sizeof nm[2], "project_L%02d", L);
     if (b.has_expand) {
-        HF_LAUNCH(e, n.stream, "pointwise_expand", launch_pointwise(n.act[L - 1], b.ex, nullptr, n.exp_buf, p_in, 1, n.stream));
+        HF_LAUNCH(e, n.stream, nm[0], launch_pointwise(n.act[L - 1], b.ex, nullptr, n.exp_buf, p_in, 1, n.stream));
         src = n.exp_buf;
     }
     const Geom g = n.geom(L - 1, L, 0, n_used);
-    HF_LAUNCH(e, n.stream, b.stride == 1 ? "depthwise_s1" : "depthwise_s2", launch_depthwise(src, b.dw, b.stride, n.dw_buf, g, n.stream));
-    HF_LAUNCH(e, n.stream, "pointwise_project",
+    HF_LAUNCH(e, n.stream, nm[1], launch_depthwise(src, b.dw, b.stride, n.dw_buf, g, n.stream));
+    HF_LAUNCH(e, n.stream, nm[2],
               launch_pointwise(n.dw_buf, b.pr, b.residual ? n.act[L - 1] : nullptr, n.act[L], p_out, 0, n.stream));
     return HFNET_OK;
 }
@@ -860,6 +864,12 @@ int hfnet_profile_reset(hfnet_engine* e) {
     API_GUARD(e, "engine");
     std::lock_guard<std::mutex> lk(e->impl.prof_mu);
     e->impl.prof.reset();
+    return HFNET_OK;
+}
+int hfnet_profile_filter(hfnet_engine* e, const char* name) {
+    API_GUARD(e, "engine");
+    std::lock_guard<std::mutex> lk(e->impl.prof_mu);
+    e->impl.prof.filter = name ? name : "";
     return HFNET_OK;
 }
 int hfnet_profile_count(hfnet_engine* e) {

@@ -268,7 +268,10 @@ int Profiler::id_of(const char* name) {
     return (int)names.size() - 1;
 }
 void Profiler::begin(const char* name, hipStream_t s) {
+    active = false;
     if (!enabled) return;
+    if (!filter.empty() && filter != name) return;
+    active = true;
     Rec r;
     r.id = id_of(name);
     auto take = [&]() { hipEvent_t e; if (!pool.empty()) { e = pool.back(); pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
@@ -278,7 +281,7 @@ void Profiler::begin(const char* name, hipStream_t s) {
     pending.push_back(r);
 }
 void Profiler::end(hipStream_t s) {
-    if (!enabled || pending.empty()) return;
+    if (!enabled || !active || pending.empty()) return;
     (void)hipEventRecord(pending.back().b, s);
 }
 void Profiler::flush() {

@@ -149,6 +149,8 @@ int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slo
 /* ---- measurement hooks (bench.py: HIP events on the engine stream around every launch) -------- */
 int hfnet_profile_enable(hfnet_engine* e, int on);
 int hfnet_profile_reset(hfnet_engine* e);
+/* record only launches whose name equals `name` (NULL or "" = every launch) */
+int hfnet_profile_filter(hfnet_engine* e, const char* name);
 /* number of distinct kernels seen since reset */
 int hfnet_profile_count(hfnet_engine* e);
 /* i-th kernel: name (<= 63 chars), launches, total milliseconds */

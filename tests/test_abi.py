@@ -1,0 +1,64 @@
+"""C-ABI surface (no compute calls: runs without a GPU)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "hfnet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hfnet_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from hfnet_slam_amd import build, capi
+    build.build()
+    lib = capi.lib()
+    declared = _declared()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/hfnet_hip.h but not exported"
+    assert sorted(capi.SYMBOLS) == declared, "capi.SYMBOLS out of sync with the header"
+    assert lib.hfnet_abi_version() == 1
+
+
+def test_header_cites_reference_for_every_group():
+    text = open(os.path.join(ROOT, "include", "hfnet_hip.h")).read()
+    for cite in ("BaseModel.h:38-54", "HFextractor.cc:82-284", "Matcher.cc:229-260", "Matcher.cc:845-889",
+                 "KeyFrameDatabase.cc:75-104", "Matcher.cc:1893-1900"):
+        assert cite in text
+
+
+def test_no_silent_cpu_fallback(tmp_path):
+    """without a GPU the product path must fail loudly, never compute on the CPU"""
+    from hfnet_slam_amd import capi, weights
+    if capi.device_count() > 0:
+        pytest.skip("GPU present")
+    p = str(tmp_path / "w.hfw")
+    weights.save(p, {k: v for k, v in list(weights.synthetic_weights(7).items())[:5]})
+    with pytest.raises(capi.HfnetError) as ei:
+        capi.Engine(p, 0)
+    assert ei.value.status == capi.ERR_DEVICE
+    assert "GPU" in str(ei.value) or "device" in str(ei.value)
+
+
+def test_product_never_imports_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/"""
+    pkg = os.path.join(ROOT, "hfnet_slam_amd")
+    pat = re.compile(r"libhfnet_oracle|from\s+oracle|import\s+oracle|#include\s*[<\"][^>\"]*hfnet_oracle\.h|dlopen")
+    for dirpath, _, files in os.walk(pkg):
+        if os.path.basename(dirpath) in ("build", "__pycache__"):
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not pat.search(src), f"{f} reaches into oracle/"
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    lines = bench.splitlines()
+    uses = [i for i, l in enumerate(lines) if re.search(r"from\s+oracle|import\s+oracle", l)]
+    assert len(uses) == 1
+    enclosing = [l for l in lines[:uses[0]] if l.startswith("def ")][-1]
+    assert enclosing.startswith("def cpu_baseline")

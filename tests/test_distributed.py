@@ -1,0 +1,60 @@
+"""N > 1 path on CPU: world_size 2, gloo backend.  The data path has no collective (replicas);
+what crosses ranks is the shard plan, the barrier and the MAX-over-ranks timing."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    from hfnet_slam_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard.frame_block(rank, world, 6)
+    mine = torch.arange(lo, hi, dtype=torch.int64)
+    got = [torch.zeros(6, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(got, mine)
+    allf = torch.cat(got)
+    assert torch.equal(allf, torch.arange(0, 6 * world)), "frame shards overlap or leave gaps"
+    seqs = shard.assign_sequences(shard.EUROC_SEQUENCES, world)
+    objs = [None] * world
+    dist.all_gather_object(objs, seqs)
+    assert all(o == seqs for o in objs), "ranks disagree on the sequence plan"
+    dist.barrier()
+    t = shard.max_over_ranks(dist, 1.0 + rank)
+    assert t == float(world)
+    ret[rank] = (lo, hi, seqs[rank], t)
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_barrier_and_max_reduce():
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[0][:2] == (0, 6) and ret[1][:2] == (6, 12)
+    assert sorted(ret[0][2] + ret[1][2]) == sorted(__import__("hfnet_slam_amd.shard", fromlist=["x"]).EUROC_SEQUENCES)
+
+
+def test_sequence_assignment_is_balanced():
+    from hfnet_slam_amd import shard
+    total = sum(shard.EUROC_SEQUENCES.values())
+    assert total == 27049
+    for world in (1, 2, 4, 8):
+        plan = shard.assign_sequences(shard.EUROC_SEQUENCES, world)
+        flat = [s for p in plan for s in p]
+        assert sorted(flat) == sorted(shard.EUROC_SEQUENCES)
+        loads = [sum(shard.EUROC_SEQUENCES[s] for s in p) for p in plan]
+        assert max(loads) <= total / world + max(shard.EUROC_SEQUENCES.values())
+    assert shard.split_even(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    with pytest.raises(ValueError):
+        shard.frame_block(2, 2, 4)
