@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace hfnet {
@@ -84,6 +85,11 @@ static void compute_offsets(Net& n, int batch) {
 int Net::build(Engine* eng, const NetConfig& c) {
     e = eng;
     cfg = c;
+    // A/B and diagnostics knobs (tests run both settings): HFNET_FUSE_BLOCKS=0 -> three launches per
+    // block; HFNET_FUSE_MAX_LAYER=n; HFNET_DENSE_DESC=1 -> dense descriptor head
+    if (const char* v = getenv("HFNET_FUSE_BLOCKS")) fuse_blocks = atoi(v);
+    if (const char* v = getenv("HFNET_FUSE_MAX_LAYER")) fuse_max_layer = atoi(v);
+    if (const char* v = getenv("HFNET_DENSE_DESC")) force_dense = atoi(v);
     const DeviceWeights& w = e->w;
     if (c.n_levels < 1 || c.n_levels > HFNET_MAX_LEVELS || c.batch < 1) { set_error("net: bad level / batch count"); return HFNET_ERR_INVALID_ARG; }
     if (c.from_intermediate && (c.n_levels != 1 || !c.global)) { set_error("net: intermediate input needs one level and the global head"); return HFNET_ERR_INVALID_ARG; }
@@ -137,6 +143,10 @@ int Net::build(Engine* eng, const NetConfig& c) {
         HF_TRY(dalloc(allocs, &cand, images * (size_t)cand_stride));
         HF_TRY(dalloc(allocs, &counters, images));
         HF_TRY(dalloc(allocs, &kps_level, images * (size_t)c.max_keypoints));
+        const size_t rows = images * (size_t)c.max_keypoints * 4;
+        HF_TRY(dalloc(allocs, &rows_hidden, rows * HFNET_DESC_DIM));
+        HF_TRY(dalloc(allocs, &rows_raw, rows * HFNET_DESC_DIM));
+        HF_TRY(dalloc(allocs, &rows_norm, rows * HFNET_DESC_DIM));
         HF_TRY(dalloc(allocs, &n_level, images));
     }
     if (c.global) {
@@ -184,6 +194,13 @@ static int run_block(Net& n, int L, int n_used) {   // layer L = block L-2, inpu
     const BlockPack& b = e->w.blocks[L - 2];
     const long long p_in = n.pix[L - 1][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
     const long long p_out = n.pix[L][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
+    if (n.fuse_blocks && L <= n.fuse_max_layer && block_fusable(b)) {
+        char fn[32];
+        snprintf(fn, sizeof fn, "block_L%02d", L);
+        const Geom gf = n.geom(L - 1, L, 0, n_used);
+        HF_LAUNCH(e, n.stream, fn, launch_block_fused(n.act[L - 1], b, n.act[L], gf, n.stream));
+        return HFNET_OK;
+    }
     const float* src = n.act[L - 1];
     char nm[3][32];
     snprintf(nm[0], sizeof nm[0], "expand_L%02d", L);
@@ -212,9 +229,6 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         const long long pc = pix_cell[HFNET_MAX_LEVELS];
         Geom gh = geom(7, 7, 0, NL);
         for (int l = 0; l < NL; ++l) { gh.lv[l].pt = gh.lv[l].pl = 1; gh.lv[l].out_off = pix_cell[l]; }
-        HF_LAUNCH(e, stream, "conv3x3_desc", launch_conv3x3(act[7], w.desc1, desc_hidden, 1, gh, stream));
-        HF_LAUNCH(e, stream, "pointwise_desc", launch_pointwise(desc_hidden, w.desc2, nullptr, desc_raw, pc, 0, stream));
-        HF_LAUNCH(e, stream, "l2norm_desc", launch_l2norm256(desc_raw, desc_norm, pc, stream));
         HF_LAUNCH(e, stream, "conv3x3_det", launch_conv3x3(act[7], w.det1, det_hidden, 1, gh, stream));
         HF_LAUNCH(e, stream, "pointwise_det", launch_pointwise(det_hidden, w.det2, nullptr, logits, pc, 0, stream));
         Geom gd = geom(7, 7, 0, NL);
@@ -225,6 +239,25 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         HF_HIP(hipMemsetAsync(counters, 0, sizeof(unsigned int) * (size_t)NL * cfg.batch, stream));
         HF_LAUNCH(e, stream, "nms", launch_nms(dense, nms, cand, counters, cand_stride, threshold, gn, stream));
         HF_LAUNCH(e, stream, "topk", launch_topk(cand, counters, cand_stride, budget, kps_level, cfg.max_keypoints, n_level, gn, stream));
+        // Descriptor head.  Only the 4 bilinear taps of every selected keypoint are ever read
+        // (HFNetTFModelV2.cc:153-167), so unless the budget covers most of the cell grid the head is
+        // evaluated at those taps only (same arithmetic per cell -> bit-identical descriptors).
+        long long tap_rows = 0;
+        for (int l = 0; l < NL; ++l) tap_rows += 4ll * std::min(budget.k[l], cfg.max_keypoints) * cfg.batch;
+        last_sparse = !force_dense && tap_rows * 5 < pc * 4;
+        dense_valid = false;
+        if (last_sparse) {
+            Geom gt = gn;   // H, W: score map; Ho, Wo: cell grid; in_off: first cell of the level
+            for (int l = 0; l < NL; ++l) { gt.lv[l].Ho = lp[l].h[7]; gt.lv[l].Wo = lp[l].w[7]; gt.lv[l].in_off = pix_cell[l]; }
+            int kmaxb = 0;
+            for (int l = 0; l < NL; ++l) kmaxb = std::max(kmaxb, std::min(budget.k[l], cfg.max_keypoints));
+            const long long rows = ((long long)(NL * cfg.batch - 1) * cfg.max_keypoints + kmaxb) * 4;
+            HF_LAUNCH(e, stream, "conv3x3_desc_taps", launch_conv3x3_taps(act[7], w.desc1, rows_hidden, 1, kps_level, n_level, cfg.max_keypoints, gt, stream));
+            HF_LAUNCH(e, stream, "pointwise_desc_taps", launch_pointwise(rows_hidden, w.desc2, nullptr, rows_raw, rows, 0, stream));
+            HF_LAUNCH(e, stream, "l2norm_desc_taps", launch_l2norm256(rows_raw, rows_norm, rows, stream));
+        } else {
+            HF_TRY(run_dense_desc());
+        }
     }
     if (cfg.global) {
         for (int L = 8; L <= 18; ++L) HF_TRY(run_block(*this, L, 1));
@@ -237,7 +270,20 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
     return HFNET_OK;
 }
 
+int Net::run_dense_desc() {
+    const DeviceWeights& w = e->w;
+    const long long pc = pix_cell[HFNET_MAX_LEVELS];
+    Geom gh = geom(7, 7, 0, cfg.n_levels);
+    for (int l = 0; l < cfg.n_levels; ++l) { gh.lv[l].pt = gh.lv[l].pl = 1; gh.lv[l].out_off = pix_cell[l]; }
+    HF_LAUNCH(e, stream, "conv3x3_desc", launch_conv3x3(act[7], w.desc1, desc_hidden, 1, gh, stream));
+    HF_LAUNCH(e, stream, "pointwise_desc", launch_pointwise(desc_hidden, w.desc2, nullptr, desc_raw, pc, 0, stream));
+    HF_LAUNCH(e, stream, "l2norm_desc", launch_l2norm256(desc_raw, desc_norm, pc, stream));
+    dense_valid = true;
+    return HFNET_OK;
+}
+
 int Net::tap(int id, std::vector<float>& out) {
+    if ((id == 18 || id == 19 || id == 26) && cfg.local && !dense_valid) HF_TRY(run_dense_desc());
     const DeviceWeights& w = e->w;
     const float* src = nullptr;
     size_t count = 0;
@@ -449,7 +495,7 @@ int hfnet_model_detect(hfnet_model* m, const uint8_t* image, int row_stride, int
     HF_TRY(net.forward(imgs, threshold, budget));
     SampleArgs sa;
     std::memset(&sa, 0, sizeof sa);
-    sa.desc_map = net.desc_norm; sa.kps_in = net.kps_level; sa.n_in = net.n_level; sa.kps_stride = net.cfg.max_keypoints;
+    sa.desc_map = net.sample_source(); sa.sparse = net.last_sparse ? 1 : 0; sa.kps_in = net.kps_level; sa.n_in = net.n_level; sa.kps_stride = net.cfg.max_keypoints;
     sa.kps_out = m->d_kps; sa.desc_out = m->d_desc; sa.n_out_frame = m->d_n; sa.n_out_level = nullptr;
     sa.out_frame_stride = m->max_keypoints; sa.scale_factor[0] = 1.0f; sa.set_octave = 0;
     Geom gs = net.geom(7, 7, 0, 1);
@@ -603,7 +649,7 @@ static int extract_chunk(hfnet_extractor* x, int nb, const uint8_t* d_images, in
     HF_TRY(net.forward(imgs, x->threshold, budget));
     SampleArgs sa;
     std::memset(&sa, 0, sizeof sa);
-    sa.desc_map = net.desc_norm; sa.kps_in = net.kps_level; sa.n_in = net.n_level; sa.kps_stride = net.cfg.max_keypoints;
+    sa.desc_map = net.sample_source(); sa.sparse = net.last_sparse ? 1 : 0; sa.kps_in = net.kps_level; sa.n_in = net.n_level; sa.kps_stride = net.cfg.max_keypoints;
     sa.kps_out = d_kps; sa.desc_out = d_desc; sa.n_out_frame = d_n; sa.n_out_level = d_n_level;
     sa.out_frame_stride = x->n_features; sa.set_octave = 1;
     for (int l = 0; l < x->n_levels; ++l) sa.scale_factor[l] = x->scale_factors[l];

@@ -56,6 +56,13 @@ struct Net {
     float* act[19] = {nullptr};                // layer outputs (device layout)
     float *exp_buf = nullptr, *dw_buf = nullptr;
     float *desc_hidden = nullptr, *desc_raw = nullptr, *desc_norm = nullptr, *det_hidden = nullptr, *logits = nullptr;
+    // sparse descriptor head: rows (image*max_keypoints + i)*4 + tap, see launch_conv3x3_taps
+    float *rows_hidden = nullptr, *rows_raw = nullptr, *rows_norm = nullptr;
+    bool last_sparse = false;      // which descriptor path the last forward() took
+    bool dense_valid = false;      // dense descriptor tensors match the last forward()
+    int force_dense = 0;           // diagnostics / A-B: always run the dense descriptor head
+    int fuse_blocks = 1;           // fused inverted-residual kernel for layers <= fuse_max_layer
+    int fuse_max_layer = 7;
     float *dense = nullptr, *nms = nullptr;
     unsigned long long* cand = nullptr;
     unsigned int* counters = nullptr;
@@ -70,6 +77,8 @@ struct Net {
     // enqueue the whole forward pass; imgs: per-level u8 sources (ignored when from_intermediate)
     int forward(const ImageSet& imgs, float threshold, const TopkBudget& budget);
     int tap(int id, std::vector<float>& out);
+    int run_dense_desc();
+    const float* sample_source() const { return last_sparse ? rows_norm : desc_norm; }
     ~Net() { release(); }
 };
 

@@ -19,8 +19,17 @@ hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* res
                             int relu6, hipStream_t s);
 // dense 3x3 stride-1 convolution (implicit GEMM on the matrix cores), per-image tiles
 hipError_t launch_conv3x3(const float* A, const ConvPack& cp, float* out, int relu6, const Geom& g, hipStream_t s);
+// the same convolution evaluated only at the 4 bilinear taps of every selected keypoint ("sparse
+// descriptor head"): row (image*kps_stride + i)*4 + t of `out` is tap t of keypoint i.  Geom: H, W =
+// score-map size, Ho, Wo = cell grid, in_off = first cell of the level.
+hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, int relu6, const hfnet_keypoint* kps,
+                               const int* n_in, long long kps_stride, const Geom& g, hipStream_t s);
 // depthwise 3x3 (stride 1 / 2) + BN + ReLU6
 hipError_t launch_depthwise(const float* in, const DwPack& dp, int stride, float* out, const Geom& g, hipStream_t s);
+// whole inverted-residual block (expand -> depthwise -> project [+ residual]) in one launch; the expanded
+// tensor lives in LDS only.  block_fusable(): project width <= 96 columns.
+bool block_fusable(const BlockPack& b);
+hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, const Geom& g, hipStream_t s);
 // channel-order conversion between the device layout and NHWC logical order (boundary tensors)
 hipError_t launch_permute_channels(const float* in, float* out, long long P, int C, int to_logical, hipStream_t s);
 
@@ -42,7 +51,8 @@ hipError_t launch_l2norm256(const float* in, float* out, long long P, hipStream_
 // bilinear Resampler + cv::normalize + keypoint rescale / concat (HFNetTFModelV2.cc:153-167,
 // BaseModel.cc:491-562, HFextractor.cc:267-281)
 struct SampleArgs {
-    const float* desc_map;        // normalised, [pixels x 256]
+    const float* desc_map;        // normalised: dense [pixels x 256], or sparse tap rows [image][kps_stride*4][256]
+    int sparse;
     const hfnet_keypoint* kps_in; // per image slot of kps_stride entries (level coordinates)
     const int* n_in;              // per image count
     long long kps_stride;

@@ -9,6 +9,8 @@
 // "physical" order of common.hpp, levels and frames concatenated ([level][frame][y][x][c]).
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 namespace hfnet {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -172,19 +174,49 @@ __global__ __launch_bounds__(256, 2) void k_pointwise(ConvArgs a) {
 
 // dense 3x3, stride 1, 'SAME' (pad 1): tiles of 32 consecutive pixels of ONE image; out-of-image taps
 // contribute fma(0, w, acc) == acc, i.e. they are skipped exactly as the oracle skips them.
-template <int NT>
-__global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g) {
+// GATHER: the 32 rows of a tile are the bilinear taps of 8 selected keypoints instead of consecutive
+// pixels (sparse descriptor head); everything else is identical, so results are bit-identical per cell.
+struct TapArgs { const hfnet_keypoint* kps; const int* n_in; long long kps_stride; };
+
+template <int NT, bool GATHER>
+__global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g, TapArgs ta) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
     const int image = blockIdx.z, level = image / g.batch, frame = image - level * g.batch;
     const LevelGeom lv = g.lv[level];
-    const int npix = lv.H * lv.W;
-    const int p0 = blockIdx.x * 128 + wave * 32;
-    if (p0 >= npix) return;
     const int nt0 = blockIdx.y * NT;
-    const bool pvalid = (p0 + r) < npix;
-    const int p = pvalid ? p0 + r : npix - 1;
-    const int y = p / lv.W, x = p - y * lv.W;
-    const long long in_base = lv.in_off + (long long)frame * npix;
+    const int p0 = blockIdx.x * 128 + wave * 32;
+    int Hc, Wc, y, x, nrows;
+    bool pvalid;
+    long long in_base, out_base;
+    if (GATHER) {
+        Hc = lv.Ho; Wc = lv.Wo;
+        const int n = ta.n_in[image];
+        nrows = n * 4;
+        if (p0 >= nrows) return;
+        const int row = p0 + r, i = row >> 2, t = row & 3;
+        pvalid = i < n;
+        const hfnet_keypoint kp = ta.kps[(long long)image * ta.kps_stride + (pvalid ? i : 0)];
+        // identical float expressions to k_sample (HFNetTFModelV2.cc:119-120, BaseModel.cc:534-539)
+        const float sw = ((float)Wc - 1.f) / (float)((float)lv.W - 1.f);
+        const float sh = ((float)Hc - 1.f) / (float)((float)lv.H - 1.f);
+        const float xf = sw * kp.x, yf = sh * kp.y;
+        const int fx = (int)floorf(xf), fy = (int)floorf(yf);
+        x = fx + ((t == 1 || t == 3) ? 1 : 0);
+        y = fy + ((t == 1 || t == 2) ? 1 : 0);
+        pvalid = pvalid && x >= 0 && x < Wc && y >= 0 && y < Hc;
+        if (!pvalid) { x = 0; y = 0; }
+        in_base = lv.in_off + (long long)frame * Hc * Wc;
+        out_base = (long long)image * ta.kps_stride * 4;
+    } else {
+        Hc = lv.H; Wc = lv.W;
+        nrows = Hc * Wc;
+        if (p0 >= nrows) return;
+        pvalid = (p0 + r) < nrows;
+        const int p = pvalid ? p0 + r : nrows - 1;
+        y = p / Wc; x = p - y * Wc;
+        in_base = lv.in_off + (long long)frame * nrows;
+        out_base = lv.out_off + (long long)frame * nrows;
+    }
     const f32x4* wp = a.W + ((size_t)nt0 * 64 + lane);
     const size_t wstep = (size_t)a.nt_total * 64;
     f32x16 acc[NT];
@@ -197,8 +229,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g) {
     for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap - ky * 3;
         const int iy = y + ky - 1, ix = x + kx - 1;
-        const bool ok = pvalid && iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W;
-        const float* ap = a.A + (in_base + (long long)(ok ? iy * lv.W + ix : 0)) * a.cin + half * 4;
+        const bool ok = pvalid && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc;
+        const float* ap = a.A + (in_base + (long long)(ok ? iy * Wc + ix : 0)) * a.cin + half * 4;
         for (int kq = 0; kq < KQ; ++kq) {
             f32x4 av = zero;
             if (ok) av = *(const f32x4*)(ap + kq * 8);
@@ -212,14 +244,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g) {
                 for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], acc[nt], 0, 0, 0);
         }
     }
-    const long long out_base = lv.out_off + (long long)frame * npix;
-    conv_epilogue<NT>(a, acc, nt0, out_base + p0, out_base + npix, half, r);
+    conv_epilogue<NT>(a, acc, nt0, out_base + p0, out_base + nrows, half, r);
 }
 
 template <int NT>
 static void launch_pw_nt(const ConvArgs& a, dim3 grid, hipStream_t s) { hipLaunchKernelGGL(k_pointwise<NT>, grid, dim3(256), 0, s, a); }
 template <int NT>
-static void launch_c3_nt(const ConvArgs& a, const Geom& g, dim3 grid, hipStream_t s) { hipLaunchKernelGGL(k_conv3x3<NT>, grid, dim3(256), 0, s, a, g); }
+static void launch_c3_nt(const ConvArgs& a, const Geom& g, const TapArgs* ta, dim3 grid, hipStream_t s) {
+    if (ta) hipLaunchKernelGGL((k_conv3x3<NT, true>), grid, dim3(256), 0, s, a, g, *ta);
+    else { TapArgs none = {nullptr, nullptr, 0}; hipLaunchKernelGGL((k_conv3x3<NT, false>), grid, dim3(256), 0, s, a, g, none); }
+}
 
 static ConvArgs make_args(const float* A, const ConvPack& cp, const float* res, float* out, long long P, int relu6) {
     ConvArgs a;
@@ -228,12 +262,24 @@ static ConvArgs make_args(const float* A, const ConvPack& cp, const float* res, 
     return a;
 }
 
+// column tiles per wave: the packed layout allows any divisor of nt_total; small-M layers (the
+// 30x47 / 15x24 global branch) take fewer tiles per wave so that the launch still fills 256 CUs
+static int pick_nt(int nt_total, int nt_pref, long long m_tiles) {
+    int best = 1;
+    for (int nt = 1; nt <= nt_pref && nt <= 8; ++nt) {
+        if (nt_total % nt) continue;
+        if (m_tiles * (nt_total / nt) >= 2048 || nt == 1) best = nt;
+    }
+    return best;
+}
+
 hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* residual, float* out, long long P, int relu6,
                             hipStream_t s) {
     if (P <= 0) return hipSuccess;
     const ConvArgs a = make_args(A, cp, residual, out, P, relu6);
-    dim3 grid((unsigned)((P + 127) / 128), cp.nt_total / cp.nt_per_block);
-    switch (cp.nt_per_block) {
+    const int nt = pick_nt(cp.nt_total, cp.nt_per_block, (P + 31) / 32);
+    dim3 grid((unsigned)((P + 127) / 128), cp.nt_total / nt);
+    switch (nt) {
         case 1: launch_pw_nt<1>(a, grid, s); break;
         case 2: launch_pw_nt<2>(a, grid, s); break;
         case 3: launch_pw_nt<3>(a, grid, s); break;
@@ -247,23 +293,406 @@ hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* res
     return hipGetLastError();
 }
 
-hipError_t launch_conv3x3(const float* A, const ConvPack& cp, float* out, int relu6, const Geom& g, hipStream_t s) {
+static hipError_t launch_conv3x3_any(const float* A, const ConvPack& cp, float* out, int relu6, const Geom& g, const TapArgs* ta,
+                                     int max_rows, hipStream_t s) {
     const ConvArgs a = make_args(A, cp, nullptr, out, 0, relu6);
-    int maxpix = 0;
-    for (int l = 0; l < g.n_levels; ++l) maxpix = max(maxpix, g.lv[l].H * g.lv[l].W);
-    dim3 grid((maxpix + 127) / 128, cp.nt_total / cp.nt_per_block, g.n_levels * g.batch);
+    dim3 grid((max_rows + 127) / 128, cp.nt_total / cp.nt_per_block, g.n_levels * g.batch);
     switch (cp.nt_per_block) {
-        case 1: launch_c3_nt<1>(a, g, grid, s); break;
-        case 2: launch_c3_nt<2>(a, g, grid, s); break;
-        case 3: launch_c3_nt<3>(a, g, grid, s); break;
-        case 4: launch_c3_nt<4>(a, g, grid, s); break;
-        case 5: launch_c3_nt<5>(a, g, grid, s); break;
-        case 6: launch_c3_nt<6>(a, g, grid, s); break;
-        case 7: launch_c3_nt<7>(a, g, grid, s); break;
-        case 8: launch_c3_nt<8>(a, g, grid, s); break;
+        case 1: launch_c3_nt<1>(a, g, ta, grid, s); break;
+        case 2: launch_c3_nt<2>(a, g, ta, grid, s); break;
+        case 3: launch_c3_nt<3>(a, g, ta, grid, s); break;
+        case 4: launch_c3_nt<4>(a, g, ta, grid, s); break;
+        case 5: launch_c3_nt<5>(a, g, ta, grid, s); break;
+        case 6: launch_c3_nt<6>(a, g, ta, grid, s); break;
+        case 7: launch_c3_nt<7>(a, g, ta, grid, s); break;
+        case 8: launch_c3_nt<8>(a, g, ta, grid, s); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+hipError_t launch_conv3x3(const float* A, const ConvPack& cp, float* out, int relu6, const Geom& g, hipStream_t s) {
+    int maxpix = 0;
+    for (int l = 0; l < g.n_levels; ++l) maxpix = max(maxpix, g.lv[l].H * g.lv[l].W);
+    return launch_conv3x3_any(A, cp, out, relu6, g, nullptr, maxpix, s);
+}
+
+hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, int relu6, const hfnet_keypoint* kps, const int* n_in,
+                               long long kps_stride, const Geom& g, hipStream_t s) {
+    const TapArgs ta = {kps, n_in, kps_stride};
+    return launch_conv3x3_any(A, cp, out, relu6, g, &ta, (int)(kps_stride * 4), s);
+}
+
+// =========================================================================== fused inverted-residual block
+// conv_blocks.py:163-312 in ONE launch: [1x1 expand + BN + ReLU6] -> depthwise 3x3 + BN + ReLU6 ->
+// 1x1 project + BN [+ input].  The expanded tensor (6x the block input, written and read twice by the
+// unfused chain) never leaves the CU: per 32-channel chunk of the expansion
+//   stage 1  MFMA: expand the (TH*s+2) x (TW*s+2) halo tile of the input into LDS (out-of-image halo = 0,
+//            which is what 'SAME' padding of the depthwise conv sees)
+//   stage 2  VALU: depthwise 3x3 from LDS to LDS
+//   stage 3  MFMA: accumulate the chunk into the projection (k-order = expansion channel order, chunks in
+//            order, so the chain is the oracle's)
+// Algorithmic HBM traffic per block drops from in + 4*expanded + out to in*(halo) + out.
+struct FusedArgs {
+    const float* X;
+    const f32x4* Wex; const float* ex_scale; const float* ex_shift; int ex_nt_total;
+    const float* Wdw; const float* dw_scale; const float* dw_shift;
+    const f32x4* Wpr; const float* pr_scale; const float* pr_shift; int pr_nt_total;
+    float* out;
+    int cin, cexp, cout, residual, has_expand;
+    int ablate;   // diagnostics: bit0 skip stage 1, bit1 skip stage 2, bit2 skip stage 3 (results are then wrong)
+};
+
+template <int STRIDE, int TH, int TW, int NTO>
+__global__ __launch_bounds__(256, 2) void k_block_fused(FusedArgs a, Geom g) {
+    constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3, IPIX = IH * IW, OPIX = TH * TW, CEP = 36;
+    constexpr int MT_IN = (IPIX + 31) / 32, MT_OUT = OPIX / 32;
+    static_assert(OPIX % 32 == 0 && MT_OUT <= 4, "output tile must be 32..128 pixels");
+    __shared__ __attribute__((aligned(16))) float E[IPIX * CEP];
+    __shared__ __attribute__((aligned(16))) float D[OPIX * CEP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
+    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
+    const LevelGeom lv = g.lv[level];
+    const int tiles_x = (lv.Wo + TW - 1) / TW, tiles_y = (lv.Ho + TH - 1) / TH;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int oy0 = tyi * TH, ox0 = txi * TW;
+    const int iy0 = oy0 * STRIDE - lv.pt, ix0 = ox0 * STRIDE - lv.pl;
+    const long long in_base = lv.in_off + (long long)frame * lv.H * lv.W;
+    const long long out_base = lv.out_off + (long long)frame * lv.Ho * lv.Wo;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x16 pacc[NTO];
+#pragma unroll
+    for (int nt = 0; nt < NTO; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pacc[nt][i] = 0.0f;
+    const int n_chunks = a.has_expand ? a.ex_nt_total : 1;
+    const int KQ = a.cin >> 3;
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int ch0 = chunk * 32;
+        if (ch0 >= a.cexp) break;                       // all-padding column tile
+        // ---- stage 1: expansion of the halo tile -> E
+        if (a.ablate & 1) {
+        } else if (a.has_expand) {
+            const float sc = a.ex_scale[ch0 + r], sh = a.ex_shift[ch0 + r];
+            for (int mt = wave; mt < MT_IN; mt += 4) {
+                const int hp = mt * 32 + r;
+                const int hy = hp / IW, hx = hp - hy * IW;
+                const int iy = iy0 + hy, ix = ix0 + hx;
+                const bool ok = hp < IPIX && iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W;
+                const float* ap = a.X + (in_base + (long long)(ok ? iy * lv.W + ix : 0)) * a.cin + half * 4;
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+                for (int kq = 0; kq < KQ; ++kq) {
+                    f32x4 av = zero4;
+                    if (ok) av = *(const f32x4*)(ap + kq * 8);
+                    const f32x4 bv = a.Wex[((size_t)kq * a.ex_nt_total + chunk) * 64 + lane];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int hp2 = mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    if (hp2 < IPIX) {
+                        const int hy2 = hp2 / IW, hx2 = hp2 - hy2 * IW;
+                        const int iy2 = iy0 + hy2, ix2 = ix0 + hx2;
+                        const bool in2 = iy2 >= 0 && iy2 < lv.H && ix2 >= 0 && ix2 < lv.W;
+                        E[hp2 * CEP + r] = in2 ? relu6f(fmaf(acc[reg], sc, sh)) : 0.0f;
+                    }
+                }
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < IPIX * 8; idx += 256) {
+                const int hp = idx >> 3, c4 = idx & 7;
+                const int hy = hp / IW, hx = hp - hy * IW;
+                const int iy = iy0 + hy, ix = ix0 + hx;
+                f32x4 v = zero4;
+                if (c4 * 4 < a.cexp && iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W)
+                    v = *(const f32x4*)(a.X + (in_base + (long long)iy * lv.W + ix) * a.cin + c4 * 4);
+                *(f32x4*)(E + hp * CEP + c4 * 4) = v;
+            }
+        }
+        __syncthreads();
+        // ---- stage 2: depthwise 3x3 + BN + ReLU6, E -> D
+        if (!(a.ablate & 2))
+        for (int idx = threadIdx.x; idx < OPIX * 8; idx += 256) {
+            const int op = idx >> 3, c4 = idx & 7;
+            const int c = ch0 + c4 * 4;
+            f32x4 o = zero4;
+            if (c < a.cexp) {
+                const int oy = op / TW, ox = op - oy * TW;
+                f32x4 acc = zero4;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const f32x4 ev = *(const f32x4*)(E + ((oy * STRIDE + ky) * IW + ox * STRIDE + kx) * CEP + c4 * 4);
+                        const f32x4 wv = *(const f32x4*)(a.Wdw + (ky * 3 + kx) * a.cexp + c);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] = fmaf(ev[j], wv[j], acc[j]);
+                    }
+                const f32x4 dsc = *(const f32x4*)(a.dw_scale + c), dsh = *(const f32x4*)(a.dw_shift + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = relu6f(fmaf(acc[j], dsc[j], dsh[j]));
+            }
+            *(f32x4*)(D + op * CEP + c4 * 4) = o;
+        }
+        __syncthreads();
+        // ---- stage 3: projection, accumulate this chunk's channels
+        if (wave < MT_OUT && !(a.ablate & 4)) {
+            const int kqc = min(4, (a.cexp - ch0) >> 3);
+            for (int kq = 0; kq < kqc; ++kq) {
+                const f32x4 av = *(const f32x4*)(D + (wave * 32 + r) * CEP + kq * 8 + half * 4);
+                f32x4 bv[NTO];
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) bv[nt] = a.Wpr[((size_t)(chunk * 4 + kq) * a.pr_nt_total + nt) * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], pacc[nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: BN (+ residual), store
+    if (wave < MT_OUT) {
+#pragma unroll
+        for (int nt = 0; nt < NTO; ++nt) {
+            const int col = nt * 32 + r;
+            if (col >= a.cout) continue;
+            const float sc = a.pr_scale[col], sh = a.pr_shift[col];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int op = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                const int oy = oy0 + op / TW, ox = ox0 + op % TW;
+                if (oy >= lv.Ho || ox >= lv.Wo) continue;
+                float v = fmaf(pacc[nt][reg], sc, sh);
+                if (a.residual) v = v + a.X[(in_base + (long long)oy * lv.W + ox) * a.cin + col];
+                a.out[(out_base + (long long)oy * lv.Wo + ox) * a.cout + col] = v;
+            }
+        }
+    }
+}
+
+// ---- v2 of the fused block for the shapes of the high-resolution layers (cin = 8*KQT known at
+// compile time).  Differences to the generic kernel above:
+//  * the expanded halo tile is kept channel-major in LDS (ET[channel][padded position]); the MFMA
+//    D fragment (lane = channel, 4 consecutive rows per register quad) goes out as ds_write_b128;
+//  * the depthwise stage runs one thread per (channel, output row): three input rows are read once as
+//    16-byte LDS loads and slide along x in registers; the 9 taps + BN live in registers per chunk;
+//  * the block input (A fragments of every halo M-tile of the wave) is loaded once and stays in
+//    registers across chunks; the chunk's expand weights are loaded once per chunk, not per M-tile.
+template <int STRIDE, int NTO, int KQT, bool HAS_EXPAND>
+__global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
+    constexpr int TH = 8, TW = STRIDE == 1 ? 16 : 8;
+    constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3, IWP = (IW + 3) / 4 * 4, NPOS = IH * IWP;
+    constexpr int MT_IN = (NPOS + 31) / 32, MTW = (MT_IN + 3) / 4, OPIX = TH * TW, MT_OUT = OPIX / 32, CEP = 36;
+    constexpr int EP = ((MT_IN * 32 / 4) % 2 == 1) ? MT_IN * 32 : MT_IN * 32 + 4;   // per-channel stride, EP/4 odd
+    constexpr int NQ = IWP / 4;
+    __shared__ __attribute__((aligned(16))) float ET[32 * EP];
+    __shared__ __attribute__((aligned(16))) float D[OPIX * CEP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
+    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
+    const LevelGeom lv = g.lv[level];
+    const int tiles_x = (lv.Wo + TW - 1) / TW, tiles_y = (lv.Ho + TH - 1) / TH;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int oy0 = tyi * TH, ox0 = txi * TW;
+    const int iy0 = oy0 * STRIDE - lv.pt, ix0 = ox0 * STRIDE - lv.pl;
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= lv.H && ix0 + IW <= lv.W;
+    const long long in_base = lv.in_off + (long long)frame * lv.H * lv.W;
+    const long long out_base = lv.out_off + (long long)frame * lv.Ho * lv.Wo;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x16 pacc[NTO];
+#pragma unroll
+    for (int nt = 0; nt < NTO; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pacc[nt][i] = 0.0f;
+    // A fragments of this wave's halo M-tiles (kept for all chunks)
+    constexpr int KQA = HAS_EXPAND ? KQT : 1;
+    f32x4 afrag[MTW][KQA];
+    if (HAS_EXPAND) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const int mt = wave + 4 * m;
+            const int pp = mt * 32 + r;
+            const int hy = pp / IWP, hx = pp - hy * IWP;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool ok = mt < MT_IN && hy < IH && hx < IW && iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W;
+            const float* ap = a.X + (in_base + (long long)(ok ? iy * lv.W + ix : 0)) * a.cin + half * 4;
+#pragma unroll
+            for (int kq = 0; kq < KQA; ++kq) afrag[m][kq] = ok ? *(const f32x4*)(ap + kq * 8) : zero4;
+        }
+    }
+    const int dc = threadIdx.x & 31, doy = threadIdx.x >> 5;      // depthwise role: channel lane, output row
+    const int n_chunks = HAS_EXPAND ? a.ex_nt_total : 1;
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int ch0 = chunk * 32;
+        if (ch0 >= a.cexp) break;
+        // depthwise taps / BN of this thread's channel (registers)
+        const int dch = ch0 + dc;
+        const bool dact = dch < a.cexp;
+        float dwt[9], dsc = 0.f, dsh = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dwt[t] = dact ? a.Wdw[t * a.cexp + dch] : 0.f;
+        if (dact) { dsc = a.dw_scale[dch]; dsh = a.dw_shift[dch]; }
+        // ---- stage 1
+        if (HAS_EXPAND) {
+            f32x4 bfrag[KQA];
+#pragma unroll
+            for (int kq = 0; kq < KQA; ++kq) bfrag[kq] = a.Wex[((size_t)kq * a.ex_nt_total + chunk) * 64 + lane];
+            const float sc = a.ex_scale[ch0 + r], sh = a.ex_shift[ch0 + r];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int mt = wave + 4 * m;
+                if (mt >= MT_IN) break;
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+                for (int kq = 0; kq < KQA; ++kq)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][kq][t], bfrag[kq][t], acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int pp = mt * 32 + 8 * q + 4 * half;
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = relu6f(fmaf(acc[4 * q + i], sc, sh));
+                    if (!interior) {
+                        const int hy = pp / IWP, hx = pp - hy * IWP;     // 4 consecutive positions share the row
+                        const int iy = iy0 + hy;
+                        const bool rowin = iy >= 0 && iy < lv.H;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { const int ix = ix0 + hx + i; if (!(rowin && ix >= 0 && ix < lv.W)) v[i] = 0.0f; }
+                    }
+                    *(f32x4*)(ET + r * EP + pp) = v;
+                }
+            }
+        } else {
+            // no expansion conv (layer_2): the block input itself is the depthwise input
+            for (int idx = threadIdx.x; idx < NPOS * 8; idx += 256) {
+                const int pp = idx >> 3, c4 = idx & 7;
+                const int hy = pp / IWP, hx = pp - hy * IWP;
+                const int iy = iy0 + hy, ix = ix0 + hx;
+                f32x4 v = zero4;
+                if (c4 * 4 < a.cexp && hx < IW && iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W)
+                    v = *(const f32x4*)(a.X + (in_base + (long long)iy * lv.W + ix) * a.cin + c4 * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ET[(c4 * 4 + j) * EP + pp] = v[j];
+            }
+        }
+        __syncthreads();
+        // ---- stage 2: thread = (channel dc, output row doy)
+        {
+            float row[3][IWP];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int qx = 0; qx < NQ; ++qx) {
+                    const f32x4 v = *(const f32x4*)(ET + dc * EP + (doy * STRIDE + ky) * IWP + qx * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) row[ky][qx * 4 + j] = v[j];
+                }
+#pragma unroll
+            for (int ox = 0; ox < TW; ++ox) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc = fmaf(row[ky][ox * STRIDE + kx], dwt[ky * 3 + kx], acc);
+                D[(doy * TW + ox) * CEP + dc] = dact ? relu6f(fmaf(acc, dsc, dsh)) : 0.0f;
+            }
+        }
+        __syncthreads();
+        // ---- stage 3
+        if (wave < MT_OUT && !(a.ablate & 4)) {
+            const int kqc = min(4, (a.cexp - ch0) >> 3);
+            for (int kq = 0; kq < kqc; ++kq) {
+                const f32x4 av = *(const f32x4*)(D + (wave * 32 + r) * CEP + kq * 8 + half * 4);
+                f32x4 bv[NTO];
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) bv[nt] = a.Wpr[((size_t)(chunk * 4 + kq) * a.pr_nt_total + nt) * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], pacc[nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (wave < MT_OUT) {
+#pragma unroll
+        for (int nt = 0; nt < NTO; ++nt) {
+            const int col = nt * 32 + r;
+            if (col >= a.cout) continue;
+            const float sc = a.pr_scale[col], sh = a.pr_shift[col];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int op = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                const int oy = oy0 + op / TW, ox = ox0 + op % TW;
+                if (oy >= lv.Ho || ox >= lv.Wo) continue;
+                float v = fmaf(pacc[nt][reg], sc, sh);
+                if (a.residual) v = v + a.X[(in_base + (long long)oy * lv.W + ox) * a.cin + col];
+                a.out[(out_base + (long long)oy * lv.Wo + ox) * a.cout + col] = v;
+            }
+        }
+    }
+}
+
+template <int STRIDE, int NTO, int KQT, bool HAS_EXPAND>
+static hipError_t launch_block_fused2_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
+    constexpr int TH = 8, TW = STRIDE == 1 ? 16 : 8;
+    int maxtiles = 0;
+    for (int l = 0; l < g.n_levels; ++l) maxtiles = max(maxtiles, ((g.lv[l].Wo + TW - 1) / TW) * ((g.lv[l].Ho + TH - 1) / TH));
+    dim3 grid(maxtiles, g.n_levels * g.batch);
+    hipLaunchKernelGGL((k_block_fused2<STRIDE, NTO, KQT, HAS_EXPAND>), grid, dim3(256), 0, s, a, g);
+    return hipGetLastError();
+}
+
+template <int STRIDE, int TH, int TW>
+static hipError_t launch_block_fused_t(const FusedArgs& a, const Geom& g, int nto, hipStream_t s) {
+    int maxtiles = 0;
+    for (int l = 0; l < g.n_levels; ++l) maxtiles = max(maxtiles, ((g.lv[l].Wo + TW - 1) / TW) * ((g.lv[l].Ho + TH - 1) / TH));
+    dim3 grid(maxtiles, g.n_levels * g.batch);
+    switch (nto) {
+        case 1: hipLaunchKernelGGL((k_block_fused<STRIDE, TH, TW, 1>), grid, dim3(256), 0, s, a, g); break;
+        case 2: hipLaunchKernelGGL((k_block_fused<STRIDE, TH, TW, 2>), grid, dim3(256), 0, s, a, g); break;
+        case 3: hipLaunchKernelGGL((k_block_fused<STRIDE, TH, TW, 3>), grid, dim3(256), 0, s, a, g); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+bool block_fusable(const BlockPack& b) {
+    const int nto = (b.cout + 31) / 32;
+    if (nto > 3 || (b.stride != 1 && b.stride != 2)) return false;
+    if (!b.has_expand && b.expand > 32) return false;
+    return b.cin % 8 == 0 && b.expand % 8 == 0;
+}
+
+hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, const Geom& g, hipStream_t s) {
+    FusedArgs a;
+    a.X = X;
+    a.Wex = (const f32x4*)b.ex.w; a.ex_scale = b.ex.scale; a.ex_shift = b.ex.shift; a.ex_nt_total = b.ex.nt_total;
+    a.Wdw = b.dw.w; a.dw_scale = b.dw.scale; a.dw_shift = b.dw.shift;
+    a.Wpr = (const f32x4*)b.pr.w; a.pr_scale = b.pr.scale; a.pr_shift = b.pr.shift; a.pr_nt_total = b.pr.nt_total;
+    { const char* v = getenv("HFNET_FUSE_ABLATE"); a.ablate = v ? atoi(v) : 0; }
+    a.out = out; a.cin = b.cin; a.cexp = b.expand; a.cout = b.cout; a.residual = b.residual; a.has_expand = b.has_expand;
+    const int nto = (b.cout + 31) / 32;
+    static const bool use_v2 = []() { const char* v = getenv("HFNET_FUSE_V2"); return v ? atoi(v) != 0 : true; }();
+    if (use_v2) {
+        const int kq = b.cin / 8, st = b.stride;
+        if (!b.has_expand && st == 1 && nto == 1) return launch_block_fused2_t<1, 1, 0, false>(a, g, s);
+        if (b.has_expand && st == 2 && kq == 2 && nto == 1) return launch_block_fused2_t<2, 1, 2, true>(a, g, s);
+        if (b.has_expand && st == 1 && kq == 3 && nto == 1) return launch_block_fused2_t<1, 1, 3, true>(a, g, s);
+        if (b.has_expand && st == 2 && kq == 3 && nto == 1) return launch_block_fused2_t<2, 1, 3, true>(a, g, s);
+        if (b.has_expand && st == 1 && kq == 3 && nto == 2) return launch_block_fused2_t<1, 2, 3, true>(a, g, s);
+        if (b.has_expand && st == 1 && kq == 6 && nto == 3) return launch_block_fused2_t<1, 3, 6, true>(a, g, s);
+    }
+    if (b.stride == 1) return launch_block_fused_t<1, 8, 16>(a, g, nto, s);
+    return launch_block_fused_t<2, 8, 8>(a, g, nto, s);
 }
 
 // =========================================================================== depthwise 3x3

@@ -77,7 +77,7 @@ hipError_t launch_softmax_d2s(const float* logits, int ld, float* dense, const G
 __global__ __launch_bounds__(256) void k_nms(const float* __restrict__ dense, float* __restrict__ nms, unsigned long long* __restrict__ cand,
                                              unsigned int* __restrict__ counters, long long cand_stride, float threshold, Geom g) {
     __shared__ float s[NMS_S * NMS_S];
-    __shared__ float tmp[NMS_S * 48];
+    __shared__ __attribute__((aligned(16))) float tmp[NMS_S * 48];
     __shared__ float m0[48 * 48];
     __shared__ float supp[40 * 40];
     __shared__ float ss[40 * 40];
@@ -142,10 +142,15 @@ __global__ __launch_bounds__(256) void k_nms(const float* __restrict__ dense, fl
     __syncthreads();
     float* dst = nms + lv.out_off + (long long)frame * H * W;
     unsigned long long* cl = cand + (long long)image * cand_stride;
-    for (int i = threadIdx.x; i < NMS_T * NMS_T; i += 256) {
+    // candidates are collected in LDS first: one global atomic per workgroup instead of one per
+    // candidate (all candidates of an image hit the same counter)
+    unsigned long long* lkeys = (unsigned long long*)tmp;     // 1024 keys = 8 KB <= sizeof(tmp) (tmp is dead after pool 3)
+    __shared__ unsigned int lcount, lbase;
+    float ovals[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = threadIdx.x + it * 256;
         const int ty = i / NMS_T, tx = i - ty * NMS_T;
-        const int gy = y0 + ty, gx = x0 + tx;
-        if (gy >= H || gx >= W) continue;
         float m = tmp[ty * 32 + tx];
 #pragma unroll
         for (int d = 1; d <= 2 * NMS_R; ++d) m = fmaxf(m, tmp[(ty + d) * 32 + tx]);
@@ -153,13 +158,29 @@ __global__ __launch_bounds__(256) void k_nms(const float* __restrict__ dense, fl
         const bool is_max0 = m0[(ty + 2 * NMS_R) * 48 + tx + 2 * NMS_R] != 0.0f;
         const bool is_supp = supp[(ty + NMS_R) * 40 + tx + NMS_R] != 0.0f;
         const bool new_max = ss[(ty + NMS_R) * 40 + tx + NMS_R] == m;
-        const float o = (is_max0 || (new_max && !is_supp)) ? sv : 0.0f;
+        ovals[it] = (is_max0 || (new_max && !is_supp)) ? sv : 0.0f;
+    }
+    if (threadIdx.x == 0) lcount = 0;
+    __syncthreads();                                           // every read of tmp is done
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = threadIdx.x + it * 256;
+        const int ty = i / NMS_T, tx = i - ty * NMS_T;
+        const int gy = y0 + ty, gx = x0 + tx;
+        if (gy >= H || gx >= W) continue;
+        const float o = ovals[it];
         dst[(long long)gy * W + gx] = o;
         if (o >= threshold) {
-            const unsigned int slot = atomicAdd(&counters[image], 1u);
-            cl[slot] = ((unsigned long long)(~__float_as_uint(o)) << 32) | (unsigned int)(gx * H + gy);
+            const unsigned int slot = atomicAdd(&lcount, 1u);
+            lkeys[slot] = ((unsigned long long)(~__float_as_uint(o)) << 32) | (unsigned int)(gx * H + gy);
         }
     }
+    __syncthreads();
+    const unsigned int cnt = lcount;
+    if (cnt == 0) return;
+    if (threadIdx.x == 0) lbase = atomicAdd(&counters[image], cnt);
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < cnt; i += 256) cl[lbase + i] = lkeys[i];
 }
 
 hipError_t launch_nms(const float* dense, float* nms, unsigned long long* cand, unsigned int* counters, long long cand_stride,
@@ -333,14 +354,23 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a, Geom g) {
     if (x > -1.0f && y > -1.0f && x < (float)dw && y < (float)dh) {
         const int fx = (int)floorf(x), fy = (int)floorf(y), cx = fx + 1, cy = fy + 1;
         const float dx = (float)cx - x, dy = (float)cy - y;
-        const float* d = a.desc_map + (lv.in_off + (long long)frame * dh * dw) * 256 + lane * 4;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         const bool fxin = fx >= 0 && fx <= dw - 1, cxin = cx >= 0 && cx <= dw - 1;
         const bool fyin = fy >= 0 && fy <= dh - 1, cyin = cy >= 0 && cy <= dh - 1;
-        const f32x4 vff = (fxin && fyin) ? *(const f32x4*)(d + (long long)(fy * dw + fx) * 256) : zero;
-        const f32x4 vcc = (cxin && cyin) ? *(const f32x4*)(d + (long long)(cy * dw + cx) * 256) : zero;
-        const f32x4 vfc = (fxin && cyin) ? *(const f32x4*)(d + (long long)(cy * dw + fx) * 256) : zero;
-        const f32x4 vcf = (cxin && fyin) ? *(const f32x4*)(d + (long long)(fy * dw + cx) * 256) : zero;
+        f32x4 vff, vcc, vfc, vcf;
+        if (a.sparse) {   // rows 4i..4i+3 of the image slot hold the taps (fx,fy) (cx,cy) (fx,cy) (cx,fy)
+            const float* d = a.desc_map + (((long long)image * a.kps_stride + i) * 4) * 256 + lane * 4;
+            vff = (fxin && fyin) ? *(const f32x4*)(d) : zero;
+            vcc = (cxin && cyin) ? *(const f32x4*)(d + 256) : zero;
+            vfc = (fxin && cyin) ? *(const f32x4*)(d + 512) : zero;
+            vcf = (cxin && fyin) ? *(const f32x4*)(d + 768) : zero;
+        } else {
+            const float* d = a.desc_map + (lv.in_off + (long long)frame * dh * dw) * 256 + lane * 4;
+            vff = (fxin && fyin) ? *(const f32x4*)(d + (long long)(fy * dw + fx) * 256) : zero;
+            vcc = (cxin && cyin) ? *(const f32x4*)(d + (long long)(cy * dw + cx) * 256) : zero;
+            vfc = (fxin && cyin) ? *(const f32x4*)(d + (long long)(cy * dw + fx) * 256) : zero;
+            vcf = (cxin && fyin) ? *(const f32x4*)(d + (long long)(fy * dw + cx) * 256) : zero;
+        }
         const float wff = dx * dy, wcc = (1.0f - dx) * (1.0f - dy), wfc = dx * (1.0f - dy), wcf = (1.0f - dx) * dy;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

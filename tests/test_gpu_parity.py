@@ -23,10 +23,18 @@ def _eq(name, a, b):
 SIZES = [(64, 96), (120, 160), (133, 171)]   # the last one exercises the crop to multiples of 8 and odd strides
 
 
+VARIANTS = {"default": {}, "unfused_dense": {"HFNET_FUSE_BLOCKS": "0", "HFNET_DENSE_DESC": "1"},
+            "fuse_all": {"HFNET_FUSE_MAX_LAYER": "18"}}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
 @pytest.mark.parametrize("hw", SIZES)
-def test_layer_taps_bit_exact(engine, oracle_model, hw):
+def test_layer_taps_bit_exact(engine, oracle_model, hw, variant, monkeypatch):
+    """every kernel variant (fused / unfused blocks, sparse / dense descriptor head) must give the same bits"""
     from hfnet_slam_amd import capi
     from oracle import oracle as O
+    for k, v in VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
     h, w = hw
     img = synth_image(h, w, 1000 + h)
     m = capi.Model(engine, capi.MODE_LOCAL_AND_GLOBAL, h, w, 500)
