@@ -764,7 +764,8 @@ int hfnet_match_search_by_bow(hfnet_engine* eh, const float* query, int n_query,
         HF_TRY(e.m_i0.ensure(sizeof(int32_t) * n_query)); HF_TRY(e.m_f0.ensure(sizeof(float) * n_query)); HF_TRY(e.m_cnt.ensure(sizeof(int)));
         d_match = e.m_i0.as<int32_t>(); d_dist = e.m_f0.as<float>(); d_cnt = e.m_cnt.as<int>();
     }
-    HF_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int), e.stream));
+    HF_LAUNCH(&e, e.stream, "match_prep", launch_bow_prep(dq, n_query, dt, n_train, dim, e.m_qn.as<float>(), e.m_tn.as<float>(),
+                                                          e.m_key.as<unsigned long long>(), d_cnt, e.stream));
     // St[t][q] = train . query  (rows of St are contiguous in q for the train pass)
     HF_LAUNCH(&e, e.stream, "match_gemm", launch_gemm_abt(dt, n_train, dq, n_query, dim, e.m_s.as<float>(), e.stream));
     HF_LAUNCH(&e, e.stream, "match_bow_select",

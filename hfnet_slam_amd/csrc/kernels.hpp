@@ -86,6 +86,9 @@ hipError_t launch_tri_select(const float* S, int n1, int n2, float threshold, in
 hipError_t launch_bow_select(const float* q, int nq, const float* t, int nt, int dim, const float* S /*[nq x nt]*/,
                              float* qnorm, float* tnorm, unsigned long long* qkey, float th_low, int32_t* match_q2t,
                              float* dist, int* n_matches, hipStream_t s);
+// norms of both sets + reset of the per-query keys and the match counter (one launch, before the GEMM)
+hipError_t launch_bow_prep(const float* q, int nq, const float* t, int nt, int dim, float* qnorm, float* tnorm,
+                           unsigned long long* qkey, int* n_matches, hipStream_t s);
 hipError_t launch_descriptor_distance(const float* a, const float* b, int dim, float* out, hipStream_t s);
 // KeyFrameDatabase scan (KeyFrameDatabase.cc:86-104, 178-197)
 hipError_t launch_db_scores(const float* q, const float* db, const unsigned char* occupied, int n, int dim, float* scores,

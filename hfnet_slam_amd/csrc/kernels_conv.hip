@@ -159,17 +159,99 @@ __global__ __launch_bounds__(256, 2) void k_pointwise(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
     const int KQ = a.cin >> 3;
-    for (int kq = 0; kq < KQ; ++kq) {
-        const f32x4 av = *(const f32x4*)(ap + kq * 8);
-        f32x4 bv[NT];
+    // software pipeline: the loads of step kq+1 are issued before the MFMAs of step kq
+    f32x4 av = *(const f32x4*)(ap);
+    f32x4 bv[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = wp[(size_t)kq * wstep + (size_t)nt * 64];
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = wp[(size_t)nt * 64];
+    for (int kq = 0; kq < KQ; ++kq) {
+        f32x4 av_n = av;
+        f32x4 bv_n[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv_n[nt] = bv[nt];
+        if (kq + 1 < KQ) {
+            av_n = *(const f32x4*)(ap + (kq + 1) * 8);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv_n[nt] = wp[(size_t)(kq + 1) * wstep + (size_t)nt * 64];
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], acc[nt], 0, 0, 0);
+        av = av_n;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
     }
     conv_epilogue<NT>(a, acc, nt0, row0, a.P, half, r);
+}
+
+// Variant for wide inputs (cin >= 64): a lane's 16-byte slices of a long activation row are 4*cin bytes
+// apart across lanes, which defeats L1 (every lane touches its own cache line, 4x over-fetch).  Here the
+// workgroup stages its 128 rows x 32 channels through LDS with fully coalesced 128-byte row segments
+// (register double-buffered, one barrier per 32 channels); fragments come from LDS (row stride 144 B:
+// conflict-free ds_read_b128).  Same MFMA order, same results.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_pointwise_lds(ConvArgs a) {
+    constexpr int LDA = 36;
+    __shared__ __attribute__((aligned(16))) float As[2][128 * LDA];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+    const long long row0wg = (long long)blockIdx.x * 128;
+    const int nt0 = blockIdx.y * NT;
+    const int KQ = a.cin >> 3, KC = (KQ + 3) >> 2;
+    const int piece = tid & 7, rsub = tid >> 3;                    // 8 x 16 B per row, 32 rows per pass
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4* wp = a.W + ((size_t)nt0 * 64 + lane);
+    const size_t wstep = (size_t)a.nt_total * 64;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
+    f32x4 stage[4];
+    auto gload = [&](int c) {
+        const int kqc = min(4, KQ - 4 * c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long row = row0wg + rsub + 32 * i;
+            stage[i] = (row < a.P && piece < 2 * kqc) ? *(const f32x4*)(a.A + row * a.cin + 32 * c + 4 * piece) : zero;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(&As[buf][(rsub + 32 * i) * LDA + 4 * piece]) = stage[i];
+    };
+    gload(0);
+    lstore(0);
+    f32x4 bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = wp[(size_t)nt * 64];
+    __syncthreads();
+    for (int c = 0; c < KC; ++c) {
+        if (c + 1 < KC) gload(c + 1);
+        const int kqc = min(4, KQ - 4 * c);
+        const float* arow = &As[c & 1][(wave * 32 + r) * LDA + half * 4];
+        for (int kq = 0; kq < kqc; ++kq) {
+            const int gk = 4 * c + kq;
+            const f32x4 av = *(const f32x4*)(arow + kq * 8);
+            f32x4 bn[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bn[nt] = bv[nt];
+            if (gk + 1 < KQ) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bn[nt] = wp[(size_t)(gk + 1) * wstep + (size_t)nt * 64];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
+        }
+        if (c + 1 < KC) lstore((c + 1) & 1);
+        __syncthreads();
+    }
+    const long long row0 = row0wg + wave * 32;
+    if (row0 < a.P) conv_epilogue<NT>(a, acc, nt0, row0, a.P, half, r);
 }
 
 // dense 3x3, stride 1, 'SAME' (pad 1): tiles of 32 consecutive pixels of ONE image; out-of-image taps
@@ -226,29 +308,57 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g, TapArgs 
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
     const int KQ = a.cin >> 3;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // per-tap source pointer / validity of this lane's pixel
+    const float* tap_ptr[9];
+    bool tap_ok[9];
+#pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap - ky * 3;
         const int iy = y + ky - 1, ix = x + kx - 1;
-        const bool ok = pvalid && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc;
-        const float* ap = a.A + (in_base + (long long)(ok ? iy * Wc + ix : 0)) * a.cin + half * 4;
-        for (int kq = 0; kq < KQ; ++kq) {
-            f32x4 av = zero;
-            if (ok) av = *(const f32x4*)(ap + kq * 8);
-            f32x4 bv[NT];
-            const size_t wrow = (size_t)(tap * KQ + kq) * wstep;
+        tap_ok[tap] = pvalid && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc;
+        tap_ptr[tap] = a.A + (in_base + (long long)(tap_ok[tap] ? iy * Wc + ix : 0)) * a.cin + half * 4;
+    }
+    // software pipeline over the flattened (tap, kq) loop
+    f32x4 av = tap_ok[0] ? *(const f32x4*)(tap_ptr[0]) : zero;
+    f32x4 bv[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = wp[wrow + (size_t)nt * 64];
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = wp[(size_t)nt * 64];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        for (int kq = 0; kq < KQ; ++kq) {
+            f32x4 av_n = zero;
+            f32x4 bv_n[NT];
+            const bool last = (tap == 8) && (kq + 1 == KQ);
+            const bool wrap = (kq + 1 == KQ);
+            const int tap_n = wrap ? (tap < 8 ? tap + 1 : 8) : tap;
+            const int kq_n = wrap ? 0 : kq + 1;
+            if (!last) {
+                if (tap_ok[tap_n]) av_n = *(const f32x4*)(tap_ptr[tap_n] + kq_n * 8);
+                const size_t wrow = (size_t)(tap_n * KQ + kq_n) * wstep;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv_n[nt] = wp[wrow + (size_t)nt * 64];
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv_n[nt] = bv[nt];
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], acc[nt], 0, 0, 0);
+            av = av_n;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
         }
     }
     conv_epilogue<NT>(a, acc, nt0, out_base + p0, out_base + nrows, half, r);
 }
 
 template <int NT>
-static void launch_pw_nt(const ConvArgs& a, dim3 grid, hipStream_t s) { hipLaunchKernelGGL(k_pointwise<NT>, grid, dim3(256), 0, s, a); }
+static void launch_pw_nt(const ConvArgs& a, dim3 grid, hipStream_t s) {
+    static const int lds_min_cin = []() { const char* v = getenv("HFNET_PW_LDS_MIN_CIN"); return v ? atoi(v) : 1 << 30; }();  // measured: no gain on MI355X, off by default
+    if (a.cin >= lds_min_cin) hipLaunchKernelGGL(k_pointwise_lds<NT>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_pointwise<NT>, grid, dim3(256), 0, s, a);
+}
 template <int NT>
 static void launch_c3_nt(const ConvArgs& a, const Geom& g, const TapArgs* ta, dim3 grid, hipStream_t s) {
     if (ta) hipLaunchKernelGGL((k_conv3x3<NT, true>), grid, dim3(256), 0, s, a, g, *ta);
@@ -512,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
     // A fragments of this wave's halo M-tiles (kept for all chunks)
     constexpr int KQA = HAS_EXPAND ? KQT : 1;
     f32x4 afrag[MTW][KQA];
-    if (HAS_EXPAND) {
+    if (HAS_EXPAND && !(a.ablate & 16)) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             const int mt = wave + 4 * m;
@@ -537,8 +647,19 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) dwt[t] = dact ? a.Wdw[t * a.cexp + dch] : 0.f;
         if (dact) { dsc = a.dw_scale[dch]; dsh = a.dw_shift[dch]; }
+        // projection weights of this chunk (issued now, consumed in stage 3)
+        const int kqc = min(4, (a.cexp - ch0) >> 3);
+        f32x4 pfrag[4][NTO];
+        if (wave < MT_OUT) {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt)
+                    pfrag[kq][nt] = kq < kqc ? a.Wpr[((size_t)(chunk * 4 + kq) * a.pr_nt_total + nt) * 64 + lane] : zero4;
+        }
         // ---- stage 1
-        if (HAS_EXPAND) {
+        if (a.ablate & 1) {
+        } else if (HAS_EXPAND) {
             f32x4 bfrag[KQA];
 #pragma unroll
             for (int kq = 0; kq < KQA; ++kq) bfrag[kq] = a.Wex[((size_t)kq * a.ex_nt_total + chunk) * 64 + lane];
@@ -585,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
         }
         __syncthreads();
         // ---- stage 2: thread = (channel dc, output row doy)
-        {
+        if (!(a.ablate & 2)) {
             float row[3][IWP];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
@@ -608,21 +729,20 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
         __syncthreads();
         // ---- stage 3
         if (wave < MT_OUT && !(a.ablate & 4)) {
-            const int kqc = min(4, (a.cexp - ch0) >> 3);
-            for (int kq = 0; kq < kqc; ++kq) {
-                const f32x4 av = *(const f32x4*)(D + (wave * 32 + r) * CEP + kq * 8 + half * 4);
-                f32x4 bv[NTO];
 #pragma unroll
-                for (int nt = 0; nt < NTO; ++nt) bv[nt] = a.Wpr[((size_t)(chunk * 4 + kq) * a.pr_nt_total + nt) * 64 + lane];
+            for (int kq = 0; kq < 4; ++kq) {
+                if (kq < kqc) {
+                    const f32x4 av = *(const f32x4*)(D + (wave * 32 + r) * CEP + kq * 8 + half * 4);
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                    for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], pacc[nt], 0, 0, 0);
+                        for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], pfrag[kq][nt][t], pacc[nt], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
     }
-    if (wave < MT_OUT) {
+    if (wave < MT_OUT && !(a.ablate & 8)) {
 #pragma unroll
         for (int nt = 0; nt < NTO; ++nt) {
             const int col = nt * 32 + r;
@@ -690,6 +810,8 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
         if (b.has_expand && st == 2 && kq == 3 && nto == 1) return launch_block_fused2_t<2, 1, 3, true>(a, g, s);
         if (b.has_expand && st == 1 && kq == 3 && nto == 2) return launch_block_fused2_t<1, 2, 3, true>(a, g, s);
         if (b.has_expand && st == 1 && kq == 6 && nto == 3) return launch_block_fused2_t<1, 3, 6, true>(a, g, s);
+        if (b.has_expand && st == 1 && kq == 6 && nto == 2) return launch_block_fused2_t<1, 2, 6, true>(a, g, s);
+        if (b.has_expand && st == 1 && kq == 9 && nto == 3) return launch_block_fused2_t<1, 3, 9, true>(a, g, s);
     }
     if (b.stride == 1) return launch_block_fused_t<1, 8, 16>(a, g, nto, s);
     return launch_block_fused_t<2, 8, 8>(a, g, nto, s);

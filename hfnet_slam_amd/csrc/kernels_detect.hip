@@ -233,11 +233,23 @@ __global__ __launch_bounds__(1024) void k_topk(const unsigned long long* __restr
                 if ((k & mask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                unsigned int rem = sh_remaining, b = 0;
-                while (hist[b] < rem) { rem -= hist[b]; ++b; }
-                sh_remaining = rem;
-                sh_prefix = prefix | ((unsigned long long)b << shift);
+            if (tid < 64) {     // wave 0: find the bucket where the cumulative count reaches `remaining`
+                const unsigned int rem = sh_remaining;
+                const unsigned int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                const unsigned int mine = h0 + h1 + h2 + h3;
+                unsigned int incl = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned int v = __shfl_up(incl, off, 64);
+                    if (tid >= off) incl += v;
+                }
+                const unsigned int excl = incl - mine;
+                if (excl < rem && rem <= incl) {          // exactly one lane
+                    unsigned int before = excl, b = 4 * tid;
+                    if (before + h0 < rem) { before += h0; ++b; if (before + h1 < rem) { before += h1; ++b; if (before + h2 < rem) { before += h2; ++b; } } }
+                    sh_remaining = rem - before;
+                    sh_prefix = prefix | ((unsigned long long)b << shift);
+                }
             }
             __syncthreads();
         }

@@ -41,7 +41,8 @@ hipError_t launch_softmax_rows(float* x, long long rows, int n, int ld, hipStrea
 }
 
 // desc[k][d] = sum_p (c[k][d] - f[p][d]) * m[p][k], pixels left to right (layers.py:82-87).
-// feat is in the device channel layout; thread handles physical slot pd == logical channel d.
+// feat is in the device channel layout; thread handles physical slot pd == logical channel d.  The
+// chain over pixels is sequential by definition; the loads are unrolled 8 deep to hide their latency.
 __global__ __launch_bounds__(256) void k_vlad_aggregate(const float* __restrict__ feat, const float* __restrict__ memb,
                                                         const float* __restrict__ clusters, float* __restrict__ out, int P, int D, int K) {
     const int frame = blockIdx.y;
@@ -54,11 +55,15 @@ __global__ __launch_bounds__(256) void k_vlad_aggregate(const float* __restrict_
     const float* f = feat + (long long)frame * P * D + pd;
     const float* m = memb + (long long)frame * P * K + k;
     float acc = 0.0f;
-    for (int p = 0; p < P; ++p) {
-        const float r = c - f[(long long)p * D];
-        const float tt = r * m[(long long)p * K];
-        acc = acc + tt;
+    int p = 0;
+    for (; p + 8 <= P; p += 8) {
+        float fv[8], mv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { fv[j] = f[(long long)(p + j) * D]; mv[j] = m[(long long)(p + j) * K]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float r = c - fv[j]; const float tt = r * mv[j]; acc = acc + tt; }
     }
+    for (; p < P; ++p) { const float r = c - f[(long long)p * D]; const float tt = r * m[(long long)p * K]; acc = acc + tt; }
     out[(long long)frame * K * D + k * D + d] = acc;
 }
 
@@ -122,15 +127,17 @@ __global__ __launch_bounds__(256) void k_fc(const float* __restrict__ x, const f
     if (j >= n_out) return;
     const int lane = threadIdx.x & 63;
     const float* w = wt + (long long)j * n_in + lane * 4;
-    for (int f0 = 0; f0 < frames; f0 += 4) {
-        const int nf = min(4, frames - f0);
-        f32x4 p[4];
+    constexpr int FB = 8;   // frames per pass over the weight row
+    for (int f0 = 0; f0 < frames; f0 += FB) {
+        const int nf = min(FB, frames - f0);
+        f32x4 p[FB];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) p[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < FB; ++f) p[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
         for (int q = 0; q < n_in; q += 256) {
             const f32x4 wv = *(const f32x4*)(w + q);
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
+            for (int f = 0; f < FB; ++f) {
                 if (f < nf) {
                     const f32x4 xv = *(const f32x4*)(x + (long long)(f0 + f) * n_in + q + lane * 4);
 #pragma unroll
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(256) void k_fc(const float* __restrict__ x, const f
             }
         }
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
+        for (int f = 0; f < FB; ++f) {
             if (f >= nf) break;
             f32x4 t = p[f];
 #pragma unroll

@@ -27,15 +27,21 @@ __global__ __launch_bounds__(256) void k_gemm_abt(const float* __restrict__ d1, 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    // software pipeline: loads of the next 8 k are in flight while the 4 MFMAs of this step issue
+    f32x4 a0 = *(const f32x4*)(ap), a1 = *(const f32x4*)(ap + 4), b0 = *(const f32x4*)(bp), b1 = *(const f32x4*)(bp + 4);
     for (int k = 0; k < dim; k += 8) {
-        const f32x4 a0 = *(const f32x4*)(ap + k), a1 = *(const f32x4*)(ap + k + 4);
-        const f32x4 b0 = *(const f32x4*)(bp + k), b1 = *(const f32x4*)(bp + k + 4);
+        f32x4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+        if (k + 8 < dim) {
+            na0 = *(const f32x4*)(ap + k + 8); na1 = *(const f32x4*)(ap + k + 12);
+            nb0 = *(const f32x4*)(bp + k + 8); nb1 = *(const f32x4*)(bp + k + 12);
+        }
         const float av0 = half ? a0[1] : a0[0], av1 = half ? a0[3] : a0[2], av2 = half ? a1[1] : a1[0], av3 = half ? a1[3] : a1[2];
         const float bv0 = half ? b0[1] : b0[0], bv1 = half ? b0[3] : b0[2], bv2 = half ? b1[1] : b1[0], bv3 = half ? b1[3] : b1[2];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av2, bv2, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av3, bv3, acc, 0, 0, 0);
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
     const int col = col0 + r;
     if (col >= n2) return;
@@ -106,15 +112,27 @@ hipError_t launch_tri_select(const float* S, int n1, int n2, float threshold, in
 // Distances are OpenCV's: sqrt(normL2Sqr), generic 4-way unrolled order  s += v0^2+v1^2+v2^2+v3^2.
 // The MFMA dot products St[t][q] only pre-select: every query whose |t|^2+|q|^2-2St lies within a
 // rigorous rounding band of the column minimum is re-evaluated in the exact form, in ascending q.
-__global__ __launch_bounds__(256) void k_row_sumsq(const float* __restrict__ x, int n, int dim, float* __restrict__ out, unsigned int* __restrict__ maxbits) {
+// one launch: |q|^2, |t|^2 (pre-filter only), reset of the per-query keys and of the match counter
+__global__ __launch_bounds__(256) void k_bow_prep(const float* __restrict__ q, int nq, const float* __restrict__ t, int nt, int dim,
+                                                  float* __restrict__ qn, float* __restrict__ tn, unsigned long long* __restrict__ qkey,
+                                                  int* __restrict__ n_matches) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n) return;
     const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_matches = 0;
+    if (i >= nq + nt) return;
+    const float* x = i < nq ? q + (long long)i * dim : t + (long long)(i - nq) * dim;
     float p = 0.0f;
-    for (int k = lane; k < dim; k += 64) { const float v = x[(long long)i * dim + k]; p = fmaf(v, v, p); }
+    for (int k = lane * 4; k < dim; k += 256) {
+        const f32x4 v = *(const f32x4*)(x + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p = fmaf(v[j], v[j], p);
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);
-    if (lane == 0) { out[i] = p; if (maxbits) atomicMax(maxbits, __float_as_uint(p)); }
+    if (lane == 0) {
+        if (i < nq) { qn[i] = p; qkey[i] = ~0ull; }
+        else tn[i - nq] = p;
+    }
 }
 
 // exact OpenCV L2 between rows a and b (dim == 256): lane g computes group g, lanes then add in order
@@ -146,24 +164,30 @@ __device__ float cv_l2_wave(const float* a, const float* b, int dim, int lane) {
 
 __global__ __launch_bounds__(256) void k_bow_train_pass(const float* __restrict__ q, int nq, const float* __restrict__ t, int nt, int dim,
                                                         const float* __restrict__ St /*[nt x nq]*/, const float* __restrict__ qn,
-                                                        const float* __restrict__ tn, const unsigned int* __restrict__ qn_maxbits,
-                                                        unsigned long long* __restrict__ qkey) {
+                                                        const float* __restrict__ tn, unsigned long long* __restrict__ qkey, float band) {
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= nt) return;
     const int lane = threadIdx.x & 63;
     const float* srow = St + (long long)j * nq;
     const float tnj = tn[j];
-    float amin = FLT_MAX;
-    for (int i = lane; i < nq; i += 64) amin = fminf(amin, (qn[i] + tnj) - 2.0f * srow[i]);
+    // d2 ~ |q|^2 + |t|^2 - 2 q.t agrees with the exactly evaluated form up to +-band * (|q|^2 + |t|^2): the
+    // rounding of a dim-term dot / difference sum is below ~4 * dim * 2^-24 of the norms; band = 4e-6 * dim + 1e-4
+    // (1.1e-3 for dim 256) keeps a > 15x margin.
+    // Every query whose lower bound is below the smallest upper bound may be the exact minimiser.
+    float umin = FLT_MAX;
+    for (int i = lane; i < nq; i += 64) {
+        const float nn = qn[i] + tnj;
+        umin = fminf(umin, (nn - 2.0f * srow[i]) + band * nn);
+    }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) amin = fminf(amin, __shfl_xor(amin, off, 64));
-    const float band = 1e-3f * (tnj + __uint_as_float(*qn_maxbits)) + 1e-30f;
+    for (int off = 32; off >= 1; off >>= 1) umin = fminf(umin, __shfl_xor(umin, off, 64));
     float bd = FLT_MAX;
     int bi = -1;
     const float* trow = t + (long long)j * dim;
     for (int i0 = 0; i0 < nq; i0 += 64) {
         const int i = i0 + lane;
-        const bool c = i < nq && ((qn[i] + tnj) - 2.0f * srow[i]) <= amin + band;
+        bool c = false;
+        if (i < nq) { const float nn = qn[i] + tnj; c = ((nn - 2.0f * srow[i]) - band * nn) <= umin; }
         unsigned long long mask = __ballot(c);
         while (mask) {
             const int b = __ffsll((long long)mask) - 1;
@@ -192,25 +216,19 @@ __global__ __launch_bounds__(256) void k_bow_finalize(const unsigned long long* 
     dist[i] = d;
 }
 
-__global__ void k_fill_u64(unsigned long long* p, long long n, unsigned long long v) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
 hipError_t launch_bow_select(const float* q, int nq, const float* t, int nt, int dim, const float* St, float* qnorm, float* tnorm,
                              unsigned long long* qkey, float th_low, int32_t* match_q2t, float* dist, int* n_matches, hipStream_t s) {
     if (nq <= 0) return hipSuccess;
     if (dim % 4) return hipErrorInvalidValue;
-    // qkey[nq] is followed by one extra 64-bit word used for the max query norm bits
-    unsigned int* maxbits = (unsigned int*)(qkey + nq);
-    hipLaunchKernelGGL(k_fill_u64, dim3((nq + 255) / 256), dim3(256), 0, s, qkey, (long long)nq, ~0ull);
-    hipLaunchKernelGGL(k_fill_u64, dim3(1), dim3(256), 0, s, qkey + nq, 1ll, 0ull);
-    hipLaunchKernelGGL(k_row_sumsq, dim3((nq + 3) / 4), dim3(256), 0, s, q, nq, dim, qnorm, maxbits);
-    if (nt > 0) {
-        hipLaunchKernelGGL(k_row_sumsq, dim3((nt + 3) / 4), dim3(256), 0, s, t, nt, dim, tnorm, (unsigned int*)nullptr);
-        hipLaunchKernelGGL(k_bow_train_pass, dim3((nt + 3) / 4), dim3(256), 0, s, q, nq, t, nt, dim, St, qnorm, tnorm, maxbits, qkey);
-    }
+    if (nt > 0) hipLaunchKernelGGL(k_bow_train_pass, dim3((nt + 3) / 4), dim3(256), 0, s, q, nq, t, nt, dim, St, qnorm, tnorm, qkey, 4e-6f * (float)dim + 1e-4f);
     hipLaunchKernelGGL(k_bow_finalize, dim3((nq + 255) / 256), dim3(256), 0, s, qkey, nq, th_low, match_q2t, dist, n_matches);
+    return hipGetLastError();
+}
+
+hipError_t launch_bow_prep(const float* q, int nq, const float* t, int nt, int dim, float* qnorm, float* tnorm, unsigned long long* qkey,
+                           int* n_matches, hipStream_t s) {
+    if (dim % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_bow_prep, dim3((nq + nt + 3) / 4 > 0 ? (nq + nt + 3) / 4 : 1), dim3(256), 0, s, q, nq, t, nt, dim, qnorm, tnorm, qkey, n_matches);
     return hipGetLastError();
 }
 
