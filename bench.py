@@ -120,7 +120,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="frames per step and GPU")
+    ap.add_argument("--batch", type=int, default=32, help="frames per step and GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="also print the per-launch timing table to stderr")
     args = ap.parse_args()
