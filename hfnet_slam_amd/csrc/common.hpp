@@ -95,7 +95,11 @@ struct ConvPack {
     float* shift = nullptr;  // device: [nt_total*32]
 };
 struct DwPack { int c = 0; float* w = nullptr; float* scale = nullptr; float* shift = nullptr; };  // [9][C] phys
-struct BlockPack { int cin, expand, stride, cout, residual, has_expand; ConvPack ex; DwPack dw; ConvPack pr; };
+struct BlockPack {
+    int cin, expand, stride, cout, residual, has_expand;
+    ConvPack ex; DwPack dw; ConvPack pr;
+    float* pr_logical = nullptr;   // projection weights [k logical][n physical] for the vector-ALU layer_2 kernel
+};
 
 struct DeviceWeights {
     int stem_out = 0, c_local = 0, c_global = 0, n_clusters = 0, global_dim = 0, det_hidden = 0;

@@ -746,7 +746,7 @@ int hfnet_descriptor_distance(hfnet_engine* eh, const float* a, const float* b, 
 int hfnet_match_search_by_bow(hfnet_engine* eh, const float* query, int n_query, const float* train, int n_train, int dim, float th_low,
                               int32_t* match_q2t, float* dist, int* n_matches, int on_device) {
     API_GUARD(eh, "engine"); API_GUARD(match_q2t, "match_q2t"); API_GUARD(dist, "dist"); API_GUARD(n_matches, "n_matches");
-    if (n_query < 0 || n_train < 0 || dim <= 0 || dim % 8) { set_error("bad matcher sizes (dim must be a multiple of 8)"); return HFNET_ERR_INVALID_ARG; }
+    if (n_query < 0 || n_train < 0 || dim <= 0 || dim % 64) { set_error("bad matcher sizes (dim must be a multiple of 64)"); return HFNET_ERR_INVALID_ARG; }
     if ((n_query && !query) || (n_train && !train)) { set_error("null descriptor matrix"); return HFNET_ERR_INVALID_ARG; }
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
@@ -783,7 +783,7 @@ int hfnet_match_search_by_bow(hfnet_engine* eh, const float* query, int n_query,
 int hfnet_match_search_for_triangulation(hfnet_engine* eh, const float* d1, int n1, const float* d2, int n2, int dim, float th_high,
                                          int32_t* match12, int* n_matches, int on_device) {
     API_GUARD(eh, "engine"); API_GUARD(match12, "match12"); API_GUARD(n_matches, "n_matches");
-    if (n1 < 0 || n2 < 0 || dim <= 0 || dim % 8) { set_error("bad matcher sizes (dim must be a multiple of 8)"); return HFNET_ERR_INVALID_ARG; }
+    if (n1 < 0 || n2 < 0 || dim <= 0 || dim % 64) { set_error("bad matcher sizes (dim must be a multiple of 64)"); return HFNET_ERR_INVALID_ARG; }
     if ((n1 && !d1) || (n2 && !d2)) { set_error("null descriptor matrix"); return HFNET_ERR_INVALID_ARG; }
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);

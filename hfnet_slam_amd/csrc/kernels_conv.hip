@@ -771,6 +771,69 @@ static hipError_t launch_block_fused2_t(const FusedArgs& a, const Geom& g, hipSt
     return hipGetLastError();
 }
 
+// ---- layer_2 (expanded_conv with expansion factor 1: no expand conv, hf_net.py:31-33): depthwise 3x3 +
+// BN + ReLU6 on CIN channels, then the 1x1 projection CIN -> COUT + BN, stride 1.  Its tensors are the
+// largest of the network (1/2 resolution) and its arithmetic the smallest: one thread per output pixel on
+// the vector ALUs, projection weights in LDS (wave-uniform reads), the fma chain over the CIN depthwise
+// outputs in logical channel order (the oracle's), 16-byte fully coalesced loads and stores.  HBM-bound.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_block_noexpand(FusedArgs a, const float* __restrict__ wproj_logical, Geom g) {
+    __shared__ float wp[CIN * COUT];     // [k logical][n physical]
+    __shared__ float wd[9 * CIN];        // [tap][c physical]
+    __shared__ float dsc[CIN], dsh[CIN], psc[COUT], psh[COUT];
+    for (int i = threadIdx.x; i < CIN * COUT; i += 256) wp[i] = wproj_logical[i];
+    for (int i = threadIdx.x; i < 9 * CIN; i += 256) wd[i] = a.Wdw[i];
+    if (threadIdx.x < CIN) { dsc[threadIdx.x] = a.dw_scale[threadIdx.x]; dsh[threadIdx.x] = a.dw_shift[threadIdx.x]; }
+    if (threadIdx.x < COUT) { psc[threadIdx.x] = a.pr_scale[threadIdx.x]; psh[threadIdx.x] = a.pr_shift[threadIdx.x]; }
+    __syncthreads();
+    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
+    const LevelGeom lv = g.lv[level];
+    const int op = blockIdx.x * 256 + threadIdx.x;
+    if (op >= lv.Ho * lv.Wo) return;
+    const int oy = op / lv.Wo, ox = op - oy * lv.Wo;
+    const float* xin = a.X + (lv.in_off + (long long)frame * lv.H * lv.W) * CIN;
+    float d[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) d[c] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy - lv.pt + ky;
+        if (iy < 0 || iy >= lv.H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox - lv.pl + kx;
+            if (ix < 0 || ix >= lv.W) continue;
+            const float* xp = xin + (long long)(iy * lv.W + ix) * CIN;
+#pragma unroll
+            for (int c4 = 0; c4 < CIN / 4; ++c4) {
+                const f32x4 xv = *(const f32x4*)(xp + c4 * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[c4 * 4 + j] = fmaf(xv[j], wd[(ky * 3 + kx) * CIN + c4 * 4 + j], d[c4 * 4 + j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) d[c] = relu6f(fmaf(d[c], dsc[c], dsh[c]));
+    float acc[COUT];
+#pragma unroll
+    for (int n = 0; n < COUT; ++n) acc[n] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < CIN; ++k) {                       // logical channel k sits in physical slot phys(k)
+        const int pk = (k & ~7) | ((k & 1) << 2) | ((k & 7) >> 1);
+        const float dk = d[pk];
+#pragma unroll
+        for (int n = 0; n < COUT; ++n) acc[n] = fmaf(dk, wp[k * COUT + n], acc[n]);
+    }
+    float* o = a.out + (lv.out_off + (long long)frame * lv.Ho * lv.Wo + op) * COUT;
+#pragma unroll
+    for (int n4 = 0; n4 < COUT / 4; ++n4) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[n4 * 4 + j], psc[n4 * 4 + j], psh[n4 * 4 + j]);
+        *(f32x4*)(o + n4 * 4) = v;
+    }
+}
+
 template <int STRIDE, int TH, int TW>
 static hipError_t launch_block_fused_t(const FusedArgs& a, const Geom& g, int nto, hipStream_t s) {
     int maxtiles = 0;
@@ -802,6 +865,12 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
     a.out = out; a.cin = b.cin; a.cexp = b.expand; a.cout = b.cout; a.residual = b.residual; a.has_expand = b.has_expand;
     const int nto = (b.cout + 31) / 32;
     static const bool use_v2 = []() { const char* v = getenv("HFNET_FUSE_V2"); return v ? atoi(v) != 0 : true; }();
+    if (use_v2 && !b.has_expand && b.stride == 1 && !b.residual && b.cin == 24 && b.cout == 16 && b.pr_logical) {
+        int maxpix = 0;
+        for (int l = 0; l < g.n_levels; ++l) maxpix = max(maxpix, g.lv[l].Ho * g.lv[l].Wo);
+        hipLaunchKernelGGL((k_block_noexpand<24, 16>), dim3((maxpix + 255) / 256, g.n_levels * g.batch), dim3(256), 0, s, a, b.pr_logical, g);
+        return hipGetLastError();
+    }
     if (use_v2) {
         const int kq = b.cin / 8, st = b.stride;
         if (!b.has_expand && st == 1 && nto == 1) return launch_block_fused2_t<1, 1, 0, false>(a, g, s);

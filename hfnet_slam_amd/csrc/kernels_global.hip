@@ -119,44 +119,52 @@ hipError_t launch_vlad(const float* feat, const float* memb, const float* cluste
 }
 
 // y[f][j] = tree256_dot(x[f], wt[j]) + b[j]  (slim.fully_connected, layers.py:99-107).
-// One wave per output j: lane l owns tree256 partials 4l..4l+3, 16-byte coalesced loads of the
-// transposed weight row (126 MB streamed once per call: HBM-bound), up to 4 frames per pass.
+// A wave owns JW = 4 outputs and up to FB = 8 frames per pass: lane l holds the tree256 partials
+// 4l..4l+3 of every (output, frame) pair; per 256 inputs it issues 4 weight + FB activation 16-byte
+// loads for 4*FB*4 fmas, so the activations (L2-resident) are not re-streamed once per output.  The
+// 126 MB of transposed weights are read once per pass: HBM-bound.
 __global__ __launch_bounds__(256) void k_fc(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
                                             float* __restrict__ y, int frames, int n_in, int n_out) {
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= n_out) return;
+    constexpr int JW = 4, FB = 8;
+    const int j0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * JW;
+    if (j0 >= n_out) return;
     const int lane = threadIdx.x & 63;
-    const float* w = wt + (long long)j * n_in + lane * 4;
-    constexpr int FB = 8;   // frames per pass over the weight row
+    const float* w[JW];
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) w[jj] = wt + (long long)min(j0 + jj, n_out - 1) * n_in + lane * 4;
     for (int f0 = 0; f0 < frames; f0 += FB) {
         const int nf = min(FB, frames - f0);
-        f32x4 p[FB];
+        f32x4 p[JW][FB];
 #pragma unroll
-        for (int f = 0; f < FB; ++f) p[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+        for (int jj = 0; jj < JW; ++jj)
+#pragma unroll
+            for (int f = 0; f < FB; ++f) p[jj][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int q = 0; q < n_in; q += 256) {
-            const f32x4 wv = *(const f32x4*)(w + q);
+            f32x4 wv[JW], xv[FB];
+#pragma unroll
+            for (int jj = 0; jj < JW; ++jj) wv[jj] = *(const f32x4*)(w[jj] + q);
+#pragma unroll
+            for (int f = 0; f < FB; ++f) xv[f] = *(const f32x4*)(x + (long long)(f0 + min(f, nf - 1)) * n_in + q + lane * 4);
+#pragma unroll
+            for (int jj = 0; jj < JW; ++jj)
+#pragma unroll
+                for (int f = 0; f < FB; ++f)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) p[jj][f][c] = fmaf(xv[f][c], wv[jj][c], p[jj][f][c]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj)
 #pragma unroll
             for (int f = 0; f < FB; ++f) {
-                if (f < nf) {
-                    const f32x4 xv = *(const f32x4*)(x + (long long)(f0 + f) * n_in + q + lane * 4);
+                f32x4 t = p[jj][f];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) p[f][c] = fmaf(xv[c], wv[c], p[f][c]);
+                for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) t[c] = t[c] + __shfl_xor(t[c], off, 64);
                 }
+                const float a = t[0] + t[2], b = t[1] + t[3];
+                if (lane == 0 && f < nf && j0 + jj < n_out) y[(long long)(f0 + f) * n_out + j0 + jj] = (a + b) + bias[j0 + jj];
             }
-        }
-#pragma unroll
-        for (int f = 0; f < FB; ++f) {
-            if (f >= nf) break;
-            f32x4 t = p[f];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) t[c] = t[c] + __shfl_xor(t[c], off, 64);
-            }
-            const float a = t[0] + t[2], b = t[1] + t[3];
-            if (lane == 0) y[(long long)(f0 + f) * n_out + j] = (a + b) + bias[j];
-        }
     }
 }
 
@@ -172,7 +180,7 @@ hipError_t launch_fc_l2(const float* x, const float* wt, const float* bias, floa
                         int n_out, hipStream_t s) {
     if (frames <= 0) return hipSuccess;
     if (n_in % 256 != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_fc, dim3((n_out + 3) / 4), dim3(256), 0, s, x, wt, bias, y_raw, frames, n_in, n_out);
+    hipLaunchKernelGGL(k_fc, dim3((n_out + 15) / 16), dim3(256), 0, s, x, wt, bias, y_raw, frames, n_in, n_out);
     hipLaunchKernelGGL(k_l2norm_vec, dim3(frames), dim3(256), 0, s, y_raw, out, n_out);
     return hipGetLastError();
 }

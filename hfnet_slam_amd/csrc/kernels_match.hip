@@ -17,45 +17,60 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // One wave per 32x32 tile of S on v_mfma_f32_32x32x2_f32; each accumulator is the fused
 // multiply-add chain over k = 0, 1, 2, ... (the oracle's order).  Rows are in logical order here, so
 // every lane loads the 8 consecutive k of its row and the two half-waves pick even / odd k.
+// Workgroup = 64 x 64 tile of S (4 waves, one 32x32 MFMA tile each); K is consumed in chunks of 64 that
+// are staged through LDS with coalesced 256-byte row segments (a lane's own row is 1 KB away from its
+// neighbour's, so direct fragment loads thrash L1).  LDS rows are 66 floats apart: the 8-byte fragment
+// reads (k = 2t, 2t+1; the half-waves pick the even / odd one) are bank-conflict free.
 __global__ __launch_bounds__(256) void k_gemm_abt(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int dim,
                                                   float* __restrict__ S) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
-    const int row0 = (blockIdx.y * 4 + wave) * 32, col0 = blockIdx.x * 32;
-    if (row0 >= n1) return;
-    const float* ap = d1 + (long long)min(row0 + r, n1 - 1) * dim;
-    const float* bp = d2 + (long long)min(col0 + r, n2 - 1) * dim;
+    constexpr int LD = 66;
+    __shared__ __attribute__((aligned(16))) float As[64 * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    const int lrow = tid >> 2, lq = tid & 3;                 // staging: 4 threads x 4 float4 per 64-float row chunk
+    const float* ag = d1 + (long long)min(row0 + lrow, n1 - 1) * dim + lq * 4;
+    const float* bg = d2 + (long long)min(col0 + lrow, n2 - 1) * dim + lq * 4;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    // software pipeline: loads of the next 8 k are in flight while the 4 MFMAs of this step issue
-    f32x4 a0 = *(const f32x4*)(ap), a1 = *(const f32x4*)(ap + 4), b0 = *(const f32x4*)(bp), b1 = *(const f32x4*)(bp + 4);
-    for (int k = 0; k < dim; k += 8) {
-        f32x4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
-        if (k + 8 < dim) {
-            na0 = *(const f32x4*)(ap + k + 8); na1 = *(const f32x4*)(ap + k + 12);
-            nb0 = *(const f32x4*)(bp + k + 8); nb1 = *(const f32x4*)(bp + k + 12);
+    f32x4 sa[4], sb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sa[j] = *(const f32x4*)(ag + j * 16); sb[j] = *(const f32x4*)(bg + j * 16); }
+    for (int k0 = 0; k0 < dim; k0 += 64) {
+        __syncthreads();                                     // previous chunk fully consumed
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { As[lrow * LD + lq * 4 + j * 16 + c] = sa[j][c]; Bs[lrow * LD + lq * 4 + j * 16 + c] = sb[j][c]; }
         }
-        const float av0 = half ? a0[1] : a0[0], av1 = half ? a0[3] : a0[2], av2 = half ? a1[1] : a1[0], av3 = half ? a1[3] : a1[2];
-        const float bv0 = half ? b0[1] : b0[0], bv1 = half ? b0[3] : b0[2], bv2 = half ? b1[1] : b1[0], bv3 = half ? b1[3] : b1[2];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av2, bv2, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av3, bv3, acc, 0, 0, 0);
-        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        __syncthreads();
+        if (k0 + 64 < dim) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sa[j] = *(const f32x4*)(ag + k0 + 64 + j * 16); sb[j] = *(const f32x4*)(bg + k0 + 64 + j * 16); }
+        }
+        const float* ap = As + (wr + r) * LD;
+        const float* bp = Bs + (wc + r) * LD;
+#pragma unroll
+        for (int k = 0; k < 64; k += 2) {
+            const float2 av = *(const float2*)(ap + k), bv = *(const float2*)(bp + k);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? av.y : av.x, half ? bv.y : bv.x, acc, 0, 0, 0);
+        }
     }
-    const int col = col0 + r;
+    const int col = col0 + wc + r;
     if (col >= n2) return;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-        const int row = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        const int row = row0 + wr + (reg & 3) + 8 * (reg >> 2) + 4 * half;
         if (row < n1) S[(long long)row * n2 + col] = acc[reg];
     }
 }
 
 hipError_t launch_gemm_abt(const float* d1, int n1, const float* d2, int n2, int dim, float* S, hipStream_t s) {
     if (n1 <= 0 || n2 <= 0) return hipSuccess;
-    if (dim % 8) return hipErrorInvalidValue;
-    dim3 grid((n2 + 31) / 32, (n1 + 127) / 128);
+    if (dim % 64) return hipErrorInvalidValue;
+    dim3 grid((n2 + 63) / 64, (n1 + 63) / 64);
     hipLaunchKernelGGL(k_gemm_abt, grid, dim3(256), 0, s, d1, n1, d2, n2, dim, S);
     return hipGetLastError();
 }
@@ -174,27 +189,56 @@ __global__ __launch_bounds__(256) void k_bow_train_pass(const float* __restrict_
     // rounding of a dim-term dot / difference sum is below ~4 * dim * 2^-24 of the norms; band = 4e-6 * dim + 1e-4
     // (1.1e-3 for dim 256) keeps a > 15x margin.
     // Every query whose lower bound is below the smallest upper bound may be the exact minimiser.
-    float umin = FLT_MAX;
-    for (int i = lane; i < nq; i += 64) {
-        const float nn = qn[i] + tnj;
-        umin = fminf(umin, (nn - 2.0f * srow[i]) + band * nn);
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) umin = fminf(umin, __shfl_xor(umin, off, 64));
     float bd = FLT_MAX;
     int bi = -1;
     const float* trow = t + (long long)j * dim;
-    for (int i0 = 0; i0 < nq; i0 += 64) {
-        const int i = i0 + lane;
-        bool c = false;
-        if (i < nq) { const float nn = qn[i] + tnj; c = ((nn - 2.0f * srow[i]) - band * nn) <= umin; }
-        unsigned long long mask = __ballot(c);
-        while (mask) {
-            const int b = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const int qi = i0 + b;
-            const float d = (dim == 256) ? cv_l2_wave256(trow, q + (long long)qi * dim, lane) : cv_l2_wave(trow, q + (long long)qi * dim, dim, lane);
-            if (d < bd) { bd = d; bi = qi; }
+    if (nq <= 1024) {
+        // one sweep: every lane keeps its <= 16 (lower bound, upper bound) pairs in registers
+        float lo[16];
+        float umin = FLT_MAX;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = u * 64 + lane;
+            lo[u] = FLT_MAX;
+            if (i < nq) {
+                const float nn = qn[i] + tnj, d2 = nn - 2.0f * srow[i];
+                lo[u] = d2 - band * nn;
+                umin = fminf(umin, d2 + band * nn);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) umin = fminf(umin, __shfl_xor(umin, off, 64));
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            unsigned long long mask = __ballot(lo[u] <= umin);
+            while (mask) {
+                const int b = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int qi = u * 64 + b;
+                const float d = (dim == 256) ? cv_l2_wave256(trow, q + (long long)qi * dim, lane) : cv_l2_wave(trow, q + (long long)qi * dim, dim, lane);
+                if (d < bd) { bd = d; bi = qi; }
+            }
+        }
+    } else {
+        float umin = FLT_MAX;
+        for (int i = lane; i < nq; i += 64) {
+            const float nn = qn[i] + tnj;
+            umin = fminf(umin, (nn - 2.0f * srow[i]) + band * nn);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) umin = fminf(umin, __shfl_xor(umin, off, 64));
+        for (int i0 = 0; i0 < nq; i0 += 64) {
+            const int i = i0 + lane;
+            bool c = false;
+            if (i < nq) { const float nn = qn[i] + tnj; c = ((nn - 2.0f * srow[i]) - band * nn) <= umin; }
+            unsigned long long mask = __ballot(c);
+            while (mask) {
+                const int b = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int qi = i0 + b;
+                const float d = (dim == 256) ? cv_l2_wave256(trow, q + (long long)qi * dim, lane) : cv_l2_wave(trow, q + (long long)qi * dim, dim, lane);
+                if (d < bd) { bd = d; bi = qi; }
+            }
         }
     }
     if (lane == 0 && bi >= 0)

@@ -220,6 +220,13 @@ int DeviceWeights::build(const WeightFile& wf) {
         HF_TRY(pack_conv_bn(*this, wf, scope + "/project", true, b.pr, &b.cout));
         if (b.pr.cin != b.expand || (b.has_expand && b.ex.cin != cin)) { set_error("block %d: channel mismatch", i); return HFNET_ERR_IO; }
         b.residual = (b.stride == 1 && b.cin == b.cout);   // conv_blocks.py:304-311
+        if (!b.has_expand) {
+            const HostTensor* pw = wf.find(scope + "/project/weights");
+            std::vector<float> wl((size_t)b.expand * b.cout);
+            for (int k = 0; k < b.expand; ++k)
+                for (int n = 0; n < b.cout; ++n) wl[(size_t)k * b.cout + n] = pw->data[(size_t)k * b.cout + logical_of_phys(n)];
+            HF_TRY(upload(*this, wl, &b.pr_logical));
+        }
         cin = b.cout;
     }
     c_local = blocks[5].cout;    // layer_7

@@ -171,7 +171,7 @@ def _unit_rows(rng, n, d=256):
     return (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
 
 
-@pytest.mark.parametrize("n1,n2,sigma", [(300, 280, 0.02), (257, 129, 0.045), (33, 1000, 0.02), (1, 1, 0.0), (40, 0, 0.0)])
+@pytest.mark.parametrize("n1,n2,sigma", [(300, 280, 0.02), (257, 129, 0.045), (33, 1000, 0.02), (1, 1, 0.0), (40, 0, 0.0), (1100, 700, 0.03)])
 def test_matchers(engine, n1, n2, sigma):
     """planted permutation: B = normalise(A[pi] + sigma * g)"""
     from oracle import oracle as O
