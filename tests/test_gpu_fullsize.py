@@ -1,0 +1,100 @@
+"""BASELINE.json's full-size configurations on the GPU: oracle parity where the oracle finishes in seconds,
+plus size-independent properties (determinism, batch invariance, budget, ordering, unit norms, self-match)."""
+import numpy as np
+import pytest
+
+from conftest import synth_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _props(kps, desc, glob, n_per_level, budget, sizes, thr):
+    assert list(n_per_level) == list(budget) and len(kps) == sum(budget)
+    assert np.allclose(np.linalg.norm(desc.astype(np.float64), axis=1), 1.0, atol=2e-6)
+    assert abs(np.linalg.norm(glob.astype(np.float64)) - 1.0) < 2e-6
+    off = 0
+    for lvl, n in enumerate(budget):
+        k = kps[off:off + n]
+        off += n
+        assert np.all(k["octave"] == lvl)
+        assert np.all(k["response"] >= thr)
+        assert np.all(np.diff(k["response"]) <= 0), "canonical order: response descending within a level"
+        sf = np.float32(1.2) ** lvl
+        w, h = sizes[lvl]
+        assert np.all(k["x"] >= 0) and np.all(k["x"] <= (w // 8 * 8 - 1) * sf + 1e-3)
+        assert np.all(k["y"] >= 0) and np.all(k["y"] <= (h // 8 * 8 - 1) * sf + 1e-3)
+        assert len({(float(a), float(b)) for a, b in zip(k["x"], k["y"])}) == n, "duplicate keypoint"
+
+
+@pytest.mark.parametrize("cfg", [(752, 480, 1000), (512, 512, 850)])     # EuRoC.yaml / TUM-VI.yaml sizes
+def test_full_size_frame_vs_oracle_and_properties(engine, oracle_model, cfg):
+    from hfnet_slam_amd import capi, spec
+    w, h, nf = cfg
+    x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, 4, max_batch=3)
+    img = synth_image(h, w, 1000)
+    n, kps, desc, g, npl = x.extract(img)
+    budget = spec.features_per_level(nf, 4, 1.2)
+    _props(kps, desc, g, npl, budget, spec.level_sizes(w, h, 4, 1.2), 0.01)
+    rn, rk, rd, rg, rnpl = oracle_model.extract(img, nf, 0.01, 4, 1.2)
+    assert n == rn and np.array_equal(npl, rnpl)
+    assert np.array_equal(kps, rk), "keypoints must be bit-exact at full size"
+    assert np.array_equal(desc, rd) and np.array_equal(g, rg)
+    # determinism and batch invariance: alone == inside a batch, at any position, twice
+    imgs = np.stack([synth_image(h, w, 1001, "natural"), img, synth_image(h, w, 1002)])
+    for _ in range(2):
+        nb, kb, db, gb = x.extract_batch(imgs)
+        assert nb[1] == n and np.array_equal(kb[1, :n], kps) and np.array_equal(db[1, :n], desc) and np.array_equal(gb[1], g)
+    # strided input (ROI of a larger buffer) gives the same result
+    big = np.zeros((h + 6, w + 40), np.uint8)
+    big[3:3 + h, 16:16 + w] = img
+    n2, k2, d2, g2, _ = x.extract(big[3:3 + h, 16:16 + w])
+    assert n2 == n and np.array_equal(k2, kps) and np.array_equal(d2, desc) and np.array_equal(g2, g)
+    x.close()
+
+
+def test_full_size_match_1000x1000(engine):
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal((1000, 256)).astype(np.float32); a /= np.linalg.norm(a, axis=1, keepdims=True)
+    perm = np.random.default_rng(12).permutation(1000)
+    b = a[perm] + 0.02 * rng.standard_normal((1000, 256)).astype(np.float32); b /= np.linalg.norm(b, axis=1, keepdims=True)
+    a = a.astype(np.float32); b = b.astype(np.float32)
+    n, m, d = engine.search_by_bow(a, b, 0.6)
+    assert n == 1000 and np.array_equal(m, np.argsort(perm))                     # planted permutation recovered
+    rn, rm, rd = O.search_by_bow(a, b, 0.6)
+    assert n == rn and np.array_equal(m, rm) and np.array_equal(d, rd)
+    n, m = engine.search_for_triangulation(a, b, 0.75)
+    rn, rm = O.search_for_triangulation(a, b, 0.75)
+    assert n == rn == 1000 and np.array_equal(m, rm)
+    # self match: every row matches itself at distance 0; symmetric under swapping the roles
+    n, m, d = engine.search_by_bow(a, a, 0.6)
+    assert n == 1000 and np.array_equal(m, np.arange(1000)) and np.all(d == 0)
+    n_ab, m_ab, _ = engine.search_by_bow(a, b, 0.6)
+    n_ba, m_ba, _ = engine.search_by_bow(b, a, 0.6)
+    assert n_ab == n_ba and np.array_equal(m_ba[m_ab], np.arange(1000))
+
+
+def test_loop_closure_stress_10k_database(engine):
+    """BASELINE config 5: 10 000 x 4096 unit rows resident in HBM, planted neighbours"""
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    rng = np.random.default_rng(13)
+    n, dim = 10000, 4096
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    rows = rows.astype(np.float32)
+    db = capi.Database(engine, n, dim)
+    for i in range(n):
+        db.add(i, rows[i])
+    for planted in (0, 4321, 9999):
+        q = rows[planted] + 0.003 * rng.standard_normal(dim).astype(np.float32)
+        q = (q / np.linalg.norm(q)).astype(np.float32)
+        cs, sc, best, scores = db.query(q, 0, want_scores=True)
+        assert cs.tolist() == [planted] and best == scores[planted] and 0.7 < best < 0.9
+        ref = O.db_scores(q, rows)
+        assert np.array_equal(scores, ref)
+        ridx, rbest = O.db_candidates(ref, 0)
+        assert np.array_equal(cs, ridx) and best == rbest
+        cs1, _, _, _ = db.query(q, 1)
+        assert cs1.tolist() == [planted]
+    db.close()
