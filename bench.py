@@ -61,6 +61,10 @@ def layer_work(batch: int):
             add(f"depthwise_L{b.index:02d}", 2.0 * 9 * pout * b.expand, 4.0 * (pin * b.expand + pout * b.expand + 9 * b.expand))
             add(f"project_L{b.index:02d}", 2.0 * pout * b.expand * b.cout,
                 4.0 * (pout * (b.expand + b.cout * (2 if b.residual else 1)) + b.expand * b.cout))
+            # the same block as ONE fused launch: all three layers' FLOP, but only the block input / output cross HBM
+            add(f"block_L{b.index:02d}",
+                (2.0 * pin * b.cin * b.expand if b.expand > b.cin else 0.0) + 2.0 * 9 * pout * b.expand + 2.0 * pout * b.expand * b.cout,
+                4.0 * (pin * b.cin + pout * b.cout * (2 if b.residual else 1) + b.cin * b.expand + 9 * b.expand + b.expand * b.cout))
             ph, pw = oh, ow
             if b.index == 7:
                 cells = ph * pw * batch
@@ -77,9 +81,31 @@ def layer_work(batch: int):
             add("pointwise_memberships", 2.0 * pg * sp.global_channels * sp.n_clusters, 4.0 * pg * (sp.global_channels + sp.n_clusters))
             add("vlad", 3.0 * pg * sp.vlad_dim / batch * batch, 4.0 * (pg * (sp.global_channels + sp.n_clusters) + 3 * batch * sp.vlad_dim))
             add("fc_l2", 2.0 * batch * sp.vlad_dim * sp.global_dim, 4.0 * (sp.vlad_dim * sp.global_dim + batch * (sp.vlad_dim + 2 * sp.global_dim)))
+    # sparse descriptor head: 4 bilinear taps per keypoint (N_FEAT keypoints per frame)
+    rows = 4.0 * N_FEAT * batch
+    work["conv3x3_desc_taps"] = (2.0 * 9 * sp.local_channels * 256 * rows, 4.0 * (rows * (9 * sp.local_channels + 256) + 9 * sp.local_channels * 256))
+    work["pointwise_desc_taps"] = (2.0 * 256 * 256 * rows, 4.0 * (rows * 512 + 256 * 256))
+    work["l2norm_desc_taps"] = (3.0 * 256 * rows, 4.0 * rows * 512)
     # matcher: one launch per frame pair
     work["match_gemm"] = (2.0 * N_FEAT * N_FEAT * 256, 4.0 * (2 * N_FEAT * 256 + N_FEAT * N_FEAT))
     return work
+
+
+def hbm_traffic(launch_name: str, batch: int):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic_b32.json:
+    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command), with the gfx950
+    correction of MI355X_MICROARCH.md (FETCH_SIZE counts 128-byte requests as 64 bytes -> doubled).  None when
+    no pass exists for this kernel / batch size."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic_b32.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        k = t["kernels"][launch_name]
+        if t["batch"] != batch:
+            return None
+        return (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def make_frames(count: int, first_index: int) -> np.ndarray:
@@ -236,7 +262,7 @@ def main() -> None:
         else:
             roof = {"bound": "hbm", "achieved": byts / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"] = None
+        roof["traffic"] = hbm_traffic(dominant, B)
         roof["kernel"] = dominant
         roof["avg_launch_us"] = avg_s * 1e6
         roof["launches"] = dom[0]

@@ -597,12 +597,22 @@ template <int STRIDE, int NTO, int KQT, bool HAS_EXPAND>
 __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
     constexpr int TH = 8, TW = STRIDE == 1 ? 16 : 8;
     constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3, IWP = (IW + 3) / 4 * 4, NPOS = IH * IWP;
-    constexpr int MT_IN = (NPOS + 31) / 32, MTW = (MT_IN + 3) / 4, OPIX = TH * TW, MT_OUT = OPIX / 32, CEP = 36;
+    constexpr int MT_IN = (NPOS + 31) / 32, OPIX = TH * TW, MT_OUT = OPIX / 32, CEP = 36;
     constexpr int EP = ((MT_IN * 32 / 4) % 2 == 1) ? MT_IN * 32 : MT_IN * 32 + 4;   // per-channel stride, EP/4 odd
     constexpr int NQ = IWP / 4;
+    // halo M-tiles per wave.  Stage 3 of chunk c runs in the same barrier phase as stage 1 of chunk c+1
+    // (see the loop), and only waves < MT_OUT have stage-3 work, so those waves own fewer halo tiles.
+    constexpr int MTC0 = STRIDE == 2 ? (KQT <= 2 ? 1 : 2) : 2;
+    constexpr int MTC1 = 2;
+    constexpr int MTC2 = STRIDE == 2 ? (KQT <= 2 ? 4 : 3) : 2;
+    constexpr int MTC3 = MT_IN - MTC0 - MTC1 - MTC2;
+    constexpr int MTW = MTC3 > MTC2 ? MTC3 : MTC2;
+    static_assert(MTC3 >= 0 && MTW <= 4, "halo tile distribution");
     __shared__ __attribute__((aligned(16))) float ET[32 * EP];
     __shared__ __attribute__((aligned(16))) float D[OPIX * CEP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
+    const int mt_first = wave == 0 ? 0 : wave == 1 ? MTC0 : wave == 2 ? MTC0 + MTC1 : MTC0 + MTC1 + MTC2;
+    const int mt_count = wave == 0 ? MTC0 : wave == 1 ? MTC1 : wave == 2 ? MTC2 : MTC3;
     const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
     const LevelGeom lv = g.lv[level];
     const int tiles_x = (lv.Wo + TW - 1) / TW, tiles_y = (lv.Ho + TH - 1) / TH;
@@ -622,77 +632,61 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
     // A fragments of this wave's halo M-tiles (kept for all chunks)
     constexpr int KQA = HAS_EXPAND ? KQT : 1;
     f32x4 afrag[MTW][KQA];
-    if (HAS_EXPAND && !(a.ablate & 16)) {
+    if (HAS_EXPAND) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
-            const int mt = wave + 4 * m;
+            const int mt = mt_first + m;
             const int pp = mt * 32 + r;
             const int hy = pp / IWP, hx = pp - hy * IWP;
             const int iy = iy0 + hy, ix = ix0 + hx;
-            const bool ok = mt < MT_IN && hy < IH && hx < IW && iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W;
+            const bool ok = m < mt_count && hy < IH && hx < IW && iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W;
             const float* ap = a.X + (in_base + (long long)(ok ? iy * lv.W + ix : 0)) * a.cin + half * 4;
 #pragma unroll
             for (int kq = 0; kq < KQA; ++kq) afrag[m][kq] = ok ? *(const f32x4*)(ap + kq * 8) : zero4;
         }
     }
     const int dc = threadIdx.x & 31, doy = threadIdx.x >> 5;      // depthwise role: channel lane, output row
-    const int n_chunks = HAS_EXPAND ? a.ex_nt_total : 1;
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    const int n_chunks_all = HAS_EXPAND ? a.ex_nt_total : 1;
+    const int n_chunks = min(n_chunks_all, (a.cexp + 31) >> 5);   // skip all-padding column tiles
+
+    // ---- stage 1 of one chunk: expansion of the halo tile -> ET (channel-major)
+    auto stage1 = [&](int chunk) {
         const int ch0 = chunk * 32;
-        if (ch0 >= a.cexp) break;
-        // depthwise taps / BN of this thread's channel (registers)
-        const int dch = ch0 + dc;
-        const bool dact = dch < a.cexp;
-        float dwt[9], dsc = 0.f, dsh = 0.f;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) dwt[t] = dact ? a.Wdw[t * a.cexp + dch] : 0.f;
-        if (dact) { dsc = a.dw_scale[dch]; dsh = a.dw_shift[dch]; }
-        // projection weights of this chunk (issued now, consumed in stage 3)
-        const int kqc = min(4, (a.cexp - ch0) >> 3);
-        f32x4 pfrag[4][NTO];
-        if (wave < MT_OUT) {
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq)
-#pragma unroll
-                for (int nt = 0; nt < NTO; ++nt)
-                    pfrag[kq][nt] = kq < kqc ? a.Wpr[((size_t)(chunk * 4 + kq) * a.pr_nt_total + nt) * 64 + lane] : zero4;
-        }
-        // ---- stage 1
-        if (a.ablate & 1) {
-        } else if (HAS_EXPAND) {
+        if (HAS_EXPAND) {
             f32x4 bfrag[KQA];
 #pragma unroll
             for (int kq = 0; kq < KQA; ++kq) bfrag[kq] = a.Wex[((size_t)kq * a.ex_nt_total + chunk) * 64 + lane];
             const float sc = a.ex_scale[ch0 + r], sh = a.ex_shift[ch0 + r];
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
-                const int mt = wave + 4 * m;
-                if (mt >= MT_IN) break;
-                f32x16 acc;
+                if (m < mt_count) {
+                    const int mt = mt_first + m;
+                    f32x16 acc;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+                    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 #pragma unroll
-                for (int kq = 0; kq < KQA; ++kq)
+                    for (int kq = 0; kq < KQA; ++kq)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][kq][t], bfrag[kq][t], acc, 0, 0, 0);
+                        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][kq][t], bfrag[kq][t], acc, 0, 0, 0);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int pp = mt * 32 + 8 * q + 4 * half;
-                    f32x4 v;
+                    for (int q = 0; q < 4; ++q) {
+                        const int pp = mt * 32 + 8 * q + 4 * half;
+                        f32x4 v;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = relu6f(fmaf(acc[4 * q + i], sc, sh));
-                    if (!interior) {
-                        const int hy = pp / IWP, hx = pp - hy * IWP;     // 4 consecutive positions share the row
-                        const int iy = iy0 + hy;
-                        const bool rowin = iy >= 0 && iy < lv.H;
+                        for (int i = 0; i < 4; ++i) v[i] = relu6f(fmaf(acc[4 * q + i], sc, sh));
+                        if (!interior) {
+                            const int hy = pp / IWP, hx = pp - hy * IWP;     // 4 consecutive positions share the row
+                            const int iy = iy0 + hy;
+                            const bool rowin = iy >= 0 && iy < lv.H;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) { const int ix = ix0 + hx + i; if (!(rowin && ix >= 0 && ix < lv.W)) v[i] = 0.0f; }
+                            for (int i = 0; i < 4; ++i) { const int ix = ix0 + hx + i; if (!(rowin && ix >= 0 && ix < lv.W)) v[i] = 0.0f; }
+                        }
+                        *(f32x4*)(ET + r * EP + pp) = v;
                     }
-                    *(f32x4*)(ET + r * EP + pp) = v;
                 }
             }
         } else {
-            // no expansion conv (layer_2): the block input itself is the depthwise input
+            // no expansion conv: the block input itself is the depthwise input
             for (int idx = threadIdx.x; idx < NPOS * 8; idx += 256) {
                 const int pp = idx >> 3, c4 = idx & 7;
                 const int hy = pp / IWP, hx = pp - hy * IWP;
@@ -704,8 +698,29 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
                 for (int j = 0; j < 4; ++j) ET[(c4 * 4 + j) * EP + pp] = v[j];
             }
         }
-        __syncthreads();
-        // ---- stage 2: thread = (channel dc, output row doy)
+    };
+
+    if (!(a.ablate & 1)) stage1(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int ch0 = chunk * 32;
+        // depthwise taps / BN of this thread's channel and the projection weights of this chunk
+        const int dch = ch0 + dc;
+        const bool dact = dch < a.cexp;
+        float dwt[9], dsc = 0.f, dsh = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dwt[t] = dact ? a.Wdw[t * a.cexp + dch] : 0.f;
+        if (dact) { dsc = a.dw_scale[dch]; dsh = a.dw_shift[dch]; }
+        const int kqc = min(4, (a.cexp - ch0) >> 3);
+        f32x4 pfrag[4][NTO];
+        if (wave < MT_OUT) {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt)
+                    pfrag[kq][nt] = kq < kqc ? a.Wpr[((size_t)(chunk * 4 + kq) * a.pr_nt_total + nt) * 64 + lane] : zero4;
+        }
+        // ---- stage 2: thread = (channel dc, output row doy), ET -> D
         if (!(a.ablate & 2)) {
             float row[3][IWP];
 #pragma unroll
@@ -726,8 +741,8 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
                 D[(doy * TW + ox) * CEP + dc] = dact ? relu6f(fmaf(acc, dsc, dsh)) : 0.0f;
             }
         }
-        __syncthreads();
-        // ---- stage 3
+        __syncthreads();          // D complete, ET free
+        // ---- stage 3 of this chunk (reads D) and stage 1 of the next one (writes ET) share this phase
         if (wave < MT_OUT && !(a.ablate & 4)) {
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) {
@@ -740,7 +755,8 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
                 }
             }
         }
-        __syncthreads();
+        if (chunk + 1 < n_chunks && !(a.ablate & 1)) stage1(chunk + 1);
+        __syncthreads();          // ET complete, D free
     }
     if (wave < MT_OUT && !(a.ablate & 8)) {
 #pragma unroll

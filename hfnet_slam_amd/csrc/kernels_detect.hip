@@ -74,13 +74,60 @@ hipError_t launch_softmax_d2s(const float* logits, int ld, float* dense, const G
 #define NMS_T 32
 #define NMS_R 4
 #define NMS_S 56   // NMS_T + 6 * NMS_R
+
+// sliding 9-max over 16 consecutive values -> 8 outputs: out[i] = max(v[i..i+8]) as
+// max(suffix-max of v[i..7], prefix-max of v[8..i+8]): 22 max operations instead of 64
+__device__ __forceinline__ void max9_strip(const float (&v)[16], float (&o)[8]) {
+    float sfx[8], pfx[8];
+    sfx[7] = v[7];
+#pragma unroll
+    for (int i = 6; i >= 0; --i) sfx[i] = fmaxf(v[i], sfx[i + 1]);
+    pfx[0] = v[8];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) pfx[i] = fmaxf(pfx[i - 1], v[8 + i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = fmaxf(sfx[i], pfx[i]);
+}
+// row pass: in [ROWS][CIN] -> out [ROWS][CIN-8]; one work item = (row, strip of 8 outputs), 16-byte LDS accesses
+template <int ROWS, int CIN>
+__device__ __forceinline__ void nms_row_pass(const float* __restrict__ in, float* __restrict__ out) {
+    constexpr int COUT = CIN - 8, STRIPS = COUT / 8;
+    for (int w = threadIdx.x; w < ROWS * STRIPS; w += 256) {
+        const int row = w / STRIPS, st = w - row * STRIPS;
+        float v[16], o[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = *(const f32x4*)(in + row * CIN + st * 8 + q * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[q * 4 + j] = t[j];
+        }
+        max9_strip(v, o);
+        *(f32x4*)(out + row * COUT + st * 8) = (f32x4){o[0], o[1], o[2], o[3]};
+        *(f32x4*)(out + row * COUT + st * 8 + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+    }
+}
+// column pass: in [RIN][COLS] -> 8 pooled values per work item (col, strip of 8 output rows), handed to `emit`
+template <int RIN, int COLS, class F>
+__device__ __forceinline__ void nms_col_pass(const float* __restrict__ in, F emit) {
+    constexpr int STRIPS = (RIN - 8) / 8;
+    for (int w = threadIdx.x; w < COLS * STRIPS; w += 256) {
+        const int st = w / COLS, col = w - st * COLS;
+        float v[16], o[8];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = in[(st * 8 + i) * COLS + col];
+        max9_strip(v, o);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) emit(st * 8 + i, col, o[i]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_nms(const float* __restrict__ dense, float* __restrict__ nms, unsigned long long* __restrict__ cand,
                                              unsigned int* __restrict__ counters, long long cand_stride, float threshold, Geom g) {
-    __shared__ float s[NMS_S * NMS_S];
+    __shared__ __attribute__((aligned(16))) float s[NMS_S * NMS_S];
     __shared__ __attribute__((aligned(16))) float tmp[NMS_S * 48];
-    __shared__ float m0[48 * 48];
-    __shared__ float supp[40 * 40];
-    __shared__ float ss[40 * 40];
+    __shared__ __attribute__((aligned(16))) float m0[48 * 48];
+    __shared__ __attribute__((aligned(16))) float supp[40 * 40];
+    __shared__ __attribute__((aligned(16))) float ss[40 * 40];
     const int image = blockIdx.z, level = image / g.batch, frame = image - level * g.batch;
     const LevelGeom lv = g.lv[level];
     const int H = lv.H, W = lv.W;
@@ -94,51 +141,25 @@ __global__ __launch_bounds__(256) void k_nms(const float* __restrict__ dense, fl
         s[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[(long long)gy * W + gx] : NEG;
     }
     __syncthreads();
-    // pool 1 on the 48x48 region (offset 4 in s)
-    for (int i = threadIdx.x; i < NMS_S * 48; i += 256) {
-        const int ty = i / 48, tx = i - ty * 48;
-        float m = s[ty * NMS_S + tx];
-#pragma unroll
-        for (int d = 1; d <= 2 * NMS_R; ++d) m = fmaxf(m, s[ty * NMS_S + tx + d]);
-        tmp[i] = m;
-    }
+    // pool 1: 56x56 -> 48x48; m0 = (score == pooled) inside the image
+    nms_row_pass<NMS_S, NMS_S>(s, tmp);
     __syncthreads();
-    for (int i = threadIdx.x; i < 48 * 48; i += 256) {
-        const int ty = i / 48, tx = i - ty * 48;
-        float m = tmp[ty * 48 + tx];
-#pragma unroll
-        for (int d = 1; d <= 2 * NMS_R; ++d) m = fmaxf(m, tmp[(ty + d) * 48 + tx]);
+    nms_col_pass<NMS_S, 48>(tmp, [&](int ty, int tx, float m) {
         const float c = s[(ty + NMS_R) * NMS_S + tx + NMS_R];
-        m0[i] = (c != NEG && c == m) ? 1.0f : 0.0f;
-    }
+        m0[ty * 48 + tx] = (c != NEG && c == m) ? 1.0f : 0.0f;
+    });
     __syncthreads();
-    // pool 2 (of the mask) on the 40x40 region (offset 8 in s, 4 in m0)
-    for (int i = threadIdx.x; i < 48 * 40; i += 256) {
-        const int ty = i / 40, tx = i - ty * 40;
-        float m = m0[ty * 48 + tx];
-#pragma unroll
-        for (int d = 1; d <= 2 * NMS_R; ++d) m = fmaxf(m, m0[ty * 48 + tx + d]);
-        tmp[i] = m;
-    }
+    // pool 2 (of the mask): 48x48 -> 40x40; suppressed scores
+    nms_row_pass<48, 48>(m0, tmp);
     __syncthreads();
-    for (int i = threadIdx.x; i < 40 * 40; i += 256) {
-        const int ty = i / 40, tx = i - ty * 40;
-        float m = tmp[ty * 40 + tx];
-#pragma unroll
-        for (int d = 1; d <= 2 * NMS_R; ++d) m = fmaxf(m, tmp[(ty + d) * 40 + tx]);
+    nms_col_pass<48, 40>(tmp, [&](int ty, int tx, float m) {
         const float c = s[(ty + 2 * NMS_R) * NMS_S + tx + 2 * NMS_R];
-        supp[i] = m;
-        ss[i] = (c == NEG) ? NEG : (m != 0.0f ? 0.0f : c);
-    }
+        supp[ty * 40 + tx] = m;
+        ss[ty * 40 + tx] = (c == NEG) ? NEG : (m != 0.0f ? 0.0f : c);
+    });
     __syncthreads();
-    // pool 3 on the 32x32 tile (offset 12 in s, 4 in ss)
-    for (int i = threadIdx.x; i < 40 * 32; i += 256) {
-        const int ty = i / 32, tx = i - ty * 32;
-        float m = ss[ty * 40 + tx];
-#pragma unroll
-        for (int d = 1; d <= 2 * NMS_R; ++d) m = fmaxf(m, ss[ty * 40 + tx + d]);
-        tmp[i] = m;
-    }
+    // pool 3: 40x40 -> 32x32 (row pass into tmp, column pass below)
+    nms_row_pass<40, 40>(ss, tmp);
     __syncthreads();
     float* dst = nms + lv.out_off + (long long)frame * H * W;
     unsigned long long* cl = cand + (long long)image * cand_stride;
@@ -147,6 +168,7 @@ __global__ __launch_bounds__(256) void k_nms(const float* __restrict__ dense, fl
     unsigned long long* lkeys = (unsigned long long*)tmp;     // 1024 keys = 8 KB <= sizeof(tmp) (tmp is dead after pool 3)
     __shared__ unsigned int lcount, lbase;
     float ovals[4];
+    // pool 3's column pass is folded into the final per-pixel stage (9 LDS reads per output)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int i = threadIdx.x + it * 256;
