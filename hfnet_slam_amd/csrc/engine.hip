@@ -194,7 +194,16 @@ static int run_block(Net& n, int L, int n_used) {   // layer L = block L-2, inpu
     const BlockPack& b = e->w.blocks[L - 2];
     const long long p_in = n.pix[L - 1][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
     const long long p_out = n.pix[L][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
-    if (n.fuse_blocks && L <= n.fuse_max_layer && block_fusable(b)) {
+    // fused launch: always for the high-resolution layers; for the 30x47 layers only when the batch gives
+    // the launch enough workgroups to fill the chip (measured: 96 WGs lose to three launches, 384 win)
+    bool fuse = n.fuse_blocks && L <= n.fuse_max_layer && block_fusable(b);
+    if (fuse && L > 7) {
+        const LevelPlan& p0 = n.lp[0];
+        const int tw = b.stride == 1 ? 16 : 8;
+        const long long wgs = (long long)((p0.w[L] + tw - 1) / tw) * ((p0.h[L] + 7) / 8) * n.cfg.batch;
+        fuse = wgs >= 256;
+    }
+    if (fuse) {
         char fn[32];
         snprintf(fn, sizeof fn, "block_L%02d", L);
         const Geom gf = n.geom(L - 1, L, 0, n_used);

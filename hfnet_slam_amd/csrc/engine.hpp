@@ -62,7 +62,7 @@ struct Net {
     bool dense_valid = false;      // dense descriptor tensors match the last forward()
     int force_dense = 0;           // diagnostics / A-B: always run the dense descriptor head
     int fuse_blocks = 1;           // fused inverted-residual kernel for layers <= fuse_max_layer
-    int fuse_max_layer = 7;
+    int fuse_max_layer = 14;
     float *dense = nullptr, *nms = nullptr;
     unsigned long long* cand = nullptr;
     unsigned int* counters = nullptr;

@@ -375,8 +375,9 @@ static ConvArgs make_args(const float* A, const ConvPack& cp, const float* res, 
 // column tiles per wave: the packed layout allows any divisor of nt_total; small-M layers (the
 // 30x47 / 15x24 global branch) take fewer tiles per wave so that the launch still fills 256 CUs
 static int pick_nt(int nt_total, int nt_pref, long long m_tiles) {
+    static const int max_nt = []() { const char* v = getenv("HFNET_MAX_NT"); return v ? atoi(v) : 4; }();   // measured on MI355X: <= 4 column tiles per wave (higher occupancy) beats 8
     int best = 1;
-    for (int nt = 1; nt <= nt_pref && nt <= 8; ++nt) {
+    for (int nt = 1; nt <= nt_pref && nt <= max_nt; ++nt) {
         if (nt_total % nt) continue;
         if (m_tiles * (nt_total / nt) >= 2048 || nt == 1) best = nt;
     }
@@ -406,8 +407,11 @@ hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* res
 static hipError_t launch_conv3x3_any(const float* A, const ConvPack& cp, float* out, int relu6, const Geom& g, const TapArgs* ta,
                                      int max_rows, hipStream_t s) {
     const ConvArgs a = make_args(A, cp, nullptr, out, 0, relu6);
-    dim3 grid((max_rows + 127) / 128, cp.nt_total / cp.nt_per_block, g.n_levels * g.batch);
-    switch (cp.nt_per_block) {
+    int ntb = cp.nt_per_block;
+    if (!ta) { static const int t = []() { const char* v = getenv("HFNET_CONV3_NT"); return v ? atoi(v) : 0; }(); if (t > 0 && cp.nt_total % t == 0) ntb = t; }
+    if (ta) { static const int t = []() { const char* v = getenv("HFNET_TAPS_NT"); return v ? atoi(v) : 4; }(); if (t > 0 && cp.nt_total % t == 0) ntb = t; }
+    dim3 grid((max_rows + 127) / 128, cp.nt_total / ntb, g.n_levels * g.batch);
+    switch (ntb) {
         case 1: launch_c3_nt<1>(a, g, ta, grid, s); break;
         case 2: launch_c3_nt<2>(a, g, ta, grid, s); break;
         case 3: launch_c3_nt<3>(a, g, ta, grid, s); break;
@@ -593,21 +597,21 @@ __global__ __launch_bounds__(256, 2) void k_block_fused(FusedArgs a, Geom g) {
 //    16-byte LDS loads and slide along x in registers; the 9 taps + BN live in registers per chunk;
 //  * the block input (A fragments of every halo M-tile of the wave) is loaded once and stays in
 //    registers across chunks; the chunk's expand weights are loaded once per chunk, not per M-tile.
-template <int STRIDE, int NTO, int KQT, bool HAS_EXPAND>
+template <int STRIDE, int NTO, int KQT, bool HAS_EXPAND, int TW>
 __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
-    constexpr int TH = 8, TW = STRIDE == 1 ? 16 : 8;
+    constexpr int TH = 8;
     constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3, IWP = (IW + 3) / 4 * 4, NPOS = IH * IWP;
     constexpr int MT_IN = (NPOS + 31) / 32, OPIX = TH * TW, MT_OUT = OPIX / 32, CEP = 36;
     constexpr int EP = ((MT_IN * 32 / 4) % 2 == 1) ? MT_IN * 32 : MT_IN * 32 + 4;   // per-channel stride, EP/4 odd
     constexpr int NQ = IWP / 4;
     // halo M-tiles per wave.  Stage 3 of chunk c runs in the same barrier phase as stage 1 of chunk c+1
     // (see the loop), and only waves < MT_OUT have stage-3 work, so those waves own fewer halo tiles.
-    constexpr int MTC0 = STRIDE == 2 ? (KQT <= 2 ? 1 : 2) : 2;
-    constexpr int MTC1 = 2;
-    constexpr int MTC2 = STRIDE == 2 ? (KQT <= 2 ? 4 : 3) : 2;
+    constexpr int MTC0 = TW == 12 ? 3 : STRIDE == 2 ? (KQT <= 2 ? 1 : 2) : 2;
+    constexpr int MTC1 = TW == 12 ? 3 : 2;
+    constexpr int MTC2 = TW == 12 ? 4 : STRIDE == 2 ? (KQT <= 2 ? 4 : 3) : 2;
     constexpr int MTC3 = MT_IN - MTC0 - MTC1 - MTC2;
     constexpr int MTW = MTC3 > MTC2 ? MTC3 : MTC2;
-    static_assert(MTC3 >= 0 && MTW <= 4, "halo tile distribution");
+    static_assert(MTC3 >= 0 && MTW <= 5, "halo tile distribution");
     __shared__ __attribute__((aligned(16))) float ET[32 * EP];
     __shared__ __attribute__((aligned(16))) float D[OPIX * CEP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
@@ -624,6 +628,7 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
     const long long in_base = lv.in_off + (long long)frame * lv.H * lv.W;
     const long long out_base = lv.out_off + (long long)frame * lv.Ho * lv.Wo;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 pacc[NTO];
 #pragma unroll
     for (int nt = 0; nt < NTO; ++nt)
@@ -661,13 +666,12 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
             for (int m = 0; m < MTW; ++m) {
                 if (m < mt_count) {
                     const int mt = mt_first + m;
-                    f32x16 acc;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][0][0], bfrag[0][0], zero16, 0, 0, 0);
 #pragma unroll
                     for (int kq = 0; kq < KQA; ++kq)
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][kq][t], bfrag[kq][t], acc, 0, 0, 0);
+                        for (int t = 0; t < 4; ++t)
+                            if (kq + t > 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][kq][t], bfrag[kq][t], acc, 0, 0, 0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int pp = mt * 32 + 8 * q + 4 * half;
@@ -708,9 +712,15 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
         const int dch = ch0 + dc;
         const bool dact = dch < a.cexp;
         float dwt[9], dsc = 0.f, dsh = 0.f;
+        if (dact) {
+            const float* wdp = a.Wdw + dch;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) dwt[t] = dact ? a.Wdw[t * a.cexp + dch] : 0.f;
-        if (dact) { dsc = a.dw_scale[dch]; dsh = a.dw_shift[dch]; }
+            for (int t = 0; t < 9; ++t) dwt[t] = wdp[t * a.cexp];
+            dsc = a.dw_scale[dch]; dsh = a.dw_shift[dch];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) dwt[t] = 0.f;
+        }
         const int kqc = min(4, (a.cexp - ch0) >> 3);
         f32x4 pfrag[4][NTO];
         if (wave < MT_OUT) {
@@ -759,31 +769,39 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
         __syncthreads();          // ET complete, D free
     }
     if (wave < MT_OUT && !(a.ablate & 8)) {
+        float* obase = a.out + out_base * a.cout;                      // uniform
+        const float* rbase = a.X + in_base * a.cin;                    // uniform (residual: same spatial size, cin == cout)
+        const bool full = oy0 + TH <= lv.Ho && ox0 + TW <= lv.Wo;
+        // op = wave*32 + (reg&3) + 8*(reg>>2) + 4*half  ->  (oy, ox) with TW a power of two
+        const int opl = wave * 32 + 4 * half;
 #pragma unroll
         for (int nt = 0; nt < NTO; ++nt) {
             const int col = nt * 32 + r;
-            if (col >= a.cout) continue;
-            const float sc = a.pr_scale[col], sh = a.pr_shift[col];
+            if (col < a.cout) {
+                const float sc = a.pr_scale[col], sh = a.pr_shift[col];
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int op = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                const int oy = oy0 + op / TW, ox = ox0 + op % TW;
-                if (oy >= lv.Ho || ox >= lv.Wo) continue;
-                float v = fmaf(pacc[nt][reg], sc, sh);
-                if (a.residual) v = v + a.X[(in_base + (long long)oy * lv.W + ox) * a.cin + col];
-                a.out[(out_base + (long long)oy * lv.Wo + ox) * a.cout + col] = v;
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int op = opl + (reg & 3) + 8 * (reg >> 2);
+                    const int oy = oy0 + op / TW, ox = ox0 + op % TW;
+                    if (full || (oy < lv.Ho && ox < lv.Wo)) {
+                        const int off = (oy * lv.Wo + ox) * a.cout + col;
+                        float v = fmaf(pacc[nt][reg], sc, sh);
+                        if (a.residual) v = v + rbase[off];
+                        obase[off] = v;
+                    }
+                }
             }
         }
     }
 }
 
-template <int STRIDE, int NTO, int KQT, bool HAS_EXPAND>
+template <int STRIDE, int NTO, int KQT, bool HAS_EXPAND, int TW = (STRIDE == 1 ? 16 : 8)>
 static hipError_t launch_block_fused2_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
-    constexpr int TH = 8, TW = STRIDE == 1 ? 16 : 8;
+    constexpr int TH = 8;
     int maxtiles = 0;
     for (int l = 0; l < g.n_levels; ++l) maxtiles = max(maxtiles, ((g.lv[l].Wo + TW - 1) / TW) * ((g.lv[l].Ho + TH - 1) / TH));
     dim3 grid(maxtiles, g.n_levels * g.batch);
-    hipLaunchKernelGGL((k_block_fused2<STRIDE, NTO, KQT, HAS_EXPAND>), grid, dim3(256), 0, s, a, g);
+    hipLaunchKernelGGL((k_block_fused2<STRIDE, NTO, KQT, HAS_EXPAND, TW>), grid, dim3(256), 0, s, a, g);
     return hipGetLastError();
 }
 
@@ -868,6 +886,7 @@ bool block_fusable(const BlockPack& b) {
     const int nto = (b.cout + 31) / 32;
     if (nto > 3 || (b.stride != 1 && b.stride != 2)) return false;
     if (!b.has_expand && b.expand > 32) return false;
+    if (b.stride == 2 && b.cin > 24) return false;   // no register-resident variant: the three-launch path is faster (layer_8)
     return b.cin % 8 == 0 && b.expand % 8 == 0;
 }
 
@@ -890,6 +909,9 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
     if (use_v2) {
         const int kq = b.cin / 8, st = b.stride;
         if (!b.has_expand && st == 1 && nto == 1) return launch_block_fused2_t<1, 1, 0, false>(a, g, s);
+        static const int tw2 = []() { const char* v = getenv("HFNET_FUSE_S2_TW"); return v ? atoi(v) : 12; }();
+        if (b.has_expand && st == 2 && kq == 2 && nto == 1 && tw2 == 12) return launch_block_fused2_t<2, 1, 2, true, 12>(a, g, s);
+        if (b.has_expand && st == 2 && kq == 3 && nto == 1 && tw2 == 12) return launch_block_fused2_t<2, 1, 3, true, 12>(a, g, s);
         if (b.has_expand && st == 2 && kq == 2 && nto == 1) return launch_block_fused2_t<2, 1, 2, true>(a, g, s);
         if (b.has_expand && st == 1 && kq == 3 && nto == 1) return launch_block_fused2_t<1, 1, 3, true>(a, g, s);
         if (b.has_expand && st == 2 && kq == 3 && nto == 1) return launch_block_fused2_t<2, 1, 3, true>(a, g, s);
