@@ -90,6 +90,7 @@ int Net::build(Engine* eng, const NetConfig& c) {
     if (const char* v = getenv("HFNET_FUSE_BLOCKS")) fuse_blocks = atoi(v);
     if (const char* v = getenv("HFNET_FUSE_MAX_LAYER")) fuse_max_layer = atoi(v);
     if (const char* v = getenv("HFNET_DENSE_DESC")) force_dense = atoi(v);
+    if (const char* v = getenv("HFNET_FUSE_STEM")) fuse_stem = atoi(v);
     const DeviceWeights& w = e->w;
     if (c.n_levels < 1 || c.n_levels > HFNET_MAX_LEVELS || c.batch < 1) { set_error("net: bad level / batch count"); return HFNET_ERR_INVALID_ARG; }
     if (c.from_intermediate && (c.n_levels != 1 || !c.global)) { set_error("net: intermediate input needs one level and the global head"); return HFNET_ERR_INVALID_ARG; }
@@ -231,8 +232,16 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
     const int NL = cfg.n_levels;
     if (!cfg.from_intermediate) {
         const Geom gs = geom(0, 1, 0, NL);
-        HF_LAUNCH(e, stream, "stem", launch_stem(imgs, w.stem_w, w.stem_scale, w.stem_shift, w.stem_out, act[1], gs, stream));
-        for (int L = 2; L <= 7; ++L) HF_TRY(run_block(*this, L, NL));
+        int first = 2;
+        if (fuse_stem && fuse_blocks && stem_block_fusable(w.stem_out, w.blocks[0])) {
+            // stem + layer_2 in one launch; the stem tensor (act[1]) is not materialised
+            HF_LAUNCH(e, stream, "stem_block_L02", launch_stem_block(imgs, w.stem_w, w.stem_scale, w.stem_shift, w.blocks[0], act[2], gs,
+                                                                   geom(1, 2, 0, NL), stream));
+            first = 3;
+        } else {
+            HF_LAUNCH(e, stream, "stem", launch_stem(imgs, w.stem_w, w.stem_scale, w.stem_shift, w.stem_out, act[1], gs, stream));
+        }
+        for (int L = first; L <= 7; ++L) HF_TRY(run_block(*this, L, NL));
     }
     if (cfg.local) {
         const long long pc = pix_cell[HFNET_MAX_LEVELS];
@@ -592,6 +601,7 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
     }
     NetConfig c;
     c.n_levels = n_levels; c.batch = max_batch; c.local = true; c.global = true; c.from_intermediate = false;
+    x->net.fuse_stem = 0;   // stem + layer_2 fusion exists (HFNET_FUSE_STEM=1) but measured slower than two launches: off
     c.max_keypoints = 1;
     for (int l = 0; l < n_levels; ++l) { c.width[l] = x->level_w[l]; c.height[l] = x->level_h[l]; c.max_keypoints = std::max(c.max_keypoints, x->features_per_level[l]); }
     HF_TRY(x->net.build(&e->impl, c));

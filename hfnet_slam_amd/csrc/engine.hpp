@@ -63,6 +63,7 @@ struct Net {
     int force_dense = 0;           // diagnostics / A-B: always run the dense descriptor head
     int fuse_blocks = 1;           // fused inverted-residual kernel for layers <= fuse_max_layer
     int fuse_max_layer = 14;
+    int fuse_stem = 0;             // stem + layer_2 in one launch (the layer_1 tap is then unavailable)
     float *dense = nullptr, *nms = nullptr;
     unsigned long long* cand = nullptr;
     unsigned int* counters = nullptr;

@@ -30,6 +30,10 @@ hipError_t launch_depthwise(const float* in, const DwPack& dp, int stride, float
 // tensor lives in LDS only.  block_fusable(): project width <= 96 columns.
 bool block_fusable(const BlockPack& b);
 hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, const Geom& g, hipStream_t s);
+// stem conv + layer_2 (no-expansion block) in one launch: the stem tensor stays in LDS
+bool stem_block_fusable(int stem_out, const BlockPack& b);
+hipError_t launch_stem_block(const ImageSet& imgs, const float* stem_w, const float* stem_scale, const float* stem_shift, const BlockPack& b,
+                             float* out, const Geom& g_stem, const Geom& g_block, hipStream_t s);
 // channel-order conversion between the device layout and NHWC logical order (boundary tensors)
 hipError_t launch_permute_channels(const float* in, float* out, long long P, int C, int to_logical, hipStream_t s);
 

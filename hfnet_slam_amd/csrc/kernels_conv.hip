@@ -811,33 +811,42 @@ static hipError_t launch_block_fused2_t(const FusedArgs& a, const Geom& g, hipSt
 // the vector ALUs, projection weights in LDS (wave-uniform reads), the fma chain over the CIN depthwise
 // outputs in logical channel order (the oracle's), 16-byte fully coalesced loads and stores.  HBM-bound.
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void k_block_noexpand(FusedArgs a, const float* __restrict__ wproj_logical, Geom g) {
-    __shared__ float wp[CIN * COUT];     // [k logical][n physical]
-    __shared__ float wd[9 * CIN];        // [tap][c physical]
-    __shared__ float dsc[CIN], dsh[CIN], psc[COUT], psh[COUT];
-    for (int i = threadIdx.x; i < CIN * COUT; i += 256) wp[i] = wproj_logical[i];
-    for (int i = threadIdx.x; i < 9 * CIN; i += 256) wd[i] = a.Wdw[i];
-    if (threadIdx.x < CIN) { dsc[threadIdx.x] = a.dw_scale[threadIdx.x]; dsh[threadIdx.x] = a.dw_shift[threadIdx.x]; }
-    if (threadIdx.x < COUT) { psc[threadIdx.x] = a.pr_scale[threadIdx.x]; psh[threadIdx.x] = a.pr_shift[threadIdx.x]; }
-    __syncthreads();
+__global__ __launch_bounds__(256) void k_block_noexpand(const float* __restrict__ X, float* __restrict__ out,
+                                                        const float* __restrict__ wd /*[9][CIN] phys*/, const float* __restrict__ dsc,
+                                                        const float* __restrict__ dsh, const float* __restrict__ wp /*[CIN logical][COUT phys]*/,
+                                                        const float* __restrict__ psc, const float* __restrict__ psh, Geom g) {
+    // 16x16 output tile per workgroup; the 18x18 input halo tile is staged through LDS with coalesced 96-byte
+    // pixel rows, so every input byte crosses HBM ~1.27x instead of up to 9x.  Weight indices are compile-time
+    // constants: those loads are wave-uniform and go through the scalar cache into SGPR fma operands.
+    constexpr int T = 16, SH = T + 2, CP = CIN + 4;
+    __shared__ __attribute__((aligned(16))) float tile[SH * SH * CP];
     const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
     const LevelGeom lv = g.lv[level];
-    const int op = blockIdx.x * 256 + threadIdx.x;
-    if (op >= lv.Ho * lv.Wo) return;
-    const int oy = op / lv.Wo, ox = op - oy * lv.Wo;
-    const float* xin = a.X + (lv.in_off + (long long)frame * lv.H * lv.W) * CIN;
+    const int tiles_x = (lv.Wo + T - 1) / T;
+    if ((int)blockIdx.x >= tiles_x * ((lv.Ho + T - 1) / T)) return;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int oy0 = tyi * T, ox0 = txi * T;
+    const float* xin = X + (lv.in_off + (long long)frame * lv.H * lv.W) * CIN;
+    for (int i = threadIdx.x; i < SH * SH * (CIN / 4); i += 256) {
+        const int p = i / (CIN / 4), c4 = i - p * (CIN / 4);
+        const int hy = p / SH, hx = p - hy * SH;
+        const int iy = oy0 - lv.pt + hy, ix = ox0 - lv.pl + hx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W) v = *(const f32x4*)(xin + (long long)(iy * lv.W + ix) * CIN + c4 * 4);
+        *(f32x4*)(tile + p * CP + c4 * 4) = v;
+    }
+    __syncthreads();
+    const int ty = threadIdx.x / T, tx = threadIdx.x - ty * T;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy >= lv.Ho || ox >= lv.Wo) return;
     float d[CIN];
 #pragma unroll
     for (int c = 0; c < CIN; ++c) d[c] = 0.0f;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy - lv.pt + ky;
-        if (iy < 0 || iy >= lv.H) continue;
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox - lv.pl + kx;
-            if (ix < 0 || ix >= lv.W) continue;
-            const float* xp = xin + (long long)(iy * lv.W + ix) * CIN;
+        for (int kx = 0; kx < 3; ++kx) {                   // out-of-image taps are zeros in the tile: fma(0, w, d) == d
+            const float* xp = tile + ((ty + ky) * SH + tx + kx) * CP;
 #pragma unroll
             for (int c4 = 0; c4 < CIN / 4; ++c4) {
                 const f32x4 xv = *(const f32x4*)(xp + c4 * 4);
@@ -845,7 +854,6 @@ __global__ __launch_bounds__(256) void k_block_noexpand(FusedArgs a, const float
                 for (int j = 0; j < 4; ++j) d[c4 * 4 + j] = fmaf(xv[j], wd[(ky * 3 + kx) * CIN + c4 * 4 + j], d[c4 * 4 + j]);
             }
         }
-    }
 #pragma unroll
     for (int c = 0; c < CIN; ++c) d[c] = relu6f(fmaf(d[c], dsc[c], dsh[c]));
     float acc[COUT];
@@ -858,7 +866,7 @@ __global__ __launch_bounds__(256) void k_block_noexpand(FusedArgs a, const float
 #pragma unroll
         for (int n = 0; n < COUT; ++n) acc[n] = fmaf(dk, wp[k * COUT + n], acc[n]);
     }
-    float* o = a.out + (lv.out_off + (long long)frame * lv.Ho * lv.Wo + op) * COUT;
+    float* o = out + (lv.out_off + (long long)frame * lv.Ho * lv.Wo + (long long)oy * lv.Wo + ox) * COUT;
 #pragma unroll
     for (int n4 = 0; n4 < COUT / 4; ++n4) {
         f32x4 v;
@@ -866,6 +874,134 @@ __global__ __launch_bounds__(256) void k_block_noexpand(FusedArgs a, const float
         for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[n4 * 4 + j], psc[n4 * 4 + j], psh[n4 * 4 + j]);
         *(f32x4*)(o + n4 * 4) = v;
     }
+}
+
+// ---- stem + layer_2 in one launch: u8 image -> [(x-128)/128, conv 3x3/2 1->CS, BN, ReLU6] -> depthwise 3x3 +
+// BN + ReLU6 -> 1x1 CS->COUT + BN.  The half-resolution CS-channel stem tensor (the largest activation of the
+// network: 8.7 MB per 752x480 frame) is produced into LDS for an 18x18 halo tile and consumed from there; only
+// the u8 image is read and the COUT-channel layer_2 output written.  Vector-ALU kernel (K = 9 / 9 / CS), one
+// thread per output pixel of a 16x16 tile; every fma chain is the oracle's.
+struct StemBlockArgs {
+    const float* stem_w; const float* stem_scale; const float* stem_shift;      // [9][CS] physical order
+    const float* dw_w; const float* dw_scale; const float* dw_shift;            // [9][CS] physical
+    const float* pr_w; const float* pr_scale; const float* pr_shift;            // [CS logical][COUT physical]
+    float* out;
+};
+
+template <int CS, int COUT>
+__global__ __launch_bounds__(256) void k_stem_block(ImageSet imgs, StemBlockArgs a, Geom gs /*image -> stem*/, Geom gb /*stem -> layer_2*/) {
+    constexpr int T = 16, SH = T + 2, SP = SH * SH, IP = 2 * SH + 1, CSP = CS + 4;
+    __shared__ __attribute__((aligned(16))) float patch[IP * IP];
+    __shared__ __attribute__((aligned(16))) float st[SP * CSP];
+    __shared__ __attribute__((aligned(16))) float w_stem[9 * CS], w_dw[9 * CS], w_pr[CS * COUT];
+    __shared__ __attribute__((aligned(16))) float sc_stem[CS], sh_stem[CS], sc_dw[CS], sh_dw[CS], sc_pr[COUT], sh_pr[COUT];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 9 * CS; i += 256) { w_stem[i] = a.stem_w[i]; w_dw[i] = a.dw_w[i]; }
+    for (int i = tid; i < CS * COUT; i += 256) w_pr[i] = a.pr_w[i];
+    if (tid < CS) { sc_stem[tid] = a.stem_scale[tid]; sh_stem[tid] = a.stem_shift[tid]; sc_dw[tid] = a.dw_scale[tid]; sh_dw[tid] = a.dw_shift[tid]; }
+    if (tid < COUT) { sc_pr[tid] = a.pr_scale[tid]; sh_pr[tid] = a.pr_shift[tid]; }
+    const int image = blockIdx.y, level = image / gs.batch, frame = image - level * gs.batch;
+    const LevelGeom ls = gs.lv[level], lb = gb.lv[level];     // ls: H,W image (cropped), Ho,Wo stem; lb: H,W stem, Ho,Wo out (same size)
+    const int tiles_x = (lb.Wo + T - 1) / T;
+    if ((int)blockIdx.x >= tiles_x * ((lb.Ho + T - 1) / T)) return;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int oy0 = tyi * T, ox0 = txi * T;
+    const int sy0 = oy0 - lb.pt, sx0 = ox0 - lb.pl;            // first stem row / col of the halo tile
+    const int iy0 = sy0 * 2 - ls.pt, ix0 = sx0 * 2 - ls.pl;    // first image row / col of the patch
+    const uint8_t* img = imgs.ptr[level] + (long long)frame * imgs.frame_stride[level];
+    const int rs = imgs.row_stride[level];
+    for (int i = tid; i < IP * IP; i += 256) {
+        const int py = i / IP, px = i - py * IP;
+        const int iy = iy0 + py, ix = ix0 + px;
+        patch[i] = (iy >= 0 && iy < ls.H && ix >= 0 && ix < ls.W) ? ((float)img[(long long)iy * rs + ix] - 128.0f) * 0.0078125f : 0.0f;
+    }
+    __syncthreads();
+    // stem conv on the SH x SH halo tile (positions outside the stem map are the depthwise conv's zero padding)
+    for (int p = tid; p < SP; p += 256) {
+        const int hy = p / SH, hx = p - hy * SH;
+        const int sy = sy0 + hy, sx = sx0 + hx;
+        const bool in = sy >= 0 && sy < ls.Ho && sx >= 0 && sx < ls.Wo;
+        float px[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) px[ky * 3 + kx] = patch[(2 * hy + ky) * IP + 2 * hx + kx];
+#pragma unroll
+        for (int c4 = 0; c4 < CS / 4; ++c4) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const f32x4 wv = *(const f32x4*)(w_stem + t * CS + c4 * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(px[t], wv[j], acc[j]);
+            }
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = in ? relu6f(fmaf(acc[j], sc_stem[c4 * 4 + j], sh_stem[c4 * 4 + j])) : 0.0f;
+            *(f32x4*)(st + p * CSP + c4 * 4) = o;
+        }
+    }
+    __syncthreads();
+    const int ty = tid / T, tx = tid - ty * T;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy >= lb.Ho || ox >= lb.Wo) return;
+    float d[CS];
+#pragma unroll
+    for (int c = 0; c < CS; ++c) d[c] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float* sp = st + ((ty + ky) * SH + tx + kx) * CSP;
+#pragma unroll
+            for (int c4 = 0; c4 < CS / 4; ++c4) {
+                const f32x4 xv = *(const f32x4*)(sp + c4 * 4);
+                const f32x4 wv = *(const f32x4*)(w_dw + (ky * 3 + kx) * CS + c4 * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[c4 * 4 + j] = fmaf(xv[j], wv[j], d[c4 * 4 + j]);
+            }
+        }
+#pragma unroll
+    for (int c = 0; c < CS; ++c) d[c] = relu6f(fmaf(d[c], sc_dw[c], sh_dw[c]));
+    float acc[COUT];
+#pragma unroll
+    for (int n = 0; n < COUT; ++n) acc[n] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < CS; ++k) {
+        const int pk = (k & ~7) | ((k & 1) << 2) | ((k & 7) >> 1);
+        const float dk = d[pk];
+#pragma unroll
+        for (int n4 = 0; n4 < COUT / 4; ++n4) {
+            const f32x4 wv = *(const f32x4*)(w_pr + k * COUT + n4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[n4 * 4 + j] = fmaf(dk, wv[j], acc[n4 * 4 + j]);
+        }
+    }
+    float* o = a.out + (lb.out_off + (long long)frame * lb.Ho * lb.Wo + (long long)oy * lb.Wo + ox) * COUT;
+#pragma unroll
+    for (int n4 = 0; n4 < COUT / 4; ++n4) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[n4 * 4 + j], sc_pr[n4 * 4 + j], sh_pr[n4 * 4 + j]);
+        *(f32x4*)(o + n4 * 4) = v;
+    }
+}
+
+bool stem_block_fusable(int stem_out, const BlockPack& b) {
+    return stem_out == 24 && !b.has_expand && b.stride == 1 && !b.residual && b.cin == 24 && b.cout == 16 && b.pr_logical != nullptr;
+}
+
+hipError_t launch_stem_block(const ImageSet& imgs, const float* stem_w, const float* stem_scale, const float* stem_shift, const BlockPack& b,
+                             float* out, const Geom& g_stem, const Geom& g_block, hipStream_t s) {
+    StemBlockArgs a;
+    a.stem_w = stem_w; a.stem_scale = stem_scale; a.stem_shift = stem_shift;
+    a.dw_w = b.dw.w; a.dw_scale = b.dw.scale; a.dw_shift = b.dw.shift;
+    a.pr_w = b.pr_logical; a.pr_scale = b.pr.scale; a.pr_shift = b.pr.shift;
+    a.out = out;
+    int maxtiles = 0;
+    for (int l = 0; l < g_block.n_levels; ++l) maxtiles = max(maxtiles, ((g_block.lv[l].Wo + 15) / 16) * ((g_block.lv[l].Ho + 15) / 16));
+    hipLaunchKernelGGL((k_stem_block<24, 16>), dim3(maxtiles, g_block.n_levels * g_block.batch), dim3(256), 0, s, imgs, a, g_stem, g_block);
+    return hipGetLastError();
 }
 
 template <int STRIDE, int TH, int TW>
@@ -901,9 +1037,10 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
     const int nto = (b.cout + 31) / 32;
     static const bool use_v2 = []() { const char* v = getenv("HFNET_FUSE_V2"); return v ? atoi(v) != 0 : true; }();
     if (use_v2 && !b.has_expand && b.stride == 1 && !b.residual && b.cin == 24 && b.cout == 16 && b.pr_logical) {
-        int maxpix = 0;
-        for (int l = 0; l < g.n_levels; ++l) maxpix = max(maxpix, g.lv[l].Ho * g.lv[l].Wo);
-        hipLaunchKernelGGL((k_block_noexpand<24, 16>), dim3((maxpix + 255) / 256, g.n_levels * g.batch), dim3(256), 0, s, a, b.pr_logical, g);
+        int maxtiles = 0;
+        for (int l = 0; l < g.n_levels; ++l) maxtiles = max(maxtiles, ((g.lv[l].Wo + 15) / 16) * ((g.lv[l].Ho + 15) / 16));
+        hipLaunchKernelGGL((k_block_noexpand<24, 16>), dim3(maxtiles, g.n_levels * g.batch), dim3(256), 0, s, a.X, a.out, a.Wdw, a.dw_scale,
+                           a.dw_shift, (const float*)b.pr_logical, a.pr_scale, a.pr_shift, g);
         return hipGetLastError();
     }
     if (use_v2) {

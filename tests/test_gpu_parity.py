@@ -143,9 +143,11 @@ def test_response_ties(weights_ties_path):
     m.close(); e.close()
 
 
+@pytest.mark.parametrize("fuse_stem", ["0", "1"])
 @pytest.mark.parametrize("cfg", [(160, 120, 300, 3), (200, 152, 500, 4), (96, 96, 64, 1)])
-def test_extractor_matches_oracle(engine, oracle_model, cfg):
+def test_extractor_matches_oracle(engine, oracle_model, cfg, fuse_stem, monkeypatch):
     from hfnet_slam_amd import capi
+    monkeypatch.setenv("HFNET_FUSE_STEM", fuse_stem)
     w, h, nf, nl = cfg
     x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, nl, max_batch=2)
     sf, fpl, lw, lh = x.tables()
