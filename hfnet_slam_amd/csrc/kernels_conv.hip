@@ -600,17 +600,18 @@ __global__ __launch_bounds__(256, 2) void k_block_fused(FusedArgs a, Geom g) {
 template <int STRIDE, int NTO, int KQT, bool HAS_EXPAND, int TW>
 __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
     constexpr int TH = 8;
-    constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3, IWP = (IW + 3) / 4 * 4, NPOS = IH * IWP;
+    // halo rows are stored back to back; an even row length keeps the depthwise stage's row reads 8-byte
+    // aligned (stride 1: 18, no padding; stride 2: odd widths are padded to a multiple of 4)
+    constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3, IWP = (IW % 2 == 0) ? IW : (IW + 3) / 4 * 4, NPOS = IH * IWP;
     constexpr int MT_IN = (NPOS + 31) / 32, OPIX = TH * TW, MT_OUT = OPIX / 32, CEP = 36;
     constexpr int EP = ((MT_IN * 32 / 4) % 2 == 1) ? MT_IN * 32 : MT_IN * 32 + 4;   // per-channel stride, EP/4 odd
-    constexpr int NQ = IWP / 4;
     // halo M-tiles per wave.  Stage 3 of chunk c runs in the same barrier phase as stage 1 of chunk c+1
     // (see the loop), and only waves < MT_OUT have stage-3 work, so those waves own fewer halo tiles.
     constexpr int MTC0 = TW == 12 ? 3 : STRIDE == 2 ? (KQT <= 2 ? 1 : 2) : 2;
     constexpr int MTC1 = TW == 12 ? 3 : 2;
-    constexpr int MTC2 = TW == 12 ? 4 : STRIDE == 2 ? (KQT <= 2 ? 4 : 3) : 2;
+    constexpr int MTC2 = TW == 12 ? 4 : STRIDE == 2 ? (KQT <= 2 ? 4 : 3) : (MT_IN >= 7 ? 2 : 1);
     constexpr int MTC3 = MT_IN - MTC0 - MTC1 - MTC2;
-    constexpr int MTW = MTC3 > MTC2 ? MTC3 : MTC2;
+    constexpr int MTWa = MTC0 > MTC1 ? MTC0 : MTC1, MTWb = MTC2 > MTC3 ? MTC2 : MTC3, MTW = MTWa > MTWb ? MTWa : MTWb;
     static_assert(MTC3 >= 0 && MTW <= 5, "halo tile distribution");
     __shared__ __attribute__((aligned(16))) float ET[32 * EP];
     __shared__ __attribute__((aligned(16))) float D[OPIX * CEP];
@@ -678,14 +679,7 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
                         f32x4 v;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = relu6f(fmaf(acc[4 * q + i], sc, sh));
-                        if (!interior) {
-                            const int hy = pp / IWP, hx = pp - hy * IWP;     // 4 consecutive positions share the row
-                            const int iy = iy0 + hy;
-                            const bool rowin = iy >= 0 && iy < lv.H;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) { const int ix = ix0 + hx + i; if (!(rowin && ix >= 0 && ix < lv.W)) v[i] = 0.0f; }
-                        }
-                        *(f32x4*)(ET + r * EP + pp) = v;
+                        *(f32x4*)(ET + r * EP + pp) = v;        // border tiles: out-of-image positions are zeroed by zero_border()
                     }
                 }
             }
@@ -704,7 +698,21 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
         }
     };
 
+    // tiles that touch the image border: the expansion of an out-of-image halo position must be 0 (the
+    // depthwise conv's 'SAME' padding), not relu6(shift).  Kept out of the MFMA epilogue: one extra pass + barrier,
+    // executed only by border workgroups.
+    auto zero_border = [&]() {
+        __syncthreads();
+        for (int pp = threadIdx.x; pp < NPOS; pp += 256) {
+            const int hy = pp / IWP, hx = pp - hy * IWP;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            if (iy < 0 || iy >= lv.H || ix < 0 || ix >= lv.W)
+                for (int c = 0; c < 32; ++c) ET[c * EP + pp] = 0.0f;
+        }
+    };
+
     if (!(a.ablate & 1)) stage1(0);
+    if (HAS_EXPAND && !interior) zero_border();
     __syncthreads();
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const int ch0 = chunk * 32;
@@ -734,13 +742,23 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
         if (!(a.ablate & 2)) {
             float row[3][IWP];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* rp = ET + dc * EP + (doy * STRIDE + ky) * IWP;
+                if constexpr (IWP % 4 == 0) {
 #pragma unroll
-                for (int qx = 0; qx < NQ; ++qx) {
-                    const f32x4 v = *(const f32x4*)(ET + dc * EP + (doy * STRIDE + ky) * IWP + qx * 4);
+                    for (int qx = 0; qx < IWP / 4; ++qx) {
+                        const f32x4 v = *(const f32x4*)(rp + qx * 4);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) row[ky][qx * 4 + j] = v[j];
+                        for (int j = 0; j < 4; ++j) row[ky][qx * 4 + j] = v[j];
+                    }
+                } else {
+#pragma unroll
+                    for (int qx = 0; qx < IWP / 2; ++qx) {
+                        const float2 v = *(const float2*)(rp + qx * 2);
+                        row[ky][qx * 2] = v.x; row[ky][qx * 2 + 1] = v.y;
+                    }
                 }
+            }
 #pragma unroll
             for (int ox = 0; ox < TW; ++ox) {
                 float acc = 0.0f;
@@ -765,7 +783,10 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
                 }
             }
         }
-        if (chunk + 1 < n_chunks && !(a.ablate & 1)) stage1(chunk + 1);
+        if (chunk + 1 < n_chunks && !(a.ablate & 1)) {
+            stage1(chunk + 1);
+            if (HAS_EXPAND && !interior) zero_border();
+        }
         __syncthreads();          // ET complete, D free
     }
     if (wave < MT_OUT && !(a.ablate & 8)) {
