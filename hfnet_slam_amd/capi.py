@@ -27,7 +27,7 @@ SYMBOLS = [
     "hfnet_model_detect", "hfnet_model_detect_global", "hfnet_model_tap",
     "hfnet_extractor_create", "hfnet_extractor_destroy", "hfnet_extractor_tables",
     "hfnet_extractor_extract", "hfnet_extractor_extract_batch",
-    "hfnet_descriptor_distance", "hfnet_match_search_by_bow", "hfnet_match_search_for_triangulation",
+    "hfnet_descriptor_distance", "hfnet_resampler", "hfnet_match_search_by_bow", "hfnet_match_search_for_triangulation",
     "hfnet_db_create", "hfnet_db_destroy", "hfnet_db_add", "hfnet_db_erase", "hfnet_db_clear", "hfnet_db_query",
     "hfnet_profile_enable", "hfnet_profile_reset", "hfnet_profile_filter", "hfnet_profile_count", "hfnet_profile_get",
 ]
@@ -120,6 +120,14 @@ class Engine:
         _chk(lib().hfnet_match_search_for_triangulation(self.h, _p(d1), d1.shape[0], _p(d2), d2.shape[0], dim,
                                                         C.c_float(th_high), _p(match), C.byref(n), 0))
         return n.value, match
+
+    def resampler(self, data, warp):
+        """Resampler(data [B,H,W,C], warp [B,N,2]) -> [B,N,C]  (BaseModel.cc:491-562)"""
+        d = np.ascontiguousarray(data, np.float32); w = np.ascontiguousarray(warp, np.float32)
+        b, dh, dw, c = d.shape
+        out = np.zeros((b, w.shape[1], c), np.float32)
+        _chk(lib().hfnet_resampler(self.h, _p(d), _p(w), _p(out), b, dh, dw, c, w.shape[1]))
+        return out
 
     # ---- profiling -------------------------------------------------------------------------
     def profile_enable(self, on: bool):

@@ -830,6 +830,27 @@ int hfnet_match_search_for_triangulation(hfnet_engine* eh, const float* d1, int 
     return HFNET_OK;
 }
 
+int hfnet_resampler(hfnet_engine* eh, const float* data, const float* warp, float* output, int batch_size, int data_height, int data_width,
+                    int data_channels, int num_sampling_points) {
+    API_GUARD(eh, "engine"); API_GUARD(data, "data"); API_GUARD(output, "output");
+    if (batch_size < 0 || data_height <= 0 || data_width <= 0 || data_channels <= 0 || num_sampling_points < 0) { set_error("resampler: bad sizes"); return HFNET_ERR_INVALID_ARG; }
+    if (batch_size == 0 || num_sampling_points == 0) return HFNET_OK;
+    API_GUARD(warp, "warp");
+    Engine& e = eh->impl;
+    std::lock_guard<std::mutex> lk(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    const size_t nd = (size_t)batch_size * data_height * data_width * data_channels, nw = (size_t)batch_size * num_sampling_points * 2;
+    const size_t no = (size_t)batch_size * num_sampling_points * data_channels;
+    HF_TRY(e.m_s.ensure(nd * sizeof(float))); HF_TRY(e.m_a.ensure(nw * sizeof(float))); HF_TRY(e.m_b.ensure(no * sizeof(float)));
+    HF_HIP(hipMemcpyAsync(e.m_s.p, data, nd * sizeof(float), hipMemcpyHostToDevice, e.stream));
+    HF_HIP(hipMemcpyAsync(e.m_a.p, warp, nw * sizeof(float), hipMemcpyHostToDevice, e.stream));
+    HF_LAUNCH(&e, e.stream, "resampler", launch_resampler(e.m_s.as<float>(), e.m_a.as<float>(), e.m_b.as<float>(), batch_size, data_height, data_width,
+                                                         data_channels, num_sampling_points, e.stream));
+    HF_HIP(hipMemcpyAsync(output, e.m_b.p, no * sizeof(float), hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));
+    return HFNET_OK;
+}
+
 // ---------------------------------------------------------------------------------------- KeyFrameDatabase
 int hfnet_db_create(hfnet_engine* eh, int capacity, int dim, hfnet_db** out) {
     API_GUARD(out, "out");

@@ -272,4 +272,20 @@ inline bool InitAllModels(ModelSet& set, const std::string& strModelPath, int wi
     return true;
 }
 
+// GetModelVec / GetGlobalModel (BaseModel.cc:95-113).  No separate global model with this backend (level 0 returns the
+// global descriptor itself, as with TensorRT: BaseModel.cc:78-81), so GetGlobalModel is nullptr.
+inline std::vector<BaseModel*> GetModelVec(const ModelSet& set) {
+    std::vector<BaseModel*> v;
+    for (const auto& m : set.models) v.push_back(m.get());
+    return v;
+}
+inline BaseModel* GetGlobalModel(const ModelSet&) { return nullptr; }
+
+// Resampler (BaseModel.h:78-80)
+inline void Resampler(const ModelSet& set, const float* data, const float* warp, float* output, const int batch_size, const int data_height,
+                      const int data_width, const int data_channels, const int num_sampling_points) {
+    if (hfnet_resampler(set.engine->h, data, warp, output, batch_size, data_height, data_width, data_channels, num_sampling_points) != HFNET_OK)
+        std::fprintf(stderr, "%s\n", hfnet_last_error());
+}
+
 }  // namespace HFNET_HIP

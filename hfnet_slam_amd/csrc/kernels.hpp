@@ -69,6 +69,9 @@ struct SampleArgs {
     int set_octave;               // 0: single model (octave stays 0, no rescale)
 };
 hipError_t launch_sample(const SampleArgs& a, const Geom& g, hipStream_t s);
+// free-standing Resampler (BaseModel.cc:491-562): out[b][p][c] for NHWC data and (x, y) warp points
+hipError_t launch_resampler(const float* data, const float* warp, float* out, int batch, int dh, int dw, int channels, int npoints,
+                            hipStream_t s);
 
 // ---- kernels_global.hip -------------------------------------------------------------------------
 hipError_t launch_softmax_rows(float* x, long long rows, int n, int ld, hipStream_t s);

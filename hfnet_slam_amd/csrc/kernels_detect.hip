@@ -435,6 +435,34 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a, Geom g) {
     }
 }
 
+// free-standing Resampler, same expression order as the reference (and as k_sample)
+__global__ __launch_bounds__(256) void k_resampler(const float* __restrict__ data, const float* __restrict__ warp, float* __restrict__ out,
+                                                   int dh, int dw, int channels, int npoints) {
+    const int b = blockIdx.y;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)npoints * channels) return;
+    const int p = (int)(idx / channels), c = (int)(idx - (long long)p * channels);
+    const float x = warp[((long long)b * npoints + p) * 2], y = warp[((long long)b * npoints + p) * 2 + 1];
+    float o = 0.0f;
+    if (x > -1.0f && y > -1.0f && x < (float)dw && y < (float)dh) {
+        const int fx = (int)floorf(x), fy = (int)floorf(y), cx = fx + 1, cy = fy + 1;
+        const float dx = (float)cx - x, dy = (float)cy - y;
+        const float* d = data + (long long)b * dh * dw * channels + c;
+        auto pt = [&](int xx, int yy) { return (xx >= 0 && yy >= 0 && xx <= dw - 1 && yy <= dh - 1) ? d[(long long)channels * ((long long)yy * dw + xx)] : 0.0f; };
+        const float t0 = dx * dy * pt(fx, fy), t1 = (1.0f - dx) * (1.0f - dy) * pt(cx, cy);
+        const float t2 = dx * (1.0f - dy) * pt(fx, cy), t3 = (1.0f - dx) * dy * pt(cx, fy);
+        o = t0 + t1 + t2 + t3;
+    }
+    out[((long long)b * npoints + p) * channels + c] = o;
+}
+
+hipError_t launch_resampler(const float* data, const float* warp, float* out, int batch, int dh, int dw, int channels, int npoints, hipStream_t s) {
+    if (batch <= 0 || npoints <= 0 || channels <= 0) return hipSuccess;
+    dim3 grid((unsigned)(((long long)npoints * channels + 255) / 256), batch);
+    hipLaunchKernelGGL(k_resampler, grid, dim3(256), 0, s, data, warp, out, dh, dw, channels, npoints);
+    return hipGetLastError();
+}
+
 hipError_t launch_sample(const SampleArgs& a, const Geom& g, hipStream_t s) {
     // grid.x covers the largest per-level budget; the caller stores it in kps_stride
     dim3 grid((unsigned)((a.kps_stride + 3) / 4), g.n_levels * g.batch);

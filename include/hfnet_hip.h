@@ -132,6 +132,12 @@ int hfnet_match_search_for_triangulation(hfnet_engine* e, const float* d1, int n
                                          int n2, int dim, float th_high, int32_t* match12,
                                          int* n_matches, int on_device);
 
+/* ---- Resampler (include/Extractors/BaseModel.h:78-80, src/Extractors/BaseModel.cc:491-562) ---------
+ * tensorflow.contrib.resampler: bilinear sampling of an NHWC fp32 map at (x, y) warp points with zero
+ * padding; output[b][p][c].  Host pointers (the fused path inside hfnet_*_detect never calls this). */
+int hfnet_resampler(hfnet_engine* e, const float* data, const float* warp, float* output, int batch_size,
+                    int data_height, int data_width, int data_channels, int num_sampling_points);
+
 /* ---- KeyFrameDatabase scan (src/KeyFrameDatabase.cc:75-104, 170-197) --------------------------- */
 int hfnet_db_create(hfnet_engine* e, int capacity, int dim, hfnet_db** out);
 void hfnet_db_destroy(hfnet_db* db);

@@ -244,3 +244,51 @@ def test_database(engine):
     cs, sc, best, _ = db.query(rows[1], 0)
     assert len(cs) == 0 and best == 0.0
     db.close()
+
+
+def test_resampler_entry_point(engine):
+    """free-standing Resampler (BaseModel.h:78-80) vs the oracle, incl. border / outside points and batch > 1"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(21)
+    data = rng.standard_normal((2, 7, 9, 24)).astype(np.float32)
+    warp = rng.uniform(-1.5, 10.5, (2, 300, 2)).astype(np.float32)
+    warp[:, :6] = [[0, 0], [8, 6], [8.5, 6.5], [-1, 0], [9, 3], [3.25, 2.75]]
+    assert np.array_equal(engine.resampler(data, warp), O.resampler(data, warp))
+
+
+def test_tracking_loop_shape(engine, oracle_model):
+    """BASELINE config 3 in miniature: per frame extract + match against the previous frame; every 5th frame is a
+    keyframe: global descriptor into the database, place-recognition query against all previous keyframes, and
+    SearchForTriangulation against the previous keyframes (LocalMapping.cc:516-520)."""
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    w, h, nf = 128, 128, 150
+    x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, 4, max_batch=1)
+    db = capi.Database(engine, 8, engine.global_dim)
+    prev, kfs, ref_prev, ref_kfs = None, [], None, []
+    for f in range(11):
+        img = synth_image(h, w, 700 + f, "natural" if f % 2 else "uniform")
+        n, kps, desc, g, _ = x.extract(img)
+        rn, rk, rd, rg, _ = oracle_model.extract(img, nf, 0.01, 4, 1.2)
+        _eq("kps", kps, rk); _eq("desc", desc, rd); _eq("global", g, rg)
+        if prev is not None:
+            c, m, d = engine.search_by_bow(prev, desc, 0.6)
+            rc, rm, rdist = O.search_by_bow(ref_prev, rd, 0.6)
+            assert c == rc
+            _eq("match", m, rm); _eq("dist", d, rdist)
+        if f % 5 == 0:
+            if kfs:
+                cs, sc, best, _ = db.query(g, 0)
+                ref = O.db_scores(rg, np.stack([k[1] for k in ref_kfs]))
+                ridx, rbest = O.db_candidates(ref, 0)
+                assert best == rbest
+                _eq("loop candidates", cs, ridx)
+                for kd in kfs:
+                    c, m = engine.search_for_triangulation(desc, kd[0], 0.75)
+                    rc, rm = O.search_for_triangulation(rd, kd[0], 0.75)
+                    assert c == rc
+                    _eq("triangulation", m, rm)
+            db.add(len(kfs), g)
+            kfs.append((desc, g)); ref_kfs.append((rd, rg))
+        prev, ref_prev = desc, rd
+    x.close(); db.close()
