@@ -86,8 +86,8 @@ def layer_work(batch: int):
     work["conv3x3_desc_taps"] = (2.0 * 9 * sp.local_channels * 256 * rows, 4.0 * (rows * (9 * sp.local_channels + 256) + 9 * sp.local_channels * 256))
     work["pointwise_desc_taps"] = (2.0 * 256 * 256 * rows, 4.0 * (rows * 512 + 256 * 256))
     work["l2norm_desc_taps"] = (3.0 * 256 * rows, 4.0 * rows * 512)
-    # matcher: one launch per frame pair
-    work["match_gemm"] = (2.0 * N_FEAT * N_FEAT * 256, 4.0 * (2 * N_FEAT * 256 + N_FEAT * N_FEAT))
+    # matcher: all frame pairs of a step in one batched call (prep + GEMM + train pass + finalize)
+    work["match_bow"] = (batch * 2.0 * N_FEAT * N_FEAT * 256, batch * 4.0 * (2 * N_FEAT * 256 + 2 * N_FEAT * N_FEAT))
     return work
 
 
@@ -178,41 +178,41 @@ def main() -> None:
 
     n_sets = 2
     frames = [torch.from_numpy(make_frames(B, (rank * n_sets + s) * B)).to(dev) for s in range(n_sets)]
+    # descriptor sets of the last n_buf steps live in one rotating store: set id = buffer * B + frame
     n_buf = 3
-    kps = [torch.zeros((B, N_FEAT, 4), dtype=torch.float32, device=dev) for _ in range(n_buf)]
-    desc = [torch.zeros((B, N_FEAT, 256), dtype=torch.float32, device=dev) for _ in range(n_buf)]
+    kps = torch.zeros((n_buf * B, N_FEAT, 4), dtype=torch.float32, device=dev)
+    desc = torch.zeros((n_buf * B, N_FEAT, 256), dtype=torch.float32, device=dev)
+    n_rows = torch.zeros((n_buf * B,), dtype=torch.int32, device=dev)          # keypoints per set, written by the extractor
     glob = torch.zeros((B, eng.global_dim), dtype=torch.float32, device=dev)
-    n_out = torch.zeros((B,), dtype=torch.int32, device=dev)
     match = torch.zeros((B, N_FEAT), dtype=torch.int32, device=dev)
     mdist = torch.zeros((B, N_FEAT), dtype=torch.float32, device=dev)
     mcnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    # frame j of buffer c is matched against its predecessor (query = previous frame, train = this frame)
+    tset = [torch.arange(c * B, (c + 1) * B, dtype=torch.int32, device=dev) for c in range(n_buf)]
+    qset = [((t.to(torch.int64) - 1) % (n_buf * B)).to(torch.int32) for t in tset]
     torch.cuda.synchronize()
     L = capi.lib()
     import ctypes as C
 
-    state = {"step": 0, "prev_n": 0, "prev_ptr": 0}
+    state = {"step": 0}
 
     def step():
         i = state["step"]
         cur = i % n_buf
         f = frames[i % n_sets]
-        ext.extract_batch_device(B, f.data_ptr(), W_IMG, W_IMG * H_IMG, kps[cur].data_ptr(), desc[cur].data_ptr(), glob.data_ptr(), n_out.data_ptr())
-        eng.synchronize()                      # keypoint counts are needed on the host to size the matches
-        n = n_out.cpu().numpy()
-        for j in range(B):
-            q_ptr, nq = (desc[cur].data_ptr() + (j - 1) * N_FEAT * 256 * 4, int(n[j - 1])) if j > 0 else (state["prev_ptr"], state["prev_n"])
-            if nq == 0 and j == 0:
-                continue                        # very first frame has no predecessor
-            t_ptr, nt = desc[cur].data_ptr() + j * N_FEAT * 256 * 4, int(n[j])
-            st = L.hfnet_match_search_by_bow(eng.h, C.c_void_p(q_ptr), nq, C.c_void_p(t_ptr), nt, 256, C.c_float(TH_LOW),
-                                             C.c_void_p(match.data_ptr() + j * N_FEAT * 4), C.c_void_p(mdist.data_ptr() + j * N_FEAT * 4),
-                                             C.c_void_p(mcnt.data_ptr() + j * 4), 1)
-            if st != 0:
-                raise RuntimeError(capi.last_error())
-        state["prev_ptr"] = desc[cur].data_ptr() + (B - 1) * N_FEAT * 256 * 4
-        state["prev_n"] = int(n[B - 1])
+        ext.extract_batch_device(B, f.data_ptr(), W_IMG, W_IMG * H_IMG, kps[cur * B].data_ptr(), desc[cur * B].data_ptr(), glob.data_ptr(),
+                                 n_rows[cur * B:].data_ptr())
+        # the next extraction overwrites the buffer the PREVIOUS step's matches still read: fence it behind them
+        eng.fence()
+        # all B SearchByBoW pairs of the step in one call; keypoint counts stay on the device (no host sync)
+        st = L.hfnet_match_search_by_bow_batch(eng.h, B, C.c_void_p(desc.data_ptr()), C.c_size_t(N_FEAT * 256), C.c_void_p(n_rows.data_ptr()),
+                                               n_buf * B, C.c_void_p(qset[cur].data_ptr()), C.c_void_p(tset[cur].data_ptr()), N_FEAT, 256,
+                                               C.c_float(TH_LOW), C.c_void_p(match.data_ptr()), C.c_void_p(mdist.data_ptr()),
+                                               C.c_void_p(mcnt.data_ptr()), 1)
+        if st != 0:
+            raise RuntimeError(capi.last_error())
         state["step"] = i + 1
-        return n
+        return n_rows[cur * B:(cur + 1) * B]
 
     def sync_all():
         eng.synchronize()
@@ -224,6 +224,8 @@ def main() -> None:
     eng.profile_reset(); eng.profile_filter(None); eng.profile_enable(True)
     for _ in range(max(args.warmup, 1)):
         n = step()
+        eng.synchronize()
+        n = n.cpu().numpy()
         if int(n.min()) < N_FEAT:
             raise SystemExit(f"synthetic frames gave only {int(n.min())} keypoints (< {N_FEAT}): budget not exercised")
     eng.synchronize()

@@ -22,12 +22,12 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4"), ("octave",
 # every symbol include/hfnet_hip.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = [
     "hfnet_last_error", "hfnet_abi_version", "hfnet_device_count",
-    "hfnet_engine_create", "hfnet_engine_destroy", "hfnet_engine_info", "hfnet_engine_synchronize",
+    "hfnet_engine_create", "hfnet_engine_destroy", "hfnet_engine_info", "hfnet_engine_synchronize", "hfnet_engine_fence",
     "hfnet_model_create", "hfnet_model_destroy", "hfnet_model_is_valid", "hfnet_model_mode",
     "hfnet_model_detect", "hfnet_model_detect_global", "hfnet_model_tap",
     "hfnet_extractor_create", "hfnet_extractor_destroy", "hfnet_extractor_tables",
     "hfnet_extractor_extract", "hfnet_extractor_extract_batch",
-    "hfnet_descriptor_distance", "hfnet_resampler", "hfnet_match_search_by_bow", "hfnet_match_search_for_triangulation",
+    "hfnet_descriptor_distance", "hfnet_resampler", "hfnet_match_search_by_bow", "hfnet_match_search_by_bow_batch", "hfnet_match_search_for_triangulation",
     "hfnet_db_create", "hfnet_db_destroy", "hfnet_db_add", "hfnet_db_erase", "hfnet_db_clear", "hfnet_db_query",
     "hfnet_profile_enable", "hfnet_profile_reset", "hfnet_profile_filter", "hfnet_profile_count", "hfnet_profile_get",
 ]
@@ -96,6 +96,9 @@ class Engine:
     def synchronize(self):
         _chk(lib().hfnet_engine_synchronize(self.h))
 
+    def fence(self):
+        _chk(lib().hfnet_engine_fence(self.h))
+
     # ---- Matcher ---------------------------------------------------------------------------
     def descriptor_distance(self, a, b) -> float:
         a = np.ascontiguousarray(a, np.float32).ravel(); b = np.ascontiguousarray(b, np.float32).ravel()
@@ -111,6 +114,17 @@ class Engine:
         _chk(lib().hfnet_match_search_by_bow(self.h, _p(q), q.shape[0], _p(t), t.shape[0], dim, C.c_float(th_low),
                                              _p(match), _p(dist), C.byref(n), 0))
         return n.value, match, dist
+
+    def search_by_bow_batch(self, sets, n_rows, pairs, th_low: float = 0.6):
+        """sets: [S, max_rows, dim] float32 (host); n_rows: [S]; pairs: list of (query_set, train_set)."""
+        sets = np.ascontiguousarray(sets, np.float32)
+        n_rows = np.ascontiguousarray(n_rows, np.int32)
+        qs = np.ascontiguousarray([p[0] for p in pairs], np.int32); ts = np.ascontiguousarray([p[1] for p in pairs], np.int32)
+        S, mr, dim = sets.shape
+        match = np.full((len(pairs), mr), -2, np.int32); dist = np.zeros((len(pairs), mr), np.float32); cnt = np.full((len(pairs),), -1, np.int32)
+        _chk(lib().hfnet_match_search_by_bow_batch(self.h, len(pairs), _p(sets), C.c_size_t(mr * dim), _p(n_rows), S, _p(qs), _p(ts), mr, dim,
+                                                   C.c_float(th_low), _p(match), _p(dist), _p(cnt), 0))
+        return cnt, match, dist
 
     def search_for_triangulation(self, d1, d2, th_high: float = 0.75):
         d1 = np.ascontiguousarray(d1, np.float32); d2 = np.ascontiguousarray(d2, np.float32)

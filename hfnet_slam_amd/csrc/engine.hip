@@ -31,9 +31,26 @@ Engine::~Engine() {
     (void)hipSetDevice(device);
     prof.flush();
     for (auto ev : prof.pool) (void)hipEventDestroy(ev);
-    for (DevMem* m : {&m_a, &m_b, &m_s, &m_qn, &m_tn, &m_key, &m_i0, &m_i1, &m_f0, &m_cnt}) m->release();
+    for (DevMem* m : {&m_a, &m_b, &m_s, &m_qn, &m_tn, &m_key, &m_i0, &m_i1, &m_f0, &m_cnt, &m_pairs}) m->release();
     w.release();
+    if (ev_extract) (void)hipEventDestroy(ev_extract);
+    if (ev_match) (void)hipEventDestroy(ev_match);
     if (stream) (void)hipStreamDestroy(stream);
+}
+
+hipError_t Engine::note_extract(hipStream_t net_stream) {
+    std::lock_guard<std::mutex> lk(ev_mu);
+    if (!ev_extract) { hipError_t r = hipEventCreateWithFlags(&ev_extract, hipEventDisableTiming); if (r != hipSuccess) return r; }
+    ev_extract_set = true;
+    return hipEventRecord(ev_extract, net_stream);
+}
+hipError_t Engine::wait_extract() {
+    std::lock_guard<std::mutex> lk(ev_mu);
+    return ev_extract_set ? hipStreamWaitEvent(stream, ev_extract, 0) : hipSuccess;
+}
+hipError_t Engine::wait_fence(hipStream_t net_stream) {
+    std::lock_guard<std::mutex> lk(ev_mu);
+    return ev_match_set ? hipStreamWaitEvent(net_stream, ev_match, 0) : hipSuccess;
 }
 
 template <class T>
@@ -450,6 +467,18 @@ int hfnet_engine_synchronize(hfnet_engine* e) {
     return HFNET_OK;
 }
 
+int hfnet_engine_fence(hfnet_engine* eh) {
+    API_GUARD(eh, "engine");
+    Engine& e = eh->impl;
+    std::lock_guard<std::mutex> lk(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    std::lock_guard<std::mutex> lk2(e.ev_mu);
+    if (!e.ev_match) HF_HIP(hipEventCreateWithFlags(&e.ev_match, hipEventDisableTiming));
+    HF_HIP(hipEventRecord(e.ev_match, e.stream));
+    e.ev_match_set = true;
+    return HFNET_OK;
+}
+
 // ---------------------------------------------------------------------------------------- BaseModel
 int hfnet_model_create(hfnet_engine* e, hfnet_mode mode, int height, int width, int max_keypoints, hfnet_model** out) {
     API_GUARD(out, "out");
@@ -695,6 +724,7 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
     HF_HIP(hipSetDevice(eng.device));
     hipStream_t st = x->net.stream;
     const int G = eng.w.global_dim;
+    if (on_device) HF_HIP(eng.wait_fence(st));
     for (int f0 = 0; f0 < n_frames; f0 += x->max_batch) {
         const int nb = std::min(x->max_batch, n_frames - f0);
         if (on_device) {
@@ -719,6 +749,7 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
             HF_HIP(hipStreamSynchronize(st));
         }
     }
+    if (on_device) HF_HIP(eng.note_extract(st));
     return HFNET_OK;
 }
 
@@ -762,6 +793,17 @@ int hfnet_descriptor_distance(hfnet_engine* eh, const float* a, const float* b, 
     return HFNET_OK;
 }
 
+// scratch for n_pairs x (max_rows x max_rows) similarity matrices, norms, keys and the pair descriptors
+static int bow_scratch(Engine& e, int n_pairs, int max_rows) {
+    const size_t np = (size_t)std::max(n_pairs, 1), mr = (size_t)std::max(max_rows, 1);
+    HF_TRY(e.m_s.ensure(sizeof(float) * np * mr * mr));
+    HF_TRY(e.m_qn.ensure(sizeof(float) * np * mr));
+    HF_TRY(e.m_tn.ensure(sizeof(float) * np * mr));
+    HF_TRY(e.m_key.ensure(sizeof(unsigned long long) * np * mr));
+    HF_TRY(e.m_pairs.ensure(sizeof(BowPair) * np));
+    return HFNET_OK;
+}
+
 int hfnet_match_search_by_bow(hfnet_engine* eh, const float* query, int n_query, const float* train, int n_train, int dim, float th_low,
                               int32_t* match_q2t, float* dist, int* n_matches, int on_device) {
     API_GUARD(eh, "engine"); API_GUARD(match_q2t, "match_q2t"); API_GUARD(dist, "dist"); API_GUARD(n_matches, "n_matches");
@@ -770,30 +812,72 @@ int hfnet_match_search_by_bow(hfnet_engine* eh, const float* query, int n_query,
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
     HF_HIP(hipSetDevice(e.device));
+    if (on_device) HF_HIP(e.wait_extract());
     if (n_query == 0) { if (!on_device) *n_matches = 0; else HF_HIP(hipMemsetAsync(n_matches, 0, sizeof(int), e.stream)); return HFNET_OK; }
     const float *dq, *dt;
     HF_TRY(stage_rows(e, e.m_a, query, (size_t)n_query * dim, on_device, &dq));
     HF_TRY(stage_rows(e, e.m_b, train, (size_t)n_train * dim, on_device, &dt));
-    HF_TRY(e.m_s.ensure(sizeof(float) * std::max<size_t>((size_t)n_query * n_train, 1)));
-    HF_TRY(e.m_qn.ensure(sizeof(float) * n_query));
-    HF_TRY(e.m_tn.ensure(sizeof(float) * std::max(n_train, 1)));
-    HF_TRY(e.m_key.ensure(sizeof(unsigned long long) * ((size_t)n_query + 1)));
+    const int max_rows = std::max(n_query, n_train);
+    HF_TRY(bow_scratch(e, 1, max_rows));
     int32_t* d_match = match_q2t; float* d_dist = dist; int* d_cnt = n_matches;
     if (!on_device) {
         HF_TRY(e.m_i0.ensure(sizeof(int32_t) * n_query)); HF_TRY(e.m_f0.ensure(sizeof(float) * n_query)); HF_TRY(e.m_cnt.ensure(sizeof(int)));
         d_match = e.m_i0.as<int32_t>(); d_dist = e.m_f0.as<float>(); d_cnt = e.m_cnt.as<int>();
     }
-    HF_LAUNCH(&e, e.stream, "match_prep", launch_bow_prep(dq, n_query, dt, n_train, dim, e.m_qn.as<float>(), e.m_tn.as<float>(),
-                                                          e.m_key.as<unsigned long long>(), d_cnt, e.stream));
-    // St[t][q] = train . query  (rows of St are contiguous in q for the train pass)
-    HF_LAUNCH(&e, e.stream, "match_gemm", launch_gemm_abt(dt, n_train, dq, n_query, dim, e.m_s.as<float>(), e.stream));
-    HF_LAUNCH(&e, e.stream, "match_bow_select",
-              launch_bow_select(dq, n_query, dt, n_train, dim, e.m_s.as<float>(), e.m_qn.as<float>(), e.m_tn.as<float>(),
-                                e.m_key.as<unsigned long long>(), th_low, d_match, d_dist, d_cnt, e.stream));
+    BowPair P;
+    P.q = dq; P.t = dt; P.St = e.m_s.as<float>(); P.qn = e.m_qn.as<float>(); P.tn = e.m_tn.as<float>(); P.qkey = e.m_key.as<unsigned long long>();
+    P.match = d_match; P.dist = d_dist; P.cnt = d_cnt; P.nq = n_query; P.nt = n_train;
+    HF_HIP(hipMemcpyAsync(e.m_pairs.p, &P, sizeof P, hipMemcpyHostToDevice, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));     // P lives on this stack frame
+    HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), 1, max_rows, dim, th_low, e.stream));
     if (!on_device) {
         HF_HIP(hipMemcpyAsync(match_q2t, d_match, sizeof(int32_t) * n_query, hipMemcpyDeviceToHost, e.stream));
         HF_HIP(hipMemcpyAsync(dist, d_dist, sizeof(float) * n_query, hipMemcpyDeviceToHost, e.stream));
         HF_HIP(hipMemcpyAsync(n_matches, d_cnt, sizeof(int), hipMemcpyDeviceToHost, e.stream));
+        HF_HIP(hipStreamSynchronize(e.stream));
+    }
+    return HFNET_OK;
+}
+
+int hfnet_match_search_by_bow_batch(hfnet_engine* eh, int n_pairs, const float* desc_base, size_t set_stride, const int32_t* n_rows, int n_sets,
+                                    const int32_t* query_set, const int32_t* train_set, int max_rows, int dim, float th_low, int32_t* match_q2t,
+                                    float* dist, int32_t* n_matches, int on_device) {
+    API_GUARD(eh, "engine");
+    if (n_pairs < 0 || n_sets < 0 || max_rows < 1 || dim <= 0 || dim % 64 || set_stride < (size_t)max_rows * dim) {
+        set_error("bad batched matcher arguments (dim multiple of 64, set_stride >= max_rows * dim)"); return HFNET_ERR_INVALID_ARG; }
+    if (n_pairs == 0) return HFNET_OK;
+    API_GUARD(desc_base, "desc_base"); API_GUARD(n_rows, "n_rows"); API_GUARD(query_set, "query_set"); API_GUARD(train_set, "train_set");
+    API_GUARD(match_q2t, "match_q2t"); API_GUARD(dist, "dist"); API_GUARD(n_matches, "n_matches");
+    Engine& e = eh->impl;
+    std::lock_guard<std::mutex> lk(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    if (on_device) HF_HIP(e.wait_extract());
+    HF_TRY(bow_scratch(e, n_pairs, max_rows));
+    const float* d_base = desc_base; const int32_t *d_rows = n_rows, *d_qs = query_set, *d_ts = train_set;
+    int32_t* d_match = match_q2t; float* d_dist = dist; int32_t* d_cnt = n_matches;
+    if (!on_device) {
+        for (int p = 0; p < n_pairs; ++p)
+            if (query_set[p] < 0 || query_set[p] >= n_sets || train_set[p] < 0 || train_set[p] >= n_sets) { set_error("pair %d references a set outside [0, %d)", p, n_sets); return HFNET_ERR_INVALID_ARG; }
+        HF_TRY(e.m_a.ensure(sizeof(float) * (size_t)std::max(n_sets, 1) * set_stride));
+        HF_TRY(e.m_b.ensure(sizeof(int32_t) * ((size_t)n_sets + 2 * (size_t)n_pairs)));
+        HF_TRY(e.m_i0.ensure(sizeof(int32_t) * (size_t)n_pairs * max_rows)); HF_TRY(e.m_f0.ensure(sizeof(float) * (size_t)n_pairs * max_rows));
+        HF_TRY(e.m_cnt.ensure(sizeof(int32_t) * n_pairs));
+        HF_HIP(hipMemcpyAsync(e.m_a.p, desc_base, sizeof(float) * (size_t)n_sets * set_stride, hipMemcpyHostToDevice, e.stream));
+        int32_t* ib = e.m_b.as<int32_t>();
+        HF_HIP(hipMemcpyAsync(ib, n_rows, sizeof(int32_t) * n_sets, hipMemcpyHostToDevice, e.stream));
+        HF_HIP(hipMemcpyAsync(ib + n_sets, query_set, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, e.stream));
+        HF_HIP(hipMemcpyAsync(ib + n_sets + n_pairs, train_set, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, e.stream));
+        d_base = e.m_a.as<float>(); d_rows = ib; d_qs = ib + n_sets; d_ts = ib + n_sets + n_pairs;
+        d_match = e.m_i0.as<int32_t>(); d_dist = e.m_f0.as<float>(); d_cnt = e.m_cnt.as<int32_t>();
+    }
+    HF_LAUNCH(&e, e.stream, "match_bow_setup",
+              launch_bow_setup(e.m_pairs.as<BowPair>(), n_pairs, d_base, (long long)set_stride, d_rows, d_qs, d_ts, max_rows, e.m_s.as<float>(),
+                               e.m_qn.as<float>(), e.m_tn.as<float>(), e.m_key.as<unsigned long long>(), d_match, d_dist, d_cnt, max_rows, e.stream));
+    HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, th_low, e.stream));
+    if (!on_device) {
+        HF_HIP(hipMemcpyAsync(match_q2t, d_match, sizeof(int32_t) * (size_t)n_pairs * max_rows, hipMemcpyDeviceToHost, e.stream));
+        HF_HIP(hipMemcpyAsync(dist, d_dist, sizeof(float) * (size_t)n_pairs * max_rows, hipMemcpyDeviceToHost, e.stream));
+        HF_HIP(hipMemcpyAsync(n_matches, d_cnt, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToHost, e.stream));
         HF_HIP(hipStreamSynchronize(e.stream));
     }
     return HFNET_OK;
@@ -807,6 +891,7 @@ int hfnet_match_search_for_triangulation(hfnet_engine* eh, const float* d1, int 
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
     HF_HIP(hipSetDevice(e.device));
+    if (on_device) HF_HIP(e.wait_extract());
     if (n1 == 0) { if (!on_device) *n_matches = 0; else HF_HIP(hipMemsetAsync(n_matches, 0, sizeof(int), e.stream)); return HFNET_OK; }
     const float *da, *db;
     HF_TRY(stage_rows(e, e.m_a, d1, (size_t)n1 * dim, on_device, &da));

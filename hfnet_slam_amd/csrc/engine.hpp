@@ -21,7 +21,14 @@ struct Engine {
     Profiler prof;
     std::mutex mu;                  // engine-level scratch + stream
     std::mutex prof_mu;
-    DevMem m_a, m_b, m_s, m_qn, m_tn, m_key, m_i0, m_i1, m_f0, m_cnt;   // matcher scratch
+    DevMem m_a, m_b, m_s, m_qn, m_tn, m_key, m_i0, m_i1, m_f0, m_cnt, m_pairs;   // matcher scratch
+    // device-side ordering between extractor streams and the matcher stream for on_device callers
+    std::mutex ev_mu;
+    hipEvent_t ev_extract = nullptr, ev_match = nullptr;   // last on_device extraction / last hfnet_engine_fence
+    bool ev_extract_set = false, ev_match_set = false;
+    hipError_t note_extract(hipStream_t net_stream);        // record: extraction enqueued up to here
+    hipError_t wait_extract();                              // matcher stream waits for it
+    hipError_t wait_fence(hipStream_t net_stream);          // extractor stream waits for the last fence
     ~Engine();
 };
 

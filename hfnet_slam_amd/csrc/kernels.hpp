@@ -89,13 +89,19 @@ hipError_t launch_gemm_abt(const float* d1, int n1, const float* d2, int n2, int
 // SearchForTriangulation selection (Matcher.cc:851-889)
 hipError_t launch_tri_select(const float* S, int n1, int n2, float threshold, int* col_best, int32_t* match12,
                              int* n_matches, hipStream_t s);
-// BFMatcher(NORM_L2, crossCheck) + distance < th_low (Matcher.cc:229-260)
-hipError_t launch_bow_select(const float* q, int nq, const float* t, int nt, int dim, const float* S /*[nq x nt]*/,
-                             float* qnorm, float* tnorm, unsigned long long* qkey, float th_low, int32_t* match_q2t,
-                             float* dist, int* n_matches, hipStream_t s);
-// norms of both sets + reset of the per-query keys and the match counter (one launch, before the GEMM)
-hipError_t launch_bow_prep(const float* q, int nq, const float* t, int nt, int dim, float* qnorm, float* tnorm,
-                           unsigned long long* qkey, int* n_matches, hipStream_t s);
+// BFMatcher(NORM_L2, crossCheck) + distance < th_low (Matcher.cc:229-260), batched over descriptor-set pairs.
+// One BowPair per (query set, train set); launch_bow_setup fills them on the device (row counts may be
+// device-resident), launch_bow_pairs runs prep / GEMM / train pass / finalize for all pairs in four launches.
+struct BowPair {
+    const float* q; const float* t;
+    float* St; float* qn; float* tn; unsigned long long* qkey;
+    int32_t* match; float* dist; int* cnt;
+    int nq, nt;
+};
+hipError_t launch_bow_setup(BowPair* pairs, int n_pairs, const float* base, long long set_stride, const int* n_rows, const int* qset,
+                            const int* tset, int max_rows, float* St, float* qn, float* tn, unsigned long long* qkey, int32_t* match, float* dist,
+                            int* cnt, long long out_stride, hipStream_t s);
+hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, hipStream_t s);
 hipError_t launch_descriptor_distance(const float* a, const float* b, int dim, float* out, hipStream_t s);
 // KeyFrameDatabase scan (KeyFrameDatabase.cc:86-104, 178-197)
 hipError_t launch_db_scores(const float* q, const float* db, const unsigned char* occupied, int n, int dim, float* scores,

@@ -21,13 +21,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // are staged through LDS with coalesced 256-byte row segments (a lane's own row is 1 KB away from its
 // neighbour's, so direct fragment loads thrash L1).  LDS rows are 66 floats apart: the 8-byte fragment
 // reads (k = 2t, 2t+1; the half-waves pick the even / odd one) are bank-conflict free.
-__global__ __launch_bounds__(256) void k_gemm_abt(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int dim,
-                                                  float* __restrict__ S) {
+__device__ __forceinline__ void gemm_abt_tile(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int dim,
+                                              float* __restrict__ S) {
     constexpr int LD = 66;
     __shared__ __attribute__((aligned(16))) float As[64 * LD];
     __shared__ __attribute__((aligned(16))) float Bs[64 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
     const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+    if (row0 >= n1 || col0 >= n2) return;                     // workgroup-uniform (batched launches are sized for the largest pair)
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
     const int lrow = tid >> 2, lq = tid & 3;                 // staging: 4 threads x 4 float4 per 64-float row chunk
     const float* ag = d1 + (long long)min(row0 + lrow, n1 - 1) * dim + lq * 4;
@@ -65,6 +66,16 @@ __global__ __launch_bounds__(256) void k_gemm_abt(const float* __restrict__ d1, 
         const int row = row0 + wr + (reg & 3) + 8 * (reg >> 2) + 4 * half;
         if (row < n1) S[(long long)row * n2 + col] = acc[reg];
     }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_abt(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int dim,
+                                                  float* __restrict__ S) {
+    gemm_abt_tile(d1, n1, d2, n2, dim, S);
+}
+// batched over descriptor-set pairs: St[p] = train[p] * query[p]^T
+__global__ __launch_bounds__(256) void k_gemm_abt_pairs(const BowPair* __restrict__ pairs, int dim) {
+    const BowPair P = pairs[blockIdx.z];
+    gemm_abt_tile(P.t, P.nt, P.q, P.nq, dim, P.St);
 }
 
 hipError_t launch_gemm_abt(const float* d1, int n1, const float* d2, int n2, int dim, float* S, hipStream_t s) {
@@ -128,12 +139,14 @@ hipError_t launch_tri_select(const float* S, int n1, int n2, float threshold, in
 // The MFMA dot products St[t][q] only pre-select: every query whose |t|^2+|q|^2-2St lies within a
 // rigorous rounding band of the column minimum is re-evaluated in the exact form, in ascending q.
 // one launch: |q|^2, |t|^2 (pre-filter only), reset of the per-query keys and of the match counter
-__global__ __launch_bounds__(256) void k_bow_prep(const float* __restrict__ q, int nq, const float* __restrict__ t, int nt, int dim,
-                                                  float* __restrict__ qn, float* __restrict__ tn, unsigned long long* __restrict__ qkey,
-                                                  int* __restrict__ n_matches) {
+__global__ __launch_bounds__(256) void k_bow_prep(const BowPair* __restrict__ pairs, int dim) {
+    const BowPair P = pairs[blockIdx.z];
+    const float* __restrict__ q = P.q; const float* __restrict__ t = P.t;
+    const int nq = P.nq, nt = P.nt;
+    float* __restrict__ qn = P.qn; float* __restrict__ tn = P.tn; unsigned long long* __restrict__ qkey = P.qkey;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_matches = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *P.cnt = 0;
     if (i >= nq + nt) return;
     const float* x = i < nq ? q + (long long)i * dim : t + (long long)(i - nq) * dim;
     float p = 0.0f;
@@ -177,11 +190,13 @@ __device__ float cv_l2_wave(const float* a, const float* b, int dim, int lane) {
     return sqrtf(s);
 }
 
-__global__ __launch_bounds__(256) void k_bow_train_pass(const float* __restrict__ q, int nq, const float* __restrict__ t, int nt, int dim,
-                                                        const float* __restrict__ St /*[nt x nq]*/, const float* __restrict__ qn,
-                                                        const float* __restrict__ tn, unsigned long long* __restrict__ qkey, float band) {
+__global__ __launch_bounds__(256) void k_bow_train_pass(const BowPair* __restrict__ pairs, int dim, float band) {
+    const BowPair P = pairs[blockIdx.z];
+    const float* __restrict__ q = P.q; const float* __restrict__ t = P.t; const float* __restrict__ St = P.St;   // St: [nt x nq]
+    const int nq = P.nq, nt = P.nt;
+    const float* __restrict__ qn = P.qn; const float* __restrict__ tn = P.tn; unsigned long long* __restrict__ qkey = P.qkey;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= nt) return;
+    if (j >= nt || nq <= 0) return;            // (an empty query set would make every padded lane a candidate)
     const int lane = threadIdx.x & 63;
     const float* srow = St + (long long)j * nq;
     const float tnj = tn[j];
@@ -245,8 +260,11 @@ __global__ __launch_bounds__(256) void k_bow_train_pass(const float* __restrict_
         atomicMin(&qkey[bi], ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned int)j);
 }
 
-__global__ __launch_bounds__(256) void k_bow_finalize(const unsigned long long* __restrict__ qkey, int nq, float th_low,
-                                                      int32_t* __restrict__ match_q2t, float* __restrict__ dist, int* __restrict__ n_matches) {
+__global__ __launch_bounds__(256) void k_bow_finalize(const BowPair* __restrict__ pairs, float th_low) {
+    const BowPair P = pairs[blockIdx.z];
+    const unsigned long long* __restrict__ qkey = P.qkey;
+    const int nq = P.nq;
+    int32_t* __restrict__ match_q2t = P.match; float* __restrict__ dist = P.dist; int* __restrict__ n_matches = P.cnt;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nq) return;
     const unsigned long long k = qkey[i];
@@ -260,19 +278,40 @@ __global__ __launch_bounds__(256) void k_bow_finalize(const unsigned long long* 
     dist[i] = d;
 }
 
-hipError_t launch_bow_select(const float* q, int nq, const float* t, int nt, int dim, const float* St, float* qnorm, float* tnorm,
-                             unsigned long long* qkey, float th_low, int32_t* match_q2t, float* dist, int* n_matches, hipStream_t s) {
-    if (nq <= 0) return hipSuccess;
-    if (dim % 4) return hipErrorInvalidValue;
-    if (nt > 0) hipLaunchKernelGGL(k_bow_train_pass, dim3((nt + 3) / 4), dim3(256), 0, s, q, nq, t, nt, dim, St, qnorm, tnorm, qkey, 4e-6f * (float)dim + 1e-4f);
-    hipLaunchKernelGGL(k_bow_finalize, dim3((nq + 255) / 256), dim3(256), 0, s, qkey, nq, th_low, match_q2t, dist, n_matches);
+// fills the per-pair descriptors on the device: row counts may live in device memory (on_device callers never
+// bring them to the host), scratch is sliced per pair
+__global__ void k_bow_setup(BowPair* __restrict__ pairs, int n_pairs, const float* __restrict__ base, long long set_stride,
+                            const int* __restrict__ n_rows, const int* __restrict__ qset, const int* __restrict__ tset, int max_rows, float* St,
+                            float* qn, float* tn, unsigned long long* qkey, int32_t* match, float* dist, int* cnt, long long out_stride) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= n_pairs) return;
+    BowPair P;
+    const int qs = qset[p], ts = tset[p];
+    P.q = base + (long long)qs * set_stride; P.t = base + (long long)ts * set_stride;
+    P.nq = min(max(n_rows[qs], 0), max_rows); P.nt = min(max(n_rows[ts], 0), max_rows);
+    P.St = St + (long long)p * max_rows * max_rows;
+    P.qn = qn + (long long)p * max_rows; P.tn = tn + (long long)p * max_rows; P.qkey = qkey + (long long)p * max_rows;
+    P.match = match + (long long)p * out_stride; P.dist = dist + (long long)p * out_stride; P.cnt = cnt + p;
+    pairs[p] = P;
+}
+
+hipError_t launch_bow_setup(BowPair* pairs, int n_pairs, const float* base, long long set_stride, const int* n_rows, const int* qset,
+                            const int* tset, int max_rows, float* St, float* qn, float* tn, unsigned long long* qkey, int32_t* match, float* dist,
+                            int* cnt, long long out_stride, hipStream_t s) {
+    hipLaunchKernelGGL(k_bow_setup, dim3((n_pairs + 63) / 64), dim3(64), 0, s, pairs, n_pairs, base, set_stride, n_rows, qset, tset, max_rows, St, qn,
+                       tn, qkey, match, dist, cnt, out_stride);
     return hipGetLastError();
 }
 
-hipError_t launch_bow_prep(const float* q, int nq, const float* t, int nt, int dim, float* qnorm, float* tnorm, unsigned long long* qkey,
-                           int* n_matches, hipStream_t s) {
-    if (dim % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_bow_prep, dim3((nq + nt + 3) / 4 > 0 ? (nq + nt + 3) / 4 : 1), dim3(256), 0, s, q, nq, t, nt, dim, qnorm, tnorm, qkey, n_matches);
+// all pairs in four launches (prep, GEMM, train pass, finalize); grids are sized for max_rows, workgroups
+// beyond a pair's row counts exit at once
+hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, hipStream_t s) {
+    if (n_pairs <= 0 || max_rows <= 0) return hipSuccess;
+    if (dim % 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_bow_prep, dim3((2 * max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim);
+    hipLaunchKernelGGL(k_gemm_abt_pairs, dim3((max_rows + 63) / 64, (max_rows + 63) / 64, n_pairs), dim3(256), 0, s, pairs, dim);
+    hipLaunchKernelGGL(k_bow_train_pass, dim3((max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim, 4e-6f * (float)dim + 1e-4f);
+    hipLaunchKernelGGL(k_bow_finalize, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, th_low);
     return hipGetLastError();
 }
 

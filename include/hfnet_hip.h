@@ -71,6 +71,12 @@ void hfnet_engine_destroy(hfnet_engine* e);
  *       3 NetVLAD clusters, 4 global descriptor length (4096), 5 device ordinal */
 int hfnet_engine_info(const hfnet_engine* e, int what);
 int hfnet_engine_synchronize(hfnet_engine* e);
+/* Stream ordering for on_device callers (no host wait anywhere):
+ *  - matcher calls with on_device != 0 run after every on_device extraction enqueued before them
+ *    (their inputs are the extractor's outputs);
+ *  - hfnet_engine_fence: on_device extraction enqueued AFTER this call runs after all matcher work
+ *    enqueued BEFORE it -- call it before re-using descriptor buffers a pending match still reads. */
+int hfnet_engine_fence(hfnet_engine* e);
 
 /* ---- BaseModel (include/Extractors/BaseModel.h:38-54; ctor HFNetTFModelV2.cc:12-60) ----------- */
 /* height/width: the input image for image modes; for HFNET_INTERMEDIATE_TO_GLOBAL the
@@ -126,6 +132,16 @@ int hfnet_descriptor_distance(hfnet_engine* e, const float* a, const float* b, i
 int hfnet_match_search_by_bow(hfnet_engine* e, const float* query, int n_query, const float* train,
                               int n_train, int dim, float th_low, int32_t* match_q2t, float* dist,
                               int* n_matches, int on_device);
+/* The same over many descriptor-set pairs in four launches (LoopClosing matches a keyframe against all its
+ * candidates' covisibles, LoopClosing.cc:606-712; offline pipelines match every frame against its predecessor).
+ * Set s holds n_rows[s] rows of `dim` floats at desc_base + s * set_stride (floats); pair p matches query set
+ * query_set[p] against train set train_set[p].  match_q2t / dist: [n_pairs][max_rows], n_matches: [n_pairs].
+ * on_device != 0: EVERY pointer (n_rows, query_set, train_set included) is a device pointer, the call only
+ * enqueues -- the keypoint counts written by hfnet_extractor_extract_batch never have to visit the host. */
+int hfnet_match_search_by_bow_batch(hfnet_engine* e, int n_pairs, const float* desc_base, size_t set_stride,
+                                    const int32_t* n_rows, int n_sets, const int32_t* query_set,
+                                    const int32_t* train_set, int max_rows, int dim, float th_low,
+                                    int32_t* match_q2t, float* dist, int32_t* n_matches, int on_device);
 /* SearchForTriangulation body (Matcher.cc:845-889): S = D1 * D2^T, threshold 1 - th_high^2 / 2,
  * row arg-max (strict >) + column cross-check.  match12[i] = row of d2 or -1. */
 int hfnet_match_search_for_triangulation(hfnet_engine* e, const float* d1, int n1, const float* d2,

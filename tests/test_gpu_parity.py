@@ -292,3 +292,27 @@ def test_tracking_loop_shape(engine, oracle_model):
             kfs.append((desc, g)); ref_kfs.append((rd, rg))
         prev, ref_prev = desc, rd
     x.close(); db.close()
+
+
+def test_batched_bow_matches_per_pair_calls(engine):
+    """hfnet_match_search_by_bow_batch == the single-pair entry point == the oracle, ragged row counts incl. an empty set"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(31)
+    S, mr = 6, 90
+    n_rows = np.array([90, 64, 1, 0, 77, 90], np.int32)
+    sets = np.zeros((S, mr, 256), np.float32)
+    base = _unit_rows(rng, mr)
+    for s_ in range(S):
+        v = base + 0.05 * (s_ + 1) * rng.standard_normal((mr, 256)).astype(np.float32)
+        sets[s_] = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    pairs = [(0, 1), (1, 0), (2, 5), (3, 4), (4, 3), (5, 5), (0, 4)]
+    cnt, match, dist = engine.search_by_bow_batch(sets, n_rows, pairs, 0.6)
+    for p, (qs, ts) in enumerate(pairs):
+        q, t = sets[qs, :n_rows[qs]], sets[ts, :n_rows[ts]]
+        rn, rm, rd = O.search_by_bow(q, t, 0.6)
+        assert cnt[p] == rn, (p, cnt[p], rn)
+        _eq(f"pair {p} match", match[p, :n_rows[qs]], rm); _eq(f"pair {p} dist", dist[p, :n_rows[qs]], rd)
+        if n_rows[qs]:
+            n1, m1, d1 = engine.search_by_bow(q, t, 0.6)
+            assert n1 == rn
+            _eq("single", m1, rm)
