@@ -121,7 +121,7 @@ def cpu_baseline(weights_path: str, max_seconds: float = 25.0):
     of this box.  Reported, never optimised against."""
     from oracle import oracle as O
     O.build()
-    threads = max(1, min(os.cpu_count() or 1, 32))
+    threads = O.usable_cpus(32)      # affinity and cgroup quota, at most 32
     O.set_threads(threads)
     m = O.Model(weights_path)
     frames = make_frames(5, 0)

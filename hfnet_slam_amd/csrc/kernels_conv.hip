@@ -10,6 +10,7 @@
 #include "kernels.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace hfnet {
 
@@ -122,23 +123,59 @@ struct ConvArgs {
     int relu6;
 };
 
+// BN (+ ReLU6) (+ residual) and store of a wave's 32 x (NT*32) accumulator tile.  VALU instructions compete
+// with the f32 MFMAs for the same pipe, so the per-element work is kept minimal: the flags are hoisted into four
+// specialised loops, addresses are a uniform 64-bit tile base plus 32-bit lane offsets (row stride multiples are
+// scalar), and only the last, partial row tile checks rows.
 template <int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT], int nt0, long long row_base, long long row_limit,
                                               int half, int r) {
+    // the tile's first row is the same for all lanes of the wave: say so, the bases then live in SGPRs
+    row_base = ((long long)__builtin_amdgcn_readfirstlane((int)(row_base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)row_base);
+    const long long left = row_limit - row_base;
+    if (left <= 0) return;
+    const int rows = left < 32 ? (int)left : 32;                      // uniform
+    float* __restrict__ obase = a.out + row_base * a.n;               // uniform
+    const float* __restrict__ rbase = a.res ? a.res + row_base * a.n : nullptr;
+    const unsigned n = (unsigned)a.n;
+    auto body = [&](auto relu_tag, auto res_tag, auto full_tag) {
+        constexpr bool RELU = decltype(relu_tag)::value, RES = decltype(res_tag)::value, FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = (nt0 + nt) * 32 + r;
-        if (col >= a.n) continue;
-        const float sc = a.scale[col], sh = a.shift[col];
+        for (int nt = 0; nt < NT; ++nt) {
+            const unsigned col = (unsigned)((nt0 + nt) * 32 + r);
+            if (col < n) {
+                const float sc = a.scale[col], sh = a.shift[col];
+                const unsigned o0 = ((unsigned)(4 * half) * n + col) * 4u;   // byte offsets inside the tile (< 2^32)
+                float rv[16];
+                if (RES) {                                              // all residual loads first: one latency, not sixteen
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const long long row = row_base + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-            if (row >= row_limit) continue;
-            float v = fmaf(acc[nt][reg], sc, sh);
-            if (a.relu6) v = relu6f(v);
-            if (a.res) v = v + a.res[row * a.n + col];
-            a.out[row * a.n + col] = v;
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int rr = (reg & 3) + 8 * (reg >> 2);
+                        rv[reg] = (FULL || rr + 4 * half < rows) ? *(const float*)((const char*)rbase + o0 + (unsigned)rr * n * 4u) : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rr = (reg & 3) + 8 * (reg >> 2);          // + 4 * half
+                    if (FULL || rr + 4 * half < rows) {
+                        const unsigned off = o0 + (unsigned)rr * n * 4u;
+                        float v = fmaf(acc[nt][reg], sc, sh);
+                        if (RELU) v = relu6f(v);
+                        if (RES) v = v + rv[reg];
+                        *(float*)((char*)obase + off) = v;
+                    }
+                }
+            }
         }
+    };
+    using T = std::true_type; using F = std::false_type;
+    const bool full = rows == 32;
+    if (a.relu6) {
+        if (a.res) { if (full) body(T{}, T{}, T{}); else body(T{}, T{}, F{}); }
+        else       { if (full) body(T{}, F{}, T{}); else body(T{}, F{}, F{}); }
+    } else {
+        if (a.res) { if (full) body(F{}, T{}, T{}); else body(F{}, T{}, F{}); }
+        else       { if (full) body(F{}, F{}, T{}); else body(F{}, F{}, F{}); }
     }
 }
 
@@ -826,6 +863,627 @@ static hipError_t launch_block_fused2_t(const FusedArgs& a, const Geom& g, hipSt
     return hipGetLastError();
 }
 
+// ---- v3 of the fused block: wave-specialised.  A workgroup is 8 waves, two per SIMD: waves 0-3 only issue the
+// two MFMA stages (expansion of chunk p, projection of chunk p-2), waves 4-7 only run the depthwise stage (chunk
+// p-1) on the vector ALUs and stage the next projection weights into LDS.  ET / D / projection weights are
+// double-buffered, so the three stages of three consecutive chunks run in the same barrier phase: the matrix
+// pipe of every SIMD always has a wave with MFMA work while the VALU work of the other wave co-issues, and
+// there is one barrier per chunk instead of two.  (v2 alternates the stages inside every wave; with 2
+// workgroups per CU the phases overlap only by chance and the matrix pipe idles ~50 % of the time.)
+struct TileSplit { int first[4], count[4], maxc; };
+// halo M-tiles per MFMA wave: the split that minimises the largest per-wave MFMA count (stage-1 MFMAs + the
+// stage-3 MFMAs of the waves that own an output tile); ties go to the smaller register footprint (max tiles per wave)
+constexpr TileSplit split_tiles(int mt_in, int mt_out, int c1, int c3) {
+    TileSplit sp{};
+    long best = -1;
+    for (int n0 = 0; n0 <= mt_in; ++n0)
+        for (int n1 = 0; n0 + n1 <= mt_in; ++n1)
+            for (int n2 = 0; n0 + n1 + n2 <= mt_in; ++n2) {
+                const int cnt[4] = {n0, n1, n2, mt_in - n0 - n1 - n2};
+                int maxload = 0, maxc = 0;
+                long sq = 0;
+                for (int w = 0; w < 4; ++w) {
+                    const int load = cnt[w] * c1 + (w < mt_out ? c3 : 0);
+                    if (load > maxload) maxload = load;
+                    if (cnt[w] > maxc) maxc = cnt[w];
+                    sq += (long)load * load;
+                }
+                const long key = ((long)maxload * 64 + maxc) * 1000000 + sq;
+                if (best < 0 || key < best) {
+                    best = key;
+                    for (int w = 0; w < 4; ++w) sp.count[w] = cnt[w];
+                    sp.maxc = maxc;
+                }
+            }
+    int f = 0;
+    for (int w = 0; w < 4; ++w) { sp.first[w] = f; f += sp.count[w]; }
+    return sp;
+}
+
+template <int STRIDE, int NTO, int KQT, int TW>
+__global__ __launch_bounds__(512) void k_block_fused3(FusedArgs a, Geom g) {
+    constexpr int TH = 8;
+    constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3, IWP = (IW % 2 == 0) ? IW : (IW + 3) / 4 * 4, NPOS = IH * IWP;
+    constexpr int MT_IN = (NPOS + 31) / 32, OPIX = TH * TW, MT_OUT = OPIX / 32, CEP = 36;
+    constexpr int EP = ((MT_IN * 32 / 4) % 2 == 1) ? MT_IN * 32 : MT_IN * 32 + 4;   // per-channel stride, EP/4 odd
+    constexpr TileSplit SP = split_tiles(MT_IN, MT_OUT, KQT * 4, NTO * 16);
+    constexpr int MTW = SP.maxc;
+    static_assert(MT_OUT <= 4 && OPIX % 32 == 0 && MTW <= 5, "output tile / halo tile split");
+    __shared__ __attribute__((aligned(16))) float ET[2][32 * EP];
+    __shared__ __attribute__((aligned(16))) float D[2][OPIX * CEP];
+    __shared__ f32x4 WP[2][4 * NTO * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
+    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
+    const LevelGeom lv = g.lv[level];
+    const int tiles_x = (lv.Wo + TW - 1) / TW, tiles_y = (lv.Ho + TH - 1) / TH;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int oy0 = tyi * TH, ox0 = txi * TW;
+    const int iy0 = oy0 * STRIDE - lv.pt, ix0 = ox0 * STRIDE - lv.pl;
+    const long long in_base = lv.in_off + (long long)frame * lv.H * lv.W;
+    const long long out_base = lv.out_off + (long long)frame * lv.Ho * lv.Wo;
+    const int n_chunks = min(a.ex_nt_total, (a.cexp + 31) >> 5);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    if (wave < 4) {
+        // ================================================================ MFMA waves
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int mt_first = wave == 0 ? SP.first[0] : wave == 1 ? SP.first[1] : wave == 2 ? SP.first[2] : SP.first[3];
+        const int mt_count = wave == 0 ? SP.count[0] : wave == 1 ? SP.count[1] : wave == 2 ? SP.count[2] : SP.count[3];
+        f32x16 pacc[NTO];
+#pragma unroll
+        for (int nt = 0; nt < NTO; ++nt) pacc[nt] = zero16;
+        // block input: the A fragments of this wave's halo M-tiles stay in registers for all chunks
+        f32x4 afrag[MTW][KQT];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const int pp = (mt_first + m) * 32 + r;
+            const int hy = pp / IWP, hx = pp - hy * IWP;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool ok = m < mt_count && hy < IH && hx < IW && iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W;
+            const float* ap = a.X + (in_base + (long long)(ok ? iy * lv.W + ix : 0)) * a.cin + half * 4;
+#pragma unroll
+            for (int kq = 0; kq < KQT; ++kq) afrag[m][kq] = ok ? *(const f32x4*)(ap + kq * 8) : zero4;
+        }
+        f32x4 bcur[KQT], bnxt[KQT];
+        float sc, sh, scn = 0.f, shn = 0.f;
+#pragma unroll
+        for (int kq = 0; kq < KQT; ++kq) { bcur[kq] = a.Wex[((size_t)kq * a.ex_nt_total) * 64 + lane]; bnxt[kq] = zero4; }
+        sc = a.ex_scale[r]; sh = a.ex_shift[r];
+        for (int p = 0; p < n_chunks + 2; ++p) {
+            const int buf = p & 1;
+            if (p + 1 < n_chunks) {                                        // expansion weights of the next chunk
+#pragma unroll
+                for (int kq = 0; kq < KQT; ++kq) bnxt[kq] = a.Wex[((size_t)kq * a.ex_nt_total + p + 1) * 64 + lane];
+                scn = a.ex_scale[(p + 1) * 32 + r]; shn = a.ex_shift[(p + 1) * 32 + r];
+            }
+            if (p >= 2 && wave < MT_OUT) {                                 // stage 3: projection of chunk p-2
+                const int kqc = min(4, (a.cexp - (p - 2) * 32) >> 3);
+                const float* dp = D[buf] + (wave * 32 + r) * CEP + half * 4;
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) {
+                    if (kq < kqc) {
+                        const f32x4 av = *(const f32x4*)(dp + kq * 8);
+                        f32x4 bv[NTO];
+#pragma unroll
+                        for (int nt = 0; nt < NTO; ++nt) bv[nt] = WP[buf][(kq * NTO + nt) * 64 + lane];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], pacc[nt], 0, 0, 0);
+                    }
+                }
+            }
+            if (p < n_chunks) {                                            // stage 1: expansion of chunk p -> ET[buf]
+                float* et = ET[buf] + r * EP + 4 * half + mt_first * 32;
+                // straight-line code per tile count: the chain of tile m+1 is issued before the epilogue of tile m,
+                // so the BN / ReLU6 / LDS writes run in the shadow of the next tile's MFMAs
+                auto chain = [&](int m) {
+                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][0][0], bcur[0][0], zero16, 0, 0, 0);
+#pragma unroll
+                    for (int kq = 0; kq < KQT; ++kq)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (kq + t > 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][kq][t], bcur[kq][t], acc, 0, 0, 0);
+                    return acc;
+                };
+                auto epi = [&](int m, const f32x16& acc) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = relu6f(fmaf(acc[4 * q + i], sc, sh));
+                        *(f32x4*)(et + m * 32 + 8 * q) = v;               // out-of-image positions are masked by stage 2
+                    }
+                };
+                auto stage1 = [&](auto cnt) {
+                    constexpr int CNT = decltype(cnt)::value;
+                    if constexpr (CNT > 0 && CNT <= MTW) {
+                        f32x16 prev = chain(0);
+#pragma unroll
+                        for (int m = 1; m < CNT; ++m) {
+                            const f32x16 cur = chain(m);
+                            epi(m - 1, prev);
+                            prev = cur;
+                            // issue order inside this pair: one MFMA, then its share of the 32 epilogue VALU ops / 4 LDS writes
+                            constexpr int NM = KQT * 4, VPM = (32 + NM - 1) / NM, DSI = NM / 4;
+#pragma unroll
+                            for (int i = 0; i < NM; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                                if (i % DSI == DSI - 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                            }
+                        }
+                        epi(CNT - 1, prev);
+                    }
+                };
+                switch (mt_count) {
+                    case 1: stage1(std::integral_constant<int, 1>{}); break;
+                    case 2: stage1(std::integral_constant<int, 2>{}); break;
+                    case 3: stage1(std::integral_constant<int, 3>{}); break;
+                    case 4: stage1(std::integral_constant<int, 4>{}); break;
+                    case 5: stage1(std::integral_constant<int, 5>{}); break;
+                    default: break;
+                }
+            }
+            if (p + 1 < n_chunks) {
+#pragma unroll
+                for (int kq = 0; kq < KQT; ++kq) bcur[kq] = bnxt[kq];
+                sc = scn; sh = shn;
+            }
+            __syncthreads();
+        }
+        // ---- epilogue: BN (+ residual), store
+        if (wave < MT_OUT) {
+            float* obase = a.out + out_base * a.cout;
+            const float* rbase = a.X + in_base * a.cin;                    // residual: same spatial size, cin == cout
+            const bool full = oy0 + TH <= lv.Ho && ox0 + TW <= lv.Wo;
+            const int opl = wave * 32 + 4 * half;
+#pragma unroll
+            for (int nt = 0; nt < NTO; ++nt) {
+                const int col = nt * 32 + r;
+                if (col < a.cout) {
+                    const float psc = a.pr_scale[col], psh = a.pr_shift[col];
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int op = opl + (reg & 3) + 8 * (reg >> 2);
+                        const int oy = oy0 + op / TW, ox = ox0 + op % TW;
+                        if (full || (oy < lv.Ho && ox < lv.Wo)) {
+                            const int off = (oy * lv.Wo + ox) * a.cout + col;
+                            float v = fmaf(pacc[nt][reg], psc, psh);
+                            if (a.residual) v = v + rbase[off];
+                            obase[off] = v;
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        // ================================================================ depthwise waves
+        const int vt = threadIdx.x - 256, dc = vt & 31, doy = vt >> 5;    // role: (channel lane, output row)
+        const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= lv.H && ix0 + IW <= lv.W;
+        float dwt[9], dsc = 0.f, dsh = 0.f, dwn[9], dscn = 0.f, dshn = 0.f;
+        bool dact = false, dactn = false;
+        f32x4 preg[NTO];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { dwt[t] = 0.f; dwn[t] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < NTO; ++j) preg[j] = zero4;
+        for (int p = 0; p < n_chunks + 2; ++p) {
+            const bool work = p >= 1 && p <= n_chunks;
+            if (work) {                                                    // publish what was fetched one phase ago
+#pragma unroll
+                for (int j = 0; j < NTO; ++j) WP[(p - 1) & 1][vt + j * 256] = preg[j];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) dwt[t] = dwn[t];
+                dsc = dscn; dsh = dshn; dact = dactn;
+            }
+            if (p < n_chunks) {                                            // fetch chunk p: projection weights, depthwise taps / BN
+                const int kqc = min(4, (a.cexp - p * 32) >> 3);
+#pragma unroll
+                for (int j = 0; j < NTO; ++j) {
+                    const int idx = vt + j * 256, kq = idx / (NTO * 64);
+                    preg[j] = kq < kqc ? a.Wpr[(size_t)p * 4 * NTO * 64 + idx] : zero4;
+                }
+                const int dch = p * 32 + dc;
+                dactn = dch < a.cexp;
+                if (dactn) {
+                    const float* wdp = a.Wdw + dch;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) dwn[t] = wdp[t * a.cexp];
+                    dscn = a.dw_scale[dch]; dshn = a.dw_shift[dch];
+                }
+            }
+            if (work) {                                                    // stage 2 of chunk p-1: ET -> D
+                const int buf = (p - 1) & 1;
+                float row[3][IWP];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float* rp = ET[buf] + dc * EP + (doy * STRIDE + ky) * IWP;
+                    if constexpr (IWP % 4 == 0) {
+#pragma unroll
+                        for (int qx = 0; qx < IWP / 4; ++qx) {
+                            const f32x4 v = *(const f32x4*)(rp + qx * 4);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) row[ky][qx * 4 + j] = v[j];
+                        }
+                    } else {
+#pragma unroll
+                        for (int qx = 0; qx < IWP / 2; ++qx) {
+                            const float2 v = *(const float2*)(rp + qx * 2);
+                            row[ky][qx * 2] = v.x; row[ky][qx * 2 + 1] = v.y;
+                        }
+                    }
+                }
+                if (!interior) {
+                    // the expansion of an out-of-image halo position must count as 0 ('SAME' padding of the depthwise conv)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const bool rok = (unsigned)(iy0 + doy * STRIDE + ky) < (unsigned)lv.H;
+#pragma unroll
+                        for (int x = 0; x < IW; ++x) row[ky][x] = (rok && (unsigned)(ix0 + x) < (unsigned)lv.W) ? row[ky][x] : 0.0f;
+                    }
+                }
+                float* dp = D[buf] + (doy * TW) * CEP + dc;
+#pragma unroll
+                for (int ox = 0; ox < TW; ++ox) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) acc = fmaf(row[ky][ox * STRIDE + kx], dwt[ky * 3 + kx], acc);
+                    dp[ox * CEP] = dact ? relu6f(fmaf(acc, dsc, dsh)) : 0.0f;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- v3p: the same wave-specialised pipeline, persistent over tiles.  One workgroup per CU walks tiles
+// b, b + gridDim.x, ...; the global phase counter keeps running across tile boundaries, so the expansion of the
+// next tile's first chunks runs while the projection of the previous tile drains (a tile costs n_chunks phases
+// instead of n_chunks + 2), the next tile's input fragments are prefetched a whole tile ahead and the BN / store
+// epilogue overlaps the next tile's MFMAs.
+struct TileGeo {
+    int oy0, ox0, iy0, ix0, H, W, Ho, Wo;
+    long long in_base, out_base;
+};
+template <int STRIDE, int TH, int TW>
+__device__ __forceinline__ TileGeo decode_tile(const Geom& g, int t) {
+    int l = 0, rem = t, tx = 1, per = 1;
+    for (;; ++l) {
+        tx = (g.lv[l].Wo + TW - 1) / TW;
+        per = tx * ((g.lv[l].Ho + TH - 1) / TH);
+        if (l == g.n_levels - 1 || rem < per * g.batch) break;
+        rem -= per * g.batch;
+    }
+    const LevelGeom lv = g.lv[l];
+    const int frame = rem / per, tile = rem - frame * per;
+    const int tyi = tile / tx, txi = tile - tyi * tx;
+    TileGeo o;
+    o.oy0 = tyi * TH; o.ox0 = txi * TW;
+    o.iy0 = o.oy0 * STRIDE - lv.pt; o.ix0 = o.ox0 * STRIDE - lv.pl;
+    o.H = lv.H; o.W = lv.W; o.Ho = lv.Ho; o.Wo = lv.Wo;
+    o.in_base = lv.in_off + (long long)frame * lv.H * lv.W;
+    o.out_base = lv.out_off + (long long)frame * lv.Ho * lv.Wo;
+    return o;
+}
+
+template <int STRIDE, int NTO, int KQT, int TW, bool RESID>
+__global__ __launch_bounds__(512) void k_block_fused3p(FusedArgs a, Geom g, int total_tiles) {
+    constexpr int TH = 8;
+    constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3, IWP = (IW % 2 == 0) ? IW : (IW + 3) / 4 * 4, NPOS = IH * IWP;
+    constexpr int MT_IN = (NPOS + 31) / 32, OPIX = TH * TW, MT_OUT = OPIX / 32, CEP = 36;
+    constexpr int EP = ((MT_IN * 32 / 4) % 2 == 1) ? MT_IN * 32 : MT_IN * 32 + 4;
+    constexpr TileSplit SP = split_tiles(MT_IN, MT_OUT, KQT * 4, NTO * 16);
+    constexpr int MTW = SP.maxc;
+    static_assert(MT_OUT <= 4 && OPIX % 32 == 0 && MTW <= 5, "output tile / halo tile split");
+    __shared__ __attribute__((aligned(16))) float ET[2][32 * EP];
+    __shared__ __attribute__((aligned(16))) float D[2][OPIX * CEP];
+    __shared__ f32x4 WP[2][4 * NTO * 64];      // projection weights of a chunk (B fragments, [kq][nt][lane])
+    __shared__ f32x4 WB[2][KQT * 64];          // expansion weights of a chunk ([kq][lane])
+    __shared__ float WS[2][64];                // expansion BN scale [0..31] / shift [32..63] of a chunk
+    const int lane = threadIdx.x & 63, hw_wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
+    // role mapping experiment (ablate bit 4): MFMA waves = even hardware waves instead of waves 0-3
+    const bool alt = (a.ablate & 16) != 0;
+    const bool is_mfma = alt ? !(hw_wave & 1) : hw_wave < 4;
+    const int wave = alt ? (hw_wave >> 1) : (hw_wave & 3);
+    const int n = min(a.ex_nt_total, (a.cexp + 31) >> 5);                         // chunks per tile
+    const int m_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (m_tiles <= 0) return;
+    const int n_phases = m_tiles * n + 2;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    if (is_mfma) {
+        // ================================================================ MFMA waves
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int mt_first = wave == 0 ? SP.first[0] : wave == 1 ? SP.first[1] : wave == 2 ? SP.first[2] : SP.first[3];
+        const int mt_count = wave == 0 ? SP.count[0] : wave == 1 ? SP.count[1] : wave == 2 ? SP.count[2] : SP.count[3];
+        f32x16 pacc[NTO];
+#pragma unroll
+        for (int nt = 0; nt < NTO; ++nt) pacc[nt] = zero16;
+        f32x4 afrag[MTW][KQT], anext[MTW][KQT];
+        auto load_a = [&](int tile_id) {
+            const TileGeo tg = decode_tile<STRIDE, TH, TW>(g, tile_id);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int pp = (mt_first + m) * 32 + r;
+                const int hy = pp / IWP, hx = pp - hy * IWP;
+                const int iy = tg.iy0 + hy, ix = tg.ix0 + hx;
+                const bool ok = m < mt_count && hy < IH && hx < IW && iy >= 0 && iy < tg.H && ix >= 0 && ix < tg.W;
+                const float* ap = a.X + (tg.in_base + (long long)(ok ? iy * tg.W + ix : 0)) * a.cin + half * 4;
+#pragma unroll
+                for (int kq = 0; kq < KQT; ++kq) anext[m][kq] = ok ? *(const f32x4*)(ap + kq * 8) : zero4;
+            }
+        };
+        load_a(blockIdx.x);
+        __syncthreads();                                                   // WB[0] / WS[0] published by the depthwise waves
+        int t1 = 0, c1 = 0;          // stage-1 position (tile, chunk) of this phase
+        int t3 = 0, c3 = 0;          // stage-3 position, valid from phase 2 on
+        for (int ph = 0; ph < n_phases; ++ph) {
+            const int buf = ph & 1;
+            const bool s1 = t1 < m_tiles;
+            if (s1 && c1 == 0) {                                           // new tile: take the prefetched input, prefetch the next one
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int kq = 0; kq < KQT; ++kq) afrag[m][kq] = anext[m][kq];
+                if (t1 + 1 < m_tiles) load_a(blockIdx.x + (t1 + 1) * gridDim.x);
+            }
+            f32x4 resid[RESID ? NTO : 1][4];                             // residual of the tile that completes in this phase
+            const bool last3 = ph >= 2 && c3 == n - 1;
+            TileGeo tg3;
+            if (last3) tg3 = decode_tile<STRIDE, TH, TW>(g, blockIdx.x + t3 * gridDim.x);
+            if (RESID && last3 && wave < MT_OUT) {
+                const float* rbase = a.X + tg3.in_base * a.cin;            // same spatial size, cin == cout
+                const int opl = wave * 32 + 4 * half;
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int op = opl + (reg & 3) + 8 * (reg >> 2);
+                        const int oy = min(tg3.oy0 + op / TW, tg3.Ho - 1), ox = min(tg3.ox0 + op % TW, tg3.Wo - 1);
+                        const int col = min(nt * 32 + r, a.cout - 1);
+                        resid[RESID ? nt : 0][reg >> 2][reg & 3] = rbase[(oy * tg3.Wo + ox) * a.cout + col];
+                    }
+            }
+            if (ph >= 2 && wave < MT_OUT && !(a.ablate & 4)) {            // stage 3: projection of chunk c3 of tile t3
+                const int kqc = min(4, (a.cexp - c3 * 32) >> 3);
+                const float* dp = D[buf] + (wave * 32 + r) * CEP + half * 4;
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) {
+                    if (kq < kqc) {
+                        const f32x4 av = *(const f32x4*)(dp + kq * 8);
+                        f32x4 bv[NTO];
+#pragma unroll
+                        for (int nt = 0; nt < NTO; ++nt) bv[nt] = WP[buf][(kq * NTO + nt) * 64 + lane];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], pacc[nt], 0, 0, 0);
+                    }
+                }
+            }
+            if (s1 && !(a.ablate & 1)) {                                   // stage 1: expansion of chunk c1 of tile t1 -> ET[buf]
+                float* et = ET[buf] + r * EP + 4 * half + mt_first * 32;
+                f32x4 bcur[KQT];
+#pragma unroll
+                for (int kq = 0; kq < KQT; ++kq) bcur[kq] = WB[buf][kq * 64 + lane];
+                const float sc = WS[buf][r], sh = WS[buf][32 + r];
+                auto chain = [&](int m) {
+                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][0][0], bcur[0][0], zero16, 0, 0, 0);
+#pragma unroll
+                    for (int kq = 0; kq < KQT; ++kq)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (kq + t > 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][kq][t], bcur[kq][t], acc, 0, 0, 0);
+                    return acc;
+                };
+                auto epi = [&](int m, const f32x16& acc) {
+                    if (a.ablate & 32) { if (acc[0] == 1234.5f) et[m] = acc[1]; return; }    // diagnostics: MFMA chains only
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = relu6f(fmaf(acc[4 * q + i], sc, sh));
+                        *(f32x4*)(et + m * 32 + 8 * q) = v;
+                    }
+                };
+                auto stage1 = [&](auto cnt) {
+                    constexpr int CNT = decltype(cnt)::value;
+                    if constexpr (CNT > 0 && CNT <= MTW) {
+                        f32x16 prev = chain(0);
+#pragma unroll
+                        for (int m = 1; m < CNT; ++m) {
+                            const f32x16 cur = chain(m);
+                            epi(m - 1, prev);
+                            prev = cur;
+                            constexpr int NM = KQT * 4, VPM = (32 + NM - 1) / NM, DSI = NM / 4;
+#pragma unroll
+                            for (int i = 0; i < NM; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                                if (i % DSI == DSI - 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                            }
+                        }
+                        epi(CNT - 1, prev);
+                    }
+                };
+                switch (mt_count) {
+                    case 1: stage1(std::integral_constant<int, 1>{}); break;
+                    case 2: stage1(std::integral_constant<int, 2>{}); break;
+                    case 3: stage1(std::integral_constant<int, 3>{}); break;
+                    case 4: stage1(std::integral_constant<int, 4>{}); break;
+                    case 5: stage1(std::integral_constant<int, 5>{}); break;
+                    default: break;
+                }
+            }
+            if (last3 && wave < MT_OUT) {                                  // tile t3 complete: BN (+ residual), store, reset
+                float* obase = a.out + tg3.out_base * a.cout;
+                const bool full = tg3.oy0 + TH <= tg3.Ho && tg3.ox0 + TW <= tg3.Wo;
+                const int opl = wave * 32 + 4 * half;
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) {
+                    const int col = nt * 32 + r;
+                    if (col < a.cout && !(a.ablate & 8)) {
+                        const float psc = a.pr_scale[col], psh = a.pr_shift[col];
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int op = opl + (reg & 3) + 8 * (reg >> 2);
+                            const int oy = tg3.oy0 + op / TW, ox = tg3.ox0 + op % TW;
+                            if (full || (oy < tg3.Ho && ox < tg3.Wo)) {
+                                float v = fmaf(pacc[nt][reg], psc, psh);
+                                if (RESID) v = v + resid[RESID ? nt : 0][reg >> 2][reg & 3];
+                                obase[(oy * tg3.Wo + ox) * a.cout + col] = v;
+                            }
+                        }
+                    }
+                    pacc[nt] = zero16;
+                }
+            }
+            if (s1) { if (++c1 == n) { c1 = 0; ++t1; } }
+            if (ph >= 2) { if (++c3 == n) { c3 = 0; ++t3; } }
+            __syncthreads();
+        }
+    } else {
+        // ================================================================ depthwise waves
+        const int vt = wave * 64 + lane, dc = vt & 31, doy = vt >> 5;    // role: (channel lane, output row)
+        float dwt[9], dsc = 0.f, dsh = 0.f, dwn[9], dscn = 0.f, dshn = 0.f;
+        bool dact = false, dactn = false;
+        f32x4 preg[NTO];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { dwt[t] = 0.f; dwn[t] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < NTO; ++j) preg[j] = zero4;
+        int t2 = 0, c2 = 0;          // stage-2 position, valid from phase 1 on
+        int cf = 0;                  // chunk whose projection / depthwise weights are fetched in this phase (the stage-1 chunk)
+        // expansion weights run two phases ahead of their stage 1: fetched at ph-2, published at ph-1 into WB[ph & 1]
+        constexpr int BJ = (KQT * 64 + 255) / 256;
+        f32x4 breg[BJ];
+        float sreg = 0.f;
+        auto fetch_b = [&](int chunk) {
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const int idx = vt + j * 256, kq = idx >> 6, ln = idx & 63;
+                breg[j] = idx < KQT * 64 ? a.Wex[((size_t)kq * a.ex_nt_total + chunk) * 64 + ln] : zero4;
+            }
+            if (vt < 64) sreg = vt < 32 ? a.ex_scale[chunk * 32 + vt] : a.ex_shift[chunk * 32 + vt - 32];
+        };
+        auto publish_b = [&](int b) {
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) { const int idx = vt + j * 256; if (idx < KQT * 64) WB[b][idx] = breg[j]; }
+            if (vt < 64) WS[b][vt] = sreg;
+        };
+        fetch_b(0); publish_b(0);
+        int cb = n > 1 ? 1 : 0;      // chunk fetched next
+        fetch_b(cb); if (++cb == n) cb = 0;
+        __syncthreads();
+        int iy0 = 0, ix0 = 0, H = 0, W = 0;
+        bool interior = true;
+        for (int ph = 0; ph < n_phases; ++ph) {
+            const bool work = ph >= 1 && ph <= m_tiles * n;
+            publish_b((ph + 1) & 1);                                       // expansion weights of the next phase's chunk
+            fetch_b(cb); if (++cb == n) cb = 0;
+            if (work) {                                                    // publish what was fetched one phase ago
+#pragma unroll
+                for (int j = 0; j < NTO; ++j) WP[(ph - 1) & 1][vt + j * 256] = preg[j];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) dwt[t] = dwn[t];
+                dsc = dscn; dsh = dshn; dact = dactn;
+                if (c2 == 0) {
+                    const TileGeo tg = decode_tile<STRIDE, TH, TW>(g, blockIdx.x + t2 * gridDim.x);
+                    iy0 = tg.iy0; ix0 = tg.ix0; H = tg.H; W = tg.W;
+                    interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= H && ix0 + IW <= W;
+                }
+            }
+            if (ph < m_tiles * n) {                                        // fetch chunk cf: projection weights, depthwise taps / BN
+                const int kqc = min(4, (a.cexp - cf * 32) >> 3);
+#pragma unroll
+                for (int j = 0; j < NTO; ++j) {
+                    const int idx = vt + j * 256, kq = idx / (NTO * 64);
+                    preg[j] = kq < kqc ? a.Wpr[(size_t)cf * 4 * NTO * 64 + idx] : zero4;
+                }
+                const int dch = cf * 32 + dc;
+                dactn = dch < a.cexp;
+                if (dactn) {
+                    const float* wdp = a.Wdw + dch;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) dwn[t] = wdp[t * a.cexp];
+                    dscn = a.dw_scale[dch]; dshn = a.dw_shift[dch];
+                }
+                if (++cf == n) cf = 0;
+            }
+            if (work && !(a.ablate & 2)) {                                 // stage 2 of chunk c2 of tile t2: ET -> D
+                const int buf = (ph - 1) & 1;
+                float row[3][IWP];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float* rp = ET[buf] + dc * EP + (doy * STRIDE + ky) * IWP;
+                    if constexpr (IWP % 4 == 0) {
+#pragma unroll
+                        for (int qx = 0; qx < IWP / 4; ++qx) {
+                            const f32x4 v = *(const f32x4*)(rp + qx * 4);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) row[ky][qx * 4 + j] = v[j];
+                        }
+                    } else {
+#pragma unroll
+                        for (int qx = 0; qx < IWP / 2; ++qx) {
+                            const float2 v = *(const float2*)(rp + qx * 2);
+                            row[ky][qx * 2] = v.x; row[ky][qx * 2 + 1] = v.y;
+                        }
+                    }
+                }
+                if (!interior) {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const bool rok = (unsigned)(iy0 + doy * STRIDE + ky) < (unsigned)H;
+#pragma unroll
+                        for (int x = 0; x < IW; ++x) row[ky][x] = (rok && (unsigned)(ix0 + x) < (unsigned)W) ? row[ky][x] : 0.0f;
+                    }
+                }
+                float* dp = D[buf] + (doy * TW) * CEP + dc;
+#pragma unroll
+                for (int ox = 0; ox < TW; ++ox) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) acc = fmaf(row[ky][ox * STRIDE + kx], dwt[ky * 3 + kx], acc);
+                    dp[ox * CEP] = dact ? relu6f(fmaf(acc, dsc, dsh)) : 0.0f;
+                }
+            }
+            if (work) { if (++c2 == n) { c2 = 0; ++t2; } }
+            __syncthreads();
+        }
+    }
+}
+
+template <int STRIDE, int NTO, int KQT, int TW>
+static hipError_t launch_block_fused3p_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
+    if (a.residual && (a.cin != a.cout || STRIDE != 1)) return hipErrorInvalidValue;
+    constexpr int TH = 8;
+    int total = 0;
+    for (int l = 0; l < g.n_levels; ++l) total += ((g.lv[l].Wo + TW - 1) / TW) * ((g.lv[l].Ho + TH - 1) / TH) * g.batch;
+    static const int n_cu = []() { const char* v = getenv("HFNET_FUSE3_WGS"); return v ? atoi(v) : 256; }();
+    const int grid = total < n_cu ? total : n_cu;
+    if (grid <= 0) return hipSuccess;
+    if (a.residual) hipLaunchKernelGGL((k_block_fused3p<STRIDE, NTO, KQT, TW, true>), dim3(grid), dim3(512), 0, s, a, g, total);
+    else hipLaunchKernelGGL((k_block_fused3p<STRIDE, NTO, KQT, TW, false>), dim3(grid), dim3(512), 0, s, a, g, total);
+    return hipGetLastError();
+}
+
+template <int STRIDE, int NTO, int KQT, int TW>
+static hipError_t launch_block_fused3_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
+    constexpr int TH = 8;
+    int maxtiles = 0;
+    for (int l = 0; l < g.n_levels; ++l) maxtiles = max(maxtiles, ((g.lv[l].Wo + TW - 1) / TW) * ((g.lv[l].Ho + TH - 1) / TH));
+    dim3 grid(maxtiles, g.n_levels * g.batch);
+    hipLaunchKernelGGL((k_block_fused3<STRIDE, NTO, KQT, TW>), grid, dim3(512), 0, s, a, g);
+    return hipGetLastError();
+}
+
 // ---- layer_2 (expanded_conv with expansion factor 1: no expand conv, hf_net.py:31-33): depthwise 3x3 +
 // BN + ReLU6 on CIN channels, then the 1x1 projection CIN -> COUT + BN, stride 1.  Its tensors are the
 // largest of the network (1/2 resolution) and its arithmetic the smallest: one thread per output pixel on
@@ -1063,6 +1721,27 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
         hipLaunchKernelGGL((k_block_noexpand<24, 16>), dim3(maxtiles, g.n_levels * g.batch), dim3(256), 0, s, a.X, a.out, a.Wdw, a.dw_scale,
                            a.dw_shift, (const float*)b.pr_logical, a.pr_scale, a.pr_shift, g);
         return hipGetLastError();
+    }
+    const bool use_v3 = []() { const char* v = getenv("HFNET_FUSE_V3"); return v ? atoi(v) != 0 : false; }();   // experiment; read per launch so tests can switch it
+    if (use_v3 && b.has_expand && b.pr.nt_total == nto) {
+        const int kq = b.cin / 8, st = b.stride;
+        const int tw3 = []() { const char* v = getenv("HFNET_FUSE3_S2_TW"); return v ? atoi(v) : 12; }();
+        const bool persist = []() { const char* v = getenv("HFNET_FUSE3_PERSIST"); return v ? atoi(v) != 0 : true; }();
+        if (persist) {
+            if (st == 2 && kq == 2 && nto == 1) return launch_block_fused3p_t<2, 1, 2, 8>(a, g, s);     // (8x12 tiles do not fit the LDS)
+            if (st == 2 && kq == 3 && nto == 1) return launch_block_fused3p_t<2, 1, 3, 8>(a, g, s);
+            if (st == 1 && kq == 3 && nto == 1) return launch_block_fused3p_t<1, 1, 3, 16>(a, g, s);
+            if (st == 1 && kq == 3 && nto == 2) return launch_block_fused3p_t<1, 2, 3, 16>(a, g, s);
+            if (st == 1 && kq == 6 && nto == 3) return launch_block_fused3p_t<1, 3, 6, 16>(a, g, s);
+            if (st == 1 && kq == 6 && nto == 2) return launch_block_fused3p_t<1, 2, 6, 16>(a, g, s);
+        }
+        if (st == 2 && kq == 2 && nto == 1) return tw3 == 12 ? launch_block_fused3_t<2, 1, 2, 12>(a, g, s) : launch_block_fused3_t<2, 1, 2, 8>(a, g, s);
+        if (st == 2 && kq == 3 && nto == 1) return tw3 == 12 ? launch_block_fused3_t<2, 1, 3, 12>(a, g, s) : launch_block_fused3_t<2, 1, 3, 8>(a, g, s);
+        if (st == 1 && kq == 3 && nto == 1) return launch_block_fused3_t<1, 1, 3, 16>(a, g, s);
+        if (st == 1 && kq == 3 && nto == 2) return launch_block_fused3_t<1, 2, 3, 16>(a, g, s);
+        if (st == 1 && kq == 6 && nto == 3) return launch_block_fused3_t<1, 3, 6, 16>(a, g, s);
+        if (st == 1 && kq == 6 && nto == 2) return launch_block_fused3_t<1, 2, 6, 16>(a, g, s);
+        if (st == 1 && kq == 9 && nto == 3) return launch_block_fused3_t<1, 3, 9, 16>(a, g, s);
     }
     if (use_v2) {
         const int kq = b.cin / 8, st = b.stride;

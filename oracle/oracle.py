@@ -31,12 +31,36 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def usable_cpus(cap: int = 32) -> int:
+    """CPUs this process may really use: the scheduler affinity AND the cgroup quota (a container that sees 256
+    CPUs but is throttled to 16 makes an OpenMP team of 256 crawl), capped at `cap`."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(parts[0]) // int(parts[1])))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, q // int(f.read().split()[0])))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, cap))
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         L = C.CDLL(_LIB_PATH)
+        L.hfo_set_threads(usable_cpus())
         fp, u8p, i32p, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_void_p
         L.hfo_model_load.restype = vp
         L.hfo_model_load.argtypes = [C.c_char_p]

@@ -24,7 +24,10 @@ SIZES = [(64, 96), (120, 160), (133, 171)]   # the last one exercises the crop t
 
 
 VARIANTS = {"default": {}, "unfused_dense": {"HFNET_FUSE_BLOCKS": "0", "HFNET_DENSE_DESC": "1"},
-            "fuse_all": {"HFNET_FUSE_MAX_LAYER": "18"}}
+            "fuse_all": {"HFNET_FUSE_MAX_LAYER": "18"},
+            # wave-specialised (persistent) fused blocks: slower than v2 on gfx950 (f32 MFMA and VALU share one pipe), kept opt-in
+            "fuse_v3": {"HFNET_FUSE_V3": "1", "HFNET_FUSE_MAX_LAYER": "18"},
+            "fuse_v3_np": {"HFNET_FUSE_V3": "1", "HFNET_FUSE3_PERSIST": "0", "HFNET_FUSE3_S2_TW": "12"}}
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
