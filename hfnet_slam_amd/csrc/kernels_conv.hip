@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256, 2) void k_pointwise(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
     const int KQ = a.cin >> 3;
-    // software pipeline: the loads of step kq+1 are issued before the MFMAs of step kq
+    // software pipeline: the loads of step kq+1 are issued before the MFMAs of step kq.  (A three-buffer, distance-2
+    // pipeline as in k_conv3x3 was measured slower here: these kernels have short k loops and live on occupancy.)
     f32x4 av = *(const f32x4*)(ap);
     f32x4 bv[NT];
 #pragma unroll
@@ -355,36 +356,83 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g, TapArgs 
         tap_ok[tap] = pvalid && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc;
         tap_ptr[tap] = a.A + (in_base + (long long)(tap_ok[tap] ? iy * Wc + ix : 0)) * a.cin + half * 4;
     }
-    // software pipeline over the flattened (tap, kq) loop
-    f32x4 av = tap_ok[0] ? *(const f32x4*)(tap_ptr[0]) : zero;
-    f32x4 bv[NT];
+    // Software pipeline over the flattened (tap, kq) steps, prefetch distance 2: three operand buffers rotate in a
+    // kq loop unrolled by three (no register copies -- a copy would make the compiler wait for the load it was
+    // just issued), so a step's operands were requested two steps (32 MFMAs, ~2000 cycles) earlier: an L2 hit
+    // takes 0.7-1 us on this part.
+    // Loads are unconditional (tap_ptr of an out-of-image tap points at a valid pixel) and the zero of a skipped tap is
+    // selected when the operand is used: a load under a branch ends up in a temporary + copies + an early wait.
+    auto issue = [&](const float* tp, int kq, size_t wrow, f32x4& av_d, f32x4 (&bv_d)[NT]) {
+        av_d = *(const f32x4*)(tp + kq * 8);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bv[nt] = wp[(size_t)nt * 64];
+        for (int nt = 0; nt < NT; ++nt) bv_d[nt] = wp[wrow + (size_t)nt * 64];
+    };
+    auto mfma16 = [&](const f32x4& av_u, bool ok, const f32x4 (&bv_u)[NT]) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        for (int kq = 0; kq < KQ; ++kq) {
-            f32x4 av_n = zero;
-            f32x4 bv_n[NT];
-            const bool last = (tap == 8) && (kq + 1 == KQ);
-            const bool wrap = (kq + 1 == KQ);
-            const int tap_n = wrap ? (tap < 8 ? tap + 1 : 8) : tap;
-            const int kq_n = wrap ? 0 : kq + 1;
-            if (!last) {
-                if (tap_ok[tap_n]) av_n = *(const f32x4*)(tap_ptr[tap_n] + kq_n * 8);
-                const size_t wrow = (size_t)(tap_n * KQ + kq_n) * wstep;
+        for (int t = 0; t < 4; ++t) {
+            const float x = ok ? av_u[t] : 0.0f;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv_n[nt] = wp[wrow + (size_t)nt * 64];
-            } else {
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, bv_u[nt][t], acc[nt], 0, 0, 0);
+        }
+    };
+    if (KQ % 3 == 0) {
+        f32x4 a0, a1, a2, b0[NT], b1[NT], b2[NT];
+        bool o0 = tap_ok[0], o1 = tap_ok[0], o2 = false;
+        issue(tap_ptr[0], 0, 0, a0, b0);
+        issue(tap_ptr[0], 1, wstep, a1, b1);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv_n[nt] = bv[nt];
+        for (int tap = 0; tap < 9; ++tap) {
+            const int tn = tap < 8 ? tap + 1 : 8;
+            for (int kq = 0; kq < KQ; kq += 3) {
+                const bool wrap = kq + 3 == KQ;                         // the steps after kq + 2 belong to the next tap
+                const bool more = !(wrap && tap == 8);                  // (the last two prefetches re-read step 0: harmless)
+                const float* tpn = wrap ? tap_ptr[tn] : tap_ptr[tap];
+                const bool okn = wrap ? tap_ok[tn] : tap_ok[tap];
+                const int kn = (wrap || !more) ? 0 : kq + 3;
+                const size_t wn = more ? (size_t)((wrap ? tn : tap) * KQ + kn) * wstep : 0;
+                // sched_barrier: the machine scheduler otherwise sinks the loads down to their first use
+                issue(tap_ptr[tap], kq + 2, (size_t)(tap * KQ + kq + 2) * wstep, a2, b2); o2 = tap_ok[tap];
+                __builtin_amdgcn_sched_barrier(0);
+                mfma16(a0, o0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                issue(tpn, kn, wn, a0, b0); o0 = okn;
+                __builtin_amdgcn_sched_barrier(0);
+                mfma16(a1, o1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                issue(tpn, kn + 1, wn + wstep, a1, b1); o1 = okn;
+                __builtin_amdgcn_sched_barrier(0);
+                mfma16(a2, o2, b2);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        }
+    } else {
+        f32x4 av = tap_ok[0] ? *(const f32x4*)(tap_ptr[0]) : zero;
+        f32x4 bv[NT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = wp[(size_t)nt * 64];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], acc[nt], 0, 0, 0);
-            av = av_n;
+        for (int tap = 0; tap < 9; ++tap) {
+            for (int kq = 0; kq < KQ; ++kq) {
+                f32x4 av_n = zero;
+                f32x4 bv_n[NT];
+                const bool last = (tap == 8) && (kq + 1 == KQ);
+                const bool wrap = (kq + 1 == KQ);
+                const int tap_n = wrap ? (tap < 8 ? tap + 1 : 8) : tap;
+                const int kq_n = wrap ? 0 : kq + 1;
+                if (!last) {
+                    if (tap_ok[tap_n]) av_n = *(const f32x4*)(tap_ptr[tap_n] + kq_n * 8);
+                    const size_t wrow = (size_t)(tap_n * KQ + kq_n) * wstep;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
+                    for (int nt = 0; nt < NT; ++nt) bv_n[nt] = wp[wrow + (size_t)nt * 64];
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv_n[nt] = bv[nt];
+                }
+                mfma16(av, true, bv);
+                av = av_n;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
+            }
         }
     }
     conv_epilogue<NT>(a, acc, nt0, out_base + p0, out_base + nrows, half, r);
