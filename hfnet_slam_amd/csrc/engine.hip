@@ -155,6 +155,8 @@ int Net::build(Engine* eng, const NetConfig& c) {
         HF_TRY(dalloc(allocs, &logits, pc * 65));
         HF_TRY(dalloc(allocs, &dense, pi));
         HF_TRY(dalloc(allocs, &nms, pi));
+        HF_TRY(dalloc(allocs, &nms_mask, pi + 16));
+        HF_TRY(dalloc(allocs, &nms_flags, pi + 16));
         cand_stride = 0;
         for (int l = 0; l < c.n_levels; ++l) cand_stride = std::max(cand_stride, (long long)lp[l].Hc * lp[l].Wc);
         const size_t images = (size_t)c.n_levels * c.batch;
@@ -272,7 +274,7 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         Geom gn = gd;
         for (int l = 0; l < NL; ++l) { gn.lv[l].H = lp[l].Hc; gn.lv[l].W = lp[l].Wc; gn.lv[l].in_off = pix_img[l]; }
         HF_HIP(hipMemsetAsync(counters, 0, sizeof(unsigned int) * (size_t)NL * cfg.batch, stream));
-        HF_LAUNCH(e, stream, "nms", launch_nms(dense, nms, cand, counters, cand_stride, threshold, gn, stream));
+        HF_LAUNCH(e, stream, "nms", launch_nms(dense, nms, nms_mask, nms_flags, cand, counters, cand_stride, threshold, gn, stream));
         HF_LAUNCH(e, stream, "topk", launch_topk(cand, counters, cand_stride, budget, kps_level, cfg.max_keypoints, n_level, gn, stream));
         // Descriptor head.  Only the 4 bilinear taps of every selected keypoint are ever read
         // (HFNetTFModelV2.cc:153-167), so unless the budget covers most of the cell grid the head is

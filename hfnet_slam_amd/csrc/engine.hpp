@@ -72,6 +72,7 @@ struct Net {
     int fuse_max_layer = 14;
     int fuse_stem = 0;             // stem + layer_2 in one launch (the layer_1 tap is then unavailable)
     float *dense = nullptr, *nms = nullptr;
+    uint8_t *nms_mask = nullptr, *nms_flags = nullptr;   // byte maps of the NMS passes
     unsigned long long* cand = nullptr;
     unsigned int* counters = nullptr;
     long long cand_stride = 0;

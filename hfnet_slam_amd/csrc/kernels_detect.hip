@@ -65,152 +65,198 @@ hipError_t launch_softmax_d2s(const float* logits, int ld, float* dense, const G
 }
 
 // =========================================================================== simple_nms + candidates
-// layers.py:10-32 with radius 4, iterations 2 (export_model.py:35,37): three dependent 9x9 max-pools.
-// A workgroup produces a 32x32 output tile from a 56x56 LDS tile (halo 3*4), each pool done
-// separably (row max, column max).  Out-of-image cells are -inf (max_pool 'SAME' ignores them).
-// Survivors with score >= threshold are appended to the image's candidate list as 64-bit keys
-//   (~score_bits << 32) | (col * H + row)
-// so ascending key order == (response descending, column-major index ascending).
-#define NMS_T 32
-#define NMS_R 4
-#define NMS_S 56   // NMS_T + 6 * NMS_R
+// layers.py:10-32 with radius 4, iterations 2 (export_model.py:35,37): three dependent 9x9 max-pools,
+//   max_mask = scores == pool(scores); supp = pool(max_mask) > 0; ss = supp ? 0 : scores;
+//   out = (max_mask | (ss == pool(ss) & !supp)) ? scores : 0            (out-of-image cells never win a max: -inf)
+// Three streaming passes without LDS tiles or barriers.  A wave owns a 64-column x 40-row window of the map:
+// every lane loads its column (40 coalesced row reads in flight), takes the vertical 9-max of 32 rows in
+// registers (22 max per 8 rows), and the horizontal 9-max comes from four wave shuffles per row.  Pass 1
+// writes the max_mask as bytes, pass 2 dilates it as packed bytes (4 columns per lane, integer ORs and
+// v_alignbyte) into a flag byte {bit0 max_mask, bit1 supp}, pass 3 rebuilds ss on the fly, pools it and emits
+// the map plus the candidate keys  (~score_bits << 32) | (col * H + row)  -- ascending key order ==
+// (response descending, column-major index ascending).  One global atomic per wave tile.
+#define NMS_RB 32          // output rows of a wave tile (+ 8 halo rows)
+#define NMS_CW 56          // output columns of a float wave tile (64 lanes - 2 * 4 halo)
+#define NMS_PW 248         // output columns of a packed-byte wave tile (62 words of 4)
 
-// sliding 9-max over 16 consecutive values -> 8 outputs: out[i] = max(v[i..i+8]) as
-// max(suffix-max of v[i..7], prefix-max of v[8..i+8]): 22 max operations instead of 64
-__device__ __forceinline__ void max9_strip(const float (&v)[16], float (&o)[8]) {
+// o[i] = max(v[OFF + i .. OFF + i + 8]) for i < 8: suffix maxima of the first 8, prefix maxima of the next 8
+template <int OFF, int NIN>
+__device__ __forceinline__ void max9_strip_at(const float (&v)[NIN], float* o) {
     float sfx[8], pfx[8];
-    sfx[7] = v[7];
+    sfx[7] = v[OFF + 7];
 #pragma unroll
-    for (int i = 6; i >= 0; --i) sfx[i] = fmaxf(v[i], sfx[i + 1]);
-    pfx[0] = v[8];
+    for (int i = 6; i >= 0; --i) sfx[i] = fmaxf(v[OFF + i], sfx[i + 1]);
+    pfx[0] = v[OFF + 8];
 #pragma unroll
-    for (int i = 1; i < 8; ++i) pfx[i] = fmaxf(pfx[i - 1], v[8 + i]);
+    for (int i = 1; i < 8; ++i) pfx[i] = fmaxf(pfx[i - 1], v[OFF + 8 + i]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = fmaxf(sfx[i], pfx[i]);
 }
-// row pass: in [ROWS][CIN] -> out [ROWS][CIN-8]; one work item = (row, strip of 8 outputs), 16-byte LDS accesses
-template <int ROWS, int CIN>
-__device__ __forceinline__ void nms_row_pass(const float* __restrict__ in, float* __restrict__ out) {
-    constexpr int COUT = CIN - 8, STRIPS = COUT / 8;
-    for (int w = threadIdx.x; w < ROWS * STRIPS; w += 256) {
-        const int row = w / STRIPS, st = w - row * STRIPS;
-        float v[16], o[8];
+template <int OFF, int NIN>
+__device__ __forceinline__ void or9_strip_at(const unsigned (&v)[NIN], unsigned* o) {
+    unsigned sfx[8], pfx[8];
+    sfx[7] = v[OFF + 7];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 t = *(const f32x4*)(in + row * CIN + st * 8 + q * 4);
+    for (int i = 6; i >= 0; --i) sfx[i] = v[OFF + i] | sfx[i + 1];
+    pfx[0] = v[OFF + 8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[q * 4 + j] = t[j];
-        }
-        max9_strip(v, o);
-        *(f32x4*)(out + row * COUT + st * 8) = (f32x4){o[0], o[1], o[2], o[3]};
-        *(f32x4*)(out + row * COUT + st * 8 + 4) = (f32x4){o[4], o[5], o[6], o[7]};
-    }
+    for (int i = 1; i < 8; ++i) pfx[i] = pfx[i - 1] | v[OFF + 8 + i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = sfx[i] | pfx[i];
 }
-// column pass: in [RIN][COLS] -> 8 pooled values per work item (col, strip of 8 output rows), handed to `emit`
-template <int RIN, int COLS, class F>
-__device__ __forceinline__ void nms_col_pass(const float* __restrict__ in, F emit) {
-    constexpr int STRIPS = (RIN - 8) / 8;
-    for (int w = threadIdx.x; w < COLS * STRIPS; w += 256) {
-        const int st = w / COLS, col = w - st * COLS;
-        float v[16], o[8];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = in[(st * 8 + i) * COLS + col];
-        max9_strip(v, o);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) emit(st * 8 + i, col, o[i]);
-    }
+// max over lanes [l - 4, l + 4] (valid for lanes 4..59)
+__device__ __forceinline__ float hmax9(float c) {
+    const float m2 = fmaxf(c, __shfl_down(c, 1, 64));
+    const float m4 = fmaxf(m2, __shfl_down(m2, 2, 64));
+    const float m8 = fmaxf(m4, __shfl_down(m4, 4, 64));
+    const float m9 = fmaxf(m8, __shfl_down(c, 8, 64));
+    return __shfl_up(m9, 4, 64);
 }
 
-__global__ __launch_bounds__(256) void k_nms(const float* __restrict__ dense, float* __restrict__ nms, unsigned long long* __restrict__ cand,
-                                             unsigned int* __restrict__ counters, long long cand_stride, float threshold, Geom g) {
-    __shared__ __attribute__((aligned(16))) float s[NMS_S * NMS_S];
-    __shared__ __attribute__((aligned(16))) float tmp[NMS_S * 48];
-    __shared__ __attribute__((aligned(16))) float m0[48 * 48];
-    __shared__ __attribute__((aligned(16))) float supp[40 * 40];
-    __shared__ __attribute__((aligned(16))) float ss[40 * 40];
-    const int image = blockIdx.z, level = image / g.batch, frame = image - level * g.batch;
+struct NmsTile { int H, W, gx, gy0, lane; long long base; bool ok; };
+template <int COLS>
+__device__ __forceinline__ NmsTile nms_tile(const Geom& g, int cols_per_lane) {
+    NmsTile t;
+    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
     const LevelGeom lv = g.lv[level];
-    const int H = lv.H, W = lv.W;
-    const int x0 = blockIdx.x * NMS_T, y0 = blockIdx.y * NMS_T;
-    if (x0 >= W || y0 >= H) return;
-    const float* src = dense + lv.in_off + (long long)frame * H * W;
-    const float NEG = -INFINITY;
-    for (int i = threadIdx.x; i < NMS_S * NMS_S; i += 256) {
-        const int ty = i / NMS_S, tx = i - ty * NMS_S;
-        const int gy = y0 - 3 * NMS_R + ty, gx = x0 - 3 * NMS_R + tx;
-        s[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[(long long)gy * W + gx] : NEG;
-    }
-    __syncthreads();
-    // pool 1: 56x56 -> 48x48; m0 = (score == pooled) inside the image
-    nms_row_pass<NMS_S, NMS_S>(s, tmp);
-    __syncthreads();
-    nms_col_pass<NMS_S, 48>(tmp, [&](int ty, int tx, float m) {
-        const float c = s[(ty + NMS_R) * NMS_S + tx + NMS_R];
-        m0[ty * 48 + tx] = (c != NEG && c == m) ? 1.0f : 0.0f;
-    });
-    __syncthreads();
-    // pool 2 (of the mask): 48x48 -> 40x40; suppressed scores
-    nms_row_pass<48, 48>(m0, tmp);
-    __syncthreads();
-    nms_col_pass<48, 40>(tmp, [&](int ty, int tx, float m) {
-        const float c = s[(ty + 2 * NMS_R) * NMS_S + tx + 2 * NMS_R];
-        supp[ty * 40 + tx] = m;
-        ss[ty * 40 + tx] = (c == NEG) ? NEG : (m != 0.0f ? 0.0f : c);
-    });
-    __syncthreads();
-    // pool 3: 40x40 -> 32x32 (row pass into tmp, column pass below)
-    nms_row_pass<40, 40>(ss, tmp);
-    __syncthreads();
-    float* dst = nms + lv.out_off + (long long)frame * H * W;
-    unsigned long long* cl = cand + (long long)image * cand_stride;
-    // candidates are collected in LDS first: one global atomic per workgroup instead of one per
-    // candidate (all candidates of an image hit the same counter)
-    unsigned long long* lkeys = (unsigned long long*)tmp;     // 1024 keys = 8 KB <= sizeof(tmp) (tmp is dead after pool 3)
-    __shared__ unsigned int lcount, lbase;
-    float ovals[4];
-    // pool 3's column pass is folded into the final per-pixel stage (9 LDS reads per output)
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int i = threadIdx.x + it * 256;
-        const int ty = i / NMS_T, tx = i - ty * NMS_T;
-        float m = tmp[ty * 32 + tx];
-#pragma unroll
-        for (int d = 1; d <= 2 * NMS_R; ++d) m = fmaxf(m, tmp[(ty + d) * 32 + tx]);
-        const float sv = s[(ty + 3 * NMS_R) * NMS_S + tx + 3 * NMS_R];
-        const bool is_max0 = m0[(ty + 2 * NMS_R) * 48 + tx + 2 * NMS_R] != 0.0f;
-        const bool is_supp = supp[(ty + NMS_R) * 40 + tx + NMS_R] != 0.0f;
-        const bool new_max = ss[(ty + NMS_R) * 40 + tx + NMS_R] == m;
-        ovals[it] = (is_max0 || (new_max && !is_supp)) ? sv : 0.0f;
-    }
-    if (threadIdx.x == 0) lcount = 0;
-    __syncthreads();                                           // every read of tmp is done
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int i = threadIdx.x + it * 256;
-        const int ty = i / NMS_T, tx = i - ty * NMS_T;
-        const int gy = y0 + ty, gx = x0 + tx;
-        if (gy >= H || gx >= W) continue;
-        const float o = ovals[it];
-        dst[(long long)gy * W + gx] = o;
-        if (o >= threshold) {
-            const unsigned int slot = atomicAdd(&lcount, 1u);
-            lkeys[slot] = ((unsigned long long)(~__float_as_uint(o)) << 32) | (unsigned int)(gx * H + gy);
-        }
-    }
-    __syncthreads();
-    const unsigned int cnt = lcount;
-    if (cnt == 0) return;
-    if (threadIdx.x == 0) lbase = atomicAdd(&counters[image], cnt);
-    __syncthreads();
-    for (unsigned int i = threadIdx.x; i < cnt; i += 256) cl[lbase + i] = lkeys[i];
+    t.H = lv.H; t.W = lv.W; t.lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tiles_x = (t.W + COLS - 1) / COLS, tiles_y = (t.H + NMS_RB - 1) / NMS_RB;
+    t.ok = wid < tiles_x * tiles_y;
+    const int ty = wid / tiles_x, tx = wid - ty * tiles_x;
+    t.gx = tx * COLS - 4 + t.lane * cols_per_lane;
+    t.gy0 = ty * NMS_RB - 4;
+    t.base = lv.in_off + (long long)frame * t.H * t.W;
+    return t;
 }
 
-hipError_t launch_nms(const float* dense, float* nms, unsigned long long* cand, unsigned int* counters, long long cand_stride,
-                      float threshold, const Geom& g, hipStream_t s) {
-    int maxw = 0, maxh = 0;
-    for (int l = 0; l < g.n_levels; ++l) { maxw = max(maxw, g.lv[l].W); maxh = max(maxh, g.lv[l].H); }
-    dim3 grid((maxw + NMS_T - 1) / NMS_T, (maxh + NMS_T - 1) / NMS_T, g.n_levels * g.batch);
-    hipLaunchKernelGGL(k_nms, grid, dim3(256), 0, s, dense, nms, cand, counters, cand_stride, threshold, g);
+// pass 1: max_mask = (scores == pool9x9(scores)) as bytes
+__global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ dense, uint8_t* __restrict__ m0, Geom g) {
+    const NmsTile t = nms_tile<NMS_CW>(g, 1);
+    if (!t.ok) return;
+    const float NEG = -INFINITY;
+    const float* src = dense + t.base;
+    const bool xin = t.gx >= 0 && t.gx < t.W;
+    float v[NMS_RB + 8];
+#pragma unroll
+    for (int i = 0; i < NMS_RB + 8; ++i) {
+        const int gy = t.gy0 + i;
+        v[i] = (xin && gy >= 0 && gy < t.H) ? src[(long long)gy * t.W + t.gx] : NEG;
+    }
+    float o[NMS_RB];
+    max9_strip_at<0>(v, o); max9_strip_at<8>(v, o + 8); max9_strip_at<16>(v, o + 16); max9_strip_at<24>(v, o + 24);
+    uint8_t* dst = m0 + t.base;
+    const bool lane_out = t.lane >= 4 && t.lane < 4 + NMS_CW && xin;
+#pragma unroll
+    for (int j = 0; j < NMS_RB; ++j) {
+        const float pooled = hmax9(o[j]);
+        const float c = v[j + 4];
+        const int gy = t.gy0 + 4 + j;
+        if (lane_out && gy < t.H) dst[(long long)gy * t.W + t.gx] = (c == pooled) ? 1 : 0;    // (in-image: c is finite)
+    }
+}
+
+// pass 2: flags = max_mask | (dilate9x9(max_mask) << 1), four columns per lane
+__global__ __launch_bounds__(256) void k_nms_dilate(const uint8_t* __restrict__ m0, uint8_t* __restrict__ flags, Geom g) {
+    const NmsTile t = nms_tile<NMS_PW>(g, 4);
+    if (!t.ok) return;
+    const bool xin = t.gx >= 0 && t.gx < t.W;                     // W % 4 == 0: a word is inside or outside as a whole
+    const uint8_t* src = m0 + t.base;
+    unsigned v[NMS_RB + 8];
+#pragma unroll
+    for (int i = 0; i < NMS_RB + 8; ++i) {
+        const int gy = t.gy0 + i;
+        v[i] = (xin && gy >= 0 && gy < t.H) ? *(const unsigned*)(src + (long long)gy * t.W + t.gx) : 0u;
+    }
+    unsigned o[NMS_RB];
+    or9_strip_at<0>(v, o); or9_strip_at<8>(v, o + 8); or9_strip_at<16>(v, o + 16); or9_strip_at<24>(v, o + 24);
+    uint8_t* dst = flags + t.base;
+    const bool lane_out = t.lane >= 1 && t.lane <= NMS_PW / 4 && xin;
+#pragma unroll
+    for (int j = 0; j < NMS_RB; ++j) {
+        const unsigned C = o[j];
+        const unsigned L = (unsigned)__shfl_up((int)C, 1, 64), R = (unsigned)__shfl_down((int)C, 1, 64);
+        // bytes of L:C:R are 12 consecutive columns; output byte k ORs columns k .. k + 8 of them
+        unsigned d = L | C | R;
+        d |= __builtin_amdgcn_alignbyte(C, L, 1) | __builtin_amdgcn_alignbyte(C, L, 2) | __builtin_amdgcn_alignbyte(C, L, 3);
+        d |= __builtin_amdgcn_alignbyte(R, C, 1) | __builtin_amdgcn_alignbyte(R, C, 2) | __builtin_amdgcn_alignbyte(R, C, 3);
+        const int gy = t.gy0 + 4 + j;
+        if (lane_out && gy < t.H) *(unsigned*)(dst + (long long)gy * t.W + t.gx) = v[j + 4] | (d << 1);
+    }
+}
+
+// pass 3: ss = supp ? 0 : scores, pool, select, emit
+__global__ __launch_bounds__(256) void k_nms_select(const float* __restrict__ dense, const uint8_t* __restrict__ flags, float* __restrict__ nms,
+                                                    unsigned long long* __restrict__ cand, unsigned int* __restrict__ counters,
+                                                    long long cand_stride, float threshold, Geom g) {
+    const NmsTile t = nms_tile<NMS_CW>(g, 1);
+    if (!t.ok) return;
+    const float NEG = -INFINITY;
+    const float* src = dense + t.base;
+    const uint8_t* fsrc = flags + t.base;
+    const bool xin = t.gx >= 0 && t.gx < t.W;
+    float v[NMS_RB + 8], sc[NMS_RB];
+    unsigned m0bits = 0, suppbits = 0;
+#pragma unroll
+    for (int i = 0; i < NMS_RB + 8; ++i) {
+        const int gy = t.gy0 + i;
+        const bool in = xin && gy >= 0 && gy < t.H;
+        const long long off = (long long)gy * t.W + t.gx;
+        const float s = in ? src[off] : NEG;
+        const unsigned f = in ? (unsigned)fsrc[off] : 0u;
+        v[i] = (f & 2u) ? 0.0f : s;
+        if (i >= 4 && i < 4 + NMS_RB) {
+            sc[i - 4] = s;
+            m0bits |= (f & 1u) << (i - 4);
+            suppbits |= ((f >> 1) & 1u) << (i - 4);
+        }
+    }
+    float o[NMS_RB];
+    max9_strip_at<0>(v, o); max9_strip_at<8>(v, o + 8); max9_strip_at<16>(v, o + 16); max9_strip_at<24>(v, o + 24);
+    float* dst = nms + t.base;
+    const bool lane_out = t.lane >= 4 && t.lane < 4 + NMS_CW && xin;
+    unsigned total = 0;
+#pragma unroll
+    for (int j = 0; j < NMS_RB; ++j) {
+        const float pooled = hmax9(o[j]);
+        const int gy = t.gy0 + 4 + j;
+        const bool live = lane_out && gy < t.H;
+        const bool is_max0 = (m0bits >> j) & 1u, is_supp = (suppbits >> j) & 1u;
+        const bool new_max = v[j + 4] == pooled;
+        const float ov = (live && (is_max0 || (new_max && !is_supp))) ? sc[j] : 0.0f;
+        if (live) dst[(long long)gy * t.W + t.gx] = ov;
+        o[j] = ov;                                                  // kept for the candidate pass
+        total += (unsigned)__popcll(__ballot(live && ov >= threshold));
+    }
+    if (total == 0) return;                                         // wave-uniform
+    unsigned base = 0;
+    if (t.lane == 0) base = atomicAdd(&counters[blockIdx.y], total);
+    base = (unsigned)__shfl((int)base, 0, 64);
+    unsigned long long* cl = cand + (long long)blockIdx.y * cand_stride;
+    const unsigned long long lt = (1ull << t.lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < NMS_RB; ++j) {
+        const int gy = t.gy0 + 4 + j;
+        const bool c = lane_out && gy < t.H && o[j] >= threshold;
+        const unsigned long long mask = __ballot(c);
+        if (c) cl[base + (unsigned)__popcll(mask & lt)] = ((unsigned long long)(~__float_as_uint(o[j])) << 32) | (unsigned int)(t.gx * t.H + gy);
+        base += (unsigned)__popcll(mask);
+    }
+}
+
+hipError_t launch_nms(const float* dense, float* nms, uint8_t* mask0, uint8_t* flags, unsigned long long* cand, unsigned int* counters,
+                      long long cand_stride, float threshold, const Geom& g, hipStream_t s) {
+    int tf = 0, tp = 0;
+    for (int l = 0; l < g.n_levels; ++l) {
+        if (g.lv[l].W % 4) return hipErrorInvalidValue;             // score maps are cropped to multiples of 8 (hf_net.py:188-190)
+        const int ty = (g.lv[l].H + NMS_RB - 1) / NMS_RB;
+        tf = max(tf, ((g.lv[l].W + NMS_CW - 1) / NMS_CW) * ty);
+        tp = max(tp, ((g.lv[l].W + NMS_PW - 1) / NMS_PW) * ty);
+    }
+    const int images = g.n_levels * g.batch;
+    hipLaunchKernelGGL(k_nms_mask, dim3((tf + 3) / 4, images), dim3(256), 0, s, dense, mask0, g);
+    hipLaunchKernelGGL(k_nms_dilate, dim3((tp + 3) / 4, images), dim3(256), 0, s, mask0, flags, g);
+    hipLaunchKernelGGL(k_nms_select, dim3((tf + 3) / 4, images), dim3(256), 0, s, dense, flags, nms, cand, counters, cand_stride, threshold, g);
     return hipGetLastError();
 }
 
