@@ -155,13 +155,15 @@ int Net::build(Engine* eng, const NetConfig& c) {
         HF_TRY(dalloc(allocs, &logits, pc * 65));
         HF_TRY(dalloc(allocs, &dense, pi));
         HF_TRY(dalloc(allocs, &nms, pi));
-        HF_TRY(dalloc(allocs, &nms_mask, pi + 16));
-        HF_TRY(dalloc(allocs, &nms_flags, pi + 16));
+        size_t mask_words = 0;                          // one word per (32-row block, column) of every image
+        for (int l = 0; l < c.n_levels; ++l) mask_words += (size_t)c.batch * ((lp[l].Hc + 31) / 32) * lp[l].Wc;
+        HF_TRY(dalloc(allocs, &nms_mask, mask_words));
+        HF_TRY(dalloc(allocs, &nms_flags, mask_words));
         cand_stride = 0;
         for (int l = 0; l < c.n_levels; ++l) cand_stride = std::max(cand_stride, (long long)lp[l].Hc * lp[l].Wc);
         const size_t images = (size_t)c.n_levels * c.batch;
         HF_TRY(dalloc(allocs, &cand, images * (size_t)cand_stride));
-        HF_TRY(dalloc(allocs, &counters, images));
+        HF_TRY(dalloc(allocs, &counters, images * HFNET_COUNTER_STRIDE));
         HF_TRY(dalloc(allocs, &kps_level, images * (size_t)c.max_keypoints));
         const size_t rows = images * (size_t)c.max_keypoints * 4;
         HF_TRY(dalloc(allocs, &rows_hidden, rows * HFNET_DESC_DIM));
@@ -273,8 +275,8 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         HF_LAUNCH(e, stream, "softmax_d2s", launch_softmax_d2s(logits, 65, dense, gd, stream));
         Geom gn = gd;
         for (int l = 0; l < NL; ++l) { gn.lv[l].H = lp[l].Hc; gn.lv[l].W = lp[l].Wc; gn.lv[l].in_off = pix_img[l]; }
-        HF_HIP(hipMemsetAsync(counters, 0, sizeof(unsigned int) * (size_t)NL * cfg.batch, stream));
-        HF_LAUNCH(e, stream, "nms", launch_nms(dense, nms, nms_mask, nms_flags, cand, counters, cand_stride, threshold, gn, stream));
+        HF_HIP(hipMemsetAsync(counters, 0, sizeof(unsigned int) * (size_t)NL * cfg.batch * HFNET_COUNTER_STRIDE, stream));
+        HF_LAUNCH(e, stream, "nms", launch_nms(dense, nullptr, nms_mask, nms_flags, cand, counters, cand_stride, threshold, gn, stream));
         HF_LAUNCH(e, stream, "topk", launch_topk(cand, counters, cand_stride, budget, kps_level, cfg.max_keypoints, n_level, gn, stream));
         // Descriptor head.  Only the 4 bilinear taps of every selected keypoint are ever read
         // (HFNetTFModelV2.cc:153-167), so unless the budget covers most of the cell grid the head is
@@ -283,6 +285,7 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         for (int l = 0; l < NL; ++l) tap_rows += 4ll * std::min(budget.k[l], cfg.max_keypoints) * cfg.batch;
         last_sparse = !force_dense && tap_rows * 5 < pc * 4;
         dense_valid = false;
+        nms_valid = false; last_threshold = threshold;
         if (last_sparse) {
             Geom gt = gn;   // H, W: score map; Ho, Wo: cell grid; in_off: first cell of the level
             for (int l = 0; l < NL; ++l) { gt.lv[l].Ho = lp[l].h[7]; gt.lv[l].Wo = lp[l].w[7]; gt.lv[l].in_off = pix_cell[l]; }
@@ -321,6 +324,14 @@ int Net::run_dense_desc() {
 
 int Net::tap(int id, std::vector<float>& out) {
     if ((id == 18 || id == 19 || id == 26) && cfg.local && !dense_valid) HF_TRY(run_dense_desc());
+    if (id == 25 && cfg.local && !nms_valid) {
+        // the product path only needs the candidate list; the suppressed map is produced on demand
+        const int NL = cfg.n_levels;
+        Geom gn = geom(7, 7, 0, NL);
+        for (int l = 0; l < NL; ++l) { gn.lv[l].H = gn.lv[l].Ho = lp[l].Hc; gn.lv[l].W = gn.lv[l].Wo = lp[l].Wc; gn.lv[l].in_off = gn.lv[l].out_off = pix_img[l]; }
+        HF_LAUNCH(e, stream, "nms_map", launch_nms(dense, nms, nms_mask, nms_flags, nullptr, nullptr, cand_stride, last_threshold, gn, stream));
+        nms_valid = true;
+    }
     const DeviceWeights& w = e->w;
     const float* src = nullptr;
     size_t count = 0;

@@ -67,12 +67,14 @@ struct Net {
     float *rows_hidden = nullptr, *rows_raw = nullptr, *rows_norm = nullptr;
     bool last_sparse = false;      // which descriptor path the last forward() took
     bool dense_valid = false;      // dense descriptor tensors match the last forward()
+    bool nms_valid = false;        // the suppressed score map (tap 25) matches the last forward()
+    float last_threshold = 0.f;
     int force_dense = 0;           // diagnostics / A-B: always run the dense descriptor head
     int fuse_blocks = 1;           // fused inverted-residual kernel for layers <= fuse_max_layer
     int fuse_max_layer = 14;
     int fuse_stem = 0;             // stem + layer_2 in one launch (the layer_1 tap is then unavailable)
     float *dense = nullptr, *nms = nullptr;
-    uint8_t *nms_mask = nullptr, *nms_flags = nullptr;   // byte maps of the NMS passes
+    unsigned *nms_mask = nullptr, *nms_flags = nullptr;   // bit-column masks of the NMS passes (max_mask, supp)
     unsigned long long* cand = nullptr;
     unsigned int* counters = nullptr;
     long long cand_stride = 0;

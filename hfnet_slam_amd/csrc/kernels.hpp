@@ -42,8 +42,12 @@ hipError_t launch_permute_channels(const float* in, float* out, long long P, int
 hipError_t launch_softmax_d2s(const float* logits, int ld, float* dense, const Geom& g, hipStream_t s);
 // simple_nms(radius 4, 2 iterations) (layers.py:10-32) + candidate emission (score >= threshold,
 // HFNetTFModelV2.cc:127-140).  counters: one uint per image, zeroed by the caller.
-// mask0 / flags: byte maps with the layout of the score map (scratch of the three passes)
-hipError_t launch_nms(const float* dense, float* nms, uint8_t* mask0, uint8_t* flags, unsigned long long* cand, unsigned int* counters,
+// counters: one uint per image, HFNET_COUNTER_STRIDE words apart (a cache line each: atomics on neighbouring words
+// serialise in one L2 channel), zeroed by the caller.
+#define HFNET_COUNTER_STRIDE 32
+// mask0 / supp: bit-column masks, one word per (32-row block, column) of every image (scratch of the three passes).
+// nms == nullptr: the suppressed map is not written; cand == nullptr: no candidates are emitted.
+hipError_t launch_nms(const float* dense, float* nms, unsigned* mask0, unsigned* supp, unsigned long long* cand, unsigned int* counters,
                       long long cand_stride, float threshold, const Geom& g, hipStream_t s);
 // top-K of the candidates in canonical order (HFNetTFModelV2.cc:144-151); writes level-resolution
 // keypoints {x, y, response, octave=0} and the per-image count

@@ -5,6 +5,8 @@
 // keypoints and their descriptors ever leave HBM.
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 #include <cfloat>
 
 namespace hfnet {
@@ -70,14 +72,14 @@ hipError_t launch_softmax_d2s(const float* logits, int ld, float* dense, const G
 //   out = (max_mask | (ss == pool(ss) & !supp)) ? scores : 0            (out-of-image cells never win a max: -inf)
 // Three streaming passes without LDS tiles or barriers.  A wave owns a 64-column x 40-row window of the map:
 // every lane loads its column (40 coalesced row reads in flight), takes the vertical 9-max of 32 rows in
-// registers (22 max per 8 rows), and the horizontal 9-max comes from four wave shuffles per row.  Pass 1
-// writes the max_mask as bytes, pass 2 dilates it as packed bytes (4 columns per lane, integer ORs and
-// v_alignbyte) into a flag byte {bit0 max_mask, bit1 supp}, pass 3 rebuilds ss on the fly, pools it and emits
-// the map plus the candidate keys  (~score_bits << 32) | (col * H + row)  -- ascending key order ==
-// (response descending, column-major index ascending).  One global atomic per wave tile.
-#define NMS_RB 32          // output rows of a wave tile (+ 8 halo rows)
-#define NMS_CW 56          // output columns of a float wave tile (64 lanes - 2 * 4 halo)
-#define NMS_PW 248         // output columns of a packed-byte wave tile (62 words of 4)
+// registers (22 max per 8 rows), and the horizontal 9-max comes from whole-wave DPP shifts.  The two masks are
+// bit columns -- one 32-bit word per (32-row block, column) -- so pass 1 stores one word per lane, pass 2 (the
+// dilation of max_mask) is a handful of 64-bit shifts and ORs per column, and pass 3 gets the flags of its 40
+// rows from four loads.  Pass 3 rebuilds ss on the fly, pools it and emits the map (optional: only taps read it)
+// plus the candidate keys  (~score_bits << 32) | (col * H + row)  -- ascending key order == (response
+// descending, column-major index ascending).  One global atomic per wave tile.
+#define NMS_RB 32          // output rows of a wave tile (+ 8 halo rows) == rows per mask word
+#define NMS_CW 56          // output columns of a wave tile (64 lanes - 2 * 4 halo)
 
 // o[i] = max(v[OFF + i .. OFF + i + 8]) for i < 8: suffix maxima of the first 8, prefix maxima of the next 8
 template <int OFF, int NIN>
@@ -92,171 +94,196 @@ __device__ __forceinline__ void max9_strip_at(const float (&v)[NIN], float* o) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = fmaxf(sfx[i], pfx[i]);
 }
-template <int OFF, int NIN>
-__device__ __forceinline__ void or9_strip_at(const unsigned (&v)[NIN], unsigned* o) {
-    unsigned sfx[8], pfx[8];
-    sfx[7] = v[OFF + 7];
-#pragma unroll
-    for (int i = 6; i >= 0; --i) sfx[i] = v[OFF + i] | sfx[i + 1];
-    pfx[0] = v[OFF + 8];
-#pragma unroll
-    for (int i = 1; i < 8; ++i) pfx[i] = pfx[i - 1] | v[OFF + 8 + i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = sfx[i] | pfx[i];
-}
-// max over lanes [l - 4, l + 4] (valid for lanes 4..59)
+// whole-wave shifts by one lane as DPP moves (wave_shl:1 / wave_shr:1): VALU only -- ds_bpermute shuffles go
+// through the LDS crossbar, which bounds these kernels otherwise.  A lane without a source lane reads 0
+// (bound_ctrl); those lanes are halo lanes whose results are never used.
+__device__ __forceinline__ int lane_next_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0x130, 0xf, 0xf, true); }
+__device__ __forceinline__ int lane_prev_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ float lane_next(float v) { return __int_as_float(lane_next_i(__float_as_int(v))); }
+__device__ __forceinline__ float lane_prev(float v) { return __int_as_float(lane_prev_i(__float_as_int(v))); }
+// max / OR over lanes [l - 4, l + 4] (valid for lanes 4..59)
 __device__ __forceinline__ float hmax9(float c) {
-    const float m2 = fmaxf(c, __shfl_down(c, 1, 64));
-    const float m4 = fmaxf(m2, __shfl_down(m2, 2, 64));
-    const float m8 = fmaxf(m4, __shfl_down(m4, 4, 64));
-    const float m9 = fmaxf(m8, __shfl_down(c, 8, 64));
-    return __shfl_up(m9, 4, 64);
+    float r = fmaxf(c, lane_next(c));          // [l, l+1]
+    r = fmaxf(c, lane_next(r));                // [l, l+2]
+    r = fmaxf(c, lane_next(r));
+    r = fmaxf(c, lane_next(r));                // [l, l+4]
+    float q = fmaxf(c, lane_prev(c));
+    q = fmaxf(c, lane_prev(q));
+    q = fmaxf(c, lane_prev(q));
+    q = fmaxf(c, lane_prev(q));                // [l-4, l]
+    return fmaxf(r, q);
+}
+__device__ __forceinline__ unsigned hor9(unsigned c) {
+    unsigned r = c | (unsigned)lane_next_i((int)c);
+    r = c | (unsigned)lane_next_i((int)r);
+    r = c | (unsigned)lane_next_i((int)r);
+    r = c | (unsigned)lane_next_i((int)r);
+    unsigned q = c | (unsigned)lane_prev_i((int)c);
+    q = c | (unsigned)lane_prev_i((int)q);
+    q = c | (unsigned)lane_prev_i((int)q);
+    q = c | (unsigned)lane_prev_i((int)q);
+    return r | q;
 }
 
-struct NmsTile { int H, W, gx, gy0, lane; long long base; bool ok; };
-template <int COLS>
-__device__ __forceinline__ NmsTile nms_tile(const Geom& g, int cols_per_lane) {
+// A wave tile: the first row / column are wave-uniform, so row addresses are scalar and every load is
+//   uniform base + scalar row offset + constant lane offset;
+// out-of-image rows / columns are clamped to a valid address and replaced after the load.
+struct NmsTile {
+    int H, W, gx, cx, gy0, ty, nby, lane;
+    bool ok, xin, lane_out;
+    long long base;      // first pixel of the image in the score map
+    long long wbase;     // first word of the image in the bit-column masks ([row block][column])
+};
+__device__ __forceinline__ NmsTile nms_tile(const Geom& g) {
     NmsTile t;
     const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
     const LevelGeom lv = g.lv[level];
     t.H = lv.H; t.W = lv.W; t.lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int tiles_x = (t.W + COLS - 1) / COLS, tiles_y = (t.H + NMS_RB - 1) / NMS_RB;
-    t.ok = wid < tiles_x * tiles_y;
-    const int ty = wid / tiles_x, tx = wid - ty * tiles_x;
-    t.gx = tx * COLS - 4 + t.lane * cols_per_lane;
-    t.gy0 = ty * NMS_RB - 4;
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int tiles_x = (t.W + NMS_CW - 1) / NMS_CW;
+    t.nby = (t.H + NMS_RB - 1) / NMS_RB;
+    t.ok = wid < tiles_x * t.nby;
+    t.ty = wid / tiles_x;
+    const int tx = wid - t.ty * tiles_x;
+    t.gx = tx * NMS_CW - 4 + t.lane;
+    t.xin = t.gx >= 0 && t.gx < t.W;
+    t.lane_out = t.lane >= 4 && t.lane < 4 + NMS_CW && t.xin;
+    t.cx = min(max(t.gx, 0), t.W - 1);
+    t.gy0 = t.ty * NMS_RB - 4;
     t.base = lv.in_off + (long long)frame * t.H * t.W;
+    long long wb = 0;
+    for (int l = 0; l < level; ++l) wb += (long long)g.batch * ((g.lv[l].H + NMS_RB - 1) / NMS_RB) * g.lv[l].W;
+    t.wbase = wb + (long long)frame * t.nby * t.W;
     return t;
 }
-
-// pass 1: max_mask = (scores == pool9x9(scores)) as bytes
-__global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ dense, uint8_t* __restrict__ m0, Geom g) {
-    const NmsTile t = nms_tile<NMS_CW>(g, 1);
-    if (!t.ok) return;
+// this lane's column of the score map: rows gy0 .. gy0 + 39, -inf outside the image
+__device__ __forceinline__ void nms_load_column(const NmsTile& t, const float* __restrict__ src, float (&v)[NMS_RB + 8]) {
     const float NEG = -INFINITY;
-    const float* src = dense + t.base;
-    const bool xin = t.gx >= 0 && t.gx < t.W;
-    float v[NMS_RB + 8];
+    if (t.gy0 >= 0 && t.gy0 + NMS_RB + 8 <= t.H) {                 // interior rows (most tiles): no per-row conditions
+        const float* p = src + t.gy0 * t.W + t.cx;
 #pragma unroll
-    for (int i = 0; i < NMS_RB + 8; ++i) {
-        const int gy = t.gy0 + i;
-        v[i] = (xin && gy >= 0 && gy < t.H) ? src[(long long)gy * t.W + t.gx] : NEG;
-    }
-    float o[NMS_RB];
-    max9_strip_at<0>(v, o); max9_strip_at<8>(v, o + 8); max9_strip_at<16>(v, o + 16); max9_strip_at<24>(v, o + 24);
-    uint8_t* dst = m0 + t.base;
-    const bool lane_out = t.lane >= 4 && t.lane < 4 + NMS_CW && xin;
+        for (int i = 0; i < NMS_RB + 8; ++i) { const float x = p[i * t.W]; v[i] = t.xin ? x : NEG; }
+    } else {
 #pragma unroll
-    for (int j = 0; j < NMS_RB; ++j) {
-        const float pooled = hmax9(o[j]);
-        const float c = v[j + 4];
-        const int gy = t.gy0 + 4 + j;
-        if (lane_out && gy < t.H) dst[(long long)gy * t.W + t.gx] = (c == pooled) ? 1 : 0;    // (in-image: c is finite)
+        for (int i = 0; i < NMS_RB + 8; ++i) {
+            const int gy = t.gy0 + i;
+            const float x = src[min(max(gy, 0), t.H - 1) * t.W + t.cx];
+            v[i] = (gy >= 0 && gy < t.H && t.xin) ? x : NEG;
+        }
     }
 }
+// bits of rows gy0 .. gy0 + 39 of this lane's column (bit i = window row i), 0 outside the image
+__device__ __forceinline__ unsigned long long nms_load_bits(const NmsTile& t, const unsigned* __restrict__ words) {
+    const unsigned* p = words + t.wbase + t.cx;
+    const unsigned cur = p[t.ty * t.W];
+    const unsigned prev = t.ty > 0 ? p[(t.ty - 1) * t.W] : 0u;
+    const unsigned next = t.ty + 1 < t.nby ? p[(t.ty + 1) * t.W] : 0u;
+    const unsigned long long w = ((unsigned long long)prev >> 28) | ((unsigned long long)cur << 4) | ((unsigned long long)next << 36);
+    return t.xin ? w : 0ull;
+}
+__device__ __forceinline__ unsigned nms_row_mask(const NmsTile& t) {     // rows of the tile that are inside the image
+    const int left = t.H - t.ty * NMS_RB;
+    return left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
+}
 
-// pass 2: flags = max_mask | (dilate9x9(max_mask) << 1), four columns per lane
-__global__ __launch_bounds__(256) void k_nms_dilate(const uint8_t* __restrict__ m0, uint8_t* __restrict__ flags, Geom g) {
-    const NmsTile t = nms_tile<NMS_PW>(g, 4);
+// pass 1: max_mask = (scores == pool9x9(scores)) as bit columns
+__global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ dense, unsigned* __restrict__ m0, Geom g) {
+    const NmsTile t = nms_tile(g);
     if (!t.ok) return;
-    const bool xin = t.gx >= 0 && t.gx < t.W;                     // W % 4 == 0: a word is inside or outside as a whole
-    const uint8_t* src = m0 + t.base;
-    unsigned v[NMS_RB + 8];
+    float v[NMS_RB + 8];
+    nms_load_column(t, dense + t.base, v);
+    float o[NMS_RB];
+    max9_strip_at<0>(v, o); max9_strip_at<8>(v, o + 8); max9_strip_at<16>(v, o + 16); max9_strip_at<24>(v, o + 24);
+    unsigned bits = 0;
 #pragma unroll
-    for (int i = 0; i < NMS_RB + 8; ++i) {
-        const int gy = t.gy0 + i;
-        v[i] = (xin && gy >= 0 && gy < t.H) ? *(const unsigned*)(src + (long long)gy * t.W + t.gx) : 0u;
-    }
-    unsigned o[NMS_RB];
-    or9_strip_at<0>(v, o); or9_strip_at<8>(v, o + 8); or9_strip_at<16>(v, o + 16); or9_strip_at<24>(v, o + 24);
-    uint8_t* dst = flags + t.base;
-    const bool lane_out = t.lane >= 1 && t.lane <= NMS_PW / 4 && xin;
-#pragma unroll
-    for (int j = 0; j < NMS_RB; ++j) {
-        const unsigned C = o[j];
-        const unsigned L = (unsigned)__shfl_up((int)C, 1, 64), R = (unsigned)__shfl_down((int)C, 1, 64);
-        // bytes of L:C:R are 12 consecutive columns; output byte k ORs columns k .. k + 8 of them
-        unsigned d = L | C | R;
-        d |= __builtin_amdgcn_alignbyte(C, L, 1) | __builtin_amdgcn_alignbyte(C, L, 2) | __builtin_amdgcn_alignbyte(C, L, 3);
-        d |= __builtin_amdgcn_alignbyte(R, C, 1) | __builtin_amdgcn_alignbyte(R, C, 2) | __builtin_amdgcn_alignbyte(R, C, 3);
-        const int gy = t.gy0 + 4 + j;
-        if (lane_out && gy < t.H) *(unsigned*)(dst + (long long)gy * t.W + t.gx) = v[j + 4] | (d << 1);
-    }
+    for (int j = 0; j < NMS_RB; ++j) bits |= (v[j + 4] == hmax9(o[j]) ? 1u : 0u) << j;      // all lanes take part in the shifts
+    if (t.lane_out) m0[t.wbase + t.ty * t.W + t.gx] = bits & nms_row_mask(t);
+}
+
+// pass 2: supp = dilate9x9(max_mask): vertical on the bits of a column, horizontal across lanes
+__global__ __launch_bounds__(256) void k_nms_dilate(const unsigned* __restrict__ m0, unsigned* __restrict__ supp, Geom g) {
+    const NmsTile t = nms_tile(g);
+    if (!t.ok) return;
+    const unsigned long long w = nms_load_bits(t, m0);
+    unsigned long long d = w | (w >> 1);
+    d |= d >> 2;
+    d |= d >> 4;
+    d |= w >> 8;                                                    // bit j: window rows j .. j + 8 == tile rows j - 4 .. j + 4
+    const unsigned r = hor9((unsigned)d);
+    if (t.lane_out) supp[t.wbase + t.ty * t.W + t.gx] = r & nms_row_mask(t);
 }
 
 // pass 3: ss = supp ? 0 : scores, pool, select, emit
-__global__ __launch_bounds__(256) void k_nms_select(const float* __restrict__ dense, const uint8_t* __restrict__ flags, float* __restrict__ nms,
-                                                    unsigned long long* __restrict__ cand, unsigned int* __restrict__ counters,
-                                                    long long cand_stride, float threshold, Geom g) {
-    const NmsTile t = nms_tile<NMS_CW>(g, 1);
+__global__ __launch_bounds__(256) void k_nms_select(const float* __restrict__ dense, const unsigned* __restrict__ m0, const unsigned* __restrict__ supp,
+                                                    float* __restrict__ nms, unsigned long long* __restrict__ cand,
+                                                    unsigned int* __restrict__ counters, long long cand_stride, float threshold, Geom g) {
+    const NmsTile t = nms_tile(g);
     if (!t.ok) return;
-    const float NEG = -INFINITY;
-    const float* src = dense + t.base;
-    const uint8_t* fsrc = flags + t.base;
-    const bool xin = t.gx >= 0 && t.gx < t.W;
     float v[NMS_RB + 8], sc[NMS_RB];
-    unsigned m0bits = 0, suppbits = 0;
+    nms_load_column(t, dense + t.base, v);
+    const unsigned m0bits = t.xin ? m0[t.wbase + t.ty * t.W + t.cx] : 0u;
+    const unsigned long long sw = nms_load_bits(t, supp);
+    const unsigned suppbits = (unsigned)(sw >> 4);
 #pragma unroll
-    for (int i = 0; i < NMS_RB + 8; ++i) {
-        const int gy = t.gy0 + i;
-        const bool in = xin && gy >= 0 && gy < t.H;
-        const long long off = (long long)gy * t.W + t.gx;
-        const float s = in ? src[off] : NEG;
-        const unsigned f = in ? (unsigned)fsrc[off] : 0u;
-        v[i] = (f & 2u) ? 0.0f : s;
-        if (i >= 4 && i < 4 + NMS_RB) {
-            sc[i - 4] = s;
-            m0bits |= (f & 1u) << (i - 4);
-            suppbits |= ((f >> 1) & 1u) << (i - 4);
-        }
-    }
+    for (int j = 0; j < NMS_RB; ++j) sc[j] = v[j + 4];
+#pragma unroll
+    for (int i = 0; i < NMS_RB + 8; ++i) v[i] = ((sw >> i) & 1ull) ? 0.0f : v[i];              // (-inf rows have no supp bit)
     float o[NMS_RB];
     max9_strip_at<0>(v, o); max9_strip_at<8>(v, o + 8); max9_strip_at<16>(v, o + 16); max9_strip_at<24>(v, o + 24);
-    float* dst = nms + t.base;
-    const bool lane_out = t.lane >= 4 && t.lane < 4 + NMS_CW && xin;
-    unsigned total = 0;
+#pragma unroll
+    for (int j = 0; j < NMS_RB; ++j) o[j] = hmax9(o[j]);
+    // per-lane bit fields from here on (bit j = tile row j): nothing wave-wide stays alive
+    unsigned newmax = 0;
+#pragma unroll
+    for (int j = 0; j < NMS_RB; ++j) newmax |= (v[j + 4] == o[j] ? 1u : 0u) << j;
+    const unsigned live = t.lane_out ? nms_row_mask(t) : 0u;
+    const unsigned sel = live & (m0bits | (newmax & ~suppbits));
+    unsigned cb = 0;
 #pragma unroll
     for (int j = 0; j < NMS_RB; ++j) {
-        const float pooled = hmax9(o[j]);
-        const int gy = t.gy0 + 4 + j;
-        const bool live = lane_out && gy < t.H;
-        const bool is_max0 = (m0bits >> j) & 1u, is_supp = (suppbits >> j) & 1u;
-        const bool new_max = v[j + 4] == pooled;
-        const float ov = (live && (is_max0 || (new_max && !is_supp))) ? sc[j] : 0.0f;
-        if (live) dst[(long long)gy * t.W + t.gx] = ov;
-        o[j] = ov;                                                  // kept for the candidate pass
-        total += (unsigned)__popcll(__ballot(live && ov >= threshold));
+        sc[j] = ((sel >> j) & 1u) ? sc[j] : 0.0f;
+        cb |= (sc[j] >= threshold ? 1u : 0u) << j;
     }
+    cb &= live;
+    if (nms) {                                                      // suppressed map (taps only)
+        float* dst = nms + t.base + (t.gy0 + 4) * t.W + t.gx;
+#pragma unroll
+        for (int j = 0; j < NMS_RB; ++j)
+            if ((live >> j) & 1u) dst[j * t.W] = sc[j];
+    }
+    if (!cand) return;
+    // candidates: the order inside the list is free (top-K sorts by key), so a lane's candidates take consecutive
+    // slots after those of the lower lanes: one wave scan of the per-lane counts, one global atomic per tile
+    const unsigned n = (unsigned)__popc(cb);
+    unsigned incl = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned up = (unsigned)__shfl_up((int)incl, d, 64);
+        if (t.lane >= d) incl += up;
+    }
+    const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
     if (total == 0) return;                                         // wave-uniform
     unsigned base = 0;
-    if (t.lane == 0) base = atomicAdd(&counters[blockIdx.y], total);
-    base = (unsigned)__shfl((int)base, 0, 64);
-    unsigned long long* cl = cand + (long long)blockIdx.y * cand_stride;
-    const unsigned long long lt = (1ull << t.lane) - 1ull;
+    if (t.lane == 0) base = atomicAdd(&counters[blockIdx.y * HFNET_COUNTER_STRIDE], total);
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    unsigned long long* cl = cand + (long long)blockIdx.y * cand_stride + base + (incl - n);
+    if (cb) {
+        const unsigned idx0 = (unsigned)(t.gx * t.H + t.gy0 + 4);
 #pragma unroll
-    for (int j = 0; j < NMS_RB; ++j) {
-        const int gy = t.gy0 + 4 + j;
-        const bool c = lane_out && gy < t.H && o[j] >= threshold;
-        const unsigned long long mask = __ballot(c);
-        if (c) cl[base + (unsigned)__popcll(mask & lt)] = ((unsigned long long)(~__float_as_uint(o[j])) << 32) | (unsigned int)(t.gx * t.H + gy);
-        base += (unsigned)__popcll(mask);
+        for (int j = 0; j < NMS_RB; ++j)
+            if ((cb >> j) & 1u)
+                cl[__popc(cb & ((1u << j) - 1u))] = ((unsigned long long)(~__float_as_uint(sc[j])) << 32) | (idx0 + j);
     }
 }
 
-hipError_t launch_nms(const float* dense, float* nms, uint8_t* mask0, uint8_t* flags, unsigned long long* cand, unsigned int* counters,
+hipError_t launch_nms(const float* dense, float* nms, unsigned* mask0, unsigned* supp, unsigned long long* cand, unsigned int* counters,
                       long long cand_stride, float threshold, const Geom& g, hipStream_t s) {
-    int tf = 0, tp = 0;
-    for (int l = 0; l < g.n_levels; ++l) {
-        if (g.lv[l].W % 4) return hipErrorInvalidValue;             // score maps are cropped to multiples of 8 (hf_net.py:188-190)
-        const int ty = (g.lv[l].H + NMS_RB - 1) / NMS_RB;
-        tf = max(tf, ((g.lv[l].W + NMS_CW - 1) / NMS_CW) * ty);
-        tp = max(tp, ((g.lv[l].W + NMS_PW - 1) / NMS_PW) * ty);
-    }
-    const int images = g.n_levels * g.batch;
-    hipLaunchKernelGGL(k_nms_mask, dim3((tf + 3) / 4, images), dim3(256), 0, s, dense, mask0, g);
-    hipLaunchKernelGGL(k_nms_dilate, dim3((tp + 3) / 4, images), dim3(256), 0, s, mask0, flags, g);
-    hipLaunchKernelGGL(k_nms_select, dim3((tf + 3) / 4, images), dim3(256), 0, s, dense, flags, nms, cand, counters, cand_stride, threshold, g);
+    int tf = 0;
+    for (int l = 0; l < g.n_levels; ++l) tf = max(tf, ((g.lv[l].W + NMS_CW - 1) / NMS_CW) * ((g.lv[l].H + NMS_RB - 1) / NMS_RB));
+    const dim3 grid((tf + 3) / 4, g.n_levels * g.batch);
+    hipLaunchKernelGGL(k_nms_mask, grid, dim3(256), 0, s, dense, mask0, g);
+    hipLaunchKernelGGL(k_nms_dilate, grid, dim3(256), 0, s, mask0, supp, g);
+    hipLaunchKernelGGL(k_nms_select, grid, dim3(256), 0, s, dense, mask0, supp, nms, cand, counters, cand_stride, threshold, g);
     return hipGetLastError();
 }
 
@@ -275,7 +302,7 @@ __global__ __launch_bounds__(1024) void k_topk(const unsigned long long* __restr
     const int image = blockIdx.x, level = image / g.batch;
     const int H = g.lv[level].H;
     const unsigned long long* cl = cand + (long long)image * cand_stride;
-    const unsigned int n = counters[image];
+    const unsigned int n = counters[image * HFNET_COUNTER_STRIDE];
     int K = kmax_per_level.k[level];
     if (K > TOPK_CAP) K = TOPK_CAP;
     const int tid = threadIdx.x;

@@ -266,16 +266,21 @@ __global__ __launch_bounds__(256) void k_bow_finalize(const BowPair* __restrict_
     const int nq = P.nq;
     int32_t* __restrict__ match_q2t = P.match; float* __restrict__ dist = P.dist; int* __restrict__ n_matches = P.cnt;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nq) return;
-    const unsigned long long k = qkey[i];
+    if (blockIdx.x * 256 >= nq) return;                     // whole workgroup beyond this pair's queries
     int m = -1;
     float d = FLT_MAX;
-    if (k != ~0ull) {
-        d = __uint_as_float((unsigned int)(k >> 32));
-        if (d < th_low) { m = (int)(unsigned int)k; atomicAdd(n_matches, 1); }
+    if (i < nq) {
+        const unsigned long long k = qkey[i];
+        if (k != ~0ull) {
+            d = __uint_as_float((unsigned int)(k >> 32));
+            if (d < th_low) m = (int)(unsigned int)k;
+        }
+        match_q2t[i] = m;
+        dist[i] = d;
     }
-    match_q2t[i] = m;
-    dist[i] = d;
+    // one atomic per wave: the counters of neighbouring pairs share a cache line
+    const int cnt = __popcll(__ballot(m >= 0));
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(n_matches, cnt);
 }
 
 // fills the per-pair descriptors on the device: row counts may live in device memory (on_device callers never
