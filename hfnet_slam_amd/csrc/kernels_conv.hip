@@ -93,12 +93,65 @@ __global__ __launch_bounds__(256) void k_stem(ImageSet imgs, const float* __rest
     }
 }
 
+// Channel count known at compile time: the weights are wave-uniform loads with constant offsets (scalar cache, SGPR
+// fma operands, no LDS reads), and the workgroup's 256 pixels x COUT channels -- one contiguous block of the output
+// tensor -- go through LDS so that the global stores are 16 bytes per lane at consecutive addresses (a thread's own
+// pixel is COUT*4 bytes from its neighbour's: written directly, every store instruction touches 64 cache lines).
+template <int COUT>
+__global__ __launch_bounds__(256) void k_stem_c(ImageSet imgs, const float* __restrict__ w, const float* __restrict__ scale,
+                                                const float* __restrict__ shift, float* __restrict__ out, Geom g) {
+    constexpr int PS = COUT + 4;                 // LDS pixel stride in floats: 16-byte aligned, 28 words -> conflict-free b128
+    static_assert(COUT % 4 == 0 && (PS % 8) == 4, "LDS pixel stride");
+    __shared__ __attribute__((aligned(16))) float tile[256 * PS];
+    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
+    const LevelGeom lv = g.lv[level];
+    const int npix = lv.Ho * lv.Wo;
+    const int idx0 = blockIdx.x * 256;
+    if (idx0 >= npix) return;
+    const int idx = min(idx0 + (int)threadIdx.x, npix - 1);
+    const int oy = idx / lv.Wo, ox = idx - oy * lv.Wo;
+    const uint8_t* img = imgs.ptr[level] + (long long)frame * imgs.frame_stride[level];
+    const int rs = imgs.row_stride[level];
+    float px[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = oy * 2 - lv.pt + ky, ix = ox * 2 - lv.pl + kx;
+            const bool ok = iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W;
+            const float raw = (float)img[(long long)(ok ? iy : 0) * rs + (ok ? ix : 0)];
+            px[ky * 3 + kx] = ok ? (raw - 128.0f) * 0.0078125f : 0.0f;
+        }
+#pragma unroll
+    for (int c = 0; c < COUT; c += 4) {
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc = fmaf(px[t], w[t * COUT + c + j], acc);
+            r[j] = relu6f(fmaf(acc, scale[c + j], shift[c + j]));
+        }
+        *(f32x4*)(tile + threadIdx.x * PS + c) = r;
+    }
+    __syncthreads();
+    const int nvalid = min(256, npix - idx0);
+    f32x4* op = (f32x4*)(out + (lv.out_off + (long long)frame * npix + idx0) * COUT);
+#pragma unroll
+    for (int k = 0; k < COUT / 4; ++k) {
+        const int q = threadIdx.x + k * 256;         // 16-byte piece of the block
+        const int p = q / (COUT / 4), part = q - p * (COUT / 4);
+        if (p < nvalid) op[q] = *(const f32x4*)(tile + p * PS + part * 4);
+    }
+}
+
 hipError_t launch_stem(const ImageSet& imgs, const float* w, const float* scale, const float* shift, int cout, float* out,
                        const Geom& g, hipStream_t s) {
     int maxpix = 0;
     for (int l = 0; l < g.n_levels; ++l) maxpix = max(maxpix, g.lv[l].Ho * g.lv[l].Wo);
     dim3 grid((maxpix + 255) / 256, g.n_levels * g.batch);
-    hipLaunchKernelGGL(k_stem, grid, dim3(256), 0, s, imgs, w, scale, shift, cout, out, g);
+    if (cout == 24) hipLaunchKernelGGL(k_stem_c<24>, grid, dim3(256), 0, s, imgs, w, scale, shift, out, g);
+    else hipLaunchKernelGGL(k_stem, grid, dim3(256), 0, s, imgs, w, scale, shift, cout, out, g);
     return hipGetLastError();
 }
 
@@ -1554,18 +1607,30 @@ __global__ __launch_bounds__(256) void k_block_noexpand(const float* __restrict_
     const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
     const int oy0 = tyi * T, ox0 = txi * T;
     const float* xin = X + (lv.in_off + (long long)frame * lv.H * lv.W) * CIN;
-    for (int i = threadIdx.x; i < SH * SH * (CIN / 4); i += 256) {
-        const int p = i / (CIN / 4), c4 = i - p * (CIN / 4);
-        const int hy = p / SH, hx = p - hy * SH;
-        const int iy = oy0 - lv.pt + hy, ix = ox0 - lv.pl + hx;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W) v = *(const f32x4*)(xin + (long long)(iy * lv.W + ix) * CIN + c4 * 4);
-        *(f32x4*)(tile + p * CP + c4 * 4) = v;
+    // a halo row is SH pixels = SH * CIN / 4 consecutive 16-byte pieces in memory: thread = (row parity, piece), so the
+    // piece -> (pixel, channel quad) split is done once per thread and a load costs an add
+    {
+        constexpr int PPR = SH * (CIN / 4);                    // pieces per halo row (108)
+        static_assert(2 * PPR <= 256, "two halo rows per pass");
+        const int rsel = threadIdx.x >= PPR ? 1 : 0, piece = threadIdx.x - rsel * PPR;
+        const int hx = piece / (CIN / 4), c4 = piece - hx * (CIN / 4);
+        const int ix = ox0 - lv.pl + hx;
+        const bool xok = threadIdx.x < 2 * PPR && ix >= 0 && ix < lv.W;
+        const float* colp = xin + (long long)(xok ? ix : 0) * CIN + c4 * 4;
+        float* tp = tile + hx * CP + c4 * 4;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (threadIdx.x < 2 * PPR) {
+#pragma unroll
+            for (int r2 = 0; r2 < SH / 2; ++r2) {
+                const int hy = r2 * 2 + rsel, iy = oy0 - lv.pt + hy;
+                const bool ok = xok && iy >= 0 && iy < lv.H;
+                const f32x4 v = *(const f32x4*)(colp + (long long)(ok ? iy : 0) * lv.W * CIN);
+                *(f32x4*)(tp + hy * SH * CP) = ok ? v : zero;
+            }
+        }
     }
     __syncthreads();
     const int ty = threadIdx.x / T, tx = threadIdx.x - ty * T;
-    const int oy = oy0 + ty, ox = ox0 + tx;
-    if (oy >= lv.Ho || ox >= lv.Wo) return;
     float d[CIN];
 #pragma unroll
     for (int c = 0; c < CIN; ++c) d[c] = 0.0f;
@@ -1593,13 +1658,28 @@ __global__ __launch_bounds__(256) void k_block_noexpand(const float* __restrict_
 #pragma unroll
         for (int n = 0; n < COUT; ++n) acc[n] = fmaf(dk, wp[k * COUT + n], acc[n]);
     }
-    float* o = out + (lv.out_off + (long long)frame * lv.Ho * lv.Wo + (long long)oy * lv.Wo + ox) * COUT;
+    // output through LDS: a tile row is T pixels x COUT channels = one contiguous 1 KB run of the output tensor;
+    // written back as consecutive 16-byte pieces per lane instead of four 64-byte-strided stores per thread
+    constexpr int OP = COUT + 4;                           // 20 words: conflict-free b128
+    __syncthreads();                                       // every thread is done reading the input tile
+    float* ot = tile;
 #pragma unroll
     for (int n4 = 0; n4 < COUT / 4; ++n4) {
         f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[n4 * 4 + j], psc[n4 * 4 + j], psh[n4 * 4 + j]);
-        *(f32x4*)(o + n4 * 4) = v;
+        *(f32x4*)(ot + threadIdx.x * OP + n4 * 4) = v;
+    }
+    __syncthreads();
+    float* obase = out + (lv.out_off + (long long)frame * lv.Ho * lv.Wo) * COUT;
+    const int cols = min(T, lv.Wo - ox0);                  // valid pixels per tile row
+#pragma unroll
+    for (int k = 0; k < COUT / 4; ++k) {
+        const int q = threadIdx.x + k * 256;               // piece of the tile: row = q / (T * COUT / 4)
+        const int row = q / (T * COUT / 4), rem = q - row * (T * COUT / 4);
+        const int px = rem / (COUT / 4), part = rem - px * (COUT / 4);
+        if (oy0 + row < lv.Ho && px < cols)
+            *(f32x4*)(obase + ((long long)(oy0 + row) * lv.Wo + ox0 + px) * COUT + part * 4) = *(const f32x4*)(ot + (row * T + px) * OP + part * 4);
     }
 }
 
