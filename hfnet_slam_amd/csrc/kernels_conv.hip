@@ -1631,33 +1631,71 @@ __global__ __launch_bounds__(256) void k_block_noexpand(const float* __restrict_
     }
     __syncthreads();
     const int ty = threadIdx.x / T, tx = threadIdx.x - ty * T;
+    // The weights are wave-uniform scalar loads (SGPR fma operands).  Left alone, the scheduler hoists all ~650 of them
+    // to the top and spills them to VGPR lanes (v_writelane / v_readlane: more VALU work than the convolution itself),
+    // so they are fetched one step ahead of their use and scheduling barriers keep each batch where it is.
     float d[CIN];
 #pragma unroll
     for (int c = 0; c < CIN; ++c) d[c] = 0.0f;
+    float wc[CIN], wn[CIN];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int c = 0; c < CIN; ++c) wc[c] = wd[c];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {                   // out-of-image taps are zeros in the tile: fma(0, w, d) == d
-            const float* xp = tile + ((ty + ky) * SH + tx + kx) * CP;
+    for (int tap = 0; tap < 9; ++tap) {                    // out-of-image taps are zeros in the tile: fma(0, w, d) == d
+        if (tap < 8) {
 #pragma unroll
-            for (int c4 = 0; c4 < CIN / 4; ++c4) {
-                const f32x4 xv = *(const f32x4*)(xp + c4 * 4);
+            for (int c = 0; c < CIN; ++c) wn[c] = wd[(tap + 1) * CIN + c];
+        } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[c4 * 4 + j] = fmaf(xv[j], wd[(ky * 3 + kx) * CIN + c4 * 4 + j], d[c4 * 4 + j]);
-            }
+            for (int c = 0; c < CIN; ++c) wn[c] = dsc[c];
         }
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+        const float* xp = tile + ((ty + tap / 3) * SH + tx + tap % 3) * CP;
 #pragma unroll
-    for (int c = 0; c < CIN; ++c) d[c] = relu6f(fmaf(d[c], dsc[c], dsh[c]));
+        for (int c4 = 0; c4 < CIN / 4; ++c4) {
+            const f32x4 xv = *(const f32x4*)(xp + c4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[c4 * 4 + j] = fmaf(xv[j], wc[c4 * 4 + j], d[c4 * 4 + j]);
+        }
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) wc[c] = wn[c];
+    }
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) wn[c] = dsh[c];
+    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) d[c] = relu6f(fmaf(d[c], wc[c], wn[c]));
+    __builtin_amdgcn_sched_barrier(0);
     float acc[COUT];
 #pragma unroll
     for (int n = 0; n < COUT; ++n) acc[n] = 0.0f;
+    float pc[COUT], pn[COUT];
+#pragma unroll
+    for (int n = 0; n < COUT; ++n) pc[n] = wp[n];
 #pragma unroll
     for (int k = 0; k < CIN; ++k) {                       // logical channel k sits in physical slot phys(k)
+        if (k + 1 < CIN) {
+#pragma unroll
+            for (int n = 0; n < COUT; ++n) pn[n] = wp[(k + 1) * COUT + n];
+        }
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
         const int pk = (k & ~7) | ((k & 1) << 2) | ((k & 7) >> 1);
         const float dk = d[pk];
 #pragma unroll
-        for (int n = 0; n < COUT; ++n) acc[n] = fmaf(dk, wp[k * COUT + n], acc[n]);
+        for (int n = 0; n < COUT; ++n) acc[n] = fmaf(dk, pc[n], acc[n]);
+        // pin this row's fmas here (pure arithmetic is not ordered by the barriers: the DAG scheduler would sink all of
+        // it below the last load and every row would be spilled in between)
+        static_assert(COUT == 16, "accumulator pinning is written for 16 outputs");
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+                          "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < COUT; ++n) pc[n] = pn[n];
     }
+#pragma unroll
+    for (int n = 0; n < COUT; ++n) pc[n] = psc[n];
+    // pc now holds the projection BN scale
     // output through LDS: a tile row is T pixels x COUT channels = one contiguous 1 KB run of the output tensor;
     // written back as consecutive 16-byte pieces per lane instead of four 64-byte-strided stores per thread
     constexpr int OP = COUT + 4;                           // 20 words: conflict-free b128
@@ -1667,7 +1705,7 @@ __global__ __launch_bounds__(256) void k_block_noexpand(const float* __restrict_
     for (int n4 = 0; n4 < COUT / 4; ++n4) {
         f32x4 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[n4 * 4 + j], psc[n4 * 4 + j], psh[n4 * 4 + j]);
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[n4 * 4 + j], pc[n4 * 4 + j], psh[n4 * 4 + j]);
         *(f32x4*)(ot + threadIdx.x * OP + n4 * 4) = v;
     }
     __syncthreads();
