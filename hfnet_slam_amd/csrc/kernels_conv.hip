@@ -22,32 +22,47 @@ __device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.0f), 
 // =========================================================================== pyramid resize
 // OpenCV 4.2 cv::resize(INTER_LINEAR) on CV_8UC1: 11-bit fixed-point coefficients, horizontal pass
 // to int, vertical pass ((b0*(r0>>4))>>16 + (b1*(r1>>4))>>16 + 2) >> 2.  Integer-exact.
+// One thread = one output column x 8 consecutive output rows.  Successive output rows mostly share a source row
+// (scale 1.2: the lower source row of one output row is the upper one of the next), so the horizontal interpolation
+// of a source row is computed once and carried to the next output row: ~2.4 byte loads per output pixel instead of
+// 4, and the column tables are read once per thread.  Lanes are consecutive columns (byte-adjacent loads / stores).
+#define RESIZE_ROWS 8
 __global__ __launch_bounds__(256) void k_resize_u8(const uint8_t* __restrict__ src, int sw, int sh, int s_row, long long s_frame,
                                                    uint8_t* __restrict__ dst, int dw, int dh, int d_row, long long d_frame,
                                                    const int* __restrict__ xofs, const short* __restrict__ ialpha,
                                                    const int* __restrict__ yofs, const short* __restrict__ ibeta) {
-    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (dx >= dw || dy >= dh) return;
+    const int dx = blockIdx.x * 256 + threadIdx.x;
+    const int dy0 = blockIdx.y * RESIZE_ROWS;
+    if (dx >= dw) return;
     const uint8_t* sp = src + (long long)blockIdx.z * s_frame;
-    const int sy = yofs[dy];
-    const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
-    const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+    uint8_t* dp = dst + (long long)blockIdx.z * d_frame + dx;
     const int sx = xofs[dx], sx1 = min(sx + 1, sw - 1);
     const int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
-    const uint8_t* r0p = sp + (long long)y0 * s_row;
-    const uint8_t* r1p = sp + (long long)y1 * s_row;
-    const int r0 = r0p[sx] * a0 + r0p[sx1] * a1;
-    const int r1 = r1p[sx] * a0 + r1p[sx1] * a1;
-    int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-    v = min(max(v, 0), 255);
-    dst[(long long)blockIdx.z * d_frame + (long long)dy * d_row + dx] = (uint8_t)v;
+    auto hrow = [&](int y) {                                   // horizontal pass of source row y (clamped), 11-bit fixed point
+        const uint8_t* rp = sp + (long long)y * s_row;
+        return rp[sx] * a0 + rp[sx1] * a1;
+    };
+    int cache_y = -1, cache_v = 0;                             // horizontal result of the last lower row
+#pragma unroll
+    for (int i = 0; i < RESIZE_ROWS; ++i) {
+        const int dy = dy0 + i;
+        if (dy >= dh) break;                                   // uniform
+        const int sy = yofs[dy];
+        const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
+        const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+        const int r0 = y0 == cache_y ? cache_v : hrow(y0);     // uniform condition
+        const int r1 = y1 == y0 ? r0 : hrow(y1);
+        cache_y = y1; cache_v = r1;
+        int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        v = min(max(v, 0), 255);
+        dp[(long long)dy * d_row] = (uint8_t)v;
+    }
 }
 
 hipError_t launch_resize_u8(const uint8_t* src, int sw, int sh, int s_row, long long s_frame, uint8_t* dst, int dw, int dh,
                             int d_row, long long d_frame, const int* xofs, const short* ialpha, const int* yofs,
                             const short* ibeta, int batch, hipStream_t s) {
-    dim3 grid((dw + 63) / 64, (dh + 3) / 4, batch);
+    dim3 grid((dw + 255) / 256, (dh + RESIZE_ROWS - 1) / RESIZE_ROWS, batch);
     hipLaunchKernelGGL(k_resize_u8, grid, dim3(256), 0, s, src, sw, sh, s_row, s_frame, dst, dw, dh, d_row, d_frame, xofs, ialpha, yofs, ibeta);
     return hipGetLastError();
 }
