@@ -189,6 +189,7 @@ struct ConvArgs {
     int n;            // valid output columns == output row stride
     int nt_total;
     int relu6;
+    int xcd_map;      // 3x3 kernel: XCD-aware tile order (measured slower so far; HFNET_C3_XCD=1)
 };
 
 // BN (+ ReLU6) (+ residual) and store of a wave's 32 x (NT*32) accumulator tile.  VALU instructions compete
@@ -371,16 +372,31 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g, TapArgs 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
     const int image = blockIdx.z, level = image / g.batch, frame = image - level * g.batch;
     const LevelGeom lv = g.lv[level];
-    const int nt0 = blockIdx.y * NT;
-    const int p0 = blockIdx.x * 128 + wave * 32;
-    int Hc, Wc, y, x, nrows;
+    const int Hc = GATHER ? lv.Ho : lv.H, Wc = GATHER ? lv.Wo : lv.W;
+    const int nrows = GATHER ? ta.n_in[image] * 4 : Hc * Wc;
+    // Tile order: x = 128-row tile, y = column-tile group, z = image.  (Experiment HFNET_C3_XCD=1: an XCD-aware order --
+    // contiguous runs of row tiles per XCD, both column groups adjacent -- cut this kernel's HBM fetches by 43 % but ran
+    // 5-50 % slower; the kernel is issue-bound, not HBM-bound.)
+    const int T = (nrows + 127) >> 7;
+    int tile;
+    const int grp = blockIdx.y;
+    if (a.xcd_map) {                                                           // experiment: contiguous eighths of the row tiles per XCD
+        const int chunk = (blockIdx.x + image) & 7, q = blockIdx.x >> 3;
+        const int first = (chunk * T) >> 3, count = (((chunk + 1) * T) >> 3) - first;
+        if (q >= count) return;
+        tile = first + q;
+    } else {
+        tile = blockIdx.x;
+        if (tile >= T) return;
+    }
+    const int nt0 = grp * NT;
+    const int p0 = tile * 128 + wave * 32;
+    int y, x;
     bool pvalid;
     long long in_base, out_base;
+    if (p0 >= nrows) return;
     if (GATHER) {
-        Hc = lv.Ho; Wc = lv.Wo;
-        const int n = ta.n_in[image];
-        nrows = n * 4;
-        if (p0 >= nrows) return;
+        const int n = nrows >> 2;
         const int row = p0 + r, i = row >> 2, t = row & 3;
         pvalid = i < n;
         const hfnet_keypoint kp = ta.kps[(long long)image * ta.kps_stride + (pvalid ? i : 0)];
@@ -396,9 +412,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g, TapArgs 
         in_base = lv.in_off + (long long)frame * Hc * Wc;
         out_base = (long long)image * ta.kps_stride * 4;
     } else {
-        Hc = lv.H; Wc = lv.W;
-        nrows = Hc * Wc;
-        if (p0 >= nrows) return;
         pvalid = (p0 + r) < nrows;
         const int p = pvalid ? p0 + r : nrows - 1;
         y = p / Wc; x = p - y * Wc;
@@ -521,7 +534,7 @@ static void launch_c3_nt(const ConvArgs& a, const Geom& g, const TapArgs* ta, di
 static ConvArgs make_args(const float* A, const ConvPack& cp, const float* res, float* out, long long P, int relu6) {
     ConvArgs a;
     a.A = A; a.W = (const f32x4*)cp.w; a.scale = cp.scale; a.shift = cp.shift; a.res = res; a.out = out;
-    a.P = P; a.cin = cp.cin; a.n = cp.n; a.nt_total = cp.nt_total; a.relu6 = relu6;
+    a.P = P; a.cin = cp.cin; a.n = cp.n; a.nt_total = cp.nt_total; a.relu6 = relu6; a.xcd_map = 0;
     return a;
 }
 
@@ -559,11 +572,13 @@ hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* res
 
 static hipError_t launch_conv3x3_any(const float* A, const ConvPack& cp, float* out, int relu6, const Geom& g, const TapArgs* ta,
                                      int max_rows, hipStream_t s) {
-    const ConvArgs a = make_args(A, cp, nullptr, out, 0, relu6);
+    ConvArgs a = make_args(A, cp, nullptr, out, 0, relu6);
+    { const char* v = getenv("HFNET_C3_XCD"); a.xcd_map = v ? atoi(v) : 0; }
     int ntb = cp.nt_per_block;
     if (!ta) { static const int t = []() { const char* v = getenv("HFNET_CONV3_NT"); return v ? atoi(v) : 0; }(); if (t > 0 && cp.nt_total % t == 0) ntb = t; }
     if (ta) { static const int t = []() { const char* v = getenv("HFNET_TAPS_NT"); return v ? atoi(v) : 4; }(); if (t > 0 && cp.nt_total % t == 0) ntb = t; }
-    dim3 grid((max_rows + 127) / 128, cp.nt_total / ntb, g.n_levels * g.batch);
+    const int tiles = (max_rows + 127) / 128;
+    dim3 grid(a.xcd_map ? 8 * ((tiles + 7) / 8) : tiles, cp.nt_total / ntb, g.n_levels * g.batch);
     switch (ntb) {
         case 1: launch_c3_nt<1>(a, g, ta, grid, s); break;
         case 2: launch_c3_nt<2>(a, g, ta, grid, s); break;

@@ -72,10 +72,76 @@ __global__ __launch_bounds__(256) void k_gemm_abt(const float* __restrict__ d1, 
                                                   float* __restrict__ S) {
     gemm_abt_tile(d1, n1, d2, n2, dim, S);
 }
+
+// 128 x 128 tile per workgroup, 64 x 64 (2 x 2 MFMA tiles) per wave: every LDS fragment feeds two MFMAs, so the
+// k loop issues one LDS read and one operand select per MFMA instead of two each (VALU instructions and f32 MFMAs
+// share the issue pipe).  Same per-accumulator order (k ascending), so the same bits as the 64 x 64 kernel.
+__device__ __forceinline__ void gemm_abt_tile128(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int dim,
+                                                 float* __restrict__ S) {
+    constexpr int LD = 66;
+    __shared__ __attribute__((aligned(16))) float As[128 * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[128 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+    const int row0 = blockIdx.y * 128, col0 = blockIdx.x * 128;
+    if (row0 >= n1 || col0 >= n2) return;                     // workgroup-uniform
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+    const int lrow = tid >> 1, lq = tid & 1;                  // staging: 2 threads per row, 8 float4 each per 64-float chunk
+    const float* ag = d1 + (long long)min(row0 + lrow, n1 - 1) * dim + lq * 4;
+    const float* bg = d2 + (long long)min(col0 + lrow, n2 - 1) * dim + lq * 4;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    f32x4 sa[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sa[j] = *(const f32x4*)(ag + j * 8); sb[j] = *(const f32x4*)(bg + j * 8); }
+    for (int k0 = 0; k0 < dim; k0 += 64) {
+        __syncthreads();                                     // previous chunk fully consumed
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float* ap = As + lrow * LD + lq * 4 + j * 8;
+            float* bp = Bs + lrow * LD + lq * 4 + j * 8;
+            *(float2*)(ap) = float2{sa[j][0], sa[j][1]}; *(float2*)(ap + 2) = float2{sa[j][2], sa[j][3]};
+            *(float2*)(bp) = float2{sb[j][0], sb[j][1]}; *(float2*)(bp + 2) = float2{sb[j][2], sb[j][3]};
+        }
+        __syncthreads();
+        if (k0 + 64 < dim) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sa[j] = *(const f32x4*)(ag + k0 + 64 + j * 8); sb[j] = *(const f32x4*)(bg + k0 + 64 + j * 8); }
+        }
+        const float* ap = As + (wr + r) * LD;
+        const float* bp = Bs + (wc + r) * LD;
+#pragma unroll
+        for (int k = 0; k < 64; k += 2) {
+            const float2 a0 = *(const float2*)(ap + k), a1 = *(const float2*)(ap + 32 * LD + k);
+            const float2 b0 = *(const float2*)(bp + k), b1 = *(const float2*)(bp + 32 * LD + k);
+            const float x0 = half ? a0.y : a0.x, x1 = half ? a1.y : a1.x, y0 = half ? b0.y : b0.x, y1 = half ? b1.y : b1.x;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, acc[1][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + wc + j * 32 + r;
+            if (col >= n2) continue;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = row0 + wr + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                if (row < n1) S[(long long)row * n2 + col] = acc[i][j][reg];
+            }
+        }
+}
 // batched over descriptor-set pairs: St[p] = train[p] * query[p]^T
 __global__ __launch_bounds__(256) void k_gemm_abt_pairs(const BowPair* __restrict__ pairs, int dim) {
     const BowPair P = pairs[blockIdx.z];
-    gemm_abt_tile(P.t, P.nt, P.q, P.nq, dim, P.St);
+    gemm_abt_tile128(P.t, P.nt, P.q, P.nq, dim, P.St);
 }
 
 hipError_t launch_gemm_abt(const float* d1, int n1, const float* d2, int n2, int dim, float* S, hipStream_t s) {
@@ -314,7 +380,7 @@ hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int
     if (n_pairs <= 0 || max_rows <= 0) return hipSuccess;
     if (dim % 64) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_bow_prep, dim3((2 * max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim);
-    hipLaunchKernelGGL(k_gemm_abt_pairs, dim3((max_rows + 63) / 64, (max_rows + 63) / 64, n_pairs), dim3(256), 0, s, pairs, dim);
+    hipLaunchKernelGGL(k_gemm_abt_pairs, dim3((max_rows + 127) / 128, (max_rows + 127) / 128, n_pairs), dim3(256), 0, s, pairs, dim);
     hipLaunchKernelGGL(k_bow_train_pass, dim3((max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim, 4e-6f * (float)dim + 1e-4f);
     hipLaunchKernelGGL(k_bow_finalize, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, th_low);
     return hipGetLastError();
