@@ -765,22 +765,54 @@ __global__ __launch_bounds__(256, 2) void k_block_fused(FusedArgs a, Geom g) {
 //    16-byte LDS loads and slide along x in registers; the 9 taps + BN live in registers per chunk;
 //  * the block input (A fragments of every halo M-tile of the wave) is loaded once and stays in
 //    registers across chunks; the chunk's expand weights are loaded once per chunk, not per M-tile.
+struct TileSplit { int first[4], count[4], maxc; };
+// halo M-tiles per MFMA wave: the split that minimises the largest per-wave MFMA count (stage-1 MFMAs + the
+// stage-3 MFMAs of the waves that own an output tile); ties go to the smaller register footprint (max tiles per wave)
+constexpr TileSplit split_tiles(int mt_in, int mt_out, int c1, int c3) {
+    TileSplit sp{};
+    long best = -1;
+    for (int n0 = 0; n0 <= mt_in; ++n0)
+        for (int n1 = 0; n0 + n1 <= mt_in; ++n1)
+            for (int n2 = 0; n0 + n1 + n2 <= mt_in; ++n2) {
+                const int cnt[4] = {n0, n1, n2, mt_in - n0 - n1 - n2};
+                int maxload = 0, maxc = 0;
+                long sq = 0;
+                for (int w = 0; w < 4; ++w) {
+                    const int load = cnt[w] * c1 + (w < mt_out ? c3 : 0);
+                    if (load > maxload) maxload = load;
+                    if (cnt[w] > maxc) maxc = cnt[w];
+                    sq += (long)load * load;
+                }
+                const long key = ((long)maxload * 64 + maxc) * 1000000 + sq;
+                if (best < 0 || key < best) {
+                    best = key;
+                    for (int w = 0; w < 4; ++w) sp.count[w] = cnt[w];
+                    sp.maxc = maxc;
+                }
+            }
+    int f = 0;
+    for (int w = 0; w < 4; ++w) { sp.first[w] = f; f += sp.count[w]; }
+    return sp;
+}
+
+// workgroups per CU the register budget is tuned for: three where the LDS tile allows it (f32 MFMA and VALU work
+// share one issue pipe, so more resident waves is what hides the LDS / barrier latencies)
+template <int STRIDE, int NTO, int KQT, int TW>
+constexpr int fused2_min_blocks() { return (STRIDE == 2 && TW == 8) || (STRIDE == 1 && KQT <= 3) ? 3 : 2; }
+
 template <int STRIDE, int NTO, int KQT, bool HAS_EXPAND, int TW>
-__global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
+__global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) void k_block_fused2(FusedArgs a, Geom g) {
     constexpr int TH = 8;
-    // halo rows are stored back to back; an even row length keeps the depthwise stage's row reads 8-byte
-    // aligned (stride 1: 18, no padding; stride 2: odd widths are padded to a multiple of 4)
-    constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3, IWP = (IW % 2 == 0) ? IW : (IW + 3) / 4 * 4, NPOS = IH * IWP;
+    // halo rows are stored back to back; an even row length keeps the depthwise stage's row reads 8-byte aligned
+    // (odd widths get one padding column: fewer halo M-tiles than padding to a multiple of 4)
+    constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3, IWP = (IW + 1) / 2 * 2, NPOS = IH * IWP;
     constexpr int MT_IN = (NPOS + 31) / 32, OPIX = TH * TW, MT_OUT = OPIX / 32, CEP = 36;
     constexpr int EP = ((MT_IN * 32 / 4) % 2 == 1) ? MT_IN * 32 : MT_IN * 32 + 4;   // per-channel stride, EP/4 odd
     // halo M-tiles per wave.  Stage 3 of chunk c runs in the same barrier phase as stage 1 of chunk c+1
     // (see the loop), and only waves < MT_OUT have stage-3 work, so those waves own fewer halo tiles.
-    constexpr int MTC0 = TW == 12 ? 3 : STRIDE == 2 ? (KQT <= 2 ? 1 : 2) : 2;
-    constexpr int MTC1 = TW == 12 ? 3 : 2;
-    constexpr int MTC2 = TW == 12 ? 4 : STRIDE == 2 ? (KQT <= 2 ? 4 : 3) : (MT_IN >= 7 ? 2 : 1);
-    constexpr int MTC3 = MT_IN - MTC0 - MTC1 - MTC2;
-    constexpr int MTWa = MTC0 > MTC1 ? MTC0 : MTC1, MTWb = MTC2 > MTC3 ? MTC2 : MTC3, MTW = MTWa > MTWb ? MTWa : MTWb;
-    static_assert(MTC3 >= 0 && MTW <= 5, "halo tile distribution");
+    constexpr TileSplit SP = split_tiles(MT_IN, MT_OUT, KQT * 4, NTO * 16);
+    constexpr int MTC0 = SP.count[0], MTC1 = SP.count[1], MTC2 = SP.count[2], MTC3 = SP.count[3], MTW = SP.maxc;
+    static_assert(MTC0 + MTC1 + MTC2 + MTC3 == MT_IN && MTW <= 5, "halo tile distribution");
     __shared__ __attribute__((aligned(16))) float ET[32 * EP];
     __shared__ __attribute__((aligned(16))) float D[OPIX * CEP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
@@ -934,7 +966,7 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) acc = fmaf(row[ky][ox * STRIDE + kx], dwt[ky * 3 + kx], acc);
-                D[(doy * TW + ox) * CEP + dc] = dact ? relu6f(fmaf(acc, dsc, dsh)) : 0.0f;
+                D[(doy * TW + ox) * CEP + dc] = relu6f(fmaf(acc, dsc, dsh));    // inactive channel: taps, scale, shift are all 0 -> 0
             }
         }
         __syncthreads();          // D complete, ET free
@@ -961,22 +993,58 @@ __global__ __launch_bounds__(256, 2) void k_block_fused2(FusedArgs a, Geom g) {
         float* obase = a.out + out_base * a.cout;                      // uniform
         const float* rbase = a.X + in_base * a.cin;                    // uniform (residual: same spatial size, cin == cout)
         const bool full = oy0 + TH <= lv.Ho && ox0 + TW <= lv.Wo;
-        // op = wave*32 + (reg&3) + 8*(reg>>2) + 4*half  ->  (oy, ox) with TW a power of two
-        const int opl = wave * 32 + 4 * half;
+        if constexpr ((TW & (TW - 1)) == 0) {
+            // TW a power of two: register reg of the D fragment is tile row (wave*32 + c) / TW, column 4*half + c % TW with
+            // c = (reg & 3) + 8 * (reg >> 2) -- the row does not depend on the lane.  One per-lane byte offset, the per-register
+            // part is scalar; partial tiles check the row with a scalar compare and the column per lane.
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            const int oyb = oy0 + (wv * 32) / TW, oxl = ox0 + 4 * half;
+            const unsigned cout4 = (unsigned)a.cout * 4u;
 #pragma unroll
-        for (int nt = 0; nt < NTO; ++nt) {
-            const int col = nt * 32 + r;
-            if (col < a.cout) {
-                const float sc = a.pr_scale[col], sh = a.pr_shift[col];
+            for (int nt = 0; nt < NTO; ++nt) {
+                const int col = nt * 32 + r;
+                if (col < a.cout) {
+                    const float sc = a.pr_scale[col], sh = a.pr_shift[col];
+                    const unsigned lane_off = (unsigned)(oyb * lv.Wo + oxl) * cout4 + (unsigned)col * 4u;
+                    float rv[16];
+                    if (a.residual) {
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int op = opl + (reg & 3) + 8 * (reg >> 2);
-                    const int oy = oy0 + op / TW, ox = ox0 + op % TW;
-                    if (full || (oy < lv.Ho && ox < lv.Wo)) {
-                        const int off = (oy * lv.Wo + ox) * a.cout + col;
-                        float v = fmaf(pacc[nt][reg], sc, sh);
-                        if (a.residual) v = v + rbase[off];
-                        obase[off] = v;
+                        for (int reg = 0; reg < 16; ++reg) {
+                            constexpr int dummy = 0; (void)dummy;
+                            const int c = (reg & 3) + 8 * (reg >> 2), ry = c / TW, rx = c % TW;
+                            const bool ok = full || (oyb + ry < lv.Ho && oxl + rx < lv.Wo);
+                            rv[reg] = ok ? *(const float*)((const char*)rbase + lane_off + (unsigned)(ry * lv.Wo + rx) * cout4) : 0.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int c = (reg & 3) + 8 * (reg >> 2), ry = c / TW, rx = c % TW;
+                        if (full || (oyb + ry < lv.Ho && oxl + rx < lv.Wo)) {
+                            float v = fmaf(pacc[nt][reg], sc, sh);
+                            if (a.residual) v = v + rv[reg];
+                            *(float*)((char*)obase + lane_off + (unsigned)(ry * lv.Wo + rx) * cout4) = v;
+                        }
+                    }
+                }
+            }
+        } else {
+            // op = wave*32 + (reg&3) + 8*(reg>>2) + 4*half  ->  (oy, ox)
+            const int opl = wave * 32 + 4 * half;
+#pragma unroll
+            for (int nt = 0; nt < NTO; ++nt) {
+                const int col = nt * 32 + r;
+                if (col < a.cout) {
+                    const float sc = a.pr_scale[col], sh = a.pr_shift[col];
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int op = opl + (reg & 3) + 8 * (reg >> 2);
+                        const int oy = oy0 + op / TW, ox = ox0 + op % TW;
+                        if (full || (oy < lv.Ho && ox < lv.Wo)) {
+                            const int off = (oy * lv.Wo + ox) * a.cout + col;
+                            float v = fmaf(pacc[nt][reg], sc, sh);
+                            if (a.residual) v = v + rbase[off];
+                            obase[off] = v;
+                        }
                     }
                 }
             }
@@ -1001,36 +1069,6 @@ static hipError_t launch_block_fused2_t(const FusedArgs& a, const Geom& g, hipSt
 // pipe of every SIMD always has a wave with MFMA work while the VALU work of the other wave co-issues, and
 // there is one barrier per chunk instead of two.  (v2 alternates the stages inside every wave; with 2
 // workgroups per CU the phases overlap only by chance and the matrix pipe idles ~50 % of the time.)
-struct TileSplit { int first[4], count[4], maxc; };
-// halo M-tiles per MFMA wave: the split that minimises the largest per-wave MFMA count (stage-1 MFMAs + the
-// stage-3 MFMAs of the waves that own an output tile); ties go to the smaller register footprint (max tiles per wave)
-constexpr TileSplit split_tiles(int mt_in, int mt_out, int c1, int c3) {
-    TileSplit sp{};
-    long best = -1;
-    for (int n0 = 0; n0 <= mt_in; ++n0)
-        for (int n1 = 0; n0 + n1 <= mt_in; ++n1)
-            for (int n2 = 0; n0 + n1 + n2 <= mt_in; ++n2) {
-                const int cnt[4] = {n0, n1, n2, mt_in - n0 - n1 - n2};
-                int maxload = 0, maxc = 0;
-                long sq = 0;
-                for (int w = 0; w < 4; ++w) {
-                    const int load = cnt[w] * c1 + (w < mt_out ? c3 : 0);
-                    if (load > maxload) maxload = load;
-                    if (cnt[w] > maxc) maxc = cnt[w];
-                    sq += (long)load * load;
-                }
-                const long key = ((long)maxload * 64 + maxc) * 1000000 + sq;
-                if (best < 0 || key < best) {
-                    best = key;
-                    for (int w = 0; w < 4; ++w) sp.count[w] = cnt[w];
-                    sp.maxc = maxc;
-                }
-            }
-    int f = 0;
-    for (int w = 0; w < 4; ++w) { sp.first[w] = f; f += sp.count[w]; }
-    return sp;
-}
-
 template <int STRIDE, int NTO, int KQT, int TW>
 __global__ __launch_bounds__(512) void k_block_fused3(FusedArgs a, Geom g) {
     constexpr int TH = 8;
@@ -1942,7 +1980,7 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
     if (use_v2) {
         const int kq = b.cin / 8, st = b.stride;
         if (!b.has_expand && st == 1 && nto == 1) return launch_block_fused2_t<1, 1, 0, false>(a, g, s);
-        static const int tw2 = []() { const char* v = getenv("HFNET_FUSE_S2_TW"); return v ? atoi(v) : 12; }();
+        static const int tw2 = []() { const char* v = getenv("HFNET_FUSE_S2_TW"); return v ? atoi(v) : 8; }();   // 8x8 tiles: 3 workgroups per CU beat 8x12 at 2
         if (b.has_expand && st == 2 && kq == 2 && nto == 1 && tw2 == 12) return launch_block_fused2_t<2, 1, 2, true, 12>(a, g, s);
         if (b.has_expand && st == 2 && kq == 3 && nto == 1 && tw2 == 12) return launch_block_fused2_t<2, 1, 3, true, 12>(a, g, s);
         if (b.has_expand && st == 2 && kq == 2 && nto == 1) return launch_block_fused2_t<2, 1, 2, true>(a, g, s);
