@@ -798,7 +798,7 @@ constexpr TileSplit split_tiles(int mt_in, int mt_out, int c1, int c3) {
 // workgroups per CU the register budget is tuned for: three where the LDS tile allows it (f32 MFMA and VALU work
 // share one issue pipe, so more resident waves is what hides the LDS / barrier latencies)
 template <int STRIDE, int NTO, int KQT, int TW>
-constexpr int fused2_min_blocks() { return (STRIDE == 2 && TW == 8) || (STRIDE == 1 && KQT <= 3) ? 3 : 2; }
+constexpr int fused2_min_blocks() { return (STRIDE == 2 && TW == 8) || (STRIDE == 1 && KQT <= 3 && NTO == 1) ? 3 : 2; }
 
 template <int STRIDE, int NTO, int KQT, bool HAS_EXPAND, int TW>
 __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) void k_block_fused2(FusedArgs a, Geom g) {
@@ -856,13 +856,23 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
     const int n_chunks = min(n_chunks_all, (a.cexp + 31) >> 5);   // skip all-padding column tiles
 
     // ---- stage 1 of one chunk: expansion of the halo tile -> ET (channel-major)
+    // expansion weights / BN of a chunk.  With few input channels (KQT <= 3) the next chunk's set is prefetched a whole
+    // phase ahead (an L2 hit takes 0.7-1 us here, a phase is 1-2 us); the wide layers have no registers to spare.
+    constexpr bool PREFETCH_B = false;    // measured on L03-L06: no gain (the other resident workgroups already cover the wait)
+    f32x4 bpre[KQA];
+    float scpre = 0.f, shpre = 0.f;
+    auto fetch_b = [&](int chunk) {
+#pragma unroll
+        for (int kq = 0; kq < KQA; ++kq) bpre[kq] = a.Wex[((size_t)kq * a.ex_nt_total + chunk) * 64 + lane];
+        scpre = a.ex_scale[chunk * 32 + r]; shpre = a.ex_shift[chunk * 32 + r];
+    };
     auto stage1 = [&](int chunk) {
-        const int ch0 = chunk * 32;
         if (HAS_EXPAND) {
+            if (!PREFETCH_B) fetch_b(chunk);
             f32x4 bfrag[KQA];
 #pragma unroll
-            for (int kq = 0; kq < KQA; ++kq) bfrag[kq] = a.Wex[((size_t)kq * a.ex_nt_total + chunk) * 64 + lane];
-            const float sc = a.ex_scale[ch0 + r], sh = a.ex_shift[ch0 + r];
+            for (int kq = 0; kq < KQA; ++kq) bfrag[kq] = bpre[kq];
+            const float sc = scpre, sh = shpre;
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
                 if (m < mt_count) {
@@ -911,11 +921,13 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
         }
     };
 
+    if (PREFETCH_B) fetch_b(0);
     if (!(a.ablate & 1)) stage1(0);
     if (HAS_EXPAND && !interior) zero_border();
     __syncthreads();
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const int ch0 = chunk * 32;
+        if (PREFETCH_B && chunk + 1 < n_chunks) fetch_b(chunk + 1);
         // depthwise taps / BN of this thread's channel and the projection weights of this chunk
         const int dch = ch0 + dc;
         const bool dact = dch < a.cexp;
