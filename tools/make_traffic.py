@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""profiles/rNN_traffic_b32.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace):
+
+    make_traffic.py fetch_counter_collection.csv write_counter_collection.csv batch out.json
+
+Per-launch means in KB as reported by rocprofv3, keyed by bench.py's launch names.  Kernels that serve several
+layers are told apart by grid size (largest grid = the high-resolution layer)."""
+import collections, csv, json, sys
+
+# launch name -> (kernel name prefix, rank of the grid size among that kernel's launches, 0 = largest)
+LAUNCHES = {
+    "conv3x3_det": ("void hfnet::k_conv3x3<4, false>", 0),
+    "conv3x3_desc_taps": ("void hfnet::k_conv3x3<4, true>", 0),
+    "block_L02": ("void hfnet::k_block_noexpand<24, 16>", 0),
+    "block_L03": ("void hfnet::k_block_fused2<2, 1, 2, true, 8>", 0),
+    "block_L04": ("void hfnet::k_block_fused2<1, 1, 3, true, 16>", 0),
+    "block_L05": ("void hfnet::k_block_fused2<2, 1, 3, true, 8>", 0),
+    "block_L06": ("void hfnet::k_block_fused2<1, 2, 3, true, 16>", 0),
+    "block_L07": ("void hfnet::k_block_fused2<1, 3, 6, true, 16>", 0),
+    "stem": ("void hfnet::k_stem_c<24>", 0),
+    "nms_select": ("hfnet::k_nms_select", 0),
+    "match_gemm": ("hfnet::k_gemm_abt_pairs", 0),
+}
+
+
+def per_launch(path):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))     # kernel -> grid -> values
+    for r in csv.DictReader(open(path)):
+        acc[r["Kernel_Name"]][int(r["Grid_Size"])].append(float(r["Counter_Value"]))
+    return acc
+
+
+def pick(acc, prefix, rank):
+    for k, grids in acc.items():
+        if k.startswith(prefix):
+            g = sorted(grids, reverse=True)[rank]
+            v = grids[g]
+            return k, sum(v) / len(v)
+    return None, None
+
+
+fetch, write = per_launch(sys.argv[1]), per_launch(sys.argv[2])
+out = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) around `python bench.py --steps 2 --warmup 1 "
+                      "--batch %s --no-cpu-baseline` on MI355X; per-launch means in KB as reported; bench.py applies MI355X_MICROARCH.md's gfx950 "
+                      "correction: HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Made by tools/make_traffic.py." % sys.argv[3],
+       "batch": int(sys.argv[3]), "kernels": {}}
+for name, (prefix, rank) in LAUNCHES.items():
+    k, f = pick(fetch, prefix, rank)
+    _, w = pick(write, prefix, rank)
+    if k is not None and w is not None:
+        out["kernels"][name] = {"kernel": k.split("(")[0], "fetch_kb": f, "write_kb": w}
+json.dump(out, open(sys.argv[4], "w"), indent=1)
+print(json.dumps(out["kernels"], indent=1))
