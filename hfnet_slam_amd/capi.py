@@ -28,7 +28,7 @@ SYMBOLS = [
     "hfnet_extractor_create", "hfnet_extractor_destroy", "hfnet_extractor_tables",
     "hfnet_extractor_extract", "hfnet_extractor_extract_batch",
     "hfnet_descriptor_distance", "hfnet_resampler", "hfnet_match_search_by_bow", "hfnet_match_search_by_bow_batch", "hfnet_match_search_for_triangulation",
-    "hfnet_db_create", "hfnet_db_destroy", "hfnet_db_add", "hfnet_db_erase", "hfnet_db_clear", "hfnet_db_query",
+    "hfnet_db_create", "hfnet_db_destroy", "hfnet_db_add", "hfnet_db_erase", "hfnet_db_clear", "hfnet_db_query", "hfnet_db_query_batch",
     "hfnet_profile_enable", "hfnet_profile_reset", "hfnet_profile_filter", "hfnet_profile_count", "hfnet_profile_get",
 ]
 
@@ -317,3 +317,14 @@ class Database:
         scores = np.zeros((self.capacity,), np.float32) if want_scores else None
         _chk(lib().hfnet_db_query(self.h, _p(q), mode, _p(slot), _p(score), C.byref(n), C.byref(best), _p(scores)))
         return slot[:n.value].copy(), score[:n.value].copy(), best.value, scores
+
+    def query_batch(self, qs: np.ndarray, mode: int = 0, want_scores=False):
+        """qs: [Q, dim]; returns per-query lists of (slots, scores), best[Q], scores_all[Q, capacity] or None"""
+        qs = np.ascontiguousarray(qs, np.float32)
+        Q = qs.shape[0]
+        assert qs.shape[1] == self.dim
+        slot = np.zeros((Q, self.capacity), np.int32); score = np.zeros((Q, self.capacity), np.float32)
+        n = np.zeros((Q,), np.int32); best = np.zeros((Q,), np.float32)
+        scores = np.zeros((Q, self.capacity), np.float32) if want_scores else None
+        _chk(lib().hfnet_db_query_batch(self.h, Q, _p(qs), mode, _p(slot), _p(score), _p(n), _p(best), _p(scores)))
+        return [(slot[i, :n[i]].copy(), score[i, :n[i]].copy()) for i in range(Q)], best, scores

@@ -966,7 +966,7 @@ int hfnet_db_create(hfnet_engine* eh, int capacity, int dim, hfnet_db** out) {
     HF_HIP(hipMalloc((void**)&db->d_cand_slot, sizeof(int32_t) * capacity));
     HF_HIP(hipMalloc((void**)&db->d_best, sizeof(float)));
     HF_HIP(hipMalloc((void**)&db->d_n, sizeof(int)));
-    HF_HIP(hipMalloc((void**)&db->d_best_bits, sizeof(unsigned int)));
+    HF_HIP(hipMalloc((void**)&db->d_best_bits, sizeof(unsigned int) * 4 * (size_t)db_scan_workgroups(capacity)));   // per-wave partial maxima
     HF_HIP(hipMemset(db->d_occ, 0, (size_t)capacity));
     *out = db.release();
     return HFNET_OK;
@@ -1018,9 +1018,8 @@ int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slo
     std::lock_guard<std::mutex> lk2(e.mu);
     HF_HIP(hipSetDevice(e.device));
     HF_HIP(hipMemcpyAsync(db->d_q, query, sizeof(float) * db->dim, hipMemcpyHostToDevice, e.stream));
-    HF_HIP(hipMemsetAsync(db->d_best_bits, 0, sizeof(unsigned int), e.stream));
     HF_LAUNCH(&e, e.stream, "db_scores", launch_db_scores(db->d_q, db->d_db, db->d_occ, db->capacity, db->dim, db->d_scores, db->d_best_bits, e.stream));
-    HF_LAUNCH(&e, e.stream, "db_filter", launch_db_filter(db->d_scores, db->capacity, mode, db->d_best_bits, db->d_cand_slot, db->d_cand_score, db->d_n, db->d_best, e.stream));
+    HF_LAUNCH(&e, e.stream, "db_filter", launch_db_filter(db->d_scores, db->capacity, mode, db->d_best_bits, 4 * db_scan_workgroups(db->capacity), db->d_cand_slot, db->d_cand_score, db->d_n, db->d_best, 1, e.stream));
     int n = 0;
     float best = 0.f;
     HF_HIP(hipMemcpyAsync(&n, db->d_n, sizeof(int), hipMemcpyDeviceToHost, e.stream));
@@ -1034,6 +1033,48 @@ int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slo
     }
     *n_cand = n;
     if (best_score) *best_score = best;
+    return HFNET_OK;
+}
+
+int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int mode, int32_t* cand_slot, float* cand_score, int32_t* n_cand,
+                         float* best_score, float* scores_all) {
+    API_GUARD(db, "db");
+    if (n_queries < 0) { set_error("db: n_queries < 0"); return HFNET_ERR_INVALID_ARG; }
+    if (n_queries == 0) return HFNET_OK;
+    API_GUARD(queries, "queries"); API_GUARD(cand_slot, "cand_slot"); API_GUARD(cand_score, "cand_score"); API_GUARD(n_cand, "n_cand");
+    if (mode != 0 && mode != 1) { set_error("db: mode must be 0 or 1"); return HFNET_ERR_INVALID_ARG; }
+    if (db->dim > 4096) { set_error("db: batched queries support dim <= 4096"); return HFNET_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> lk(db->mu);
+    Engine& e = db->eng->impl;
+    std::lock_guard<std::mutex> lk2(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    const size_t Q = (size_t)n_queries, cap = (size_t)db->capacity;
+    // per-call scratch: [Q][dim] queries, [Q][cap] scores / candidates, [Q] best / counts
+    HF_TRY(e.m_a.ensure(sizeof(float) * Q * db->dim));
+    HF_TRY(e.m_s.ensure(sizeof(float) * Q * cap));
+    HF_TRY(e.m_f0.ensure(sizeof(float) * Q * cap));
+    HF_TRY(e.m_i0.ensure(sizeof(int32_t) * Q * cap));
+    HF_TRY(e.m_cnt.ensure(sizeof(int32_t) * Q));
+    HF_TRY(e.m_qn.ensure(sizeof(float) * Q));
+    const int parts = 4 * db_batch_workgroups(db->capacity);
+    HF_TRY(e.m_key.ensure(sizeof(unsigned int) * Q * parts));
+    float* d_q = e.m_a.as<float>(); float* d_scores = e.m_s.as<float>(); float* d_cs = e.m_f0.as<float>();
+    int32_t* d_slot = e.m_i0.as<int32_t>(); int* d_n = e.m_cnt.as<int>(); float* d_best = e.m_qn.as<float>();
+    unsigned int* d_bits = e.m_key.as<unsigned int>();
+    HF_HIP(hipMemcpyAsync(d_q, queries, sizeof(float) * Q * db->dim, hipMemcpyHostToDevice, e.stream));
+    HF_LAUNCH(&e, e.stream, "db_scores_batch", launch_db_scores_batch(d_q, n_queries, db->d_db, db->d_occ, db->capacity, db->dim, d_scores, d_bits, e.stream));
+    HF_LAUNCH(&e, e.stream, "db_filter", launch_db_filter(d_scores, db->capacity, mode, d_bits, parts, d_slot, d_cs, d_n, d_best, n_queries, e.stream));
+    HF_HIP(hipMemcpyAsync(n_cand, d_n, sizeof(int32_t) * Q, hipMemcpyDeviceToHost, e.stream));
+    if (best_score) HF_HIP(hipMemcpyAsync(best_score, d_best, sizeof(float) * Q, hipMemcpyDeviceToHost, e.stream));
+    if (scores_all) HF_HIP(hipMemcpyAsync(scores_all, d_scores, sizeof(float) * Q * cap, hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));
+    for (size_t qi = 0; qi < Q; ++qi) {
+        const int n = n_cand[qi];
+        if (n <= 0) continue;
+        HF_HIP(hipMemcpyAsync(cand_slot + qi * cap, d_slot + qi * cap, sizeof(int32_t) * n, hipMemcpyDeviceToHost, e.stream));
+        HF_HIP(hipMemcpyAsync(cand_score + qi * cap, d_cs + qi * cap, sizeof(float) * n, hipMemcpyDeviceToHost, e.stream));
+    }
+    HF_HIP(hipStreamSynchronize(e.stream));
     return HFNET_OK;
 }
 

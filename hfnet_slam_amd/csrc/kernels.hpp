@@ -109,9 +109,17 @@ hipError_t launch_bow_setup(BowPair* pairs, int n_pairs, const float* base, long
 hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, hipStream_t s);
 hipError_t launch_descriptor_distance(const float* a, const float* b, int dim, float* out, hipStream_t s);
 // KeyFrameDatabase scan (KeyFrameDatabase.cc:86-104, 178-197)
+// best_partial: one word per wave of the scan (db_scan_workgroups(n) * 4, resp. db_batch_workgroups(n) * 4 per query);
+// launch_db_filter reduces them (no atomics on the data path)
+int db_scan_workgroups(int n);
+int db_batch_workgroups(int n);
 hipError_t launch_db_scores(const float* q, const float* db, const unsigned char* occupied, int n, int dim, float* scores,
-                            unsigned int* best_bits, hipStream_t s);
-hipError_t launch_db_filter(const float* scores, int n, int mode, const unsigned int* best_bits, int32_t* cand_slot,
-                            float* cand_score, int* n_cand, float* best, hipStream_t s);
+                            unsigned int* best_partial, hipStream_t s);
+// n_queries rows of n scores / candidates, one best / count per query
+hipError_t launch_db_filter(const float* scores, int n, int mode, const unsigned int* best_partial, int n_partials, int32_t* cand_slot,
+                            float* cand_score, int* n_cand, float* best, int n_queries, hipStream_t s);
+// scores[q][slot] for n_queries queries (dim <= 4096): the database is read once per 8 queries
+hipError_t launch_db_scores_batch(const float* q, int n_queries, const float* db, const unsigned char* occupied, int n, int dim,
+                                  float* scores, unsigned int* best_partial, hipStream_t s);
 
 }  // namespace hfnet

@@ -421,34 +421,111 @@ hipError_t launch_descriptor_distance(const float* a, const float* b, int dim, f
 // score = max(0, 1 - ||q - d||) for every occupied slot; one wave per slot, 16-byte coalesced loads
 // (HBM-bound: dim*4 bytes per slot); the best score is tracked with an atomic max on the float bits.
 __global__ __launch_bounds__(256) void k_db_scores(const float* __restrict__ q, const float* __restrict__ db, const unsigned char* __restrict__ occupied,
-                                                   int n, int dim, float* __restrict__ scores, unsigned int* __restrict__ best_bits) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n) return;
-    const int lane = threadIdx.x & 63;
-    if (!occupied[i]) { if (lane == 0) scores[i] = -1.0f; return; }
-    const float* d = db + (long long)i * dim;
-    f32x4 p = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < dim; k += 256) {
-        const f32x4 qv = *(const f32x4*)(q + k + lane * 4), dv = *(const f32x4*)(d + k + lane * 4);
+                                                   int n, int dim, float* __restrict__ scores, unsigned int* __restrict__ best_partial) {
+    const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    float best = 0.0f;
+    for (int i = wid; i < n; i += gridDim.x * 4) {
+        if (!occupied[i]) { if (lane == 0) scores[i] = -1.0f; continue; }
+        const float* d = db + (long long)i * dim + lane * 4;
+        const float* qp = q + lane * 4;
+        f32x4 p = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < dim; k0 += 2048) {                       // 8 row loads in flight per lane
+            f32x4 dv[8];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const float df = qv[c] - dv[c]; p[c] = fmaf(df, df, p[c]); }
-    }
-    const float ss = tree256_wave4(p);
-    if (lane == 0) {
+            for (int u = 0; u < 8; ++u) dv[u] = k0 + u * 256 < dim ? *(const f32x4*)(d + k0 + u * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k0 + u * 256 < dim) {
+                    const f32x4 qv = *(const f32x4*)(qp + k0 + u * 256);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { const float df = qv[c] - dv[u][c]; p[c] = fmaf(df, df, p[c]); }
+                }
+            }
+        }
+        const float ss = tree256_wave4(p);
         const float sc = 1 - sqrtf(ss);
         const float score = sc > 0.f ? sc : 0.f;
-        scores[i] = score;
-        atomicMax(best_bits, __float_as_uint(score));
+        if (lane == 0) scores[i] = score;
+        best = fmaxf(best, score);
+    }
+    // no atomics: 10 000 atomic maxima on one word cost more than the scan; the filter kernel reduces the partials
+    if (lane == 0) best_partial[wid] = __float_as_uint(best);
+}
+
+// Several queries per pass over the database (loop-closure stress, BASELINE config 5): a wave keeps one
+// database row in registers (dim <= 4096: 64 floats per lane) and scores it against a tile of DBQ queries staged
+// in LDS, so the row crosses HBM once per DBQ queries.  Per (query, row) the arithmetic and its order are those
+// of k_db_scores -- the same bits.  The best score of a query is kept per wave and published with one atomic.
+#define DBQ 8
+__global__ __launch_bounds__(256) void k_db_scores_batch(const float* __restrict__ q, int n_queries, const float* __restrict__ db,
+                                                         const unsigned char* __restrict__ occupied, int n, int dim,
+                                                         float* __restrict__ scores, unsigned int* __restrict__ best_bits) {
+    extern __shared__ __attribute__((aligned(16))) float qs[];         // [DBQ][dim]
+    const int q0 = blockIdx.y * DBQ, nq = min(DBQ, n_queries - q0);
+    for (int i = threadIdx.x * 4; i < nq * dim; i += 1024) *(f32x4*)(qs + i) = *(const f32x4*)(q + (long long)q0 * dim + i);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunks = dim >> 8;                                       // 256 floats per chunk, <= 16
+    float best[DBQ];
+#pragma unroll
+    for (int j = 0; j < DBQ; ++j) best[j] = 0.0f;
+    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+        if (!occupied[i]) {
+            if (lane < nq) scores[(long long)(q0 + lane) * n + i] = -1.0f;
+            continue;
+        }
+        const float* d = db + (long long)i * dim + lane * 4;
+        f32x4 row[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) row[k] = k < chunks ? *(const f32x4*)(d + k * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < DBQ; ++j) {
+            if (j < nq) {
+                const float* qp = qs + j * dim + lane * 4;
+                f32x4 p = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (k < chunks) {
+                        const f32x4 qv = *(const f32x4*)(qp + k * 256);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { const float df = qv[c] - row[k][c]; p[c] = fmaf(df, df, p[c]); }
+                    }
+                }
+                const float ss = tree256_wave4(p);
+                const float sc = 1 - sqrtf(ss);
+                const float score = sc > 0.f ? sc : 0.f;
+                if (lane == 0) scores[(long long)(q0 + j) * n + i] = score;
+                best[j] = fmaxf(best[j], score);
+            }
+        }
+    }
+    if (lane == 0) {
+        const int wid = blockIdx.x * 4 + wave, parts = gridDim.x * 4;
+#pragma unroll
+        for (int j = 0; j < DBQ; ++j)
+            if (j < nq) best_bits[(long long)(q0 + j) * parts + wid] = __float_as_uint(best[j]);
     }
 }
 
 // keep slots with score > 0.8*best (mode 0) / > max(0.5, 0.8*best) (mode 1), ascending slot order
 __global__ __launch_bounds__(1024) void k_db_filter(const float* __restrict__ scores, int n, int mode, const unsigned int* __restrict__ best_bits,
-                                                    int32_t* __restrict__ cand_slot, float* __restrict__ cand_score, int* __restrict__ n_cand,
-                                                    float* __restrict__ best_out) {
+                                                    int n_partials, int32_t* __restrict__ cand_slot, float* __restrict__ cand_score,
+                                                    int* __restrict__ n_cand, float* __restrict__ best_out) {
     __shared__ int wsum[16];
     __shared__ int base;
-    const float best = __uint_as_float(*best_bits);
+    // one workgroup per query (blockIdx.x): rows of n scores / candidates
+    scores += (long long)blockIdx.x * n; cand_slot += (long long)blockIdx.x * n; cand_score += (long long)blockIdx.x * n;
+    best_bits += (long long)blockIdx.x * n_partials; n_cand += blockIdx.x; best_out += blockIdx.x;
+    __shared__ float wbest[16];
+    float bl = 0.0f;                                          // scores are >= 0
+    for (int i = threadIdx.x; i < n_partials; i += 1024) bl = fmaxf(bl, __uint_as_float(best_bits[i]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) bl = fmaxf(bl, __shfl_xor(bl, off, 64));
+    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = bl;
+    __syncthreads();
+    float best = wbest[0];
+    for (int w = 1; w < 16; ++w) best = fmaxf(best, wbest[w]);
+    __syncthreads();
     float min_score = best * 0.8f;
     if (mode == 1) min_score = fmaxf(0.5f, min_score);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -472,16 +549,32 @@ __global__ __launch_bounds__(1024) void k_db_filter(const float* __restrict__ sc
     if (tid == 0) { *n_cand = base; *best_out = best; }
 }
 
+// workgroups of the scan kernels (4 waves each); the per-wave best scores are the filter kernel's partials
+int db_scan_workgroups(int n) { const int w = (n + 3) / 4; return w < 1024 ? (w > 0 ? w : 1) : 1024; }
+
 hipError_t launch_db_scores(const float* q, const float* db, const unsigned char* occupied, int n, int dim, float* scores,
-                            unsigned int* best_bits, hipStream_t s) {
+                            unsigned int* best_partial, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     if (dim % 256) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_db_scores, dim3((n + 3) / 4), dim3(256), 0, s, q, db, occupied, n, dim, scores, best_bits);
+    hipLaunchKernelGGL(k_db_scores, dim3(db_scan_workgroups(n)), dim3(256), 0, s, q, db, occupied, n, dim, scores, best_partial);
     return hipGetLastError();
 }
-hipError_t launch_db_filter(const float* scores, int n, int mode, const unsigned int* best_bits, int32_t* cand_slot, float* cand_score,
-                            int* n_cand, float* best, hipStream_t s) {
-    hipLaunchKernelGGL(k_db_filter, dim3(1), dim3(1024), 0, s, scores, n, mode, best_bits, cand_slot, cand_score, n_cand, best);
+hipError_t launch_db_scores_batch(const float* q, int n_queries, const float* db, const unsigned char* occupied, int n, int dim, float* scores,
+                                  unsigned int* best_partial, hipStream_t s) {
+    if (n <= 0 || n_queries <= 0) return hipSuccess;
+    if (dim % 256 || dim > 4096) return hipErrorInvalidValue;
+    const size_t lds = (size_t)DBQ * dim * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_db_scores_batch, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr_set = true; }
+    const int w = db_scan_workgroups(n), wgs = w < 256 ? w : 256;      // one 128 KB query tile per CU
+    hipLaunchKernelGGL(k_db_scores_batch, dim3(wgs, (n_queries + DBQ - 1) / DBQ), dim3(256), lds, s, q, n_queries, db, occupied, n, dim, scores, best_partial);
+    return hipGetLastError();
+}
+int db_batch_workgroups(int n) { const int w = db_scan_workgroups(n); return w < 256 ? w : 256; }
+hipError_t launch_db_filter(const float* scores, int n, int mode, const unsigned int* best_partial, int n_partials, int32_t* cand_slot,
+                            float* cand_score, int* n_cand, float* best, int n_queries, hipStream_t s) {
+    if (n_queries <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_db_filter, dim3(n_queries), dim3(1024), 0, s, scores, n, mode, best_partial, n_partials, cand_slot, cand_score, n_cand, best);
     return hipGetLastError();
 }
 

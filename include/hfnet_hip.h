@@ -167,6 +167,13 @@ int hfnet_db_clear(hfnet_db* db);
  * filled in ascending slot order; scores_all (may be NULL): one score per slot, -1 for empty. */
 int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slot, float* cand_score,
                    int* n_cand, float* best_score, float* scores_all);
+/* The same scan for n_queries descriptors at once (a burst of keyframes at loop closing / relocalisation,
+ * BASELINE config 5): the database crosses HBM once per 8 queries instead of once per query; per query the
+ * results equal hfnet_db_query's bit for bit.  queries: [n_queries][dim]; cand_slot / cand_score:
+ * [n_queries][capacity] (row q holds n_cand[q] entries); best_score: [n_queries] or NULL; scores_all:
+ * [n_queries][capacity] or NULL. */
+int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int mode, int32_t* cand_slot,
+                         float* cand_score, int32_t* n_cand, float* best_score, float* scores_all);
 
 /* ---- measurement hooks (bench.py: HIP events on the engine stream around every launch) -------- */
 int hfnet_profile_enable(hfnet_engine* e, int on);

@@ -97,4 +97,18 @@ def test_loop_closure_stress_10k_database(engine):
         assert np.array_equal(cs, ridx) and best == rbest
         cs1, _, _, _ = db.query(q, 1)
         assert cs1.tolist() == [planted]
+    # config 5, Q = 64 (not a multiple of the 8-query tile + an erased slot): batched == single-query == oracle
+    db.erase(17)
+    planted = rng.integers(0, n, 67)
+    qs = rows[planted] + 0.003 * rng.standard_normal((67, dim)).astype(np.float32)
+    qs = (qs / np.linalg.norm(qs, axis=1, keepdims=True)).astype(np.float32)
+    for mode in (0, 1):
+        cands, best, scores = db.query_batch(qs, mode, want_scores=True)
+        for i in (0, 7, 8, 33, 66):
+            cs, sc, b1, s1 = db.query(qs[i], mode, want_scores=True)
+            assert np.array_equal(scores[i], s1) and best[i] == b1
+            assert np.array_equal(cands[i][0], cs) and np.array_equal(cands[i][1], sc)
+        ref = O.db_scores(qs[5], rows)
+        ref[17] = -1.0
+        assert np.array_equal(scores[5], ref)
     db.close()
