@@ -27,7 +27,7 @@ SYMBOLS = [
     "hfnet_model_detect", "hfnet_model_detect_global", "hfnet_model_tap",
     "hfnet_extractor_create", "hfnet_extractor_destroy", "hfnet_extractor_tables",
     "hfnet_extractor_extract", "hfnet_extractor_extract_batch",
-    "hfnet_descriptor_distance", "hfnet_resampler", "hfnet_match_search_by_bow", "hfnet_match_search_by_bow_batch", "hfnet_match_search_for_triangulation",
+    "hfnet_descriptor_distance", "hfnet_resampler", "hfnet_match_search_by_bow", "hfnet_match_search_by_bow_batch", "hfnet_match_search_for_triangulation", "hfnet_match_search_for_triangulation_batch",
     "hfnet_db_create", "hfnet_db_destroy", "hfnet_db_add", "hfnet_db_erase", "hfnet_db_clear", "hfnet_db_query", "hfnet_db_query_batch",
     "hfnet_profile_enable", "hfnet_profile_reset", "hfnet_profile_filter", "hfnet_profile_count", "hfnet_profile_get",
 ]
@@ -125,6 +125,17 @@ class Engine:
         _chk(lib().hfnet_match_search_by_bow_batch(self.h, len(pairs), _p(sets), C.c_size_t(mr * dim), _p(n_rows), S, _p(qs), _p(ts), mr, dim,
                                                    C.c_float(th_low), _p(match), _p(dist), _p(cnt), 0))
         return cnt, match, dist
+
+    def search_for_triangulation_batch(self, sets, n_rows, pairs, th_high: float = 0.75):
+        """sets: [S, max_rows, dim] float32 (host); n_rows: [S]; pairs: list of (set1, set2)."""
+        sets = np.ascontiguousarray(sets, np.float32)
+        n_rows = np.ascontiguousarray(n_rows, np.int32)
+        s1 = np.ascontiguousarray([p[0] for p in pairs], np.int32); s2 = np.ascontiguousarray([p[1] for p in pairs], np.int32)
+        S, mr, dim = sets.shape
+        match = np.full((len(pairs), mr), -2, np.int32); cnt = np.full((len(pairs),), -1, np.int32)
+        _chk(lib().hfnet_match_search_for_triangulation_batch(self.h, len(pairs), _p(sets), C.c_size_t(mr * dim), _p(n_rows), S, _p(s1), _p(s2),
+                                                              mr, dim, C.c_float(th_high), _p(match), _p(cnt), 0))
+        return cnt, match
 
     def search_for_triangulation(self, d1, d2, th_high: float = 0.75):
         d1 = np.ascontiguousarray(d1, np.float32); d2 = np.ascontiguousarray(d2, np.float32)

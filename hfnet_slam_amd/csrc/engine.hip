@@ -852,22 +852,23 @@ int hfnet_match_search_by_bow(hfnet_engine* eh, const float* query, int n_query,
     return HFNET_OK;
 }
 
-int hfnet_match_search_by_bow_batch(hfnet_engine* eh, int n_pairs, const float* desc_base, size_t set_stride, const int32_t* n_rows, int n_sets,
-                                    const int32_t* query_set, const int32_t* train_set, int max_rows, int dim, float th_low, int32_t* match_q2t,
-                                    float* dist, int32_t* n_matches, int on_device) {
+static int match_pairs_batch(hfnet_engine* eh, int n_pairs, const float* desc_base, size_t set_stride, const int32_t* n_rows, int n_sets,
+                             const int32_t* query_set, const int32_t* train_set, int max_rows, int dim, float th, int32_t* match_q2t,
+                             float* dist, int32_t* n_matches, int on_device, bool triangulation) {
     API_GUARD(eh, "engine");
     if (n_pairs < 0 || n_sets < 0 || max_rows < 1 || dim <= 0 || dim % 64 || set_stride < (size_t)max_rows * dim) {
         set_error("bad batched matcher arguments (dim multiple of 64, set_stride >= max_rows * dim)"); return HFNET_ERR_INVALID_ARG; }
     if (n_pairs == 0) return HFNET_OK;
     API_GUARD(desc_base, "desc_base"); API_GUARD(n_rows, "n_rows"); API_GUARD(query_set, "query_set"); API_GUARD(train_set, "train_set");
-    API_GUARD(match_q2t, "match_q2t"); API_GUARD(dist, "dist"); API_GUARD(n_matches, "n_matches");
+    API_GUARD(match_q2t, "match"); API_GUARD(n_matches, "n_matches");
+    if (!triangulation) API_GUARD(dist, "dist");
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
     HF_HIP(hipSetDevice(e.device));
     if (on_device) HF_HIP(e.wait_extract());
     HF_TRY(bow_scratch(e, n_pairs, max_rows));
     const float* d_base = desc_base; const int32_t *d_rows = n_rows, *d_qs = query_set, *d_ts = train_set;
-    int32_t* d_match = match_q2t; float* d_dist = dist; int32_t* d_cnt = n_matches;
+    int32_t* d_match = match_q2t; float* d_dist = dist ? dist : (float*)match_q2t; int32_t* d_cnt = n_matches;
     if (!on_device) {
         for (int p = 0; p < n_pairs; ++p)
             if (query_set[p] < 0 || query_set[p] >= n_sets || train_set[p] < 0 || train_set[p] >= n_sets) { set_error("pair %d references a set outside [0, %d)", p, n_sets); return HFNET_ERR_INVALID_ARG; }
@@ -886,14 +887,33 @@ int hfnet_match_search_by_bow_batch(hfnet_engine* eh, int n_pairs, const float* 
     HF_LAUNCH(&e, e.stream, "match_bow_setup",
               launch_bow_setup(e.m_pairs.as<BowPair>(), n_pairs, d_base, (long long)set_stride, d_rows, d_qs, d_ts, max_rows, e.m_s.as<float>(),
                                e.m_qn.as<float>(), e.m_tn.as<float>(), e.m_key.as<unsigned long long>(), d_match, d_dist, d_cnt, max_rows, e.stream));
-    HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, th_low, e.stream));
+    if (triangulation) {
+        const float threshold = (float)(-0.5 * th * th + 1);   // Matcher.cc:851
+        HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, threshold, e.stream));
+    } else {
+        HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, th, e.stream));
+    }
     if (!on_device) {
         HF_HIP(hipMemcpyAsync(match_q2t, d_match, sizeof(int32_t) * (size_t)n_pairs * max_rows, hipMemcpyDeviceToHost, e.stream));
-        HF_HIP(hipMemcpyAsync(dist, d_dist, sizeof(float) * (size_t)n_pairs * max_rows, hipMemcpyDeviceToHost, e.stream));
+        if (!triangulation) HF_HIP(hipMemcpyAsync(dist, d_dist, sizeof(float) * (size_t)n_pairs * max_rows, hipMemcpyDeviceToHost, e.stream));
         HF_HIP(hipMemcpyAsync(n_matches, d_cnt, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToHost, e.stream));
         HF_HIP(hipStreamSynchronize(e.stream));
     }
     return HFNET_OK;
+}
+
+int hfnet_match_search_by_bow_batch(hfnet_engine* eh, int n_pairs, const float* desc_base, size_t set_stride, const int32_t* n_rows, int n_sets,
+                                    const int32_t* query_set, const int32_t* train_set, int max_rows, int dim, float th_low, int32_t* match_q2t,
+                                    float* dist, int32_t* n_matches, int on_device) {
+    return match_pairs_batch(eh, n_pairs, desc_base, set_stride, n_rows, n_sets, query_set, train_set, max_rows, dim, th_low, match_q2t, dist,
+                             n_matches, on_device, false);
+}
+
+int hfnet_match_search_for_triangulation_batch(hfnet_engine* eh, int n_pairs, const float* desc_base, size_t set_stride, const int32_t* n_rows,
+                                               int n_sets, const int32_t* set1, const int32_t* set2, int max_rows, int dim, float th_high,
+                                               int32_t* match12, int32_t* n_matches, int on_device) {
+    return match_pairs_batch(eh, n_pairs, desc_base, set_stride, n_rows, n_sets, set1, set2, max_rows, dim, th_high, match12, nullptr, n_matches,
+                             on_device, true);
 }
 
 int hfnet_match_search_for_triangulation(hfnet_engine* eh, const float* d1, int n1, const float* d2, int n2, int dim, float th_high,

@@ -106,6 +106,8 @@ struct BowPair {
 hipError_t launch_bow_setup(BowPair* pairs, int n_pairs, const float* base, long long set_stride, const int* n_rows, const int* qset,
                             const int* tset, int max_rows, float* St, float* qn, float* tn, unsigned long long* qkey, int32_t* match, float* dist,
                             int* cnt, long long out_stride, hipStream_t s);
+// SearchForTriangulation over the same pair descriptors (q = set 1, t = set 2; dist / qn / qkey unused)
+hipError_t launch_tri_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float threshold, hipStream_t s);
 hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, hipStream_t s);
 hipError_t launch_descriptor_distance(const float* a, const float* b, int dim, float* out, hipStream_t s);
 // KeyFrameDatabase scan (KeyFrameDatabase.cc:86-104, 178-197)

@@ -198,6 +198,67 @@ hipError_t launch_tri_select(const float* S, int n1, int n2, float threshold, in
     return hipGetLastError();
 }
 
+// ---- the same over many descriptor-set pairs (blockIdx.z = pair): LocalMapping matches a new keyframe against its
+// ~30 covisible neighbours (LocalMapping.cc:516-520) -- one GEMM launch and two selection launches for all of them.
+// Scratch per pair: St = S [n1 x n2], tn reinterpreted as the column arg-max.
+__global__ __launch_bounds__(256) void k_gemm_abt_pairs_qt(const BowPair* __restrict__ pairs, int dim) {
+    const BowPair P = pairs[blockIdx.z];
+    gemm_abt_tile128(P.q, P.nq, P.t, P.nt, dim, P.St);
+}
+__global__ __launch_bounds__(256) void k_col_argmax_pairs(const BowPair* __restrict__ pairs, float threshold) {
+    const BowPair P = pairs[blockIdx.z];
+    const int n1 = P.nq, n2 = P.nt;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *P.cnt = 0;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n2) return;
+    float best = threshold;
+    int bi = -1;
+    for (int i = 0; i < n1; ++i) {
+        const float d = P.St[(long long)i * n2 + j];
+        if (d > best) { best = d; bi = i; }
+    }
+    ((int*)P.tn)[j] = bi;
+}
+__global__ __launch_bounds__(256) void k_row_match_pairs(const BowPair* __restrict__ pairs, float threshold) {
+    __shared__ int wg_count;
+    const BowPair P = pairs[blockIdx.z];
+    const int n1 = P.nq, n2 = P.nt;
+    if (blockIdx.x * 4 >= n1) return;                          // workgroup-uniform
+    if (threadIdx.x == 0) wg_count = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i < n1) {
+        float best = threshold;
+        int bj = 0x7fffffff;
+        for (int j = lane; j < n2; j += 64) {
+            const float d = P.St[(long long)i * n2 + j];
+            if (d > best) { best = d; bj = j; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ob = __shfl_xor(best, off, 64);
+            const int oj = __shfl_xor(bj, off, 64);
+            if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+        }
+        if (lane == 0) {
+            int m = -1;
+            if (bj != 0x7fffffff && ((const int*)P.tn)[bj] == i) { m = bj; atomicAdd(&wg_count, 1); }
+            P.match[i] = m;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_count) atomicAdd(P.cnt, wg_count);
+}
+hipError_t launch_tri_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float threshold, hipStream_t s) {
+    if (n_pairs <= 0 || max_rows <= 0) return hipSuccess;
+    if (dim % 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_gemm_abt_pairs_qt, dim3((max_rows + 127) / 128, (max_rows + 127) / 128, n_pairs), dim3(256), 0, s, pairs, dim);
+    hipLaunchKernelGGL(k_col_argmax_pairs, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, threshold);
+    hipLaunchKernelGGL(k_row_match_pairs, dim3((max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, threshold);
+    return hipGetLastError();
+}
+
 // =========================================================================== SearchByBoW (BFMatcher)
 // cv::BFMatcher(NORM_L2, crossCheck=true) == batchDistance(K=1, crosscheck): every train row picks its
 // nearest query (first minimum); a query is matched to the nearest train row that picked it.

@@ -148,6 +148,14 @@ int hfnet_match_search_for_triangulation(hfnet_engine* e, const float* d1, int n
                                          int n2, int dim, float th_high, int32_t* match12,
                                          int* n_matches, int on_device);
 
+/* SearchForTriangulation over many pairs (a new keyframe against its ~30 covisible neighbours,
+ * LocalMapping.cc:516-520): same set store / pair description as hfnet_match_search_by_bow_batch; pair p matches the
+ * rows of set1[p] against set2[p]; match12: [n_pairs][max_rows], n_matches: [n_pairs]. */
+int hfnet_match_search_for_triangulation_batch(hfnet_engine* e, int n_pairs, const float* desc_base,
+                                               size_t set_stride, const int32_t* n_rows, int n_sets,
+                                               const int32_t* set1, const int32_t* set2, int max_rows, int dim,
+                                               float th_high, int32_t* match12, int32_t* n_matches, int on_device);
+
 /* ---- Resampler (include/Extractors/BaseModel.h:78-80, src/Extractors/BaseModel.cc:491-562) ---------
  * tensorflow.contrib.resampler: bilinear sampling of an NHWC fp32 map at (x, y) warp points with zero
  * padding; output[b][p][c].  Host pointers (the fused path inside hfnet_*_detect never calls this). */

@@ -319,3 +319,27 @@ def test_batched_bow_matches_per_pair_calls(engine):
             n1, m1, d1 = engine.search_by_bow(q, t, 0.6)
             assert n1 == rn
             _eq("single", m1, rm)
+
+
+def test_batched_triangulation_matches_per_pair_calls(engine):
+    """hfnet_match_search_for_triangulation_batch == the single-pair entry point == the oracle (30 neighbours, ragged)"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(32)
+    S, mr = 7, 150
+    n_rows = np.array([150, 131, 1, 0, 97, 150, 64], np.int32)
+    base = _unit_rows(rng, mr)
+    sets = np.zeros((S, mr, 256), np.float32)
+    for s_ in range(S):
+        v = base[rng.permutation(mr)] + 0.03 * (s_ + 1) * rng.standard_normal((mr, 256)).astype(np.float32)
+        sets[s_] = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    pairs = [(0, s_) for s_ in range(S)] + [(4, 1), (2, 5), (3, 3), (6, 0)]
+    cnt, match = engine.search_for_triangulation_batch(sets, n_rows, pairs, 0.75)
+    for p, (a, b) in enumerate(pairs):
+        d1, d2 = sets[a, :n_rows[a]], sets[b, :n_rows[b]]
+        rn, rm = O.search_for_triangulation(d1, d2, 0.75)
+        assert cnt[p] == rn, (p, cnt[p], rn)
+        _eq(f"pair {p}", match[p, :n_rows[a]], rm)
+        if n_rows[a]:
+            n1, m1 = engine.search_for_triangulation(d1, d2, 0.75)
+            assert n1 == rn
+            _eq("single", m1, rm)
