@@ -108,11 +108,25 @@ def hbm_traffic(launch_name: str, batch: int):
         return None
 
 
-def make_frames(count: int, first_index: int) -> np.ndarray:
-    """iid uniform u8 frames, seed 1000 + frame index"""
+def make_frames(count: int, first_index: int, kind: str = "uniform") -> np.ndarray:
+    """seed 1000 + frame index; "uniform" = iid uniform u8, "natural" = sum of 6 octaves of bilinearly
+    up-sampled uniform noise, clipped (smooth structures at several scales)"""
     out = np.empty((count, H_IMG, W_IMG), np.uint8)
     for i in range(count):
-        out[i] = np.random.default_rng(1000 + first_index + i).integers(0, 256, (H_IMG, W_IMG), dtype=np.uint8)
+        rng = np.random.default_rng(1000 + first_index + i)
+        if kind == "uniform":
+            out[i] = rng.integers(0, 256, (H_IMG, W_IMG), dtype=np.uint8)
+            continue
+        acc = np.zeros((H_IMG, W_IMG), np.float64)
+        for o in range(6):
+            gh, gw = 2 + (H_IMG >> (6 - o)), 2 + (W_IMG >> (6 - o))
+            g = rng.random((gh, gw))
+            ys = np.linspace(0, gh - 1.001, H_IMG); xs = np.linspace(0, gw - 1.001, W_IMG)
+            y0 = ys.astype(int); x0 = xs.astype(int); fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+            up = (g[y0][:, x0] * (1 - fy) * (1 - fx) + g[y0][:, x0 + 1] * (1 - fy) * fx + g[y0 + 1][:, x0] * fy * (1 - fx) + g[y0 + 1][:, x0 + 1] * fy * fx)
+            acc += up * 0.5 ** (5 - o)
+        acc = (acc - acc.min()) / (acc.max() - acc.min())
+        out[i] = np.clip(acc * 1.2 * 255.0 - 25.0, 0, 255).astype(np.uint8)
     return out
 
 
@@ -147,6 +161,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="frames per step and GPU")
+    ap.add_argument("--frames", choices=["uniform", "natural"], default="uniform", help="synthetic frame distribution (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="also print the per-launch timing table to stderr")
     args = ap.parse_args()
@@ -177,7 +192,7 @@ def main() -> None:
     ext = capi.Extractor(eng, W_IMG, H_IMG, N_FEAT, THRESH, SCALE, N_LEVELS, max_batch=B)
 
     n_sets = 2
-    frames = [torch.from_numpy(make_frames(B, (rank * n_sets + s) * B)).to(dev) for s in range(n_sets)]
+    frames = [torch.from_numpy(make_frames(B, (rank * n_sets + s) * B, args.frames)).to(dev) for s in range(n_sets)]
     # descriptor sets of the last n_buf steps live in one rotating store: set id = buffer * B + frame
     n_buf = 3
     kps = torch.zeros((n_buf * B, N_FEAT, 4), dtype=torch.float32, device=dev)
@@ -272,7 +287,7 @@ def main() -> None:
             "metric": "frames/sec HF-Net extract+match, 752x480, 1000 kpts",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seeded uniform u8 frames, seeded random-init weights of the reference architecture)",
+            "dtype": "f32", "data": f"synthetic (seeded {args.frames} u8 frames, seeded random-init weights of the reference architecture)",
             "config": {"workload": "EuRoC-size 752x480 mono, HF-Net extract (4 levels x1.2, budget 322/268/224/186, thr 0.01, "
                                    "level 0 incl. NetVLAD 4096-D) + SearchByBoW brute-force match vs previous frame",
                        "frames_per_step_per_gpu": B, "parallelism": f"replicas x{world} (no collective)"},
