@@ -132,6 +132,13 @@ int Net::build(Engine* eng, const NetConfig& c) {
     }
     compute_offsets(*this, c.batch);
     HF_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (c.global && c.local) {
+        HF_HIP(hipStreamCreateWithFlags(&stream_global, hipStreamNonBlocking));
+        HF_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HF_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        const char* v = getenv("HFNET_TWO_STREAMS");
+        two_streams = v ? atoi(v) : 1;
+    }
     const int first_layer = c.from_intermediate ? 7 : 1;
     const int last_layer = c.global ? 18 : 7;
     size_t exp_max = 0, dw_max = 0;
@@ -189,6 +196,9 @@ void Net::release() {
     for (void* p : allocs) (void)hipFree(p);
     allocs.clear();
     if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+    if (stream_global) { (void)hipStreamDestroy(stream_global); stream_global = nullptr; }
+    if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
+    if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
 }
 
 // layer_in == 0: the cropped input image
@@ -211,7 +221,7 @@ Geom Net::geom(int layer_in, int layer_out, int first_level, int n_used) const {
     return g;
 }
 
-static int run_block(Net& n, int L, int n_used) {   // layer L = block L-2, input act[L-1]
+static int run_block(Net& n, int L, int n_used, hipStream_t st) {   // layer L = block L-2, input act[L-1]
     Engine* e = n.e;
     const BlockPack& b = e->w.blocks[L - 2];
     const long long p_in = n.pix[L - 1][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
@@ -229,7 +239,7 @@ static int run_block(Net& n, int L, int n_used) {   // layer L = block L-2, inpu
         char fn[32];
         snprintf(fn, sizeof fn, "block_L%02d", L);
         const Geom gf = n.geom(L - 1, L, 0, n_used);
-        HF_LAUNCH(e, n.stream, fn, launch_block_fused(n.act[L - 1], b, n.act[L], gf, n.stream));
+        HF_LAUNCH(e, st, fn, launch_block_fused(n.act[L - 1], b, n.act[L], gf, st));
         return HFNET_OK;
     }
     const float* src = n.act[L - 1];
@@ -238,13 +248,13 @@ static int run_block(Net& n, int L, int n_used) {   // layer L = block L-2, inpu
     snprintf(nm[1], sizeof nm[1], "depthwise_L%02d", L);
     snprintf(nm[2], sizeof nm[2], "project_L%02d", L);
     if (b.has_expand) {
-        HF_LAUNCH(e, n.stream, nm[0], launch_pointwise(n.act[L - 1], b.ex, nullptr, n.exp_buf, p_in, 1, n.stream));
+        HF_LAUNCH(e, st, nm[0], launch_pointwise(n.act[L - 1], b.ex, nullptr, n.exp_buf, p_in, 1, st));
         src = n.exp_buf;
     }
     const Geom g = n.geom(L - 1, L, 0, n_used);
-    HF_LAUNCH(e, n.stream, nm[1], launch_depthwise(src, b.dw, b.stride, n.dw_buf, g, n.stream));
-    HF_LAUNCH(e, n.stream, nm[2],
-              launch_pointwise(n.dw_buf, b.pr, b.residual ? n.act[L - 1] : nullptr, n.act[L], p_out, 0, n.stream));
+    HF_LAUNCH(e, st, nm[1], launch_depthwise(src, b.dw, b.stride, n.dw_buf, g, st));
+    HF_LAUNCH(e, st, nm[2],
+              launch_pointwise(n.dw_buf, b.pr, b.residual ? n.act[L - 1] : nullptr, n.act[L], p_out, 0, st));
     return HFNET_OK;
 }
 
@@ -262,7 +272,14 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         } else {
             HF_LAUNCH(e, stream, "stem", launch_stem(imgs, w.stem_w, w.stem_scale, w.stem_shift, w.stem_out, act[1], gs, stream));
         }
-        for (int L = first; L <= 7; ++L) HF_TRY(run_block(*this, L, NL));
+        for (int L = first; L <= 7; ++L) HF_TRY(run_block(*this, L, NL, stream));
+    }
+    const bool fork = cfg.global && cfg.local && two_streams && stream_global;
+    if (cfg.global && fork) {
+        HF_HIP(hipEventRecord(ev_fork, stream));
+        HF_HIP(hipStreamWaitEvent(stream_global, ev_fork, 0));
+        HF_TRY(forward_global(stream_global));
+        HF_HIP(hipEventRecord(ev_join, stream_global));
     }
     if (cfg.local) {
         const long long pc = pix_cell[HFNET_MAX_LEVELS];
@@ -299,14 +316,20 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
             HF_TRY(run_dense_desc());
         }
     }
-    if (cfg.global) {
-        for (int L = 8; L <= 18; ++L) HF_TRY(run_block(*this, L, 1));
-        const int P = lp[0].h[18] * lp[0].w[18];
-        HF_LAUNCH(e, stream, "pointwise_memberships", launch_pointwise(act[18], w.memb, nullptr, memb, (long long)cfg.batch * P, 0, stream));
-        HF_LAUNCH(e, stream, "softmax_memberships", launch_softmax_rows(memb, (long long)cfg.batch * P, w.n_clusters, w.n_clusters, stream));
-        HF_LAUNCH(e, stream, "vlad", launch_vlad(act[18], memb, w.clusters, vlad_tap, vlad_out, vlad_raw, cfg.batch, P, w.c_global, w.n_clusters, stream));
-        HF_LAUNCH(e, stream, "fc_l2", launch_fc_l2(vlad_out, w.fc_wt, w.fc_b, fc_raw, global_out, cfg.batch, w.n_clusters * w.c_global, w.global_dim, stream));
-    }
+    if (cfg.global && fork) HF_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+    else if (cfg.global) HF_TRY(forward_global(stream));
+    return HFNET_OK;
+}
+
+// layers 8-18, NetVLAD, dimensionality reduction on stream st
+int Net::forward_global(hipStream_t st) {
+    const DeviceWeights& w = e->w;
+    for (int L = 8; L <= 18; ++L) HF_TRY(run_block(*this, L, 1, st));
+    const int P = lp[0].h[18] * lp[0].w[18];
+    HF_LAUNCH(e, st, "pointwise_memberships", launch_pointwise(act[18], w.memb, nullptr, memb, (long long)cfg.batch * P, 0, st));
+    HF_LAUNCH(e, st, "softmax_memberships", launch_softmax_rows(memb, (long long)cfg.batch * P, w.n_clusters, w.n_clusters, st));
+    HF_LAUNCH(e, st, "vlad", launch_vlad(act[18], memb, w.clusters, vlad_tap, vlad_out, vlad_raw, cfg.batch, P, w.c_global, w.n_clusters, st));
+    HF_LAUNCH(e, st, "fc_l2", launch_fc_l2(vlad_out, w.fc_wt, w.fc_b, fc_raw, global_out, cfg.batch, w.n_clusters * w.c_global, w.global_dim, st));
     return HFNET_OK;
 }
 

@@ -55,6 +55,11 @@ struct Net {
     Engine* e = nullptr;
     NetConfig cfg;
     hipStream_t stream = nullptr;
+    // the global branch (layers 8-18, NetVLAD, FC) only depends on layer 7: it runs on a second stream next to the
+    // local heads (small launches that do not fill the chip next to MFMA-bound ones)
+    hipStream_t stream_global = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int two_streams = 1;
     LevelPlan lp[HFNET_MAX_LEVELS];
     long long pix[19][HFNET_MAX_LEVELS + 1];   // pixel offset of level l (frame 0) in layer L's tensor; [n_levels] = total
     long long pix_img[HFNET_MAX_LEVELS + 1];   // same for the cropped full-resolution maps
@@ -89,6 +94,7 @@ struct Net {
     int forward(const ImageSet& imgs, float threshold, const TopkBudget& budget);
     int tap(int id, std::vector<float>& out);
     int run_dense_desc();
+    int forward_global(hipStream_t st);
     const float* sample_source() const { return last_sparse ? rows_norm : desc_norm; }
     ~Net() { release(); }
 };
