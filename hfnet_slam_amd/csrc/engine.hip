@@ -41,6 +41,9 @@ Engine::~Engine() {
 hipError_t Engine::note_extract(hipStream_t net_stream) {
     std::lock_guard<std::mutex> lk(ev_mu);
     if (!ev_extract) { hipError_t r = hipEventCreateWithFlags(&ev_extract, hipEventDisableTiming); if (r != hipSuccess) return r; }
+    // extractions may come from several extractors (streams): chain them, so that waiting for the latest record
+    // implies every earlier one
+    if (ev_extract_set) { hipError_t r = hipStreamWaitEvent(net_stream, ev_extract, 0); if (r != hipSuccess) return r; }
     ev_extract_set = true;
     return hipEventRecord(ev_extract, net_stream);
 }
