@@ -817,7 +817,7 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
     __shared__ __attribute__((aligned(16))) float D[OPIX * CEP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
     const int mt_first = wave == 0 ? 0 : wave == 1 ? MTC0 : wave == 2 ? MTC0 + MTC1 : MTC0 + MTC1 + MTC2;
-    const int mt_count = wave == 0 ? MTC0 : wave == 1 ? MTC1 : wave == 2 ? MTC2 : MTC3;
+    int mt_count = wave == 0 ? MTC0 : wave == 1 ? MTC1 : wave == 2 ? MTC2 : MTC3;
     const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
     const LevelGeom lv = g.lv[level];
     const int tiles_x = (lv.Wo + TW - 1) / TW, tiles_y = (lv.Ho + TH - 1) / TH;
@@ -826,6 +826,17 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
     const int oy0 = tyi * TH, ox0 = txi * TW;
     const int iy0 = oy0 * STRIDE - lv.pt, ix0 = ox0 * STRIDE - lv.pl;
     const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= lv.H && ix0 + IW <= lv.W;
+    // Tiles hanging over the bottom edge (the pyramid levels are not multiples of the tile height: up to 30 % of a level's
+    // tile area at 1/8 resolution): halo M-tiles below the last needed input row, depthwise rows and projection M-tiles
+    // below the last output row are skipped.  Skipped regions of ET / D keep stale values that only ever feed rows of
+    // MFMA tiles which are never stored (a row of A only affects the same row of D).
+    const int rows_valid = min(TH, lv.Ho - oy0);                               // uniform, >= 1
+    {
+        const int hy_max = (rows_valid - 1) * STRIDE + 2;                      // last halo row any valid output row reads
+        const int n_live = ((hy_max + 1) * IWP + 31) >> 5;                     // halo M-tiles covering positions < (hy_max + 1) * IWP
+        mt_count = max(0, min(mt_count, n_live - mt_first));
+    }
+    const bool out_live = wave < MT_OUT && (wave * 32) / TW < rows_valid;      // this wave's projection tile has a valid row
     const long long in_base = lv.in_off + (long long)frame * lv.H * lv.W;
     const long long out_base = lv.out_off + (long long)frame * lv.Ho * lv.Wo;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -943,7 +954,7 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
         }
         const int kqc = min(4, (a.cexp - ch0) >> 3);
         f32x4 pfrag[4][NTO];
-        if (wave < MT_OUT) {
+        if (out_live) {
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq)
 #pragma unroll
@@ -951,7 +962,7 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
                     pfrag[kq][nt] = kq < kqc ? a.Wpr[((size_t)(chunk * 4 + kq) * a.pr_nt_total + nt) * 64 + lane] : zero4;
         }
         // ---- stage 2: thread = (channel dc, output row doy), ET -> D
-        if (!(a.ablate & 2)) {
+        if (!(a.ablate & 2) && doy < rows_valid) {
             float row[3][IWP];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
@@ -983,7 +994,7 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
         }
         __syncthreads();          // D complete, ET free
         // ---- stage 3 of this chunk (reads D) and stage 1 of the next one (writes ET) share this phase
-        if (wave < MT_OUT && !(a.ablate & 4)) {
+        if (out_live && !(a.ablate & 4)) {
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) {
                 if (kq < kqc) {
@@ -1001,7 +1012,7 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
         }
         __syncthreads();          // ET complete, D free
     }
-    if (wave < MT_OUT && !(a.ablate & 8)) {
+    if (out_live && !(a.ablate & 8)) {
         float* obase = a.out + out_base * a.cout;                      // uniform
         const float* rbase = a.X + in_base * a.cin;                    // uniform (residual: same spatial size, cin == cout)
         const bool full = oy0 + TH <= lv.Ho && ox0 + TW <= lv.Wo;
