@@ -22,8 +22,8 @@ hipError_t launch_conv3x3(const float* A, const ConvPack& cp, float* out, int re
 // the same convolution evaluated only at the 4 bilinear taps of every selected keypoint ("sparse
 // descriptor head"): row (image*kps_stride + i)*4 + t of `out` is tap t of keypoint i.  Geom: H, W =
 // score-map size, Ho, Wo = cell grid, in_off = first cell of the level.
-hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, int relu6, const hfnet_keypoint* kps,
-                               const int* n_in, long long kps_stride, const Geom& g, hipStream_t s);
+hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, int relu6, const hfnet_keypoint* kps, const int* n_in,
+                               long long kps_stride, const int* level_keypoints /* upper bound of n_in per level */, const Geom& g, hipStream_t s);
 // depthwise 3x3 (stride 1 / 2) + BN + ReLU6
 hipError_t launch_depthwise(const float* in, const DwPack& dp, int stride, float* out, const Geom& g, hipStream_t s);
 // whole inverted-residual block (expand -> depthwise -> project [+ residual]) in one launch; the expanded

@@ -9,6 +9,7 @@
 // "physical" order of common.hpp, levels and frames concatenated ([level][frame][y][x][c]).
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -189,7 +190,7 @@ struct ConvArgs {
     int n;            // valid output columns == output row stride
     int nt_total;
     int relu6;
-    int xcd_map;      // 3x3 kernel: XCD-aware tile order (measured slower so far; HFNET_C3_XCD=1)
+    int level_tiles[HFNET_MAX_LEVELS];   // 3x3 kernel: 128-row tiles launched per image of each level (exact 1-D grid)
 };
 
 // BN (+ ReLU6) (+ residual) and store of a wave's 32 x (NT*32) accumulator tile.  VALU instructions compete
@@ -370,25 +371,27 @@ struct TapArgs { const hfnet_keypoint* kps; const int* n_in; long long kps_strid
 template <int NT, bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g, TapArgs ta) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
-    const int image = blockIdx.z, level = image / g.batch, frame = image - level * g.batch;
+    // exact 1-D grid, order [level][frame][column-tile group][row tile]: no workgroups are launched for tiles a
+    // level does not have (the smaller pyramid levels have a third of level 0's tiles)
+    const int G = a.nt_total / NT;
+    int level = 0, rest = blockIdx.x;
+    for (; level < g.n_levels - 1; ++level) {
+        const int per = g.batch * G * a.level_tiles[level];
+        if (rest < per) break;
+        rest -= per;
+    }
+    const int tl = a.level_tiles[level];
+    const int frame = rest / (G * tl);
+    rest -= frame * G * tl;
+    const int grp = rest / tl, tile = rest - grp * tl;
+    const int image = level * g.batch + frame;
     const LevelGeom lv = g.lv[level];
     const int Hc = GATHER ? lv.Ho : lv.H, Wc = GATHER ? lv.Wo : lv.W;
     const int nrows = GATHER ? ta.n_in[image] * 4 : Hc * Wc;
-    // Tile order: x = 128-row tile, y = column-tile group, z = image.  (Experiment HFNET_C3_XCD=1: an XCD-aware order --
-    // contiguous runs of row tiles per XCD, both column groups adjacent -- cut this kernel's HBM fetches by 43 % but ran
-    // 5-50 % slower; the kernel is issue-bound, not HBM-bound.)
+    // (An XCD-aware order -- contiguous runs of row tiles per XCD, both column groups adjacent -- cut this kernel's HBM
+    // fetches by 43 % but ran 5-50 % slower: the kernel is issue-bound, not HBM-bound.)
     const int T = (nrows + 127) >> 7;
-    int tile;
-    const int grp = blockIdx.y;
-    if (a.xcd_map) {                                                           // experiment: contiguous eighths of the row tiles per XCD
-        const int chunk = (blockIdx.x + image) & 7, q = blockIdx.x >> 3;
-        const int first = (chunk * T) >> 3, count = (((chunk + 1) * T) >> 3) - first;
-        if (q >= count) return;
-        tile = first + q;
-    } else {
-        tile = blockIdx.x;
-        if (tile >= T) return;
-    }
+    if (tile >= T) return;                                      // (gather: an image with fewer keypoints than its level's budget)
     const int nt0 = grp * NT;
     const int p0 = tile * 128 + wave * 32;
     int y, x;
@@ -534,7 +537,8 @@ static void launch_c3_nt(const ConvArgs& a, const Geom& g, const TapArgs* ta, di
 static ConvArgs make_args(const float* A, const ConvPack& cp, const float* res, float* out, long long P, int relu6) {
     ConvArgs a;
     a.A = A; a.W = (const f32x4*)cp.w; a.scale = cp.scale; a.shift = cp.shift; a.res = res; a.out = out;
-    a.P = P; a.cin = cp.cin; a.n = cp.n; a.nt_total = cp.nt_total; a.relu6 = relu6; a.xcd_map = 0;
+    a.P = P; a.cin = cp.cin; a.n = cp.n; a.nt_total = cp.nt_total; a.relu6 = relu6;
+    for (int l = 0; l < HFNET_MAX_LEVELS; ++l) a.level_tiles[l] = 1;
     return a;
 }
 
@@ -571,14 +575,18 @@ hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* res
 }
 
 static hipError_t launch_conv3x3_any(const float* A, const ConvPack& cp, float* out, int relu6, const Geom& g, const TapArgs* ta,
-                                     int max_rows, hipStream_t s) {
+                                     const int* level_rows, hipStream_t s) {
     ConvArgs a = make_args(A, cp, nullptr, out, 0, relu6);
-    { const char* v = getenv("HFNET_C3_XCD"); a.xcd_map = v ? atoi(v) : 0; }
     int ntb = cp.nt_per_block;
     if (!ta) { static const int t = []() { const char* v = getenv("HFNET_CONV3_NT"); return v ? atoi(v) : 0; }(); if (t > 0 && cp.nt_total % t == 0) ntb = t; }
     if (ta) { static const int t = []() { const char* v = getenv("HFNET_TAPS_NT"); return v ? atoi(v) : 4; }(); if (t > 0 && cp.nt_total % t == 0) ntb = t; }
-    const int tiles = (max_rows + 127) / 128;
-    dim3 grid(a.xcd_map ? 8 * ((tiles + 7) / 8) : tiles, cp.nt_total / ntb, g.n_levels * g.batch);
+    long long wgs = 0;
+    for (int l = 0; l < HFNET_MAX_LEVELS; ++l) {
+        a.level_tiles[l] = l < g.n_levels ? std::max((level_rows[l] + 127) / 128, 1) : 1;
+        if (l < g.n_levels) wgs += (long long)g.batch * (cp.nt_total / ntb) * a.level_tiles[l];
+    }
+    if (wgs <= 0 || wgs > 0x7fffffffll) return hipErrorInvalidValue;
+    dim3 grid((unsigned)wgs, 1, 1);
     switch (ntb) {
         case 1: launch_c3_nt<1>(a, g, ta, grid, s); break;
         case 2: launch_c3_nt<2>(a, g, ta, grid, s); break;
@@ -594,15 +602,17 @@ static hipError_t launch_conv3x3_any(const float* A, const ConvPack& cp, float* 
 }
 
 hipError_t launch_conv3x3(const float* A, const ConvPack& cp, float* out, int relu6, const Geom& g, hipStream_t s) {
-    int maxpix = 0;
-    for (int l = 0; l < g.n_levels; ++l) maxpix = max(maxpix, g.lv[l].H * g.lv[l].W);
-    return launch_conv3x3_any(A, cp, out, relu6, g, nullptr, maxpix, s);
+    int rows[HFNET_MAX_LEVELS] = {0};
+    for (int l = 0; l < g.n_levels; ++l) rows[l] = g.lv[l].H * g.lv[l].W;
+    return launch_conv3x3_any(A, cp, out, relu6, g, nullptr, rows, s);
 }
 
 hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, int relu6, const hfnet_keypoint* kps, const int* n_in,
-                               long long kps_stride, const Geom& g, hipStream_t s) {
+                               long long kps_stride, const int* level_keypoints, const Geom& g, hipStream_t s) {
     const TapArgs ta = {kps, n_in, kps_stride};
-    return launch_conv3x3_any(A, cp, out, relu6, g, &ta, (int)(kps_stride * 4), s);
+    int rows[HFNET_MAX_LEVELS] = {0};
+    for (int l = 0; l < g.n_levels; ++l) rows[l] = 4 * (int)std::min<long long>(level_keypoints[l], kps_stride);
+    return launch_conv3x3_any(A, cp, out, relu6, g, &ta, rows, s);
 }
 
 // =========================================================================== fused inverted-residual block
