@@ -6,6 +6,8 @@
 //   KeyFrameDatabase scans            src/KeyFrameDatabase.cc:86-104, 178-197
 #include "kernels.hpp"
 
+#include <mutex>
+
 #include <cfloat>
 
 namespace hfnet {
@@ -625,8 +627,8 @@ hipError_t launch_db_scores_batch(const float* q, int n_queries, const float* db
     if (n <= 0 || n_queries <= 0) return hipSuccess;
     if (dim % 256 || dim > 4096) return hipErrorInvalidValue;
     const size_t lds = (size_t)DBQ * dim * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_db_scores_batch, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr_set = true; }
+    static std::once_flag attr_once;                                    // > 64 KB of dynamic LDS has to be requested once
+    std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)k_db_scores_batch, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); });
     const int w = db_scan_workgroups(n), wgs = w < 256 ? w : 256;      // one 128 KB query tile per CU
     hipLaunchKernelGGL(k_db_scores_batch, dim3(wgs, (n_queries + DBQ - 1) / DBQ), dim3(256), lds, s, q, n_queries, db, occupied, n, dim, scores, best_partial);
     return hipGetLastError();
