@@ -140,7 +140,7 @@ int Net::build(Engine* eng, const NetConfig& c) {
         HF_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         HF_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         const char* v = getenv("HFNET_TWO_STREAMS");
-        two_streams = v ? atoi(v) : 1;
+        two_streams = v ? atoi(v) : 3;   // 0 one stream; 1 fork after layer 7; 2 fork after the detector conv; 3 = 2 + deferred join
     }
     const int first_layer = c.from_intermediate ? 7 : 1;
     const int last_layer = c.global ? 18 : 7;
@@ -261,7 +261,7 @@ static int run_block(Net& n, int L, int n_used, hipStream_t st) {   // layer L =
     return HFNET_OK;
 }
 
-int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget) {
+int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget, bool defer_global) {
     const DeviceWeights& w = e->w;
     const int NL = cfg.n_levels;
     if (!cfg.from_intermediate) {
@@ -275,10 +275,17 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         } else {
             HF_LAUNCH(e, stream, "stem", launch_stem(imgs, w.stem_w, w.stem_scale, w.stem_shift, w.stem_out, act[1], gs, stream));
         }
-        for (int L = first; L <= 7; ++L) HF_TRY(run_block(*this, L, NL, stream));
+        for (int L = first; L <= 7; ++L) {
+            // the previous step's global branch (deferred join) still reads layer 7 on its own stream
+            if (L == 7 && join_pending) { HF_HIP(hipStreamWaitEvent(stream, ev_join, 0)); join_pending = false; }
+            HF_TRY(run_block(*this, L, NL, stream));
+        }
     }
+    if (join_pending) { HF_HIP(hipStreamWaitEvent(stream, ev_join, 0)); join_pending = false; }   // (intermediate-input models)
     const bool fork = cfg.global && cfg.local && two_streams && stream_global;
-    if (cfg.global && fork) {
+    // deferring needs every layer up to 7 fused (the unfused chain shares its scratch tensors with the global branch)
+    const bool defer = defer_global && fork && two_streams == 3 && fuse_blocks && fuse_max_layer >= 7;
+    if (fork && two_streams == 1) {
         HF_HIP(hipEventRecord(ev_fork, stream));
         HF_HIP(hipStreamWaitEvent(stream_global, ev_fork, 0));
         HF_TRY(forward_global(stream_global));
@@ -289,6 +296,14 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         Geom gh = geom(7, 7, 0, NL);
         for (int l = 0; l < NL; ++l) { gh.lv[l].pt = gh.lv[l].pl = 1; gh.lv[l].out_off = pix_cell[l]; }
         HF_LAUNCH(e, stream, "conv3x3_det", launch_conv3x3(act[7], w.det1, det_hidden, 1, gh, stream));
+        if (fork && two_streams >= 2) {
+            // the global branch starts after the (chip-filling, MFMA-bound) detector conv: it overlaps the long tail of
+            // small kernels (softmax, NMS, top-K, sparse descriptor head) instead of time-sharing with that conv
+            HF_HIP(hipEventRecord(ev_fork, stream));
+            HF_HIP(hipStreamWaitEvent(stream_global, ev_fork, 0));
+            HF_TRY(forward_global(stream_global));
+            HF_HIP(hipEventRecord(ev_join, stream_global));
+        }
         HF_LAUNCH(e, stream, "pointwise_det", launch_pointwise(det_hidden, w.det2, nullptr, logits, pc, 0, stream));
         Geom gd = geom(7, 7, 0, NL);
         for (int l = 0; l < NL; ++l) { gd.lv[l].Ho = lp[l].Hc; gd.lv[l].Wo = lp[l].Wc; gd.lv[l].in_off = pix_cell[l]; gd.lv[l].out_off = pix_img[l]; }
@@ -319,7 +334,8 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
             HF_TRY(run_dense_desc());
         }
     }
-    if (cfg.global && fork) HF_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+    if (cfg.global && fork && defer) join_pending = true;
+    else if (cfg.global && fork) HF_HIP(hipStreamWaitEvent(stream, ev_join, 0));
     else if (cfg.global) HF_TRY(forward_global(stream));
     return HFNET_OK;
 }
@@ -733,7 +749,8 @@ static int extract_chunk(hfnet_extractor* x, int nb, const uint8_t* d_images, in
     TopkBudget budget;
     std::memset(&budget, 0, sizeof budget);
     for (int l = 0; l < x->n_levels; ++l) budget.k[l] = x->features_per_level[l];
-    HF_TRY(net.forward(imgs, x->threshold, budget));
+    const bool defer = d_n_level == nullptr;      // device-resident call: nothing of the global branch is needed on this stream
+    HF_TRY(net.forward(imgs, x->threshold, budget, defer));
     SampleArgs sa;
     std::memset(&sa, 0, sizeof sa);
     sa.desc_map = net.sample_source(); sa.sparse = net.last_sparse ? 1 : 0; sa.kps_in = net.kps_level; sa.n_in = net.n_level; sa.kps_stride = net.cfg.max_keypoints;
@@ -747,7 +764,8 @@ static int extract_chunk(hfnet_extractor* x, int nb, const uint8_t* d_images, in
     }
     HF_LAUNCH(&eng, net.stream, "sample", launch_sample(sa, gs, net.stream));
     if (d_global)
-        HF_HIP(hipMemcpyAsync(d_global, net.global_out, sizeof(float) * (size_t)nb * eng.w.global_dim, hipMemcpyDeviceToDevice, net.stream));
+        HF_HIP(hipMemcpyAsync(d_global, net.global_out, sizeof(float) * (size_t)nb * eng.w.global_dim, hipMemcpyDeviceToDevice,
+                              net.join_pending ? net.stream_global : net.stream));
     return HFNET_OK;
 }
 

@@ -91,7 +91,10 @@ struct Net {
     void release();
     Geom geom(int layer_in, int layer_out, int first_level, int n_levels_used) const;
     // enqueue the whole forward pass; imgs: per-level u8 sources (ignored when from_intermediate)
-    int forward(const ImageSet& imgs, float threshold, const TopkBudget& budget);
+    // defer_global: do not wait for the global branch at the end; the caller consumes global_out on stream_global and the
+    // next forward() waits for it before layer 7 is overwritten
+    int forward(const ImageSet& imgs, float threshold, const TopkBudget& budget, bool defer_global = false);
+    bool join_pending = false;
     int tap(int id, std::vector<float>& out);
     int run_dense_desc();
     int forward_global(hipStream_t st);

@@ -118,7 +118,9 @@ int hfnet_extractor_extract(hfnet_extractor* x, const uint8_t* image, int row_st
 /* Batched form (independent frames, BASELINE config 4): images are n_frames buffers of
  * height x row_stride bytes, `frame_stride` bytes apart; outputs are n_frames slots of n_features
  * rows each.  `on_device` != 0: every pointer is a device pointer on the engine's GPU and the call
- * only enqueues work on the engine stream (use hfnet_engine_synchronize). */
+ * only enqueues work (use hfnet_engine_synchronize; the matcher entry points order themselves behind it, see
+ * hfnet_engine_fence).  The global descriptors of such a call are produced on a second stream that may still run
+ * while the next call's backbone executes: they are complete after hfnet_engine_synchronize. */
 int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_t* images,
                                   int row_stride, size_t frame_stride, hfnet_keypoint* kps,
                                   float* local_desc, float* global_desc, int* n_out, int on_device);

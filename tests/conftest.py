@@ -39,6 +39,14 @@ def oracle_model(weights_path):
 
 @pytest.fixture(scope="session")
 def engine(weights_path):
+    # torch (used by one device-resident test for its device buffers) bundles its own HIP runtime: it has to initialise
+    # before libhfnet_hip.so pulls in the system one, or it sees no devices afterwards (bench.py has the same order)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     from hfnet_slam_amd import capi
     if capi.device_count() < 1:
         pytest.fail("GPU test selected but no HIP device is visible: " + capi.last_error())

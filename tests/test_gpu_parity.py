@@ -343,3 +343,58 @@ def test_batched_triangulation_matches_per_pair_calls(engine):
             n1, m1 = engine.search_for_triangulation(d1, d2, 0.75)
             assert n1 == rn
             _eq("single", m1, rm)
+
+
+@pytest.mark.parametrize("streams", ["0", "1", "2", "3"])
+def test_device_resident_pipeline_matches_host_path(engine, streams, monkeypatch):
+    """bench.py's path: on_device extract_batch + batched SearchByBoW over consecutive steps, the global branch on its own
+    stream with the join deferred into the next step (HFNET_TWO_STREAMS=3) -- every step must equal the host-pointer path."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU (its HIP runtime must initialise before libhfnet_hip.so: run with -m gpu)")
+    from hfnet_slam_amd import capi
+    import ctypes as C
+    monkeypatch.setenv("HFNET_TWO_STREAMS", streams)
+    w, h, nf, B, steps = 192, 144, 300, 3, 4
+    dev = torch.device("cuda", 0)
+    x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, 3, max_batch=B)
+    xh = capi.Extractor(engine, w, h, nf, 0.01, 1.2, 3, max_batch=B)          # reference: host-pointer calls
+    imgs = np.stack([synth_image(h, w, 900 + i, "natural" if i % 2 else "uniform") for i in range(B * steps)])
+    d_img = torch.from_numpy(imgs).to(dev)
+    kps = torch.zeros((steps * B, nf, 4), dtype=torch.float32, device=dev)
+    desc = torch.zeros((steps * B, nf, 256), dtype=torch.float32, device=dev)
+    glob = torch.zeros((steps * B, engine.global_dim), dtype=torch.float32, device=dev)
+    n_rows = torch.zeros((steps * B,), dtype=torch.int32, device=dev)
+    match = torch.zeros((steps * B, nf), dtype=torch.int32, device=dev)
+    mdist = torch.zeros((steps * B, nf), dtype=torch.float32, device=dev)
+    mcnt = torch.zeros((steps * B,), dtype=torch.int32, device=dev)
+    tset = torch.arange(0, steps * B, dtype=torch.int32, device=dev)
+    qset = torch.clamp(tset - 1, min=0).to(torch.int32)
+    torch.cuda.synchronize()
+    L = capi.lib()
+    for s_ in range(steps):                                                    # nothing waits on the host inside the loop
+        o = s_ * B
+        x.extract_batch_device(B, d_img[o].data_ptr(), w, w * h, kps[o].data_ptr(), desc[o].data_ptr(), glob[o].data_ptr(), n_rows[o:].data_ptr())
+        engine.fence()
+        st = L.hfnet_match_search_by_bow_batch(engine.h, B, C.c_void_p(desc.data_ptr()), C.c_size_t(nf * 256), C.c_void_p(n_rows.data_ptr()), steps * B,
+                                               C.c_void_p(qset[o:].data_ptr()), C.c_void_p(tset[o:].data_ptr()), nf, 256, C.c_float(0.6),
+                                               C.c_void_p(match[o].data_ptr()), C.c_void_p(mdist[o].data_ptr()), C.c_void_p(mcnt[o:].data_ptr()), 1)
+        assert st == capi.OK, capi.last_error()
+    engine.synchronize(); torch.cuda.synchronize()
+    n_d = n_rows.cpu().numpy(); k_d = kps.cpu().numpy(); d_d = desc.cpu().numpy(); g_d = glob.cpu().numpy()
+    m_d = match.cpu().numpy(); c_d = mcnt.cpu().numpy()
+    prev = None
+    for i in range(steps * B):
+        n, k, d, g, _ = xh.extract(imgs[i])
+        assert n_d[i] == n, (i, n_d[i], n)
+        kk = k_d[i, :n]
+        for j, f in enumerate(("x", "y", "response")):
+            _eq(f"frame {i} kps.{f}", kk[:, j], k[f])
+        _eq(f"frame {i} desc", d_d[i, :n], d)
+        _eq(f"frame {i} global", g_d[i], g)
+        if prev is not None:
+            cn, cm, _ = engine.search_by_bow(prev, d, 0.6)
+            assert c_d[i] == cn
+            _eq(f"frame {i} matches", m_d[i, :len(prev)], cm)
+        prev = d
+    x.close(); xh.close()
