@@ -806,9 +806,15 @@ constexpr TileSplit split_tiles(int mt_in, int mt_out, int c1, int c3) {
 }
 
 // workgroups per CU the register budget is tuned for: three where the LDS tile allows it (f32 MFMA and VALU work
-// share one issue pipe, so more resident waves is what hides the LDS / barrier latencies)
+// share one issue pipe, so more resident waves is what hides the LDS / barrier latencies).  "Diet": the widest
+// high-resolution block does not keep its input fragments and projection weights in registers across the chunk
+// loop (236 VGPRs, 2 workgroups per CU) but re-reads them from L1 / L2 when they are used (<= 168, 3 workgroups).
 template <int STRIDE, int NTO, int KQT, int TW>
-constexpr int fused2_min_blocks() { return (STRIDE == 2 && TW == 8) || (STRIDE == 1 && KQT <= 3 && NTO == 1) ? 3 : 2; }
+constexpr bool fused2_diet() { return STRIDE == 1 && (KQT >= 6 || NTO >= 2); }    // layers 6, 7, 9-14
+template <int STRIDE, int NTO, int KQT, int TW>
+constexpr int fused2_min_blocks() {
+    return (STRIDE == 2 && TW == 8) || (STRIDE == 1 && KQT <= 3 && NTO == 1) || fused2_diet<STRIDE, NTO, KQT, TW>() ? 3 : 2;
+}
 
 template <int STRIDE, int NTO, int KQT, bool HAS_EXPAND, int TW>
 __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) void k_block_fused2(FusedArgs a, Geom g) {
@@ -856,9 +862,12 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
     for (int nt = 0; nt < NTO; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) pacc[nt][i] = 0.0f;
-    // A fragments of this wave's halo M-tiles (kept for all chunks)
+    // A fragments of this wave's halo M-tiles: kept for all chunks, or (diet) only their addresses
     constexpr int KQA = HAS_EXPAND ? KQT : 1;
-    f32x4 afrag[MTW][KQA];
+    constexpr bool DIET = HAS_EXPAND && fused2_diet<STRIDE, NTO, KQT, TW>();
+    f32x4 afrag[DIET ? 1 : MTW][KQA];
+    const float* aptr[MTW];
+    bool aok[MTW];
     if (HAS_EXPAND) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
@@ -868,8 +877,11 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
             const int iy = iy0 + hy, ix = ix0 + hx;
             const bool ok = m < mt_count && hy < IH && hx < IW && iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W;
             const float* ap = a.X + (in_base + (long long)(ok ? iy * lv.W + ix : 0)) * a.cin + half * 4;
+            aptr[m] = ap; aok[m] = ok;
+            if (!DIET) {
 #pragma unroll
-            for (int kq = 0; kq < KQA; ++kq) afrag[m][kq] = ok ? *(const f32x4*)(ap + kq * 8) : zero4;
+                for (int kq = 0; kq < KQA; ++kq) afrag[m][kq] = ok ? *(const f32x4*)(ap + kq * 8) : zero4;
+            }
         }
     }
     const int dc = threadIdx.x & 31, doy = threadIdx.x >> 5;      // depthwise role: channel lane, output row
@@ -898,12 +910,18 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
             for (int m = 0; m < MTW; ++m) {
                 if (m < mt_count) {
                     const int mt = mt_first + m;
-                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][0][0], bfrag[0][0], zero16, 0, 0, 0);
+                    f32x4 af[KQA];
+#pragma unroll
+                    for (int kq = 0; kq < KQA; ++kq) {
+                        if (DIET) { const f32x4 v = *(const f32x4*)(aptr[m] + kq * 8); af[kq] = aok[m] ? v : zero4; }
+                        else af[kq] = afrag[m][kq];
+                    }
+                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][0], bfrag[0][0], zero16, 0, 0, 0);
 #pragma unroll
                     for (int kq = 0; kq < KQA; ++kq)
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
-                            if (kq + t > 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][kq][t], bfrag[kq][t], acc, 0, 0, 0);
+                            if (kq + t > 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kq][t], bfrag[kq][t], acc, 0, 0, 0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int pp = mt * 32 + 8 * q + 4 * half;
@@ -964,13 +982,14 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
         }
         const int kqc = min(4, (a.cexp - ch0) >> 3);
         f32x4 pfrag[4][NTO];
-        if (out_live) {
+        auto fetch_p = [&]() {
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq)
 #pragma unroll
                 for (int nt = 0; nt < NTO; ++nt)
                     pfrag[kq][nt] = kq < kqc ? a.Wpr[((size_t)(chunk * 4 + kq) * a.pr_nt_total + nt) * 64 + lane] : zero4;
-        }
+        };
+        if (out_live && !DIET) fetch_p();
         // ---- stage 2: thread = (channel dc, output row doy), ET -> D
         if (!(a.ablate & 2) && doy < rows_valid) {
             float row[3][IWP];
@@ -1005,6 +1024,7 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
         __syncthreads();          // D complete, ET free
         // ---- stage 3 of this chunk (reads D) and stage 1 of the next one (writes ET) share this phase
         if (out_live && !(a.ablate & 4)) {
+            if (DIET) fetch_p();
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) {
                 if (kq < kqc) {
