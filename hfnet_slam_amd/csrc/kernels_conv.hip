@@ -293,74 +293,8 @@ __global__ __launch_bounds__(256, 2) void k_pointwise(ConvArgs a) {
     conv_epilogue<NT>(a, acc, nt0, row0, a.P, half, r);
 }
 
-// Variant for wide inputs (cin >= 64): a lane's 16-byte slices of a long activation row are 4*cin bytes
-// apart across lanes, which defeats L1 (every lane touches its own cache line, 4x over-fetch).  Here the
-// workgroup stages its 128 rows x 32 channels through LDS with fully coalesced 128-byte row segments
-// (register double-buffered, one barrier per 32 channels); fragments come from LDS (row stride 144 B:
-// conflict-free ds_read_b128).  Same MFMA order, same results.
-template <int NT>
-__global__ __launch_bounds__(256, 2) void k_pointwise_lds(ConvArgs a) {
-    constexpr int LDA = 36;
-    __shared__ __attribute__((aligned(16))) float As[2][128 * LDA];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
-    const long long row0wg = (long long)blockIdx.x * 128;
-    const int nt0 = blockIdx.y * NT;
-    const int KQ = a.cin >> 3, KC = (KQ + 3) >> 2;
-    const int piece = tid & 7, rsub = tid >> 3;                    // 8 x 16 B per row, 32 rows per pass
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const f32x4* wp = a.W + ((size_t)nt0 * 64 + lane);
-    const size_t wstep = (size_t)a.nt_total * 64;
-    f32x16 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
-    f32x4 stage[4];
-    auto gload = [&](int c) {
-        const int kqc = min(4, KQ - 4 * c);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long long row = row0wg + rsub + 32 * i;
-            stage[i] = (row < a.P && piece < 2 * kqc) ? *(const f32x4*)(a.A + row * a.cin + 32 * c + 4 * piece) : zero;
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *(f32x4*)(&As[buf][(rsub + 32 * i) * LDA + 4 * piece]) = stage[i];
-    };
-    gload(0);
-    lstore(0);
-    f32x4 bv[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bv[nt] = wp[(size_t)nt * 64];
-    __syncthreads();
-    for (int c = 0; c < KC; ++c) {
-        if (c + 1 < KC) gload(c + 1);
-        const int kqc = min(4, KQ - 4 * c);
-        const float* arow = &As[c & 1][(wave * 32 + r) * LDA + half * 4];
-        for (int kq = 0; kq < kqc; ++kq) {
-            const int gk = 4 * c + kq;
-            const f32x4 av = *(const f32x4*)(arow + kq * 8);
-            f32x4 bn[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bn[nt] = bv[nt];
-            if (gk + 1 < KQ) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bn[nt] = wp[(size_t)(gk + 1) * wstep + (size_t)nt * 64];
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], acc[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
-        }
-        if (c + 1 < KC) lstore((c + 1) & 1);
-        __syncthreads();
-    }
-    const long long row0 = row0wg + wave * 32;
-    if (row0 < a.P) conv_epilogue<NT>(a, acc, nt0, row0, a.P, half, r);
-}
+// (An LDS-staged variant for wide inputs -- coalesced 128-byte row segments instead of per-lane 16-byte slices -- was
+// measured on MI355X and gave no gain; it is not kept.)
 
 // dense 3x3, stride 1, 'SAME' (pad 1): tiles of 32 consecutive pixels of ONE image; out-of-image taps
 // contribute fma(0, w, acc) == acc, i.e. they are skipped exactly as the oracle skips them.
@@ -524,9 +458,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g, TapArgs 
 
 template <int NT>
 static void launch_pw_nt(const ConvArgs& a, dim3 grid, hipStream_t s) {
-    static const int lds_min_cin = []() { const char* v = getenv("HFNET_PW_LDS_MIN_CIN"); return v ? atoi(v) : 1 << 30; }();  // measured: no gain on MI355X, off by default
-    if (a.cin >= lds_min_cin) hipLaunchKernelGGL(k_pointwise_lds<NT>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_pointwise<NT>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_pointwise<NT>, grid, dim3(256), 0, s, a);
 }
 template <int NT>
 static void launch_c3_nt(const ConvArgs& a, const Geom& g, const TapArgs* ta, dim3 grid, hipStream_t s) {
