@@ -742,7 +742,7 @@ constexpr TileSplit split_tiles(int mt_in, int mt_out, int c1, int c3) {
 // high-resolution block does not keep its input fragments and projection weights in registers across the chunk
 // loop (236 VGPRs, 2 workgroups per CU) but re-reads them from L1 / L2 when they are used (<= 168, 3 workgroups).
 template <int STRIDE, int NTO, int KQT, int TW>
-constexpr bool fused2_diet() { return STRIDE == 1 && (KQT >= 6 || NTO >= 2); }    // layers 6, 7, 9-14
+constexpr bool fused2_diet() { return (STRIDE == 1 && (KQT >= 6 || NTO >= 2)) || KQT >= 12; }    // layers 6, 7, 8, 9-14
 template <int STRIDE, int NTO, int KQT, int TW>
 constexpr int fused2_min_blocks() {
     return (STRIDE == 2 && TW == 8) || (STRIDE == 1 && KQT <= 3 && NTO == 1) || fused2_diet<STRIDE, NTO, KQT, TW>() ? 3 : 2;
@@ -1920,7 +1920,7 @@ bool block_fusable(const BlockPack& b) {
     const int nto = (b.cout + 31) / 32;
     if (nto > 3 || (b.stride != 1 && b.stride != 2)) return false;
     if (!b.has_expand && b.expand > 32) return false;
-    if (b.stride == 2 && b.cin > 24) return false;   // no register-resident variant: the three-launch path is faster (layer_8)
+    if (b.stride == 2 && b.cin > 24 && !(b.cin == 96 && nto == 2)) return false;   // wide stride-2 blocks: only layer_8's shape has a (register-diet) variant
     return b.cin % 8 == 0 && b.expand % 8 == 0;
 }
 
@@ -1975,6 +1975,7 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
         if (b.has_expand && st == 1 && kq == 6 && nto == 3) return launch_block_fused2_t<1, 3, 6, true>(a, g, s);
         if (b.has_expand && st == 1 && kq == 6 && nto == 2) return launch_block_fused2_t<1, 2, 6, true>(a, g, s);
         if (b.has_expand && st == 1 && kq == 9 && nto == 3) return launch_block_fused2_t<1, 3, 9, true>(a, g, s);
+        if (b.has_expand && st == 2 && kq == 12 && nto == 2) return launch_block_fused2_t<2, 2, 12, true>(a, g, s);
     }
     if (b.stride == 1) return launch_block_fused_t<1, 8, 16>(a, g, nto, s);
     return launch_block_fused_t<2, 8, 8>(a, g, nto, s);
