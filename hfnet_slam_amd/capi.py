@@ -218,6 +218,8 @@ class Model:
 
     def detect_global(self, intermediate: np.ndarray):
         x = np.ascontiguousarray(intermediate, np.float32)
+        if self.mode == MODE_INTERMEDIATE_TO_GLOBAL and x.size != self.height * self.width * self.engine.c_local:
+            raise ValueError(f"intermediate map of {x.shape} given to a {self.height}x{self.width}x{self.engine.c_local} model")
         g = np.zeros((self.engine.global_dim,), np.float32)
         st = lib().hfnet_model_detect_global(self.h, _p(x), _p(g))
         return st, g

@@ -398,3 +398,67 @@ def test_device_resident_pipeline_matches_host_path(engine, streams, monkeypatch
             _eq(f"frame {i} matches", m_d[i, :len(prev)], cm)
         prev = d
     x.close(); xh.close()
+
+
+def test_concurrent_callers(engine, oracle_model):
+    """SURVEY.md 8(b) threading contract: the per-level model instances are called concurrently from worker threads
+    (HFextractor.cc:265), the global-only model from two SLAM threads at once (Tracking.cc:2026, LocalMapping.cc:367), the
+    matcher from anywhere -- different contexts run concurrently, one context serialises internally; results stay exact."""
+    import threading
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    sizes = [(120, 160), (100, 133), (83, 111), (69, 92)]
+    imgs = [synth_image(h, w, 700 + i) for i, (h, w) in enumerate(sizes)]
+    models = [capi.Model(engine, capi.MODE_LOCAL_AND_INTERMEDIATE if i == 0 else capi.MODE_LOCAL, h, w, 300) for i, (h, w) in enumerate(sizes)]
+    refs = [oracle_model.detect(img, O.MODE_LOCAL_AND_INTERMEDIATE if i == 0 else O.MODE_LOCAL, 200, 0.01) for i, img in enumerate(imgs)]
+    gm = capi.Model(engine, capi.MODE_INTERMEDIATE_TO_GLOBAL, sizes[0][0] // 8, sizes[0][1] // 8, 1)    # the intermediate map's size
+    inter = refs[0][3]
+    ok_g, ref_g = oracle_model.detect_global(inter)
+    assert ok_g
+    rng = np.random.default_rng(5)
+    a = _unit_rows(rng, 200); b = _unit_rows(rng, 180)
+    ref_m = O.search_by_bow(a, b, 0.6)
+    errors = []
+
+    def level_worker(i):
+        try:
+            for _ in range(8):
+                st, kps, desc, aux = models[i].detect(imgs[i], 200, 0.01, with_aux=(i == 0))
+                assert st == capi.OK, capi.last_error()
+                ok, rk, rd, ri = refs[i]
+                assert len(kps) == len(rk)
+                for f in ("x", "y", "response"):
+                    assert np.array_equal(kps[f], rk[f]), (i, f)
+                assert np.array_equal(desc, rd), i
+                if i == 0:
+                    assert np.array_equal(aux, ri)
+        except Exception as e:                                   # noqa: BLE001 -- reported below
+            errors.append(("level", i, repr(e)))
+
+    def global_worker(k):
+        try:
+            for _ in range(8):
+                st, g = gm.detect_global(inter)
+                assert st == capi.OK and np.array_equal(g, ref_g), k
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(("global", k, repr(e)))
+
+    def match_worker(k):
+        try:
+            for _ in range(8):
+                n, m, d = engine.search_by_bow(a, b, 0.6)
+                assert n == ref_m[0] and np.array_equal(m, ref_m[1]) and np.array_equal(d, ref_m[2]), k
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(("match", k, repr(e)))
+
+    threads = [threading.Thread(target=level_worker, args=(i,)) for i in range(4)]
+    threads += [threading.Thread(target=global_worker, args=(k,)) for k in range(2)]
+    threads += [threading.Thread(target=match_worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for m in models:
+        m.close()
+    gm.close()
+    assert not errors, errors
