@@ -686,6 +686,7 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
     NetConfig c;
     c.n_levels = n_levels; c.batch = max_batch; c.local = true; c.global = true; c.from_intermediate = false;
     x->net.fuse_stem = 0;   // stem + layer_2 fusion exists (HFNET_FUSE_STEM=1) but measured slower than two launches: off
+    { const char* v = getenv("HFNET_GRAPH"); x->use_graph = v ? atoi(v) : 1; }
     c.max_keypoints = 1;
     for (int l = 0; l < n_levels; ++l) { c.width[l] = x->level_w[l]; c.height[l] = x->level_h[l]; c.max_keypoints = std::max(c.max_keypoints, x->features_per_level[l]); }
     HF_TRY(x->net.build(&e->impl, c));
@@ -715,6 +716,7 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
 void hfnet_extractor_destroy(hfnet_extractor* x) {
     if (!x) return;
     (void)hipSetDevice(x->eng->impl.device);
+    for (auto& kv : x->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : x->allocs) (void)hipFree(p);
     delete x;
 }
@@ -769,6 +771,37 @@ static int extract_chunk(hfnet_extractor* x, int nb, const uint8_t* d_images, in
     return HFNET_OK;
 }
 
+// host-pointer path: the chunk's launches always use the extractor's own staging buffers, so they are captured once per
+// chunk size into a graph (both streams: the global branch forks and joins inside it) and replayed afterwards
+static int extract_chunk_graphed(hfnet_extractor* x, int nb) {
+    Engine& eng = x->eng->impl;
+    Net& net = x->net;
+    hipStream_t st = net.stream;
+    auto direct = [&]() { return extract_chunk(x, nb, x->d_pyr[0], x->width, (long long)x->width * x->height, x->d_kps, x->d_desc, nullptr, x->d_n, x->d_n_level); };
+    if (!x->use_graph || eng.prof.enabled) return direct();
+    if (net.join_pending) { HF_HIP(hipStreamWaitEvent(st, net.ev_join, 0)); net.join_pending = false; }   // (not capturable: recorded outside)
+    auto it = x->graphs.find(nb);
+    if (it == x->graphs.end()) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); x->use_graph = 0; return direct(); }
+        const int rc = direct();
+        const hipError_t er = hipStreamEndCapture(st, &graph);
+        if (rc != HFNET_OK || er != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (graph) (void)hipGraphDestroy(graph);
+            x->use_graph = 0;                                     // capture is not available here: plain launches from now on
+            if (getenv("HFNET_GRAPH_VERBOSE")) fprintf(stderr, "hfnet: graph capture failed (rc %d, %s)\n", rc, hipGetErrorString(er));
+            return direct();
+        }
+        (void)hipGraphDestroy(graph);
+        if (getenv("HFNET_GRAPH_VERBOSE")) fprintf(stderr, "hfnet: captured the %d-frame chunk into a graph\n", nb);
+        it = x->graphs.emplace(nb, exec).first;
+    }
+    HF_HIP(hipGraphLaunch(it->second, st));
+    return HFNET_OK;
+}
+
 int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_t* images, int row_stride, size_t frame_stride,
                                   hfnet_keypoint* kps, float* local_desc, float* global_desc, int* n_out, int on_device) {
     API_GUARD(x, "extractor");
@@ -792,7 +825,7 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
             for (int f = 0; f < nb; ++f)
                 HF_HIP(hipMemcpy2DAsync(x->d_pyr[0] + (size_t)f * x->width * x->height, x->width, images + (size_t)(f0 + f) * frame_stride, row_stride,
                                         x->width, x->height, hipMemcpyHostToDevice, st));
-            HF_TRY(extract_chunk(x, nb, x->d_pyr[0], x->width, (long long)x->width * x->height, x->d_kps, x->d_desc, nullptr, x->d_n, x->d_n_level));
+            HF_TRY(extract_chunk_graphed(x, nb));
             HF_HIP(hipMemcpyAsync(n_out + f0, x->d_n, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
             if (global_desc) HF_HIP(hipMemcpyAsync(global_desc + (size_t)f0 * G, x->net.global_out, sizeof(float) * (size_t)nb * G, hipMemcpyDeviceToHost, st));
             HF_HIP(hipStreamSynchronize(st));

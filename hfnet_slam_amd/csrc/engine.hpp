@@ -2,6 +2,7 @@
 #pragma once
 #include "kernels.hpp"
 
+#include <map>
 #include <memory>
 
 namespace hfnet {
@@ -137,6 +138,10 @@ struct hfnet_extractor {
     float* d_desc = nullptr;             // [max_batch][n_features][256]
     int* d_n = nullptr;                  // [max_batch]
     int* d_n_level = nullptr;            // [max_batch][n_levels]
+    // host-pointer calls replay a captured graph of the ~75 launches of a chunk (same staging buffers every call): a
+    // frame at a time the launches themselves are a good part of the latency.  One executable graph per chunk size.
+    std::map<int, hipGraphExec_t> graphs;
+    int use_graph = 1;
     std::mutex mu;
 };
 
