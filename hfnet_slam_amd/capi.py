@@ -28,6 +28,8 @@ SYMBOLS = [
     "hfnet_extractor_create", "hfnet_extractor_destroy", "hfnet_extractor_tables",
     "hfnet_extractor_extract", "hfnet_extractor_extract_batch",
     "hfnet_descriptor_distance", "hfnet_resampler", "hfnet_match_search_by_bow", "hfnet_match_search_by_bow_batch", "hfnet_match_search_for_triangulation", "hfnet_match_search_for_triangulation_batch",
+    "hfnet_store_create", "hfnet_store_destroy", "hfnet_store_put", "hfnet_store_rows", "hfnet_store_search_by_bow",
+    "hfnet_store_search_for_triangulation",
     "hfnet_db_create", "hfnet_db_destroy", "hfnet_db_add", "hfnet_db_erase", "hfnet_db_clear", "hfnet_db_query", "hfnet_db_query_batch",
     "hfnet_profile_enable", "hfnet_profile_reset", "hfnet_profile_filter", "hfnet_profile_count", "hfnet_profile_get",
 ]
@@ -51,7 +53,7 @@ def lib() -> C.CDLL:
         L.hfnet_last_error.restype = C.c_char_p
         for s in SYMBOLS:
             getattr(L, s)  # AttributeError if the library does not export it
-        for s in ("hfnet_engine_destroy", "hfnet_model_destroy", "hfnet_extractor_destroy", "hfnet_db_destroy"):
+        for s in ("hfnet_engine_destroy", "hfnet_model_destroy", "hfnet_extractor_destroy", "hfnet_db_destroy", "hfnet_store_destroy"):
             getattr(L, s).restype = None
             getattr(L, s).argtypes = [C.c_void_p]
         _lib = L
@@ -290,6 +292,49 @@ class Extractor:
         """All pointers are raw device addresses (ints); only enqueues work on the engine's GPU."""
         _chk(lib().hfnet_extractor_extract_batch(self.h, int(n_frames), C.c_void_p(d_images), int(row_stride), C.c_size_t(frame_stride),
                                                  C.c_void_p(d_kps), C.c_void_p(d_desc), C.c_void_p(d_global), C.c_void_p(d_n), 1))
+
+
+class Store:
+    """Device-resident descriptor sets (one slot per keyframe) for the batched matchers."""
+
+    def __init__(self, engine: Engine, n_sets: int, max_rows: int, dim: int = DESC_DIM):
+        self.engine, self.n_sets, self.max_rows, self.dim = engine, n_sets, max_rows, dim
+        self.h = C.c_void_p()
+        _chk(lib().hfnet_store_create(engine.h, n_sets, max_rows, dim, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().hfnet_store_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def put(self, slot: int, rows: np.ndarray):
+        r = np.ascontiguousarray(rows, np.float32)
+        _chk(lib().hfnet_store_put(self.h, int(slot), _p(r), int(r.shape[0])))
+
+    def rows(self, slot: int) -> int:
+        return lib().hfnet_store_rows(self.h, int(slot))
+
+    def _pairs(self, pairs):
+        return (np.ascontiguousarray([p[0] for p in pairs], np.int32), np.ascontiguousarray([p[1] for p in pairs], np.int32))
+
+    def search_by_bow(self, pairs, th_low: float = 0.6):
+        a, b = self._pairs(pairs)
+        match = np.full((len(pairs), self.max_rows), -2, np.int32); dist = np.zeros((len(pairs), self.max_rows), np.float32)
+        cnt = np.full((len(pairs),), -1, np.int32)
+        _chk(lib().hfnet_store_search_by_bow(self.h, len(pairs), _p(a), _p(b), C.c_float(th_low), _p(match), _p(dist), _p(cnt)))
+        return cnt, match, dist
+
+    def search_for_triangulation(self, pairs, th_high: float = 0.75):
+        a, b = self._pairs(pairs)
+        match = np.full((len(pairs), self.max_rows), -2, np.int32); cnt = np.full((len(pairs),), -1, np.int32)
+        _chk(lib().hfnet_store_search_for_triangulation(self.h, len(pairs), _p(a), _p(b), C.c_float(th_high), _p(match), _p(cnt)))
+        return cnt, match
 
 
 class Database:

@@ -993,6 +993,102 @@ int hfnet_match_search_for_triangulation_batch(hfnet_engine* eh, int n_pairs, co
                              on_device, true);
 }
 
+// ---------------------------------------------------------------------------------------- descriptor store
+int hfnet_store_create(hfnet_engine* eh, int n_sets, int max_rows, int dim, hfnet_store** out) {
+    API_GUARD(out, "out");
+    *out = nullptr;
+    API_GUARD(eh, "engine");
+    if (n_sets < 1 || max_rows < 1 || dim <= 0 || dim % 64) { set_error("store: n_sets, max_rows >= 1 and dim a multiple of 64 required"); return HFNET_ERR_INVALID_ARG; }
+    HF_HIP(hipSetDevice(eh->impl.device));
+    std::unique_ptr<hfnet_store> st(new hfnet_store);
+    st->eng = eh; st->n_sets = n_sets; st->max_rows = max_rows; st->dim = dim;
+    st->rows.assign(n_sets, 0);
+    HF_HIP(hipMalloc((void**)&st->d_desc, sizeof(float) * (size_t)n_sets * max_rows * dim));
+    if (hipMalloc((void**)&st->d_rows, sizeof(int32_t) * n_sets) != hipSuccess) { (void)hipFree(st->d_desc); set_error("store: out of device memory"); return HFNET_ERR_DEVICE; }
+    HF_HIP(hipMemset(st->d_rows, 0, sizeof(int32_t) * n_sets));
+    *out = st.release();
+    return HFNET_OK;
+}
+
+void hfnet_store_destroy(hfnet_store* st) {
+    if (!st) return;
+    (void)hipSetDevice(st->eng->impl.device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(st->d_desc);
+    (void)hipFree(st->d_rows);
+    delete st;
+}
+
+int hfnet_store_put(hfnet_store* st, int slot, const float* rows, int n_rows) {
+    API_GUARD(st, "store");
+    if (slot < 0 || slot >= st->n_sets || n_rows < 0 || n_rows > st->max_rows) { set_error("store: slot %d / %d rows outside [0, %d) / [0, %d]", slot, n_rows, st->n_sets, st->max_rows); return HFNET_ERR_INVALID_ARG; }
+    if (n_rows && !rows) { set_error("null descriptor matrix"); return HFNET_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> lk(st->mu);
+    Engine& e = st->eng->impl;
+    std::lock_guard<std::mutex> lk2(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    const int32_t n = n_rows;
+    if (n_rows) HF_HIP(hipMemcpyAsync(st->d_desc + (size_t)slot * st->max_rows * st->dim, rows, sizeof(float) * (size_t)n_rows * st->dim, hipMemcpyHostToDevice, e.stream));
+    HF_HIP(hipMemcpyAsync(st->d_rows + slot, &n, sizeof n, hipMemcpyHostToDevice, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));                          // the host buffers may go away
+    st->rows[slot] = n;
+    return HFNET_OK;
+}
+
+int hfnet_store_rows(const hfnet_store* st, int slot) {
+    if (!st || slot < 0 || slot >= st->n_sets) return -1;
+    return st->rows[slot];
+}
+
+// pairs of resident sets -> host results.  Only the pair lists go up and the matches come down.
+static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const int32_t* set2, float th, int32_t* match, float* dist,
+                       int32_t* n_matches, bool triangulation) {
+    API_GUARD(st, "store");
+    if (n_pairs < 0) { set_error("n_pairs < 0"); return HFNET_ERR_INVALID_ARG; }
+    if (n_pairs == 0) return HFNET_OK;
+    API_GUARD(set1, "set1"); API_GUARD(set2, "set2"); API_GUARD(match, "match"); API_GUARD(n_matches, "n_matches");
+    if (!triangulation) API_GUARD(dist, "dist");
+    for (int p = 0; p < n_pairs; ++p)
+        if (set1[p] < 0 || set1[p] >= st->n_sets || set2[p] < 0 || set2[p] >= st->n_sets) { set_error("pair %d references a set outside [0, %d)", p, st->n_sets); return HFNET_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> lks(st->mu);
+    Engine& e = st->eng->impl;
+    std::lock_guard<std::mutex> lk(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    const int mr = st->max_rows;
+    HF_TRY(bow_scratch(e, n_pairs, mr));
+    HF_TRY(e.m_b.ensure(sizeof(int32_t) * 2 * (size_t)n_pairs));
+    HF_TRY(e.m_i0.ensure(sizeof(int32_t) * (size_t)n_pairs * mr)); HF_TRY(e.m_f0.ensure(sizeof(float) * (size_t)n_pairs * mr));
+    HF_TRY(e.m_cnt.ensure(sizeof(int32_t) * n_pairs));
+    int32_t* ib = e.m_b.as<int32_t>();
+    HF_HIP(hipMemcpyAsync(ib, set1, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, e.stream));
+    HF_HIP(hipMemcpyAsync(ib + n_pairs, set2, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, e.stream));
+    int32_t* d_match = e.m_i0.as<int32_t>(); float* d_dist = e.m_f0.as<float>(); int32_t* d_cnt = e.m_cnt.as<int32_t>();
+    HF_LAUNCH(&e, e.stream, "match_bow_setup",
+              launch_bow_setup(e.m_pairs.as<BowPair>(), n_pairs, st->d_desc, (long long)mr * st->dim, st->d_rows, ib, ib + n_pairs, mr, e.m_s.as<float>(),
+                               e.m_qn.as<float>(), e.m_tn.as<float>(), e.m_key.as<unsigned long long>(), d_match, d_dist, d_cnt, mr, e.stream));
+    if (triangulation) {
+        const float threshold = (float)(-0.5 * th * th + 1);       // Matcher.cc:851
+        HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, threshold, e.stream));
+    } else {
+        HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, th, e.stream));
+    }
+    HF_HIP(hipMemcpyAsync(match, d_match, sizeof(int32_t) * (size_t)n_pairs * mr, hipMemcpyDeviceToHost, e.stream));
+    if (!triangulation) HF_HIP(hipMemcpyAsync(dist, d_dist, sizeof(float) * (size_t)n_pairs * mr, hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipMemcpyAsync(n_matches, d_cnt, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));
+    return HFNET_OK;
+}
+
+int hfnet_store_search_by_bow(hfnet_store* st, int n_pairs, const int32_t* query_set, const int32_t* train_set, float th_low, int32_t* match_q2t,
+                              float* dist, int32_t* n_matches) {
+    return match_store(st, n_pairs, query_set, train_set, th_low, match_q2t, dist, n_matches, false);
+}
+
+int hfnet_store_search_for_triangulation(hfnet_store* st, int n_pairs, const int32_t* set1, const int32_t* set2, float th_high, int32_t* match12,
+                                         int32_t* n_matches) {
+    return match_store(st, n_pairs, set1, set2, th_high, match12, nullptr, n_matches, true);
+}
+
 int hfnet_match_search_for_triangulation(hfnet_engine* eh, const float* d1, int n1, const float* d2, int n2, int dim, float th_high,
                                          int32_t* match12, int* n_matches, int on_device) {
     API_GUARD(eh, "engine"); API_GUARD(match12, "match12"); API_GUARD(n_matches, "n_matches");

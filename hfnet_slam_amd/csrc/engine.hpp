@@ -145,6 +145,16 @@ struct hfnet_extractor {
     std::mutex mu;
 };
 
+// device-resident descriptor sets of keyframes: uploaded once, matched many times
+struct hfnet_store {
+    hfnet_engine* eng = nullptr;
+    int n_sets = 0, max_rows = 0, dim = 0;
+    float* d_desc = nullptr;       // [n_sets][max_rows][dim]
+    int32_t* d_rows = nullptr;     // [n_sets]
+    std::vector<int32_t> rows;     // host mirror of d_rows
+    std::mutex mu;
+};
+
 struct hfnet_db {
     hfnet_engine* eng = nullptr;
     int capacity = 0, dim = 0;

@@ -250,6 +250,54 @@ private:
     int mCapacity;
 };
 
+// ---- device-resident descriptor blocks of keyframes --------------------------------------------------
+// What LocalMapping::CreateNewMapPoints / LoopClosing need around Matcher.cc:808 and :231: the block of a keyframe is put
+// once when the keyframe is made (slot = the caller's dense keyframe index), and one call matches it against all its
+// neighbours.  matches[p] has one entry per descriptor of first[p] (-1: none).
+class KeyFrameDescriptorStore {
+public:
+    KeyFrameDescriptorStore(std::shared_ptr<EngineHandle> engine, int capacity, int maxRows) : mEngine(std::move(engine)), mMaxRows(maxRows) {
+        if (hfnet_store_create(mEngine->h, capacity, maxRows, 256, &mStore) != HFNET_OK) mStore = nullptr;
+    }
+    ~KeyFrameDescriptorStore() { hfnet_store_destroy(mStore); }
+    bool IsValid() const { return mStore != nullptr; }
+    bool put(int slot, const Mat& descriptors) { return mStore && hfnet_store_put(mStore, slot, descriptors.ptr<float>(), descriptors.rows) == HFNET_OK; }
+    int rows(int slot) const { return hfnet_store_rows(mStore, slot); }
+    // Matcher::SearchForTriangulation's descriptor stage (Matcher.cc:808-871) for many keyframe pairs at once
+    bool SearchForTriangulation(const std::vector<int>& first, const std::vector<int>& second, float thHigh, std::vector<std::vector<int>>& matches,
+                                std::vector<int>& nMatches) const {
+        return run(first, second, thHigh, matches, nullptr, nMatches, true);
+    }
+    // Matcher::SearchByBoW's descriptor stage (Matcher.cc:231-291) for many pairs at once
+    bool SearchByBoW(const std::vector<int>& query, const std::vector<int>& train, float thLow, std::vector<std::vector<int>>& matches,
+                     std::vector<std::vector<float>>& distances, std::vector<int>& nMatches) const {
+        return run(query, train, thLow, matches, &distances, nMatches, false);
+    }
+
+private:
+    bool run(const std::vector<int>& a, const std::vector<int>& b, float th, std::vector<std::vector<int>>& matches, std::vector<std::vector<float>>* distances,
+             std::vector<int>& nMatches, bool triangulation) const {
+        const int n = (int)a.size();
+        if (!mStore || b.size() != a.size()) return false;
+        std::vector<int32_t> m((size_t)n * mMaxRows), cnt((size_t)n);
+        std::vector<float> d(triangulation ? 0 : (size_t)n * mMaxRows);
+        const int rc = triangulation ? hfnet_store_search_for_triangulation(mStore, n, a.data(), b.data(), th, m.data(), cnt.data())
+                                     : hfnet_store_search_by_bow(mStore, n, a.data(), b.data(), th, m.data(), d.data(), cnt.data());
+        if (rc != HFNET_OK) return false;
+        matches.resize((size_t)n); nMatches.assign(cnt.begin(), cnt.end());
+        if (distances) distances->resize((size_t)n);
+        for (int p = 0; p < n; ++p) {
+            const int r = rows(a[p]);
+            matches[p].assign(m.begin() + (size_t)p * mMaxRows, m.begin() + (size_t)p * mMaxRows + r);
+            if (distances) (*distances)[p].assign(d.begin() + (size_t)p * mMaxRows, d.begin() + (size_t)p * mMaxRows + r);
+        }
+        return true;
+    }
+    std::shared_ptr<EngineHandle> mEngine;
+    hfnet_store* mStore = nullptr;
+    int mMaxRows;
+};
+
 // ---- InitAllModels / GetModelVec / GetGlobalModel (BaseModel.cc:24-113) ---------------------------
 // Same wiring as the TensorRT backend: level 0 = kImageToLocalAndGlobal, other levels kImageToLocal,
 // no separate global model.  The factory reports failure instead of exit(-1).

@@ -56,6 +56,7 @@ typedef struct { float x, y, response; int32_t octave; } hfnet_keypoint;
 typedef struct hfnet_engine hfnet_engine;        /* one GPU: weights resident in HBM, streams, scratch */
 typedef struct hfnet_model hfnet_model;          /* == one BaseModel instance (fixed input shape + mode) */
 typedef struct hfnet_extractor hfnet_extractor;  /* == one HFextractor (pyramid + per-level budget)      */
+typedef struct hfnet_store hfnet_store;          /* device-resident descriptor sets of keyframes          */
 typedef struct hfnet_db hfnet_db;                /* == KeyFrameDatabase's descriptor store + scan        */
 
 const char* hfnet_last_error(void);
@@ -157,6 +158,20 @@ int hfnet_match_search_for_triangulation_batch(hfnet_engine* e, int n_pairs, con
                                                size_t set_stride, const int32_t* n_rows, int n_sets,
                                                const int32_t* set1, const int32_t* set2, int max_rows, int dim,
                                                float th_high, int32_t* match12, int32_t* n_matches, int on_device);
+
+/* ---- device-resident descriptor store --------------------------------------------
+ * Matcher.cc re-gathers and would re-upload the N x 256 blocks of both keyframes on every call (Matcher.cc:231-246,
+ * 808-834).  A store keeps each keyframe's block on the GPU: hfnet_store_put uploads a set once (slot ids are managed by
+ * the caller, like the database's), the two searches then take slot pairs and only move the pair lists and the matches.
+ * match arrays: [n_pairs][max_rows] (row r of pair p: set1[p]'s descriptor r), n_matches: [n_pairs]. */
+int hfnet_store_create(hfnet_engine* e, int n_sets, int max_rows, int dim, hfnet_store** out);
+void hfnet_store_destroy(hfnet_store* s);
+int hfnet_store_put(hfnet_store* s, int slot, const float* rows, int n_rows);
+int hfnet_store_rows(const hfnet_store* s, int slot);            /* rows of a slot, -1 for a bad slot */
+int hfnet_store_search_by_bow(hfnet_store* s, int n_pairs, const int32_t* query_set, const int32_t* train_set,
+                              float th_low, int32_t* match_q2t, float* dist, int32_t* n_matches);
+int hfnet_store_search_for_triangulation(hfnet_store* s, int n_pairs, const int32_t* set1, const int32_t* set2,
+                                         float th_high, int32_t* match12, int32_t* n_matches);
 
 /* ---- Resampler (include/Extractors/BaseModel.h:78-80, src/Extractors/BaseModel.cc:491-562) ---------
  * tensorflow.contrib.resampler: bilinear sampling of an NHWC fp32 map at (x, y) warp points with zero

@@ -75,6 +75,17 @@ int main(int argc, char** argv) {
     int nc = db.DetectCandidates(global, false, slots, scores, &best);
     put(fo, &nc, 4); put(fo, &best, 4);
     put(fo, slots.data(), slots.size() * 4);
+
+    // KeyFrameDescriptorStore: the same two matches through device-resident blocks
+    KeyFrameDescriptorStore store(set.engine, 4, std::max(std::max(n, en), 1));
+    int okStore = store.IsValid() && store.put(0, local) && store.put(2, edesc);
+    std::vector<std::vector<int>> sm, tm; std::vector<std::vector<float>> sd; std::vector<int> sn, tn;
+    okStore = okStore && store.SearchByBoW({0, 2}, {2, 0}, 0.6f, sm, sd, sn) && store.SearchForTriangulation({0}, {2}, 0.75f, tm, tn);
+    put(fo, &okStore, 4);
+    if (okStore) {
+        put(fo, sn.data(), 8); put(fo, sm[0].data(), sm[0].size() * 4); put(fo, sd[0].data(), sd[0].size() * 4); put(fo, sm[1].data(), sm[1].size() * 4);
+        put(fo, tn.data(), 4); put(fo, tm[0].data(), tm[0].size() * 4);
+    }
     fclose(fo);
     return 0;
 }

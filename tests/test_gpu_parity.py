@@ -462,3 +462,36 @@ def test_concurrent_callers(engine, oracle_model):
         m.close()
     gm.close()
     assert not errors, errors
+
+
+def test_descriptor_store_matches_host_calls(engine):
+    """device-resident keyframe descriptor sets: put once, match by slot pairs == the host-pointer entry points == the oracle"""
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    rng = np.random.default_rng(41)
+    mr, S = 140, 6
+    base = _unit_rows(rng, mr)
+    store = capi.Store(engine, S, mr)
+    sets = []
+    for s_ in range(S):
+        n = [140, 99, 1, 0, 140, 77][s_]
+        v = base[rng.permutation(mr)][:n] + 0.03 * (s_ + 1) * rng.standard_normal((n, 256)).astype(np.float32)
+        v = (v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-12)).astype(np.float32).reshape(n, 256)
+        sets.append(v)
+        store.put(s_, v)
+        assert store.rows(s_) == n
+    assert store.rows(S) == -1
+    store.put(1, sets[5]); store.put(1, sets[1])                 # overwrite a slot
+    pairs = [(0, 1), (1, 0), (4, 0), (2, 5), (3, 4), (5, 3), (4, 4)]
+    cnt, match, dist = store.search_by_bow(pairs, 0.6)
+    tcnt, tmatch = store.search_for_triangulation(pairs, 0.75)
+    for p, (a, b) in enumerate(pairs):
+        rn, rm, rd = O.search_by_bow(sets[a], sets[b], 0.6)
+        assert cnt[p] == rn
+        _eq(f"bow {p}", match[p, :len(sets[a])], rm); _eq(f"bow dist {p}", dist[p, :len(sets[a])], rd)
+        tn, tm = O.search_for_triangulation(sets[a], sets[b], 0.75)
+        assert tcnt[p] == tn
+        _eq(f"tri {p}", tmatch[p, :len(sets[a])], tm)
+    with pytest.raises(capi.HfnetError):
+        store.search_by_bow([(0, S)], 0.6)
+    store.close()

@@ -80,3 +80,9 @@ def test_mirror_matches_oracle(mirror_exe, weights_path, oracle_model, tmp_path)
     assert take(np.float32, 1)[0] == np.float32(O.descriptor_distance(rd[0], rd[1]))
     nc = int(take(np.int32, 1)[0]); best = take(np.float32, 1)[0]; slots = take(np.int32, nc)
     assert nc >= 1 and 3 in slots and best == np.float32(1.0)
+    assert take(np.int32, 1)[0] == 1                       # KeyFrameDescriptorStore calls all succeeded
+    sn = take(np.int32, 2); s0 = take(np.int32, n); sd0 = take(np.float32, n); s1 = take(np.int32, en)
+    rn1, rs1, _ = O.search_by_bow(red, rd, 0.6)
+    assert sn[0] == rnb and np.array_equal(s0, rm1) and np.array_equal(sd0, rd1)
+    assert sn[1] == rn1 and np.array_equal(s1, rs1)
+    assert take(np.int32, 1)[0] == rnt and np.array_equal(take(np.int32, n), rm2)

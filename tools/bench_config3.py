@@ -6,7 +6,10 @@ entry points, as Tracking / LocalMapping / LoopClosing would call them:
   every 5th frame "keyframe": database add + DetectNBestCandidates scan over all previous keyframes
                   + SearchForTriangulation against the 30 most recent keyframes (one batched call)
 
-    python tools/bench_config3.py [nFeatures=1000] [frames=300]
+    python tools/bench_config3.py [nFeatures=1000] [frames=300] [store=1]
+
+store=1 keeps every keyframe's descriptor block in a device-resident hfnet_store (uploaded once when the keyframe is made);
+store=0 re-packs and re-uploads the 31 blocks on every keyframe through the host-pointer batch call.
 """
 import json, os, sys, tempfile, time
 import numpy as np
@@ -15,12 +18,14 @@ from hfnet_slam_amd import capi, weights
 
 NF = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 FRAMES = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+STORE = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 W = H = 512
 wp = os.path.join(tempfile.gettempdir(), "hfnet_synth_seed7_cfg3.hfw")
 weights.save(wp, weights.synthetic_weights(7))
 eng = capi.Engine(wp, 0)
 ext = capi.Extractor(eng, W, H, NF, 0.01, 1.2, 4, max_batch=1)
 db = capi.Database(eng, FRAMES // 5 + 8, eng.global_dim)
+store = capi.Store(eng, FRAMES // 5 + 8, NF) if STORE else None
 imgs = [np.random.default_rng(1000 + i).integers(0, 256, (H, W), dtype=np.uint8) for i in range(16)]
 for i in range(3):
     ext.extract(imgs[i])
@@ -37,7 +42,11 @@ for i in range(FRAMES):
     t1 = time.perf_counter()
     t_frame.append(t1 - t0)
     if i % 5 == 0:
-        if n_kf:
+        if n_kf and STORE:
+            db.query(g, 0)
+            store.put(n_kf, desc)
+            store.search_for_triangulation([(n_kf, j) for j in range(max(0, n_kf - 30), n_kf)], 0.75)
+        elif n_kf:
             db.query(g, 0)
             nb = kf_desc[-30:]
             mr = max(d.shape[0] for d in nb + [desc])
@@ -46,10 +55,12 @@ for i in range(FRAMES):
             for j, d in enumerate([desc] + nb):
                 sets[j, :d.shape[0]] = d; rows[j] = d.shape[0]
             eng.search_for_triangulation_batch(sets, rows, [(0, j + 1) for j in range(len(nb))], 0.75)
+        if STORE and not n_kf:
+            store.put(0, desc)
         db.add(n_kf, g); kf_desc.append(desc); n_kf += 1
         t_kf.append(time.perf_counter() - t1)
 wall = time.perf_counter() - t_all0
 med = lambda v: float(np.median(v)) * 1e3
-print(json.dumps({"config": f"tracking loop, 512x512, 4 levels, {NF} keypoints, {FRAMES} frames, keyframe every 5th, 1 MI355X, host-pointer calls",
+print(json.dumps({"config": f"tracking loop, 512x512, 4 levels, {NF} keypoints, {FRAMES} frames, keyframe every 5th, 1 MI355X, " + ("device-resident keyframe store" if STORE else "host-pointer calls"),
                   "frame_ms_median": med(t_frame), "keyframe_extra_ms_median": med(t_kf[31:] if len(t_kf) > 40 else t_kf[1:]),
                   "keyframes": n_kf, "frames_per_s_whole_loop": FRAMES / wall}))
