@@ -28,7 +28,7 @@ SYMBOLS = [
     "hfnet_extractor_create", "hfnet_extractor_destroy", "hfnet_extractor_tables",
     "hfnet_extractor_extract", "hfnet_extractor_extract_batch",
     "hfnet_descriptor_distance", "hfnet_resampler", "hfnet_match_search_by_bow", "hfnet_match_search_by_bow_batch", "hfnet_match_search_for_triangulation", "hfnet_match_search_for_triangulation_batch",
-    "hfnet_store_create", "hfnet_store_destroy", "hfnet_store_put", "hfnet_store_rows", "hfnet_store_search_by_bow",
+    "hfnet_store_create", "hfnet_store_destroy", "hfnet_store_put", "hfnet_store_rows", "hfnet_store_set_flags", "hfnet_store_search_by_bow",
     "hfnet_store_search_for_triangulation",
     "hfnet_db_create", "hfnet_db_destroy", "hfnet_db_add", "hfnet_db_erase", "hfnet_db_clear", "hfnet_db_query", "hfnet_db_query_batch",
     "hfnet_profile_enable", "hfnet_profile_reset", "hfnet_profile_filter", "hfnet_profile_count", "hfnet_profile_get",
@@ -294,6 +294,9 @@ class Extractor:
                                                  C.c_void_p(d_kps), C.c_void_p(d_desc), C.c_void_p(d_global), C.c_void_p(d_n), 1))
 
 
+ROWS_ALL, ROWS_FLAGGED, ROWS_UNFLAGGED = 0, 1, 2
+
+
 class Store:
     """Device-resident descriptor sets (one slot per keyframe) for the batched matchers."""
 
@@ -320,20 +323,24 @@ class Store:
     def rows(self, slot: int) -> int:
         return lib().hfnet_store_rows(self.h, int(slot))
 
+    def set_flags(self, slot: int, flags: np.ndarray):
+        f = np.ascontiguousarray(flags, np.uint8)
+        _chk(lib().hfnet_store_set_flags(self.h, int(slot), _p(f), int(f.shape[0])))
+
     def _pairs(self, pairs):
         return (np.ascontiguousarray([p[0] for p in pairs], np.int32), np.ascontiguousarray([p[1] for p in pairs], np.int32))
 
-    def search_by_bow(self, pairs, th_low: float = 0.6):
+    def search_by_bow(self, pairs, th_low: float = 0.6, query_rows: int = ROWS_ALL, train_rows: int = ROWS_ALL):
         a, b = self._pairs(pairs)
         match = np.full((len(pairs), self.max_rows), -2, np.int32); dist = np.zeros((len(pairs), self.max_rows), np.float32)
         cnt = np.full((len(pairs),), -1, np.int32)
-        _chk(lib().hfnet_store_search_by_bow(self.h, len(pairs), _p(a), _p(b), C.c_float(th_low), _p(match), _p(dist), _p(cnt)))
+        _chk(lib().hfnet_store_search_by_bow(self.h, len(pairs), _p(a), _p(b), int(query_rows), int(train_rows), C.c_float(th_low), _p(match), _p(dist), _p(cnt)))
         return cnt, match, dist
 
-    def search_for_triangulation(self, pairs, th_high: float = 0.75):
+    def search_for_triangulation(self, pairs, th_high: float = 0.75, rows1: int = ROWS_ALL, rows2: int = ROWS_ALL):
         a, b = self._pairs(pairs)
         match = np.full((len(pairs), self.max_rows), -2, np.int32); cnt = np.full((len(pairs),), -1, np.int32)
-        _chk(lib().hfnet_store_search_for_triangulation(self.h, len(pairs), _p(a), _p(b), C.c_float(th_high), _p(match), _p(cnt)))
+        _chk(lib().hfnet_store_search_for_triangulation(self.h, len(pairs), _p(a), _p(b), int(rows1), int(rows2), C.c_float(th_high), _p(match), _p(cnt)))
         return cnt, match
 
 

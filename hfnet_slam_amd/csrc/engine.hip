@@ -31,7 +31,7 @@ Engine::~Engine() {
     (void)hipSetDevice(device);
     prof.flush();
     for (auto ev : prof.pool) (void)hipEventDestroy(ev);
-    for (DevMem* m : {&m_a, &m_b, &m_s, &m_qn, &m_tn, &m_key, &m_i0, &m_i1, &m_f0, &m_cnt, &m_pairs}) m->release();
+    for (DevMem* m : {&m_a, &m_b, &m_s, &m_qn, &m_tn, &m_key, &m_i0, &m_i1, &m_f0, &m_f1, &m_cnt, &m_pairs}) m->release();
     w.release();
     if (ev_extract) (void)hipEventDestroy(ev_extract);
     if (ev_match) (void)hipEventDestroy(ev_match);
@@ -1005,7 +1005,9 @@ int hfnet_store_create(hfnet_engine* eh, int n_sets, int max_rows, int dim, hfne
     st->rows.assign(n_sets, 0);
     HF_HIP(hipMalloc((void**)&st->d_desc, sizeof(float) * (size_t)n_sets * max_rows * dim));
     if (hipMalloc((void**)&st->d_rows, sizeof(int32_t) * n_sets) != hipSuccess) { (void)hipFree(st->d_desc); set_error("store: out of device memory"); return HFNET_ERR_DEVICE; }
+    if (hipMalloc((void**)&st->d_flags, (size_t)n_sets * max_rows) != hipSuccess) { (void)hipFree(st->d_desc); (void)hipFree(st->d_rows); set_error("store: out of device memory"); return HFNET_ERR_DEVICE; }
     HF_HIP(hipMemset(st->d_rows, 0, sizeof(int32_t) * n_sets));
+    HF_HIP(hipMemset(st->d_flags, 0, (size_t)n_sets * max_rows));
     *out = st.release();
     return HFNET_OK;
 }
@@ -1016,6 +1018,7 @@ void hfnet_store_destroy(hfnet_store* st) {
     (void)hipDeviceSynchronize();
     (void)hipFree(st->d_desc);
     (void)hipFree(st->d_rows);
+    (void)hipFree(st->d_flags);
     delete st;
 }
 
@@ -1030,6 +1033,7 @@ int hfnet_store_put(hfnet_store* st, int slot, const float* rows, int n_rows) {
     const int32_t n = n_rows;
     if (n_rows) HF_HIP(hipMemcpyAsync(st->d_desc + (size_t)slot * st->max_rows * st->dim, rows, sizeof(float) * (size_t)n_rows * st->dim, hipMemcpyHostToDevice, e.stream));
     HF_HIP(hipMemcpyAsync(st->d_rows + slot, &n, sizeof n, hipMemcpyHostToDevice, e.stream));
+    HF_HIP(hipMemsetAsync(st->d_flags + (size_t)slot * st->max_rows, 0, (size_t)st->max_rows, e.stream));
     HF_HIP(hipStreamSynchronize(e.stream));                          // the host buffers may go away
     st->rows[slot] = n;
     return HFNET_OK;
@@ -1040,11 +1044,26 @@ int hfnet_store_rows(const hfnet_store* st, int slot) {
     return st->rows[slot];
 }
 
+int hfnet_store_set_flags(hfnet_store* st, int slot, const uint8_t* flags, int n_rows) {
+    API_GUARD(st, "store");
+    if (slot < 0 || slot >= st->n_sets || n_rows < 0 || n_rows > st->max_rows) { set_error("store: slot %d / %d rows outside [0, %d) / [0, %d]", slot, n_rows, st->n_sets, st->max_rows); return HFNET_ERR_INVALID_ARG; }
+    if (n_rows == 0) return HFNET_OK;
+    API_GUARD(flags, "flags");
+    std::lock_guard<std::mutex> lk(st->mu);
+    Engine& e = st->eng->impl;
+    std::lock_guard<std::mutex> lk2(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    HF_HIP(hipMemcpyAsync(st->d_flags + (size_t)slot * st->max_rows, flags, (size_t)n_rows, hipMemcpyHostToDevice, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));
+    return HFNET_OK;
+}
+
 // pairs of resident sets -> host results.  Only the pair lists go up and the matches come down.
-static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const int32_t* set2, float th, int32_t* match, float* dist,
-                       int32_t* n_matches, bool triangulation) {
+static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const int32_t* set2, int rows1, int rows2, float th, int32_t* match,
+                       float* dist, int32_t* n_matches, bool triangulation) {
     API_GUARD(st, "store");
     if (n_pairs < 0) { set_error("n_pairs < 0"); return HFNET_ERR_INVALID_ARG; }
+    if (rows1 < HFNET_ROWS_ALL || rows1 > HFNET_ROWS_UNFLAGGED || rows2 < HFNET_ROWS_ALL || rows2 > HFNET_ROWS_UNFLAGGED) { set_error("row filter must be HFNET_ROWS_ALL / _FLAGGED / _UNFLAGGED"); return HFNET_ERR_INVALID_ARG; }
     if (n_pairs == 0) return HFNET_OK;
     API_GUARD(set1, "set1"); API_GUARD(set2, "set2"); API_GUARD(match, "match"); API_GUARD(n_matches, "n_matches");
     if (!triangulation) API_GUARD(dist, "dist");
@@ -1055,23 +1074,55 @@ static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const 
     std::lock_guard<std::mutex> lk(e.mu);
     HF_HIP(hipSetDevice(e.device));
     const int mr = st->max_rows;
+    const long long stride = (long long)mr * st->dim;
+    // filtered sides: one compacted copy per distinct (slot, filter)
+    std::vector<int32_t> host;                                     // [qsel | tsel | c_slot | c_filter]
+    std::vector<int32_t> qsel(set1, set1 + n_pairs), tsel(set2, set2 + n_pairs), c_slot, c_filter;
+    if (rows1 != HFNET_ROWS_ALL || rows2 != HFNET_ROWS_ALL) {
+        std::map<std::pair<int, int>, int> seen;
+        auto compacted = [&](int slot, int filter) {
+            auto it = seen.find({slot, filter});
+            if (it == seen.end()) { it = seen.emplace(std::make_pair(slot, filter), (int)c_slot.size()).first; c_slot.push_back(slot); c_filter.push_back(filter); }
+            return ~it->second;
+        };
+        for (int p = 0; p < n_pairs; ++p) {
+            if (rows1 != HFNET_ROWS_ALL) qsel[p] = compacted(set1[p], rows1);
+            if (rows2 != HFNET_ROWS_ALL) tsel[p] = compacted(set2[p], rows2);
+        }
+    }
+    const int nc = (int)c_slot.size();
+    host.insert(host.end(), qsel.begin(), qsel.end()); host.insert(host.end(), tsel.begin(), tsel.end());
+    host.insert(host.end(), c_slot.begin(), c_slot.end()); host.insert(host.end(), c_filter.begin(), c_filter.end());
     HF_TRY(bow_scratch(e, n_pairs, mr));
-    HF_TRY(e.m_b.ensure(sizeof(int32_t) * 2 * (size_t)n_pairs));
+    // m_b: [qsel | tsel | c_slot | c_filter | c_rows | map nc*mr | inv nc*mr]
+    HF_TRY(e.m_b.ensure(sizeof(int32_t) * (2 * (size_t)n_pairs + 3 * (size_t)nc + 2 * (size_t)nc * mr)));
     HF_TRY(e.m_i0.ensure(sizeof(int32_t) * (size_t)n_pairs * mr)); HF_TRY(e.m_f0.ensure(sizeof(float) * (size_t)n_pairs * mr));
     HF_TRY(e.m_cnt.ensure(sizeof(int32_t) * n_pairs));
+    if (nc) { HF_TRY(e.m_a.ensure(sizeof(float) * (size_t)nc * stride)); HF_TRY(e.m_i1.ensure(sizeof(int32_t) * (size_t)n_pairs * mr)); HF_TRY(e.m_f1.ensure(sizeof(float) * (size_t)n_pairs * mr)); }
     int32_t* ib = e.m_b.as<int32_t>();
-    HF_HIP(hipMemcpyAsync(ib, set1, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, e.stream));
-    HF_HIP(hipMemcpyAsync(ib + n_pairs, set2, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, e.stream));
+    int32_t *d_qsel = ib, *d_tsel = ib + n_pairs, *d_cslot = ib + 2 * n_pairs, *d_cfilter = d_cslot + nc, *d_crows = d_cfilter + nc, *d_map = d_crows + nc,
+            *d_inv = d_map + (size_t)nc * mr;
+    HF_HIP(hipMemcpyAsync(ib, host.data(), sizeof(int32_t) * host.size(), hipMemcpyHostToDevice, e.stream));
     int32_t* d_match = e.m_i0.as<int32_t>(); float* d_dist = e.m_f0.as<float>(); int32_t* d_cnt = e.m_cnt.as<int32_t>();
-    HF_LAUNCH(&e, e.stream, "match_bow_setup",
-              launch_bow_setup(e.m_pairs.as<BowPair>(), n_pairs, st->d_desc, (long long)mr * st->dim, st->d_rows, ib, ib + n_pairs, mr, e.m_s.as<float>(),
-                               e.m_qn.as<float>(), e.m_tn.as<float>(), e.m_key.as<unsigned long long>(), d_match, d_dist, d_cnt, mr, e.stream));
+    int32_t* w_match = nc ? e.m_i1.as<int32_t>() : d_match; float* w_dist = nc ? e.m_f1.as<float>() : d_dist;   // results in compacted numbering
+    if (nc)
+        HF_LAUNCH(&e, e.stream, "store_compact",
+                  launch_store_compact(st->d_desc, st->d_flags, stride, st->d_rows, nc, d_cslot, d_cfilter, mr, st->dim, d_map, d_inv, d_crows,
+                                       e.m_a.as<float>(), e.stream));
+    HF_LAUNCH(&e, e.stream, "store_setup",
+              launch_store_setup(e.m_pairs.as<BowPair>(), n_pairs, st->d_desc, e.m_a.as<float>(), stride, st->d_rows, d_crows, d_qsel, d_tsel, mr,
+                                 e.m_s.as<float>(), e.m_qn.as<float>(), e.m_tn.as<float>(), e.m_key.as<unsigned long long>(), w_match, w_dist, d_cnt,
+                                 e.stream));
     if (triangulation) {
         const float threshold = (float)(-0.5 * th * th + 1);       // Matcher.cc:851
         HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, threshold, e.stream));
     } else {
         HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, th, e.stream));
     }
+    if (nc)
+        HF_LAUNCH(&e, e.stream, "store_remap",
+                  launch_store_remap(n_pairs, d_qsel, d_tsel, d_cslot, st->d_rows, d_map, d_inv, mr, w_match, triangulation ? nullptr : w_dist, d_match,
+                                     triangulation ? nullptr : d_dist, e.stream));
     HF_HIP(hipMemcpyAsync(match, d_match, sizeof(int32_t) * (size_t)n_pairs * mr, hipMemcpyDeviceToHost, e.stream));
     if (!triangulation) HF_HIP(hipMemcpyAsync(dist, d_dist, sizeof(float) * (size_t)n_pairs * mr, hipMemcpyDeviceToHost, e.stream));
     HF_HIP(hipMemcpyAsync(n_matches, d_cnt, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToHost, e.stream));
@@ -1079,14 +1130,14 @@ static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const 
     return HFNET_OK;
 }
 
-int hfnet_store_search_by_bow(hfnet_store* st, int n_pairs, const int32_t* query_set, const int32_t* train_set, float th_low, int32_t* match_q2t,
-                              float* dist, int32_t* n_matches) {
-    return match_store(st, n_pairs, query_set, train_set, th_low, match_q2t, dist, n_matches, false);
+int hfnet_store_search_by_bow(hfnet_store* st, int n_pairs, const int32_t* query_set, const int32_t* train_set, int query_rows, int train_rows,
+                              float th_low, int32_t* match_q2t, float* dist, int32_t* n_matches) {
+    return match_store(st, n_pairs, query_set, train_set, query_rows, train_rows, th_low, match_q2t, dist, n_matches, false);
 }
 
-int hfnet_store_search_for_triangulation(hfnet_store* st, int n_pairs, const int32_t* set1, const int32_t* set2, float th_high, int32_t* match12,
-                                         int32_t* n_matches) {
-    return match_store(st, n_pairs, set1, set2, th_high, match12, nullptr, n_matches, true);
+int hfnet_store_search_for_triangulation(hfnet_store* st, int n_pairs, const int32_t* set1, const int32_t* set2, int rows1, int rows2, float th_high,
+                                         int32_t* match12, int32_t* n_matches) {
+    return match_store(st, n_pairs, set1, set2, rows1, rows2, th_high, match12, nullptr, n_matches, true);
 }
 
 int hfnet_match_search_for_triangulation(hfnet_engine* eh, const float* d1, int n1, const float* d2, int n2, int dim, float th_high,

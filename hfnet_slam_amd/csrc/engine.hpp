@@ -22,7 +22,7 @@ struct Engine {
     Profiler prof;
     std::mutex mu;                  // engine-level scratch + stream
     std::mutex prof_mu;
-    DevMem m_a, m_b, m_s, m_qn, m_tn, m_key, m_i0, m_i1, m_f0, m_cnt, m_pairs;   // matcher scratch
+    DevMem m_a, m_b, m_s, m_qn, m_tn, m_key, m_i0, m_i1, m_f0, m_f1, m_cnt, m_pairs;   // matcher scratch
     // device-side ordering between extractor streams and the matcher stream for on_device callers
     std::mutex ev_mu;
     hipEvent_t ev_extract = nullptr, ev_match = nullptr;   // last on_device extraction / last hfnet_engine_fence
@@ -151,6 +151,7 @@ struct hfnet_store {
     int n_sets = 0, max_rows = 0, dim = 0;
     float* d_desc = nullptr;       // [n_sets][max_rows][dim]
     int32_t* d_rows = nullptr;     // [n_sets]
+    unsigned char* d_flags = nullptr;   // [n_sets][max_rows] "has a MapPoint" flag per row
     std::vector<int32_t> rows;     // host mirror of d_rows
     std::mutex mu;
 };

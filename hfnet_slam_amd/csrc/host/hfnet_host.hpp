@@ -263,26 +263,31 @@ public:
     bool IsValid() const { return mStore != nullptr; }
     bool put(int slot, const Mat& descriptors) { return mStore && hfnet_store_put(mStore, slot, descriptors.ptr<float>(), descriptors.rows) == HFNET_OK; }
     int rows(int slot) const { return hfnet_store_rows(mStore, slot); }
+    // one byte per row: 1 = the keypoint has a MapPoint (KeyFrame::GetMapPointMatches)
+    bool setMapPointFlags(int slot, const std::vector<unsigned char>& flags) { return mStore && hfnet_store_set_flags(mStore, slot, flags.data(), (int)flags.size()) == HFNET_OK; }
     // Matcher::SearchForTriangulation's descriptor stage (Matcher.cc:808-871) for many keyframe pairs at once
+    // rows = HFNET_ROWS_UNFLAGGED on both sides is the reference's "keypoints without a MapPoint" gather (:808-834)
     bool SearchForTriangulation(const std::vector<int>& first, const std::vector<int>& second, float thHigh, std::vector<std::vector<int>>& matches,
-                                std::vector<int>& nMatches) const {
-        return run(first, second, thHigh, matches, nullptr, nMatches, true);
+                                std::vector<int>& nMatches, int rows1 = HFNET_ROWS_ALL, int rows2 = HFNET_ROWS_ALL) const {
+        return run(first, second, rows1, rows2, thHigh, matches, nullptr, nMatches, true);
     }
     // Matcher::SearchByBoW's descriptor stage (Matcher.cc:231-291) for many pairs at once
+    // queryRows = HFNET_ROWS_FLAGGED is the reference's "keypoints with a MapPoint" gather (:231-246)
     bool SearchByBoW(const std::vector<int>& query, const std::vector<int>& train, float thLow, std::vector<std::vector<int>>& matches,
-                     std::vector<std::vector<float>>& distances, std::vector<int>& nMatches) const {
-        return run(query, train, thLow, matches, &distances, nMatches, false);
+                     std::vector<std::vector<float>>& distances, std::vector<int>& nMatches, int queryRows = HFNET_ROWS_ALL,
+                     int trainRows = HFNET_ROWS_ALL) const {
+        return run(query, train, queryRows, trainRows, thLow, matches, &distances, nMatches, false);
     }
 
 private:
-    bool run(const std::vector<int>& a, const std::vector<int>& b, float th, std::vector<std::vector<int>>& matches, std::vector<std::vector<float>>* distances,
+    bool run(const std::vector<int>& a, const std::vector<int>& b, int rowsA, int rowsB, float th, std::vector<std::vector<int>>& matches, std::vector<std::vector<float>>* distances,
              std::vector<int>& nMatches, bool triangulation) const {
         const int n = (int)a.size();
         if (!mStore || b.size() != a.size()) return false;
         std::vector<int32_t> m((size_t)n * mMaxRows), cnt((size_t)n);
         std::vector<float> d(triangulation ? 0 : (size_t)n * mMaxRows);
-        const int rc = triangulation ? hfnet_store_search_for_triangulation(mStore, n, a.data(), b.data(), th, m.data(), cnt.data())
-                                     : hfnet_store_search_by_bow(mStore, n, a.data(), b.data(), th, m.data(), d.data(), cnt.data());
+        const int rc = triangulation ? hfnet_store_search_for_triangulation(mStore, n, a.data(), b.data(), rowsA, rowsB, th, m.data(), cnt.data())
+                                     : hfnet_store_search_by_bow(mStore, n, a.data(), b.data(), rowsA, rowsB, th, m.data(), d.data(), cnt.data());
         if (rc != HFNET_OK) return false;
         matches.resize((size_t)n); nMatches.assign(cnt.begin(), cnt.end());
         if (distances) distances->resize((size_t)n);

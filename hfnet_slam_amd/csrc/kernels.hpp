@@ -106,6 +106,16 @@ struct BowPair {
 hipError_t launch_bow_setup(BowPair* pairs, int n_pairs, const float* base, long long set_stride, const int* n_rows, const int* qset,
                             const int* tset, int max_rows, float* St, float* qn, float* tn, unsigned long long* qkey, int32_t* match, float* dist,
                             int* cnt, long long out_stride, hipStream_t s);
+// row-filtered matching over a descriptor store (flag byte per row; sel >= 0 store slot, sel < 0 compacted set ~sel)
+hipError_t launch_store_compact(const float* base, const unsigned char* flags, long long set_stride, const int* store_rows, int n_compact,
+                                const int* c_slot, const int* c_filter, int max_rows, int dim, int* map, int* inv, int* c_rows, float* comp,
+                                hipStream_t s);
+hipError_t launch_store_setup(BowPair* pairs, int n_pairs, const float* base, const float* comp, long long set_stride, const int* store_rows,
+                              const int* c_rows, const int* qsel, const int* tsel, int max_rows, float* St, float* qn, float* tn,
+                              unsigned long long* qkey, int32_t* match, float* dist, int* cnt, hipStream_t s);
+hipError_t launch_store_remap(int n_pairs, const int* qsel, const int* tsel, const int* c_slot, const int* store_rows, const int* map,
+                              const int* inv, int max_rows, const int32_t* c_match, const float* c_dist, int32_t* match, float* dist,
+                              hipStream_t s);
 // SearchForTriangulation over the same pair descriptors (q = set 1, t = set 2; dist / qn / qkey unused)
 hipError_t launch_tri_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float threshold, hipStream_t s);
 hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, hipStream_t s);

@@ -437,6 +437,118 @@ hipError_t launch_bow_setup(BowPair* pairs, int n_pairs, const float* base, long
     return hipGetLastError();
 }
 
+// =========================================================================== row-filtered store matching
+// Matcher.cc gathers the rows of a keyframe with (SearchByBoW, :231-246) or without (SearchForTriangulation,
+// :808-834) a MapPoint before the brute-force step.  The store keeps one flag byte per row; a filtered side of a
+// pair is compacted on the device (order preserved, like the CPU gather), matched as usual and mapped back to
+// the original row numbers.  sel >= 0: store slot, unfiltered; sel < 0: compacted set ~sel.
+__global__ __launch_bounds__(256) void k_store_compact_map(const unsigned char* __restrict__ flags, const int* __restrict__ store_rows,
+                                                           const int* __restrict__ c_slot, const int* __restrict__ c_filter, int max_rows,
+                                                           int* __restrict__ map, int* __restrict__ inv, int* __restrict__ c_rows) {
+    __shared__ int wave_tot[4];
+    const int c = blockIdx.x, slot = c_slot[c];
+    const bool want = c_filter[c] == 1;
+    const int rows = min(max(store_rows[slot], 0), max_rows);
+    const unsigned char* __restrict__ f = flags + (long long)slot * max_rows;
+    int* __restrict__ mp = map + (long long)c * max_rows;
+    int* __restrict__ iv = inv + (long long)c * max_rows;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int running = 0;
+    for (int r0 = 0; r0 < max_rows; r0 += 256) {
+        const int r = r0 + threadIdx.x;
+        const bool keep = r < rows && ((f[min(r, max_rows - 1)] != 0) == want);
+        const unsigned long long b = __ballot(keep);
+        const int before = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(b);
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+        if (r < max_rows) iv[r] = keep ? off + before : -1;
+        if (keep) mp[off + before] = r;
+        running += total;
+    }
+    if (threadIdx.x == 0) c_rows[c] = running;
+}
+
+__global__ __launch_bounds__(256) void k_store_compact_copy(const float* __restrict__ base, long long set_stride, const int* __restrict__ c_slot,
+                                                            const int* __restrict__ map, const int* __restrict__ c_rows, int max_rows, int dim,
+                                                            float* __restrict__ comp) {
+    const int c = blockIdx.y, k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= c_rows[c]) return;
+    const int r = map[(long long)c * max_rows + k];
+    const float4* __restrict__ src = (const float4*)(base + (long long)c_slot[c] * set_stride + (long long)r * dim);
+    float4* __restrict__ dst = (float4*)(comp + (long long)c * set_stride + (long long)k * dim);
+    for (int i = lane; i < dim / 4; i += 64) dst[i] = src[i];
+}
+
+__global__ void k_store_setup(BowPair* __restrict__ pairs, int n_pairs, const float* __restrict__ base, const float* __restrict__ comp,
+                              long long set_stride, const int* __restrict__ store_rows, const int* __restrict__ c_rows,
+                              const int* __restrict__ qsel, const int* __restrict__ tsel, int max_rows, float* St, float* qn, float* tn,
+                              unsigned long long* qkey, int32_t* match, float* dist, int* cnt) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= n_pairs) return;
+    BowPair P;
+    const int qs = qsel[p], ts = tsel[p];
+    P.q = qs >= 0 ? base + (long long)qs * set_stride : comp + (long long)(~qs) * set_stride;
+    P.t = ts >= 0 ? base + (long long)ts * set_stride : comp + (long long)(~ts) * set_stride;
+    P.nq = min(max(qs >= 0 ? store_rows[qs] : c_rows[~qs], 0), max_rows);
+    P.nt = min(max(ts >= 0 ? store_rows[ts] : c_rows[~ts], 0), max_rows);
+    P.St = St + (long long)p * max_rows * max_rows;
+    P.qn = qn + (long long)p * max_rows; P.tn = tn + (long long)p * max_rows; P.qkey = qkey + (long long)p * max_rows;
+    P.match = match + (long long)p * max_rows; P.dist = dist + (long long)p * max_rows; P.cnt = cnt + p;
+    pairs[p] = P;
+}
+
+// compacted results -> original row numbers of both sides
+__global__ __launch_bounds__(256) void k_store_remap(int n_pairs, const int* __restrict__ qsel, const int* __restrict__ tsel,
+                                                     const int* __restrict__ c_slot, const int* __restrict__ store_rows,
+                                                     const int* __restrict__ map, const int* __restrict__ inv, int max_rows,
+                                                     const int32_t* __restrict__ c_match, const float* __restrict__ c_dist,
+                                                     int32_t* __restrict__ match, float* __restrict__ dist) {
+    const int p = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= max_rows) return;
+    const int qs = qsel[p], ts = tsel[p];
+    const int rows = min(max(store_rows[qs >= 0 ? qs : c_slot[~qs]], 0), max_rows);
+    int m = -1;
+    float d = FLT_MAX;
+    if (r < rows) {
+        const int c = qs >= 0 ? r : inv[(long long)(~qs) * max_rows + r];
+        if (c >= 0) {
+            m = c_match[(long long)p * max_rows + c];
+            if (c_dist) d = c_dist[(long long)p * max_rows + c];
+            if (m >= 0 && ts < 0) m = map[(long long)(~ts) * max_rows + m];
+        }
+    }
+    match[(long long)p * max_rows + r] = m;
+    if (dist) dist[(long long)p * max_rows + r] = d;
+}
+
+hipError_t launch_store_compact(const float* base, const unsigned char* flags, long long set_stride, const int* store_rows, int n_compact,
+                                const int* c_slot, const int* c_filter, int max_rows, int dim, int* map, int* inv, int* c_rows, float* comp,
+                                hipStream_t s) {
+    if (n_compact <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_store_compact_map, dim3(n_compact), dim3(256), 0, s, flags, store_rows, c_slot, c_filter, max_rows, map, inv, c_rows);
+    hipLaunchKernelGGL(k_store_compact_copy, dim3((max_rows + 3) / 4, n_compact), dim3(256), 0, s, base, set_stride, c_slot, map, c_rows, max_rows,
+                       dim, comp);
+    return hipGetLastError();
+}
+hipError_t launch_store_setup(BowPair* pairs, int n_pairs, const float* base, const float* comp, long long set_stride, const int* store_rows,
+                              const int* c_rows, const int* qsel, const int* tsel, int max_rows, float* St, float* qn, float* tn,
+                              unsigned long long* qkey, int32_t* match, float* dist, int* cnt, hipStream_t s) {
+    hipLaunchKernelGGL(k_store_setup, dim3((n_pairs + 63) / 64), dim3(64), 0, s, pairs, n_pairs, base, comp, set_stride, store_rows, c_rows, qsel,
+                       tsel, max_rows, St, qn, tn, qkey, match, dist, cnt);
+    return hipGetLastError();
+}
+hipError_t launch_store_remap(int n_pairs, const int* qsel, const int* tsel, const int* c_slot, const int* store_rows, const int* map,
+                              const int* inv, int max_rows, const int32_t* c_match, const float* c_dist, int32_t* match, float* dist,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(k_store_remap, dim3((max_rows + 255) / 256, n_pairs), dim3(256), 0, s, n_pairs, qsel, tsel, c_slot, store_rows, map, inv,
+                       max_rows, c_match, c_dist, match, dist);
+    return hipGetLastError();
+}
+
 // all pairs in four launches (prep, GEMM, train pass, finalize); grids are sized for max_rows, workgroups
 // beyond a pair's row counts exit at once
 hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, hipStream_t s) {

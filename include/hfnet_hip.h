@@ -163,15 +163,22 @@ int hfnet_match_search_for_triangulation_batch(hfnet_engine* e, int n_pairs, con
  * Matcher.cc re-gathers and would re-upload the N x 256 blocks of both keyframes on every call (Matcher.cc:231-246,
  * 808-834).  A store keeps each keyframe's block on the GPU: hfnet_store_put uploads a set once (slot ids are managed by
  * the caller, like the database's), the two searches then take slot pairs and only move the pair lists and the matches.
+ * Each row carries a flag byte ("has a MapPoint", hfnet_store_set_flags, 0 after put); a search can restrict either
+ * side to the flagged or unflagged rows, which is the gather of Matcher.cc:231-246 (rows WITH a MapPoint) and :808-834
+ * (rows WITHOUT one) done on the device; results keep the ORIGINAL row numbers of both sides, excluded rows get -1
+ * (distance FLT_MAX).
  * match arrays: [n_pairs][max_rows] (row r of pair p: set1[p]'s descriptor r), n_matches: [n_pairs]. */
+enum { HFNET_ROWS_ALL = 0, HFNET_ROWS_FLAGGED = 1, HFNET_ROWS_UNFLAGGED = 2 };
 int hfnet_store_create(hfnet_engine* e, int n_sets, int max_rows, int dim, hfnet_store** out);
 void hfnet_store_destroy(hfnet_store* s);
 int hfnet_store_put(hfnet_store* s, int slot, const float* rows, int n_rows);
 int hfnet_store_rows(const hfnet_store* s, int slot);            /* rows of a slot, -1 for a bad slot */
+int hfnet_store_set_flags(hfnet_store* s, int slot, const uint8_t* flags, int n_rows);
 int hfnet_store_search_by_bow(hfnet_store* s, int n_pairs, const int32_t* query_set, const int32_t* train_set,
-                              float th_low, int32_t* match_q2t, float* dist, int32_t* n_matches);
+                              int query_rows, int train_rows, float th_low, int32_t* match_q2t, float* dist,
+                              int32_t* n_matches);
 int hfnet_store_search_for_triangulation(hfnet_store* s, int n_pairs, const int32_t* set1, const int32_t* set2,
-                                         float th_high, int32_t* match12, int32_t* n_matches);
+                                         int rows1, int rows2, float th_high, int32_t* match12, int32_t* n_matches);
 
 /* ---- Resampler (include/Extractors/BaseModel.h:78-80, src/Extractors/BaseModel.cc:491-562) ---------
  * tensorflow.contrib.resampler: bilinear sampling of an NHWC fp32 map at (x, y) warp points with zero

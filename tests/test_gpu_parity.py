@@ -495,3 +495,50 @@ def test_descriptor_store_matches_host_calls(engine):
     with pytest.raises(capi.HfnetError):
         store.search_by_bow([(0, S)], 0.6)
     store.close()
+
+
+def test_descriptor_store_row_filters(engine):
+    """flag-filtered sides (rows with / without a MapPoint, Matcher.cc:231-246, 808-834) == gather on the host + oracle + scatter"""
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    rng = np.random.default_rng(43)
+    mr, S = 300, 5
+    base = _unit_rows(rng, mr)
+    store = capi.Store(engine, S, mr)
+    sizes = [300, 257, 64, 300, 5]
+    sets, flags = [], []
+    for s_ in range(S):
+        n = sizes[s_]
+        v = base[rng.permutation(mr)][:n] + 0.03 * (s_ + 1) * rng.standard_normal((n, 256)).astype(np.float32)
+        v = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+        f = (rng.random(n) < [0.5, 0.3, 1.0, 0.0, 0.6][s_]).astype(np.uint8)
+        sets.append(v); flags.append(f)
+        store.put(s_, v); store.set_flags(s_, f)
+    pairs = [(0, 1), (1, 0), (0, 2), (2, 3), (3, 0), (4, 1), (0, 0), (1, 4)]
+
+    def rows(s_, filt):
+        if filt == capi.ROWS_ALL:
+            return np.arange(sizes[s_])
+        return np.nonzero(flags[s_] == (1 if filt == capi.ROWS_FLAGGED else 0))[0]
+
+    for f1, f2 in [(capi.ROWS_UNFLAGGED, capi.ROWS_UNFLAGGED), (capi.ROWS_FLAGGED, capi.ROWS_ALL), (capi.ROWS_ALL, capi.ROWS_FLAGGED)]:
+        cnt, match, dist = store.search_by_bow(pairs, 0.6, f1, f2)
+        tcnt, tmatch = store.search_for_triangulation(pairs, 0.75, f1, f2)
+        for p, (a, b) in enumerate(pairs):
+            ia, ib = rows(a, f1), rows(b, f2)
+            rn, rm, rd = O.search_by_bow(sets[a][ia], sets[b][ib], 0.6)
+            exp_m = np.full(sizes[a], -1, np.int32); exp_d = np.full(sizes[a], np.finfo(np.float32).max, np.float32)
+            exp_m[ia] = np.where(rm >= 0, ib[np.maximum(rm, 0)] if len(ib) else -1, -1); exp_d[ia] = rd
+            assert cnt[p] == rn, (f1, f2, p)
+            _eq(f"bow {f1}{f2} {p}", match[p, :sizes[a]], exp_m); _eq(f"bow dist {f1}{f2} {p}", dist[p, :sizes[a]], exp_d)
+            tn, tm = O.search_for_triangulation(sets[a][ia], sets[b][ib], 0.75)
+            exp_t = np.full(sizes[a], -1, np.int32)
+            exp_t[ia] = np.where(tm >= 0, ib[np.maximum(tm, 0)] if len(ib) else -1, -1)
+            assert tcnt[p] == tn, (f1, f2, p)
+            _eq(f"tri {f1}{f2} {p}", tmatch[p, :sizes[a]], exp_t)
+    store.put(0, sets[0])                                            # put clears the flags of the slot
+    cnt, _, _ = store.search_by_bow([(0, 1)], 0.6, capi.ROWS_FLAGGED, capi.ROWS_ALL)
+    assert cnt[0] == 0
+    with pytest.raises(capi.HfnetError):
+        store.search_by_bow([(0, 1)], 0.6, 3, 0)
+    store.close()
