@@ -75,21 +75,29 @@ __global__ __launch_bounds__(256) void k_gemm_abt(const float* __restrict__ d1, 
     gemm_abt_tile(d1, n1, d2, n2, dim, S);
 }
 
-// 128 x 128 tile per workgroup, 64 x 64 (2 x 2 MFMA tiles) per wave: every LDS fragment feeds two MFMAs, so the
-// k loop issues one LDS read and one operand select per MFMA instead of two each (VALU instructions and f32 MFMAs
-// share the issue pipe).  Same per-accumulator order (k ascending), so the same bits as the 64 x 64 kernel.
+// 128 x 128 tile per workgroup, 64 x 64 (2 x 2 MFMA tiles) per wave: every LDS fragment feeds two MFMAs.  The LDS
+// rows hold the even k of a 64-float chunk in their first half and the odd k in the second, so a half-wave (which
+// supplies the even resp. odd k of every MFMA step) reads the operands of four consecutive steps with one 16-byte
+// read and no select (VALU instructions and f32 MFMAs share the issue pipe).  Same per-accumulator order
+// (k ascending), so the same bits as the 64 x 64 kernel.  Rows are 68 floats apart: 16-byte reads of 16 consecutive
+// rows cover all 64 banks once.
 __device__ __forceinline__ void gemm_abt_tile128(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int dim,
                                                  float* __restrict__ S) {
-    constexpr int LD = 66;
+    constexpr int LD = 68;
     __shared__ __attribute__((aligned(16))) float As[128 * LD];
     __shared__ __attribute__((aligned(16))) float Bs[128 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
     const int row0 = blockIdx.y * 128, col0 = blockIdx.x * 128;
     if (row0 >= n1 || col0 >= n2) return;                     // workgroup-uniform
     const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
-    const int lrow = tid >> 1, lq = tid & 1;                  // staging: 2 threads per row, 8 float4 each per 64-float chunk
-    const float* ag = d1 + (long long)min(row0 + lrow, n1 - 1) * dim + lq * 4;
-    const float* bg = d2 + (long long)min(col0 + lrow, n2 - 1) * dim + lq * 4;
+    // staging: 16 threads cover the 256 contiguous bytes of a row chunk; a thread handles rows (tid / 16) * 8 + j
+    const int lc = tid & 15, lrow = (tid >> 4) * 8;
+    long long aoff[8], boff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        aoff[j] = (long long)min(row0 + lrow + j, n1 - 1) * dim + lc * 4;
+        boff[j] = (long long)min(col0 + lrow + j, n2 - 1) * dim + lc * 4;
+    }
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -99,32 +107,34 @@ __device__ __forceinline__ void gemm_abt_tile128(const float* __restrict__ d1, i
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     f32x4 sa[8], sb[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sa[j] = *(const f32x4*)(ag + j * 8); sb[j] = *(const f32x4*)(bg + j * 8); }
+    for (int j = 0; j < 8; ++j) { sa[j] = *(const f32x4*)(d1 + aoff[j]); sb[j] = *(const f32x4*)(d2 + boff[j]); }
     for (int k0 = 0; k0 < dim; k0 += 64) {
         __syncthreads();                                     // previous chunk fully consumed
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float* ap = As + lrow * LD + lq * 4 + j * 8;
-            float* bp = Bs + lrow * LD + lq * 4 + j * 8;
-            *(float2*)(ap) = float2{sa[j][0], sa[j][1]}; *(float2*)(ap + 2) = float2{sa[j][2], sa[j][3]};
-            *(float2*)(bp) = float2{sb[j][0], sb[j][1]}; *(float2*)(bp + 2) = float2{sb[j][2], sb[j][3]};
+            float* ap = As + (lrow + j) * LD + lc * 2;
+            float* bp = Bs + (lrow + j) * LD + lc * 2;
+            *(float2*)(ap) = float2{sa[j][0], sa[j][2]}; *(float2*)(ap + 32) = float2{sa[j][1], sa[j][3]};
+            *(float2*)(bp) = float2{sb[j][0], sb[j][2]}; *(float2*)(bp + 32) = float2{sb[j][1], sb[j][3]};
         }
         __syncthreads();
         if (k0 + 64 < dim) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { sa[j] = *(const f32x4*)(ag + k0 + 64 + j * 8); sb[j] = *(const f32x4*)(bg + k0 + 64 + j * 8); }
+            for (int j = 0; j < 8; ++j) { sa[j] = *(const f32x4*)(d1 + aoff[j] + k0 + 64); sb[j] = *(const f32x4*)(d2 + boff[j] + k0 + 64); }
         }
-        const float* ap = As + (wr + r) * LD;
-        const float* bp = Bs + (wc + r) * LD;
+        const float* ap = As + (wr + r) * LD + half * 32;
+        const float* bp = Bs + (wc + r) * LD + half * 32;
 #pragma unroll
-        for (int k = 0; k < 64; k += 2) {
-            const float2 a0 = *(const float2*)(ap + k), a1 = *(const float2*)(ap + 32 * LD + k);
-            const float2 b0 = *(const float2*)(bp + k), b1 = *(const float2*)(bp + 32 * LD + k);
-            const float x0 = half ? a0.y : a0.x, x1 = half ? a1.y : a1.x, y0 = half ? b0.y : b0.x, y1 = half ? b1.y : b1.x;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, acc[1][1], 0, 0, 0);
+        for (int m = 0; m < 8; ++m) {
+            const f32x4 a0 = *(const f32x4*)(ap + 4 * m), a1 = *(const f32x4*)(ap + 32 * LD + 4 * m);
+            const f32x4 b0 = *(const f32x4*)(bp + 4 * m), b1 = *(const f32x4*)(bp + 32 * LD + 4 * m);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
+            }
         }
     }
 #pragma unroll

@@ -52,6 +52,21 @@ def test_full_size_frame_vs_oracle_and_properties(engine, oracle_model, cfg):
     x.close()
 
 
+def test_monocular_initialisation_extractor_5x_features(engine, oracle_model):
+    """Tracking.cc:693 builds the initialisation extractor with 5 * nFeatures on the same models; with the 8-level pyramid
+    of the monocular yaml files the small levels run out of candidates before their budget is met."""
+    from hfnet_slam_amd import capi, spec
+    w, h, nf, nl = 752, 480, 5000, 8
+    x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, nl, max_batch=1)
+    img = synth_image(h, w, 1003, "natural")
+    n, kps, desc, g, npl = x.extract(img)
+    rn, rk, rd, rg, rnpl = oracle_model.extract(img, nf, 0.01, nl, 1.2)
+    budget = spec.features_per_level(nf, nl, 1.2)
+    assert n == rn and np.array_equal(npl, rnpl) and all(a <= b for a, b in zip(npl, budget)) and n > 1000
+    assert np.array_equal(kps, rk) and np.array_equal(desc, rd) and np.array_equal(g, rg)
+    x.close()
+
+
 def test_full_size_match_1000x1000(engine):
     from oracle import oracle as O
     rng = np.random.default_rng(11)
