@@ -17,48 +17,53 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // =========================================================================== S = D1 * D2^T
 // One wave per 32x32 tile of S on v_mfma_f32_32x32x2_f32; each accumulator is the fused
-// multiply-add chain over k = 0, 1, 2, ... (the oracle's order).  Rows are in logical order here, so
-// every lane loads the 8 consecutive k of its row and the two half-waves pick even / odd k.
+// multiply-add chain over k = 0, 1, 2, ... (the oracle's order).
 // Workgroup = 64 x 64 tile of S (4 waves, one 32x32 MFMA tile each); K is consumed in chunks of 64 that
 // are staged through LDS with coalesced 256-byte row segments (a lane's own row is 1 KB away from its
-// neighbour's, so direct fragment loads thrash L1).  LDS rows are 66 floats apart: the 8-byte fragment
-// reads (k = 2t, 2t+1; the half-waves pick the even / odd one) are bank-conflict free.
+// neighbour's, so direct fragment loads thrash L1).
 __device__ __forceinline__ void gemm_abt_tile(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int dim,
                                               float* __restrict__ S) {
-    constexpr int LD = 66;
+    constexpr int LD = 68;                                    // even k in floats [0, 32), odd k in [32, 64) of a row (see the 128 x 128 tile)
     __shared__ __attribute__((aligned(16))) float As[64 * LD];
     __shared__ __attribute__((aligned(16))) float Bs[64 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
     const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
     if (row0 >= n1 || col0 >= n2) return;                     // workgroup-uniform (batched launches are sized for the largest pair)
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-    const int lrow = tid >> 2, lq = tid & 3;                 // staging: 4 threads x 4 float4 per 64-float row chunk
-    const float* ag = d1 + (long long)min(row0 + lrow, n1 - 1) * dim + lq * 4;
-    const float* bg = d2 + (long long)min(col0 + lrow, n2 - 1) * dim + lq * 4;
+    const int lc = tid & 15, lrow = (tid >> 4) * 4;          // staging: 16 threads per 256-byte row chunk, rows (tid / 16) * 4 + j
+    long long aoff[4], boff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        aoff[j] = (long long)min(row0 + lrow + j, n1 - 1) * dim + lc * 4;
+        boff[j] = (long long)min(col0 + lrow + j, n2 - 1) * dim + lc * 4;
+    }
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
     f32x4 sa[4], sb[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { sa[j] = *(const f32x4*)(ag + j * 16); sb[j] = *(const f32x4*)(bg + j * 16); }
+    for (int j = 0; j < 4; ++j) { sa[j] = *(const f32x4*)(d1 + aoff[j]); sb[j] = *(const f32x4*)(d2 + boff[j]); }
     for (int k0 = 0; k0 < dim; k0 += 64) {
         __syncthreads();                                     // previous chunk fully consumed
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { As[lrow * LD + lq * 4 + j * 16 + c] = sa[j][c]; Bs[lrow * LD + lq * 4 + j * 16 + c] = sb[j][c]; }
+            float* ap = As + (lrow + j) * LD + lc * 2;
+            float* bp = Bs + (lrow + j) * LD + lc * 2;
+            *(float2*)(ap) = float2{sa[j][0], sa[j][2]}; *(float2*)(ap + 32) = float2{sa[j][1], sa[j][3]};
+            *(float2*)(bp) = float2{sb[j][0], sb[j][2]}; *(float2*)(bp + 32) = float2{sb[j][1], sb[j][3]};
         }
         __syncthreads();
         if (k0 + 64 < dim) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { sa[j] = *(const f32x4*)(ag + k0 + 64 + j * 16); sb[j] = *(const f32x4*)(bg + k0 + 64 + j * 16); }
+            for (int j = 0; j < 4; ++j) { sa[j] = *(const f32x4*)(d1 + aoff[j] + k0 + 64); sb[j] = *(const f32x4*)(d2 + boff[j] + k0 + 64); }
         }
-        const float* ap = As + (wr + r) * LD;
-        const float* bp = Bs + (wc + r) * LD;
+        const float* ap = As + (wr + r) * LD + half * 32;
+        const float* bp = Bs + (wc + r) * LD + half * 32;
 #pragma unroll
-        for (int k = 0; k < 64; k += 2) {
-            const float2 av = *(const float2*)(ap + k), bv = *(const float2*)(bp + k);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? av.y : av.x, half ? bv.y : bv.x, acc, 0, 0, 0);
+        for (int m = 0; m < 8; ++m) {
+            const f32x4 av = *(const f32x4*)(ap + 4 * m), bv = *(const f32x4*)(bp + 4 * m);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
         }
     }
     const int col = col0 + wc + r;
