@@ -293,6 +293,61 @@ __global__ __launch_bounds__(256, 2) void k_pointwise(ConvArgs a) {
     conv_epilogue<NT>(a, acc, nt0, row0, a.P, half, r);
 }
 
+// Low-latency 1x1 convolution for launches that cannot fill the GPU (single frames: the projections of the 30x47 / 15x24
+// layers of the global branch are a few dozen workgroups with 288-720 input channels).  k_pointwise prefetches one
+// k-step ahead, which is right when other waves fill the gaps; alone on its SIMD a wave then pays one memory latency
+// (~0.35 us) per k-step.  This variant keeps PWD_NBUF - 1 k-steps of loads in flight in rotating register buffers.
+// Same MFMA order, same bits.  (A 16 x 16 tile per wave on v_mfma_f32_16x16x4_f32 -- bit-identical as well, see
+// tools/micro/mfma_order.hip -- quarters the MFMA chain but triples the address-coalescer work and measured slower.)
+// Tensors must stay below 2 GB (32-bit lane offsets on scalar bases).
+constexpr int PWD_NBUF = 8;
+template <int NT>
+__global__ __launch_bounds__(256) void k_pointwise_deep(ConvArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
+    const int row0 = blockIdx.x * 128 + wave * 32;
+    if (row0 >= (int)a.P) return;
+    const int nt0 = blockIdx.y * NT;
+    const int row = min(row0 + r, (int)a.P - 1);
+    const unsigned aoff = ((unsigned)row * (unsigned)a.cin + (unsigned)(half * 4)) * 4u;         // bytes
+    const unsigned woff = (unsigned)lane * 16u;
+    const char* __restrict__ abase = (const char*)a.A;                                          // uniform
+    const char* __restrict__ wbase = (const char*)(a.W + (size_t)nt0 * 64);                     // uniform
+    const unsigned wstep = (unsigned)a.nt_total * 64u * 16u;                                    // bytes per k-step
+    const int KQ = a.cin >> 3;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
+    f32x4 av[PWD_NBUF], bv[PWD_NBUF][NT];
+    auto load = [&](int kq, auto buf_tag) {
+        constexpr int buf = decltype(buf_tag)::value;
+        // unconditional (past the end: the last step again, an L1 hit nobody uses): a branch around the loads would make
+        // the compiler's wait counts assume the shorter path and drain the queue before every step
+        kq = min(kq, KQ - 1);
+        av[buf] = *(const f32x4*)(abase + (size_t)kq * 32 + aoff);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[buf][nt] = *(const f32x4*)(wbase + (size_t)kq * wstep + nt * 1024 + woff);
+    };
+    auto compute = [&](int kq, auto buf_tag) {
+        constexpr int buf = decltype(buf_tag)::value;
+        if (kq < KQ) {                                           // uniform
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][t], bv[buf][nt][t], acc[nt], 0, 0, 0);
+        }
+    };
+    static_assert(PWD_NBUF == 8, "rotation below is written for eight buffers");
+#define PWD_B(i) std::integral_constant<int, i>{}
+    load(0, PWD_B(0)); load(1, PWD_B(1)); load(2, PWD_B(2)); load(3, PWD_B(3)); load(4, PWD_B(4)); load(5, PWD_B(5)); load(6, PWD_B(6));
+#define PWD_STEP(i) load(kq + i + 7, PWD_B((i + 7) % 8)); __builtin_amdgcn_sched_barrier(0); compute(kq + i, PWD_B(i)); __builtin_amdgcn_sched_barrier(0);
+    for (int kq = 0; kq < KQ; kq += 8) { PWD_STEP(0) PWD_STEP(1) PWD_STEP(2) PWD_STEP(3) PWD_STEP(4) PWD_STEP(5) PWD_STEP(6) PWD_STEP(7) }
+#undef PWD_STEP
+#undef PWD_B
+    conv_epilogue<NT>(a, acc, nt0, row0, a.P, half, r);
+}
+
 // (An LDS-staged variant for wide inputs -- coalesced 128-byte row segments instead of per-lane 16-byte slices -- was
 // measured on MI355X and gave no gain; it is not kept.)
 
@@ -491,6 +546,14 @@ hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* res
     if (P <= 0) return hipSuccess;
     const ConvArgs a = make_args(A, cp, residual, out, P, relu6);
     const int nt = pick_nt(cp.nt_total, cp.nt_per_block, (P + 31) / 32);
+    // long k chains on few tiles: latency-bound, see k_pointwise_deep
+    static const long long lowlat_waves = []() { const char* v = getenv("HFNET_PWD_WAVES"); return v ? atoll(v) : 1024ll; }();
+    if (nt <= 2 && cp.cin >= 192 && (P + 31) / 32 * cp.nt_total < lowlat_waves && P * (long long)std::max(cp.cin, cp.n) * 4 < (1ll << 31)) {
+        dim3 grid((unsigned)((P + 127) / 128), cp.nt_total / nt);
+        if (nt == 1) hipLaunchKernelGGL(k_pointwise_deep<1>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_pointwise_deep<2>, grid, dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     dim3 grid((unsigned)((P + 127) / 128), cp.nt_total / nt);
     switch (nt) {
         case 1: launch_pw_nt<1>(a, grid, s); break;
@@ -512,11 +575,20 @@ static hipError_t launch_conv3x3_any(const float* A, const ConvPack& cp, float* 
     int ntb = cp.nt_per_block;
     if (!ta) { static const int t = []() { const char* v = getenv("HFNET_CONV3_NT"); return v ? atoi(v) : 0; }(); if (t > 0 && cp.nt_total % t == 0) ntb = t; }
     if (ta) { static const int t = []() { const char* v = getenv("HFNET_TAPS_NT"); return v ? atoi(v) : 4; }(); if (t > 0 && cp.nt_total % t == 0) ntb = t; }
-    long long wgs = 0;
+    long long tiles = 0;
     for (int l = 0; l < HFNET_MAX_LEVELS; ++l) {
         a.level_tiles[l] = l < g.n_levels ? std::max((level_rows[l] + 127) / 128, 1) : 1;
-        if (l < g.n_levels) wgs += (long long)g.batch * (cp.nt_total / ntb) * a.level_tiles[l];
+        if (l < g.n_levels) tiles += (long long)g.batch * a.level_tiles[l];
     }
+    // small batches: a wave's 3x3 chain over 9 * cin is ~50 us long with four column tiles, and a single frame has only
+    // ~110 row tiles -- take fewer column tiles per wave until the launch has two workgroups per CU (latency, not throughput)
+    static const int min_wgs = []() { const char* v = getenv("HFNET_CONV3_MIN_WGS"); return v ? atoi(v) : 512; }();
+    while (ntb > 1 && tiles * (cp.nt_total / ntb) < min_wgs) {
+        int next = ntb - 1;
+        while (next > 1 && cp.nt_total % next) --next;
+        ntb = next;
+    }
+    const long long wgs = tiles * (cp.nt_total / ntb);
     if (wgs <= 0 || wgs > 0x7fffffffll) return hipErrorInvalidValue;
     dim3 grid((unsigned)wgs, 1, 1);
     switch (ntb) {
