@@ -542,3 +542,25 @@ def test_descriptor_store_row_filters(engine):
     with pytest.raises(capi.HfnetError):
         store.search_by_bow([(0, 1)], 0.6, 3, 0)
     store.close()
+
+
+def test_random_geometries_match_oracle(engine, oracle_model):
+    """sizes around the tile edges of the fused kernels (cell grids of 15..17, 31..33 columns, odd remainders, one to five
+    levels), two frames per call: keypoints, descriptors and global descriptors are the oracle's, bit for bit"""
+    from hfnet_slam_amd import capi
+    rng = np.random.default_rng(20260928)
+    cases = [(8 * 16 + 3, 8 * 15 + 1, 2), (8 * 17, 8 * 33 + 7, 3), (8 * 31 + 5, 8 * 9, 1), (8 * 32, 8 * 32, 4), (8 * 33 + 1, 8 * 7 + 6, 2)]
+    for _ in range(5):
+        cases.append((int(rng.integers(72, 400)), int(rng.integers(72, 300)), int(rng.integers(1, 6))))
+    for ci, (w, h, nl) in enumerate(cases):
+        nf = int(rng.integers(40, 400))
+        x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, nl, max_batch=2)
+        imgs = np.stack([synth_image(h, w, 4000 + 2 * ci, "natural"), synth_image(h, w, 4001 + 2 * ci)])
+        nb, kb, db, gb = x.extract_batch(imgs)
+        for f in range(2):
+            rn, rk, rd, rg, _ = oracle_model.extract(imgs[f], nf, 0.01, nl, 1.2)
+            assert nb[f] == rn, (w, h, nl, f)
+            assert np.array_equal(kb[f, :rn], rk), (w, h, nl, f)
+            _eq(f"desc {w}x{h}x{nl} frame {f}", db[f, :rn], rd)
+            _eq(f"global {w}x{h}x{nl} frame {f}", gb[f], rg)
+        x.close()
