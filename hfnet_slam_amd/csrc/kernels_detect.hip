@@ -41,9 +41,19 @@ __global__ __launch_bounds__(256) void k_softmax_d2s(const float* __restrict__ l
     const int cy = cell / lv.W, cx = cell - cy * lv.W;
     const float* r = logits + (lv.in_off + (long long)frame * lv.H * lv.W + cell) * ld;
     float e[65];
-    float mx = r[0];
+    // a cell's 65 logits are only 4-byte aligned: 16 unaligned 16-byte loads + 1 instead of 65 scalar ones (every load
+    // instruction of a wave touches 64 different cache lines, the address coalescer is what bounds this kernel)
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
-    for (int k = 0; k < 65; ++k) { e[k] = r[k]; mx = fmaxf(mx, e[k]); }
+    for (int k4 = 0; k4 < 16; ++k4) {
+        const f32x4u v = *(const f32x4u*)(r + 4 * k4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) e[4 * k4 + c] = v[c];
+    }
+    e[64] = r[64];
+    float mx = e[0];
+#pragma unroll
+    for (int k = 1; k < 65; ++k) mx = fmaxf(mx, e[k]);
     float sum = 0.0f;
 #pragma unroll
     for (int k = 0; k < 65; ++k) { e[k] = hf_expf(e[k] - mx); sum = sum + e[k]; }
