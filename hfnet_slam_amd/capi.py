@@ -28,7 +28,7 @@ SYMBOLS = [
     "hfnet_extractor_create", "hfnet_extractor_destroy", "hfnet_extractor_tables",
     "hfnet_extractor_extract", "hfnet_extractor_extract_batch",
     "hfnet_descriptor_distance", "hfnet_resampler", "hfnet_match_search_by_bow", "hfnet_match_search_by_bow_batch", "hfnet_match_search_for_triangulation", "hfnet_match_search_for_triangulation_batch",
-    "hfnet_store_create", "hfnet_store_destroy", "hfnet_store_put", "hfnet_store_rows", "hfnet_store_set_flags", "hfnet_store_search_by_bow",
+    "hfnet_store_create", "hfnet_store_destroy", "hfnet_store_put", "hfnet_store_put_extracted", "hfnet_store_rows", "hfnet_store_set_flags", "hfnet_store_search_by_bow",
     "hfnet_store_search_for_triangulation",
     "hfnet_db_create", "hfnet_db_destroy", "hfnet_db_add", "hfnet_db_erase", "hfnet_db_clear", "hfnet_db_query", "hfnet_db_query_batch",
     "hfnet_profile_enable", "hfnet_profile_reset", "hfnet_profile_filter", "hfnet_profile_count", "hfnet_profile_get",
@@ -319,6 +319,9 @@ class Store:
     def put(self, slot: int, rows: np.ndarray):
         r = np.ascontiguousarray(rows, np.float32)
         _chk(lib().hfnet_store_put(self.h, int(slot), _p(r), int(r.shape[0])))
+
+    def put_extracted(self, slot: int, extractor, frame: int = 0):
+        _chk(lib().hfnet_store_put_extracted(self.h, int(slot), extractor.h, int(frame)))
 
     def rows(self, slot: int) -> int:
         return lib().hfnet_store_rows(self.h, int(slot))

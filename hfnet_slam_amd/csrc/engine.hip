@@ -709,6 +709,23 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
     HF_TRY(dalloc(x->allocs, &x->d_desc, (size_t)max_batch * n_features * HFNET_DESC_DIM));
     HF_TRY(dalloc(x->allocs, &x->d_n, (size_t)max_batch));
     HF_TRY(dalloc(x->allocs, &x->d_n_level, (size_t)max_batch * n_levels));
+    x->last_n.assign((size_t)max_batch, -1);
+    {   // pinned block of the latency path (see hfnet_extractor::h_pin); without it the pageable path is used
+        const char* v = getenv("HFNET_PINNED_FRAMES");
+        const int pf = std::min(max_batch, v ? atoi(v) : 4);
+        if (pf > 0) {
+            auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+            size_t off = up((size_t)pf * width * height);
+            x->pin_n = off; off += up(sizeof(int) * pf);
+            x->pin_nl = off; off += up(sizeof(int) * (size_t)pf * n_levels);
+            x->pin_g = off; off += up(sizeof(float) * (size_t)pf * e->impl.w.global_dim);
+            x->pin_k = off; off += up(sizeof(hfnet_keypoint) * (size_t)pf * n_features);
+            x->pin_d = off; off += up(sizeof(float) * HFNET_DESC_DIM * (size_t)pf * n_features);
+            void* hp = nullptr;
+            if (hipHostMalloc(&hp, off, hipHostMallocDefault) == hipSuccess) { x->h_pin = (unsigned char*)hp; x->pinned_frames = pf; }
+            else (void)hipGetLastError();
+        }
+    }
     *out = x.release();
     return HFNET_OK;
 }
@@ -718,6 +735,7 @@ void hfnet_extractor_destroy(hfnet_extractor* x) {
     (void)hipSetDevice(x->eng->impl.device);
     for (auto& kv : x->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : x->allocs) (void)hipFree(p);
+    if (x->h_pin) (void)hipHostFree(x->h_pin);
     delete x;
 }
 
@@ -773,14 +791,28 @@ static int extract_chunk(hfnet_extractor* x, int nb, const uint8_t* d_images, in
 
 // host-pointer path: the chunk's launches always use the extractor's own staging buffers, so they are captured once per
 // chunk size into a graph (both streams: the global branch forks and joins inside it) and replayed afterwards
-static int extract_chunk_graphed(hfnet_extractor* x, int nb) {
+static int extract_chunk_graphed(hfnet_extractor* x, int nb, bool pinned) {
     Engine& eng = x->eng->impl;
     Net& net = x->net;
     hipStream_t st = net.stream;
-    auto direct = [&]() { return extract_chunk(x, nb, x->d_pyr[0], x->width, (long long)x->width * x->height, x->d_kps, x->d_desc, nullptr, x->d_n, x->d_n_level); };
+    const int G = eng.w.global_dim;
+    auto direct = [&]() -> int {
+        const size_t img_bytes = (size_t)x->width * x->height;
+        if (pinned) HF_HIP(hipMemcpyAsync(x->d_pyr[0], x->h_pin, img_bytes * nb, hipMemcpyHostToDevice, st));
+        HF_TRY(extract_chunk(x, nb, x->d_pyr[0], x->width, (long long)img_bytes, x->d_kps, x->d_desc, nullptr, x->d_n, x->d_n_level));
+        if (pinned) {                                              // results of the whole chunk at full capacity: sizes are static
+            HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_n, x->d_n, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+            HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_nl, x->d_n_level, sizeof(int) * (size_t)x->n_levels * nb, hipMemcpyDeviceToHost, st));
+            if (net.cfg.global) HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_g, net.global_out, sizeof(float) * (size_t)nb * G, hipMemcpyDeviceToHost, st));
+            HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_k, x->d_kps, sizeof(hfnet_keypoint) * (size_t)nb * x->n_features, hipMemcpyDeviceToHost, st));
+            HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_d, x->d_desc, sizeof(float) * HFNET_DESC_DIM * (size_t)nb * x->n_features, hipMemcpyDeviceToHost, st));
+        }
+        return HFNET_OK;
+    };
     if (!x->use_graph || eng.prof.enabled) return direct();
     if (net.join_pending) { HF_HIP(hipStreamWaitEvent(st, net.ev_join, 0)); net.join_pending = false; }   // (not capturable: recorded outside)
-    auto it = x->graphs.find(nb);
+    const int key = pinned ? -nb : nb;
+    auto it = x->graphs.find(key);
     if (it == x->graphs.end()) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
@@ -796,7 +828,7 @@ static int extract_chunk_graphed(hfnet_extractor* x, int nb) {
         }
         (void)hipGraphDestroy(graph);
         if (getenv("HFNET_GRAPH_VERBOSE")) fprintf(stderr, "hfnet: captured the %d-frame chunk into a graph\n", nb);
-        it = x->graphs.emplace(nb, exec).first;
+        it = x->graphs.emplace(key, exec).first;
     }
     HF_HIP(hipGraphLaunch(it->second, st));
     return HFNET_OK;
@@ -814,23 +846,47 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
     HF_HIP(hipSetDevice(eng.device));
     hipStream_t st = x->net.stream;
     const int G = eng.w.global_dim;
-    if (on_device) HF_HIP(eng.wait_fence(st));
+    if (on_device) { HF_HIP(eng.wait_fence(st)); std::fill(x->last_n.begin(), x->last_n.end(), -1); }
     for (int f0 = 0; f0 < n_frames; f0 += x->max_batch) {
         const int nb = std::min(x->max_batch, n_frames - f0);
         if (on_device) {
             HF_TRY(extract_chunk(x, nb, images + (size_t)f0 * frame_stride, row_stride, (long long)frame_stride, kps + (size_t)f0 * x->n_features,
                                  local_desc + (size_t)f0 * x->n_features * HFNET_DESC_DIM, global_desc ? global_desc + (size_t)f0 * G : nullptr,
                                  n_out + f0, nullptr));
+        } else if (nb <= x->pinned_frames && x->h_pin) {
+            // latency path: image -> pinned block (CPU), one graph (upload, ~75 kernels on two streams, downloads), one sync,
+            // pinned block -> caller's buffers (CPU, only the rows that exist)
+            const size_t img_bytes = (size_t)x->width * x->height;
+            for (int f = 0; f < nb; ++f) {
+                const uint8_t* src = images + (size_t)(f0 + f) * frame_stride;
+                unsigned char* dst = x->h_pin + (size_t)f * img_bytes;
+                if (row_stride == x->width) std::memcpy(dst, src, img_bytes);
+                else for (int y = 0; y < x->height; ++y) std::memcpy(dst + (size_t)y * x->width, src + (size_t)y * row_stride, (size_t)x->width);
+            }
+            HF_TRY(extract_chunk_graphed(x, nb, true));
+            HF_HIP(hipStreamSynchronize(st));
+            const int* hn = (const int*)(x->h_pin + x->pin_n);
+            for (int f = 0; f < nb; ++f) {
+                const int n = hn[f];
+                n_out[f0 + f] = n;
+                x->last_n[f] = n;
+                if (global_desc) std::memcpy(global_desc + (size_t)(f0 + f) * G, x->h_pin + x->pin_g + sizeof(float) * (size_t)f * G, sizeof(float) * G);
+                if (n <= 0) continue;
+                std::memcpy(kps + (size_t)(f0 + f) * x->n_features, x->h_pin + x->pin_k + sizeof(hfnet_keypoint) * (size_t)f * x->n_features, sizeof(hfnet_keypoint) * n);
+                std::memcpy(local_desc + (size_t)(f0 + f) * x->n_features * HFNET_DESC_DIM,
+                            x->h_pin + x->pin_d + sizeof(float) * HFNET_DESC_DIM * (size_t)f * x->n_features, sizeof(float) * HFNET_DESC_DIM * n);
+            }
         } else {
             for (int f = 0; f < nb; ++f)
                 HF_HIP(hipMemcpy2DAsync(x->d_pyr[0] + (size_t)f * x->width * x->height, x->width, images + (size_t)(f0 + f) * frame_stride, row_stride,
                                         x->width, x->height, hipMemcpyHostToDevice, st));
-            HF_TRY(extract_chunk_graphed(x, nb));
+            HF_TRY(extract_chunk_graphed(x, nb, false));
             HF_HIP(hipMemcpyAsync(n_out + f0, x->d_n, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
             if (global_desc) HF_HIP(hipMemcpyAsync(global_desc + (size_t)f0 * G, x->net.global_out, sizeof(float) * (size_t)nb * G, hipMemcpyDeviceToHost, st));
             HF_HIP(hipStreamSynchronize(st));
             for (int f = 0; f < nb; ++f) {
                 const int n = n_out[f0 + f];
+                x->last_n[f] = n;
                 if (n <= 0) continue;
                 HF_HIP(hipMemcpyAsync(kps + (size_t)(f0 + f) * x->n_features, x->d_kps + (size_t)f * x->n_features, sizeof(hfnet_keypoint) * n, hipMemcpyDeviceToHost, st));
                 HF_HIP(hipMemcpyAsync(local_desc + (size_t)(f0 + f) * x->n_features * HFNET_DESC_DIM, x->d_desc + (size_t)f * x->n_features * HFNET_DESC_DIM,
@@ -853,7 +909,8 @@ int hfnet_extractor_extract(hfnet_extractor* x, const uint8_t* image, int row_st
     *n_out = n;
     if (n_per_level) {
         std::lock_guard<std::mutex> lk(x->mu);
-        HF_HIP(hipMemcpy(n_per_level, x->d_n_level, sizeof(int) * x->n_levels, hipMemcpyDeviceToHost));
+        if (x->h_pin && x->pinned_frames >= 1) std::memcpy(n_per_level, x->h_pin + x->pin_nl, sizeof(int) * x->n_levels);   // came down with the frame
+        else HF_HIP(hipMemcpy(n_per_level, x->d_n_level, sizeof(int) * x->n_levels, hipMemcpyDeviceToHost));
     }
     return HFNET_OK;
 }
@@ -1055,6 +1112,30 @@ int hfnet_store_set_flags(hfnet_store* st, int slot, const uint8_t* flags, int n
     HF_HIP(hipSetDevice(e.device));
     HF_HIP(hipMemcpyAsync(st->d_flags + (size_t)slot * st->max_rows, flags, (size_t)n_rows, hipMemcpyHostToDevice, e.stream));
     HF_HIP(hipStreamSynchronize(e.stream));
+    return HFNET_OK;
+}
+
+int hfnet_store_put_extracted(hfnet_store* st, int slot, hfnet_extractor* x, int frame) {
+    API_GUARD(st, "store"); API_GUARD(x, "extractor");
+    if (st->eng != x->eng) { set_error("store and extractor belong to different engines"); return HFNET_ERR_INVALID_ARG; }
+    if (slot < 0 || slot >= st->n_sets || frame < 0 || frame >= x->max_batch) { set_error("store: slot %d / frame %d out of range", slot, frame); return HFNET_ERR_INVALID_ARG; }
+    if (st->dim != HFNET_DESC_DIM) { set_error("store: descriptor width %d, extractor produces %d", st->dim, HFNET_DESC_DIM); return HFNET_ERR_SHAPE; }
+    std::lock_guard<std::mutex> lkx(x->mu);
+    const int n = x->last_n[frame];
+    if (n < 0) { set_error("store: no host-pointer extraction result in staging frame %d", frame); return HFNET_ERR_INVALID_ARG; }
+    if (n > st->max_rows) { set_error("store: %d rows > capacity %d", n, st->max_rows); return HFNET_ERR_CAPACITY; }
+    std::lock_guard<std::mutex> lk(st->mu);
+    Engine& e = st->eng->impl;
+    std::lock_guard<std::mutex> lk2(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    // the extraction that filled the staging buffers was synchronised by its host-pointer call; the copies are ordered
+    // before later matches by the engine stream, and before the next extraction by the synchronisation below
+    if (n) HF_HIP(hipMemcpyAsync(st->d_desc + (size_t)slot * st->max_rows * st->dim, x->d_desc + (size_t)frame * x->n_features * HFNET_DESC_DIM,
+                                 sizeof(float) * (size_t)n * st->dim, hipMemcpyDeviceToDevice, e.stream));
+    HF_HIP(hipMemcpyAsync(st->d_rows + slot, x->d_n + frame, sizeof(int32_t), hipMemcpyDeviceToDevice, e.stream));
+    HF_HIP(hipMemsetAsync(st->d_flags + (size_t)slot * st->max_rows, 0, (size_t)st->max_rows, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));
+    st->rows[slot] = n;
     return HFNET_OK;
 }
 

@@ -142,6 +142,13 @@ struct hfnet_extractor {
     // frame at a time the launches themselves are a good part of the latency.  One executable graph per chunk size.
     std::map<int, hipGraphExec_t> graphs;
     int use_graph = 1;
+    // Small chunks (<= pinned_frames) also move their input and results through one pinned block inside the same graph:
+    // one launch and one host synchronisation per call instead of three blocking pageable copies.
+    // [images | n | n_level | global | keypoints | descriptors] for pinned_frames frames
+    unsigned char* h_pin = nullptr;
+    std::vector<int> last_n;             // keypoint counts of the last host-pointer call per staging frame (-1: unknown)
+    int pinned_frames = 0;
+    size_t pin_n = 0, pin_nl = 0, pin_g = 0, pin_k = 0, pin_d = 0;   // byte offsets of the sections
     std::mutex mu;
 };
 

@@ -172,6 +172,9 @@ enum { HFNET_ROWS_ALL = 0, HFNET_ROWS_FLAGGED = 1, HFNET_ROWS_UNFLAGGED = 2 };
 int hfnet_store_create(hfnet_engine* e, int n_sets, int max_rows, int dim, hfnet_store** out);
 void hfnet_store_destroy(hfnet_store* s);
 int hfnet_store_put(hfnet_store* s, int slot, const float* rows, int n_rows);
+/* the descriptors of staging frame `frame` of the extractor's last host-pointer call, device to device: the block of a
+ * frame that was just extracted never travels back up (slot flags are cleared, like hfnet_store_put) */
+int hfnet_store_put_extracted(hfnet_store* s, int slot, hfnet_extractor* x, int frame);
 int hfnet_store_rows(const hfnet_store* s, int slot);            /* rows of a slot, -1 for a bad slot */
 int hfnet_store_set_flags(hfnet_store* s, int slot, const uint8_t* flags, int n_rows);
 int hfnet_store_search_by_bow(hfnet_store* s, int n_pairs, const int32_t* query_set, const int32_t* train_set,

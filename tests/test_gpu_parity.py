@@ -564,3 +564,36 @@ def test_random_geometries_match_oracle(engine, oracle_model):
             _eq(f"desc {w}x{h}x{nl} frame {f}", db[f, :rn], rd)
             _eq(f"global {w}x{h}x{nl} frame {f}", gb[f], rg)
         x.close()
+
+
+def test_store_put_extracted_matches_host_round_trip(engine, oracle_model):
+    """frame-to-frame tracking without the descriptors leaving the GPU: extract, keep the block in a store slot, match by slot"""
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    w, h, nf = 200, 152, 260
+    x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, 3, max_batch=2)
+    store = capi.Store(engine, 3, nf)
+    descs = []
+    for i in range(3):
+        img = synth_image(h, w, 8100 + i, "natural")
+        if i == 2:                                               # two frames per call: staging frame 1
+            nb, _, db, _ = x.extract_batch(np.stack([synth_image(h, w, 1, "uniform"), img]))
+            n, d = int(nb[1]), db[1, :nb[1]]
+            store.put_extracted(i, x, 1)
+        else:
+            n, _, d, _, _ = x.extract(img)
+            store.put_extracted(i, x, 0)
+        assert store.rows(i) == n
+        descs.append(np.array(d))
+    pairs = [(0, 1), (1, 2), (2, 0)]
+    cnt, match, dist = store.search_by_bow(pairs, 0.6)
+    for p, (a, b) in enumerate(pairs):
+        rn, rm, rd = O.search_by_bow(descs[a], descs[b], 0.6)
+        assert cnt[p] == rn
+        _eq(f"match {p}", match[p, :len(descs[a])], rm); _eq(f"dist {p}", dist[p, :len(descs[a])], rd)
+    with pytest.raises(capi.HfnetError):
+        store.put_extracted(0, x, 2)
+    small = capi.Store(engine, 1, 8)
+    with pytest.raises(capi.HfnetError):
+        small.put_extracted(0, x, 0)
+    small.close(); store.close(); x.close()

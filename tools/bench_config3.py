@@ -25,7 +25,8 @@ weights.save(wp, weights.synthetic_weights(7))
 eng = capi.Engine(wp, 0)
 ext = capi.Extractor(eng, W, H, NF, 0.01, 1.2, 4, max_batch=1)
 db = capi.Database(eng, FRAMES // 5 + 8, eng.global_dim)
-store = capi.Store(eng, FRAMES // 5 + 8, NF) if STORE else None
+store = capi.Store(eng, FRAMES // 5 + 8, NF) if STORE else None       # keyframe slots; the last two slots hold the current / previous frame
+F0 = FRAMES // 5 + 6
 imgs = [np.random.default_rng(1000 + i).integers(0, 256, (H, W), dtype=np.uint8) for i in range(16)]
 for i in range(3):
     ext.extract(imgs[i])
@@ -36,7 +37,11 @@ t_all0 = time.perf_counter()
 for i in range(FRAMES):
     t0 = time.perf_counter()
     n, kps, desc, g, _ = ext.extract(imgs[i % len(imgs)])
-    if prev is not None:
+    if STORE:                                        # frame-to-frame match by slot: the descriptors stay on the GPU
+        store.put_extracted(F0 + (i & 1), ext, 0)
+        if i:
+            store.search_by_bow([(F0 + 1 - (i & 1), F0 + (i & 1))], 0.6)
+    elif prev is not None:
         eng.search_by_bow(prev, desc, 0.6)
     prev = desc
     t1 = time.perf_counter()
@@ -44,7 +49,7 @@ for i in range(FRAMES):
     if i % 5 == 0:
         if n_kf and STORE:
             db.query(g, 0)
-            store.put(n_kf, desc)
+            store.put_extracted(n_kf, ext, 0)
             store.search_for_triangulation([(n_kf, j) for j in range(max(0, n_kf - 30), n_kf)], 0.75)
         elif n_kf:
             db.query(g, 0)
@@ -56,7 +61,7 @@ for i in range(FRAMES):
                 sets[j, :d.shape[0]] = d; rows[j] = d.shape[0]
             eng.search_for_triangulation_batch(sets, rows, [(0, j + 1) for j in range(len(nb))], 0.75)
         if STORE and not n_kf:
-            store.put(0, desc)
+            store.put_extracted(0, ext, 0)
         db.add(n_kf, g); kf_desc.append(desc); n_kf += 1
         t_kf.append(time.perf_counter() - t1)
 wall = time.perf_counter() - t_all0
