@@ -179,6 +179,7 @@ public:
     }
     int GetLevels() const { return nlevels; }
     std::vector<float> GetScaleFactors() const { return mvScaleFactor; }
+    hfnet_extractor* handle() const { return mExtractor; }      // for KeyFrameDescriptorStore::putExtracted
     std::vector<int> mnFeaturesPerLevel;
     std::vector<float> mvScaleFactor;
 
@@ -262,6 +263,8 @@ public:
     ~KeyFrameDescriptorStore() { hfnet_store_destroy(mStore); }
     bool IsValid() const { return mStore != nullptr; }
     bool put(int slot, const Mat& descriptors) { return mStore && hfnet_store_put(mStore, slot, descriptors.ptr<float>(), descriptors.rows) == HFNET_OK; }
+    // the block of the frame `extractor` produced last, device to device (no upload)
+    bool putExtracted(int slot, const HFextractor& extractor) { return mStore && hfnet_store_put_extracted(mStore, slot, extractor.handle(), 0) == HFNET_OK; }
     int rows(int slot) const { return hfnet_store_rows(mStore, slot); }
     // one byte per row: 1 = the keypoint has a MapPoint (KeyFrame::GetMapPointMatches)
     bool setMapPointFlags(int slot, const std::vector<unsigned char>& flags) { return mStore && hfnet_store_set_flags(mStore, slot, flags.data(), (int)flags.size()) == HFNET_OK; }

@@ -78,7 +78,8 @@ int main(int argc, char** argv) {
 
     // KeyFrameDescriptorStore: the same two matches through device-resident blocks
     KeyFrameDescriptorStore store(set.engine, 4, std::max(std::max(n, en), 1));
-    int okStore = store.IsValid() && store.put(0, local) && store.put(2, edesc);
+    // slot 2: the block of the frame `ext` extracted last, taken from its device buffers (the empty-image call above ran nothing)
+    int okStore = store.IsValid() && store.put(0, local) && store.putExtracted(2, ext) && store.rows(2) == en;
     std::vector<std::vector<int>> sm, tm; std::vector<std::vector<float>> sd; std::vector<int> sn, tn;
     okStore = okStore && store.SearchByBoW({0, 2}, {2, 0}, 0.6f, sm, sd, sn) && store.SearchForTriangulation({0}, {2}, 0.75f, tm, tn);
     put(fo, &okStore, 4);
