@@ -146,7 +146,9 @@ int Net::build(Engine* eng, const NetConfig& c) {
     const int last_layer = c.global ? 18 : 7;
     size_t exp_max = 0, dw_max = 0;
     for (int L = first_layer; L <= last_layer; ++L) {
-        HF_TRY(dalloc(allocs, &act[L], (size_t)pix[L][HFNET_MAX_LEVELS] * layer_channels(w, L)));
+        const bool stem_elided = L == 1 && fuse_stem && fuse_blocks && stem_block_fusable(w.stem_out, w.blocks[0]);
+        if (L == 1) stem_elems_max = (size_t)pix[L][HFNET_MAX_LEVELS] * layer_channels(w, L);
+        if (!stem_elided) HF_TRY(dalloc(allocs, &act[L], (size_t)pix[L][HFNET_MAX_LEVELS] * layer_channels(w, L)));   // (elided: allocated by the first tap request)
         if (L >= 2 && L > first_layer) {
             const BlockPack& b = w.blocks[L - 2];
             exp_max = std::max(exp_max, (size_t)pix[L - 1][HFNET_MAX_LEVELS] * b.expand);
@@ -267,6 +269,7 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
     if (!cfg.from_intermediate) {
         const Geom gs = geom(0, 1, 0, NL);
         int first = 2;
+        last_imgs = imgs; stem_valid = false;
         if (fuse_stem && fuse_blocks && stem_block_fusable(w.stem_out, w.blocks[0])) {
             // stem + layer_2 in one launch; the stem tensor (act[1]) is not materialised
             HF_LAUNCH(e, stream, "stem_block_L02", launch_stem_block(imgs, w.stem_w, w.stem_scale, w.stem_shift, w.blocks[0], act[2], gs,
@@ -274,6 +277,7 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
             first = 3;
         } else {
             HF_LAUNCH(e, stream, "stem", launch_stem(imgs, w.stem_w, w.stem_scale, w.stem_shift, w.stem_out, act[1], gs, stream));
+            stem_valid = true;
         }
         for (int L = first; L <= 7; ++L) {
             // the previous step's global branch (deferred join) still reads layer 7 on its own stream
@@ -375,6 +379,12 @@ int Net::tap(int id, std::vector<float>& out) {
         nms_valid = true;
     }
     const DeviceWeights& w = e->w;
+    if (id == 0 && !cfg.from_intermediate && !stem_valid) {
+        // the fused stem + layer_2 kernel never writes the stem tensor: produce it for the tap from the last input
+        if (!act[1]) HF_TRY(dalloc(allocs, &act[1], stem_elems_max));
+        HF_LAUNCH(e, stream, "stem_tap", launch_stem(last_imgs, w.stem_w, w.stem_scale, w.stem_shift, w.stem_out, act[1], geom(0, 1, 0, cfg.n_levels), stream));
+        stem_valid = true;
+    }
     const float* src = nullptr;
     size_t count = 0;
     int permute_c = 0;
@@ -685,7 +695,6 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
     }
     NetConfig c;
     c.n_levels = n_levels; c.batch = max_batch; c.local = true; c.global = true; c.from_intermediate = false;
-    x->net.fuse_stem = 0;   // stem + layer_2 fusion exists (HFNET_FUSE_STEM=1) but measured slower than two launches: off
     { const char* v = getenv("HFNET_GRAPH"); x->use_graph = v ? atoi(v) : 1; }
     c.max_keypoints = 1;
     for (int l = 0; l < n_levels; ++l) { c.width[l] = x->level_w[l]; c.height[l] = x->level_h[l]; c.max_keypoints = std::max(c.max_keypoints, x->features_per_level[l]); }

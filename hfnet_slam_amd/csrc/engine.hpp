@@ -78,7 +78,10 @@ struct Net {
     int force_dense = 0;           // diagnostics / A-B: always run the dense descriptor head
     int fuse_blocks = 1;           // fused inverted-residual kernel for layers <= fuse_max_layer
     int fuse_max_layer = 14;
-    int fuse_stem = 0;             // stem + layer_2 in one launch (the layer_1 tap is then unavailable)
+    int fuse_stem = 1;             // stem + layer_2 in one launch: the stem tensor is not materialised (its tap recomputes it on demand)
+    ImageSet last_imgs;            // input of the last forward (for that tap)
+    bool stem_valid = false;
+    size_t stem_elems_max = 0;     // size of the stem tensor at the configured (largest) batch
     float *dense = nullptr, *nms = nullptr;
     unsigned *nms_mask = nullptr, *nms_flags = nullptr;   // bit-column masks of the NMS passes (max_mask, supp)
     unsigned long long* cand = nullptr;

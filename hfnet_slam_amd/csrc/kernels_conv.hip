@@ -1957,6 +1957,172 @@ __global__ __launch_bounds__(256) void k_stem_block(ImageSet imgs, StemBlockArgs
     }
 }
 
+// Second version of the stem + layer_2 fusion, built on k_block_noexpand: its halo-tile load is replaced by the stem
+// convolution of the 18 x 18 halo positions straight from the u8 image (wave-uniform scalar weights; the 324 positions
+// x 2 channel halves are 12 wave-sized work units, three per wave), everything after it is k_block_noexpand unchanged.
+// The 24-channel half-resolution stem tensor -- 690 MB per 32-frame step, written by one kernel and read by the next --
+// never exists.
+template <int CS, int COUT>
+__global__ __launch_bounds__(256) void k_stem_block2(ImageSet imgs, const float* __restrict__ stem_w, const float* __restrict__ stem_scale,
+                                                     const float* __restrict__ stem_shift, const float* __restrict__ wd,
+                                                     const float* __restrict__ dsc, const float* __restrict__ dsh, const float* __restrict__ wp,
+                                                     const float* __restrict__ psc, const float* __restrict__ psh, float* __restrict__ out,
+                                                     Geom gs /*image -> stem*/, Geom gb /*stem -> layer_2*/) {
+    constexpr int T = 16, SH = T + 2, SP = SH * SH, CP = CS + 4, CH = CS / 2;
+    static_assert(CS == 24 && COUT == 16, "written for the 0.75-width network");
+    __shared__ __attribute__((aligned(16))) float tile[SP * CP];
+    const int image = blockIdx.y, level = image / gs.batch, frame = image - level * gs.batch;
+    const LevelGeom ls = gs.lv[level], lb = gb.lv[level];     // ls: H,W image (cropped), Ho,Wo stem; lb: H,W stem, Ho,Wo out (same size)
+    const int tiles_x = (lb.Wo + T - 1) / T;
+    if ((int)blockIdx.x >= tiles_x * ((lb.Ho + T - 1) / T)) return;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int oy0 = tyi * T, ox0 = txi * T;
+    const int sy0 = oy0 - lb.pt, sx0 = ox0 - lb.pl;            // first stem row / col of the halo tile
+    const uint8_t* img = imgs.ptr[level] + (long long)frame * imgs.frame_stride[level];
+    const int rs = imgs.row_stride[level];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // ---- stem on the halo tile: unit u = wave + 4 * pass covers positions [54 * (u % 6), +54) and channel half u / 6
+    constexpr int CHUNK = SP / 6;                              // 54 positions per unit
+    static_assert(CHUNK * 6 == SP && CHUNK <= 64, "halo positions split into six wave-sized chunks");
+#pragma unroll 1
+    for (int pass = 0; pass < 3; ++pass) {
+        const int u = wave + 4 * pass, chunk = u % 6, hsel = u / 6;          // uniform
+        const int p = chunk * CHUNK + min(lane, CHUNK - 1);
+        const int hy = p / SH, hx = p - hy * SH;
+        const int sy = sy0 + hy, sx = sx0 + hx;
+        const bool in = sy >= 0 && sy < ls.Ho && sx >= 0 && sx < ls.Wo;
+        float px[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = sy * 2 - ls.pt + ky, ix = sx * 2 - ls.pl + kx;
+                const bool ok = in && iy >= 0 && iy < ls.H && ix >= 0 && ix < ls.W;
+                const float raw = (float)img[(long long)(ok ? iy : 0) * rs + (ok ? ix : 0)];
+                px[ky * 3 + kx] = ok ? (raw - 128.0f) * 0.0078125f : 0.0f;
+            }
+        // weights of four channels at a time as wave-uniform 16-byte scalar loads, fetched one group ahead of their use
+        // (left alone the compiler waits for every channel's nine weights right after asking for them)
+        const f32x4* __restrict__ w4 = (const f32x4*)(stem_w + hsel * CH);    // uniform; row t is w4[t * CS / 4 + group]
+        const f32x4* __restrict__ sc4 = (const f32x4*)(stem_scale + hsel * CH);
+        const f32x4* __restrict__ sh4 = (const f32x4*)(stem_shift + hsel * CH);
+        float* tp = tile + p * CP + hsel * CH;
+        f32x4 wq[9], wqn[9], scq, shq, scn, shn;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wq[t] = w4[t * (CS / 4)];
+        scq = sc4[0]; shq = sh4[0];
+#pragma unroll
+        for (int grp = 0; grp < CH / 4; ++grp) {
+            if (grp + 1 < CH / 4) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wqn[t] = w4[t * (CS / 4) + grp + 1];
+                scn = sc4[grp + 1]; shn = sh4[grp + 1];
+            }
+            asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+            f32x4 r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc = fmaf(px[t], wq[t][j], acc);
+                float v = relu6f(fmaf(acc, scq[j], shq[j]));
+                asm volatile("" : "+v"(v));                                    // computed by every lane: a select, not a branch
+                r[j] = in ? v : 0.0f;                                          // outside the stem map: the depthwise conv's zero padding
+            }
+            if (lane < CHUNK) *(f32x4*)(tp + grp * 4) = r;
+            asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+            if (grp + 1 < CH / 4) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wq[t] = wqn[t];
+                scq = scn; shq = shn;
+            }
+        }
+    }
+    __syncthreads();
+    const int ty = threadIdx.x / T, tx = threadIdx.x - ty * T;
+    constexpr int CIN = CS;
+    float d[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) d[c] = 0.0f;
+    float wc[CIN], wn[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) wc[c] = wd[c];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {                    // (see k_block_noexpand for the weight staging)
+        if (tap < 8) {
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) wn[c] = wd[(tap + 1) * CIN + c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) wn[c] = dsc[c];
+        }
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+        const float* xp = tile + ((ty + tap / 3) * SH + tx + tap % 3) * CP;
+#pragma unroll
+        for (int c4 = 0; c4 < CIN / 4; ++c4) {
+            const f32x4 xv = *(const f32x4*)(xp + c4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[c4 * 4 + j] = fmaf(xv[j], wc[c4 * 4 + j], d[c4 * 4 + j]);
+        }
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) wc[c] = wn[c];
+    }
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) wn[c] = dsh[c];
+    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) d[c] = relu6f(fmaf(d[c], wc[c], wn[c]));
+    __builtin_amdgcn_sched_barrier(0);
+    float acc[COUT];
+#pragma unroll
+    for (int n = 0; n < COUT; ++n) acc[n] = 0.0f;
+    float pc[COUT], pn[COUT];
+#pragma unroll
+    for (int n = 0; n < COUT; ++n) pc[n] = wp[n];
+#pragma unroll
+    for (int k = 0; k < CIN; ++k) {                       // logical channel k sits in physical slot phys(k)
+        if (k + 1 < CIN) {
+#pragma unroll
+            for (int n = 0; n < COUT; ++n) pn[n] = wp[(k + 1) * COUT + n];
+        }
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+        const int pk = (k & ~7) | ((k & 1) << 2) | ((k & 7) >> 1);
+        const float dk = d[pk];
+#pragma unroll
+        for (int n = 0; n < COUT; ++n) acc[n] = fmaf(dk, pc[n], acc[n]);
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+                          "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < COUT; ++n) pc[n] = pn[n];
+    }
+#pragma unroll
+    for (int n = 0; n < COUT; ++n) pc[n] = psc[n];
+    constexpr int OP = COUT + 4;
+    __syncthreads();                                       // every thread is done reading the stem tile
+    float* ot = tile;
+#pragma unroll
+    for (int n4 = 0; n4 < COUT / 4; ++n4) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[n4 * 4 + j], pc[n4 * 4 + j], psh[n4 * 4 + j]);
+        *(f32x4*)(ot + threadIdx.x * OP + n4 * 4) = v;
+    }
+    __syncthreads();
+    float* obase = out + (lb.out_off + (long long)frame * lb.Ho * lb.Wo) * COUT;
+    const int cols = min(T, lb.Wo - ox0);
+#pragma unroll
+    for (int k = 0; k < COUT / 4; ++k) {
+        const int q = threadIdx.x + k * 256;
+        const int row = q / (T * COUT / 4), rem = q - row * (T * COUT / 4);
+        const int px2 = rem / (COUT / 4), part = rem - px2 * (COUT / 4);
+        if (oy0 + row < lb.Ho && px2 < cols)
+            *(f32x4*)(obase + ((long long)(oy0 + row) * lb.Wo + ox0 + px2) * COUT + part * 4) = *(const f32x4*)(ot + (row * T + px2) * OP + part * 4);
+    }
+}
+
 bool stem_block_fusable(int stem_out, const BlockPack& b) {
     return stem_out == 24 && !b.has_expand && b.stride == 1 && !b.residual && b.cin == 24 && b.cout == 16 && b.pr_logical != nullptr;
 }
@@ -1970,7 +2136,10 @@ hipError_t launch_stem_block(const ImageSet& imgs, const float* stem_w, const fl
     a.out = out;
     int maxtiles = 0;
     for (int l = 0; l < g_block.n_levels; ++l) maxtiles = max(maxtiles, ((g_block.lv[l].Wo + 15) / 16) * ((g_block.lv[l].Ho + 15) / 16));
-    hipLaunchKernelGGL((k_stem_block<24, 16>), dim3(maxtiles, g_block.n_levels * g_block.batch), dim3(256), 0, s, imgs, a, g_stem, g_block);
+    static const int v2 = []() { const char* v = getenv("HFNET_STEM_BLOCK_V"); return v ? atoi(v) : 2; }();
+    if (v2 == 2) hipLaunchKernelGGL((k_stem_block2<24, 16>), dim3(maxtiles, g_block.n_levels * g_block.batch), dim3(256), 0, s, imgs, a.stem_w, a.stem_scale,
+                                    a.stem_shift, a.dw_w, a.dw_scale, a.dw_shift, a.pr_w, a.pr_scale, a.pr_shift, a.out, g_stem, g_block);
+    else hipLaunchKernelGGL((k_stem_block<24, 16>), dim3(maxtiles, g_block.n_levels * g_block.batch), dim3(256), 0, s, imgs, a, g_stem, g_block);
     return hipGetLastError();
 }
 
