@@ -1985,60 +1985,69 @@ __global__ __launch_bounds__(256) void k_stem_block2(ImageSet imgs, const float*
     // ---- stem on the halo tile: unit u = wave + 4 * pass covers positions [54 * (u % 6), +54) and channel half u / 6
     constexpr int CHUNK = SP / 6;                              // 54 positions per unit
     static_assert(CHUNK * 6 == SP && CHUNK <= 64, "halo positions split into six wave-sized chunks");
+    // tiles whose halo and image patch lie inside the maps (the vast majority) skip every bounds check and select
+    const int iy_first = sy0 * 2 - ls.pt, ix_first = sx0 * 2 - ls.pl;
+    const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + SH <= ls.Ho && sx0 + SH <= ls.Wo && iy_first >= 0 && ix_first >= 0 &&
+                          iy_first + 2 * SH < ls.H && ix_first + 2 * SH < ls.W;     // uniform
+    auto stem_passes = [&](auto interior_tag) {
+        constexpr bool INT = decltype(interior_tag)::value;
 #pragma unroll 1
-    for (int pass = 0; pass < 3; ++pass) {
-        const int u = wave + 4 * pass, chunk = u % 6, hsel = u / 6;          // uniform
-        const int p = chunk * CHUNK + min(lane, CHUNK - 1);
-        const int hy = p / SH, hx = p - hy * SH;
-        const int sy = sy0 + hy, sx = sx0 + hx;
-        const bool in = sy >= 0 && sy < ls.Ho && sx >= 0 && sx < ls.Wo;
-        float px[9];
+        for (int pass = 0; pass < 3; ++pass) {
+            const int u = wave + 4 * pass, chunk = u % 6, hsel = u / 6;          // uniform
+            const int p = chunk * CHUNK + min(lane, CHUNK - 1);
+            const int hy = p / SH, hx = p - hy * SH;
+            const int sy = sy0 + hy, sx = sx0 + hx;
+            const bool in = INT || (sy >= 0 && sy < ls.Ho && sx >= 0 && sx < ls.Wo);
+            float px[9];
+            if (INT) {
+                const uint8_t* ip = img + (long long)(sy * 2 - ls.pt) * rs + (sx * 2 - ls.pl);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+                for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int iy = sy * 2 - ls.pt + ky, ix = sx * 2 - ls.pl + kx;
-                const bool ok = in && iy >= 0 && iy < ls.H && ix >= 0 && ix < ls.W;
-                const float raw = (float)img[(long long)(ok ? iy : 0) * rs + (ok ? ix : 0)];
-                px[ky * 3 + kx] = ok ? (raw - 128.0f) * 0.0078125f : 0.0f;
+                    for (int kx = 0; kx < 3; ++kx) px[ky * 3 + kx] = ((float)ip[ky * rs + kx] - 128.0f) * 0.0078125f;
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int iy = sy * 2 - ls.pt + ky, ix = sx * 2 - ls.pl + kx;
+                        const bool ok = in && iy >= 0 && iy < ls.H && ix >= 0 && ix < ls.W;
+                        const float raw = (float)img[(long long)(ok ? iy : 0) * rs + (ok ? ix : 0)];
+                        px[ky * 3 + kx] = ok ? (raw - 128.0f) * 0.0078125f : 0.0f;
+                    }
             }
-        // weights of four channels at a time as wave-uniform 16-byte scalar loads, fetched one group ahead of their use
-        // (left alone the compiler waits for every channel's nine weights right after asking for them)
-        const f32x4* __restrict__ w4 = (const f32x4*)(stem_w + hsel * CH);    // uniform; row t is w4[t * CS / 4 + group]
-        const f32x4* __restrict__ sc4 = (const f32x4*)(stem_scale + hsel * CH);
-        const f32x4* __restrict__ sh4 = (const f32x4*)(stem_shift + hsel * CH);
-        float* tp = tile + p * CP + hsel * CH;
-        f32x4 wq[9], wqn[9], scq, shq, scn, shn;
+            // weights of four channels at a time as wave-uniform 16-byte scalar loads (36 + 8 SGPRs per group: a second set
+            // prefetched ahead does not fit next to the geometry without spilling to VGPR lanes)
+            const f32x4* __restrict__ w4 = (const f32x4*)(stem_w + hsel * CH);    // uniform; row t is w4[t * CS / 4 + group]
+            const f32x4* __restrict__ sc4 = (const f32x4*)(stem_scale + hsel * CH);
+            const f32x4* __restrict__ sh4 = (const f32x4*)(stem_shift + hsel * CH);
+            float* tp = tile + p * CP + hsel * CH;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wq[t] = w4[t * (CS / 4)];
-        scq = sc4[0]; shq = sh4[0];
+            for (int grp = 0; grp < CH / 4; ++grp) {
+                f32x4 wq[9];
 #pragma unroll
-        for (int grp = 0; grp < CH / 4; ++grp) {
-            if (grp + 1 < CH / 4) {
+                for (int t = 0; t < 9; ++t) wq[t] = w4[t * (CS / 4) + grp];
+                const f32x4 scq = sc4[grp], shq = sh4[grp];
+                asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+                f32x4 r;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) wqn[t] = w4[t * (CS / 4) + grp + 1];
-                scn = sc4[grp + 1]; shn = sh4[grp + 1];
-            }
-            asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-            f32x4 r;
+                for (int j = 0; j < 4; ++j) {
+                    float acc = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) acc = fmaf(px[t], wq[t][j], acc);
-                float v = relu6f(fmaf(acc, scq[j], shq[j]));
-                asm volatile("" : "+v"(v));                                    // computed by every lane: a select, not a branch
-                r[j] = in ? v : 0.0f;                                          // outside the stem map: the depthwise conv's zero padding
-            }
-            if (lane < CHUNK) *(f32x4*)(tp + grp * 4) = r;
-            asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-            if (grp + 1 < CH / 4) {
-#pragma unroll
-                for (int t = 0; t < 9; ++t) wq[t] = wqn[t];
-                scq = scn; shq = shn;
+                    for (int t = 0; t < 9; ++t) acc = fmaf(px[t], wq[t][j], acc);
+                    float v = relu6f(fmaf(acc, scq[j], shq[j]));
+                    if (!INT) {
+                        asm volatile("" : "+v"(v));                                // computed by every lane: a select, not a branch
+                        v = in ? v : 0.0f;                                         // outside the stem map: the depthwise conv's zero padding
+                    }
+                    r[j] = v;
+                }
+                if (lane < CHUNK) *(f32x4*)(tp + grp * 4) = r;
+                asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
             }
         }
-    }
+    };
+    if (interior) stem_passes(std::true_type{}); else stem_passes(std::false_type{});
     __syncthreads();
     const int ty = threadIdx.x / T, tx = threadIdx.x - ty * T;
     constexpr int CIN = CS;
