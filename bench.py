@@ -65,6 +65,10 @@ def layer_work(batch: int):
             add(f"block_L{b.index:02d}",
                 (2.0 * pin * b.cin * b.expand if b.expand > b.cin else 0.0) + 2.0 * 9 * pout * b.expand + 2.0 * pout * b.expand * b.cout,
                 4.0 * (pin * b.cin + pout * b.cout * (2 if b.residual else 1) + b.cin * b.expand + 9 * b.expand + b.expand * b.cout))
+            if b.index == 2:
+                # stem + layer_2 as ONE launch (the default): u8 image in, layer_2 output out
+                add("stem_block_L02", 2.0 * 9 * sp.stem_out * px + 2.0 * 9 * pout * b.expand + 2.0 * pout * b.expand * b.cout,
+                    hc * wc * batch + 4.0 * (pout * b.cout + 9 * sp.stem_out + 9 * b.expand + b.expand * b.cout))
             ph, pw = oh, ow
             if b.index == 7:
                 cells = ph * pw * batch

@@ -11,6 +11,7 @@ import collections, csv, json, sys
 LAUNCHES = {
     "conv3x3_det": ("void hfnet::k_conv3x3<4, false>", 0),
     "conv3x3_desc_taps": ("void hfnet::k_conv3x3<4, true>", 0),
+    "stem_block_L02": ("void hfnet::k_stem_block2<24, 16>", 0),
     "block_L02": ("void hfnet::k_block_noexpand<24, 16>", 0),
     "block_L03": ("void hfnet::k_block_fused2<2, 1, 2, true, 8>", 0),
     "block_L04": ("void hfnet::k_block_fused2<1, 1, 3, true, 16>", 0),
