@@ -1858,106 +1858,7 @@ struct StemBlockArgs {
     float* out;
 };
 
-template <int CS, int COUT>
-__global__ __launch_bounds__(256) void k_stem_block(ImageSet imgs, StemBlockArgs a, Geom gs /*image -> stem*/, Geom gb /*stem -> layer_2*/) {
-    constexpr int T = 16, SH = T + 2, SP = SH * SH, IP = 2 * SH + 1, CSP = CS + 4;
-    __shared__ __attribute__((aligned(16))) float patch[IP * IP];
-    __shared__ __attribute__((aligned(16))) float st[SP * CSP];
-    __shared__ __attribute__((aligned(16))) float w_stem[9 * CS], w_dw[9 * CS], w_pr[CS * COUT];
-    __shared__ __attribute__((aligned(16))) float sc_stem[CS], sh_stem[CS], sc_dw[CS], sh_dw[CS], sc_pr[COUT], sh_pr[COUT];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 9 * CS; i += 256) { w_stem[i] = a.stem_w[i]; w_dw[i] = a.dw_w[i]; }
-    for (int i = tid; i < CS * COUT; i += 256) w_pr[i] = a.pr_w[i];
-    if (tid < CS) { sc_stem[tid] = a.stem_scale[tid]; sh_stem[tid] = a.stem_shift[tid]; sc_dw[tid] = a.dw_scale[tid]; sh_dw[tid] = a.dw_shift[tid]; }
-    if (tid < COUT) { sc_pr[tid] = a.pr_scale[tid]; sh_pr[tid] = a.pr_shift[tid]; }
-    const int image = blockIdx.y, level = image / gs.batch, frame = image - level * gs.batch;
-    const LevelGeom ls = gs.lv[level], lb = gb.lv[level];     // ls: H,W image (cropped), Ho,Wo stem; lb: H,W stem, Ho,Wo out (same size)
-    const int tiles_x = (lb.Wo + T - 1) / T;
-    if ((int)blockIdx.x >= tiles_x * ((lb.Ho + T - 1) / T)) return;
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-    const int oy0 = tyi * T, ox0 = txi * T;
-    const int sy0 = oy0 - lb.pt, sx0 = ox0 - lb.pl;            // first stem row / col of the halo tile
-    const int iy0 = sy0 * 2 - ls.pt, ix0 = sx0 * 2 - ls.pl;    // first image row / col of the patch
-    const uint8_t* img = imgs.ptr[level] + (long long)frame * imgs.frame_stride[level];
-    const int rs = imgs.row_stride[level];
-    for (int i = tid; i < IP * IP; i += 256) {
-        const int py = i / IP, px = i - py * IP;
-        const int iy = iy0 + py, ix = ix0 + px;
-        patch[i] = (iy >= 0 && iy < ls.H && ix >= 0 && ix < ls.W) ? ((float)img[(long long)iy * rs + ix] - 128.0f) * 0.0078125f : 0.0f;
-    }
-    __syncthreads();
-    // stem conv on the SH x SH halo tile (positions outside the stem map are the depthwise conv's zero padding)
-    for (int p = tid; p < SP; p += 256) {
-        const int hy = p / SH, hx = p - hy * SH;
-        const int sy = sy0 + hy, sx = sx0 + hx;
-        const bool in = sy >= 0 && sy < ls.Ho && sx >= 0 && sx < ls.Wo;
-        float px[9];
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) px[ky * 3 + kx] = patch[(2 * hy + ky) * IP + 2 * hx + kx];
-#pragma unroll
-        for (int c4 = 0; c4 < CS / 4; ++c4) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const f32x4 wv = *(const f32x4*)(w_stem + t * CS + c4 * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = fmaf(px[t], wv[j], acc[j]);
-            }
-            f32x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = in ? relu6f(fmaf(acc[j], sc_stem[c4 * 4 + j], sh_stem[c4 * 4 + j])) : 0.0f;
-            *(f32x4*)(st + p * CSP + c4 * 4) = o;
-        }
-    }
-    __syncthreads();
-    const int ty = tid / T, tx = tid - ty * T;
-    const int oy = oy0 + ty, ox = ox0 + tx;
-    if (oy >= lb.Ho || ox >= lb.Wo) return;
-    float d[CS];
-#pragma unroll
-    for (int c = 0; c < CS; ++c) d[c] = 0.0f;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const float* sp = st + ((ty + ky) * SH + tx + kx) * CSP;
-#pragma unroll
-            for (int c4 = 0; c4 < CS / 4; ++c4) {
-                const f32x4 xv = *(const f32x4*)(sp + c4 * 4);
-                const f32x4 wv = *(const f32x4*)(w_dw + (ky * 3 + kx) * CS + c4 * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) d[c4 * 4 + j] = fmaf(xv[j], wv[j], d[c4 * 4 + j]);
-            }
-        }
-#pragma unroll
-    for (int c = 0; c < CS; ++c) d[c] = relu6f(fmaf(d[c], sc_dw[c], sh_dw[c]));
-    float acc[COUT];
-#pragma unroll
-    for (int n = 0; n < COUT; ++n) acc[n] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < CS; ++k) {
-        const int pk = (k & ~7) | ((k & 1) << 2) | ((k & 7) >> 1);
-        const float dk = d[pk];
-#pragma unroll
-        for (int n4 = 0; n4 < COUT / 4; ++n4) {
-            const f32x4 wv = *(const f32x4*)(w_pr + k * COUT + n4 * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[n4 * 4 + j] = fmaf(dk, wv[j], acc[n4 * 4 + j]);
-        }
-    }
-    float* o = a.out + (lb.out_off + (long long)frame * lb.Ho * lb.Wo + (long long)oy * lb.Wo + ox) * COUT;
-#pragma unroll
-    for (int n4 = 0; n4 < COUT / 4; ++n4) {
-        f32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[n4 * 4 + j], sc_pr[n4 * 4 + j], sh_pr[n4 * 4 + j]);
-        *(f32x4*)(o + n4 * 4) = v;
-    }
-}
-
-// Second version of the stem + layer_2 fusion, built on k_block_noexpand: its halo-tile load is replaced by the stem
+// Built on k_block_noexpand: its halo-tile load is replaced by the stem
 // convolution of the 18 x 18 halo positions straight from the u8 image (wave-uniform scalar weights; the 324 positions
 // x 2 channel halves are 12 wave-sized work units, three per wave), everything after it is k_block_noexpand unchanged.
 // The 24-channel half-resolution stem tensor -- 690 MB per 32-frame step, written by one kernel and read by the next --
@@ -2145,10 +2046,8 @@ hipError_t launch_stem_block(const ImageSet& imgs, const float* stem_w, const fl
     a.out = out;
     int maxtiles = 0;
     for (int l = 0; l < g_block.n_levels; ++l) maxtiles = max(maxtiles, ((g_block.lv[l].Wo + 15) / 16) * ((g_block.lv[l].Ho + 15) / 16));
-    static const int v2 = []() { const char* v = getenv("HFNET_STEM_BLOCK_V"); return v ? atoi(v) : 2; }();
-    if (v2 == 2) hipLaunchKernelGGL((k_stem_block2<24, 16>), dim3(maxtiles, g_block.n_levels * g_block.batch), dim3(256), 0, s, imgs, a.stem_w, a.stem_scale,
+    hipLaunchKernelGGL((k_stem_block2<24, 16>), dim3(maxtiles, g_block.n_levels * g_block.batch), dim3(256), 0, s, imgs, a.stem_w, a.stem_scale,
                                     a.stem_shift, a.dw_w, a.dw_scale, a.dw_shift, a.pr_w, a.pr_scale, a.pr_shift, a.out, g_stem, g_block);
-    else hipLaunchKernelGGL((k_stem_block<24, 16>), dim3(maxtiles, g_block.n_levels * g_block.batch), dim3(256), 0, s, imgs, a, g_stem, g_block);
     return hipGetLastError();
 }
 
