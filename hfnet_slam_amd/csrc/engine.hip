@@ -858,6 +858,7 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
     if (on_device) { HF_HIP(eng.wait_fence(st)); std::fill(x->last_n.begin(), x->last_n.end(), -1); }
     for (int f0 = 0; f0 < n_frames; f0 += x->max_batch) {
         const int nb = std::min(x->max_batch, n_frames - f0);
+        if (!on_device) std::fill(x->last_n.begin() + nb, x->last_n.end(), -1);   // staging frames this chunk does not write
         if (on_device) {
             HF_TRY(extract_chunk(x, nb, images + (size_t)f0 * frame_stride, row_stride, (long long)frame_stride, kps + (size_t)f0 * x->n_features,
                                  local_desc + (size_t)f0 * x->n_features * HFNET_DESC_DIM, global_desc ? global_desc + (size_t)f0 * G : nullptr,
