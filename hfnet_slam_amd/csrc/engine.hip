@@ -180,7 +180,6 @@ int Net::build(Engine* eng, const NetConfig& c) {
         const size_t rows = images * (size_t)c.max_keypoints * 4;
         HF_TRY(dalloc(allocs, &rows_hidden, rows * HFNET_DESC_DIM));
         HF_TRY(dalloc(allocs, &rows_raw, rows * HFNET_DESC_DIM));
-        HF_TRY(dalloc(allocs, &rows_norm, rows * HFNET_DESC_DIM));
         HF_TRY(dalloc(allocs, &n_level, images));
     }
     if (c.global) {
@@ -333,7 +332,6 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
             const long long rows = ((long long)(NL * cfg.batch - 1) * cfg.max_keypoints + kmaxb) * 4;
             HF_LAUNCH(e, stream, "conv3x3_desc_taps", launch_conv3x3_taps(act[7], w.desc1, rows_hidden, 1, kps_level, n_level, cfg.max_keypoints, budget.k, gt, stream));
             HF_LAUNCH(e, stream, "pointwise_desc_taps", launch_pointwise(rows_hidden, w.desc2, nullptr, rows_raw, rows, 0, stream));
-            HF_LAUNCH(e, stream, "l2norm_desc_taps", launch_l2norm256(rows_raw, rows_norm, rows, stream));
         } else {
             HF_TRY(run_dense_desc());
         }

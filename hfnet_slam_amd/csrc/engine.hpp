@@ -70,7 +70,7 @@ struct Net {
     float *exp_buf = nullptr, *dw_buf = nullptr;
     float *desc_hidden = nullptr, *desc_raw = nullptr, *desc_norm = nullptr, *det_hidden = nullptr, *logits = nullptr;
     // sparse descriptor head: rows (image*max_keypoints + i)*4 + tap, see launch_conv3x3_taps
-    float *rows_hidden = nullptr, *rows_raw = nullptr, *rows_norm = nullptr;
+    float *rows_hidden = nullptr, *rows_raw = nullptr;
     bool last_sparse = false;      // which descriptor path the last forward() took
     bool dense_valid = false;      // dense descriptor tensors match the last forward()
     bool nms_valid = false;        // the suppressed score map (tap 25) matches the last forward()
@@ -102,7 +102,7 @@ struct Net {
     int tap(int id, std::vector<float>& out);
     int run_dense_desc();
     int forward_global(hipStream_t st);
-    const float* sample_source() const { return last_sparse ? rows_norm : desc_norm; }
+    const float* sample_source() const { return last_sparse ? rows_raw : desc_norm; }   // sparse rows are normalised by k_sample
     ~Net() { release(); }
 };
 

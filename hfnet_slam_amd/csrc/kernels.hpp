@@ -60,7 +60,7 @@ hipError_t launch_l2norm256(const float* in, float* out, long long P, hipStream_
 // bilinear Resampler + cv::normalize + keypoint rescale / concat (HFNetTFModelV2.cc:153-167,
 // BaseModel.cc:491-562, HFextractor.cc:267-281)
 struct SampleArgs {
-    const float* desc_map;        // normalised: dense [pixels x 256], or sparse tap rows [image][kps_stride*4][256]
+    const float* desc_map;        // dense: normalised [pixels x 256]; sparse: RAW tap rows [image][kps_stride*4][256] (normalised on the fly)
     int sparse;
     const hfnet_keypoint* kps_in; // per image slot of kps_stride entries (level coordinates)
     const int* n_in;              // per image count

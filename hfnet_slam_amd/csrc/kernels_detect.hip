@@ -481,6 +481,17 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a, Geom g) {
             vcc = (cxin && cyin) ? *(const f32x4*)(d + 256) : zero;
             vfc = (fxin && cyin) ? *(const f32x4*)(d + 512) : zero;
             vcf = (cxin && fyin) ? *(const f32x4*)(d + 768) : zero;
+            // the rows come straight from the 1x1 conv: tf.nn.l2_normalize of each (hf_net.py:80) here instead of in a
+            // separate pass over them -- same expressions as k_l2norm256 (a skipped tap stays zero)
+            auto l2n = [](f32x4& v) {
+                f32x4 sq;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sq[j] = v[j] * v[j];
+                const float inv = 1.0f / sqrtf(fmaxf(tree256_wave(sq), 1e-12f));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] * inv;
+            };
+            l2n(vff); l2n(vcc); l2n(vfc); l2n(vcf);
         } else {
             const float* d = a.desc_map + (lv.in_off + (long long)frame * dh * dw) * 256 + lane * 4;
             vff = (fxin && fyin) ? *(const f32x4*)(d + (long long)(fy * dw + fx) * 256) : zero;
