@@ -296,21 +296,28 @@ __global__ __launch_bounds__(256, 2) void k_pointwise(ConvArgs a) {
 // Low-latency 1x1 convolution for launches that cannot fill the GPU (single frames: the projections of the 30x47 / 15x24
 // layers of the global branch are a few dozen workgroups with 288-720 input channels).  k_pointwise prefetches one
 // k-step ahead, which is right when other waves fill the gaps; alone on its SIMD a wave then pays one memory latency
-// (~0.35 us) per k-step.  This variant keeps PWD_NBUF - 1 k-steps of loads in flight in rotating register buffers.
+// (~0.35 us) per k-step.  This variant keeps NBUF - 1 k-steps of loads in flight in rotating register buffers.
 // Same MFMA order, same bits.  (A 16 x 16 tile per wave on v_mfma_f32_16x16x4_f32 -- bit-identical as well, see
-// tools/micro/mfma_order.hip -- quarters the MFMA chain but triples the address-coalescer work and measured slower.)
+// tools/micro/mfma_order.hip -- quarters the MFMA chain but triples the address-coalescer work and measured slower; for the
+// big GEMM-shaped launches, e.g. 256 -> 256 on 128k descriptor rows, three steps in flight are no faster than one.)
 // Tensors must stay below 2 GB (32-bit lane offsets on scalar bases).
-constexpr int PWD_NBUF = 8;
-template <int NT>
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int NT, int NBUF>
 __global__ __launch_bounds__(256) void k_pointwise_deep(ConvArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
-    const int row0 = blockIdx.x * 128 + wave * 32;
-    if (row0 >= (int)a.P) return;
+    const long long row0 = (long long)blockIdx.x * 128 + wave * 32;
+    if (row0 >= a.P) return;
     const int nt0 = blockIdx.y * NT;
-    const int row = min(row0 + r, (int)a.P - 1);
-    const unsigned aoff = ((unsigned)row * (unsigned)a.cin + (unsigned)(half * 4)) * 4u;         // bytes
+    const long long row = min(row0 + r, a.P - 1);
+    // uniform tile base + 32-bit lane offset (the tile's rows span < 4 GB)
+    const long long tile_row0 = ((long long)__builtin_amdgcn_readfirstlane((int)(row0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)row0);
+    const unsigned aoff = ((unsigned)(row - tile_row0) * (unsigned)a.cin + (unsigned)(half * 4)) * 4u;   // bytes
     const unsigned woff = (unsigned)lane * 16u;
-    const char* __restrict__ abase = (const char*)a.A;                                          // uniform
+    const char* __restrict__ abase = (const char*)(a.A + tile_row0 * a.cin);                    // uniform
     const char* __restrict__ wbase = (const char*)(a.W + (size_t)nt0 * 64);                     // uniform
     const unsigned wstep = (unsigned)a.nt_total * 64u * 16u;                                    // bytes per k-step
     const int KQ = a.cin >> 3;
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(256) void k_pointwise_deep(ConvArgs a) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
-    f32x4 av[PWD_NBUF], bv[PWD_NBUF][NT];
+    f32x4 av[NBUF], bv[NBUF][NT];
     auto load = [&](int kq, auto buf_tag) {
         constexpr int buf = decltype(buf_tag)::value;
         // unconditional (past the end: the last step again, an L1 hit nobody uses): a branch around the loads would make
@@ -338,13 +345,16 @@ __global__ __launch_bounds__(256) void k_pointwise_deep(ConvArgs a) {
                 for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][t], bv[buf][nt][t], acc[nt], 0, 0, 0);
         }
     };
-    static_assert(PWD_NBUF == 8, "rotation below is written for eight buffers");
-#define PWD_B(i) std::integral_constant<int, i>{}
-    load(0, PWD_B(0)); load(1, PWD_B(1)); load(2, PWD_B(2)); load(3, PWD_B(3)); load(4, PWD_B(4)); load(5, PWD_B(5)); load(6, PWD_B(6));
-#define PWD_STEP(i) load(kq + i + 7, PWD_B((i + 7) % 8)); __builtin_amdgcn_sched_barrier(0); compute(kq + i, PWD_B(i)); __builtin_amdgcn_sched_barrier(0);
-    for (int kq = 0; kq < KQ; kq += 8) { PWD_STEP(0) PWD_STEP(1) PWD_STEP(2) PWD_STEP(3) PWD_STEP(4) PWD_STEP(5) PWD_STEP(6) PWD_STEP(7) }
-#undef PWD_STEP
-#undef PWD_B
+    static_for<NBUF - 1>([&](auto i) { load(decltype(i)::value, i); });
+    for (int kq = 0; kq < KQ; kq += NBUF) {
+        static_for<NBUF>([&](auto i) {
+            constexpr int I = decltype(i)::value;
+            load(kq + I + NBUF - 1, std::integral_constant<int, (I + NBUF - 1) % NBUF>{});
+            __builtin_amdgcn_sched_barrier(0);
+            compute(kq + I, i);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
     conv_epilogue<NT>(a, acc, nt0, row0, a.P, half, r);
 }
 
@@ -548,10 +558,10 @@ hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* res
     const int nt = pick_nt(cp.nt_total, cp.nt_per_block, (P + 31) / 32);
     // long k chains on few tiles: latency-bound, see k_pointwise_deep
     static const long long lowlat_waves = []() { const char* v = getenv("HFNET_PWD_WAVES"); return v ? atoll(v) : 1024ll; }();
-    if (nt <= 2 && cp.cin >= 192 && (P + 31) / 32 * cp.nt_total < lowlat_waves && P * (long long)std::max(cp.cin, cp.n) * 4 < (1ll << 31)) {
+    if (nt <= 2 && cp.cin >= 192 && (P + 31) / 32 * cp.nt_total < lowlat_waves) {
         dim3 grid((unsigned)((P + 127) / 128), cp.nt_total / nt);
-        if (nt == 1) hipLaunchKernelGGL(k_pointwise_deep<1>, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(k_pointwise_deep<2>, grid, dim3(256), 0, s, a);
+        if (nt == 1) hipLaunchKernelGGL((k_pointwise_deep<1, 8>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_pointwise_deep<2, 8>), grid, dim3(256), 0, s, a);
         return hipGetLastError();
     }
     dim3 grid((unsigned)((P + 127) / 128), cp.nt_total / nt);
