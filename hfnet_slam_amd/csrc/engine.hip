@@ -698,7 +698,7 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
     for (int l = 0; l < n_levels; ++l) { c.width[l] = x->level_w[l]; c.height[l] = x->level_h[l]; c.max_keypoints = std::max(c.max_keypoints, x->features_per_level[l]); }
     HF_TRY(x->net.build(&e->impl, c));
     for (int l = 0; l < n_levels; ++l) {
-        HF_TRY(dalloc(x->allocs, &x->d_pyr[l], (size_t)max_batch * x->level_w[l] * x->level_h[l]));
+        HF_TRY(dalloc(x->allocs, &x->d_pyr[l], (size_t)max_batch * ((x->level_w[l] + 3) & ~3) * x->level_h[l]));   // levels >= 1: rows padded to 4 bytes
         if (l == 0) continue;
         std::vector<int> xofs, yofs;
         std::vector<short> ia, ib;
@@ -768,10 +768,11 @@ static int extract_chunk(hfnet_extractor* x, int nb, const uint8_t* d_images, in
     imgs.ptr[0] = d_images; imgs.row_stride[0] = row_stride; imgs.frame_stride[0] = frame_stride;
     for (int l = 1; l < x->n_levels; ++l) {
         const int sw = x->level_w[l - 1], sh = x->level_h[l - 1], dw = x->level_w[l], dh = x->level_h[l];
+        const int dwp = (dw + 3) & ~3;              // pyramid rows are padded to 4 bytes (packed stores)
         HF_LAUNCH(&eng, net.stream, "pyramid_resize",
-                  launch_resize_u8(imgs.ptr[l - 1], sw, sh, imgs.row_stride[l - 1], imgs.frame_stride[l - 1], x->d_pyr[l], dw, dh, dw,
-                                   (long long)dw * dh, x->d_xofs[l], x->d_ialpha[l], x->d_yofs[l], x->d_ibeta[l], nb, net.stream));
-        imgs.ptr[l] = x->d_pyr[l]; imgs.row_stride[l] = dw; imgs.frame_stride[l] = (long long)dw * dh;
+                  launch_resize_u8(imgs.ptr[l - 1], sw, sh, imgs.row_stride[l - 1], imgs.frame_stride[l - 1], x->d_pyr[l], dw, dh, dwp,
+                                   (long long)dwp * dh, x->d_xofs[l], x->d_ialpha[l], x->d_yofs[l], x->d_ibeta[l], nb, net.stream));
+        imgs.ptr[l] = x->d_pyr[l]; imgs.row_stride[l] = dwp; imgs.frame_stride[l] = (long long)dwp * dh;
     }
     TopkBudget budget;
     std::memset(&budget, 0, sizeof budget);

@@ -32,18 +32,30 @@ __global__ __launch_bounds__(256) void k_resize_u8(const uint8_t* __restrict__ s
                                                    uint8_t* __restrict__ dst, int dw, int dh, int d_row, long long d_frame,
                                                    const int* __restrict__ xofs, const short* __restrict__ ialpha,
                                                    const int* __restrict__ yofs, const short* __restrict__ ibeta) {
-    const int dx = blockIdx.x * 256 + threadIdx.x;
+    // a thread owns 4 consecutive output columns and RESIZE_ROWS rows and stores packed 32-bit words (destination rows
+    // are padded to a multiple of 4 bytes; the columns past dw repeat the last one and land in the padding)
+    const int dx4 = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int dy0 = blockIdx.y * RESIZE_ROWS;
-    if (dx >= dw) return;
+    if (dx4 >= dw) return;
     const uint8_t* sp = src + (long long)blockIdx.z * s_frame;
-    uint8_t* dp = dst + (long long)blockIdx.z * d_frame + dx;
-    const int sx = xofs[dx], sx1 = min(sx + 1, sw - 1);
-    const int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
+    unsigned* dp = (unsigned*)(dst + (long long)blockIdx.z * d_frame + dx4);
+    int sx[4], sx1[4], a0[4], a1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int dx = min(dx4 + c, dw - 1);
+        sx[c] = xofs[dx]; sx1[c] = min(sx[c] + 1, sw - 1);
+        a0[c] = ialpha[2 * dx]; a1[c] = ialpha[2 * dx + 1];
+    }
+    struct H4 { int v[4]; };
     auto hrow = [&](int y) {                                   // horizontal pass of source row y (clamped), 11-bit fixed point
         const uint8_t* rp = sp + (long long)y * s_row;
-        return rp[sx] * a0 + rp[sx1] * a1;
+        H4 h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) h.v[c] = rp[sx[c]] * a0[c] + rp[sx1[c]] * a1[c];
+        return h;
     };
-    int cache_y = -1, cache_v = 0;                             // horizontal result of the last lower row
+    int cache_y = -1;
+    H4 cache_v = {{0, 0, 0, 0}};                               // horizontal result of the last lower row
 #pragma unroll
     for (int i = 0; i < RESIZE_ROWS; ++i) {
         const int dy = dy0 + i;
@@ -51,19 +63,25 @@ __global__ __launch_bounds__(256) void k_resize_u8(const uint8_t* __restrict__ s
         const int sy = yofs[dy];
         const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
         const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
-        const int r0 = y0 == cache_y ? cache_v : hrow(y0);     // uniform condition
-        const int r1 = y1 == y0 ? r0 : hrow(y1);
+        const H4 r0 = y0 == cache_y ? cache_v : hrow(y0);      // uniform condition
+        const H4 r1 = y1 == y0 ? r0 : hrow(y1);
         cache_y = y1; cache_v = r1;
-        int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        v = min(max(v, 0), 255);
-        dp[(long long)dy * d_row] = (uint8_t)v;
+        unsigned packed = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int v = (((b0 * (r0.v[c] >> 4)) >> 16) + ((b1 * (r1.v[c] >> 4)) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+            packed |= (unsigned)v << (8 * c);
+        }
+        dp[((long long)dy * d_row) >> 2] = packed;
     }
 }
 
 hipError_t launch_resize_u8(const uint8_t* src, int sw, int sh, int s_row, long long s_frame, uint8_t* dst, int dw, int dh,
                             int d_row, long long d_frame, const int* xofs, const short* ialpha, const int* yofs,
                             const short* ibeta, int batch, hipStream_t s) {
-    dim3 grid((dw + 255) / 256, (dh + RESIZE_ROWS - 1) / RESIZE_ROWS, batch);
+    if ((d_row & 3) || (d_frame & 3) || ((size_t)dst & 3)) return hipErrorInvalidValue;      // packed 32-bit stores
+    dim3 grid(((dw + 3) / 4 + 255) / 256, (dh + RESIZE_ROWS - 1) / RESIZE_ROWS, batch);
     hipLaunchKernelGGL(k_resize_u8, grid, dim3(256), 0, s, src, sw, sh, s_row, s_frame, dst, dw, dh, d_row, d_frame, xofs, ialpha, yofs, ibeta);
     return hipGetLastError();
 }
