@@ -7,7 +7,9 @@ are bit-identical to the oracle's accumulation order; the compiler must not fuse
 """
 from __future__ import annotations
 
+import hashlib
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -16,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libhfnet_hip.so")
-SOURCES = ["weights.cpp", "kernels_conv.hip", "kernels_detect.hip", "kernels_global.hip", "kernels_match.hip", "engine.hip"]
+SOURCES = ["weights.cpp", "kernels_conv.hip", "kernels_block.hip", "kernels_detect.hip", "kernels_global.hip", "kernels_match.hip", "engine.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", "engine.hpp", os.path.join("..", "..", "include", "hfnet_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
          "-Wno-unused-result", "-x", "hip"]
@@ -29,6 +31,26 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+def source_id() -> str:
+    """sha256 (16 hex digits) over every source and header of the library, in a fixed order"""
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS + [os.path.join("host", "hfnet_host.hpp")]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read() + b"\0")
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def library_id():
+    """the build id compiled into libhfnet_hip.so (HFNET_BUILD_ID), read from the file without loading it; None if absent"""
+    try:
+        with open(LIB, "rb") as fh:
+            m = re.search(rb"hfnet-build-id:([0-9a-f]{16})", fh.read())
+        return m.group(1).decode() if m else None
+    except OSError:
+        return None
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -38,14 +60,18 @@ def _stale(target: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
+    sid = source_id()
+    if not force and library_id() == sid:
+        return LIB
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, os.path.splitext(s)[0] + ".o")
-        if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+        extra = [f'-DHFNET_BUILD_ID="hfnet-build-id:{sid}"'] if s == "engine.hip" else []     # (engine.hip exports hfnet_build_id)
+        if force or extra or _stale(obj, [src] + hdrs):
+            jobs.append([hipcc] + FLAGS + extra + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

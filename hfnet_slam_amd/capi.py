@@ -21,8 +21,9 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4"), ("octave",
 
 # every symbol include/hfnet_hip.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = [
-    "hfnet_last_error", "hfnet_abi_version", "hfnet_device_count",
-    "hfnet_engine_create", "hfnet_engine_destroy", "hfnet_engine_info", "hfnet_engine_synchronize", "hfnet_engine_fence",
+    "hfnet_last_error", "hfnet_abi_version", "hfnet_build_id", "hfnet_device_count",
+    "hfnet_engine_create", "hfnet_engine_destroy", "hfnet_engine_info", "hfnet_engine_set_option", "hfnet_engine_get_option",
+    "hfnet_engine_synchronize", "hfnet_engine_fence",
     "hfnet_model_create", "hfnet_model_destroy", "hfnet_model_is_valid", "hfnet_model_mode",
     "hfnet_model_detect", "hfnet_model_detect_global", "hfnet_model_tap",
     "hfnet_extractor_create", "hfnet_extractor_destroy", "hfnet_extractor_tables",
@@ -45,12 +46,24 @@ _lib = None
 
 
 def lib() -> C.CDLL:
+    """loads libhfnet_hip.so -- after checking that it was built from the sources in this tree (the build id compiled
+    into the library is the hash of csrc/ + include/; a stale or missing library is rebuilt when hipcc is here)"""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m hfnet_slam_amd.build` (there is no CPU fallback)")
+        from . import build as _build
+        want = _build.source_id()
+        have = _build.library_id()
+        if have != want:
+            try:
+                _build.build()
+            except Exception as ex:
+                raise RuntimeError(f"{LIB_PATH} is {'missing' if have is None else 'stale (built from ' + have + ', tree is ' + want + ')'} "
+                                   f"and cannot be rebuilt here: {ex} (there is no CPU fallback)")
         L = C.CDLL(LIB_PATH)
         L.hfnet_last_error.restype = C.c_char_p
+        L.hfnet_build_id.restype = C.c_char_p
+        if L.hfnet_build_id().decode() != want:
+            raise RuntimeError(f"{LIB_PATH} reports build id {L.hfnet_build_id().decode()}, the sources hash to {want}")
         for s in SYMBOLS:
             getattr(L, s)  # AttributeError if the library does not export it
         for s in ("hfnet_engine_destroy", "hfnet_model_destroy", "hfnet_extractor_destroy", "hfnet_db_destroy", "hfnet_store_destroy"):
@@ -71,6 +84,10 @@ def _chk(status: int) -> None:
 
 def _p(a):
     return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def build_id() -> str:
+    return lib().hfnet_build_id().decode()
 
 
 def device_count() -> int:
@@ -94,6 +111,19 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, name: str, value: int):
+        _chk(lib().hfnet_engine_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int(0)
+        _chk(lib().hfnet_engine_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    OPTIONS = ("fuse_blocks", "fuse_max_layer", "fused_variant", "fuse_stem", "dense_desc", "two_streams", "graph", "pinned_frames")
+
+    def options(self) -> dict:
+        return {n: self.get_option(n) for n in self.OPTIONS}
 
     def synchronize(self):
         _chk(lib().hfnet_engine_synchronize(self.h))

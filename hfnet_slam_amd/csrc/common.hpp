@@ -83,7 +83,8 @@ struct WeightFile {
     const HostTensor* find(const std::string& name) const;
 };
 
-// one convolution packed for the MFMA kernels
+// one convolution packed for the MFMA kernels.  Inference BatchNorm is folded on the host exactly as the oracle folds it
+// (oracle/hfnet_oracle.c fold_bn): w[..., c] *= scale[c], bias[c] = shift[c]; accumulators start at bias[c].
 struct ConvPack {
     int taps = 1;        // 1 (1x1) or 9 (3x3)
     int cin = 0;         // channels per tap (multiple of 8)
@@ -91,10 +92,19 @@ struct ConvPack {
     int nt_total = 0;    // 32-wide column tiles (padded to a multiple of nt_per_block)
     int nt_per_block = 1;
     float* w = nullptr;      // device: [taps*cin/8][nt_total][64][4]
-    float* scale = nullptr;  // device: [nt_total*32]
-    float* shift = nullptr;  // device: [nt_total*32]
+    float* bias = nullptr;   // device: [nt_total*32], zero padded
 };
-struct DwPack { int c = 0; float* w = nullptr; float* scale = nullptr; float* shift = nullptr; };  // [9][C] phys
+// x @ W + b (layers.py:99-107) for v_mfma_f32_16x16x4_f32: 16 frames x 16 outputs per wave, one accumulator chain over
+// i = 0 .. n_in-1 from b[j] (the oracle's order).  MFMA number m of the chain consumes inputs 4m .. 4m+3, lane (g = lane / 16)
+// supplies input 4m + g; a lane loads 16 bytes = its operands of four consecutive MFMAs, so both the activations and the
+// weights are stored with the inputs of every group of 16 in slot order: slot 4 g + t holds logical input 4 t + g.
+struct FcPack {
+    int n_in = 0, n_out = 0;
+    float* w = nullptr;      // device: [n_in/16][n_out/16][64 lanes][4]
+    float* bias = nullptr;   // device: [n_out]
+};
+inline int fc_slot_of_logical(int i) { const int r = i & 15; return (i & ~15) | ((r & 3) << 2) | (r >> 2); }
+struct DwPack { int c = 0; float* w = nullptr; float* bias = nullptr; };  // [9][C] phys (BN folded)
 struct BlockPack {
     int cin, expand, stride, cout, residual, has_expand;
     ConvPack ex; DwPack dw; ConvPack pr;
@@ -103,14 +113,12 @@ struct BlockPack {
 
 struct DeviceWeights {
     int stem_out = 0, c_local = 0, c_global = 0, n_clusters = 0, global_dim = 0, det_hidden = 0;
-    float* stem_w = nullptr;      // [9][stem_out] phys order
-    float* stem_scale = nullptr;
-    float* stem_shift = nullptr;
+    float* stem_w = nullptr;      // [9][stem_out] phys order (BN folded)
+    float* stem_bias = nullptr;
     BlockPack blocks[17];
     ConvPack desc1, desc2, det1, det2, memb;
     float* clusters = nullptr;    // [K][D] logical
-    float* fc_wt = nullptr;       // [global_dim][K*D]  (transposed for coalesced tree256 dot products)
-    float* fc_b = nullptr;
+    FcPack fc;                    // dimensionality reduction 7680 -> 4096
     std::vector<void*> allocations;
     int build(const WeightFile& wf);
     void release();

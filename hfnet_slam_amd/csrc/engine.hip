@@ -13,6 +13,15 @@
 
 namespace hfnet {
 
+int* Options::find(const char* name) {
+    if (!name) return nullptr;
+    const struct { const char* n; int* p; } tab[] = {{"fuse_blocks", &fuse_blocks}, {"fuse_max_layer", &fuse_max_layer}, {"fused_variant", &fused_variant},
+                                                       {"fuse_stem", &fuse_stem}, {"dense_desc", &dense_desc}, {"two_streams", &two_streams},
+                                                       {"graph", &graph}, {"pinned_frames", &pinned_frames}};
+    for (const auto& t : tab) if (std::strcmp(t.n, name) == 0) return t.p;
+    return nullptr;
+}
+
 // ------------------------------------------------------------------------------------ memory
 int DevMem::ensure(size_t n) {
     if (n <= bytes) return HFNET_OK;
@@ -105,12 +114,9 @@ static void compute_offsets(Net& n, int batch) {
 int Net::build(Engine* eng, const NetConfig& c) {
     e = eng;
     cfg = c;
-    // A/B and diagnostics knobs (tests run both settings): HFNET_FUSE_BLOCKS=0 -> three launches per
-    // block; HFNET_FUSE_MAX_LAYER=n; HFNET_DENSE_DESC=1 -> dense descriptor head
-    if (const char* v = getenv("HFNET_FUSE_BLOCKS")) fuse_blocks = atoi(v);
-    if (const char* v = getenv("HFNET_FUSE_MAX_LAYER")) fuse_max_layer = atoi(v);
-    if (const char* v = getenv("HFNET_DENSE_DESC")) force_dense = atoi(v);
-    if (const char* v = getenv("HFNET_FUSE_STEM")) fuse_stem = atoi(v);
+    // A/B and diagnostics switches of the engine (hfnet_engine_set_option), fixed for the lifetime of this network
+    fuse_blocks = e->opt.fuse_blocks; fuse_max_layer = e->opt.fuse_max_layer; fused_variant = e->opt.fused_variant;
+    force_dense = e->opt.dense_desc; fuse_stem = e->opt.fuse_stem;
     const DeviceWeights& w = e->w;
     if (c.n_levels < 1 || c.n_levels > HFNET_MAX_LEVELS || c.batch < 1) { set_error("net: bad level / batch count"); return HFNET_ERR_INVALID_ARG; }
     if (c.from_intermediate && (c.n_levels != 1 || !c.global)) { set_error("net: intermediate input needs one level and the global head"); return HFNET_ERR_INVALID_ARG; }
@@ -139,8 +145,7 @@ int Net::build(Engine* eng, const NetConfig& c) {
         HF_HIP(hipStreamCreateWithFlags(&stream_global, hipStreamNonBlocking));
         HF_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         HF_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-        const char* v = getenv("HFNET_TWO_STREAMS");
-        two_streams = v ? atoi(v) : 3;   // 0 one stream; 1 fork after layer 7; 2 fork after the detector conv; 3 = 2 + deferred join
+        two_streams = e->opt.two_streams;
     }
     const int first_layer = c.from_intermediate ? 7 : 1;
     const int last_layer = c.global ? 18 : 7;
@@ -232,18 +237,18 @@ static int run_block(Net& n, int L, int n_used, hipStream_t st) {   // layer L =
     const long long p_out = n.pix[L][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
     // fused launch: always for the high-resolution layers; for the 30x47 layers only when the batch gives
     // the launch enough workgroups to fill the chip (measured: 96 WGs lose to three launches, 384 win)
-    bool fuse = n.fuse_blocks && L <= n.fuse_max_layer && block_fusable(b);
+    bool fuse = n.fuse_blocks && L <= n.fuse_max_layer && block_fusable(b, n.fused_variant);
     if (fuse && L > 7) {
         const LevelPlan& p0 = n.lp[0];
-        const int tw = b.stride == 1 ? 16 : 8;
-        const long long wgs = (long long)((p0.w[L] + tw - 1) / tw) * ((p0.h[L] + 7) / 8) * n.cfg.batch;
+        // (in 128-pixel tiles: 96 lose to three launches, 384 win)
+        const long long wgs = (long long)((p0.w[L] + 15) / 16) * ((p0.h[L] + 7) / 8) * n.cfg.batch;
         fuse = wgs >= 256;
     }
     if (fuse) {
         char fn[32];
         snprintf(fn, sizeof fn, "block_L%02d", L);
         const Geom gf = n.geom(L - 1, L, 0, n_used);
-        HF_LAUNCH(e, st, fn, launch_block_fused(n.act[L - 1], b, n.act[L], gf, st));
+        HF_LAUNCH(e, st, fn, launch_block_fused(n.act[L - 1], b, n.act[L], gf, n.fused_variant, st));
         return HFNET_OK;
     }
     const float* src = n.act[L - 1];
@@ -271,11 +276,11 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         last_imgs = imgs; stem_valid = false;
         if (fuse_stem && fuse_blocks && stem_block_fusable(w.stem_out, w.blocks[0])) {
             // stem + layer_2 in one launch; the stem tensor (act[1]) is not materialised
-            HF_LAUNCH(e, stream, "stem_block_L02", launch_stem_block(imgs, w.stem_w, w.stem_scale, w.stem_shift, w.blocks[0], act[2], gs,
+            HF_LAUNCH(e, stream, "stem_block_L02", launch_stem_block(imgs, w.stem_w, w.stem_bias, w.blocks[0], act[2], gs,
                                                                    geom(1, 2, 0, NL), stream));
             first = 3;
         } else {
-            HF_LAUNCH(e, stream, "stem", launch_stem(imgs, w.stem_w, w.stem_scale, w.stem_shift, w.stem_out, act[1], gs, stream));
+            HF_LAUNCH(e, stream, "stem", launch_stem(imgs, w.stem_w, w.stem_bias, w.stem_out, act[1], gs, stream));
             stem_valid = true;
         }
         for (int L = first; L <= 7; ++L) {
@@ -285,9 +290,13 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         }
     }
     if (join_pending) { HF_HIP(hipStreamWaitEvent(stream, ev_join, 0)); join_pending = false; }   // (intermediate-input models)
-    const bool fork = cfg.global && cfg.local && two_streams && stream_global;
+    // per-launch profiling wants every kernel alone on the GPU: one stream while the profiler is on
+    const bool fork = cfg.global && cfg.local && two_streams && stream_global && !e->prof.enabled;
     // deferring needs every layer up to 7 fused (the unfused chain shares its scratch tensors with the global branch)
-    const bool defer = defer_global && fork && two_streams == 3 && fuse_blocks && fuse_max_layer >= 7;
+    bool front_fused = fuse_blocks && fuse_max_layer >= 7;
+    for (int L = 3; L <= 7 && front_fused; ++L) front_fused = block_fusable(w.blocks[L - 2], fused_variant);
+    front_fused = front_fused && (block_fusable(w.blocks[0], fused_variant) || (fuse_stem && stem_block_fusable(w.stem_out, w.blocks[0])));
+    const bool defer = defer_global && fork && two_streams == 3 && front_fused;
     if (fork && two_streams == 1) {
         HF_HIP(hipEventRecord(ev_fork, stream));
         HF_HIP(hipStreamWaitEvent(stream_global, ev_fork, 0));
@@ -350,7 +359,7 @@ int Net::forward_global(hipStream_t st) {
     HF_LAUNCH(e, st, "pointwise_memberships", launch_pointwise(act[18], w.memb, nullptr, memb, (long long)cfg.batch * P, 0, st));
     HF_LAUNCH(e, st, "softmax_memberships", launch_softmax_rows(memb, (long long)cfg.batch * P, w.n_clusters, w.n_clusters, st));
     HF_LAUNCH(e, st, "vlad", launch_vlad(act[18], memb, w.clusters, vlad_tap, vlad_out, vlad_raw, cfg.batch, P, w.c_global, w.n_clusters, st));
-    HF_LAUNCH(e, st, "fc_l2", launch_fc_l2(vlad_out, w.fc_wt, w.fc_b, fc_raw, global_out, cfg.batch, w.n_clusters * w.c_global, w.global_dim, st));
+    HF_LAUNCH(e, st, "fc_l2", launch_fc_l2(vlad_out, w.fc, fc_raw, global_out, cfg.batch, st));
     return HFNET_OK;
 }
 
@@ -380,7 +389,7 @@ int Net::tap(int id, std::vector<float>& out) {
     if (id == 0 && !cfg.from_intermediate && !stem_valid) {
         // the fused stem + layer_2 kernel never writes the stem tensor: produce it for the tap from the last input
         if (!act[1]) HF_TRY(dalloc(allocs, &act[1], stem_elems_max));
-        HF_LAUNCH(e, stream, "stem_tap", launch_stem(last_imgs, w.stem_w, w.stem_scale, w.stem_shift, w.stem_out, act[1], geom(0, 1, 0, cfg.n_levels), stream));
+        HF_LAUNCH(e, stream, "stem_tap", launch_stem(last_imgs, w.stem_w, w.stem_bias, w.stem_out, act[1], geom(0, 1, 0, cfg.n_levels), stream));
         stem_valid = true;
     }
     const float* src = nullptr;
@@ -480,6 +489,11 @@ extern "C" {
 
 const char* hfnet_last_error(void) { return get_error(); }
 int hfnet_abi_version(void) { return HFNET_ABI_VERSION; }
+#ifndef HFNET_BUILD_ID
+#define HFNET_BUILD_ID "hfnet-build-id:unknown"
+#endif
+// (the marker prefix lets hfnet_slam_amd/build.py read the id from the file without loading it)
+const char* hfnet_build_id(void) { static const char id[] = HFNET_BUILD_ID; return &id[sizeof("hfnet-build-id:") - 1]; }
 
 int hfnet_device_count(void) {
     int n = 0;
@@ -521,6 +535,21 @@ int hfnet_engine_info(const hfnet_engine* e, int what) {
         case 5: return e->impl.device;
         default: return -1;
     }
+}
+
+int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value) {
+    API_GUARD(e, "engine");
+    int* p = e->impl.opt.find(name);
+    if (!p) { set_error("unknown engine option '%s'", name ? name : "(null)"); return HFNET_ERR_INVALID_ARG; }
+    *p = value;
+    return HFNET_OK;
+}
+int hfnet_engine_get_option(hfnet_engine* e, const char* name, int* value) {
+    API_GUARD(e, "engine"); API_GUARD(value, "value");
+    const int* p = e->impl.opt.find(name);
+    if (!p) { set_error("unknown engine option '%s'", name ? name : "(null)"); return HFNET_ERR_INVALID_ARG; }
+    *value = *p;
+    return HFNET_OK;
 }
 
 int hfnet_engine_synchronize(hfnet_engine* e) {
@@ -693,7 +722,7 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
     }
     NetConfig c;
     c.n_levels = n_levels; c.batch = max_batch; c.local = true; c.global = true; c.from_intermediate = false;
-    { const char* v = getenv("HFNET_GRAPH"); x->use_graph = v ? atoi(v) : 1; }
+    x->use_graph = e->impl.opt.graph;
     c.max_keypoints = 1;
     for (int l = 0; l < n_levels; ++l) { c.width[l] = x->level_w[l]; c.height[l] = x->level_h[l]; c.max_keypoints = std::max(c.max_keypoints, x->features_per_level[l]); }
     HF_TRY(x->net.build(&e->impl, c));
@@ -718,8 +747,7 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
     HF_TRY(dalloc(x->allocs, &x->d_n_level, (size_t)max_batch * n_levels));
     x->last_n.assign((size_t)max_batch, -1);
     {   // pinned block of the latency path (see hfnet_extractor::h_pin); without it the pageable path is used
-        const char* v = getenv("HFNET_PINNED_FRAMES");
-        const int pf = std::min(max_batch, v ? atoi(v) : 4);
+        const int pf = std::min(max_batch, e->impl.opt.pinned_frames);
         if (pf > 0) {
             auto up = [](size_t b) { return (b + 255) / 256 * 256; };
             size_t off = up((size_t)pf * width * height);
@@ -831,11 +859,9 @@ static int extract_chunk_graphed(hfnet_extractor* x, int nb, bool pinned) {
             (void)hipGetLastError();
             if (graph) (void)hipGraphDestroy(graph);
             x->use_graph = 0;                                     // capture is not available here: plain launches from now on
-            if (getenv("HFNET_GRAPH_VERBOSE")) fprintf(stderr, "hfnet: graph capture failed (rc %d, %s)\n", rc, hipGetErrorString(er));
             return direct();
         }
         (void)hipGraphDestroy(graph);
-        if (getenv("HFNET_GRAPH_VERBOSE")) fprintf(stderr, "hfnet: captured the %d-frame chunk into a graph\n", nb);
         it = x->graphs.emplace(key, exec).first;
     }
     HF_HIP(hipGraphLaunch(it->second, st));
@@ -1015,6 +1041,8 @@ static int match_pairs_batch(hfnet_engine* eh, int n_pairs, const float* desc_ba
     if (!on_device) {
         for (int p = 0; p < n_pairs; ++p)
             if (query_set[p] < 0 || query_set[p] >= n_sets || train_set[p] < 0 || train_set[p] >= n_sets) { set_error("pair %d references a set outside [0, %d)", p, n_sets); return HFNET_ERR_INVALID_ARG; }
+        for (int s = 0; s < n_sets; ++s)
+            if (n_rows[s] < 0 || n_rows[s] > max_rows) { set_error("set %d has %d rows, outside [0, %d]", s, n_rows[s], max_rows); return HFNET_ERR_INVALID_ARG; }
         HF_TRY(e.m_a.ensure(sizeof(float) * (size_t)std::max(n_sets, 1) * set_stride));
         HF_TRY(e.m_b.ensure(sizeof(int32_t) * ((size_t)n_sets + 2 * (size_t)n_pairs)));
         HF_TRY(e.m_i0.ensure(sizeof(int32_t) * (size_t)n_pairs * max_rows)); HF_TRY(e.m_f0.ensure(sizeof(float) * (size_t)n_pairs * max_rows));
@@ -1026,6 +1054,10 @@ static int match_pairs_batch(hfnet_engine* eh, int n_pairs, const float* desc_ba
         HF_HIP(hipMemcpyAsync(ib + n_sets + n_pairs, train_set, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, e.stream));
         d_base = e.m_a.as<float>(); d_rows = ib; d_qs = ib + n_sets; d_ts = ib + n_sets + n_pairs;
         d_match = e.m_i0.as<int32_t>(); d_dist = e.m_f0.as<float>(); d_cnt = e.m_cnt.as<int32_t>();
+        // rows at or beyond a pair's query count are not written by the kernels: the caller gets -1 there (and 0xFF.. = NaN
+        // in the distances of such rows)
+        HF_HIP(hipMemsetAsync(d_match, 0xFF, sizeof(int32_t) * (size_t)n_pairs * max_rows, e.stream));
+        if (!triangulation) HF_HIP(hipMemsetAsync(d_dist, 0xFF, sizeof(float) * (size_t)n_pairs * max_rows, e.stream));
     }
     HF_LAUNCH(&e, e.stream, "match_bow_setup",
               launch_bow_setup(e.m_pairs.as<BowPair>(), n_pairs, d_base, (long long)set_stride, d_rows, d_qs, d_ts, max_rows, e.m_s.as<float>(),
@@ -1320,9 +1352,12 @@ int hfnet_db_add(hfnet_db* db, int slot, const float* descriptor) {
     if (slot < 0 || slot >= db->capacity) { set_error("db: slot %d outside [0, %d)", slot, db->capacity); return HFNET_ERR_CAPACITY; }
     std::lock_guard<std::mutex> lk(db->mu);
     Engine& e = db->eng->impl;
+    std::lock_guard<std::mutex> lk2(e.mu);
     HF_HIP(hipSetDevice(e.device));
-    HF_HIP(hipMemcpy(db->d_db + (size_t)slot * db->dim, descriptor, sizeof(float) * db->dim, hipMemcpyHostToDevice));
-    HF_HIP(hipMemset(db->d_occ + slot, 1, 1));
+    // on the stream the scans run on (created non-blocking: the null stream would not order with it)
+    HF_HIP(hipMemcpyAsync(db->d_db + (size_t)slot * db->dim, descriptor, sizeof(float) * db->dim, hipMemcpyHostToDevice, e.stream));
+    HF_HIP(hipMemsetAsync(db->d_occ + slot, 1, 1, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));                          // the host buffer may go away
     return HFNET_OK;
 }
 
@@ -1330,16 +1365,22 @@ int hfnet_db_erase(hfnet_db* db, int slot) {
     API_GUARD(db, "db");
     if (slot < 0 || slot >= db->capacity) { set_error("db: slot %d outside [0, %d)", slot, db->capacity); return HFNET_ERR_CAPACITY; }
     std::lock_guard<std::mutex> lk(db->mu);
-    HF_HIP(hipSetDevice(db->eng->impl.device));
-    HF_HIP(hipMemset(db->d_occ + slot, 0, 1));
+    Engine& e = db->eng->impl;
+    std::lock_guard<std::mutex> lk2(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    HF_HIP(hipMemsetAsync(db->d_occ + slot, 0, 1, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));
     return HFNET_OK;
 }
 
 int hfnet_db_clear(hfnet_db* db) {
     API_GUARD(db, "db");
     std::lock_guard<std::mutex> lk(db->mu);
-    HF_HIP(hipSetDevice(db->eng->impl.device));
-    HF_HIP(hipMemset(db->d_occ, 0, (size_t)db->capacity));
+    Engine& e = db->eng->impl;
+    std::lock_guard<std::mutex> lk2(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    HF_HIP(hipMemsetAsync(db->d_occ, 0, (size_t)db->capacity, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));
     return HFNET_OK;
 }
 

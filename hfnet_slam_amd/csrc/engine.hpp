@@ -15,8 +15,22 @@ struct DevMem {
     template <class T> T* as() const { return (T*)p; }
 };
 
+// diagnostics / A-B switches (hfnet_engine_set_option): read when a model / extractor is created from the engine
+struct Options {
+    int fuse_blocks = 1;      // 0: expand / depthwise / project as three launches per block (the reference variant of the tests)
+    int fuse_max_layer = 14;  // last layer that may use a fused block kernel
+    int fused_variant = 4;    // 4: wave-autonomous tiles where they exist; 2: the barrier-phased kernel everywhere
+    int fuse_stem = 1;        // stem + layer_2 in one launch
+    int dense_desc = 0;       // 1: always evaluate the dense descriptor head (default: only the taps of the selected keypoints)
+    int two_streams = 3;      // 0 one stream; 1 fork after layer 7; 2 fork after the detector conv; 3 = 2 + deferred join
+    int graph = 1;            // host-pointer extractor calls replay a captured graph
+    int pinned_frames = 4;    // chunks up to this many frames move through one pinned block inside that graph
+    int* find(const char* name);
+};
+
 struct Engine {
     int device = 0;
+    Options opt;
     hipStream_t stream = nullptr;   // matcher / database work
     DeviceWeights w;
     Profiler prof;
@@ -78,6 +92,7 @@ struct Net {
     int force_dense = 0;           // diagnostics / A-B: always run the dense descriptor head
     int fuse_blocks = 1;           // fused inverted-residual kernel for layers <= fuse_max_layer
     int fuse_max_layer = 14;
+    int fused_variant = 4;
     int fuse_stem = 1;             // stem + layer_2 in one launch: the stem tensor is not materialised (its tap recomputes it on demand)
     ImageSet last_imgs;            // input of the last forward (for that tap)
     bool stem_valid = false;

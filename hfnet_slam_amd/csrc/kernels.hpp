@@ -12,8 +12,7 @@ hipError_t launch_resize_u8(const uint8_t* src, int sw, int sh, int s_row, long 
                             const int* xofs, const short* ialpha, const int* yofs, const short* ibeta,
                             int batch, hipStream_t s);
 // image prep + stem conv 3x3/2 + BN + ReLU6 (HFNetTFModelV2.cc:204-208, layers.py:6-7, hf_net.py:30,188-190)
-hipError_t launch_stem(const ImageSet& imgs, const float* w, const float* scale, const float* shift, int cout,
-                       float* out, const Geom& g, hipStream_t s);
+hipError_t launch_stem(const ImageSet& imgs, const float* w, const float* bias, int cout, float* out, const Geom& g, hipStream_t s);
 // 1x1 convolution on the matrix cores: out[P x n] = epilogue(A[P x cin] * W)
 hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* residual, float* out, long long P,
                             int relu6, hipStream_t s);
@@ -27,13 +26,14 @@ hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, i
 // depthwise 3x3 (stride 1 / 2) + BN + ReLU6
 hipError_t launch_depthwise(const float* in, const DwPack& dp, int stride, float* out, const Geom& g, hipStream_t s);
 // whole inverted-residual block (expand -> depthwise -> project [+ residual]) in one launch; the expanded
-// tensor lives in LDS only.  block_fusable(): project width <= 96 columns.
-bool block_fusable(const BlockPack& b);
-hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, const Geom& g, hipStream_t s);
+// tensor lives in LDS only.  block_fusable(): the block's shape has a fused kernel (kernels_block.hip).
+// variant: 4 = wave-autonomous tiles where available (default), 2 = the barrier-phased kernel everywhere (A/B of the tests)
+bool block_fusable(const BlockPack& b, int variant);
+hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, const Geom& g, int variant, hipStream_t s);
 // stem conv + layer_2 (no-expansion block) in one launch: the stem tensor stays in LDS
 bool stem_block_fusable(int stem_out, const BlockPack& b);
-hipError_t launch_stem_block(const ImageSet& imgs, const float* stem_w, const float* stem_scale, const float* stem_shift, const BlockPack& b,
-                             float* out, const Geom& g_stem, const Geom& g_block, hipStream_t s);
+hipError_t launch_stem_block(const ImageSet& imgs, const float* stem_w, const float* stem_bias, const BlockPack& b, float* out,
+                             const Geom& g_stem, const Geom& g_block, hipStream_t s);
 // channel-order conversion between the device layout and NHWC logical order (boundary tensors)
 hipError_t launch_permute_channels(const float* in, float* out, long long P, int C, int to_logical, hipStream_t s);
 
@@ -81,12 +81,13 @@ hipError_t launch_resampler(const float* data, const float* warp, float* out, in
 // ---- kernels_global.hip -------------------------------------------------------------------------
 hipError_t launch_softmax_rows(float* x, long long rows, int n, int ld, hipStream_t s);
 // NetVLAD aggregation + intra-normalisation + both L2 normalisations (layers.py:77-97)
+// vlad_tap: logical order; out: the FC kernel's slot order within every group of 16 (fc_slot_of_logical)
 hipError_t launch_vlad(const float* feat /*phys layout [frames x P x D]*/, const float* memb /*[frames x P x K]*/,
                        const float* clusters, float* vlad_tap /*[frames x K*D] or null*/, float* out /*[frames x K*D]*/,
                        float* scratch /*[frames x K*D]*/, int frames, int P, int D, int K, hipStream_t s);
-// dimensionality reduction: FC (tree256 dot products) + bias + L2 normalise (layers.py:98-108)
-hipError_t launch_fc_l2(const float* x, const float* wt, const float* bias, float* y_raw, float* out, int frames,
-                        int n_in, int n_out, hipStream_t s);
+// dimensionality reduction: FC + bias as one MFMA GEMM over the frames of the batch (weights cross HBM once) + L2
+// normalise (layers.py:98-108).  x: [frames][n_in] in the FC slot order (fc_slot_of_logical), pack: FcPack of weights.cpp
+hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* y_raw, float* out, int frames, hipStream_t s);
 
 // ---- kernels_match.hip --------------------------------------------------------------------------
 // S[n1 x n2] = D1 * D2^T, fused multiply-add chain over k = 0..dim-1 (Matcher.cc:845-849)

@@ -1,0 +1,925 @@
+// kernels_block.hip -- MobileNetV2 inverted-residual blocks (conv_blocks.py:163-312) as single launches for gfx950:
+// the expanded tensor never leaves the CU.  Also layer_2 (no expansion conv) and stem + layer_2.
+//
+// Numerics: as kernels_conv.hip -- every accumulation is the oracle's fma chain (oracle/hfnet_oracle.h): BatchNorm is
+// folded into the weights, accumulators start at the folded bias, ReLU6 is one v_med3_f32.
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace hfnet {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float relu6f(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f); }
+
+// =========================================================================== fused inverted-residual block
+// conv_blocks.py:163-312 in ONE launch: [1x1 expand + BN + ReLU6] -> depthwise 3x3 + BN + ReLU6 ->
+// 1x1 project + BN [+ input].  The expanded tensor (6x the block input, written and read twice by the
+// unfused chain) never leaves the CU: per 32-channel chunk of the expansion
+//   stage 1  MFMA: expand the (TH*s+2) x (TW*s+2) halo tile of the input into LDS (out-of-image halo = 0,
+//            which is what 'SAME' padding of the depthwise conv sees)
+//   stage 2  VALU: depthwise 3x3 from LDS to LDS
+//   stage 3  MFMA: accumulate the chunk into the projection (k-order = expansion channel order, chunks in
+//            order, so the chain is the oracle's)
+// Algorithmic HBM traffic per block drops from in + 4*expanded + out to in*(halo) + out.
+struct FusedArgs {
+    const float* X;
+    const f32x4* Wex; const float* ex_bias; int ex_nt_total;     // BatchNorm folded (weights.cpp): accumulators start at the bias
+    const float* Wdw; const float* dw_bias;
+    const f32x4* Wpr; const float* pr_bias; int pr_nt_total;
+    float* out;
+    int cin, cexp, cout, residual, has_expand;
+};
+
+
+// ---- v2 of the fused block for the shapes of the high-resolution layers (cin = 8*KQT known at
+// compile time).  Differences to the generic kernel above:
+//  * the expanded halo tile is kept channel-major in LDS (ET[channel][padded position]); the MFMA
+//    D fragment (lane = channel, 4 consecutive rows per register quad) goes out as ds_write_b128;
+//  * the depthwise stage runs one thread per (channel, output row): three input rows are read once as
+//    16-byte LDS loads and slide along x in registers; the 9 taps + BN live in registers per chunk;
+//  * the block input (A fragments of every halo M-tile of the wave) is loaded once and stays in
+//    registers across chunks; the chunk's expand weights are loaded once per chunk, not per M-tile.
+struct TileSplit { int first[4], count[4], maxc; };
+// halo M-tiles per MFMA wave: the split that minimises the largest per-wave MFMA count (stage-1 MFMAs + the
+// stage-3 MFMAs of the waves that own an output tile); ties go to the smaller register footprint (max tiles per wave)
+constexpr TileSplit split_tiles(int mt_in, int mt_out, int c1, int c3) {
+    TileSplit sp{};
+    long best = -1;
+    for (int n0 = 0; n0 <= mt_in; ++n0)
+        for (int n1 = 0; n0 + n1 <= mt_in; ++n1)
+            for (int n2 = 0; n0 + n1 + n2 <= mt_in; ++n2) {
+                const int cnt[4] = {n0, n1, n2, mt_in - n0 - n1 - n2};
+                int maxload = 0, maxc = 0;
+                long sq = 0;
+                for (int w = 0; w < 4; ++w) {
+                    const int load = cnt[w] * c1 + (w < mt_out ? c3 : 0);
+                    if (load > maxload) maxload = load;
+                    if (cnt[w] > maxc) maxc = cnt[w];
+                    sq += (long)load * load;
+                }
+                const long key = ((long)maxload * 64 + maxc) * 1000000 + sq;
+                if (best < 0 || key < best) {
+                    best = key;
+                    for (int w = 0; w < 4; ++w) sp.count[w] = cnt[w];
+                    sp.maxc = maxc;
+                }
+            }
+    int f = 0;
+    for (int w = 0; w < 4; ++w) { sp.first[w] = f; f += sp.count[w]; }
+    return sp;
+}
+
+// workgroups per CU the register budget is tuned for: three where the LDS tile allows it (f32 MFMA and VALU work
+// share one issue pipe, so more resident waves is what hides the LDS / barrier latencies).  "Diet": the widest
+// high-resolution block does not keep its input fragments and projection weights in registers across the chunk
+// loop (236 VGPRs, 2 workgroups per CU) but re-reads them from L1 / L2 when they are used (<= 168, 3 workgroups).
+template <int STRIDE, int NTO, int KQT, int TW>
+constexpr bool fused2_diet() { return (STRIDE == 1 && (KQT >= 6 || NTO >= 2)) || KQT >= 12; }    // layers 6, 7, 8, 9-14
+template <int STRIDE, int NTO, int KQT, int TW>
+constexpr int fused2_min_blocks() {
+    return (STRIDE == 2 && TW == 8) || (STRIDE == 1 && KQT <= 3 && NTO == 1) || fused2_diet<STRIDE, NTO, KQT, TW>() ? 3 : 2;
+}
+
+template <int STRIDE, int NTO, int KQT, bool HAS_EXPAND, int TW>
+__global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) void k_block_fused2(FusedArgs a, Geom g) {
+    constexpr int TH = 8;
+    // halo rows are stored back to back; an even row length keeps the depthwise stage's row reads 8-byte aligned
+    // (odd widths get one padding column: fewer halo M-tiles than padding to a multiple of 4)
+    constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3, IWP = (IW + 1) / 2 * 2, NPOS = IH * IWP;
+    constexpr int MT_IN = (NPOS + 31) / 32, OPIX = TH * TW, MT_OUT = OPIX / 32, CEP = 36;
+    constexpr int EP = ((MT_IN * 32 / 4) % 2 == 1) ? MT_IN * 32 : MT_IN * 32 + 4;   // per-channel stride, EP/4 odd
+    // halo M-tiles per wave.  Stage 3 of chunk c runs in the same barrier phase as stage 1 of chunk c+1
+    // (see the loop), and only waves < MT_OUT have stage-3 work, so those waves own fewer halo tiles.
+    constexpr TileSplit SP = split_tiles(MT_IN, MT_OUT, KQT * 4, NTO * 16);
+    constexpr int MTC0 = SP.count[0], MTC1 = SP.count[1], MTC2 = SP.count[2], MTC3 = SP.count[3], MTW = SP.maxc;
+    static_assert(MTC0 + MTC1 + MTC2 + MTC3 == MT_IN && MTW <= 5, "halo tile distribution");
+    __shared__ __attribute__((aligned(16))) float ET[32 * EP];
+    __shared__ __attribute__((aligned(16))) float D[OPIX * CEP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
+    const int mt_first = wave == 0 ? 0 : wave == 1 ? MTC0 : wave == 2 ? MTC0 + MTC1 : MTC0 + MTC1 + MTC2;
+    int mt_count = wave == 0 ? MTC0 : wave == 1 ? MTC1 : wave == 2 ? MTC2 : MTC3;
+    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
+    const LevelGeom lv = g.lv[level];
+    const int tiles_x = (lv.Wo + TW - 1) / TW, tiles_y = (lv.Ho + TH - 1) / TH;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int oy0 = tyi * TH, ox0 = txi * TW;
+    const int iy0 = oy0 * STRIDE - lv.pt, ix0 = ox0 * STRIDE - lv.pl;
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= lv.H && ix0 + IW <= lv.W;
+    // Tiles hanging over the bottom edge (the pyramid levels are not multiples of the tile height: up to 30 % of a level's
+    // tile area at 1/8 resolution): halo M-tiles below the last needed input row, depthwise rows and projection M-tiles
+    // below the last output row are skipped.  Skipped regions of ET / D keep stale values that only ever feed rows of
+    // MFMA tiles which are never stored (a row of A only affects the same row of D).
+    const int rows_valid = min(TH, lv.Ho - oy0);                               // uniform, >= 1
+    {
+        const int hy_max = (rows_valid - 1) * STRIDE + 2;                      // last halo row any valid output row reads
+        const int n_live = ((hy_max + 1) * IWP + 31) >> 5;                     // halo M-tiles covering positions < (hy_max + 1) * IWP
+        mt_count = max(0, min(mt_count, n_live - mt_first));
+    }
+    const bool out_live = wave < MT_OUT && (wave * 32) / TW < rows_valid;      // this wave's projection tile has a valid row
+    const long long in_base = lv.in_off + (long long)frame * lv.H * lv.W;
+    const long long out_base = lv.out_off + (long long)frame * lv.Ho * lv.Wo;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x16 pacc[NTO];
+#pragma unroll
+    for (int nt = 0; nt < NTO; ++nt) {
+        const float pb = a.pr_bias[nt * 32 + r];                   // (zero padded to pr_nt_total * 32)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pacc[nt][i] = pb;
+    }
+    // A fragments of this wave's halo M-tiles: kept for all chunks, or (diet) only their addresses
+    constexpr int KQA = HAS_EXPAND ? KQT : 1;
+    constexpr bool DIET = HAS_EXPAND && fused2_diet<STRIDE, NTO, KQT, TW>();
+    f32x4 afrag[DIET ? 1 : MTW][KQA];
+    const float* aptr[MTW];
+    bool aok[MTW];
+    if (HAS_EXPAND) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const int mt = mt_first + m;
+            const int pp = mt * 32 + r;
+            const int hy = pp / IWP, hx = pp - hy * IWP;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool ok = m < mt_count && hy < IH && hx < IW && iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W;
+            const float* ap = a.X + (in_base + (long long)(ok ? iy * lv.W + ix : 0)) * a.cin + half * 4;
+            aptr[m] = ap; aok[m] = ok;
+            if (!DIET) {
+#pragma unroll
+                for (int kq = 0; kq < KQA; ++kq) afrag[m][kq] = ok ? *(const f32x4*)(ap + kq * 8) : zero4;
+            }
+        }
+    }
+    const int dc = threadIdx.x & 31, doy = threadIdx.x >> 5;      // depthwise role: channel lane, output row
+    const int n_chunks_all = HAS_EXPAND ? a.ex_nt_total : 1;
+    const int n_chunks = min(n_chunks_all, (a.cexp + 31) >> 5);   // skip all-padding column tiles
+
+    // ---- stage 1 of one chunk: expansion of the halo tile -> ET (channel-major)
+    // expansion weights / BN of a chunk.  With few input channels (KQT <= 3) the next chunk's set is prefetched a whole
+    // phase ahead (an L2 hit takes 0.7-1 us here, a phase is 1-2 us); the wide layers have no registers to spare.
+    constexpr bool PREFETCH_B = false;    // measured on L03-L06: no gain (the other resident workgroups already cover the wait)
+    f32x4 bpre[KQA];
+    float shpre = 0.f;
+    auto fetch_b = [&](int chunk) {
+#pragma unroll
+        for (int kq = 0; kq < KQA; ++kq) bpre[kq] = a.Wex[((size_t)kq * a.ex_nt_total + chunk) * 64 + lane];
+        shpre = a.ex_bias[chunk * 32 + r];
+    };
+    auto stage1 = [&](int chunk) {
+        if (HAS_EXPAND) {
+            if (!PREFETCH_B) fetch_b(chunk);
+            f32x4 bfrag[KQA];
+#pragma unroll
+            for (int kq = 0; kq < KQA; ++kq) bfrag[kq] = bpre[kq];
+            f32x16 bias16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bias16[i] = shpre;
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                if (m < mt_count) {
+                    const int mt = mt_first + m;
+                    f32x4 af[KQA];
+#pragma unroll
+                    for (int kq = 0; kq < KQA; ++kq) {
+                        if (DIET) { const f32x4 v = *(const f32x4*)(aptr[m] + kq * 8); af[kq] = aok[m] ? v : zero4; }
+                        else af[kq] = afrag[m][kq];
+                    }
+                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][0], bfrag[0][0], bias16, 0, 0, 0);
+#pragma unroll
+                    for (int kq = 0; kq < KQA; ++kq)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (kq + t > 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kq][t], bfrag[kq][t], acc, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int pp = mt * 32 + 8 * q + 4 * half;
+                        f32x4 v;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = relu6f(acc[4 * q + i]);
+                        *(f32x4*)(ET + r * EP + pp) = v;        // border tiles: out-of-image positions are zeroed by zero_border()
+                    }
+                }
+            }
+        } else {
+            // no expansion conv: the block input itself is the depthwise input
+            for (int idx = threadIdx.x; idx < NPOS * 8; idx += 256) {
+                const int pp = idx >> 3, c4 = idx & 7;
+                const int hy = pp / IWP, hx = pp - hy * IWP;
+                const int iy = iy0 + hy, ix = ix0 + hx;
+                f32x4 v = zero4;
+                if (c4 * 4 < a.cexp && hx < IW && iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W)
+                    v = *(const f32x4*)(a.X + (in_base + (long long)iy * lv.W + ix) * a.cin + c4 * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ET[(c4 * 4 + j) * EP + pp] = v[j];
+            }
+        }
+    };
+
+    // tiles that touch the image border: the expansion of an out-of-image halo position must be 0 (the
+    // depthwise conv's 'SAME' padding), not relu6(shift).  Kept out of the MFMA epilogue: one extra pass + barrier,
+    // executed only by border workgroups.
+    auto zero_border = [&]() {
+        __syncthreads();
+        for (int pp = threadIdx.x; pp < NPOS; pp += 256) {
+            const int hy = pp / IWP, hx = pp - hy * IWP;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            if (iy < 0 || iy >= lv.H || ix < 0 || ix >= lv.W)
+                for (int c = 0; c < 32; ++c) ET[c * EP + pp] = 0.0f;
+        }
+    };
+
+    if (PREFETCH_B) fetch_b(0);
+    stage1(0);
+    if (HAS_EXPAND && !interior) zero_border();
+    __syncthreads();
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int ch0 = chunk * 32;
+        if (PREFETCH_B && chunk + 1 < n_chunks) fetch_b(chunk + 1);
+        // depthwise taps / BN of this thread's channel and the projection weights of this chunk
+        const int dch = ch0 + dc;
+        const bool dact = dch < a.cexp;
+        float dwt[9], dsh = 0.f;
+        if (dact) {
+            const float* wdp = a.Wdw + dch;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) dwt[t] = wdp[t * a.cexp];
+            dsh = a.dw_bias[dch];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) dwt[t] = 0.f;
+        }
+        const int kqc = min(4, (a.cexp - ch0) >> 3);
+        f32x4 pfrag[4][NTO];
+        auto fetch_p = [&]() {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt)
+                    pfrag[kq][nt] = kq < kqc ? a.Wpr[((size_t)(chunk * 4 + kq) * a.pr_nt_total + nt) * 64 + lane] : zero4;
+        };
+        if (out_live && !DIET) fetch_p();
+        // ---- stage 2: thread = (channel dc, output row doy), ET -> D
+        if (doy < rows_valid) {
+            float row[3][IWP];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* rp = ET + dc * EP + (doy * STRIDE + ky) * IWP;
+                if constexpr (IWP % 4 == 0) {
+#pragma unroll
+                    for (int qx = 0; qx < IWP / 4; ++qx) {
+                        const f32x4 v = *(const f32x4*)(rp + qx * 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) row[ky][qx * 4 + j] = v[j];
+                    }
+                } else {
+#pragma unroll
+                    for (int qx = 0; qx < IWP / 2; ++qx) {
+                        const float2 v = *(const float2*)(rp + qx * 2);
+                        row[ky][qx * 2] = v.x; row[ky][qx * 2 + 1] = v.y;
+                    }
+                }
+            }
+#pragma unroll
+            for (int ox = 0; ox < TW; ++ox) {
+                float acc = dsh;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc = fmaf(row[ky][ox * STRIDE + kx], dwt[ky * 3 + kx], acc);
+                D[(doy * TW + ox) * CEP + dc] = relu6f(acc);    // inactive channel: taps and bias are all 0 -> 0
+            }
+        }
+        __syncthreads();          // D complete, ET free
+        // ---- stage 3 of this chunk (reads D) and stage 1 of the next one (writes ET) share this phase
+        if (out_live) {
+            if (DIET) fetch_p();
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                if (kq < kqc) {
+                    const f32x4 av = *(const f32x4*)(D + (wave * 32 + r) * CEP + kq * 8 + half * 4);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], pfrag[kq][nt][t], pacc[nt], 0, 0, 0);
+                }
+            }
+        }
+        if (chunk + 1 < n_chunks) {
+            stage1(chunk + 1);
+            if (HAS_EXPAND && !interior) zero_border();
+        }
+        __syncthreads();          // ET complete, D free
+    }
+    if (out_live) {
+        float* obase = a.out + out_base * a.cout;                      // uniform
+        const float* rbase = a.X + in_base * a.cin;                    // uniform (residual: same spatial size, cin == cout)
+        const bool full = oy0 + TH <= lv.Ho && ox0 + TW <= lv.Wo;
+        if constexpr ((TW & (TW - 1)) == 0) {
+            // TW a power of two: register reg of the D fragment is tile row (wave*32 + c) / TW, column 4*half + c % TW with
+            // c = (reg & 3) + 8 * (reg >> 2) -- the row does not depend on the lane.  One per-lane byte offset, the per-register
+            // part is scalar; partial tiles check the row with a scalar compare and the column per lane.
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            const int oyb = oy0 + (wv * 32) / TW, oxl = ox0 + 4 * half;
+            const unsigned cout4 = (unsigned)a.cout * 4u;
+#pragma unroll
+            for (int nt = 0; nt < NTO; ++nt) {
+                const int col = nt * 32 + r;
+                if (col < a.cout) {
+                    const unsigned lane_off = (unsigned)(oyb * lv.Wo + oxl) * cout4 + (unsigned)col * 4u;
+                    float rv[16];
+                    if (a.residual) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            constexpr int dummy = 0; (void)dummy;
+                            const int c = (reg & 3) + 8 * (reg >> 2), ry = c / TW, rx = c % TW;
+                            const bool ok = full || (oyb + ry < lv.Ho && oxl + rx < lv.Wo);
+                            rv[reg] = ok ? *(const float*)((const char*)rbase + lane_off + (unsigned)(ry * lv.Wo + rx) * cout4) : 0.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int c = (reg & 3) + 8 * (reg >> 2), ry = c / TW, rx = c % TW;
+                        if (full || (oyb + ry < lv.Ho && oxl + rx < lv.Wo)) {
+                            float v = pacc[nt][reg];
+                            if (a.residual) v = v + rv[reg];
+                            *(float*)((char*)obase + lane_off + (unsigned)(ry * lv.Wo + rx) * cout4) = v;
+                        }
+                    }
+                }
+            }
+        } else {
+            // op = wave*32 + (reg&3) + 8*(reg>>2) + 4*half  ->  (oy, ox)
+            const int opl = wave * 32 + 4 * half;
+#pragma unroll
+            for (int nt = 0; nt < NTO; ++nt) {
+                const int col = nt * 32 + r;
+                if (col < a.cout) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int op = opl + (reg & 3) + 8 * (reg >> 2);
+                        const int oy = oy0 + op / TW, ox = ox0 + op % TW;
+                        if (full || (oy < lv.Ho && ox < lv.Wo)) {
+                            const int off = (oy * lv.Wo + ox) * a.cout + col;
+                            float v = pacc[nt][reg];
+                            if (a.residual) v = v + rbase[off];
+                            obase[off] = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int STRIDE, int NTO, int KQT, bool HAS_EXPAND, int TW = (STRIDE == 1 ? 16 : 8)>
+static hipError_t launch_block_fused2_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
+    constexpr int TH = 8;
+    int maxtiles = 0;
+    for (int l = 0; l < g.n_levels; ++l) maxtiles = max(maxtiles, ((g.lv[l].Wo + TW - 1) / TW) * ((g.lv[l].Ho + TH - 1) / TH));
+    dim3 grid(maxtiles, g.n_levels * g.batch);
+    hipLaunchKernelGGL((k_block_fused2<STRIDE, NTO, KQT, HAS_EXPAND, TW>), grid, dim3(256), 0, s, a, g);
+    return hipGetLastError();
+}
+
+// ---- v4 of the fused block: wave-autonomous tiles, no workgroup barriers.
+// Every wave owns a 4 x 8 output tile of one image and runs all three stages on it by itself, per 32-channel chunk of
+// the expansion:
+//   expand   (MFMA)  the (3 s + 3) x (7 s + 3) halo positions of the tile as M-tiles of 32 positions (s1: 60 -> 2 tiles,
+//                    s2: 153 -> 5 tiles), chained from the folded bias, ReLU6, ds_write_b128 into the wave's own LDS slice
+//                    (channel-major ET[channel][position])
+//   depthwise (VALU) lane = (channel, half of the output rows): the input rows are read once as 16-byte LDS loads, 16
+//                    outputs per lane, written back over the same slice as D[pixel][channel] (LDS operations of one wave
+//                    execute in order: all reads are issued before the first write)
+//   project  (MFMA)  A fragments from D, accumulate into the tile's 32 x (NTO*32) accumulators (k order = expansion channel
+//                    order: the oracle's chain)
+// f32 MFMA and VALU instructions share one issue port per SIMD, so what counts is that the port never
+// idles: v2 synchronises its four waves twice per chunk and its phases are too short to hide their start-up latencies
+// (measured: stage times add up exactly, expansion at 42 % of its MFMA rate).  Here nothing couples the 2-3 waves of a
+// SIMD, so one wave's LDS round trips, weight fetches and VALU stretches are covered by the others' MFMA chains.  Price:
+// the halo of a 32-pixel tile is relatively larger (stride 1: 2.0 instead of 1.5 expansion rows per output pixel).
+// The tile's input fragments stay in registers for all chunks; weights come from L1 / L2 one phase ahead.
+template <int S> struct F4Geo {
+    static constexpr int TH = 4, TW = 8, IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, NPOS = IH * IW, MT_IN = (NPOS + 31) / 32;
+    static constexpr int EP = MT_IN * 32 + 4;        // channel stride of ET in floats: EP / 4 odd -> conflict-free 16-byte accesses
+    static constexpr int CEP = 36;                    // pixel stride of D
+    static_assert((EP / 4) % 2 == 1, "ET channel stride");
+};
+
+template <int STRIDE, int NTO, int KQT, bool RES, int OCC, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
+    using G = F4Geo<STRIDE>;
+    constexpr int TH = G::TH, TW = G::TW, IH = G::IH, IW = G::IW, NPOS = G::NPOS, MT_IN = G::MT_IN, EP = G::EP, CEP = G::CEP;
+    __shared__ __attribute__((aligned(16))) float lds_all[WAVES][32 * EP];
+    const int lane = threadIdx.x & 63, half = lane >> 5, r = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* const ET = lds_all[wave];
+    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
+    const LevelGeom lv = g.lv[level];
+    const int tiles_x = (lv.Wo + TW - 1) / TW, ntiles = tiles_x * ((lv.Ho + TH - 1) / TH);
+    // workgroup b runs on XCD b % 8 (observed; speed only): every XCD gets one contiguous run of THIS image's tiles (an
+    // eighth of them: the pyramid levels differ in size, the grid is sized for the largest), so that the halo rows shared
+    // by vertical neighbours meet in one L2 and every XCD carries the same load
+    const int nwg = (ntiles + WAVES - 1) / WAVES, q = nwg >> 3, rem = nwg & 7;
+    const int xr = (blockIdx.x + image) & 7, slot = blockIdx.x >> 3;  // (the XCDs that take the remainder rotate with the image)
+    if (slot >= q + (xr < rem ? 1 : 0)) return;
+    const int wg = xr * q + min(xr, rem) + slot;
+    const int tile = wg * WAVES + wave;
+    if (tile >= ntiles) return;                                    // (no workgroup barriers anywhere below)
+    const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int oy0 = tyi * TH, ox0 = txi * TW;
+    const int iy0 = oy0 * STRIDE - lv.pt, ix0 = ox0 * STRIDE - lv.pl;
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= lv.H && ix0 + IW <= lv.W;
+    const long long in_base = lv.in_off + (long long)frame * lv.H * lv.W;
+    const long long out_base = lv.out_off + (long long)frame * lv.Ho * lv.Wo;
+    const char* __restrict__ xb = (const char*)(a.X + in_base * a.cin);      // uniform; lane offsets are 32-bit (one image < 4 GB)
+
+    // ---- block input: A fragments of the halo M-tiles (out-of-image / padding positions read a clamped pixel: a row of A
+    //      only feeds the same row of the expansion, and those rows are zeroed below or never read)
+    f32x4 afrag[MT_IN][KQT];
+#pragma unroll
+    for (int m = 0; m < MT_IN; ++m) {
+        const int pp = m * 32 + r;
+        const int hy = pp / IW, hx = pp - hy * IW;
+        const int iy = min(max(iy0 + hy, 0), lv.H - 1), ix = min(max(ix0 + hx, 0), lv.W - 1);
+        const unsigned off = ((unsigned)(iy * lv.W + ix) * (unsigned)a.cin + (unsigned)(half * 4)) * 4u;
+#pragma unroll
+        for (int kq = 0; kq < KQT; ++kq) afrag[m][kq] = *(const f32x4*)(xb + off + kq * 32);
+    }
+    // out-of-image halo positions (the depthwise conv's 'SAME' zero padding): one bit per position, border tiles only
+    unsigned long long outside[(NPOS + 63) / 64] = {};
+    if (!interior) {
+#pragma unroll
+        for (int pp = 0; pp < NPOS; ++pp) {
+            const int hy = pp / IW, hx = pp - hy * IW;
+            if (iy0 + hy < 0 || iy0 + hy >= lv.H || ix0 + hx < 0 || ix0 + hx >= lv.W) outside[pp >> 6] |= 1ull << (pp & 63);
+        }
+    }
+    f32x16 pacc[NTO];
+#pragma unroll
+    for (int nt = 0; nt < NTO; ++nt) {
+        const float pb = a.pr_bias[nt * 32 + r];                   // (zero padded to pr_nt_total * 32)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pacc[nt][i] = pb;
+    }
+    const int n_chunks = min(a.ex_nt_total, (a.cexp + 31) >> 5);  // skip all-padding column tiles
+    f32x4 bfrag[KQT];
+    float ebias;
+    auto load_b = [&](int chunk) {
+#pragma unroll
+        for (int kq = 0; kq < KQT; ++kq) bfrag[kq] = a.Wex[((size_t)kq * a.ex_nt_total + chunk) * 64 + lane];
+        ebias = a.ex_bias[chunk * 32 + r];
+    };
+    load_b(0);
+    const int rh = half;                                           // depthwise role: channel r, output rows 2 rh, 2 rh + 1
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int ch0 = chunk * 32;
+        const int kqc = min(4, (a.cexp - ch0) >> 3);               // (channels past cexp are never consumed: clamp, do not zero)
+        // this chunk's projection weights and depthwise taps: requested now, used after the expansion
+        f32x4 pfrag[4][NTO];
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+            for (int nt = 0; nt < NTO; ++nt) pfrag[kq][nt] = a.Wpr[((size_t)(chunk * 4 + min(kq, kqc - 1)) * a.pr_nt_total + nt) * 64 + lane];
+        const int dch = min(ch0 + r, a.cexp - 1);
+        float dwt[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dwt[t] = a.Wdw[t * a.cexp + dch];
+        const float dwb = a.dw_bias[dch];
+        // ---- expansion
+        {
+            f32x16 bias16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bias16[i] = ebias;
+#pragma unroll
+            for (int m = 0; m < MT_IN; ++m) {
+                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][0][0], bfrag[0][0], bias16, 0, 0, 0);
+#pragma unroll
+                for (int kq = 0; kq < KQT; ++kq)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (kq + t > 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][kq][t], bfrag[kq][t], acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = relu6f(acc[4 * q + i]);
+                    *(f32x4*)(ET + r * EP + m * 32 + 8 * q + 4 * half) = v;
+                }
+            }
+        }
+        if (!interior) {
+#pragma unroll
+            for (int wd = 0; wd < (NPOS + 63) / 64; ++wd) {
+                unsigned long long msk = outside[wd];                                  // uniform
+                while (msk) {
+                    const int pp = wd * 64 + (int)__builtin_ctzll(msk);
+                    msk &= msk - 1;
+                    if (half == 0) ET[r * EP + pp] = 0.0f;
+                }
+            }
+        }
+        if (chunk + 1 < n_chunks) load_b(chunk + 1);               // next chunk's expansion weights: a whole phase ahead
+        asm volatile("" ::: "memory");
+        // ---- depthwise: channel r, output rows 2 rh and 2 rh + 1 (input rows 2 rh s .. 2 rh s + s + 2)
+        {
+            constexpr int NR = STRIDE + 3;                         // input rows for two output rows
+            float row[NR][IW];
+            const float* rp = ET + r * EP + rh * 2 * STRIDE * IW;
+            if constexpr ((NR * IW) % 4 == 0 && (2 * STRIDE * IW) % 4 == 0) {
+#pragma unroll
+                for (int qx = 0; qx < NR * IW / 4; ++qx) {
+                    const f32x4 v = *(const f32x4*)(rp + qx * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) row[(qx * 4 + j) / IW][(qx * 4 + j) % IW] = v[j];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NR * IW; ++i) row[i / IW][i % IW] = rp[i];
+            }
+            float o[2][TW];
+#pragma unroll
+            for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+                for (int ox = 0; ox < TW; ++ox) {
+                    float acc = dwb;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) acc = fmaf(row[ro * STRIDE + ky][ox * STRIDE + kx], dwt[ky * 3 + kx], acc);
+                    o[ro][ox] = relu6f(acc);
+                }
+            asm volatile("" ::: "memory");                         // every ET read is issued before D overwrites the slice
+#pragma unroll
+            for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+                for (int ox = 0; ox < TW; ++ox) ET[((rh * 2 + ro) * TW + ox) * CEP + r] = o[ro][ox];
+        }
+        asm volatile("" ::: "memory");
+        // ---- projection of this chunk's channels
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            if (kq < kqc) {
+                const f32x4 av = *(const f32x4*)(ET + r * CEP + kq * 8 + half * 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], pfrag[kq][nt][t], pacc[nt], 0, 0, 0);
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    // ---- output (+ residual): every 32-column tile goes through the LDS slice so that a lane moves 16 consecutive bytes
+    float* __restrict__ ob = a.out + out_base * a.cout;                                // uniform
+    const float* __restrict__ rb = a.X + in_base * a.cin;                              // residual: same size, cin == cout
+#pragma unroll
+    for (int nt = 0; nt < NTO; ++nt) {
+        if (nt * 32 < a.cout) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) ET[((reg & 3) + 8 * (reg >> 2) + 4 * half) * CEP + r] = pacc[nt][reg];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int piece = lane + 64 * k, px = piece >> 3, c4 = piece & 7;
+                const int col = nt * 32 + c4 * 4;
+                const int oy = oy0 + px / TW, ox = ox0 + px % TW;
+                f32x4 v = *(const f32x4*)(ET + px * CEP + c4 * 4);
+                if (col < a.cout && oy < lv.Ho && ox < lv.Wo) {
+                    const unsigned off = (unsigned)(oy * lv.Wo + ox) * (unsigned)a.cout + (unsigned)col;
+                    if (RES) {
+                        const f32x4 rv = *(const f32x4*)(rb + off);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] + rv[j];
+                    }
+                    *(f32x4*)(ob + off) = v;
+                }
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+}
+
+template <int STRIDE, int NTO, int KQT, int OCC, int WAVES = 4>
+static hipError_t launch_block_fused4_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
+    using G = F4Geo<STRIDE>;
+    if (a.residual && (STRIDE != 1 || a.cin != a.cout)) return hipErrorInvalidValue;
+    int maxtiles = 0;
+    for (int l = 0; l < g.n_levels; ++l) maxtiles = max(maxtiles, ((g.lv[l].Wo + G::TW - 1) / G::TW) * ((g.lv[l].Ho + G::TH - 1) / G::TH));
+    const int wgs = (((maxtiles + WAVES - 1) / WAVES + 7) / 8) * 8;  // multiple of 8: see the XCD mapping in the kernel
+    dim3 grid(wgs, g.n_levels * g.batch);
+    if (a.residual) hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, true, OCC, WAVES>), grid, dim3(WAVES * 64), 0, s, a, g);
+    else hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, false, OCC, WAVES>), grid, dim3(WAVES * 64), 0, s, a, g);
+    return hipGetLastError();
+}
+
+// ---- layer_2 (expanded_conv with expansion factor 1: no expand conv, hf_net.py:31-33): depthwise 3x3 + BN + ReLU6 on
+// CIN channels, then the 1x1 projection CIN -> COUT + BN, stride 1.  Its tensors are the largest of the network (1/2
+// resolution) and its arithmetic the smallest: one thread per output pixel of a 16 x 16 tile on the vector ALUs, the
+// fma chain over the CIN depthwise outputs in logical channel order (the oracle's), 16-byte fully coalesced stores.
+//
+// Shared tail of k_block_noexpand and k_stem_block2: `tile` holds the (T+2)^2 halo tile of the block input, CP floats per
+// position (out-of-image positions are zeros: fma(0, w, d) == d, the oracle skips those taps).  The weights are
+// wave-uniform scalar loads with compile-time offsets (SGPR fma operands).  Left alone, the scheduler hoists all ~650 of
+// them to the top and spills them to VGPR lanes (v_writelane / v_readlane: more VALU work than the convolution itself), so
+// they are fetched one step ahead of their use and scheduling barriers keep each batch where it is.
+template <int CIN, int COUT, int T>
+__device__ __forceinline__ void dw_project_tail(const float* tile, int ty, int tx, const float* __restrict__ wd /*[9][CIN] phys, BN folded*/,
+                                                const float* __restrict__ dbias, const float* __restrict__ wp /*[CIN logical][COUT phys], BN folded*/,
+                                                const float* __restrict__ pbias, float (&acc)[COUT]) {
+    constexpr int SH = T + 2, CP = CIN + 4;
+    float d[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) d[c] = dbias[c];         // accumulators start at the folded bias
+    float wc[CIN], wn[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) wc[c] = wd[c];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        if (tap < 8) {
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) wn[c] = wd[(tap + 1) * CIN + c];
+        }
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+        const float* xp = tile + ((ty + tap / 3) * SH + tx + tap % 3) * CP;
+#pragma unroll
+        for (int c4 = 0; c4 < CIN / 4; ++c4) {
+            const f32x4 xv = *(const f32x4*)(xp + c4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[c4 * 4 + j] = fmaf(xv[j], wc[c4 * 4 + j], d[c4 * 4 + j]);
+        }
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+        if (tap < 8) {
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) wc[c] = wn[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) d[c] = relu6f(d[c]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < COUT; ++n) acc[n] = pbias[n];
+    float pc[COUT], pn[COUT];
+#pragma unroll
+    for (int n = 0; n < COUT; ++n) pc[n] = wp[n];
+#pragma unroll
+    for (int k = 0; k < CIN; ++k) {                       // logical channel k sits in physical slot phys(k)
+        if (k + 1 < CIN) {
+#pragma unroll
+            for (int n = 0; n < COUT; ++n) pn[n] = wp[(k + 1) * COUT + n];
+        }
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+        const int pk = (k & ~7) | ((k & 1) << 2) | ((k & 7) >> 1);
+        const float dk = d[pk];
+#pragma unroll
+        for (int n = 0; n < COUT; ++n) acc[n] = fmaf(dk, pc[n], acc[n]);
+        // pin this row's fmas here (pure arithmetic is not ordered by the barriers: the DAG scheduler would sink all of
+        // it below the last load and every row would be spilled in between)
+        static_assert(COUT == 16, "accumulator pinning is written for 16 outputs");
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+                          "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 1 < CIN) {
+#pragma unroll
+            for (int n = 0; n < COUT; ++n) pc[n] = pn[n];
+        }
+    }
+}
+
+// output of a 16 x 16 tile through LDS: a tile row is T pixels x COUT channels = one contiguous 1 KB run of the output
+// tensor; written back as consecutive 16-byte pieces per lane instead of four 64-byte-strided stores per thread
+template <int COUT, int T>
+__device__ __forceinline__ void store_tile_via_lds(float* tile, const float (&acc)[COUT], float* __restrict__ obase, int oy0, int ox0, int Ho, int Wo) {
+    constexpr int OP = COUT + 4;                           // 20 words: conflict-free b128
+    __syncthreads();                                       // every thread is done reading the input tile
+#pragma unroll
+    for (int n4 = 0; n4 < COUT / 4; ++n4) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[n4 * 4 + j];
+        *(f32x4*)(tile + threadIdx.x * OP + n4 * 4) = v;
+    }
+    __syncthreads();
+    const int cols = min(T, Wo - ox0);                     // valid pixels per tile row
+#pragma unroll
+    for (int k = 0; k < COUT / 4; ++k) {
+        const int q = threadIdx.x + k * 256;               // piece of the tile: row = q / (T * COUT / 4)
+        const int row = q / (T * COUT / 4), rem = q - row * (T * COUT / 4);
+        const int px = rem / (COUT / 4), part = rem - px * (COUT / 4);
+        if (oy0 + row < Ho && px < cols)
+            *(f32x4*)(obase + ((long long)(oy0 + row) * Wo + ox0 + px) * COUT + part * 4) = *(const f32x4*)(tile + (row * T + px) * OP + part * 4);
+    }
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_block_noexpand(const float* __restrict__ X, float* __restrict__ out, const float* __restrict__ wd,
+                                                        const float* __restrict__ dbias, const float* __restrict__ wp,
+                                                        const float* __restrict__ pbias, Geom g) {
+    // 16x16 output tile per workgroup; the 18x18 input halo tile is staged through LDS with coalesced 96-byte
+    // pixel rows, so every input byte crosses HBM ~1.27x instead of up to 9x.
+    constexpr int T = 16, SH = T + 2, CP = CIN + 4;
+    __shared__ __attribute__((aligned(16))) float tile[SH * SH * CP];
+    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
+    const LevelGeom lv = g.lv[level];
+    const int tiles_x = (lv.Wo + T - 1) / T;
+    if ((int)blockIdx.x >= tiles_x * ((lv.Ho + T - 1) / T)) return;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int oy0 = tyi * T, ox0 = txi * T;
+    const float* xin = X + (lv.in_off + (long long)frame * lv.H * lv.W) * CIN;
+    // a halo row is SH pixels = SH * CIN / 4 consecutive 16-byte pieces in memory: thread = (row parity, piece), so the
+    // piece -> (pixel, channel quad) split is done once per thread and a load costs an add
+    {
+        constexpr int PPR = SH * (CIN / 4);                    // pieces per halo row (108)
+        static_assert(2 * PPR <= 256, "two halo rows per pass");
+        const int rsel = threadIdx.x >= PPR ? 1 : 0, piece = threadIdx.x - rsel * PPR;
+        const int hx = piece / (CIN / 4), c4 = piece - hx * (CIN / 4);
+        const int ix = ox0 - lv.pl + hx;
+        const bool xok = threadIdx.x < 2 * PPR && ix >= 0 && ix < lv.W;
+        const float* colp = xin + (long long)(xok ? ix : 0) * CIN + c4 * 4;
+        float* tp = tile + hx * CP + c4 * 4;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (threadIdx.x < 2 * PPR) {
+#pragma unroll
+            for (int r2 = 0; r2 < SH / 2; ++r2) {
+                const int hy = r2 * 2 + rsel, iy = oy0 - lv.pt + hy;
+                const bool ok = xok && iy >= 0 && iy < lv.H;
+                const f32x4 v = *(const f32x4*)(colp + (long long)(ok ? iy : 0) * lv.W * CIN);
+                *(f32x4*)(tp + hy * SH * CP) = ok ? v : zero;
+            }
+        }
+    }
+    __syncthreads();
+    const int ty = threadIdx.x / T, tx = threadIdx.x - ty * T;
+    float acc[COUT];
+    dw_project_tail<CIN, COUT, T>(tile, ty, tx, wd, dbias, wp, pbias, acc);
+    store_tile_via_lds<COUT, T>(tile, acc, out + (lv.out_off + (long long)frame * lv.Ho * lv.Wo) * COUT, oy0, ox0, lv.Ho, lv.Wo);
+}
+
+// ---- stem + layer_2 in one launch: u8 image -> [(x-128)/128, conv 3x3/2 1->CS, BN, ReLU6] -> depthwise 3x3 +
+// BN + ReLU6 -> 1x1 CS->COUT + BN.  The half-resolution CS-channel stem tensor (the largest activation of the
+// network: 8.7 MB per 752x480 frame, 690 MB per 32-frame step, written by one kernel and read by the next) is produced
+// into LDS for an 18x18 halo tile and consumed from there; only the u8 image is read and the COUT-channel layer_2 output
+// written.  Vector-ALU kernel (K = 9 / 9 / CS), one thread per output pixel of a 16x16 tile; every fma chain is the
+// oracle's.  The stem of the 18 x 18 halo positions comes straight from the u8 image (wave-uniform scalar weights; the
+// 324 positions x 2 channel halves are 12 wave-sized work units, three per wave), the rest is dw_project_tail.
+template <int CS, int COUT>
+__global__ __launch_bounds__(256) void k_stem_block2(ImageSet imgs, const float* __restrict__ stem_w, const float* __restrict__ stem_bias,
+                                                     const float* __restrict__ wd, const float* __restrict__ dbias, const float* __restrict__ wp,
+                                                     const float* __restrict__ pbias, float* __restrict__ out,
+                                                     Geom gs /*image -> stem*/, Geom gb /*stem -> layer_2*/) {
+    constexpr int T = 16, SH = T + 2, SP = SH * SH, CP = CS + 4, CH = CS / 2;
+    static_assert(CS == 24 && COUT == 16, "written for the 0.75-width network");
+    __shared__ __attribute__((aligned(16))) float tile[SP * CP];
+    const int image = blockIdx.y, level = image / gs.batch, frame = image - level * gs.batch;
+    const LevelGeom ls = gs.lv[level], lb = gb.lv[level];     // ls: H,W image (cropped), Ho,Wo stem; lb: H,W stem, Ho,Wo out (same size)
+    const int tiles_x = (lb.Wo + T - 1) / T;
+    if ((int)blockIdx.x >= tiles_x * ((lb.Ho + T - 1) / T)) return;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int oy0 = tyi * T, ox0 = txi * T;
+    const int sy0 = oy0 - lb.pt, sx0 = ox0 - lb.pl;            // first stem row / col of the halo tile
+    const uint8_t* img = imgs.ptr[level] + (long long)frame * imgs.frame_stride[level];
+    const int rs = imgs.row_stride[level];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // ---- stem on the halo tile: unit u = wave + 4 * pass covers positions [54 * (u % 6), +54) and channel half u / 6
+    constexpr int CHUNK = SP / 6;                              // 54 positions per unit
+    static_assert(CHUNK * 6 == SP && CHUNK <= 64, "halo positions split into six wave-sized chunks");
+    // tiles whose halo and image patch lie inside the maps (the vast majority) skip every bounds check and select
+    const int iy_first = sy0 * 2 - ls.pt, ix_first = sx0 * 2 - ls.pl;
+    const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + SH <= ls.Ho && sx0 + SH <= ls.Wo && iy_first >= 0 && ix_first >= 0 &&
+                          iy_first + 2 * SH < ls.H && ix_first + 2 * SH < ls.W;     // uniform
+    auto stem_passes = [&](auto interior_tag) {
+        constexpr bool INT = decltype(interior_tag)::value;
+#pragma unroll 1
+        for (int pass = 0; pass < 3; ++pass) {
+            const int u = wave + 4 * pass, chunk = u % 6, hsel = u / 6;          // uniform
+            const int p = chunk * CHUNK + min(lane, CHUNK - 1);
+            const int hy = p / SH, hx = p - hy * SH;
+            const int sy = sy0 + hy, sx = sx0 + hx;
+            const bool in = INT || (sy >= 0 && sy < ls.Ho && sx >= 0 && sx < ls.Wo);
+            float px[9];
+            if (INT) {
+                const uint8_t* ip = img + (long long)(sy * 2 - ls.pt) * rs + (sx * 2 - ls.pl);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) px[ky * 3 + kx] = ((float)ip[ky * rs + kx] - 128.0f) * 0.0078125f;
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int iy = sy * 2 - ls.pt + ky, ix = sx * 2 - ls.pl + kx;
+                        const bool ok = in && iy >= 0 && iy < ls.H && ix >= 0 && ix < ls.W;
+                        const float raw = (float)img[(long long)(ok ? iy : 0) * rs + (ok ? ix : 0)];
+                        px[ky * 3 + kx] = ok ? (raw - 128.0f) * 0.0078125f : 0.0f;
+                    }
+            }
+            // weights of four channels at a time as wave-uniform 16-byte scalar loads (36 + 4 SGPRs per group: a second set
+            // prefetched ahead does not fit next to the geometry without spilling to VGPR lanes)
+            const f32x4* __restrict__ w4 = (const f32x4*)(stem_w + hsel * CH);    // uniform; row t is w4[t * CS / 4 + group]
+            const f32x4* __restrict__ sh4 = (const f32x4*)(stem_bias + hsel * CH);
+            float* tp = tile + p * CP + hsel * CH;
+#pragma unroll
+            for (int grp = 0; grp < CH / 4; ++grp) {
+                f32x4 wq[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wq[t] = w4[t * (CS / 4) + grp];
+                const f32x4 shq = sh4[grp];
+                asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+                f32x4 r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float acc = shq[j];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc = fmaf(px[t], wq[t][j], acc);
+                    float v = relu6f(acc);
+                    if (!INT) {
+                        asm volatile("" : "+v"(v));                                // computed by every lane: a select, not a branch
+                        v = in ? v : 0.0f;                                         // outside the stem map: the depthwise conv's zero padding
+                    }
+                    r[j] = v;
+                }
+                if (lane < CHUNK) *(f32x4*)(tp + grp * 4) = r;
+                asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    if (interior) stem_passes(std::true_type{}); else stem_passes(std::false_type{});
+    __syncthreads();
+    const int ty = threadIdx.x / T, tx = threadIdx.x - ty * T;
+    float acc[COUT];
+    dw_project_tail<CS, COUT, T>(tile, ty, tx, wd, dbias, wp, pbias, acc);
+    store_tile_via_lds<COUT, T>(tile, acc, out + (lb.out_off + (long long)frame * lb.Ho * lb.Wo) * COUT, oy0, ox0, lb.Ho, lb.Wo);
+}
+
+bool stem_block_fusable(int stem_out, const BlockPack& b) {
+    return stem_out == 24 && !b.has_expand && b.stride == 1 && !b.residual && b.cin == 24 && b.cout == 16 && b.pr_logical != nullptr;
+}
+
+hipError_t launch_stem_block(const ImageSet& imgs, const float* stem_w, const float* stem_bias, const BlockPack& b, float* out, const Geom& g_stem,
+                             const Geom& g_block, hipStream_t s) {
+    int maxtiles = 0;
+    for (int l = 0; l < g_block.n_levels; ++l) maxtiles = max(maxtiles, ((g_block.lv[l].Wo + 15) / 16) * ((g_block.lv[l].Ho + 15) / 16));
+    hipLaunchKernelGGL((k_stem_block2<24, 16>), dim3(maxtiles, g_block.n_levels * g_block.batch), dim3(256), 0, s, imgs, stem_w, stem_bias, b.dw.w,
+                       b.dw.bias, b.pr_logical, b.pr.bias, out, g_stem, g_block);
+    return hipGetLastError();
+}
+
+// the shapes with a fused kernel (the 0.75-width network's; anything else runs as expand / depthwise / project launches)
+enum FusedKind { FUSED_NONE = 0, FUSED_NOEXPAND, FUSED_V4, FUSED_V2 };
+static FusedKind fused_kind(const BlockPack& b, int variant) {
+    const int nto = (b.cout + 31) / 32, kq = b.cin / 8, st = b.stride;
+    if (b.cin % 8 || b.expand % 8) return FUSED_NONE;
+    if (!b.has_expand) return (st == 1 && !b.residual && b.cin == 24 && b.cout == 16 && b.pr_logical) ? FUSED_NOEXPAND : FUSED_NONE;
+    if (b.pr.nt_total != nto) return FUSED_NONE;
+    const bool v2 = (st == 2 && (kq == 2 || kq == 3) && nto == 1) || (st == 2 && kq == 12 && nto == 2) ||
+                    (st == 1 && kq == 3 && nto <= 2) || (st == 1 && kq == 6 && (nto == 2 || nto == 3)) || (st == 1 && kq == 9 && nto == 3);
+    const bool v4 = (st == 1 && kq == 3 && nto <= 2) || (st == 1 && kq == 6 && (nto == 2 || nto == 3)) || (st == 1 && kq == 9 && nto == 3) ||
+                    (st == 2 && (kq == 2 || kq == 3) && nto == 1);
+    if (variant != 2 && v4) return FUSED_V4;
+    return v2 ? FUSED_V2 : FUSED_NONE;
+}
+bool block_fusable(const BlockPack& b, int variant) { return fused_kind(b, variant) != FUSED_NONE; }
+
+hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, const Geom& g, int variant, hipStream_t s) {
+    FusedArgs a;
+    a.X = X;
+    a.Wex = (const f32x4*)b.ex.w; a.ex_bias = b.ex.bias; a.ex_nt_total = b.ex.nt_total;
+    a.Wdw = b.dw.w; a.dw_bias = b.dw.bias;
+    a.Wpr = (const f32x4*)b.pr.w; a.pr_bias = b.pr.bias; a.pr_nt_total = b.pr.nt_total;
+    a.out = out; a.cin = b.cin; a.cexp = b.expand; a.cout = b.cout; a.residual = b.residual; a.has_expand = b.has_expand;
+    const int nto = (b.cout + 31) / 32, kq = b.cin / 8, st = b.stride;
+    switch (fused_kind(b, variant)) {
+        case FUSED_NOEXPAND: {
+            int maxtiles = 0;
+            for (int l = 0; l < g.n_levels; ++l) maxtiles = max(maxtiles, ((g.lv[l].Wo + 15) / 16) * ((g.lv[l].Ho + 15) / 16));
+            hipLaunchKernelGGL((k_block_noexpand<24, 16>), dim3(maxtiles, g.n_levels * g.batch), dim3(256), 0, s, a.X, a.out, a.Wdw, a.dw_bias,
+                               (const float*)b.pr_logical, a.pr_bias, g);
+            return hipGetLastError();
+        }
+        case FUSED_V4:
+            if (st == 1 && kq == 3 && nto == 1) return launch_block_fused4_t<1, 1, 3, 2>(a, g, s);
+            if (st == 1 && kq == 3 && nto == 2) return launch_block_fused4_t<1, 2, 3, 2>(a, g, s);
+            if (st == 1 && kq == 6 && nto == 2) return launch_block_fused4_t<1, 2, 6, 2>(a, g, s);
+            if (st == 1 && kq == 6 && nto == 3) return launch_block_fused4_t<1, 3, 6, 2>(a, g, s);
+            if (st == 1 && kq == 9 && nto == 3) return launch_block_fused4_t<1, 3, 9, 2>(a, g, s);
+            if (st == 2 && kq == 2 && nto == 1) return launch_block_fused4_t<2, 1, 2, 2, 1>(a, g, s);
+            if (st == 2 && kq == 3 && nto == 1) return launch_block_fused4_t<2, 1, 3, 2, 1>(a, g, s);
+            return hipErrorInvalidValue;
+        case FUSED_V2:
+            if (st == 2 && kq == 2 && nto == 1) return launch_block_fused2_t<2, 1, 2, true>(a, g, s);
+            if (st == 1 && kq == 3 && nto == 1) return launch_block_fused2_t<1, 1, 3, true>(a, g, s);
+            if (st == 2 && kq == 3 && nto == 1) return launch_block_fused2_t<2, 1, 3, true>(a, g, s);
+            if (st == 1 && kq == 3 && nto == 2) return launch_block_fused2_t<1, 2, 3, true>(a, g, s);
+            if (st == 1 && kq == 6 && nto == 3) return launch_block_fused2_t<1, 3, 6, true>(a, g, s);
+            if (st == 1 && kq == 6 && nto == 2) return launch_block_fused2_t<1, 2, 6, true>(a, g, s);
+            if (st == 1 && kq == 9 && nto == 3) return launch_block_fused2_t<1, 3, 9, true>(a, g, s);
+            if (st == 2 && kq == 12 && nto == 2) return launch_block_fused2_t<2, 2, 12, true>(a, g, s);
+            return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace hfnet

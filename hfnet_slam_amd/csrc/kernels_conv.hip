@@ -2,15 +2,16 @@
 // convolutions on v_mfma_f32_32x32x2_f32, depthwise 3x3.
 //
 // Numerics: every accumulation is the fused multiply-add chain the oracle defines
-// (oracle/hfnet_oracle.h): the f32 MFMA is bit-for-bit a k-ordered fmaf chain, the vector
-// kernels use explicit fmaf.  Built with -ffp-contract=off.
+// (oracle/hfnet_oracle.h): BatchNorm is folded into the weights on the host (weights.cpp), every
+// accumulator STARTS at the folded bias (the MFMA's C operand) and the f32 MFMA is bit-for-bit a
+// k-ordered fmaf chain; the vector kernels use explicit fmaf.  ReLU6 is one v_med3_f32.
+// Built with -ffp-contract=off.
 //
 // Data layout: activations are [pixel][channel] fp32 with the channels of each group of 8 in the
 // "physical" order of common.hpp, levels and frames concatenated ([level][frame][y][x][c]).
 #include "kernels.hpp"
 
 #include <algorithm>
-#include <cstdlib>
 #include <type_traits>
 
 namespace hfnet {
@@ -18,7 +19,7 @@ namespace hfnet {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
+__device__ __forceinline__ float relu6f(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f); }   // no NaNs on this path
 
 // =========================================================================== pyramid resize
 // OpenCV 4.2 cv::resize(INTER_LINEAR) on CV_8UC1: 11-bit fixed-point coefficients, horizontal pass
@@ -89,12 +90,12 @@ hipError_t launch_resize_u8(const uint8_t* src, int sw, int sh, int s_row, long 
 // =========================================================================== stem
 // u8 -> (x-128)/128 -> crop to multiples of 8 (Geom carries the cropped size) -> conv 3x3 stride 2
 // 1 -> cout, BN, ReLU6.  One thread per output pixel, weights in LDS.  HBM-bound on the output write.
-__global__ __launch_bounds__(256) void k_stem(ImageSet imgs, const float* __restrict__ w, const float* __restrict__ scale,
-                                              const float* __restrict__ shift, int cout, float* __restrict__ out, Geom g) {
+__global__ __launch_bounds__(256) void k_stem(ImageSet imgs, const float* __restrict__ w, const float* __restrict__ bias, int cout,
+                                              float* __restrict__ out, Geom g) {
     __shared__ float sw[9 * 64];
-    __shared__ float ssc[64], ssh[64];
+    __shared__ float ssh[64];
     for (int i = threadIdx.x; i < 9 * cout; i += 256) sw[i] = w[i];
-    if (threadIdx.x < cout) { ssc[threadIdx.x] = scale[threadIdx.x]; ssh[threadIdx.x] = shift[threadIdx.x]; }
+    if (threadIdx.x < cout) ssh[threadIdx.x] = bias[threadIdx.x];
     __syncthreads();
     const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
     const LevelGeom lv = g.lv[level];
@@ -118,10 +119,10 @@ __global__ __launch_bounds__(256) void k_stem(ImageSet imgs, const float* __rest
         f32x4 r;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float acc = 0.0f;
+            float acc = ssh[c + j];
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc = fmaf(px[t], sw[t * cout + c + j], acc);
-            r[j] = relu6f(fmaf(acc, ssc[c + j], ssh[c + j]));
+            r[j] = relu6f(acc);
         }
         *(f32x4*)(op + c) = r;
     }
@@ -132,8 +133,8 @@ __global__ __launch_bounds__(256) void k_stem(ImageSet imgs, const float* __rest
 // tensor -- go through LDS so that the global stores are 16 bytes per lane at consecutive addresses (a thread's own
 // pixel is COUT*4 bytes from its neighbour's: written directly, every store instruction touches 64 cache lines).
 template <int COUT>
-__global__ __launch_bounds__(256) void k_stem_c(ImageSet imgs, const float* __restrict__ w, const float* __restrict__ scale,
-                                                const float* __restrict__ shift, float* __restrict__ out, Geom g) {
+__global__ __launch_bounds__(256) void k_stem_c(ImageSet imgs, const float* __restrict__ w, const float* __restrict__ bias,
+                                                float* __restrict__ out, Geom g) {
     constexpr int PS = COUT + 4;                 // LDS pixel stride in floats: 16-byte aligned, 28 words -> conflict-free b128
     static_assert(COUT % 4 == 0 && (PS % 8) == 4, "LDS pixel stride");
     __shared__ __attribute__((aligned(16))) float tile[256 * PS];
@@ -161,10 +162,10 @@ __global__ __launch_bounds__(256) void k_stem_c(ImageSet imgs, const float* __re
         f32x4 r;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float acc = 0.0f;
+            float acc = bias[c + j];
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc = fmaf(px[t], w[t * COUT + c + j], acc);
-            r[j] = relu6f(fmaf(acc, scale[c + j], shift[c + j]));
+            r[j] = relu6f(acc);
         }
         *(f32x4*)(tile + threadIdx.x * PS + c) = r;
     }
@@ -179,13 +180,12 @@ __global__ __launch_bounds__(256) void k_stem_c(ImageSet imgs, const float* __re
     }
 }
 
-hipError_t launch_stem(const ImageSet& imgs, const float* w, const float* scale, const float* shift, int cout, float* out,
-                       const Geom& g, hipStream_t s) {
+hipError_t launch_stem(const ImageSet& imgs, const float* w, const float* bias, int cout, float* out, const Geom& g, hipStream_t s) {
     int maxpix = 0;
     for (int l = 0; l < g.n_levels; ++l) maxpix = max(maxpix, g.lv[l].Ho * g.lv[l].Wo);
     dim3 grid((maxpix + 255) / 256, g.n_levels * g.batch);
-    if (cout == 24) hipLaunchKernelGGL(k_stem_c<24>, grid, dim3(256), 0, s, imgs, w, scale, shift, out, g);
-    else hipLaunchKernelGGL(k_stem, grid, dim3(256), 0, s, imgs, w, scale, shift, cout, out, g);
+    if (cout == 24) hipLaunchKernelGGL(k_stem_c<24>, grid, dim3(256), 0, s, imgs, w, bias, out, g);
+    else hipLaunchKernelGGL(k_stem, grid, dim3(256), 0, s, imgs, w, bias, cout, out, g);
     return hipGetLastError();
 }
 
@@ -199,8 +199,7 @@ hipError_t launch_stem(const ImageSet& imgs, const float* w, const float* scale,
 struct ConvArgs {
     const float* A;
     const f32x4* W;
-    const float* scale;
-    const float* shift;
+    const float* bias;    // folded BatchNorm shift / layer bias: the accumulators start here ([nt_total*32], zero padded)
     const float* res;
     float* out;
     long long P;      // rows (pointwise) -- unused by the 3x3 kernel
@@ -211,7 +210,8 @@ struct ConvArgs {
     int level_tiles[HFNET_MAX_LEVELS];   // 3x3 kernel: 128-row tiles launched per image of each level (exact 1-D grid)
 };
 
-// BN (+ ReLU6) (+ residual) and store of a wave's 32 x (NT*32) accumulator tile.  VALU instructions compete
+// (ReLU6) (+ residual) and store of a wave's 32 x (NT*32) accumulator tile (BatchNorm: folded weights, the accumulators
+// started at the folded bias -- conv_acc_init).  VALU instructions compete
 // with the f32 MFMAs for the same pipe, so the per-element work is kept minimal: the flags are hoisted into four
 // specialised loops, addresses are a uniform 64-bit tile base plus 32-bit lane offsets (row stride multiples are
 // scalar), and only the last, partial row tile checks rows.
@@ -232,7 +232,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
         for (int nt = 0; nt < NT; ++nt) {
             const unsigned col = (unsigned)((nt0 + nt) * 32 + r);
             if (col < n) {
-                const float sc = a.scale[col], sh = a.shift[col];
                 const unsigned o0 = ((unsigned)(4 * half) * n + col) * 4u;   // byte offsets inside the tile (< 2^32)
                 float rv[16];
                 if (RES) {                                              // all residual loads first: one latency, not sixteen
@@ -247,7 +246,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
                     const int rr = (reg & 3) + 8 * (reg >> 2);          // + 4 * half
                     if (FULL || rr + 4 * half < rows) {
                         const unsigned off = o0 + (unsigned)rr * n * 4u;
-                        float v = fmaf(acc[nt][reg], sc, sh);
+                        float v = acc[nt][reg];
                         if (RELU) v = relu6f(v);
                         if (RES) v = v + rv[reg];
                         *(float*)((char*)obase + off) = v;
@@ -267,6 +266,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
     }
 }
 
+// accumulators start at the folded bias of the lane's output column (D[row][col]: col = lane & 31)
+template <int NT>
+__device__ __forceinline__ void conv_acc_init(const ConvArgs& a, f32x16 (&acc)[NT], int nt0, int r) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float b = a.bias[(nt0 + nt) * 32 + r];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = b;
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(256, 2) void k_pointwise(ConvArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
@@ -279,10 +289,7 @@ __global__ __launch_bounds__(256, 2) void k_pointwise(ConvArgs a) {
     const f32x4* wp = a.W + ((size_t)nt0 * 64 + lane);
     const size_t wstep = (size_t)a.nt_total * 64;
     f32x16 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
+    conv_acc_init<NT>(a, acc, nt0, r);
     const int KQ = a.cin >> 3;
     // software pipeline: the loads of step kq+1 are issued before the MFMAs of step kq.  (A three-buffer, distance-2
     // pipeline as in k_conv3x3 was measured slower here: these kernels have short k loops and live on occupancy.)
@@ -340,10 +347,7 @@ __global__ __launch_bounds__(256) void k_pointwise_deep(ConvArgs a) {
     const unsigned wstep = (unsigned)a.nt_total * 64u * 16u;                                    // bytes per k-step
     const int KQ = a.cin >> 3;
     f32x16 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
+    conv_acc_init<NT>(a, acc, nt0, r);
     f32x4 av[NBUF], bv[NBUF][NT];
     auto load = [&](int kq, auto buf_tag) {
         constexpr int buf = decltype(buf_tag)::value;
@@ -441,10 +445,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g, TapArgs 
     const f32x4* wp = a.W + ((size_t)nt0 * 64 + lane);
     const size_t wstep = (size_t)a.nt_total * 64;
     f32x16 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
+    conv_acc_init<NT>(a, acc, nt0, r);
     const int KQ = a.cin >> 3;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     // per-tap source pointer / validity of this lane's pixel
@@ -551,7 +552,7 @@ static void launch_c3_nt(const ConvArgs& a, const Geom& g, const TapArgs* ta, di
 
 static ConvArgs make_args(const float* A, const ConvPack& cp, const float* res, float* out, long long P, int relu6) {
     ConvArgs a;
-    a.A = A; a.W = (const f32x4*)cp.w; a.scale = cp.scale; a.shift = cp.shift; a.res = res; a.out = out;
+    a.A = A; a.W = (const f32x4*)cp.w; a.bias = cp.bias; a.res = res; a.out = out;
     a.P = P; a.cin = cp.cin; a.n = cp.n; a.nt_total = cp.nt_total; a.relu6 = relu6;
     for (int l = 0; l < HFNET_MAX_LEVELS; ++l) a.level_tiles[l] = 1;
     return a;
@@ -560,7 +561,7 @@ static ConvArgs make_args(const float* A, const ConvPack& cp, const float* res, 
 // column tiles per wave: the packed layout allows any divisor of nt_total; small-M layers (the
 // 30x47 / 15x24 global branch) take fewer tiles per wave so that the launch still fills 256 CUs
 static int pick_nt(int nt_total, int nt_pref, long long m_tiles) {
-    static const int max_nt = []() { const char* v = getenv("HFNET_MAX_NT"); return v ? atoi(v) : 4; }();   // measured on MI355X: <= 4 column tiles per wave (higher occupancy) beats 8
+    constexpr int max_nt = 4;   // measured on MI355X: <= 4 column tiles per wave (higher occupancy) beats 8
     int best = 1;
     for (int nt = 1; nt <= nt_pref && nt <= max_nt; ++nt) {
         if (nt_total % nt) continue;
@@ -575,7 +576,7 @@ hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* res
     const ConvArgs a = make_args(A, cp, residual, out, P, relu6);
     const int nt = pick_nt(cp.nt_total, cp.nt_per_block, (P + 31) / 32);
     // long k chains on few tiles: latency-bound, see k_pointwise_deep
-    static const long long lowlat_waves = []() { const char* v = getenv("HFNET_PWD_WAVES"); return v ? atoll(v) : 1024ll; }();
+    constexpr long long lowlat_waves = 1024;
     if (nt <= 2 && cp.cin >= 192 && (P + 31) / 32 * cp.nt_total < lowlat_waves) {
         dim3 grid((unsigned)((P + 127) / 128), cp.nt_total / nt);
         if (nt == 1) hipLaunchKernelGGL((k_pointwise_deep<1, 8>), grid, dim3(256), 0, s, a);
@@ -601,8 +602,7 @@ static hipError_t launch_conv3x3_any(const float* A, const ConvPack& cp, float* 
                                      const int* level_rows, hipStream_t s) {
     ConvArgs a = make_args(A, cp, nullptr, out, 0, relu6);
     int ntb = cp.nt_per_block;
-    if (!ta) { static const int t = []() { const char* v = getenv("HFNET_CONV3_NT"); return v ? atoi(v) : 0; }(); if (t > 0 && cp.nt_total % t == 0) ntb = t; }
-    if (ta) { static const int t = []() { const char* v = getenv("HFNET_TAPS_NT"); return v ? atoi(v) : 4; }(); if (t > 0 && cp.nt_total % t == 0) ntb = t; }
+    if (ta && cp.nt_total % 4 == 0) ntb = 4;           // gathered rows: four column tiles per wave
     long long tiles = 0;
     for (int l = 0; l < HFNET_MAX_LEVELS; ++l) {
         a.level_tiles[l] = l < g.n_levels ? std::max((level_rows[l] + 127) / 128, 1) : 1;
@@ -610,7 +610,7 @@ static hipError_t launch_conv3x3_any(const float* A, const ConvPack& cp, float* 
     }
     // small batches: a wave's 3x3 chain over 9 * cin is ~50 us long with four column tiles, and a single frame has only
     // ~110 row tiles -- take fewer column tiles per wave until the launch has two workgroups per CU (latency, not throughput)
-    static const int min_wgs = []() { const char* v = getenv("HFNET_CONV3_MIN_WGS"); return v ? atoi(v) : 512; }();
+    constexpr int min_wgs = 512;
     while (ntb > 1 && tiles * (cp.nt_total / ntb) < min_wgs) {
         int next = ntb - 1;
         while (next > 1 && cp.nt_total % next) --next;
@@ -647,1522 +647,10 @@ hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, i
     return launch_conv3x3_any(A, cp, out, relu6, g, &ta, rows, s);
 }
 
-// =========================================================================== fused inverted-residual block
-// conv_blocks.py:163-312 in ONE launch: [1x1 expand + BN + ReLU6] -> depthwise 3x3 + BN + ReLU6 ->
-// 1x1 project + BN [+ input].  The expanded tensor (6x the block input, written and read twice by the
-// unfused chain) never leaves the CU: per 32-channel chunk of the expansion
-//   stage 1  MFMA: expand the (TH*s+2) x (TW*s+2) halo tile of the input into LDS (out-of-image halo = 0,
-//            which is what 'SAME' padding of the depthwise conv sees)
-//   stage 2  VALU: depthwise 3x3 from LDS to LDS
-//   stage 3  MFMA: accumulate the chunk into the projection (k-order = expansion channel order, chunks in
-//            order, so the chain is the oracle's)
-// Algorithmic HBM traffic per block drops from in + 4*expanded + out to in*(halo) + out.
-struct FusedArgs {
-    const float* X;
-    const f32x4* Wex; const float* ex_scale; const float* ex_shift; int ex_nt_total;
-    const float* Wdw; const float* dw_scale; const float* dw_shift;
-    const f32x4* Wpr; const float* pr_scale; const float* pr_shift; int pr_nt_total;
-    float* out;
-    int cin, cexp, cout, residual, has_expand;
-    int ablate;   // diagnostics: bit0 skip stage 1, bit1 skip stage 2, bit2 skip stage 3 (results are then wrong)
-};
-
-template <int STRIDE, int TH, int TW, int NTO>
-__global__ __launch_bounds__(256, 2) void k_block_fused(FusedArgs a, Geom g) {
-    constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3, IPIX = IH * IW, OPIX = TH * TW, CEP = 36;
-    constexpr int MT_IN = (IPIX + 31) / 32, MT_OUT = OPIX / 32;
-    static_assert(OPIX % 32 == 0 && MT_OUT <= 4, "output tile must be 32..128 pixels");
-    __shared__ __attribute__((aligned(16))) float E[IPIX * CEP];
-    __shared__ __attribute__((aligned(16))) float D[OPIX * CEP];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
-    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
-    const LevelGeom lv = g.lv[level];
-    const int tiles_x = (lv.Wo + TW - 1) / TW, tiles_y = (lv.Ho + TH - 1) / TH;
-    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-    const int oy0 = tyi * TH, ox0 = txi * TW;
-    const int iy0 = oy0 * STRIDE - lv.pt, ix0 = ox0 * STRIDE - lv.pl;
-    const long long in_base = lv.in_off + (long long)frame * lv.H * lv.W;
-    const long long out_base = lv.out_off + (long long)frame * lv.Ho * lv.Wo;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x16 pacc[NTO];
-#pragma unroll
-    for (int nt = 0; nt < NTO; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) pacc[nt][i] = 0.0f;
-    const int n_chunks = a.has_expand ? a.ex_nt_total : 1;
-    const int KQ = a.cin >> 3;
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
-        const int ch0 = chunk * 32;
-        if (ch0 >= a.cexp) break;                       // all-padding column tile
-        // ---- stage 1: expansion of the halo tile -> E
-        if (a.ablate & 1) {
-        } else if (a.has_expand) {
-            const float sc = a.ex_scale[ch0 + r], sh = a.ex_shift[ch0 + r];
-            for (int mt = wave; mt < MT_IN; mt += 4) {
-                const int hp = mt * 32 + r;
-                const int hy = hp / IW, hx = hp - hy * IW;
-                const int iy = iy0 + hy, ix = ix0 + hx;
-                const bool ok = hp < IPIX && iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W;
-                const float* ap = a.X + (in_base + (long long)(ok ? iy * lv.W + ix : 0)) * a.cin + half * 4;
-                f32x16 acc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-                for (int kq = 0; kq < KQ; ++kq) {
-                    f32x4 av = zero4;
-                    if (ok) av = *(const f32x4*)(ap + kq * 8);
-                    const f32x4 bv = a.Wex[((size_t)kq * a.ex_nt_total + chunk) * 64 + lane];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int hp2 = mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                    if (hp2 < IPIX) {
-                        const int hy2 = hp2 / IW, hx2 = hp2 - hy2 * IW;
-                        const int iy2 = iy0 + hy2, ix2 = ix0 + hx2;
-                        const bool in2 = iy2 >= 0 && iy2 < lv.H && ix2 >= 0 && ix2 < lv.W;
-                        E[hp2 * CEP + r] = in2 ? relu6f(fmaf(acc[reg], sc, sh)) : 0.0f;
-                    }
-                }
-            }
-        } else {
-            for (int idx = threadIdx.x; idx < IPIX * 8; idx += 256) {
-                const int hp = idx >> 3, c4 = idx & 7;
-                const int hy = hp / IW, hx = hp - hy * IW;
-                const int iy = iy0 + hy, ix = ix0 + hx;
-                f32x4 v = zero4;
-                if (c4 * 4 < a.cexp && iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W)
-                    v = *(const f32x4*)(a.X + (in_base + (long long)iy * lv.W + ix) * a.cin + c4 * 4);
-                *(f32x4*)(E + hp * CEP + c4 * 4) = v;
-            }
-        }
-        __syncthreads();
-        // ---- stage 2: depthwise 3x3 + BN + ReLU6, E -> D
-        if (!(a.ablate & 2))
-        for (int idx = threadIdx.x; idx < OPIX * 8; idx += 256) {
-            const int op = idx >> 3, c4 = idx & 7;
-            const int c = ch0 + c4 * 4;
-            f32x4 o = zero4;
-            if (c < a.cexp) {
-                const int oy = op / TW, ox = op - oy * TW;
-                f32x4 acc = zero4;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const f32x4 ev = *(const f32x4*)(E + ((oy * STRIDE + ky) * IW + ox * STRIDE + kx) * CEP + c4 * 4);
-                        const f32x4 wv = *(const f32x4*)(a.Wdw + (ky * 3 + kx) * a.cexp + c);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[j] = fmaf(ev[j], wv[j], acc[j]);
-                    }
-                const f32x4 dsc = *(const f32x4*)(a.dw_scale + c), dsh = *(const f32x4*)(a.dw_shift + c);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = relu6f(fmaf(acc[j], dsc[j], dsh[j]));
-            }
-            *(f32x4*)(D + op * CEP + c4 * 4) = o;
-        }
-        __syncthreads();
-        // ---- stage 3: projection, accumulate this chunk's channels
-        if (wave < MT_OUT && !(a.ablate & 4)) {
-            const int kqc = min(4, (a.cexp - ch0) >> 3);
-            for (int kq = 0; kq < kqc; ++kq) {
-                const f32x4 av = *(const f32x4*)(D + (wave * 32 + r) * CEP + kq * 8 + half * 4);
-                f32x4 bv[NTO];
-#pragma unroll
-                for (int nt = 0; nt < NTO; ++nt) bv[nt] = a.Wpr[((size_t)(chunk * 4 + kq) * a.pr_nt_total + nt) * 64 + lane];
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], pacc[nt], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-    // ---- epilogue: BN (+ residual), store
-    if (wave < MT_OUT) {
-#pragma unroll
-        for (int nt = 0; nt < NTO; ++nt) {
-            const int col = nt * 32 + r;
-            if (col >= a.cout) continue;
-            const float sc = a.pr_scale[col], sh = a.pr_shift[col];
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int op = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                const int oy = oy0 + op / TW, ox = ox0 + op % TW;
-                if (oy >= lv.Ho || ox >= lv.Wo) continue;
-                float v = fmaf(pacc[nt][reg], sc, sh);
-                if (a.residual) v = v + a.X[(in_base + (long long)oy * lv.W + ox) * a.cin + col];
-                a.out[(out_base + (long long)oy * lv.Wo + ox) * a.cout + col] = v;
-            }
-        }
-    }
-}
-
-// ---- v2 of the fused block for the shapes of the high-resolution layers (cin = 8*KQT known at
-// compile time).  Differences to the generic kernel above:
-//  * the expanded halo tile is kept channel-major in LDS (ET[channel][padded position]); the MFMA
-//    D fragment (lane = channel, 4 consecutive rows per register quad) goes out as ds_write_b128;
-//  * the depthwise stage runs one thread per (channel, output row): three input rows are read once as
-//    16-byte LDS loads and slide along x in registers; the 9 taps + BN live in registers per chunk;
-//  * the block input (A fragments of every halo M-tile of the wave) is loaded once and stays in
-//    registers across chunks; the chunk's expand weights are loaded once per chunk, not per M-tile.
-struct TileSplit { int first[4], count[4], maxc; };
-// halo M-tiles per MFMA wave: the split that minimises the largest per-wave MFMA count (stage-1 MFMAs + the
-// stage-3 MFMAs of the waves that own an output tile); ties go to the smaller register footprint (max tiles per wave)
-constexpr TileSplit split_tiles(int mt_in, int mt_out, int c1, int c3) {
-    TileSplit sp{};
-    long best = -1;
-    for (int n0 = 0; n0 <= mt_in; ++n0)
-        for (int n1 = 0; n0 + n1 <= mt_in; ++n1)
-            for (int n2 = 0; n0 + n1 + n2 <= mt_in; ++n2) {
-                const int cnt[4] = {n0, n1, n2, mt_in - n0 - n1 - n2};
-                int maxload = 0, maxc = 0;
-                long sq = 0;
-                for (int w = 0; w < 4; ++w) {
-                    const int load = cnt[w] * c1 + (w < mt_out ? c3 : 0);
-                    if (load > maxload) maxload = load;
-                    if (cnt[w] > maxc) maxc = cnt[w];
-                    sq += (long)load * load;
-                }
-                const long key = ((long)maxload * 64 + maxc) * 1000000 + sq;
-                if (best < 0 || key < best) {
-                    best = key;
-                    for (int w = 0; w < 4; ++w) sp.count[w] = cnt[w];
-                    sp.maxc = maxc;
-                }
-            }
-    int f = 0;
-    for (int w = 0; w < 4; ++w) { sp.first[w] = f; f += sp.count[w]; }
-    return sp;
-}
-
-// workgroups per CU the register budget is tuned for: three where the LDS tile allows it (f32 MFMA and VALU work
-// share one issue pipe, so more resident waves is what hides the LDS / barrier latencies).  "Diet": the widest
-// high-resolution block does not keep its input fragments and projection weights in registers across the chunk
-// loop (236 VGPRs, 2 workgroups per CU) but re-reads them from L1 / L2 when they are used (<= 168, 3 workgroups).
-template <int STRIDE, int NTO, int KQT, int TW>
-constexpr bool fused2_diet() { return (STRIDE == 1 && (KQT >= 6 || NTO >= 2)) || KQT >= 12; }    // layers 6, 7, 8, 9-14
-template <int STRIDE, int NTO, int KQT, int TW>
-constexpr int fused2_min_blocks() {
-    return (STRIDE == 2 && TW == 8) || (STRIDE == 1 && KQT <= 3 && NTO == 1) || fused2_diet<STRIDE, NTO, KQT, TW>() ? 3 : 2;
-}
-
-template <int STRIDE, int NTO, int KQT, bool HAS_EXPAND, int TW>
-__global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) void k_block_fused2(FusedArgs a, Geom g) {
-    constexpr int TH = 8;
-    // halo rows are stored back to back; an even row length keeps the depthwise stage's row reads 8-byte aligned
-    // (odd widths get one padding column: fewer halo M-tiles than padding to a multiple of 4)
-    constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3, IWP = (IW + 1) / 2 * 2, NPOS = IH * IWP;
-    constexpr int MT_IN = (NPOS + 31) / 32, OPIX = TH * TW, MT_OUT = OPIX / 32, CEP = 36;
-    constexpr int EP = ((MT_IN * 32 / 4) % 2 == 1) ? MT_IN * 32 : MT_IN * 32 + 4;   // per-channel stride, EP/4 odd
-    // halo M-tiles per wave.  Stage 3 of chunk c runs in the same barrier phase as stage 1 of chunk c+1
-    // (see the loop), and only waves < MT_OUT have stage-3 work, so those waves own fewer halo tiles.
-    constexpr TileSplit SP = split_tiles(MT_IN, MT_OUT, KQT * 4, NTO * 16);
-    constexpr int MTC0 = SP.count[0], MTC1 = SP.count[1], MTC2 = SP.count[2], MTC3 = SP.count[3], MTW = SP.maxc;
-    static_assert(MTC0 + MTC1 + MTC2 + MTC3 == MT_IN && MTW <= 5, "halo tile distribution");
-    __shared__ __attribute__((aligned(16))) float ET[32 * EP];
-    __shared__ __attribute__((aligned(16))) float D[OPIX * CEP];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
-    const int mt_first = wave == 0 ? 0 : wave == 1 ? MTC0 : wave == 2 ? MTC0 + MTC1 : MTC0 + MTC1 + MTC2;
-    int mt_count = wave == 0 ? MTC0 : wave == 1 ? MTC1 : wave == 2 ? MTC2 : MTC3;
-    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
-    const LevelGeom lv = g.lv[level];
-    const int tiles_x = (lv.Wo + TW - 1) / TW, tiles_y = (lv.Ho + TH - 1) / TH;
-    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-    const int oy0 = tyi * TH, ox0 = txi * TW;
-    const int iy0 = oy0 * STRIDE - lv.pt, ix0 = ox0 * STRIDE - lv.pl;
-    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= lv.H && ix0 + IW <= lv.W;
-    // Tiles hanging over the bottom edge (the pyramid levels are not multiples of the tile height: up to 30 % of a level's
-    // tile area at 1/8 resolution): halo M-tiles below the last needed input row, depthwise rows and projection M-tiles
-    // below the last output row are skipped.  Skipped regions of ET / D keep stale values that only ever feed rows of
-    // MFMA tiles which are never stored (a row of A only affects the same row of D).
-    const int rows_valid = min(TH, lv.Ho - oy0);                               // uniform, >= 1
-    {
-        const int hy_max = (rows_valid - 1) * STRIDE + 2;                      // last halo row any valid output row reads
-        const int n_live = ((hy_max + 1) * IWP + 31) >> 5;                     // halo M-tiles covering positions < (hy_max + 1) * IWP
-        mt_count = max(0, min(mt_count, n_live - mt_first));
-    }
-    const bool out_live = wave < MT_OUT && (wave * 32) / TW < rows_valid;      // this wave's projection tile has a valid row
-    const long long in_base = lv.in_off + (long long)frame * lv.H * lv.W;
-    const long long out_base = lv.out_off + (long long)frame * lv.Ho * lv.Wo;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 pacc[NTO];
-#pragma unroll
-    for (int nt = 0; nt < NTO; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) pacc[nt][i] = 0.0f;
-    // A fragments of this wave's halo M-tiles: kept for all chunks, or (diet) only their addresses
-    constexpr int KQA = HAS_EXPAND ? KQT : 1;
-    constexpr bool DIET = HAS_EXPAND && fused2_diet<STRIDE, NTO, KQT, TW>();
-    f32x4 afrag[DIET ? 1 : MTW][KQA];
-    const float* aptr[MTW];
-    bool aok[MTW];
-    if (HAS_EXPAND) {
-#pragma unroll
-        for (int m = 0; m < MTW; ++m) {
-            const int mt = mt_first + m;
-            const int pp = mt * 32 + r;
-            const int hy = pp / IWP, hx = pp - hy * IWP;
-            const int iy = iy0 + hy, ix = ix0 + hx;
-            const bool ok = m < mt_count && hy < IH && hx < IW && iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W;
-            const float* ap = a.X + (in_base + (long long)(ok ? iy * lv.W + ix : 0)) * a.cin + half * 4;
-            aptr[m] = ap; aok[m] = ok;
-            if (!DIET) {
-#pragma unroll
-                for (int kq = 0; kq < KQA; ++kq) afrag[m][kq] = ok ? *(const f32x4*)(ap + kq * 8) : zero4;
-            }
-        }
-    }
-    const int dc = threadIdx.x & 31, doy = threadIdx.x >> 5;      // depthwise role: channel lane, output row
-    const int n_chunks_all = HAS_EXPAND ? a.ex_nt_total : 1;
-    const int n_chunks = min(n_chunks_all, (a.cexp + 31) >> 5);   // skip all-padding column tiles
-
-    // ---- stage 1 of one chunk: expansion of the halo tile -> ET (channel-major)
-    // expansion weights / BN of a chunk.  With few input channels (KQT <= 3) the next chunk's set is prefetched a whole
-    // phase ahead (an L2 hit takes 0.7-1 us here, a phase is 1-2 us); the wide layers have no registers to spare.
-    constexpr bool PREFETCH_B = false;    // measured on L03-L06: no gain (the other resident workgroups already cover the wait)
-    f32x4 bpre[KQA];
-    float scpre = 0.f, shpre = 0.f;
-    auto fetch_b = [&](int chunk) {
-#pragma unroll
-        for (int kq = 0; kq < KQA; ++kq) bpre[kq] = a.Wex[((size_t)kq * a.ex_nt_total + chunk) * 64 + lane];
-        scpre = a.ex_scale[chunk * 32 + r]; shpre = a.ex_shift[chunk * 32 + r];
-    };
-    auto stage1 = [&](int chunk) {
-        if (HAS_EXPAND) {
-            if (!PREFETCH_B) fetch_b(chunk);
-            f32x4 bfrag[KQA];
-#pragma unroll
-            for (int kq = 0; kq < KQA; ++kq) bfrag[kq] = bpre[kq];
-            const float sc = scpre, sh = shpre;
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-                if (m < mt_count) {
-                    const int mt = mt_first + m;
-                    f32x4 af[KQA];
-#pragma unroll
-                    for (int kq = 0; kq < KQA; ++kq) {
-                        if (DIET) { const f32x4 v = *(const f32x4*)(aptr[m] + kq * 8); af[kq] = aok[m] ? v : zero4; }
-                        else af[kq] = afrag[m][kq];
-                    }
-                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][0], bfrag[0][0], zero16, 0, 0, 0);
-#pragma unroll
-                    for (int kq = 0; kq < KQA; ++kq)
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            if (kq + t > 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kq][t], bfrag[kq][t], acc, 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int pp = mt * 32 + 8 * q + 4 * half;
-                        f32x4 v;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = relu6f(fmaf(acc[4 * q + i], sc, sh));
-                        *(f32x4*)(ET + r * EP + pp) = v;        // border tiles: out-of-image positions are zeroed by zero_border()
-                    }
-                }
-            }
-        } else {
-            // no expansion conv: the block input itself is the depthwise input
-            for (int idx = threadIdx.x; idx < NPOS * 8; idx += 256) {
-                const int pp = idx >> 3, c4 = idx & 7;
-                const int hy = pp / IWP, hx = pp - hy * IWP;
-                const int iy = iy0 + hy, ix = ix0 + hx;
-                f32x4 v = zero4;
-                if (c4 * 4 < a.cexp && hx < IW && iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W)
-                    v = *(const f32x4*)(a.X + (in_base + (long long)iy * lv.W + ix) * a.cin + c4 * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ET[(c4 * 4 + j) * EP + pp] = v[j];
-            }
-        }
-    };
-
-    // tiles that touch the image border: the expansion of an out-of-image halo position must be 0 (the
-    // depthwise conv's 'SAME' padding), not relu6(shift).  Kept out of the MFMA epilogue: one extra pass + barrier,
-    // executed only by border workgroups.
-    auto zero_border = [&]() {
-        __syncthreads();
-        for (int pp = threadIdx.x; pp < NPOS; pp += 256) {
-            const int hy = pp / IWP, hx = pp - hy * IWP;
-            const int iy = iy0 + hy, ix = ix0 + hx;
-            if (iy < 0 || iy >= lv.H || ix < 0 || ix >= lv.W)
-                for (int c = 0; c < 32; ++c) ET[c * EP + pp] = 0.0f;
-        }
-    };
-
-    if (PREFETCH_B) fetch_b(0);
-    if (!(a.ablate & 1)) stage1(0);
-    if (HAS_EXPAND && !interior) zero_border();
-    __syncthreads();
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
-        const int ch0 = chunk * 32;
-        if (PREFETCH_B && chunk + 1 < n_chunks) fetch_b(chunk + 1);
-        // depthwise taps / BN of this thread's channel and the projection weights of this chunk
-        const int dch = ch0 + dc;
-        const bool dact = dch < a.cexp;
-        float dwt[9], dsc = 0.f, dsh = 0.f;
-        if (dact) {
-            const float* wdp = a.Wdw + dch;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) dwt[t] = wdp[t * a.cexp];
-            dsc = a.dw_scale[dch]; dsh = a.dw_shift[dch];
-        } else {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) dwt[t] = 0.f;
-        }
-        const int kqc = min(4, (a.cexp - ch0) >> 3);
-        f32x4 pfrag[4][NTO];
-        auto fetch_p = [&]() {
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq)
-#pragma unroll
-                for (int nt = 0; nt < NTO; ++nt)
-                    pfrag[kq][nt] = kq < kqc ? a.Wpr[((size_t)(chunk * 4 + kq) * a.pr_nt_total + nt) * 64 + lane] : zero4;
-        };
-        if (out_live && !DIET) fetch_p();
-        // ---- stage 2: thread = (channel dc, output row doy), ET -> D
-        if (!(a.ablate & 2) && doy < rows_valid) {
-            float row[3][IWP];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const float* rp = ET + dc * EP + (doy * STRIDE + ky) * IWP;
-                if constexpr (IWP % 4 == 0) {
-#pragma unroll
-                    for (int qx = 0; qx < IWP / 4; ++qx) {
-                        const f32x4 v = *(const f32x4*)(rp + qx * 4);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) row[ky][qx * 4 + j] = v[j];
-                    }
-                } else {
-#pragma unroll
-                    for (int qx = 0; qx < IWP / 2; ++qx) {
-                        const float2 v = *(const float2*)(rp + qx * 2);
-                        row[ky][qx * 2] = v.x; row[ky][qx * 2 + 1] = v.y;
-                    }
-                }
-            }
-#pragma unroll
-            for (int ox = 0; ox < TW; ++ox) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) acc = fmaf(row[ky][ox * STRIDE + kx], dwt[ky * 3 + kx], acc);
-                D[(doy * TW + ox) * CEP + dc] = relu6f(fmaf(acc, dsc, dsh));    // inactive channel: taps, scale, shift are all 0 -> 0
-            }
-        }
-        __syncthreads();          // D complete, ET free
-        // ---- stage 3 of this chunk (reads D) and stage 1 of the next one (writes ET) share this phase
-        if (out_live && !(a.ablate & 4)) {
-            if (DIET) fetch_p();
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) {
-                if (kq < kqc) {
-                    const f32x4 av = *(const f32x4*)(D + (wave * 32 + r) * CEP + kq * 8 + half * 4);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], pfrag[kq][nt][t], pacc[nt], 0, 0, 0);
-                }
-            }
-        }
-        if (chunk + 1 < n_chunks && !(a.ablate & 1)) {
-            stage1(chunk + 1);
-            if (HAS_EXPAND && !interior) zero_border();
-        }
-        __syncthreads();          // ET complete, D free
-    }
-    if (out_live && !(a.ablate & 8)) {
-        float* obase = a.out + out_base * a.cout;                      // uniform
-        const float* rbase = a.X + in_base * a.cin;                    // uniform (residual: same spatial size, cin == cout)
-        const bool full = oy0 + TH <= lv.Ho && ox0 + TW <= lv.Wo;
-        if constexpr ((TW & (TW - 1)) == 0) {
-            // TW a power of two: register reg of the D fragment is tile row (wave*32 + c) / TW, column 4*half + c % TW with
-            // c = (reg & 3) + 8 * (reg >> 2) -- the row does not depend on the lane.  One per-lane byte offset, the per-register
-            // part is scalar; partial tiles check the row with a scalar compare and the column per lane.
-            const int wv = __builtin_amdgcn_readfirstlane(wave);
-            const int oyb = oy0 + (wv * 32) / TW, oxl = ox0 + 4 * half;
-            const unsigned cout4 = (unsigned)a.cout * 4u;
-#pragma unroll
-            for (int nt = 0; nt < NTO; ++nt) {
-                const int col = nt * 32 + r;
-                if (col < a.cout) {
-                    const float sc = a.pr_scale[col], sh = a.pr_shift[col];
-                    const unsigned lane_off = (unsigned)(oyb * lv.Wo + oxl) * cout4 + (unsigned)col * 4u;
-                    float rv[16];
-                    if (a.residual) {
-#pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) {
-                            constexpr int dummy = 0; (void)dummy;
-                            const int c = (reg & 3) + 8 * (reg >> 2), ry = c / TW, rx = c % TW;
-                            const bool ok = full || (oyb + ry < lv.Ho && oxl + rx < lv.Wo);
-                            rv[reg] = ok ? *(const float*)((const char*)rbase + lane_off + (unsigned)(ry * lv.Wo + rx) * cout4) : 0.0f;
-                        }
-                    }
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int c = (reg & 3) + 8 * (reg >> 2), ry = c / TW, rx = c % TW;
-                        if (full || (oyb + ry < lv.Ho && oxl + rx < lv.Wo)) {
-                            float v = fmaf(pacc[nt][reg], sc, sh);
-                            if (a.residual) v = v + rv[reg];
-                            *(float*)((char*)obase + lane_off + (unsigned)(ry * lv.Wo + rx) * cout4) = v;
-                        }
-                    }
-                }
-            }
-        } else {
-            // op = wave*32 + (reg&3) + 8*(reg>>2) + 4*half  ->  (oy, ox)
-            const int opl = wave * 32 + 4 * half;
-#pragma unroll
-            for (int nt = 0; nt < NTO; ++nt) {
-                const int col = nt * 32 + r;
-                if (col < a.cout) {
-                    const float sc = a.pr_scale[col], sh = a.pr_shift[col];
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int op = opl + (reg & 3) + 8 * (reg >> 2);
-                        const int oy = oy0 + op / TW, ox = ox0 + op % TW;
-                        if (full || (oy < lv.Ho && ox < lv.Wo)) {
-                            const int off = (oy * lv.Wo + ox) * a.cout + col;
-                            float v = fmaf(pacc[nt][reg], sc, sh);
-                            if (a.residual) v = v + rbase[off];
-                            obase[off] = v;
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int STRIDE, int NTO, int KQT, bool HAS_EXPAND, int TW = (STRIDE == 1 ? 16 : 8)>
-static hipError_t launch_block_fused2_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
-    constexpr int TH = 8;
-    int maxtiles = 0;
-    for (int l = 0; l < g.n_levels; ++l) maxtiles = max(maxtiles, ((g.lv[l].Wo + TW - 1) / TW) * ((g.lv[l].Ho + TH - 1) / TH));
-    dim3 grid(maxtiles, g.n_levels * g.batch);
-    hipLaunchKernelGGL((k_block_fused2<STRIDE, NTO, KQT, HAS_EXPAND, TW>), grid, dim3(256), 0, s, a, g);
-    return hipGetLastError();
-}
-
-// ---- v3 of the fused block: wave-specialised.  A workgroup is 8 waves, two per SIMD: waves 0-3 only issue the
-// two MFMA stages (expansion of chunk p, projection of chunk p-2), waves 4-7 only run the depthwise stage (chunk
-// p-1) on the vector ALUs and stage the next projection weights into LDS.  ET / D / projection weights are
-// double-buffered, so the three stages of three consecutive chunks run in the same barrier phase: the matrix
-// pipe of every SIMD always has a wave with MFMA work while the VALU work of the other wave co-issues, and
-// there is one barrier per chunk instead of two.  (v2 alternates the stages inside every wave; with 2
-// workgroups per CU the phases overlap only by chance and the matrix pipe idles ~50 % of the time.)
-template <int STRIDE, int NTO, int KQT, int TW>
-__global__ __launch_bounds__(512) void k_block_fused3(FusedArgs a, Geom g) {
-    constexpr int TH = 8;
-    constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3, IWP = (IW % 2 == 0) ? IW : (IW + 3) / 4 * 4, NPOS = IH * IWP;
-    constexpr int MT_IN = (NPOS + 31) / 32, OPIX = TH * TW, MT_OUT = OPIX / 32, CEP = 36;
-    constexpr int EP = ((MT_IN * 32 / 4) % 2 == 1) ? MT_IN * 32 : MT_IN * 32 + 4;   // per-channel stride, EP/4 odd
-    constexpr TileSplit SP = split_tiles(MT_IN, MT_OUT, KQT * 4, NTO * 16);
-    constexpr int MTW = SP.maxc;
-    static_assert(MT_OUT <= 4 && OPIX % 32 == 0 && MTW <= 5, "output tile / halo tile split");
-    __shared__ __attribute__((aligned(16))) float ET[2][32 * EP];
-    __shared__ __attribute__((aligned(16))) float D[2][OPIX * CEP];
-    __shared__ f32x4 WP[2][4 * NTO * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
-    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
-    const LevelGeom lv = g.lv[level];
-    const int tiles_x = (lv.Wo + TW - 1) / TW, tiles_y = (lv.Ho + TH - 1) / TH;
-    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-    const int oy0 = tyi * TH, ox0 = txi * TW;
-    const int iy0 = oy0 * STRIDE - lv.pt, ix0 = ox0 * STRIDE - lv.pl;
-    const long long in_base = lv.in_off + (long long)frame * lv.H * lv.W;
-    const long long out_base = lv.out_off + (long long)frame * lv.Ho * lv.Wo;
-    const int n_chunks = min(a.ex_nt_total, (a.cexp + 31) >> 5);
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    if (wave < 4) {
-        // ================================================================ MFMA waves
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int mt_first = wave == 0 ? SP.first[0] : wave == 1 ? SP.first[1] : wave == 2 ? SP.first[2] : SP.first[3];
-        const int mt_count = wave == 0 ? SP.count[0] : wave == 1 ? SP.count[1] : wave == 2 ? SP.count[2] : SP.count[3];
-        f32x16 pacc[NTO];
-#pragma unroll
-        for (int nt = 0; nt < NTO; ++nt) pacc[nt] = zero16;
-        // block input: the A fragments of this wave's halo M-tiles stay in registers for all chunks
-        f32x4 afrag[MTW][KQT];
-#pragma unroll
-        for (int m = 0; m < MTW; ++m) {
-            const int pp = (mt_first + m) * 32 + r;
-            const int hy = pp / IWP, hx = pp - hy * IWP;
-            const int iy = iy0 + hy, ix = ix0 + hx;
-            const bool ok = m < mt_count && hy < IH && hx < IW && iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W;
-            const float* ap = a.X + (in_base + (long long)(ok ? iy * lv.W + ix : 0)) * a.cin + half * 4;
-#pragma unroll
-            for (int kq = 0; kq < KQT; ++kq) afrag[m][kq] = ok ? *(const f32x4*)(ap + kq * 8) : zero4;
-        }
-        f32x4 bcur[KQT], bnxt[KQT];
-        float sc, sh, scn = 0.f, shn = 0.f;
-#pragma unroll
-        for (int kq = 0; kq < KQT; ++kq) { bcur[kq] = a.Wex[((size_t)kq * a.ex_nt_total) * 64 + lane]; bnxt[kq] = zero4; }
-        sc = a.ex_scale[r]; sh = a.ex_shift[r];
-        for (int p = 0; p < n_chunks + 2; ++p) {
-            const int buf = p & 1;
-            if (p + 1 < n_chunks) {                                        // expansion weights of the next chunk
-#pragma unroll
-                for (int kq = 0; kq < KQT; ++kq) bnxt[kq] = a.Wex[((size_t)kq * a.ex_nt_total + p + 1) * 64 + lane];
-                scn = a.ex_scale[(p + 1) * 32 + r]; shn = a.ex_shift[(p + 1) * 32 + r];
-            }
-            if (p >= 2 && wave < MT_OUT) {                                 // stage 3: projection of chunk p-2
-                const int kqc = min(4, (a.cexp - (p - 2) * 32) >> 3);
-                const float* dp = D[buf] + (wave * 32 + r) * CEP + half * 4;
-#pragma unroll
-                for (int kq = 0; kq < 4; ++kq) {
-                    if (kq < kqc) {
-                        const f32x4 av = *(const f32x4*)(dp + kq * 8);
-                        f32x4 bv[NTO];
-#pragma unroll
-                        for (int nt = 0; nt < NTO; ++nt) bv[nt] = WP[buf][(kq * NTO + nt) * 64 + lane];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-#pragma unroll
-                            for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], pacc[nt], 0, 0, 0);
-                    }
-                }
-            }
-            if (p < n_chunks) {                                            // stage 1: expansion of chunk p -> ET[buf]
-                float* et = ET[buf] + r * EP + 4 * half + mt_first * 32;
-                // straight-line code per tile count: the chain of tile m+1 is issued before the epilogue of tile m,
-                // so the BN / ReLU6 / LDS writes run in the shadow of the next tile's MFMAs
-                auto chain = [&](int m) {
-                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][0][0], bcur[0][0], zero16, 0, 0, 0);
-#pragma unroll
-                    for (int kq = 0; kq < KQT; ++kq)
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            if (kq + t > 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][kq][t], bcur[kq][t], acc, 0, 0, 0);
-                    return acc;
-                };
-                auto epi = [&](int m, const f32x16& acc) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f32x4 v;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = relu6f(fmaf(acc[4 * q + i], sc, sh));
-                        *(f32x4*)(et + m * 32 + 8 * q) = v;               // out-of-image positions are masked by stage 2
-                    }
-                };
-                auto stage1 = [&](auto cnt) {
-                    constexpr int CNT = decltype(cnt)::value;
-                    if constexpr (CNT > 0 && CNT <= MTW) {
-                        f32x16 prev = chain(0);
-#pragma unroll
-                        for (int m = 1; m < CNT; ++m) {
-                            const f32x16 cur = chain(m);
-                            epi(m - 1, prev);
-                            prev = cur;
-                            // issue order inside this pair: one MFMA, then its share of the 32 epilogue VALU ops / 4 LDS writes
-                            constexpr int NM = KQT * 4, VPM = (32 + NM - 1) / NM, DSI = NM / 4;
-#pragma unroll
-                            for (int i = 0; i < NM; ++i) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-                                if (i % DSI == DSI - 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                            }
-                        }
-                        epi(CNT - 1, prev);
-                    }
-                };
-                switch (mt_count) {
-                    case 1: stage1(std::integral_constant<int, 1>{}); break;
-                    case 2: stage1(std::integral_constant<int, 2>{}); break;
-                    case 3: stage1(std::integral_constant<int, 3>{}); break;
-                    case 4: stage1(std::integral_constant<int, 4>{}); break;
-                    case 5: stage1(std::integral_constant<int, 5>{}); break;
-                    default: break;
-                }
-            }
-            if (p + 1 < n_chunks) {
-#pragma unroll
-                for (int kq = 0; kq < KQT; ++kq) bcur[kq] = bnxt[kq];
-                sc = scn; sh = shn;
-            }
-            __syncthreads();
-        }
-        // ---- epilogue: BN (+ residual), store
-        if (wave < MT_OUT) {
-            float* obase = a.out + out_base * a.cout;
-            const float* rbase = a.X + in_base * a.cin;                    // residual: same spatial size, cin == cout
-            const bool full = oy0 + TH <= lv.Ho && ox0 + TW <= lv.Wo;
-            const int opl = wave * 32 + 4 * half;
-#pragma unroll
-            for (int nt = 0; nt < NTO; ++nt) {
-                const int col = nt * 32 + r;
-                if (col < a.cout) {
-                    const float psc = a.pr_scale[col], psh = a.pr_shift[col];
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int op = opl + (reg & 3) + 8 * (reg >> 2);
-                        const int oy = oy0 + op / TW, ox = ox0 + op % TW;
-                        if (full || (oy < lv.Ho && ox < lv.Wo)) {
-                            const int off = (oy * lv.Wo + ox) * a.cout + col;
-                            float v = fmaf(pacc[nt][reg], psc, psh);
-                            if (a.residual) v = v + rbase[off];
-                            obase[off] = v;
-                        }
-                    }
-                }
-            }
-        }
-    } else {
-        // ================================================================ depthwise waves
-        const int vt = threadIdx.x - 256, dc = vt & 31, doy = vt >> 5;    // role: (channel lane, output row)
-        const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= lv.H && ix0 + IW <= lv.W;
-        float dwt[9], dsc = 0.f, dsh = 0.f, dwn[9], dscn = 0.f, dshn = 0.f;
-        bool dact = false, dactn = false;
-        f32x4 preg[NTO];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) { dwt[t] = 0.f; dwn[t] = 0.f; }
-#pragma unroll
-        for (int j = 0; j < NTO; ++j) preg[j] = zero4;
-        for (int p = 0; p < n_chunks + 2; ++p) {
-            const bool work = p >= 1 && p <= n_chunks;
-            if (work) {                                                    // publish what was fetched one phase ago
-#pragma unroll
-                for (int j = 0; j < NTO; ++j) WP[(p - 1) & 1][vt + j * 256] = preg[j];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) dwt[t] = dwn[t];
-                dsc = dscn; dsh = dshn; dact = dactn;
-            }
-            if (p < n_chunks) {                                            // fetch chunk p: projection weights, depthwise taps / BN
-                const int kqc = min(4, (a.cexp - p * 32) >> 3);
-#pragma unroll
-                for (int j = 0; j < NTO; ++j) {
-                    const int idx = vt + j * 256, kq = idx / (NTO * 64);
-                    preg[j] = kq < kqc ? a.Wpr[(size_t)p * 4 * NTO * 64 + idx] : zero4;
-                }
-                const int dch = p * 32 + dc;
-                dactn = dch < a.cexp;
-                if (dactn) {
-                    const float* wdp = a.Wdw + dch;
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) dwn[t] = wdp[t * a.cexp];
-                    dscn = a.dw_scale[dch]; dshn = a.dw_shift[dch];
-                }
-            }
-            if (work) {                                                    // stage 2 of chunk p-1: ET -> D
-                const int buf = (p - 1) & 1;
-                float row[3][IWP];
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const float* rp = ET[buf] + dc * EP + (doy * STRIDE + ky) * IWP;
-                    if constexpr (IWP % 4 == 0) {
-#pragma unroll
-                        for (int qx = 0; qx < IWP / 4; ++qx) {
-                            const f32x4 v = *(const f32x4*)(rp + qx * 4);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) row[ky][qx * 4 + j] = v[j];
-                        }
-                    } else {
-#pragma unroll
-                        for (int qx = 0; qx < IWP / 2; ++qx) {
-                            const float2 v = *(const float2*)(rp + qx * 2);
-                            row[ky][qx * 2] = v.x; row[ky][qx * 2 + 1] = v.y;
-                        }
-                    }
-                }
-                if (!interior) {
-                    // the expansion of an out-of-image halo position must count as 0 ('SAME' padding of the depthwise conv)
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const bool rok = (unsigned)(iy0 + doy * STRIDE + ky) < (unsigned)lv.H;
-#pragma unroll
-                        for (int x = 0; x < IW; ++x) row[ky][x] = (rok && (unsigned)(ix0 + x) < (unsigned)lv.W) ? row[ky][x] : 0.0f;
-                    }
-                }
-                float* dp = D[buf] + (doy * TW) * CEP + dc;
-#pragma unroll
-                for (int ox = 0; ox < TW; ++ox) {
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) acc = fmaf(row[ky][ox * STRIDE + kx], dwt[ky * 3 + kx], acc);
-                    dp[ox * CEP] = dact ? relu6f(fmaf(acc, dsc, dsh)) : 0.0f;
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// ---- v3p: the same wave-specialised pipeline, persistent over tiles.  One workgroup per CU walks tiles
-// b, b + gridDim.x, ...; the global phase counter keeps running across tile boundaries, so the expansion of the
-// next tile's first chunks runs while the projection of the previous tile drains (a tile costs n_chunks phases
-// instead of n_chunks + 2), the next tile's input fragments are prefetched a whole tile ahead and the BN / store
-// epilogue overlaps the next tile's MFMAs.
-struct TileGeo {
-    int oy0, ox0, iy0, ix0, H, W, Ho, Wo;
-    long long in_base, out_base;
-};
-template <int STRIDE, int TH, int TW>
-__device__ __forceinline__ TileGeo decode_tile(const Geom& g, int t) {
-    int l = 0, rem = t, tx = 1, per = 1;
-    for (;; ++l) {
-        tx = (g.lv[l].Wo + TW - 1) / TW;
-        per = tx * ((g.lv[l].Ho + TH - 1) / TH);
-        if (l == g.n_levels - 1 || rem < per * g.batch) break;
-        rem -= per * g.batch;
-    }
-    const LevelGeom lv = g.lv[l];
-    const int frame = rem / per, tile = rem - frame * per;
-    const int tyi = tile / tx, txi = tile - tyi * tx;
-    TileGeo o;
-    o.oy0 = tyi * TH; o.ox0 = txi * TW;
-    o.iy0 = o.oy0 * STRIDE - lv.pt; o.ix0 = o.ox0 * STRIDE - lv.pl;
-    o.H = lv.H; o.W = lv.W; o.Ho = lv.Ho; o.Wo = lv.Wo;
-    o.in_base = lv.in_off + (long long)frame * lv.H * lv.W;
-    o.out_base = lv.out_off + (long long)frame * lv.Ho * lv.Wo;
-    return o;
-}
-
-template <int STRIDE, int NTO, int KQT, int TW, bool RESID>
-__global__ __launch_bounds__(512) void k_block_fused3p(FusedArgs a, Geom g, int total_tiles) {
-    constexpr int TH = 8;
-    constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3, IWP = (IW % 2 == 0) ? IW : (IW + 3) / 4 * 4, NPOS = IH * IWP;
-    constexpr int MT_IN = (NPOS + 31) / 32, OPIX = TH * TW, MT_OUT = OPIX / 32, CEP = 36;
-    constexpr int EP = ((MT_IN * 32 / 4) % 2 == 1) ? MT_IN * 32 : MT_IN * 32 + 4;
-    constexpr TileSplit SP = split_tiles(MT_IN, MT_OUT, KQT * 4, NTO * 16);
-    constexpr int MTW = SP.maxc;
-    static_assert(MT_OUT <= 4 && OPIX % 32 == 0 && MTW <= 5, "output tile / halo tile split");
-    __shared__ __attribute__((aligned(16))) float ET[2][32 * EP];
-    __shared__ __attribute__((aligned(16))) float D[2][OPIX * CEP];
-    __shared__ f32x4 WP[2][4 * NTO * 64];      // projection weights of a chunk (B fragments, [kq][nt][lane])
-    __shared__ f32x4 WB[2][KQT * 64];          // expansion weights of a chunk ([kq][lane])
-    __shared__ float WS[2][64];                // expansion BN scale [0..31] / shift [32..63] of a chunk
-    const int lane = threadIdx.x & 63, hw_wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
-    // role mapping experiment (ablate bit 4): MFMA waves = even hardware waves instead of waves 0-3
-    const bool alt = (a.ablate & 16) != 0;
-    const bool is_mfma = alt ? !(hw_wave & 1) : hw_wave < 4;
-    const int wave = alt ? (hw_wave >> 1) : (hw_wave & 3);
-    const int n = min(a.ex_nt_total, (a.cexp + 31) >> 5);                         // chunks per tile
-    const int m_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    if (m_tiles <= 0) return;
-    const int n_phases = m_tiles * n + 2;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    if (is_mfma) {
-        // ================================================================ MFMA waves
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int mt_first = wave == 0 ? SP.first[0] : wave == 1 ? SP.first[1] : wave == 2 ? SP.first[2] : SP.first[3];
-        const int mt_count = wave == 0 ? SP.count[0] : wave == 1 ? SP.count[1] : wave == 2 ? SP.count[2] : SP.count[3];
-        f32x16 pacc[NTO];
-#pragma unroll
-        for (int nt = 0; nt < NTO; ++nt) pacc[nt] = zero16;
-        f32x4 afrag[MTW][KQT], anext[MTW][KQT];
-        auto load_a = [&](int tile_id) {
-            const TileGeo tg = decode_tile<STRIDE, TH, TW>(g, tile_id);
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-                const int pp = (mt_first + m) * 32 + r;
-                const int hy = pp / IWP, hx = pp - hy * IWP;
-                const int iy = tg.iy0 + hy, ix = tg.ix0 + hx;
-                const bool ok = m < mt_count && hy < IH && hx < IW && iy >= 0 && iy < tg.H && ix >= 0 && ix < tg.W;
-                const float* ap = a.X + (tg.in_base + (long long)(ok ? iy * tg.W + ix : 0)) * a.cin + half * 4;
-#pragma unroll
-                for (int kq = 0; kq < KQT; ++kq) anext[m][kq] = ok ? *(const f32x4*)(ap + kq * 8) : zero4;
-            }
-        };
-        load_a(blockIdx.x);
-        __syncthreads();                                                   // WB[0] / WS[0] published by the depthwise waves
-        int t1 = 0, c1 = 0;          // stage-1 position (tile, chunk) of this phase
-        int t3 = 0, c3 = 0;          // stage-3 position, valid from phase 2 on
-        for (int ph = 0; ph < n_phases; ++ph) {
-            const int buf = ph & 1;
-            const bool s1 = t1 < m_tiles;
-            if (s1 && c1 == 0) {                                           // new tile: take the prefetched input, prefetch the next one
-#pragma unroll
-                for (int m = 0; m < MTW; ++m)
-#pragma unroll
-                    for (int kq = 0; kq < KQT; ++kq) afrag[m][kq] = anext[m][kq];
-                if (t1 + 1 < m_tiles) load_a(blockIdx.x + (t1 + 1) * gridDim.x);
-            }
-            f32x4 resid[RESID ? NTO : 1][4];                             // residual of the tile that completes in this phase
-            const bool last3 = ph >= 2 && c3 == n - 1;
-            TileGeo tg3;
-            if (last3) tg3 = decode_tile<STRIDE, TH, TW>(g, blockIdx.x + t3 * gridDim.x);
-            if (RESID && last3 && wave < MT_OUT) {
-                const float* rbase = a.X + tg3.in_base * a.cin;            // same spatial size, cin == cout
-                const int opl = wave * 32 + 4 * half;
-#pragma unroll
-                for (int nt = 0; nt < NTO; ++nt)
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int op = opl + (reg & 3) + 8 * (reg >> 2);
-                        const int oy = min(tg3.oy0 + op / TW, tg3.Ho - 1), ox = min(tg3.ox0 + op % TW, tg3.Wo - 1);
-                        const int col = min(nt * 32 + r, a.cout - 1);
-                        resid[RESID ? nt : 0][reg >> 2][reg & 3] = rbase[(oy * tg3.Wo + ox) * a.cout + col];
-                    }
-            }
-            if (ph >= 2 && wave < MT_OUT && !(a.ablate & 4)) {            // stage 3: projection of chunk c3 of tile t3
-                const int kqc = min(4, (a.cexp - c3 * 32) >> 3);
-                const float* dp = D[buf] + (wave * 32 + r) * CEP + half * 4;
-#pragma unroll
-                for (int kq = 0; kq < 4; ++kq) {
-                    if (kq < kqc) {
-                        const f32x4 av = *(const f32x4*)(dp + kq * 8);
-                        f32x4 bv[NTO];
-#pragma unroll
-                        for (int nt = 0; nt < NTO; ++nt) bv[nt] = WP[buf][(kq * NTO + nt) * 64 + lane];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-#pragma unroll
-                            for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], pacc[nt], 0, 0, 0);
-                    }
-                }
-            }
-            if (s1 && !(a.ablate & 1)) {                                   // stage 1: expansion of chunk c1 of tile t1 -> ET[buf]
-                float* et = ET[buf] + r * EP + 4 * half + mt_first * 32;
-                f32x4 bcur[KQT];
-#pragma unroll
-                for (int kq = 0; kq < KQT; ++kq) bcur[kq] = WB[buf][kq * 64 + lane];
-                const float sc = WS[buf][r], sh = WS[buf][32 + r];
-                auto chain = [&](int m) {
-                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][0][0], bcur[0][0], zero16, 0, 0, 0);
-#pragma unroll
-                    for (int kq = 0; kq < KQT; ++kq)
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            if (kq + t > 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][kq][t], bcur[kq][t], acc, 0, 0, 0);
-                    return acc;
-                };
-                auto epi = [&](int m, const f32x16& acc) {
-                    if (a.ablate & 32) { if (acc[0] == 1234.5f) et[m] = acc[1]; return; }    // diagnostics: MFMA chains only
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f32x4 v;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = relu6f(fmaf(acc[4 * q + i], sc, sh));
-                        *(f32x4*)(et + m * 32 + 8 * q) = v;
-                    }
-                };
-                auto stage1 = [&](auto cnt) {
-                    constexpr int CNT = decltype(cnt)::value;
-                    if constexpr (CNT > 0 && CNT <= MTW) {
-                        f32x16 prev = chain(0);
-#pragma unroll
-                        for (int m = 1; m < CNT; ++m) {
-                            const f32x16 cur = chain(m);
-                            epi(m - 1, prev);
-                            prev = cur;
-                            constexpr int NM = KQT * 4, VPM = (32 + NM - 1) / NM, DSI = NM / 4;
-#pragma unroll
-                            for (int i = 0; i < NM; ++i) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-                                if (i % DSI == DSI - 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                            }
-                        }
-                        epi(CNT - 1, prev);
-                    }
-                };
-                switch (mt_count) {
-                    case 1: stage1(std::integral_constant<int, 1>{}); break;
-                    case 2: stage1(std::integral_constant<int, 2>{}); break;
-                    case 3: stage1(std::integral_constant<int, 3>{}); break;
-                    case 4: stage1(std::integral_constant<int, 4>{}); break;
-                    case 5: stage1(std::integral_constant<int, 5>{}); break;
-                    default: break;
-                }
-            }
-            if (last3 && wave < MT_OUT) {                                  // tile t3 complete: BN (+ residual), store, reset
-                float* obase = a.out + tg3.out_base * a.cout;
-                const bool full = tg3.oy0 + TH <= tg3.Ho && tg3.ox0 + TW <= tg3.Wo;
-                const int opl = wave * 32 + 4 * half;
-#pragma unroll
-                for (int nt = 0; nt < NTO; ++nt) {
-                    const int col = nt * 32 + r;
-                    if (col < a.cout && !(a.ablate & 8)) {
-                        const float psc = a.pr_scale[col], psh = a.pr_shift[col];
-#pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) {
-                            const int op = opl + (reg & 3) + 8 * (reg >> 2);
-                            const int oy = tg3.oy0 + op / TW, ox = tg3.ox0 + op % TW;
-                            if (full || (oy < tg3.Ho && ox < tg3.Wo)) {
-                                float v = fmaf(pacc[nt][reg], psc, psh);
-                                if (RESID) v = v + resid[RESID ? nt : 0][reg >> 2][reg & 3];
-                                obase[(oy * tg3.Wo + ox) * a.cout + col] = v;
-                            }
-                        }
-                    }
-                    pacc[nt] = zero16;
-                }
-            }
-            if (s1) { if (++c1 == n) { c1 = 0; ++t1; } }
-            if (ph >= 2) { if (++c3 == n) { c3 = 0; ++t3; } }
-            __syncthreads();
-        }
-    } else {
-        // ================================================================ depthwise waves
-        const int vt = wave * 64 + lane, dc = vt & 31, doy = vt >> 5;    // role: (channel lane, output row)
-        float dwt[9], dsc = 0.f, dsh = 0.f, dwn[9], dscn = 0.f, dshn = 0.f;
-        bool dact = false, dactn = false;
-        f32x4 preg[NTO];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) { dwt[t] = 0.f; dwn[t] = 0.f; }
-#pragma unroll
-        for (int j = 0; j < NTO; ++j) preg[j] = zero4;
-        int t2 = 0, c2 = 0;          // stage-2 position, valid from phase 1 on
-        int cf = 0;                  // chunk whose projection / depthwise weights are fetched in this phase (the stage-1 chunk)
-        // expansion weights run two phases ahead of their stage 1: fetched at ph-2, published at ph-1 into WB[ph & 1]
-        constexpr int BJ = (KQT * 64 + 255) / 256;
-        f32x4 breg[BJ];
-        float sreg = 0.f;
-        auto fetch_b = [&](int chunk) {
-#pragma unroll
-            for (int j = 0; j < BJ; ++j) {
-                const int idx = vt + j * 256, kq = idx >> 6, ln = idx & 63;
-                breg[j] = idx < KQT * 64 ? a.Wex[((size_t)kq * a.ex_nt_total + chunk) * 64 + ln] : zero4;
-            }
-            if (vt < 64) sreg = vt < 32 ? a.ex_scale[chunk * 32 + vt] : a.ex_shift[chunk * 32 + vt - 32];
-        };
-        auto publish_b = [&](int b) {
-#pragma unroll
-            for (int j = 0; j < BJ; ++j) { const int idx = vt + j * 256; if (idx < KQT * 64) WB[b][idx] = breg[j]; }
-            if (vt < 64) WS[b][vt] = sreg;
-        };
-        fetch_b(0); publish_b(0);
-        int cb = n > 1 ? 1 : 0;      // chunk fetched next
-        fetch_b(cb); if (++cb == n) cb = 0;
-        __syncthreads();
-        int iy0 = 0, ix0 = 0, H = 0, W = 0;
-        bool interior = true;
-        for (int ph = 0; ph < n_phases; ++ph) {
-            const bool work = ph >= 1 && ph <= m_tiles * n;
-            publish_b((ph + 1) & 1);                                       // expansion weights of the next phase's chunk
-            fetch_b(cb); if (++cb == n) cb = 0;
-            if (work) {                                                    // publish what was fetched one phase ago
-#pragma unroll
-                for (int j = 0; j < NTO; ++j) WP[(ph - 1) & 1][vt + j * 256] = preg[j];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) dwt[t] = dwn[t];
-                dsc = dscn; dsh = dshn; dact = dactn;
-                if (c2 == 0) {
-                    const TileGeo tg = decode_tile<STRIDE, TH, TW>(g, blockIdx.x + t2 * gridDim.x);
-                    iy0 = tg.iy0; ix0 = tg.ix0; H = tg.H; W = tg.W;
-                    interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= H && ix0 + IW <= W;
-                }
-            }
-            if (ph < m_tiles * n) {                                        // fetch chunk cf: projection weights, depthwise taps / BN
-                const int kqc = min(4, (a.cexp - cf * 32) >> 3);
-#pragma unroll
-                for (int j = 0; j < NTO; ++j) {
-                    const int idx = vt + j * 256, kq = idx / (NTO * 64);
-                    preg[j] = kq < kqc ? a.Wpr[(size_t)cf * 4 * NTO * 64 + idx] : zero4;
-                }
-                const int dch = cf * 32 + dc;
-                dactn = dch < a.cexp;
-                if (dactn) {
-                    const float* wdp = a.Wdw + dch;
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) dwn[t] = wdp[t * a.cexp];
-                    dscn = a.dw_scale[dch]; dshn = a.dw_shift[dch];
-                }
-                if (++cf == n) cf = 0;
-            }
-            if (work && !(a.ablate & 2)) {                                 // stage 2 of chunk c2 of tile t2: ET -> D
-                const int buf = (ph - 1) & 1;
-                float row[3][IWP];
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const float* rp = ET[buf] + dc * EP + (doy * STRIDE + ky) * IWP;
-                    if constexpr (IWP % 4 == 0) {
-#pragma unroll
-                        for (int qx = 0; qx < IWP / 4; ++qx) {
-                            const f32x4 v = *(const f32x4*)(rp + qx * 4);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) row[ky][qx * 4 + j] = v[j];
-                        }
-                    } else {
-#pragma unroll
-                        for (int qx = 0; qx < IWP / 2; ++qx) {
-                            const float2 v = *(const float2*)(rp + qx * 2);
-                            row[ky][qx * 2] = v.x; row[ky][qx * 2 + 1] = v.y;
-                        }
-                    }
-                }
-                if (!interior) {
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const bool rok = (unsigned)(iy0 + doy * STRIDE + ky) < (unsigned)H;
-#pragma unroll
-                        for (int x = 0; x < IW; ++x) row[ky][x] = (rok && (unsigned)(ix0 + x) < (unsigned)W) ? row[ky][x] : 0.0f;
-                    }
-                }
-                float* dp = D[buf] + (doy * TW) * CEP + dc;
-#pragma unroll
-                for (int ox = 0; ox < TW; ++ox) {
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) acc = fmaf(row[ky][ox * STRIDE + kx], dwt[ky * 3 + kx], acc);
-                    dp[ox * CEP] = dact ? relu6f(fmaf(acc, dsc, dsh)) : 0.0f;
-                }
-            }
-            if (work) { if (++c2 == n) { c2 = 0; ++t2; } }
-            __syncthreads();
-        }
-    }
-}
-
-template <int STRIDE, int NTO, int KQT, int TW>
-static hipError_t launch_block_fused3p_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
-    if (a.residual && (a.cin != a.cout || STRIDE != 1)) return hipErrorInvalidValue;
-    constexpr int TH = 8;
-    int total = 0;
-    for (int l = 0; l < g.n_levels; ++l) total += ((g.lv[l].Wo + TW - 1) / TW) * ((g.lv[l].Ho + TH - 1) / TH) * g.batch;
-    static const int n_cu = []() { const char* v = getenv("HFNET_FUSE3_WGS"); return v ? atoi(v) : 256; }();
-    const int grid = total < n_cu ? total : n_cu;
-    if (grid <= 0) return hipSuccess;
-    if (a.residual) hipLaunchKernelGGL((k_block_fused3p<STRIDE, NTO, KQT, TW, true>), dim3(grid), dim3(512), 0, s, a, g, total);
-    else hipLaunchKernelGGL((k_block_fused3p<STRIDE, NTO, KQT, TW, false>), dim3(grid), dim3(512), 0, s, a, g, total);
-    return hipGetLastError();
-}
-
-template <int STRIDE, int NTO, int KQT, int TW>
-static hipError_t launch_block_fused3_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
-    constexpr int TH = 8;
-    int maxtiles = 0;
-    for (int l = 0; l < g.n_levels; ++l) maxtiles = max(maxtiles, ((g.lv[l].Wo + TW - 1) / TW) * ((g.lv[l].Ho + TH - 1) / TH));
-    dim3 grid(maxtiles, g.n_levels * g.batch);
-    hipLaunchKernelGGL((k_block_fused3<STRIDE, NTO, KQT, TW>), grid, dim3(512), 0, s, a, g);
-    return hipGetLastError();
-}
-
-// ---- layer_2 (expanded_conv with expansion factor 1: no expand conv, hf_net.py:31-33): depthwise 3x3 +
-// BN + ReLU6 on CIN channels, then the 1x1 projection CIN -> COUT + BN, stride 1.  Its tensors are the
-// largest of the network (1/2 resolution) and its arithmetic the smallest: one thread per output pixel on
-// the vector ALUs, projection weights in LDS (wave-uniform reads), the fma chain over the CIN depthwise
-// outputs in logical channel order (the oracle's), 16-byte fully coalesced loads and stores.  HBM-bound.
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void k_block_noexpand(const float* __restrict__ X, float* __restrict__ out,
-                                                        const float* __restrict__ wd /*[9][CIN] phys*/, const float* __restrict__ dsc,
-                                                        const float* __restrict__ dsh, const float* __restrict__ wp /*[CIN logical][COUT phys]*/,
-                                                        const float* __restrict__ psc, const float* __restrict__ psh, Geom g) {
-    // 16x16 output tile per workgroup; the 18x18 input halo tile is staged through LDS with coalesced 96-byte
-    // pixel rows, so every input byte crosses HBM ~1.27x instead of up to 9x.  Weight indices are compile-time
-    // constants: those loads are wave-uniform and go through the scalar cache into SGPR fma operands.
-    constexpr int T = 16, SH = T + 2, CP = CIN + 4;
-    __shared__ __attribute__((aligned(16))) float tile[SH * SH * CP];
-    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
-    const LevelGeom lv = g.lv[level];
-    const int tiles_x = (lv.Wo + T - 1) / T;
-    if ((int)blockIdx.x >= tiles_x * ((lv.Ho + T - 1) / T)) return;
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-    const int oy0 = tyi * T, ox0 = txi * T;
-    const float* xin = X + (lv.in_off + (long long)frame * lv.H * lv.W) * CIN;
-    // a halo row is SH pixels = SH * CIN / 4 consecutive 16-byte pieces in memory: thread = (row parity, piece), so the
-    // piece -> (pixel, channel quad) split is done once per thread and a load costs an add
-    {
-        constexpr int PPR = SH * (CIN / 4);                    // pieces per halo row (108)
-        static_assert(2 * PPR <= 256, "two halo rows per pass");
-        const int rsel = threadIdx.x >= PPR ? 1 : 0, piece = threadIdx.x - rsel * PPR;
-        const int hx = piece / (CIN / 4), c4 = piece - hx * (CIN / 4);
-        const int ix = ox0 - lv.pl + hx;
-        const bool xok = threadIdx.x < 2 * PPR && ix >= 0 && ix < lv.W;
-        const float* colp = xin + (long long)(xok ? ix : 0) * CIN + c4 * 4;
-        float* tp = tile + hx * CP + c4 * 4;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        if (threadIdx.x < 2 * PPR) {
-#pragma unroll
-            for (int r2 = 0; r2 < SH / 2; ++r2) {
-                const int hy = r2 * 2 + rsel, iy = oy0 - lv.pt + hy;
-                const bool ok = xok && iy >= 0 && iy < lv.H;
-                const f32x4 v = *(const f32x4*)(colp + (long long)(ok ? iy : 0) * lv.W * CIN);
-                *(f32x4*)(tp + hy * SH * CP) = ok ? v : zero;
-            }
-        }
-    }
-    __syncthreads();
-    const int ty = threadIdx.x / T, tx = threadIdx.x - ty * T;
-    // The weights are wave-uniform scalar loads (SGPR fma operands).  Left alone, the scheduler hoists all ~650 of them
-    // to the top and spills them to VGPR lanes (v_writelane / v_readlane: more VALU work than the convolution itself),
-    // so they are fetched one step ahead of their use and scheduling barriers keep each batch where it is.
-    float d[CIN];
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) d[c] = 0.0f;
-    float wc[CIN], wn[CIN];
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) wc[c] = wd[c];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {                    // out-of-image taps are zeros in the tile: fma(0, w, d) == d
-        if (tap < 8) {
-#pragma unroll
-            for (int c = 0; c < CIN; ++c) wn[c] = wd[(tap + 1) * CIN + c];
-        } else {
-#pragma unroll
-            for (int c = 0; c < CIN; ++c) wn[c] = dsc[c];
-        }
-        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-        const float* xp = tile + ((ty + tap / 3) * SH + tx + tap % 3) * CP;
-#pragma unroll
-        for (int c4 = 0; c4 < CIN / 4; ++c4) {
-            const f32x4 xv = *(const f32x4*)(xp + c4 * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) d[c4 * 4 + j] = fmaf(xv[j], wc[c4 * 4 + j], d[c4 * 4 + j]);
-        }
-        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < CIN; ++c) wc[c] = wn[c];
-    }
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) wn[c] = dsh[c];
-    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) d[c] = relu6f(fmaf(d[c], wc[c], wn[c]));
-    __builtin_amdgcn_sched_barrier(0);
-    float acc[COUT];
-#pragma unroll
-    for (int n = 0; n < COUT; ++n) acc[n] = 0.0f;
-    float pc[COUT], pn[COUT];
-#pragma unroll
-    for (int n = 0; n < COUT; ++n) pc[n] = wp[n];
-#pragma unroll
-    for (int k = 0; k < CIN; ++k) {                       // logical channel k sits in physical slot phys(k)
-        if (k + 1 < CIN) {
-#pragma unroll
-            for (int n = 0; n < COUT; ++n) pn[n] = wp[(k + 1) * COUT + n];
-        }
-        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-        const int pk = (k & ~7) | ((k & 1) << 2) | ((k & 7) >> 1);
-        const float dk = d[pk];
-#pragma unroll
-        for (int n = 0; n < COUT; ++n) acc[n] = fmaf(dk, pc[n], acc[n]);
-        // pin this row's fmas here (pure arithmetic is not ordered by the barriers: the DAG scheduler would sink all of
-        // it below the last load and every row would be spilled in between)
-        static_assert(COUT == 16, "accumulator pinning is written for 16 outputs");
-        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
-                          "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int n = 0; n < COUT; ++n) pc[n] = pn[n];
-    }
-#pragma unroll
-    for (int n = 0; n < COUT; ++n) pc[n] = psc[n];
-    // pc now holds the projection BN scale
-    // output through LDS: a tile row is T pixels x COUT channels = one contiguous 1 KB run of the output tensor;
-    // written back as consecutive 16-byte pieces per lane instead of four 64-byte-strided stores per thread
-    constexpr int OP = COUT + 4;                           // 20 words: conflict-free b128
-    __syncthreads();                                       // every thread is done reading the input tile
-    float* ot = tile;
-#pragma unroll
-    for (int n4 = 0; n4 < COUT / 4; ++n4) {
-        f32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[n4 * 4 + j], pc[n4 * 4 + j], psh[n4 * 4 + j]);
-        *(f32x4*)(ot + threadIdx.x * OP + n4 * 4) = v;
-    }
-    __syncthreads();
-    float* obase = out + (lv.out_off + (long long)frame * lv.Ho * lv.Wo) * COUT;
-    const int cols = min(T, lv.Wo - ox0);                  // valid pixels per tile row
-#pragma unroll
-    for (int k = 0; k < COUT / 4; ++k) {
-        const int q = threadIdx.x + k * 256;               // piece of the tile: row = q / (T * COUT / 4)
-        const int row = q / (T * COUT / 4), rem = q - row * (T * COUT / 4);
-        const int px = rem / (COUT / 4), part = rem - px * (COUT / 4);
-        if (oy0 + row < lv.Ho && px < cols)
-            *(f32x4*)(obase + ((long long)(oy0 + row) * lv.Wo + ox0 + px) * COUT + part * 4) = *(const f32x4*)(ot + (row * T + px) * OP + part * 4);
-    }
-}
-
-// ---- stem + layer_2 in one launch: u8 image -> [(x-128)/128, conv 3x3/2 1->CS, BN, ReLU6] -> depthwise 3x3 +
-// BN + ReLU6 -> 1x1 CS->COUT + BN.  The half-resolution CS-channel stem tensor (the largest activation of the
-// network: 8.7 MB per 752x480 frame) is produced into LDS for an 18x18 halo tile and consumed from there; only
-// the u8 image is read and the COUT-channel layer_2 output written.  Vector-ALU kernel (K = 9 / 9 / CS), one
-// thread per output pixel of a 16x16 tile; every fma chain is the oracle's.
-struct StemBlockArgs {
-    const float* stem_w; const float* stem_scale; const float* stem_shift;      // [9][CS] physical order
-    const float* dw_w; const float* dw_scale; const float* dw_shift;            // [9][CS] physical
-    const float* pr_w; const float* pr_scale; const float* pr_shift;            // [CS logical][COUT physical]
-    float* out;
-};
-
-// Built on k_block_noexpand: its halo-tile load is replaced by the stem
-// convolution of the 18 x 18 halo positions straight from the u8 image (wave-uniform scalar weights; the 324 positions
-// x 2 channel halves are 12 wave-sized work units, three per wave), everything after it is k_block_noexpand unchanged.
-// The 24-channel half-resolution stem tensor -- 690 MB per 32-frame step, written by one kernel and read by the next --
-// never exists.
-template <int CS, int COUT>
-__global__ __launch_bounds__(256) void k_stem_block2(ImageSet imgs, const float* __restrict__ stem_w, const float* __restrict__ stem_scale,
-                                                     const float* __restrict__ stem_shift, const float* __restrict__ wd,
-                                                     const float* __restrict__ dsc, const float* __restrict__ dsh, const float* __restrict__ wp,
-                                                     const float* __restrict__ psc, const float* __restrict__ psh, float* __restrict__ out,
-                                                     Geom gs /*image -> stem*/, Geom gb /*stem -> layer_2*/) {
-    constexpr int T = 16, SH = T + 2, SP = SH * SH, CP = CS + 4, CH = CS / 2;
-    static_assert(CS == 24 && COUT == 16, "written for the 0.75-width network");
-    __shared__ __attribute__((aligned(16))) float tile[SP * CP];
-    const int image = blockIdx.y, level = image / gs.batch, frame = image - level * gs.batch;
-    const LevelGeom ls = gs.lv[level], lb = gb.lv[level];     // ls: H,W image (cropped), Ho,Wo stem; lb: H,W stem, Ho,Wo out (same size)
-    const int tiles_x = (lb.Wo + T - 1) / T;
-    if ((int)blockIdx.x >= tiles_x * ((lb.Ho + T - 1) / T)) return;
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-    const int oy0 = tyi * T, ox0 = txi * T;
-    const int sy0 = oy0 - lb.pt, sx0 = ox0 - lb.pl;            // first stem row / col of the halo tile
-    const uint8_t* img = imgs.ptr[level] + (long long)frame * imgs.frame_stride[level];
-    const int rs = imgs.row_stride[level];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // ---- stem on the halo tile: unit u = wave + 4 * pass covers positions [54 * (u % 6), +54) and channel half u / 6
-    constexpr int CHUNK = SP / 6;                              // 54 positions per unit
-    static_assert(CHUNK * 6 == SP && CHUNK <= 64, "halo positions split into six wave-sized chunks");
-    // tiles whose halo and image patch lie inside the maps (the vast majority) skip every bounds check and select
-    const int iy_first = sy0 * 2 - ls.pt, ix_first = sx0 * 2 - ls.pl;
-    const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + SH <= ls.Ho && sx0 + SH <= ls.Wo && iy_first >= 0 && ix_first >= 0 &&
-                          iy_first + 2 * SH < ls.H && ix_first + 2 * SH < ls.W;     // uniform
-    auto stem_passes = [&](auto interior_tag) {
-        constexpr bool INT = decltype(interior_tag)::value;
-#pragma unroll 1
-        for (int pass = 0; pass < 3; ++pass) {
-            const int u = wave + 4 * pass, chunk = u % 6, hsel = u / 6;          // uniform
-            const int p = chunk * CHUNK + min(lane, CHUNK - 1);
-            const int hy = p / SH, hx = p - hy * SH;
-            const int sy = sy0 + hy, sx = sx0 + hx;
-            const bool in = INT || (sy >= 0 && sy < ls.Ho && sx >= 0 && sx < ls.Wo);
-            float px[9];
-            if (INT) {
-                const uint8_t* ip = img + (long long)(sy * 2 - ls.pt) * rs + (sx * 2 - ls.pl);
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) px[ky * 3 + kx] = ((float)ip[ky * rs + kx] - 128.0f) * 0.0078125f;
-            } else {
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int iy = sy * 2 - ls.pt + ky, ix = sx * 2 - ls.pl + kx;
-                        const bool ok = in && iy >= 0 && iy < ls.H && ix >= 0 && ix < ls.W;
-                        const float raw = (float)img[(long long)(ok ? iy : 0) * rs + (ok ? ix : 0)];
-                        px[ky * 3 + kx] = ok ? (raw - 128.0f) * 0.0078125f : 0.0f;
-                    }
-            }
-            // weights of four channels at a time as wave-uniform 16-byte scalar loads (36 + 8 SGPRs per group: a second set
-            // prefetched ahead does not fit next to the geometry without spilling to VGPR lanes)
-            const f32x4* __restrict__ w4 = (const f32x4*)(stem_w + hsel * CH);    // uniform; row t is w4[t * CS / 4 + group]
-            const f32x4* __restrict__ sc4 = (const f32x4*)(stem_scale + hsel * CH);
-            const f32x4* __restrict__ sh4 = (const f32x4*)(stem_shift + hsel * CH);
-            float* tp = tile + p * CP + hsel * CH;
-#pragma unroll
-            for (int grp = 0; grp < CH / 4; ++grp) {
-                f32x4 wq[9];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) wq[t] = w4[t * (CS / 4) + grp];
-                const f32x4 scq = sc4[grp], shq = sh4[grp];
-                asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-                f32x4 r;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) acc = fmaf(px[t], wq[t][j], acc);
-                    float v = relu6f(fmaf(acc, scq[j], shq[j]));
-                    if (!INT) {
-                        asm volatile("" : "+v"(v));                                // computed by every lane: a select, not a branch
-                        v = in ? v : 0.0f;                                         // outside the stem map: the depthwise conv's zero padding
-                    }
-                    r[j] = v;
-                }
-                if (lane < CHUNK) *(f32x4*)(tp + grp * 4) = r;
-                asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-    if (interior) stem_passes(std::true_type{}); else stem_passes(std::false_type{});
-    __syncthreads();
-    const int ty = threadIdx.x / T, tx = threadIdx.x - ty * T;
-    constexpr int CIN = CS;
-    float d[CIN];
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) d[c] = 0.0f;
-    float wc[CIN], wn[CIN];
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) wc[c] = wd[c];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {                    // (see k_block_noexpand for the weight staging)
-        if (tap < 8) {
-#pragma unroll
-            for (int c = 0; c < CIN; ++c) wn[c] = wd[(tap + 1) * CIN + c];
-        } else {
-#pragma unroll
-            for (int c = 0; c < CIN; ++c) wn[c] = dsc[c];
-        }
-        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-        const float* xp = tile + ((ty + tap / 3) * SH + tx + tap % 3) * CP;
-#pragma unroll
-        for (int c4 = 0; c4 < CIN / 4; ++c4) {
-            const f32x4 xv = *(const f32x4*)(xp + c4 * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) d[c4 * 4 + j] = fmaf(xv[j], wc[c4 * 4 + j], d[c4 * 4 + j]);
-        }
-        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < CIN; ++c) wc[c] = wn[c];
-    }
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) wn[c] = dsh[c];
-    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) d[c] = relu6f(fmaf(d[c], wc[c], wn[c]));
-    __builtin_amdgcn_sched_barrier(0);
-    float acc[COUT];
-#pragma unroll
-    for (int n = 0; n < COUT; ++n) acc[n] = 0.0f;
-    float pc[COUT], pn[COUT];
-#pragma unroll
-    for (int n = 0; n < COUT; ++n) pc[n] = wp[n];
-#pragma unroll
-    for (int k = 0; k < CIN; ++k) {                       // logical channel k sits in physical slot phys(k)
-        if (k + 1 < CIN) {
-#pragma unroll
-            for (int n = 0; n < COUT; ++n) pn[n] = wp[(k + 1) * COUT + n];
-        }
-        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-        const int pk = (k & ~7) | ((k & 1) << 2) | ((k & 7) >> 1);
-        const float dk = d[pk];
-#pragma unroll
-        for (int n = 0; n < COUT; ++n) acc[n] = fmaf(dk, pc[n], acc[n]);
-        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
-                          "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int n = 0; n < COUT; ++n) pc[n] = pn[n];
-    }
-#pragma unroll
-    for (int n = 0; n < COUT; ++n) pc[n] = psc[n];
-    constexpr int OP = COUT + 4;
-    __syncthreads();                                       // every thread is done reading the stem tile
-    float* ot = tile;
-#pragma unroll
-    for (int n4 = 0; n4 < COUT / 4; ++n4) {
-        f32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[n4 * 4 + j], pc[n4 * 4 + j], psh[n4 * 4 + j]);
-        *(f32x4*)(ot + threadIdx.x * OP + n4 * 4) = v;
-    }
-    __syncthreads();
-    float* obase = out + (lb.out_off + (long long)frame * lb.Ho * lb.Wo) * COUT;
-    const int cols = min(T, lb.Wo - ox0);
-#pragma unroll
-    for (int k = 0; k < COUT / 4; ++k) {
-        const int q = threadIdx.x + k * 256;
-        const int row = q / (T * COUT / 4), rem = q - row * (T * COUT / 4);
-        const int px2 = rem / (COUT / 4), part = rem - px2 * (COUT / 4);
-        if (oy0 + row < lb.Ho && px2 < cols)
-            *(f32x4*)(obase + ((long long)(oy0 + row) * lb.Wo + ox0 + px2) * COUT + part * 4) = *(const f32x4*)(ot + (row * T + px2) * OP + part * 4);
-    }
-}
-
-bool stem_block_fusable(int stem_out, const BlockPack& b) {
-    return stem_out == 24 && !b.has_expand && b.stride == 1 && !b.residual && b.cin == 24 && b.cout == 16 && b.pr_logical != nullptr;
-}
-
-hipError_t launch_stem_block(const ImageSet& imgs, const float* stem_w, const float* stem_scale, const float* stem_shift, const BlockPack& b,
-                             float* out, const Geom& g_stem, const Geom& g_block, hipStream_t s) {
-    StemBlockArgs a;
-    a.stem_w = stem_w; a.stem_scale = stem_scale; a.stem_shift = stem_shift;
-    a.dw_w = b.dw.w; a.dw_scale = b.dw.scale; a.dw_shift = b.dw.shift;
-    a.pr_w = b.pr_logical; a.pr_scale = b.pr.scale; a.pr_shift = b.pr.shift;
-    a.out = out;
-    int maxtiles = 0;
-    for (int l = 0; l < g_block.n_levels; ++l) maxtiles = max(maxtiles, ((g_block.lv[l].Wo + 15) / 16) * ((g_block.lv[l].Ho + 15) / 16));
-    hipLaunchKernelGGL((k_stem_block2<24, 16>), dim3(maxtiles, g_block.n_levels * g_block.batch), dim3(256), 0, s, imgs, a.stem_w, a.stem_scale,
-                                    a.stem_shift, a.dw_w, a.dw_scale, a.dw_shift, a.pr_w, a.pr_scale, a.pr_shift, a.out, g_stem, g_block);
-    return hipGetLastError();
-}
-
-template <int STRIDE, int TH, int TW>
-static hipError_t launch_block_fused_t(const FusedArgs& a, const Geom& g, int nto, hipStream_t s) {
-    int maxtiles = 0;
-    for (int l = 0; l < g.n_levels; ++l) maxtiles = max(maxtiles, ((g.lv[l].Wo + TW - 1) / TW) * ((g.lv[l].Ho + TH - 1) / TH));
-    dim3 grid(maxtiles, g.n_levels * g.batch);
-    switch (nto) {
-        case 1: hipLaunchKernelGGL((k_block_fused<STRIDE, TH, TW, 1>), grid, dim3(256), 0, s, a, g); break;
-        case 2: hipLaunchKernelGGL((k_block_fused<STRIDE, TH, TW, 2>), grid, dim3(256), 0, s, a, g); break;
-        case 3: hipLaunchKernelGGL((k_block_fused<STRIDE, TH, TW, 3>), grid, dim3(256), 0, s, a, g); break;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-bool block_fusable(const BlockPack& b) {
-    const int nto = (b.cout + 31) / 32;
-    if (nto > 3 || (b.stride != 1 && b.stride != 2)) return false;
-    if (!b.has_expand && b.expand > 32) return false;
-    if (b.stride == 2 && b.cin > 24 && !(b.cin == 96 && nto == 2)) return false;   // wide stride-2 blocks: only layer_8's shape has a (register-diet) variant
-    return b.cin % 8 == 0 && b.expand % 8 == 0;
-}
-
-hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, const Geom& g, hipStream_t s) {
-    FusedArgs a;
-    a.X = X;
-    a.Wex = (const f32x4*)b.ex.w; a.ex_scale = b.ex.scale; a.ex_shift = b.ex.shift; a.ex_nt_total = b.ex.nt_total;
-    a.Wdw = b.dw.w; a.dw_scale = b.dw.scale; a.dw_shift = b.dw.shift;
-    a.Wpr = (const f32x4*)b.pr.w; a.pr_scale = b.pr.scale; a.pr_shift = b.pr.shift; a.pr_nt_total = b.pr.nt_total;
-    { const char* v = getenv("HFNET_FUSE_ABLATE"); a.ablate = v ? atoi(v) : 0; }
-    a.out = out; a.cin = b.cin; a.cexp = b.expand; a.cout = b.cout; a.residual = b.residual; a.has_expand = b.has_expand;
-    const int nto = (b.cout + 31) / 32;
-    static const bool use_v2 = []() { const char* v = getenv("HFNET_FUSE_V2"); return v ? atoi(v) != 0 : true; }();
-    if (use_v2 && !b.has_expand && b.stride == 1 && !b.residual && b.cin == 24 && b.cout == 16 && b.pr_logical) {
-        int maxtiles = 0;
-        for (int l = 0; l < g.n_levels; ++l) maxtiles = max(maxtiles, ((g.lv[l].Wo + 15) / 16) * ((g.lv[l].Ho + 15) / 16));
-        hipLaunchKernelGGL((k_block_noexpand<24, 16>), dim3(maxtiles, g.n_levels * g.batch), dim3(256), 0, s, a.X, a.out, a.Wdw, a.dw_scale,
-                           a.dw_shift, (const float*)b.pr_logical, a.pr_scale, a.pr_shift, g);
-        return hipGetLastError();
-    }
-    const bool use_v3 = []() { const char* v = getenv("HFNET_FUSE_V3"); return v ? atoi(v) != 0 : false; }();   // experiment; read per launch so tests can switch it
-    if (use_v3 && b.has_expand && b.pr.nt_total == nto) {
-        const int kq = b.cin / 8, st = b.stride;
-        const int tw3 = []() { const char* v = getenv("HFNET_FUSE3_S2_TW"); return v ? atoi(v) : 12; }();
-        const bool persist = []() { const char* v = getenv("HFNET_FUSE3_PERSIST"); return v ? atoi(v) != 0 : true; }();
-        if (persist) {
-            if (st == 2 && kq == 2 && nto == 1) return launch_block_fused3p_t<2, 1, 2, 8>(a, g, s);     // (8x12 tiles do not fit the LDS)
-            if (st == 2 && kq == 3 && nto == 1) return launch_block_fused3p_t<2, 1, 3, 8>(a, g, s);
-            if (st == 1 && kq == 3 && nto == 1) return launch_block_fused3p_t<1, 1, 3, 16>(a, g, s);
-            if (st == 1 && kq == 3 && nto == 2) return launch_block_fused3p_t<1, 2, 3, 16>(a, g, s);
-            if (st == 1 && kq == 6 && nto == 3) return launch_block_fused3p_t<1, 3, 6, 16>(a, g, s);
-            if (st == 1 && kq == 6 && nto == 2) return launch_block_fused3p_t<1, 2, 6, 16>(a, g, s);
-        }
-        if (st == 2 && kq == 2 && nto == 1) return tw3 == 12 ? launch_block_fused3_t<2, 1, 2, 12>(a, g, s) : launch_block_fused3_t<2, 1, 2, 8>(a, g, s);
-        if (st == 2 && kq == 3 && nto == 1) return tw3 == 12 ? launch_block_fused3_t<2, 1, 3, 12>(a, g, s) : launch_block_fused3_t<2, 1, 3, 8>(a, g, s);
-        if (st == 1 && kq == 3 && nto == 1) return launch_block_fused3_t<1, 1, 3, 16>(a, g, s);
-        if (st == 1 && kq == 3 && nto == 2) return launch_block_fused3_t<1, 2, 3, 16>(a, g, s);
-        if (st == 1 && kq == 6 && nto == 3) return launch_block_fused3_t<1, 3, 6, 16>(a, g, s);
-        if (st == 1 && kq == 6 && nto == 2) return launch_block_fused3_t<1, 2, 6, 16>(a, g, s);
-        if (st == 1 && kq == 9 && nto == 3) return launch_block_fused3_t<1, 3, 9, 16>(a, g, s);
-    }
-    if (use_v2) {
-        const int kq = b.cin / 8, st = b.stride;
-        if (!b.has_expand && st == 1 && nto == 1) return launch_block_fused2_t<1, 1, 0, false>(a, g, s);
-        static const int tw2 = []() { const char* v = getenv("HFNET_FUSE_S2_TW"); return v ? atoi(v) : 8; }();   // 8x8 tiles: 3 workgroups per CU beat 8x12 at 2
-        if (b.has_expand && st == 2 && kq == 2 && nto == 1 && tw2 == 12) return launch_block_fused2_t<2, 1, 2, true, 12>(a, g, s);
-        if (b.has_expand && st == 2 && kq == 3 && nto == 1 && tw2 == 12) return launch_block_fused2_t<2, 1, 3, true, 12>(a, g, s);
-        if (b.has_expand && st == 2 && kq == 2 && nto == 1) return launch_block_fused2_t<2, 1, 2, true>(a, g, s);
-        if (b.has_expand && st == 1 && kq == 3 && nto == 1) return launch_block_fused2_t<1, 1, 3, true>(a, g, s);
-        if (b.has_expand && st == 2 && kq == 3 && nto == 1) return launch_block_fused2_t<2, 1, 3, true>(a, g, s);
-        if (b.has_expand && st == 1 && kq == 3 && nto == 2) return launch_block_fused2_t<1, 2, 3, true>(a, g, s);
-        if (b.has_expand && st == 1 && kq == 6 && nto == 3) return launch_block_fused2_t<1, 3, 6, true>(a, g, s);
-        if (b.has_expand && st == 1 && kq == 6 && nto == 2) return launch_block_fused2_t<1, 2, 6, true>(a, g, s);
-        if (b.has_expand && st == 1 && kq == 9 && nto == 3) return launch_block_fused2_t<1, 3, 9, true>(a, g, s);
-        if (b.has_expand && st == 2 && kq == 12 && nto == 2) return launch_block_fused2_t<2, 2, 12, true>(a, g, s);
-    }
-    if (b.stride == 1) return launch_block_fused_t<1, 8, 16>(a, g, nto, s);
-    return launch_block_fused_t<2, 8, 8>(a, g, nto, s);
-}
-
 // =========================================================================== depthwise 3x3
 // One thread per (output pixel, 4 channels).  HBM / L2-bound: 9 (stride 1) or 2.25 (stride 2)
 // cached reads and one write per output element.
-__global__ __launch_bounds__(256) void k_depthwise(const float* __restrict__ in, const float* __restrict__ w,
-                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+__global__ __launch_bounds__(256) void k_depthwise(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
                                                    float* __restrict__ out, int C, int stride, Geom g) {
     const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
     const LevelGeom lv = g.lv[level];
@@ -2172,7 +660,7 @@ __global__ __launch_bounds__(256) void k_depthwise(const float* __restrict__ in,
     const int op = (int)(idx / c4), cq = (int)(idx - (long long)op * c4);
     const int oy = op / lv.Wo, ox = op - oy * lv.Wo;
     const float* ip = in + (lv.in_off + (long long)frame * lv.H * lv.W) * C + cq * 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = *(const f32x4*)(bias + cq * 4);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int iy = oy * stride - lv.pt + ky;
@@ -2187,10 +675,9 @@ __global__ __launch_bounds__(256) void k_depthwise(const float* __restrict__ in,
             for (int j = 0; j < 4; ++j) acc[j] = fmaf(xv[j], wv[j], acc[j]);
         }
     }
-    const f32x4 sc = *(const f32x4*)(scale + cq * 4), sh = *(const f32x4*)(shift + cq * 4);
     f32x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = relu6f(fmaf(acc[j], sc[j], sh[j]));
+    for (int j = 0; j < 4; ++j) o[j] = relu6f(acc[j]);
     *(f32x4*)(out + (lv.out_off + (long long)frame * lv.Ho * lv.Wo + op) * C + cq * 4) = o;
 }
 
@@ -2198,7 +685,7 @@ hipError_t launch_depthwise(const float* in, const DwPack& dp, int stride, float
     long long maxwork = 0;
     for (int l = 0; l < g.n_levels; ++l) maxwork = max(maxwork, (long long)g.lv[l].Ho * g.lv[l].Wo * (dp.c / 4));
     dim3 grid((unsigned)((maxwork + 255) / 256), g.n_levels * g.batch);
-    hipLaunchKernelGGL(k_depthwise, grid, dim3(256), 0, s, in, dp.w, dp.scale, dp.shift, out, dp.c, stride, g);
+    hipLaunchKernelGGL(k_depthwise, grid, dim3(256), 0, s, in, dp.w, dp.bias, out, dp.c, stride, g);
     return hipGetLastError();
 }
 

@@ -2,6 +2,9 @@
 // The memberships 1x1 conv runs on the MFMA pointwise kernel; everything after it is here.
 #include "kernels.hpp"
 
+#include <type_traits>
+#include <utility>
+
 namespace hfnet {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -106,7 +109,11 @@ __global__ __launch_bounds__(256) void k_vlad_norm(const float* __restrict__ raw
     if (vlad_tap) for (int i = threadIdx.x; i < N; i += 256) vlad_tap[(long long)frame * N + i] = v[i];
     ss = block_sumsq_tree256(v, N, red);
     inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
-    for (int i = threadIdx.x; i < N; i += 256) out[(long long)frame * N + i] = v[i] * inv;
+    // handed to the FC kernel in its slot order within every group of 16 inputs (FcPack, common.hpp)
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const int rr = i & 15;
+        out[(long long)frame * N + ((i & ~15) | ((rr & 3) << 2) | (rr >> 2))] = v[i] * inv;
+    }
 }
 
 hipError_t launch_vlad(const float* feat, const float* memb, const float* clusters, float* vlad_tap, float* out, float* scratch,
@@ -118,53 +125,60 @@ hipError_t launch_vlad(const float* feat, const float* memb, const float* cluste
     return hipGetLastError();
 }
 
-// y[f][j] = tree256_dot(x[f], wt[j]) + b[j]  (slim.fully_connected, layers.py:99-107).
-// A wave owns JW = 4 outputs and up to FB = 8 frames per pass: lane l holds the tree256 partials
-// 4l..4l+3 of every (output, frame) pair; per 256 inputs it issues 4 weight + FB activation 16-byte
-// loads for 4*FB*4 fmas, so the activations (L2-resident) are not re-streamed once per output.  The
-// 126 MB of transposed weights are read once per pass: HBM-bound.
-__global__ __launch_bounds__(256) void k_fc(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
-                                            float* __restrict__ y, int frames, int n_in, int n_out) {
-    constexpr int JW = 4, FB = 8;
-    const int j0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * JW;
-    if (j0 >= n_out) return;
-    const int lane = threadIdx.x & 63;
-    const float* w[JW];
+// y[f][j] = b[j] + sum_i x[f][i] * W[i][j], i ascending: slim.fully_connected (layers.py:99-107) as ONE GEMM over the
+// frames of the batch on v_mfma_f32_16x16x4_f32 (bit-for-bit the k-ordered fma chain from C = b[j], like every other
+// matmul of the path).  A wave owns 16 frames x 16 outputs and walks the whole chain: n_in / 4 dependent MFMAs (40 cycles
+// each) -- 32 us for 7680 inputs, about what streaming the 126 MB of weights from HBM takes; the 512 waves of a 32-frame
+// batch put one chain on every other SIMD.  Operands of four consecutive MFMAs are one 16-byte load per lane (FcPack,
+// common.hpp); NBUF groups are in flight per lane to cover the HBM latency.  The weights cross HBM once per batch: the two
+// 16-frame row tiles of a column tile run on the same XCD at the same time.
+template <class F, int... I>
+__device__ __forceinline__ void fc_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void fc_static_for(F&& f) { fc_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int NBUF>
+__global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                 float* __restrict__ y, int frames, int n_in, int n_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ctiles = n_out >> 4, ct = blockIdx.x * 4 + wave, rt = blockIdx.y;
+    if (ct >= ctiles) return;
+    const int row = min(rt * 16 + (lane & 15), frames - 1);
+    const f32x4* __restrict__ ap = (const f32x4*)(x + (long long)row * n_in) + (lane >> 4);
+    const f32x4* __restrict__ wp = (const f32x4*)w + (size_t)ct * 64 + lane;
+    const size_t wstep = (size_t)ctiles * 64;
+    const int KG = n_in >> 4;
+    const float b = bias[ct * 16 + (lane & 15)];
+    f32x4 acc = {b, b, b, b};
+    f32x4 av[NBUF], bv[NBUF];
+    auto load = [&](int kg, auto buf_tag) {
+        constexpr int buf = decltype(buf_tag)::value;
+        kg = min(kg, KG - 1);                          // unconditional (see k_pointwise_deep)
+        av[buf] = ap[kg * 4];
+        bv[buf] = wp[(size_t)kg * wstep];
+    };
+    auto compute = [&](int kg, auto buf_tag) {
+        constexpr int buf = decltype(buf_tag)::value;
+        if (kg < KG) {                                 // uniform
 #pragma unroll
-    for (int jj = 0; jj < JW; ++jj) w[jj] = wt + (long long)min(j0 + jj, n_out - 1) * n_in + lane * 4;
-    for (int f0 = 0; f0 < frames; f0 += FB) {
-        const int nf = min(FB, frames - f0);
-        f32x4 p[JW][FB];
-#pragma unroll
-        for (int jj = 0; jj < JW; ++jj)
-#pragma unroll
-            for (int f = 0; f < FB; ++f) p[jj][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int q = 0; q < n_in; q += 256) {
-            f32x4 wv[JW], xv[FB];
-#pragma unroll
-            for (int jj = 0; jj < JW; ++jj) wv[jj] = *(const f32x4*)(w[jj] + q);
-#pragma unroll
-            for (int f = 0; f < FB; ++f) xv[f] = *(const f32x4*)(x + (long long)(f0 + min(f, nf - 1)) * n_in + q + lane * 4);
-#pragma unroll
-            for (int jj = 0; jj < JW; ++jj)
-#pragma unroll
-                for (int f = 0; f < FB; ++f)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) p[jj][f][c] = fmaf(xv[f][c], wv[jj][c], p[jj][f][c]);
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][t], bv[buf][t], acc, 0, 0, 0);
         }
+    };
+    fc_static_for<NBUF - 1>([&](auto i) { load(decltype(i)::value, i); });
+    for (int kg = 0; kg < KG; kg += NBUF) {
+        fc_static_for<NBUF>([&](auto i) {
+            constexpr int I = decltype(i)::value;
+            load(kg + I + NBUF - 1, std::integral_constant<int, (I + NBUF - 1) % NBUF>{});
+            __builtin_amdgcn_sched_barrier(0);
+            compute(kg + I, i);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    const int col = ct * 16 + (lane & 15);
 #pragma unroll
-        for (int jj = 0; jj < JW; ++jj)
-#pragma unroll
-            for (int f = 0; f < FB; ++f) {
-                f32x4 t = p[jj][f];
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) t[c] = t[c] + __shfl_xor(t[c], off, 64);
-                }
-                const float a = t[0] + t[2], b = t[1] + t[3];
-                if (lane == 0 && f < nf && j0 + jj < n_out) y[(long long)(f0 + f) * n_out + j0 + jj] = (a + b) + bias[j0 + jj];
-            }
+    for (int reg = 0; reg < 4; ++reg) {
+        const int rr = rt * 16 + (lane >> 4) * 4 + reg;
+        if (rr < frames) y[(long long)rr * n_out + col] = acc[reg];
     }
 }
 
@@ -176,12 +190,11 @@ __global__ __launch_bounds__(256) void k_l2norm_vec(const float* __restrict__ in
     for (int i = threadIdx.x; i < n; i += 256) out[(long long)blockIdx.x * n + i] = v[i] * inv;
 }
 
-hipError_t launch_fc_l2(const float* x, const float* wt, const float* bias, float* y_raw, float* out, int frames, int n_in,
-                        int n_out, hipStream_t s) {
+hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* y_raw, float* out, int frames, hipStream_t s) {
     if (frames <= 0) return hipSuccess;
-    if (n_in % 256 != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_fc, dim3((n_out + 15) / 16), dim3(256), 0, s, x, wt, bias, y_raw, frames, n_in, n_out);
-    hipLaunchKernelGGL(k_l2norm_vec, dim3(frames), dim3(256), 0, s, y_raw, out, n_out);
+    if (fc.n_in % 16 || fc.n_out % 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_fc_mfma<16>, dim3((fc.n_out / 16 + 3) / 4, (frames + 15) / 16), dim3(256), 0, s, x, fc.w, fc.bias, y_raw, frames, fc.n_in, fc.n_out);
+    hipLaunchKernelGGL(k_l2norm_vec, dim3(frames), dim3(256), 0, s, y_raw, out, fc.n_out);
     return hipGetLastError();
 }
 

@@ -43,7 +43,9 @@ int WeightFile::load(const char* path) {
     for (uint32_t i = 0; i < n; ++i) {
         RawEntry e;
         std::memcpy(&e, blob.data() + 16 + (size_t)i * sizeof(RawEntry), sizeof e);
-        if (e.ndim > 4 || e.offset + e.nbytes > blob.size() || (e.offset & 3)) { set_error("'%s': bad entry %u", path, i); return HFNET_ERR_IO; }
+        const size_t table_end = 16 + (size_t)n * sizeof(RawEntry);
+        if (e.ndim > 4 || e.offset < table_end || e.offset > blob.size() || e.nbytes > blob.size() - e.offset || (e.offset & 3)) {
+            set_error("'%s': bad entry %u", path, i); return HFNET_ERR_IO; }
         HostTensor t;
         e.name[95] = 0;
         t.name = e.name;
@@ -67,18 +69,22 @@ namespace {
 
 struct Folded { std::vector<float> scale, shift; };
 
-// slim.batch_norm (inference) as y = fma(x, scale, shift); the same float expression as the
-// oracle (oracle/hfnet_oracle.c fold_bn): scale = gamma / sqrt(var + 1e-3), shift = beta - mean*scale
+// slim.batch_norm (inference): y = x * scale + shift; the same float expressions as the oracle
+// (oracle/hfnet_oracle.c fold_bn): scale = gamma / sqrt(var + 1e-3), shift = beta - mean*scale.  The caller folds the
+// scale into the weights (w * scale, one f32 rounding) and starts the accumulators at the shift.  gamma is optional:
+// slim.batch_norm defaults to scale=False and the NetVLAD memberships conv is built outside the mobilenet arg_scope
+// (hfnet/models/utils/layers.py:71-76), so a real checkpoint has no gamma there.
 int fold_bn(const WeightFile& wf, const std::string& scope, int c, Folded& out) {
     const HostTensor* g = wf.find(scope + "/BatchNorm/gamma");
     const HostTensor* b = wf.find(scope + "/BatchNorm/beta");
     const HostTensor* m = wf.find(scope + "/BatchNorm/moving_mean");
     const HostTensor* v = wf.find(scope + "/BatchNorm/moving_variance");
-    if (!g || !b || !m || !v || g->dims[0] != c) { set_error("weights: BatchNorm of '%s' missing or mis-sized", scope.c_str()); return HFNET_ERR_IO; }
+    if (!b || !m || !v || b->dims[0] != c || m->dims[0] != c || v->dims[0] != c || (g && g->dims[0] != c)) {
+        set_error("weights: BatchNorm of '%s' missing or mis-sized", scope.c_str()); return HFNET_ERR_IO; }
     out.scale.resize(c);
     out.shift.resize(c);
     for (int i = 0; i < c; ++i) {
-        const float s = g->data[i] / sqrtf(v->data[i] + 1e-3f);
+        const float s = (g ? g->data[i] : 1.0f) / sqrtf(v->data[i] + 1e-3f);
         const float ms = m->data[i] * s;
         out.scale[i] = s;
         out.shift[i] = b->data[i] - ms;
@@ -118,7 +124,7 @@ static int pack_conv(DeviceWeights& dw, const float* W, int taps, int cin, int n
     cp.nt_per_block = choose_nt(tiles);
     cp.nt_total = (tiles + cp.nt_per_block - 1) / cp.nt_per_block * cp.nt_per_block;
     const int KQ = taps * cin / 8;
-    std::vector<float> w((size_t)KQ * cp.nt_total * 64 * 4, 0.f), sc((size_t)cp.nt_total * 32, 0.f), sh((size_t)cp.nt_total * 32, 0.f);
+    std::vector<float> w((size_t)KQ * cp.nt_total * 64 * 4, 0.f), sh((size_t)cp.nt_total * 32, 0.f);
     for (int kq = 0; kq < KQ; ++kq) {
         const int tap = (kq * 8) / cin, c0 = (kq * 8) % cin;
         for (int nt = 0; nt < cp.nt_total; ++nt)
@@ -128,18 +134,16 @@ static int pack_conv(DeviceWeights& dw, const float* W, int taps, int cin, int n
                 const int nl = out_phys ? logical_of_phys(j) : j;
                 for (int t = 0; t < 4; ++t) {
                     const int cl = c0 + 2 * t + half;   // logical input channel of MFMA t, k = half
-                    w[(((size_t)kq * cp.nt_total + nt) * 64 + lane) * 4 + t] = W[((size_t)tap * cin + cl) * n + nl];
+                    w[(((size_t)kq * cp.nt_total + nt) * 64 + lane) * 4 + t] = W[((size_t)tap * cin + cl) * n + nl] * scale_l[nl];
                 }
             }
     }
     for (int j = 0; j < n; ++j) {
         const int nl = out_phys ? logical_of_phys(j) : j;
-        sc[j] = scale_l[nl];
         sh[j] = shift_l[nl];
     }
     HF_TRY(upload(dw, w, &cp.w));
-    HF_TRY(upload(dw, sc, &cp.scale));
-    HF_TRY(upload(dw, sh, &cp.shift));
+    HF_TRY(upload(dw, sh, &cp.bias));
     return HFNET_OK;
 }
 
@@ -153,7 +157,7 @@ static int pack_conv_bn(DeviceWeights& dw, const WeightFile& wf, const std::stri
     return pack_conv(dw, w->data, taps, cin, n, f.scale.data(), f.shift.data(), out_phys, cp);
 }
 
-// 1x1 conv with biases and no normaliser (hf_net.py:66-72): y = acc + b == fma(acc, 1, b)
+// 1x1 conv with biases and no normaliser (hf_net.py:66-72): scale 1 (w * 1.0f is exact), accumulators start at b
 static int pack_conv_bias(DeviceWeights& dw, const WeightFile& wf, const std::string& scope, ConvPack& cp, int* n_out) {
     const HostTensor* w = wf.find(scope + "/weights");
     const HostTensor* b = wf.find(scope + "/biases");
@@ -171,17 +175,15 @@ static int pack_dw(DeviceWeights& dw, const WeightFile& wf, const std::string& s
     if (c % 8) { set_error("depthwise '%s': %d channels not a multiple of 8", scope.c_str(), c); return HFNET_ERR_IO; }
     Folded f;
     HF_TRY(fold_bn(wf, scope, c, f));
-    std::vector<float> wp((size_t)9 * c), sc(c), sh(c);
+    std::vector<float> wp((size_t)9 * c), sh(c);
     for (int p = 0; p < c; ++p) {
         const int l = logical_of_phys(p);
-        for (int t = 0; t < 9; ++t) wp[(size_t)t * c + p] = w->data[(size_t)t * c + l];
-        sc[p] = f.scale[l];
+        for (int t = 0; t < 9; ++t) wp[(size_t)t * c + p] = w->data[(size_t)t * c + l] * f.scale[l];
         sh[p] = f.shift[l];
     }
     dp.c = c;
     HF_TRY(upload(dw, wp, &dp.w));
-    HF_TRY(upload(dw, sc, &dp.scale));
-    HF_TRY(upload(dw, sh, &dp.shift));
+    HF_TRY(upload(dw, sh, &dp.bias));
     return HFNET_OK;
 }
 
@@ -195,16 +197,14 @@ int DeviceWeights::build(const WeightFile& wf) {
         if (stem_out % 8 || stem_out > 64) { set_error("stem width %d unsupported", stem_out); return HFNET_ERR_IO; }
         Folded f;
         HF_TRY(fold_bn(wf, "MobilenetV2/Conv", stem_out, f));
-        std::vector<float> wp((size_t)9 * stem_out), sc(stem_out), sh(stem_out);
+        std::vector<float> wp((size_t)9 * stem_out), sh(stem_out);
         for (int p = 0; p < stem_out; ++p) {
             const int l = logical_of_phys(p);
-            for (int t = 0; t < 9; ++t) wp[(size_t)t * stem_out + p] = w->data[(size_t)t * stem_out + l];
-            sc[p] = f.scale[l];
+            for (int t = 0; t < 9; ++t) wp[(size_t)t * stem_out + p] = w->data[(size_t)t * stem_out + l] * f.scale[l];
             sh[p] = f.shift[l];
         }
         HF_TRY(upload(*this, wp, &stem_w));
-        HF_TRY(upload(*this, sc, &stem_scale));
-        HF_TRY(upload(*this, sh, &stem_shift));
+        HF_TRY(upload(*this, sh, &stem_bias));
     }
     int cin = stem_out;
     for (int i = 0; i < 17; ++i) {
@@ -222,9 +222,14 @@ int DeviceWeights::build(const WeightFile& wf) {
         b.residual = (b.stride == 1 && b.cin == b.cout);   // conv_blocks.py:304-311
         if (!b.has_expand) {
             const HostTensor* pw = wf.find(scope + "/project/weights");
+            Folded pf;
+            HF_TRY(fold_bn(wf, scope + "/project", b.cout, pf));
             std::vector<float> wl((size_t)b.expand * b.cout);
             for (int k = 0; k < b.expand; ++k)
-                for (int n = 0; n < b.cout; ++n) wl[(size_t)k * b.cout + n] = pw->data[(size_t)k * b.cout + logical_of_phys(n)];
+                for (int n = 0; n < b.cout; ++n) {
+                    const int nl = logical_of_phys(n);
+                    wl[(size_t)k * b.cout + n] = pw->data[(size_t)k * b.cout + nl] * pf.scale[nl];
+                }
             HF_TRY(upload(*this, wl, &b.pr_logical));
         }
         cin = b.cout;
@@ -250,13 +255,20 @@ int DeviceWeights::build(const WeightFile& wf) {
     {
         std::vector<float> c(cl->data, cl->data + (size_t)n_clusters * c_global);
         HF_TRY(upload(*this, c, &clusters));
-        const size_t N = (size_t)n_clusters * c_global, G = (size_t)global_dim;
-        std::vector<float> t(N * G);
-        for (size_t i = 0; i < N; ++i)
-            for (size_t j = 0; j < G; ++j) t[j * N + i] = fw->data[i * G + j];
-        HF_TRY(upload(*this, t, &fc_wt));
+        // x @ W + b (layers.py:99-107) as one MFMA GEMM over the frames of a batch (FcPack, common.hpp): the oracle's chain
+        // b[j] + sum_i x[i] * W[i][j], i ascending
+        const int N = n_clusters * c_global, G = global_dim;
+        if (N % 16 || G % 16) { set_error("weights: FC %d -> %d: both must be multiples of 16", N, G); return HFNET_ERR_IO; }
+        std::vector<float> t((size_t)N * G);
+        for (int kg = 0; kg < N / 16; ++kg)
+            for (int ct = 0; ct < G / 16; ++ct)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int tt = 0; tt < 4; ++tt)      // MFMA 4 kg + tt of the chain, k slot lane / 16, column lane % 16
+                        t[((((size_t)kg * (G / 16) + ct) * 64) + lane) * 4 + tt] = fw->data[(size_t)(kg * 16 + 4 * tt + lane / 16) * G + ct * 16 + lane % 16];
+        fc.n_in = N; fc.n_out = G;
+        HF_TRY(upload(*this, t, &fc.w));
         std::vector<float> b(fb->data, fb->data + G);
-        HF_TRY(upload(*this, b, &fc_b));
+        HF_TRY(upload(*this, b, &fc.bias));
     }
     return HFNET_OK;
 }

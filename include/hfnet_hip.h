@@ -14,7 +14,8 @@
  *
  * Numeric contract: fp32 end to end (f32 MFMA, fused multiply-add chains in the order fixed by
  * the CPU oracle, oracle/hfnet_oracle.h) -- keypoint coordinates / match indices / candidate
- * indices are bit-exact against the oracle, float outputs are bit-exact or within 1e-6 abs.
+ * indices are bit-exact against the oracle, float outputs are bit-exact; the one exception is the
+ * batched database scan for >= 8 queries (hfnet_db_query_batch), stated there.
  */
 #ifndef HFNET_HIP_H
 #define HFNET_HIP_H
@@ -61,6 +62,8 @@ typedef struct hfnet_db hfnet_db;                /* == KeyFrameDatabase's descri
 
 const char* hfnet_last_error(void);
 int hfnet_abi_version(void);
+/* hash of the library's sources, compiled in by hfnet_slam_amd/build.py: says which tree a measured binary was built from */
+const char* hfnet_build_id(void);
 /* number of visible HIP devices; HFNET_ERR_DEVICE text in hfnet_last_error() when none */
 int hfnet_device_count(void);
 
@@ -71,6 +74,15 @@ void hfnet_engine_destroy(hfnet_engine* e);
 /* what: 0 stem channels, 1 local (intermediate) channels, 2 global-branch channels,
  *       3 NetVLAD clusters, 4 global descriptor length (4096), 5 device ordinal */
 int hfnet_engine_info(const hfnet_engine* e, int what);
+/* Diagnostics / A-B switches, read when a model or extractor is created from the engine (no environment variables):
+ *   "fuse_blocks" (1)   0: every inverted-residual block as three launches (the tests' reference variant)
+ *   "fuse_max_layer" (14), "fused_variant" (4: wave-autonomous tiles, 2: barrier-phased kernel), "fuse_stem" (1)
+ *   "dense_desc" (0)    1: dense descriptor head instead of the taps of the selected keypoints
+ *   "two_streams" (3)   0 one stream; 1 fork after layer 7; 2 fork after the detector conv; 3 = 2 + deferred join
+ *   "graph" (1), "pinned_frames" (4): host-pointer extractor calls
+ * Every setting produces the same bits (tests/test_gpu_parity.py). */
+int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value);
+int hfnet_engine_get_option(hfnet_engine* e, const char* name, int* value);
 int hfnet_engine_synchronize(hfnet_engine* e);
 /* Stream ordering for on_device callers (no host wait anywhere):
  *  - matcher calls with on_device != 0 run after every on_device extraction enqueued before them

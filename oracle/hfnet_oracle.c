@@ -41,7 +41,10 @@ typedef struct { char name[96]; uint32_t ndim; uint32_t dims[4]; uint64_t offset
 
 _Static_assert(sizeof(hfo_entry) == 136, "container entry layout");
 
-typedef struct { const float* w; float* scale; float* shift; } hfo_convbn; /* scale/shift folded BN */
+/* convolution + inference BatchNorm folded the way inference engines fold it (the reference's default backend,
+ * TensorRT, does the same to the exported graph): w[..., c] *= scale[c] (one f32 rounding per weight) and
+ * bias[c] = shift[c]; the accumulator then STARTS at bias[c].  w is owned. */
+typedef struct { float* w; float* bias; } hfo_convbn;
 
 typedef struct {
     int cin, expand, stride, cout, residual, has_expand;
@@ -71,35 +74,41 @@ static const float* tensor(const hfo_model* m, const char* name, const hfo_entry
     return e ? (const float*)(m->blob + e->offset) : NULL;
 }
 
-/* slim.batch_norm inference folded to y = fma(x, scale, shift):
- *   scale = gamma / sqrt(var + eps), shift = beta - mean * scale */
-static int fold_bn(const hfo_model* m, const char* scope, int c, hfo_convbn* out) {
+/* slim.batch_norm inference: y = x * scale + shift with scale = gamma / sqrt(var + eps), shift = beta - mean * scale,
+ * folded into the convolution: wf[k][c] = w[k][c] * scale[c], bias[c] = shift[c].  gamma is optional: slim.batch_norm
+ * defaults to scale=False, and the NetVLAD memberships conv is built outside the mobilenet arg_scope
+ * (hfnet/models/utils/layers.py:71-76), so a real checkpoint has no gamma there -> 1. */
+static int fold_bn(const hfo_model* m, const char* scope, const float* w, size_t rows, int c, hfo_convbn* out) {
     char nm[160];
     const float *g, *b, *mu, *var;
     snprintf(nm, sizeof nm, "%s/BatchNorm/gamma", scope);           g = tensor(m, nm, NULL);
     snprintf(nm, sizeof nm, "%s/BatchNorm/beta", scope);            b = tensor(m, nm, NULL);
     snprintf(nm, sizeof nm, "%s/BatchNorm/moving_mean", scope);     mu = tensor(m, nm, NULL);
     snprintf(nm, sizeof nm, "%s/BatchNorm/moving_variance", scope); var = tensor(m, nm, NULL);
-    if (!g || !b || !mu || !var) return 0;
-    out->scale = (float*)malloc(sizeof(float) * c);
-    out->shift = (float*)malloc(sizeof(float) * c);
+    if (!b || !mu || !var) return 0;
+    out->w = (float*)malloc(sizeof(float) * rows * (size_t)c);
+    out->bias = (float*)malloc(sizeof(float) * c);
     for (int i = 0; i < c; ++i) {
-        float s = g[i] / sqrtf(var[i] + HFO_BN_EPS);
+        float s = (g ? g[i] : 1.0f) / sqrtf(var[i] + HFO_BN_EPS);
         float ms = mu[i] * s;
-        out->scale[i] = s;
-        out->shift[i] = b[i] - ms;
+        out->bias[i] = b[i] - ms;
+        for (size_t r = 0; r < rows; ++r) out->w[r * (size_t)c + i] = w[r * (size_t)c + i] * s;
     }
     return 1;
 }
 
+/* weights: [..., cout] with cout the last (fastest) dimension in every layout used here (HWIO convs; depthwise
+ * [3,3,C,1] read as [9][C]) */
 static int load_convbn(const hfo_model* m, const char* scope, const char* wname, int cout_dim, hfo_convbn* out, int* cout) {
     char nm[160];
     const hfo_entry* e;
     snprintf(nm, sizeof nm, "%s/%s", scope, wname);
-    out->w = tensor(m, nm, &e);
-    if (!out->w) return 0;
+    const float* w = tensor(m, nm, &e);
+    if (!w) return 0;
     *cout = (int)e->dims[cout_dim];
-    return fold_bn(m, scope, *cout, out);
+    size_t total = 1;
+    for (uint32_t d = 0; d < e->ndim; ++d) total *= e->dims[d];
+    return fold_bn(m, scope, w, total / (size_t)*cout, *cout, out);
 }
 
 hfo_model* hfo_model_load(const char* path) {
@@ -166,7 +175,7 @@ static const float* fc_weights_t(const hfo_model* cm) {
     return m->fc_wt;
 }
 
-static void free_convbn(hfo_convbn* c) { free(c->scale); free(c->shift); }
+static void free_convbn(hfo_convbn* c) { free(c->w); free(c->bias); }
 
 void hfo_model_free(hfo_model* m) {
     if (!m) return;
@@ -232,14 +241,6 @@ static float sumsq_diff_tree256(const float* a, const float* b, int n) {
     return p[0];
 }
 
-static float dot_tree256(const float* a, const float* b, int n) {
-    float p[256];
-    for (int i = 0; i < 256; ++i) p[i] = 0.0f;
-    for (int i = 0; i < n; ++i) p[i & 255] = fmaf(a[i], b[i], p[i & 255]);
-    for (int off = 128; off >= 1; off >>= 1) for (int i = 0; i < off; ++i) p[i] = p[i] + p[i + off];
-    return p[0];
-}
-
 /* tf.nn.l2_normalize over a contiguous vector: x * rsqrt(max(sum x^2, 1e-12)) */
 static void l2_normalize_vec(float* x, int n) {
     float ss = hfo_sumsq_tree256(x, n);
@@ -257,9 +258,9 @@ static void same_pad(int in, int k, int stride, int* out, int* before) {
 
 /* ------------------------------------------------------------------ layers (NHWC, fp32) */
 
-/* act: 0 none, 1 relu6.  scale/shift may be NULL (then bias may be given). */
+/* act: 0 none, 1 relu6.  Every accumulator starts at bias[c] (folded BN shift, or the layer's bias). */
 static void conv2d(const float* x, int h, int w, int cin, const float* wt, int k, int stride, int cout,
-                   const float* scale, const float* shift, const float* bias, int act, float* y, int* ho, int* wo) {
+                   const float* bias, int act, float* y, int* ho, int* wo) {
     int oh, ow, pt, pl;
     same_pad(h, k, stride, &oh, &pt); same_pad(w, k, stride, &ow, &pl);
     *ho = oh; *wo = ow;
@@ -269,7 +270,7 @@ static void conv2d(const float* x, int h, int w, int cin, const float* wt, int k
 #pragma omp for schedule(static)
         for (int oy = 0; oy < oh; ++oy) {
             for (int ox = 0; ox < ow; ++ox) {
-                for (int c = 0; c < cout; ++c) acc[c] = 0.0f;
+                for (int c = 0; c < cout; ++c) acc[c] = bias[c];
                 for (int ky = 0; ky < k; ++ky) {
                     int iy = oy * stride - pt + ky;
                     if (iy < 0 || iy >= h) continue;
@@ -288,8 +289,6 @@ static void conv2d(const float* x, int h, int w, int cin, const float* wt, int k
                 float* yp = y + ((size_t)oy * ow + ox) * cout;
                 for (int c = 0; c < cout; ++c) {
                     float v = acc[c];
-                    if (scale) v = fmaf(v, scale[c], shift[c]);
-                    if (bias) v = v + bias[c];
                     if (act) v = relu6f(v);
                     yp[c] = v;
                 }
@@ -300,7 +299,7 @@ static void conv2d(const float* x, int h, int w, int cin, const float* wt, int k
 }
 
 static void depthwise3x3(const float* x, int h, int w, int c, const float* wt, int stride,
-                         const float* scale, const float* shift, float* y, int* ho, int* wo) {
+                         const float* bias, float* y, int* ho, int* wo) {
     int oh, ow, pt, pl;
     same_pad(h, 3, stride, &oh, &pt); same_pad(w, 3, stride, &ow, &pl);
     *ho = oh; *wo = ow;
@@ -308,7 +307,7 @@ static void depthwise3x3(const float* x, int h, int w, int c, const float* wt, i
     for (int oy = 0; oy < oh; ++oy) {
         for (int ox = 0; ox < ow; ++ox) {
             float* yp = y + ((size_t)oy * ow + ox) * c;
-            for (int ch = 0; ch < c; ++ch) yp[ch] = 0.0f;
+            for (int ch = 0; ch < c; ++ch) yp[ch] = bias[ch];
             for (int ky = 0; ky < 3; ++ky) {
                 int iy = oy * stride - pt + ky;
                 if (iy < 0 || iy >= h) continue;
@@ -320,7 +319,7 @@ static void depthwise3x3(const float* x, int h, int w, int c, const float* wt, i
                     for (int ch = 0; ch < c; ++ch) yp[ch] = fmaf(xp[ch], wp[ch], yp[ch]);
                 }
             }
-            for (int ch = 0; ch < c; ++ch) yp[ch] = relu6f(fmaf(yp[ch], scale[ch], shift[ch]));
+            for (int ch = 0; ch < c; ++ch) yp[ch] = relu6f(yp[ch]);
         }
     }
 }
@@ -335,14 +334,14 @@ static float* run_block(const hfo_block* b, float* x, int* h, int* w) {
     float* e = x;
     if (b->has_expand) {
         e = (float*)malloc(sizeof(float) * (size_t)hh * ww * b->expand);
-        conv2d(x, hh, ww, b->cin, b->ex.w, 1, 1, b->expand, b->ex.scale, b->ex.shift, NULL, 1, e, &th, &tw);
+        conv2d(x, hh, ww, b->cin, b->ex.w, 1, 1, b->expand, b->ex.bias, 1, e, &th, &tw);
     }
     same_pad(hh, 3, b->stride, &oh, &th); same_pad(ww, 3, b->stride, &ow, &tw);
     float* d = (float*)malloc(sizeof(float) * (size_t)oh * ow * b->expand);
-    depthwise3x3(e, hh, ww, b->expand, b->dw.w, b->stride, b->dw.scale, b->dw.shift, d, &oh, &ow);
+    depthwise3x3(e, hh, ww, b->expand, b->dw.w, b->stride, b->dw.bias, d, &oh, &ow);
     if (e != x) free(e);
     float* y = (float*)malloc(sizeof(float) * (size_t)oh * ow * b->cout);
-    conv2d(d, oh, ow, b->expand, b->pr.w, 1, 1, b->cout, b->pr.scale, b->pr.shift, NULL, 0, y, &th, &tw);
+    conv2d(d, oh, ow, b->expand, b->pr.w, 1, 1, b->cout, b->pr.bias, 0, y, &th, &tw);
     free(d);
     if (b->residual) { size_t n = (size_t)oh * ow * b->cout; for (size_t i = 0; i < n; ++i) y[i] = y[i] + x[i]; }
     free(x);
@@ -398,7 +397,7 @@ static void global_head(const hfo_model* m, const float* feat, int h, int w, flo
     const int K = m->n_clusters, D = m->c_global, P = h * w;
     int th, tw;
     float* mem = (float*)malloc(sizeof(float) * (size_t)P * K);
-    conv2d(feat, h, w, D, m->memb.w, 1, 1, K, m->memb.scale, m->memb.shift, NULL, 0, mem, &th, &tw);
+    conv2d(feat, h, w, D, m->memb.w, 1, 1, K, m->memb.bias, 0, mem, &th, &tw);
     for (int p = 0; p < P; ++p) {                                   /* softmax over K */
         float* r = mem + (size_t)p * K;
         float mx = r[0]; for (int k = 1; k < K; ++k) if (r[k] > mx) mx = r[k];
@@ -424,10 +423,16 @@ static void global_head(const hfo_model* m, const float* feat, int h, int w, flo
     l2_normalize_vec(v, K * D);                                     /* layers.py:92 (flatten is K-major) */
     tap_copy(taps, HFO_TAP_VLAD, v, (size_t)K * D);
     l2_normalize_vec(v, K * D);                                     /* layers.py:97 */
-    const int G = m->global_dim, N = K * D;                         /* layers.py:99-107: x @ W + b, tree256 order */
+    const int G = m->global_dim, N = K * D;                         /* layers.py:99-107: x @ W + b as a matmul like any
+                                                                       other: accumulator from b[j], fma over i = 0..N-1 */
     const float* wt = fc_weights_t(m);
 #pragma omp parallel for schedule(static)
-    for (int j = 0; j < G; ++j) out[j] = dot_tree256(v, wt + (size_t)j * N, N) + m->fc_b[j];
+    for (int j = 0; j < G; ++j) {
+        const float* wr = wt + (size_t)j * N;
+        float acc = m->fc_b[j];
+        for (int i = 0; i < N; ++i) acc = fmaf(v[i], wr[i], acc);
+        out[j] = acc;
+    }
     l2_normalize_vec(out, G);                                       /* layers.py:108 */
     free(mem); free(v);
 }
@@ -460,7 +465,7 @@ int hfo_run_local(const hfo_model* m, const uint8_t* img, int h, int w, int stri
         for (int xx = 0; xx < wc; ++xx) x[(size_t)y * wc + xx] = ((float)img[(size_t)y * stride + xx] - 128.0f) / 128.0f;
     int ch, cw;
     float* s = (float*)malloc(sizeof(float) * (size_t)((hc + 1) / 2) * ((wc + 1) / 2) * m->stem_out);
-    conv2d(x, hc, wc, 1, m->stem.w, 3, 2, m->stem_out, m->stem.scale, m->stem.shift, NULL, 1, s, &ch, &cw);
+    conv2d(x, hc, wc, 1, m->stem.w, 3, 2, m->stem_out, m->stem.bias, 1, s, &ch, &cw);
     free(x);
     tap_copy(taps, HFO_TAP_STEM, s, (size_t)ch * cw * m->stem_out);
     x = s;
@@ -475,9 +480,9 @@ int hfo_run_local(const hfo_model* m, const uint8_t* img, int h, int w, int stri
     if (desc_map || (taps && (taps[HFO_TAP_DESC_HIDDEN] || taps[HFO_TAP_DESC_RAW]))) {      /* hf_net.py:74-80 */
         float* t1 = (float*)malloc(sizeof(float) * P * HFO_DESC_DIM);
         float* t2 = (float*)malloc(sizeof(float) * P * HFO_DESC_DIM);
-        conv2d(x, hd, wd, cl, m->desc1.w, 3, 1, HFO_DESC_DIM, m->desc1.scale, m->desc1.shift, NULL, 1, t1, &th, &tw);
+        conv2d(x, hd, wd, cl, m->desc1.w, 3, 1, HFO_DESC_DIM, m->desc1.bias, 1, t1, &th, &tw);
         tap_copy(taps, HFO_TAP_DESC_HIDDEN, t1, P * HFO_DESC_DIM);
-        conv2d(t1, hd, wd, HFO_DESC_DIM, m->desc2_w, 1, 1, HFO_DESC_DIM, NULL, NULL, m->desc2_b, 0, t2, &th, &tw);
+        conv2d(t1, hd, wd, HFO_DESC_DIM, m->desc2_w, 1, 1, HFO_DESC_DIM, m->desc2_b, 0, t2, &th, &tw);
         tap_copy(taps, HFO_TAP_DESC_RAW, t2, P * HFO_DESC_DIM);
         for (size_t p = 0; p < P; ++p) l2_normalize_vec(t2 + p * HFO_DESC_DIM, HFO_DESC_DIM);
         if (desc_map) memcpy(desc_map, t2, sizeof(float) * P * HFO_DESC_DIM);
@@ -486,9 +491,9 @@ int hfo_run_local(const hfo_model* m, const uint8_t* img, int h, int w, int stri
     if (scores_nms || (taps && (taps[HFO_TAP_DET_HIDDEN] || taps[HFO_TAP_LOGITS] || taps[HFO_TAP_SCORES_DENSE]))) {  /* hf_net.py:82-93 */
         float* t1 = (float*)malloc(sizeof(float) * P * m->det_hidden);
         float* lg = (float*)malloc(sizeof(float) * P * HFO_DET_CH);
-        conv2d(x, hd, wd, cl, m->det1.w, 3, 1, m->det_hidden, m->det1.scale, m->det1.shift, NULL, 1, t1, &th, &tw);
+        conv2d(x, hd, wd, cl, m->det1.w, 3, 1, m->det_hidden, m->det1.bias, 1, t1, &th, &tw);
         tap_copy(taps, HFO_TAP_DET_HIDDEN, t1, P * m->det_hidden);
-        conv2d(t1, hd, wd, m->det_hidden, m->det2_w, 1, 1, HFO_DET_CH, NULL, NULL, m->det2_b, 0, lg, &th, &tw);
+        conv2d(t1, hd, wd, m->det_hidden, m->det2_w, 1, 1, HFO_DET_CH, m->det2_b, 0, lg, &th, &tw);
         tap_copy(taps, HFO_TAP_LOGITS, lg, P * HFO_DET_CH);
         float* dense = (float*)malloc(sizeof(float) * (size_t)hc * wc);
         for (int cy = 0; cy < hd; ++cy)

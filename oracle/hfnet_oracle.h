@@ -16,12 +16,13 @@
  * Floating-point contract ("canonical order").  The reference leaves summation order to Eigen /
  * OpenCV SIMD code, i.e. unspecified.  The oracle fixes one order so results are reproducible
  * bit-for-bit by any implementation that follows it:
- *   - convolutions / matmuls: one accumulator per output, started at +0, updated with a fused
- *     multiply-add per term, terms in (ky, kx, cin) order; epilogue y = fma(acc, scale, shift).
+ *   - convolutions / matmuls (the 7680 -> 4096 dimensionality reduction included): inference BatchNorm is folded
+ *     into the layer as inference engines do (w[..., c] *= gamma[c] / sqrt(var[c] + eps), one f32 rounding per weight;
+ *     bias[c] = beta[c] - mean[c] * that scale); one accumulator per output, STARTED AT bias[c], updated with a fused
+ *     multiply-add per term, terms in (ky, kx, cin) order; then ReLU6 where the layer has one.
  *   - short sums (softmax over 65 / 32 channels, NetVLAD over pixels, intra-norm over K):
  *     left to right.
- *   - long vector reductions (L2 norms over 256 / 4096 / 7680 elements, descriptor distances, the
- *     7680 -> 4096 dimensionality-reduction matmul): "tree256" --
+ *   - long vector reductions (L2 norms over 256 / 4096 / 7680 elements, descriptor distances): "tree256" --
  *     256 interleaved partial sums (element i goes to partial i % 256, in increasing i) followed
  *     by a binary tree (stride 128, 64, ..., 1).
  *   - exp() in the softmaxes is hfo_expf below (Cephes-style polynomial, the same family Eigen's

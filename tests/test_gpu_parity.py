@@ -23,21 +23,32 @@ def _eq(name, a, b):
 SIZES = [(64, 96), (120, 160), (133, 171)]   # the last one exercises the crop to multiples of 8 and odd strides
 
 
-VARIANTS = {"default": {}, "unfused_dense": {"HFNET_FUSE_BLOCKS": "0", "HFNET_DENSE_DESC": "1"},
-            "fuse_all": {"HFNET_FUSE_MAX_LAYER": "18"},
-            # wave-specialised (persistent) fused blocks: slower than v2 on gfx950 (f32 MFMA and VALU share one pipe), kept opt-in
-            "fuse_v3": {"HFNET_FUSE_V3": "1", "HFNET_FUSE_MAX_LAYER": "18"},
-            "fuse_v3_np": {"HFNET_FUSE_V3": "1", "HFNET_FUSE3_PERSIST": "0", "HFNET_FUSE3_S2_TW": "12"}}
+# engine options (hfnet_engine_set_option) of the kernel variants: the default (wave-autonomous fused blocks, sparse
+# descriptor head), the reference variant (every block as three launches, dense descriptor head), and the barrier-phased
+# fused kernel for every block shape it covers
+VARIANTS = {"default": {}, "unfused_dense": {"fuse_blocks": 0, "dense_desc": 1}, "fused_v2": {"fused_variant": 2}}
+
+
+@pytest.fixture
+def engine_options(engine):
+    """set engine options for the objects a test creates; the defaults come back afterwards"""
+    saved = engine.options()
+
+    def apply(opts):
+        for k, v in opts.items():
+            engine.set_option(k, v)
+    yield apply
+    for k, v in saved.items():
+        engine.set_option(k, v)
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
 @pytest.mark.parametrize("hw", SIZES)
-def test_layer_taps_bit_exact(engine, oracle_model, hw, variant, monkeypatch):
+def test_layer_taps_bit_exact(engine, oracle_model, hw, variant, engine_options):
     """every kernel variant (fused / unfused blocks, sparse / dense descriptor head) must give the same bits"""
     from hfnet_slam_amd import capi
     from oracle import oracle as O
-    for k, v in VARIANTS[variant].items():
-        monkeypatch.setenv(k, v)
+    engine_options(VARIANTS[variant])
     h, w = hw
     img = synth_image(h, w, 1000 + h)
     m = capi.Model(engine, capi.MODE_LOCAL_AND_GLOBAL, h, w, 500)
@@ -146,11 +157,11 @@ def test_response_ties(weights_ties_path):
     m.close(); e.close()
 
 
-@pytest.mark.parametrize("fuse_stem", ["0", "1"])
+@pytest.mark.parametrize("fuse_stem", [0, 1])
 @pytest.mark.parametrize("cfg", [(160, 120, 300, 3), (200, 152, 500, 4), (96, 96, 64, 1)])
-def test_extractor_matches_oracle(engine, oracle_model, cfg, fuse_stem, monkeypatch):
+def test_extractor_matches_oracle(engine, oracle_model, cfg, fuse_stem, engine_options):
     from hfnet_slam_amd import capi
-    monkeypatch.setenv("HFNET_FUSE_STEM", fuse_stem)
+    engine_options({"fuse_stem": fuse_stem})
     w, h, nf, nl = cfg
     x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, nl, max_batch=2)
     sf, fpl, lw, lh = x.tables()
@@ -345,16 +356,16 @@ def test_batched_triangulation_matches_per_pair_calls(engine):
             _eq("single", m1, rm)
 
 
-@pytest.mark.parametrize("streams", ["0", "1", "2", "3"])
-def test_device_resident_pipeline_matches_host_path(engine, streams, monkeypatch):
+@pytest.mark.parametrize("streams", [0, 1, 2, 3])
+def test_device_resident_pipeline_matches_host_path(engine, streams, engine_options):
     """bench.py's path: on_device extract_batch + batched SearchByBoW over consecutive steps, the global branch on its own
-    stream with the join deferred into the next step (HFNET_TWO_STREAMS=3) -- every step must equal the host-pointer path."""
+    stream with the join deferred into the next step (engine option two_streams = 3) -- every step must equal the host-pointer path."""
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("torch sees no GPU (its HIP runtime must initialise before libhfnet_hip.so: run with -m gpu)")
     from hfnet_slam_amd import capi
     import ctypes as C
-    monkeypatch.setenv("HFNET_TWO_STREAMS", streams)
+    engine_options({"two_streams": streams})
     w, h, nf, B, steps = 192, 144, 300, 3, 4
     dev = torch.device("cuda", 0)
     x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, 3, max_batch=B)
