@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- frames/sec of HF-Net extract + brute-force match, 752x480, 1000 keypoints.
+"""bench.py -- frames/sec of HF-Net extract + brute-force match, 752x480, 1000 keypoints (BASELINE.json).
 
     python bench.py --gpus N --steps K --warmup W            (N == 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one batch of `--batch` synthetic 752x480 frames through the whole front end on one
-GPU: 4-level pyramid (x1.2), HF-Net (MobileNetV2 backbone, detector + descriptor heads, NetVLAD
-on level 0), NMS, per-level top-K (budget 322/268/224/186), bilinear descriptor sampling, then one
-SearchByBoW-style brute-force match (1000 x 1000 x 256, L2 cross-check, < 0.6) of every frame
-against its predecessor.  Inputs are resident in HBM before the timed region; outputs stay in HBM.
-Frames are independent, so N GPUs run N replicas on disjoint frames (weak scaling, no collective
-on the data path); the timed region is bracketed by barrier + device synchronise, MAX over ranks.
+Headline = BASELINE config 2.  One "step" = one batch of `--batch` (512) synthetic 752x480 frames through the whole
+front end on one GPU, in chunks of `--chunk` (32) frames: 4-level pyramid (x1.2), HF-Net (MobileNetV2 backbone,
+detector + descriptor heads, NetVLAD on level 0), NMS, per-level top-K (budget 322/268/224/186), bilinear descriptor
+sampling, then one SearchByBoW-style brute-force match (1000 x 1000 x 256, L2 cross-check, < 0.6) of every frame
+against its predecessor.  Inputs are resident in HBM before the timed region; outputs stay in HBM.  Frames are
+independent, so N GPUs run N replicas on disjoint frames (weak scaling, no collective on the data path); the timed
+region is bracketed by barrier + device synchronise, MAX over ranks.
 
-Rank 0 prints ONE JSON line (contract: see the task description / DESIGN.md section "Measurement").
+The same run also measures, as sub-records of the one JSON line (`configs`), the other BASELINE configs:
+  2-latency  one frame per call through the host-pointer entry points (upload, extract, download, match)
+  2-host-io  the batch path with host buffers on both sides (images up, keypoints / descriptors / global down)
+  3          TUM-VI 512x512 tracking loop: extract + match per frame, every 5th frame a keyframe (database scan +
+             SearchForTriangulation against 30 neighbours)
+  4          all 11 EuRoC sequences (27 049 frames) assigned to the ranks longest-first, per-sequence frame order
+  5          loop-closure stress: 10 000 x 4096 database scans (Q = 1 warm / cold, Q = 64) and 32 1000 x 1000 x 256 matches
+and a time-weighted per-launch roofline table from a dedicated single-stream profiling pass (`roofline.table`).
+Rank 0 prints ONE JSON line (contract: the task description / DESIGN.md section "Measurement").
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -29,28 +38,45 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W_IMG, H_IMG, N_FEAT, N_LEVELS, SCALE, THRESH, TH_LOW = 752, 480, 1000, 4, 1.2, 0.01, 0.6
+W_IMG, H_IMG, N_FEAT, N_LEVELS, SCALE, THRESH, TH_LOW, TH_HIGH = 752, 480, 1000, 4, 1.2, 0.01, 0.6, 0.75
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA (v_mfma_f32_32x32x2_f32)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4)
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic_b32.json")
+ALL_CONFIGS = ["2-latency", "2-host-io", "3", "4", "5"]
 
 
-def layer_work(batch: int):
-    """Algorithmic FLOP and bytes (fp32, each layer reads its input once, writes its output once,
-    reads its weights once -- SURVEY.md 8d) per launch, keyed by the profiler's launch names."""
+# ------------------------------------------------------------------------------------------------ work model
+def layer_work(batch: int, width: int = W_IMG, height: int = H_IMG, n_feat: int = N_FEAT):
+    """Per launch name: (algorithmic FLOP, algorithmic bytes, executed FLOP) for one chunk of `batch` frames.
+    Algorithmic = fp32, every layer reads its input once, writes its output once, reads its weights once (SURVEY.md
+    8d); executed = what the kernels really issue (halo recompute and M-tile padding of the fused blocks)."""
     from hfnet_slam_amd import spec as S
     sp = S.net_spec()
-    sizes = S.level_sizes(W_IMG, H_IMG, N_LEVELS, SCALE)
+    sizes = S.level_sizes(width, height, N_LEVELS, SCALE)
     work = {}
 
-    def add(name, flop, byts):
-        f, b = work.get(name, (0.0, 0.0))
-        work[name] = (f + flop, b + byts)
+    def add(name, flop, byts, executed=None):
+        f, b, x = work.get(name, (0.0, 0.0, 0.0))
+        work[name] = (f + flop, b + byts, x + (flop if executed is None else executed))
+
+    def fused_executed(b, oh, ow):
+        """FLOP the fused block kernel issues for one image: wave tiles of 4 x 8 outputs, expansion of the
+        (3 s + 3) x (7 s + 3) halo in M-tiles of 32 positions, 32-channel chunks (kernels_block.hip)"""
+        s = b.stride
+        tiles = -(-oh // 4) * -(-ow // 8)
+        mt_in = -(-((3 * s + 3) * (7 * s + 3)) // 32)
+        chunks = -(-b.expand // 32)
+        nto = -(-b.cout // 32)
+        mfma = tiles * (chunks * mt_in * (b.cin // 2) + (b.expand // 8) * 4 * nto)       # v_mfma_f32_32x32x2_f32: 4096 FLOP
+        return mfma * 4096.0 + 2.0 * 9 * b.expand * tiles * 32
 
     for lvl, (w, h) in enumerate(sizes):
         hc, wc = S.cropped(h), S.cropped(w)
         ph, pw = S.same_pad(hc, 3, 2)[0], S.same_pad(wc, 3, 2)[0]
         px = ph * pw * batch
         add("stem", 2.0 * 9 * sp.stem_out * px, hc * wc * batch + 4.0 * px * sp.stem_out)
+        if lvl:
+            add("pyramid_resize", 8.0 * h * w * batch, (1.0 + 1.44) * h * w * batch)
         for b in sp.blocks:
             if b.index > 7 and lvl > 0:
                 break
@@ -62,13 +88,17 @@ def layer_work(batch: int):
             add(f"project_L{b.index:02d}", 2.0 * pout * b.expand * b.cout,
                 4.0 * (pout * (b.expand + b.cout * (2 if b.residual else 1)) + b.expand * b.cout))
             # the same block as ONE fused launch: all three layers' FLOP, but only the block input / output cross HBM
-            add(f"block_L{b.index:02d}",
-                (2.0 * pin * b.cin * b.expand if b.expand > b.cin else 0.0) + 2.0 * 9 * pout * b.expand + 2.0 * pout * b.expand * b.cout,
-                4.0 * (pin * b.cin + pout * b.cout * (2 if b.residual else 1) + b.cin * b.expand + 9 * b.expand + b.expand * b.cout))
+            alg = (2.0 * pin * b.cin * b.expand if b.expand > b.cin else 0.0) + 2.0 * 9 * pout * b.expand + 2.0 * pout * b.expand * b.cout
+            add(f"block_L{b.index:02d}", alg,
+                4.0 * (pin * b.cin + pout * b.cout * (2 if b.residual else 1) + b.cin * b.expand + 9 * b.expand + b.expand * b.cout),
+                batch * fused_executed(b, oh, ow) if b.expand > b.cin else alg)
             if b.index == 2:
-                # stem + layer_2 as ONE launch (the default): u8 image in, layer_2 output out
+                # stem + layer_2 as ONE launch (the default): u8 image in, layer_2 output out; the stem is recomputed on
+                # the 18 x 18 halo of every 16 x 16 tile
+                tiles = -(-oh // 16) * -(-ow // 16) * batch
                 add("stem_block_L02", 2.0 * 9 * sp.stem_out * px + 2.0 * 9 * pout * b.expand + 2.0 * pout * b.expand * b.cout,
-                    hc * wc * batch + 4.0 * (pout * b.cout + 9 * sp.stem_out + 9 * b.expand + b.expand * b.cout))
+                    hc * wc * batch + 4.0 * (pout * b.cout + 9 * sp.stem_out + 9 * b.expand + b.expand * b.cout),
+                    tiles * (324 * 2.0 * 9 * sp.stem_out + 256 * (2.0 * 9 * b.expand + 2.0 * b.expand * b.cout)))
             ph, pw = oh, ow
             if b.index == 7:
                 cells = ph * pw * batch
@@ -77,32 +107,46 @@ def layer_work(batch: int):
                 add("pointwise_desc", 2.0 * 256 * 256 * cells, 4.0 * (cells * 512 + 256 * 256))
                 add("l2norm_desc", 3.0 * 256 * cells, 4.0 * cells * 512)
                 add("conv3x3_det", 2.0 * 9 * c7 * 128 * cells, 4.0 * (cells * (c7 + 128) + 9 * c7 * 128))
-                add("pointwise_det", 2.0 * 128 * 65 * cells, 4.0 * (cells * (128 + 65) + 128 * 65))
+                add("pointwise_det", 2.0 * 128 * 65 * cells, 4.0 * (cells * (128 + 65) + 128 * 65), 2.0 * 128 * 96 * cells)
                 add("softmax_d2s", 4.0 * 65 * cells, 4.0 * cells * (65 + 64))
                 add("nms", 2.0 * 3 * 18 * hc * wc * batch, 4.0 * 2 * hc * wc * batch)
         if lvl == 0:
             pg = ph * pw * batch
             add("pointwise_memberships", 2.0 * pg * sp.global_channels * sp.n_clusters, 4.0 * pg * (sp.global_channels + sp.n_clusters))
-            add("vlad", 3.0 * pg * sp.vlad_dim / batch * batch, 4.0 * (pg * (sp.global_channels + sp.n_clusters) + 3 * batch * sp.vlad_dim))
-            add("fc_l2", 2.0 * batch * sp.vlad_dim * sp.global_dim, 4.0 * (sp.vlad_dim * sp.global_dim + batch * (sp.vlad_dim + 2 * sp.global_dim)))
-    # sparse descriptor head: 4 bilinear taps per keypoint (N_FEAT keypoints per frame)
-    rows = 4.0 * N_FEAT * batch
-    work["conv3x3_desc_taps"] = (2.0 * 9 * sp.local_channels * 256 * rows, 4.0 * (rows * (9 * sp.local_channels + 256) + 9 * sp.local_channels * 256))
-    work["pointwise_desc_taps"] = (2.0 * 256 * 256 * rows, 4.0 * (rows * 512 + 256 * 256))
-    work["l2norm_desc_taps"] = (3.0 * 256 * rows, 4.0 * rows * 512)
-    # matcher: all frame pairs of a step in one batched call (prep + GEMM + train pass + finalize)
-    work["match_bow"] = (batch * 2.0 * N_FEAT * N_FEAT * 256, batch * 4.0 * (2 * N_FEAT * 256 + 2 * N_FEAT * N_FEAT))
+            add("vlad", 3.0 * pg * sp.vlad_dim, 4.0 * (pg * (sp.global_channels + sp.n_clusters) + 3 * batch * sp.vlad_dim))
+            add("fc_l2", 2.0 * batch * sp.vlad_dim * sp.global_dim, 4.0 * (sp.vlad_dim * sp.global_dim + batch * (sp.vlad_dim + 2 * sp.global_dim)),
+                2.0 * (-(-batch // 16) * 16) * sp.vlad_dim * sp.global_dim)
+    # sparse descriptor head: 4 bilinear taps per keypoint
+    rows = 4.0 * n_feat * batch
+    work["conv3x3_desc_taps"] = (2.0 * 9 * sp.local_channels * 256 * rows, 4.0 * (rows * (9 * sp.local_channels + 256) + 9 * sp.local_channels * 256),
+                                 2.0 * 9 * sp.local_channels * 256 * rows)
+    work["pointwise_desc_taps"] = (2.0 * 256 * 256 * rows, 4.0 * (rows * 512 + 256 * 256), 2.0 * 256 * 256 * rows)
+    work["sample"] = (8.0 * 256 * n_feat * batch, 4.0 * (rows * 256 + n_feat * batch * 260), 8.0 * 256 * n_feat * batch)
+    work["topk"] = (0.0, 8.0 * 4 * n_feat * batch * 16, 0.0)
+    # matcher: all frame pairs of a chunk in one batched call (prep + GEMM + train pass + finalize)
+    mm = batch * 2.0 * n_feat * n_feat * 256
+    work["match_bow"] = (mm, batch * 4.0 * (2 * n_feat * 256 + 2 * n_feat * n_feat), batch * 2.0 * 1024 * 1024 * 256)
     return work
 
 
+def roofline_entry(flop, byts, seconds):
+    """{bound, achieved, peak, unit, frac} of one launch: the MFMA roof when the arithmetic intensity is above the
+    machine balance (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B), the HBM roof otherwise."""
+    if byts > 0 and flop / byts >= MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+        r = {"bound": "mfma", "achieved": flop / seconds / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s"}
+    else:
+        r = {"bound": "hbm", "achieved": byts / seconds / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    r["frac"] = r["achieved"] / r["peak"]
+    return r
+
+
 def hbm_traffic(launch_name: str, batch: int):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic_b32.json:
-    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command), with the gfx950
-    correction of MI355X_MICROARCH.md (FETCH_SIZE counts 128-byte requests as 64 bytes -> doubled).  None when
-    no pass exists for this kernel / batch size."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic_b32.json")
+    """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate
+    runs of this command, folded by tools/make_traffic.py), with the gfx950 correction of MI355X_MICROARCH.md
+    (FETCH_SIZE counts 128-byte requests as 64 bytes -> doubled).  None when no pass exists for this kernel / chunk size.
+    NOT a measurement of the present run: rocprofv3 cannot run inside the timed process."""
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
             t = json.load(f)
         k = t["kernels"][launch_name]
         if t["batch"] != batch:
@@ -112,20 +156,21 @@ def hbm_traffic(launch_name: str, batch: int):
         return None
 
 
-def make_frames(count: int, first_index: int, kind: str = "uniform") -> np.ndarray:
+# ------------------------------------------------------------------------------------------------ synthetic data
+def make_frames(count: int, first_index: int, kind: str = "uniform", w: int = W_IMG, h: int = H_IMG) -> np.ndarray:
     """seed 1000 + frame index; "uniform" = iid uniform u8, "natural" = sum of 6 octaves of bilinearly
     up-sampled uniform noise, clipped (smooth structures at several scales)"""
-    out = np.empty((count, H_IMG, W_IMG), np.uint8)
+    out = np.empty((count, h, w), np.uint8)
     for i in range(count):
         rng = np.random.default_rng(1000 + first_index + i)
         if kind == "uniform":
-            out[i] = rng.integers(0, 256, (H_IMG, W_IMG), dtype=np.uint8)
+            out[i] = rng.integers(0, 256, (h, w), dtype=np.uint8)
             continue
-        acc = np.zeros((H_IMG, W_IMG), np.float64)
+        acc = np.zeros((h, w), np.float64)
         for o in range(6):
-            gh, gw = 2 + (H_IMG >> (6 - o)), 2 + (W_IMG >> (6 - o))
+            gh, gw = 2 + (h >> (6 - o)), 2 + (w >> (6 - o))
             g = rng.random((gh, gw))
-            ys = np.linspace(0, gh - 1.001, H_IMG); xs = np.linspace(0, gw - 1.001, W_IMG)
+            ys = np.linspace(0, gh - 1.001, h); xs = np.linspace(0, gw - 1.001, w)
             y0 = ys.astype(int); x0 = xs.astype(int); fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
             up = (g[y0][:, x0] * (1 - fy) * (1 - fx) + g[y0][:, x0 + 1] * (1 - fy) * fx + g[y0 + 1][:, x0] * fy * (1 - fx) + g[y0 + 1][:, x0 + 1] * fy * fx)
             acc += up * 0.5 ** (5 - o)
@@ -134,42 +179,350 @@ def make_frames(count: int, first_index: int, kind: str = "uniform") -> np.ndarr
     return out
 
 
-def cpu_baseline(weights_path: str, max_seconds: float = 25.0):
-    """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload, host cores
-    of this box.  Reported, never optimised against."""
+def unit_rows(rng, n, d):
+    a = rng.standard_normal((n, d)).astype(np.float32)
+    return (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(weights_path: str, budget_s: float = 24.0):
+    """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload, host cores of this box: all
+    usable cores (the headline `value`), 4 threads (the reference runs one OpenCV worker per pyramid level,
+    HFextractor.cc:265), and the matcher / database scan on half the cores (the reference gives Eigen nbThreads / 2,
+    System.cc:49).  Reported, never optimised against."""
     from oracle import oracle as O
     O.build()
-    threads = O.usable_cpus(32)      # affinity and cgroup quota, at most 32
-    O.set_threads(threads)
+    cores = O.usable_cpus(32)      # affinity and cgroup quota, at most 32
     m = O.Model(weights_path)
-    frames = make_frames(5, 0)
+    frames = make_frames(6, 0)
+    O.set_threads(cores)
     m.extract(frames[0], N_FEAT, THRESH, N_LEVELS, SCALE)       # warm-up (page-in, FC transpose)
-    done, t_total, prev = 0, 0.0, None
-    t0 = time.perf_counter()
-    for i in range(1, len(frames)):
-        n, kps, desc, g, _ = m.extract(frames[i], N_FEAT, THRESH, N_LEVELS, SCALE)
+
+    def run(threads, n_max, seconds):
+        O.set_threads(threads)
+        done, prev, t0 = 0, None, time.perf_counter()
+        for i in range(1, 1 + n_max):
+            _, _, desc, _, _ = m.extract(frames[i % len(frames)], N_FEAT, THRESH, N_LEVELS, SCALE)
+            if prev is not None:
+                O.search_by_bow(prev, desc, TH_LOW)
+            prev = desc
+            done += 1
+            if time.perf_counter() - t0 > seconds:
+                break
+        return done, time.perf_counter() - t0
+
+    n_all, t_all = run(cores, 5, budget_s * 0.4)
+    n_4, t_4 = run(min(4, cores), 3, budget_s * 0.4)
+    half = max(cores // 2, 1)
+    O.set_threads(half)
+    rng = np.random.default_rng(11)
+    a = unit_rows(rng, 1000, 256); b = unit_rows(rng, 1000, 256)
+    t0 = time.perf_counter(); O.search_by_bow(a, b, TH_LOW); t_match = time.perf_counter() - t0
+    t0 = time.perf_counter(); O.search_for_triangulation(a, b, TH_HIGH); t_tri = time.perf_counter() - t0
+    db = unit_rows(rng, 2000, 4096)
+    t0 = time.perf_counter(); O.db_scores(db[0], db); t_db = (time.perf_counter() - t0) * 5.0      # scaled to 10 000 rows
+    return {"value": n_all / t_all, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n_all} frames 752x480 extract (4 levels, 1000 kpts) + {max(n_all - 1, 0)} SearchByBoW matches, oracle/libhfnet_oracle.so, {cores} OpenMP threads",
+            "variants": {"extract_match_4_threads_frames_per_s": n_4 / t_4, "threads_4": min(4, cores),
+                         "search_by_bow_1000x1000_ms": t_match * 1e3, "search_for_triangulation_1000x1000_ms": t_tri * 1e3,
+                         "db_scan_10000x4096_ms": t_db * 1e3, "matcher_db_threads": half}}
+
+
+# ------------------------------------------------------------------------------------------------ headline pipeline
+class Pipeline:
+    """Device-resident extract + match of frame chunks: one hfnet_extractor_extract_batch(on_device) and one
+    hfnet_match_search_by_bow_batch(on_device) call per chunk, no host synchronisation in between (keypoint counts stay on
+    the device; the matcher stream waits for the extraction by event, hfnet_engine_fence orders buffer reuse)."""
+
+    def __init__(self, torch, capi, eng, dev, width, height, chunk, n_buf=3):
+        self.torch, self.capi, self.eng, self.dev, self.B, self.n_buf = torch, capi, eng, dev, chunk, n_buf
+        self.w, self.h = width, height
+        self.ext = capi.Extractor(eng, width, height, N_FEAT, THRESH, SCALE, N_LEVELS, max_batch=chunk)
+        B = chunk
+        self.kps = torch.zeros((n_buf * B, N_FEAT, 4), dtype=torch.float32, device=dev)
+        self.desc = torch.zeros((n_buf * B, N_FEAT, 256), dtype=torch.float32, device=dev)
+        self.n_rows = torch.zeros((n_buf * B,), dtype=torch.int32, device=dev)      # keypoints per set, written by the extractor
+        self.glob = torch.zeros((B, eng.global_dim), dtype=torch.float32, device=dev)
+        self.match = torch.zeros((B, N_FEAT), dtype=torch.int32, device=dev)
+        self.mdist = torch.zeros((B, N_FEAT), dtype=torch.float32, device=dev)
+        self.mcnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.cur = 0
+        self._pairs = {}
+        self.L = capi.lib()
+
+    def run_chunk(self, d_images, n_frames, qset=None, tset=None, n_pairs=None):
+        """d_images: device tensor [>= n_frames, h, w] u8.  qset / tset: device int32 slot lists of the match pairs
+        (default: every frame against its predecessor, the first one against the previous chunk's last frame)."""
+        B, s0 = self.B, self.cur * self.B
+        self.ext.extract_batch_device(n_frames, d_images.data_ptr(), self.w, self.w * self.h, self.kps[s0].data_ptr(), self.desc[s0].data_ptr(),
+                                      self.glob.data_ptr(), self.n_rows[s0:].data_ptr())
+        # the next extraction overwrites the buffer the PREVIOUS chunk's matches still read: fence it behind them
+        self.eng.fence()
+        if qset is None:
+            qset, tset, n_pairs = self._default_pairs(s0, n_frames)
+        if n_pairs:
+            st = self.L.hfnet_match_search_by_bow_batch(self.eng.h, n_pairs, C.c_void_p(self.desc.data_ptr()), C.c_size_t(N_FEAT * 256),
+                                                        C.c_void_p(self.n_rows.data_ptr()), self.n_buf * B, C.c_void_p(qset.data_ptr()),
+                                                        C.c_void_p(tset.data_ptr()), N_FEAT, 256, C.c_float(TH_LOW), C.c_void_p(self.match.data_ptr()),
+                                                        C.c_void_p(self.mdist.data_ptr()), C.c_void_p(self.mcnt.data_ptr()), 1)
+            if st != 0:
+                raise RuntimeError(self.capi.last_error())
+        self.cur = (self.cur + 1) % self.n_buf
+        return self.n_rows[s0:s0 + n_frames]
+
+    def _default_pairs(self, s0, n):
+        if (s0, n) not in self._pairs:
+            t = self.torch.arange(s0, s0 + n, dtype=self.torch.int32, device=self.dev)
+            q = ((t.to(self.torch.int64) - 1) % (self.n_buf * self.B)).to(self.torch.int32)
+            self._pairs[(s0, n)] = (q, t, n)
+        return self._pairs[(s0, n)]
+
+    def close(self):
+        self.ext.close()
+
+
+def profile_pass(eng, pipe, frames, chunk, reps=2):
+    """dedicated profiling pass: HIP events around EVERY launch, one stream (the engine serialises the global branch while
+    an unfiltered profile is on), so no kernel shares the GPU with another.  Returns {name: (launches, total_ms)} per chunk."""
+    eng.synchronize()
+    eng.profile_reset(); eng.profile_filter(None); eng.profile_enable(True)
+    for i in range(reps):
+        pipe.run_chunk(frames[i % len(frames)], chunk)
+    eng.synchronize()
+    prof = eng.profile()
+    eng.profile_enable(False)
+    return {k: (v[0] / reps, v[1] / reps) for k, v in prof.items()}
+
+
+def roofline_table(prof, work, chunk_seconds_sum):
+    """time-weighted table of every launch name with >= 2 % of the profiled chunk time"""
+    rows = []
+    for name, (launches, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+        share = ms * 1e-3 / chunk_seconds_sum
+        if share < 0.02 or name not in work or launches <= 0:
+            continue
+        flop, byts, executed = work[name]
+        sec = ms * 1e-3 / launches
+        e = roofline_entry(flop / launches, byts / launches, sec)
+        e.update({"name": name, "us": sec * 1e6, "launches_per_chunk": launches, "share": share, "flop": flop / launches, "bytes": byts / launches,
+                  "frac_executed": (executed / launches) / sec / 1e12 / MFMA_F32_PEAK_TFLOPS if e["bound"] == "mfma" else None})
+        rows.append(e)
+    return rows
+
+
+# ------------------------------------------------------------------------------------------------ sub-configs
+def config_latency(capi, eng, n=60):
+    """config 2, per-frame view: one HFextractor call through the host-pointer entry point (upload, 4 levels + global
+    descriptor, download, host sync), then SearchByBoW against the previous frame."""
+    ext = capi.Extractor(eng, W_IMG, H_IMG, N_FEAT, THRESH, SCALE, N_LEVELS, max_batch=1)
+    frames = make_frames(8, 0)
+    for f in frames[:3]:
+        ext.extract(f)
+    t_ext, t_both, prev = [], [], None
+    for i in range(n):
+        f = frames[i % len(frames)]
+        t0 = time.perf_counter()
+        nk, _, desc, _, _ = ext.extract(f)
+        t1 = time.perf_counter()
         if prev is not None:
-            O.search_by_bow(prev, desc, TH_LOW)
-        prev = desc
-        done += 1
-        t_total = time.perf_counter() - t0
-        if t_total > max_seconds:
-            break
-    return {"value": done / t_total, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{done} frames 752x480 extract (4 levels, 1000 kpts) + {max(done - 1, 0)} SearchByBoW matches, oracle/libhfnet_oracle.so, {threads} OpenMP threads"}
+            eng.search_by_bow(prev, desc, TH_LOW)
+        t2 = time.perf_counter()
+        t_ext.append(t1 - t0); t_both.append(t2 - t0); prev = desc
+    store = capi.Store(eng, 2, N_FEAT)       # descriptors kept on the GPU: device-to-device into a two-slot store, match by slot
+    t_dev = []
+    for i in range(n):
+        t0 = time.perf_counter()
+        ext.extract(frames[i % len(frames)])
+        store.put_extracted(i & 1, ext, 0)
+        if i:
+            store.search_by_bow([(1 - (i & 1), i & 1)], TH_LOW)
+        t_dev.append(time.perf_counter() - t0)
+    store.close(); ext.close()
+    med = lambda v: float(np.median(v)) * 1e3
+    return {"workload": "752x480, 4 levels, 1000 keypoints, one frame per call, host pointers", "extract_ms_median": med(t_ext),
+            "extract_plus_match_ms_median": med(t_both[1:]), "extract_plus_store_match_ms_median": med(t_dev[1:]), "keypoints": int(nk),
+            "frames_per_s_unpipelined": 1e3 / med(t_dev[1:])}
 
 
+def config_host_io(capi, eng, chunk, reps=6):
+    """the batch path with host buffers on both sides: images go up, keypoints + descriptors + global descriptors come
+    down (what the reference's extraction time includes, HFNetRTModel.cc:128,134), the frame-to-frame match runs on the
+    device-resident copies (hfnet_store) and only the matches come down."""
+    ext = capi.Extractor(eng, W_IMG, H_IMG, N_FEAT, THRESH, SCALE, N_LEVELS, max_batch=chunk)
+    store = capi.Store(eng, 2 * chunk, N_FEAT)
+    imgs = make_frames(chunk, 0)
+    ext.extract_batch(imgs)
+    t_e, t_all = [], []
+    for r in range(reps):
+        base = (r & 1) * chunk
+        t0 = time.perf_counter()
+        ext.extract_batch(imgs)
+        t1 = time.perf_counter()
+        for f in range(chunk):
+            store.put_extracted(base + f, ext, f)
+        pairs = [(base + f - 1, base + f) for f in range(1, chunk)] + ([((1 - (r & 1)) * chunk + chunk - 1, base)] if r else [])
+        store.search_by_bow(pairs, TH_LOW)
+        t_all.append(time.perf_counter() - t0); t_e.append(t1 - t0)
+    store.close(); ext.close()
+    return {"workload": f"752x480, {chunk} frames per call, host buffers in and out (pageable numpy arrays)", "extract_frames_per_s": chunk / float(np.median(t_e)),
+            "extract_plus_match_frames_per_s": chunk / float(np.median(t_all[1:]))}
+
+
+def config_tracking(capi, eng, n_feat, frames_n=400):
+    """config 3 (TUM-VI corridor-style loop) one frame at a time through the host-pointer entry points, keyframes'
+    descriptor blocks resident in an hfnet_store: every frame extract + SearchByBoW vs the last frame; every 5th frame a
+    keyframe: database add + DetectNBestCandidates scan + SearchForTriangulation against the 30 most recent keyframes."""
+    W = H = 512
+    ext = capi.Extractor(eng, W, H, n_feat, THRESH, SCALE, N_LEVELS, max_batch=1)
+    db = capi.Database(eng, frames_n // 5 + 8, eng.global_dim)
+    store = capi.Store(eng, frames_n // 5 + 8, n_feat)       # keyframe slots; the last two slots hold the current / previous frame
+    F0 = frames_n // 5 + 6
+    imgs = make_frames(16, 0, w=W, h=H)
+    for i in range(3):
+        ext.extract(imgs[i])
+    t_frame, t_kf, n_kf = [], [], 0
+    t_all0 = time.perf_counter()
+    for i in range(frames_n):
+        t0 = time.perf_counter()
+        _, _, _, g, _ = ext.extract(imgs[i % len(imgs)])
+        store.put_extracted(F0 + (i & 1), ext, 0)
+        if i:
+            store.search_by_bow([(F0 + 1 - (i & 1), F0 + (i & 1))], TH_LOW)
+        t1 = time.perf_counter()
+        t_frame.append(t1 - t0)
+        if i % 5 == 0:
+            if n_kf:
+                db.query(g, 0)
+                store.put_extracted(n_kf, ext, 0)
+                store.search_for_triangulation([(n_kf, j) for j in range(max(0, n_kf - 30), n_kf)], TH_HIGH)
+            else:
+                store.put_extracted(0, ext, 0)
+            db.add(n_kf, g); n_kf += 1
+            t_kf.append(time.perf_counter() - t1)
+    wall = time.perf_counter() - t_all0
+    store.close(); db.close(); ext.close()
+    med = lambda v: float(np.median(v)) * 1e3
+    return {"frame_ms_median": med(t_frame), "keyframe_extra_ms_median": med(t_kf[31:] if len(t_kf) > 40 else t_kf[1:]), "keyframes": n_kf,
+            "frames": frames_n, "frames_per_s_whole_loop": frames_n / wall}
+
+
+def config_sequences(torch, pipe, dev, rank, world, dist, pool_frames=64):
+    """config 4: the 11 EuRoC sequences (27 049 frames) assigned to the ranks longest-first (hfnet_slam_amd/shard.py), each
+    rank walks its sequences in frame order in chunks of the pipeline's chunk size; frame i is matched against frame i - 1
+    of the same sequence.  Frames come from a pool of synthetic frames resident in HBM."""
+    from hfnet_slam_amd import shard
+    B = pipe.B
+    plan = shard.assign_sequences(shard.EUROC_SEQUENCES, world)
+    chunks = shard.sequence_chunks(plan[rank], shard.EUROC_SEQUENCES, B)
+    pool = torch.from_numpy(make_frames(pool_frames + B, 10_000 * (rank + 1))).to(dev)
+    # pair lists of every chunk, built before the timed region (slots rotate with the pipeline's buffers)
+    cur, todo = pipe.cur, []
+    for ci, (name, f0, n) in enumerate(chunks):
+        s0 = cur * B
+        q, t = shard.chunk_pairs(f0, n, s0, (s0 - 1) % (pipe.n_buf * B))
+        todo.append((n, torch.tensor(q, dtype=torch.int32, device=dev), torch.tensor(t, dtype=torch.int32, device=dev), len(q), (ci * B) % pool_frames))
+        cur = (cur + 1) % pipe.n_buf
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for n, q, t, npairs, off in todo:
+        pipe.run_chunk(pool[off:], n, q, t, npairs)
+    pipe.eng.synchronize(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    mine = sum(c[2] for c in chunks)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        cnt = torch.tensor([mine], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt)
+        total = int(cnt.item())
+    else:
+        total = mine
+    return {"workload": "11 EuRoC sequences, 27049 synthetic 752x480 frames, sequences assigned to GPUs longest-first, frame order kept, "
+                        "extract + SearchByBoW vs the previous frame of the sequence", "frames": total, "sequences": sum(len(p) for p in plan),
+            "gpus": world, "seconds": elapsed, "frames_per_s": total / elapsed, "rank0_sequences": plan[0], "scaling": "strong"}
+
+
+def config_loop_closure(capi, eng, reps=10):
+    """config 5: keyframe-database scans at 10 000 x 4096 (Q = 1 and Q = 64; warm: the 164 MB database stays in the 256 MB
+    Infinity Cache between scans; cold: a 65 536-row = 1 GB database) and 32 SearchByBoW matches of 1000 x 1000 x 256.
+    Kernel times are HIP-event times of the library's profiler."""
+    N, DIM = 10000, 4096
+    rng = np.random.default_rng(13)
+    rows = unit_rows(rng, N, DIM)
+    db = capi.Database(eng, N, DIM)
+    for i in range(N):
+        db.add(i, rows[i])
+    qs = rows[rng.integers(0, N, 64)] + 0.003 * rng.standard_normal((64, DIM)).astype(np.float32)
+    qs = (qs / np.linalg.norm(qs, axis=1, keepdims=True)).astype(np.float32)
+    a = unit_rows(rng, 1000, 256)
+    b = a[rng.permutation(1000)] + 0.02 * rng.standard_normal((1000, 256)).astype(np.float32)
+    b = (b / np.linalg.norm(b, axis=1, keepdims=True)).astype(np.float32)
+    sets = np.stack([a, b]).astype(np.float32)
+    nr = np.array([1000, 1000], np.int32)
+    db.query(qs[0]); db.query_batch(qs); eng.search_by_bow_batch(sets, nr, [(0, 1)] * 32, TH_LOW)       # warm-up
+    eng.synchronize()
+    eng.profile_reset(); eng.profile_filter(None); eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        db.query(qs[0])
+    t_q1_call = (time.perf_counter() - t0) / reps
+    for _ in range(reps):
+        db.query_batch(qs)
+    for _ in range(reps):
+        eng.search_by_bow_batch(sets, nr, [(0, 1)] * 32, TH_LOW)
+    eng.synchronize()
+    prof = eng.profile(); eng.profile_enable(False)
+    db.close()
+    ms = lambda p, k: p[k][1] / max(p[k][0], 1) if k in p else float("nan")
+    q64 = next((k for k in ("db_gemm", "db_scores_batch") if k in prof), "db_scores_batch")
+    out = {"workload": "10000 x 4096 f32 database resident in HBM; 1000 x 1000 x 256 SearchByBoW x 32 pairs",
+           "db_q1_warm_us": ms(prof, "db_scores") * 1e3, "db_q1_warm_GBps": N * DIM * 4 / (ms(prof, "db_scores") * 1e-3) / 1e9,
+           "db_q1_call_us_incl_copies": t_q1_call * 1e6,
+           "db_q64_kernel": q64, "db_q64_us": ms(prof, q64) * 1e3, "db_q64_TFLOPs": 64 * N * DIM * 2 / (ms(prof, q64) * 1e-3) / 1e12,
+           "db_q64_frac_mfma_f32": 64 * N * DIM * 2 / (ms(prof, q64) * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+           "match_32_pairs_us": ms(prof, "match_bow") * 1e3, "match_TFLOPs": 32 * 2 * 1000 * 1000 * 256 / (ms(prof, "match_bow") * 1e-3) / 1e12,
+           "match_frac_mfma_f32": 32 * 2 * 1000 * 1000 * 256 / (ms(prof, "match_bow") * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
+    # cold: a 1 GB database (4x the Infinity Cache): every scan streams it from HBM
+    NC = 65536
+    dbc = capi.Database(eng, NC, DIM)
+    blk = unit_rows(rng, 2048, DIM)
+    for i in range(NC):
+        dbc.add(i, blk[i & 2047])
+    dbc.query(qs[0])
+    eng.synchronize()
+    eng.profile_reset(); eng.profile_enable(True)
+    for i in range(6):
+        dbc.query(qs[i])
+    eng.synchronize()
+    prof = eng.profile(); eng.profile_enable(False)
+    dbc.close()
+    out["db_q1_cold_rows"] = NC
+    out["db_q1_cold_us"] = ms(prof, "db_scores") * 1e3
+    out["db_q1_cold_GBps"] = NC * DIM * 4 / (ms(prof, "db_scores") * 1e-3) / 1e9
+    out["db_q1_cold_frac_hbm"] = out["db_q1_cold_GBps"] / HBM_PEAK_GBS
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="frames per step and GPU")
+    ap.add_argument("--batch", type=int, default=512, help="frames per step and GPU")
+    ap.add_argument("--chunk", type=int, default=32, help="frames per extract / match call (the extractor's batch)")
     ap.add_argument("--frames", choices=["uniform", "natural"], default="uniform", help="synthetic frame distribution (SURVEY.md 8d)")
+    ap.add_argument("--configs", default="all", help="comma list of sub-records to measure besides the headline: " + ",".join(ALL_CONFIGS) + " | all | none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="also print the per-launch timing table to stderr")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option (hfnet_engine_set_option), e.g. fused_variant=2")
     args = ap.parse_args()
+    want = ALL_CONFIGS if args.configs == "all" else [] if args.configs == "none" else [c.strip() for c in args.configs.split(",")]
+    if args.batch % args.chunk:
+        raise SystemExit("--batch must be a multiple of --chunk")
 
     import torch
     from hfnet_slam_amd import capi, weights
@@ -196,46 +549,18 @@ def main() -> None:
     for o in args.opt:
         k, v = o.split("=")
         eng.set_option(k, int(v))
-    B = args.batch
-    ext = capi.Extractor(eng, W_IMG, H_IMG, N_FEAT, THRESH, SCALE, N_LEVELS, max_batch=B)
-
+    B, chunks_per_step = args.chunk, args.batch // args.chunk
+    pipe = Pipeline(torch, capi, eng, dev, W_IMG, H_IMG, B)
     n_sets = 2
     frames = [torch.from_numpy(make_frames(B, (rank * n_sets + s) * B, args.frames)).to(dev) for s in range(n_sets)]
-    # descriptor sets of the last n_buf steps live in one rotating store: set id = buffer * B + frame
-    n_buf = 3
-    kps = torch.zeros((n_buf * B, N_FEAT, 4), dtype=torch.float32, device=dev)
-    desc = torch.zeros((n_buf * B, N_FEAT, 256), dtype=torch.float32, device=dev)
-    n_rows = torch.zeros((n_buf * B,), dtype=torch.int32, device=dev)          # keypoints per set, written by the extractor
-    glob = torch.zeros((B, eng.global_dim), dtype=torch.float32, device=dev)
-    match = torch.zeros((B, N_FEAT), dtype=torch.int32, device=dev)
-    mdist = torch.zeros((B, N_FEAT), dtype=torch.float32, device=dev)
-    mcnt = torch.zeros((B,), dtype=torch.int32, device=dev)
-    # frame j of buffer c is matched against its predecessor (query = previous frame, train = this frame)
-    tset = [torch.arange(c * B, (c + 1) * B, dtype=torch.int32, device=dev) for c in range(n_buf)]
-    qset = [((t.to(torch.int64) - 1) % (n_buf * B)).to(torch.int32) for t in tset]
     torch.cuda.synchronize()
-    L = capi.lib()
-    import ctypes as C
-
-    state = {"step": 0}
+    state = {"i": 0}
 
     def step():
-        i = state["step"]
-        cur = i % n_buf
-        f = frames[i % n_sets]
-        ext.extract_batch_device(B, f.data_ptr(), W_IMG, W_IMG * H_IMG, kps[cur * B].data_ptr(), desc[cur * B].data_ptr(), glob.data_ptr(),
-                                 n_rows[cur * B:].data_ptr())
-        # the next extraction overwrites the buffer the PREVIOUS step's matches still read: fence it behind them
-        eng.fence()
-        # all B SearchByBoW pairs of the step in one call; keypoint counts stay on the device (no host sync)
-        st = L.hfnet_match_search_by_bow_batch(eng.h, B, C.c_void_p(desc.data_ptr()), C.c_size_t(N_FEAT * 256), C.c_void_p(n_rows.data_ptr()),
-                                               n_buf * B, C.c_void_p(qset[cur].data_ptr()), C.c_void_p(tset[cur].data_ptr()), N_FEAT, 256,
-                                               C.c_float(TH_LOW), C.c_void_p(match.data_ptr()), C.c_void_p(mdist.data_ptr()),
-                                               C.c_void_p(mcnt.data_ptr()), 1)
-        if st != 0:
-            raise RuntimeError(capi.last_error())
-        state["step"] = i + 1
-        return n_rows[cur * B:(cur + 1) * B]
+        for _ in range(chunks_per_step):
+            n = pipe.run_chunk(frames[state["i"] % n_sets], B)
+            state["i"] += 1
+        return n
 
     def sync_all():
         eng.synchronize()
@@ -243,26 +568,25 @@ def main() -> None:
         if dist is not None:
             dist.barrier()
 
-    # ---- warm-up (full per-launch profile -> dominant kernel) -----------------------------------
-    eng.profile_reset(); eng.profile_filter(None); eng.profile_enable(True)
-    for _ in range(max(args.warmup, 1)):
-        n = step()
-        eng.synchronize()
-        n = n.cpu().numpy()
-        if int(n.min()) < N_FEAT and not os.environ.get("BENCH_NO_KP_CHECK"):
-            raise SystemExit(f"synthetic frames gave only {int(n.min())} keypoints (< {N_FEAT}): budget not exercised")
+    # ---- warm-up, budget check, per-launch profile (single stream, every kernel alone) ---------
+    n = pipe.run_chunk(frames[0], B)
     eng.synchronize()
-    prof = eng.profile()
-    eng.profile_enable(False)
-    if args.profile_all and rank == 0:
-        tot = sum(v[1] for v in prof.values())
-        for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1]):
-            print(f"  {k:26s} launches {v[0]:5d}  avg {v[1] / max(v[0], 1) * 1e3:9.1f} us  share {v[1] / tot * 100:5.1f}%", file=sys.stderr)
+    n = n.cpu().numpy()
+    if int(n.min()) < N_FEAT and not os.environ.get("BENCH_NO_KP_CHECK"):
+        raise SystemExit(f"synthetic frames gave only {int(n.min())} keypoints (< {N_FEAT}): budget not exercised")
+    prof = profile_pass(eng, pipe, frames, B)
     work = layer_work(B)
-    dominant = max((k for k in prof if k in work), key=lambda k: prof[k][1])
-    eng.profile_reset(); eng.profile_filter(dominant); eng.profile_enable(True)
+    prof_sum_s = sum(v[1] for v in prof.values()) * 1e-3
+    if args.profile_all and rank == 0:
+        for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+            print(f"  {k:26s} launches {v[0]:5.1f}  avg {v[1] / max(v[0], 1e-9) * 1e3:9.1f} us  share {v[1] * 1e-3 / prof_sum_s * 100:5.1f}%", file=sys.stderr)
+    table = roofline_table(prof, work, prof_sum_s)
+    dominant = max((k for k in prof if k in work), key=lambda k: prof[k][1])      # largest by TIME in the single-stream pass
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
 
-    # ---- timed region ----------------------------------------------------------------------------
+    # ---- timed region: the dominant kernel is timed live with HIP events on its own stream ------
+    eng.profile_reset(); eng.profile_filter(dominant); eng.profile_enable(True)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -274,40 +598,65 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     dom = eng.profile().get(dominant, (0, 0.0))
-    eng.profile_enable(False)
+    eng.profile_enable(False); eng.profile_filter(None)
 
+    out = None
     if rank == 0:
-        frames_total = world * B * args.steps
-        value = frames_total / elapsed
-        flop, byts = work[dominant]
+        frames_total = world * args.batch * args.steps
+        flop, byts, executed = work[dominant]
+        launches_per_chunk = max(prof[dominant][0], 1.0)
         avg_s = dom[1] / max(dom[0], 1) * 1e-3
-        intensity = flop / byts
-        if intensity >= MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
-            roof = {"bound": "mfma", "achieved": flop / avg_s / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s"}
-        else:
-            roof = {"bound": "hbm", "achieved": byts / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-        roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"] = hbm_traffic(dominant, B)
-        roof["kernel"] = dominant
-        roof["avg_launch_us"] = avg_s * 1e6
-        roof["launches"] = dom[0]
+        roof = roofline_entry(flop / launches_per_chunk, byts / launches_per_chunk, avg_s)
+        roof.update({"traffic": hbm_traffic(dominant, B),
+                     "traffic_source": f"{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at chunk {B} (committed; not measured in this run)",
+                     "kernel": dominant, "avg_launch_us": avg_s * 1e6, "launches": dom[0],
+                     "selection": "largest launch name by time in the single-stream profiling pass; timed live (HIP events on its stream) over the timed region"})
+        chunk_s = elapsed / args.steps / chunks_per_step
+        alg = sum(work[k][0] for k in prof if k in work)
+        exe = sum(work[k][2] for k in prof if k in work)
+        roof["step_frac_algorithmic"] = alg / chunk_s / 1e12 / MFMA_F32_PEAK_TFLOPS
+        roof["step_frac_executed"] = exe / chunk_s / 1e12 / MFMA_F32_PEAK_TFLOPS
+        roof["profiled_chunk_ms_single_stream"] = prof_sum_s * 1e3
+        roof["table"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in table]
         out = {
             "metric": "frames/sec HF-Net extract+match, 752x480, 1000 kpts",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": f"synthetic (seeded {args.frames} u8 frames, seeded random-init weights of the reference architecture)",
             "config": {"workload": "EuRoC-size 752x480 mono, HF-Net extract (4 levels x1.2, budget 322/268/224/186, thr 0.01, "
                                    "level 0 incl. NetVLAD 4096-D) + SearchByBoW brute-force match vs previous frame",
-                       "frames_per_step_per_gpu": B, "parallelism": f"replicas x{world} (no collective)"},
-            "roofline": roof,
+                       "frames_per_step_per_gpu": args.batch, "frames_per_call": B, "parallelism": f"replicas x{world} (no collective)"},
+            "roofline": roof, "build_id": capi.build_id(), "options": eng.options(),
         }
+
+    # ---- the other BASELINE configs (sub-records) ------------------------------------------------
+    configs = {}
+    if "4" in want:
+        r = config_sequences(torch, pipe, dev, rank, world, dist)
+        if rank == 0:
+            configs["4"] = r
+    if rank == 0 and world == 1:
+        if "2-latency" in want:
+            configs["2-latency"] = config_latency(capi, eng)
+        if "2-host-io" in want:
+            configs["2-host-io"] = config_host_io(capi, eng, B)
+            out["value_host_io"] = configs["2-host-io"]["extract_plus_match_frames_per_s"]
+        if "3" in want:
+            configs["3"] = {"workload": "TUM-VI-size 512x512 tracking loop, 4 levels, one frame per call, keyframe every 5th (database scan + 30 "
+                                        "SearchForTriangulation pairs), device-resident keyframe store",
+                            "nFeatures_1000": config_tracking(capi, eng, 1000), "nFeatures_850": config_tracking(capi, eng, 850)}
+        if "5" in want:
+            configs["5"] = config_loop_closure(capi, eng)
+    if rank == 0:
+        out["configs"] = configs
+        out["configs_not_run"] = [c for c in ALL_CONFIGS if c not in configs]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wpath)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ext.close(); eng.close()
+    pipe.close(); eng.close()
 
 
 if __name__ == "__main__":

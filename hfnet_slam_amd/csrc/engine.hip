@@ -290,8 +290,8 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         }
     }
     if (join_pending) { HF_HIP(hipStreamWaitEvent(stream, ev_join, 0)); join_pending = false; }   // (intermediate-input models)
-    // per-launch profiling wants every kernel alone on the GPU: one stream while the profiler is on
-    const bool fork = cfg.global && cfg.local && two_streams && stream_global && !e->prof.enabled;
+    // the per-launch profile of EVERY kernel (no name filter) wants each kernel alone on the GPU: one stream for that pass
+    const bool fork = cfg.global && cfg.local && two_streams && stream_global && !(e->prof.enabled && e->prof.filter.empty());
     // deferring needs every layer up to 7 fused (the unfused chain shares its scratch tensors with the global branch)
     bool front_fused = fuse_blocks && fuse_max_layer >= 7;
     for (int L = 3; L <= 7 && front_fused; ++L) front_fused = block_fusable(w.blocks[L - 2], fused_variant);

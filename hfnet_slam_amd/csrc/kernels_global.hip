@@ -130,19 +130,21 @@ hipError_t launch_vlad(const float* feat, const float* memb, const float* cluste
 // matmul of the path).  A wave owns 16 frames x 16 outputs and walks the whole chain: n_in / 4 dependent MFMAs (40 cycles
 // each) -- 32 us for 7680 inputs, about what streaming the 126 MB of weights from HBM takes; the 512 waves of a 32-frame
 // batch put one chain on every other SIMD.  Operands of four consecutive MFMAs are one 16-byte load per lane (FcPack,
-// common.hpp); NBUF groups are in flight per lane to cover the HBM latency.  The weights cross HBM once per batch: the two
-// 16-frame row tiles of a column tile run on the same XCD at the same time.
+// common.hpp); NBUF groups are in flight per lane to cover the HBM latency.  A workgroup is the two 16-frame row tiles of
+// ONE column tile (two waves in step: the second wave's weight loads hit L1), one workgroup per column tile: the 126 MB of
+// weights cross HBM and every CU's load path once per 32 frames (a CU sustains ~10 B/clk of loads -- with four column
+// tiles per workgroup on half the CUs that alone took 80 us).
 template <class F, int... I>
 __device__ __forceinline__ void fc_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F>
 __device__ __forceinline__ void fc_static_for(F&& f) { fc_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 template <int NBUF>
-__global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+__global__ __launch_bounds__(128) void k_fc_mfma(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                  float* __restrict__ y, int frames, int n_in, int n_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ctiles = n_out >> 4, ct = blockIdx.x * 4 + wave, rt = blockIdx.y;
-    if (ct >= ctiles) return;
+    const int ctiles = n_out >> 4, ct = blockIdx.x, rt = blockIdx.y * 2 + wave;
+    if (rt * 16 >= frames) return;
     const int row = min(rt * 16 + (lane & 15), frames - 1);
     const f32x4* __restrict__ ap = (const f32x4*)(x + (long long)row * n_in) + (lane >> 4);
     const f32x4* __restrict__ wp = (const f32x4*)w + (size_t)ct * 64 + lane;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void k_l2norm_vec(const float* __restrict__ in
 hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* y_raw, float* out, int frames, hipStream_t s) {
     if (frames <= 0) return hipSuccess;
     if (fc.n_in % 16 || fc.n_out % 16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_fc_mfma<16>, dim3((fc.n_out / 16 + 3) / 4, (frames + 15) / 16), dim3(256), 0, s, x, fc.w, fc.bias, y_raw, frames, fc.n_in, fc.n_out);
+    hipLaunchKernelGGL(k_fc_mfma<16>, dim3(fc.n_out / 16, (frames + 31) / 32), dim3(128), 0, s, x, fc.w, fc.bias, y_raw, frames, fc.n_in, fc.n_out);
     hipLaunchKernelGGL(k_l2norm_vec, dim3(frames), dim3(256), 0, s, y_raw, out, fc.n_out);
     return hipGetLastError();
 }

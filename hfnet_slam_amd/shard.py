@@ -25,6 +25,34 @@ def assign_sequences(lengths: Dict[str, int], world: int) -> List[List[str]]:
     return out
 
 
+def sequence_chunks(names: Sequence[str], lengths: Dict[str, int], chunk: int) -> List[Tuple[str, int, int]]:
+    """BASELINE config 4, one rank: its sequences in order, each cut into chunks of at most `chunk` consecutive frames
+    (a chunk never spans two sequences: the frame-to-frame match stops at a sequence boundary).
+    Returns [(sequence, first_frame, n_frames), ...]."""
+    if chunk < 1:
+        raise ValueError("chunk < 1")
+    out: List[Tuple[str, int, int]] = []
+    for name in names:
+        n = lengths[name]
+        for f0 in range(0, n, chunk):
+            out.append((name, f0, min(chunk, n - f0)))
+    return out
+
+
+def chunk_pairs(first_frame: int, n_frames: int, slot0: int, prev_slot: int) -> Tuple[List[int], List[int]]:
+    """Frame-vs-previous match pairs of one chunk whose frames land in descriptor slots slot0 .. slot0 + n_frames - 1;
+    `prev_slot` holds the last frame of the previous chunk of the same sequence.  The first frame of a sequence has no
+    predecessor.  Returns (query_slots, train_slots) -- query = the earlier frame."""
+    q: List[int] = []
+    t: List[int] = []
+    for i in range(n_frames):
+        if first_frame + i == 0:
+            continue
+        q.append(slot0 + i - 1 if i > 0 else prev_slot)
+        t.append(slot0 + i)
+    return q, t
+
+
 def frame_block(rank: int, world: int, frames_per_rank: int) -> Tuple[int, int]:
     """Weak-scaling shard used by bench.py: rank r owns frames [r*F, (r+1)*F)."""
     if not (0 <= rank < world):

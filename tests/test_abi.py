@@ -62,3 +62,4 @@ def test_product_never_imports_the_oracle():
     assert len(uses) == 1
     enclosing = [l for l in lines[:uses[0]] if l.startswith("def ")][-1]
     assert enclosing.startswith("def cpu_baseline")
+    assert "from oracle" not in open(os.path.join(ROOT, "hfnet_slam_amd", "shard.py")).read()

@@ -15,4 +15,4 @@ for P in "$P1" "$P2"; do
   python $GRAFT_REPO_ROOT/tools/pmc_summary.py $f > $OUT/pmc$i.txt
   i=$((i+1))
 done
-head -n 24 $OUT/pmc1.txt | cut -c1-220
+grep -E "kernel|fused" $OUT/pmc1.txt | cut -c1-220; grep -E "kernel|fused" $OUT/pmc2.txt | cut -c1-220
