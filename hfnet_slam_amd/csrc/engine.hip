@@ -17,7 +17,7 @@ int* Options::find(const char* name) {
     if (!name) return nullptr;
     const struct { const char* n; int* p; } tab[] = {{"fuse_blocks", &fuse_blocks}, {"fuse_max_layer", &fuse_max_layer}, {"fused_variant", &fused_variant},
                                                        {"fuse_stem", &fuse_stem}, {"dense_desc", &dense_desc}, {"two_streams", &two_streams},
-                                                       {"graph", &graph}, {"pinned_frames", &pinned_frames}};
+                                                       {"graph", &graph}, {"pinned_frames", &pinned_frames}, {"db_gemm_min_queries", &db_gemm_min_queries}};
     for (const auto& t : tab) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -1327,6 +1327,8 @@ int hfnet_db_create(hfnet_engine* eh, int capacity, int dim, hfnet_db** out) {
     HF_HIP(hipMalloc((void**)&db->d_db, sizeof(float) * (size_t)capacity * dim));
     HF_HIP(hipMalloc((void**)&db->d_occ, (size_t)capacity));
     HF_HIP(hipMalloc((void**)&db->d_q, sizeof(float) * dim));
+    HF_HIP(hipMalloc((void**)&db->d_norm, sizeof(float) * capacity));
+    HF_HIP(hipMemset(db->d_norm, 0, sizeof(float) * capacity));
     HF_HIP(hipMalloc((void**)&db->d_scores, sizeof(float) * capacity));
     HF_HIP(hipMalloc((void**)&db->d_cand_score, sizeof(float) * capacity));
     HF_HIP(hipMalloc((void**)&db->d_cand_slot, sizeof(int32_t) * capacity));
@@ -1342,7 +1344,7 @@ void hfnet_db_destroy(hfnet_db* db) {
     if (!db) return;
     (void)hipSetDevice(db->eng->impl.device);
     for (void* p : {(void*)db->d_db, (void*)db->d_occ, (void*)db->d_q, (void*)db->d_scores, (void*)db->d_cand_score, (void*)db->d_cand_slot,
-                    (void*)db->d_best, (void*)db->d_n, (void*)db->d_best_bits})
+                    (void*)db->d_best, (void*)db->d_n, (void*)db->d_best_bits, (void*)db->d_norm})
         if (p) (void)hipFree(p);
     delete db;
 }
@@ -1357,6 +1359,7 @@ int hfnet_db_add(hfnet_db* db, int slot, const float* descriptor) {
     // on the stream the scans run on (created non-blocking: the null stream would not order with it)
     HF_HIP(hipMemcpyAsync(db->d_db + (size_t)slot * db->dim, descriptor, sizeof(float) * db->dim, hipMemcpyHostToDevice, e.stream));
     HF_HIP(hipMemsetAsync(db->d_occ + slot, 1, 1, e.stream));
+    HF_LAUNCH(&e, e.stream, "db_norm", launch_sumsq_rows(db->d_db + (size_t)slot * db->dim, 1, db->dim, db->d_norm + slot, e.stream));
     HF_HIP(hipStreamSynchronize(e.stream));                          // the host buffer may go away
     return HFNET_OK;
 }
@@ -1418,10 +1421,11 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
     if (n_queries == 0) return HFNET_OK;
     API_GUARD(queries, "queries"); API_GUARD(cand_slot, "cand_slot"); API_GUARD(cand_score, "cand_score"); API_GUARD(n_cand, "n_cand");
     if (mode != 0 && mode != 1) { set_error("db: mode must be 0 or 1"); return HFNET_ERR_INVALID_ARG; }
-    if (db->dim > 4096) { set_error("db: batched queries support dim <= 4096"); return HFNET_ERR_INVALID_ARG; }
     std::lock_guard<std::mutex> lk(db->mu);
     Engine& e = db->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
+    const bool gemm = n_queries >= e.opt.db_gemm_min_queries && db->dim % 512 == 0;
+    if (!gemm && db->dim > 4096) { set_error("db: the exact batched scan supports dim <= 4096"); return HFNET_ERR_INVALID_ARG; }
     HF_HIP(hipSetDevice(e.device));
     const size_t Q = (size_t)n_queries, cap = (size_t)db->capacity;
     // per-call scratch: [Q][dim] queries, [Q][cap] scores / candidates, [Q] best / counts
@@ -1431,13 +1435,20 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
     HF_TRY(e.m_i0.ensure(sizeof(int32_t) * Q * cap));
     HF_TRY(e.m_cnt.ensure(sizeof(int32_t) * Q));
     HF_TRY(e.m_qn.ensure(sizeof(float) * Q));
-    const int parts = 4 * db_batch_workgroups(db->capacity);
+    const int parts = gemm ? db_gemm_partials(db->capacity) : 4 * db_batch_workgroups(db->capacity);
     HF_TRY(e.m_key.ensure(sizeof(unsigned int) * Q * parts));
+    if (gemm) { HF_TRY(e.m_tn.ensure(sizeof(float) * Q)); HF_TRY(e.m_b.ensure(sizeof(float) * db_gemm_scratch_floats(db->capacity, n_queries))); }
     float* d_q = e.m_a.as<float>(); float* d_scores = e.m_s.as<float>(); float* d_cs = e.m_f0.as<float>();
     int32_t* d_slot = e.m_i0.as<int32_t>(); int* d_n = e.m_cnt.as<int>(); float* d_best = e.m_qn.as<float>();
     unsigned int* d_bits = e.m_key.as<unsigned int>();
     HF_HIP(hipMemcpyAsync(d_q, queries, sizeof(float) * Q * db->dim, hipMemcpyHostToDevice, e.stream));
-    HF_LAUNCH(&e, e.stream, "db_scores_batch", launch_db_scores_batch(d_q, n_queries, db->d_db, db->d_occ, db->capacity, db->dim, d_scores, d_bits, e.stream));
+    if (gemm) {
+        HF_LAUNCH(&e, e.stream, "db_qnorm", launch_sumsq_rows(d_q, n_queries, db->dim, e.m_tn.as<float>(), e.stream));
+        HF_LAUNCH(&e, e.stream, "db_gemm", launch_db_gemm(d_q, n_queries, e.m_tn.as<float>(), db->d_db, db->d_norm, db->d_occ, db->capacity, db->dim,
+                                                       d_scores, d_bits, e.m_b.as<float>(), e.stream));
+    } else {
+        HF_LAUNCH(&e, e.stream, "db_scores_batch", launch_db_scores_batch(d_q, n_queries, db->d_db, db->d_occ, db->capacity, db->dim, d_scores, d_bits, e.stream));
+    }
     HF_LAUNCH(&e, e.stream, "db_filter", launch_db_filter(d_scores, db->capacity, mode, d_bits, parts, d_slot, d_cs, d_n, d_best, n_queries, e.stream));
     HF_HIP(hipMemcpyAsync(n_cand, d_n, sizeof(int32_t) * Q, hipMemcpyDeviceToHost, e.stream));
     if (best_score) HF_HIP(hipMemcpyAsync(best_score, d_best, sizeof(float) * Q, hipMemcpyDeviceToHost, e.stream));

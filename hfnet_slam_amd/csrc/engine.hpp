@@ -25,6 +25,7 @@ struct Options {
     int two_streams = 3;      // 0 one stream; 1 fork after layer 7; 2 fork after the detector conv; 3 = 2 + deferred join
     int graph = 1;            // host-pointer extractor calls replay a captured graph
     int pinned_frames = 4;    // chunks up to this many frames move through one pinned block inside that graph
+    int db_gemm_min_queries = 8;   // hfnet_db_query_batch: from this many queries on, the scores come from the MFMA GEMM form
     int* find(const char* name);
 };
 
@@ -187,6 +188,7 @@ struct hfnet_db {
     float* d_db = nullptr;
     unsigned char* d_occ = nullptr;
     float *d_q = nullptr, *d_scores = nullptr, *d_cand_score = nullptr, *d_best = nullptr;
+    float* d_norm = nullptr;       // |d|^2 per slot (tree256 order), computed when a row is added: the GEMM form of the scores needs it
     int32_t* d_cand_slot = nullptr;
     int* d_n = nullptr;
     unsigned int* d_best_bits = nullptr;

@@ -6,6 +6,7 @@
 //   KeyFrameDatabase scans            src/KeyFrameDatabase.cc:86-104, 178-197
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <mutex>
 
 #include <cfloat>
@@ -695,6 +696,163 @@ __global__ __launch_bounds__(256) void k_db_scores_batch(const float* __restrict
         for (int j = 0; j < DBQ; ++j)
             if (j < nq) best_bits[(long long)(q0 + j) * parts + wid] = __float_as_uint(best[j]);
     }
+}
+
+// ---- many queries at once on the matrix cores (loop-closure bursts, BASELINE config 5): S = DB * Q^T on
+// v_mfma_f32_32x32x2_f32, then  score = max(0, 1 - sqrt(max(0, |q|^2 + |d|^2 - 2 S)))  -- the same place-recognition
+// score in its inner-product form (KeyFrameDatabase.cc:93 computes the norm of the difference; for the unit-norm NetVLAD
+// descriptors both are 1 - sqrt(2 - 2 q.d)).  Not bit-identical to the scan above (different rounding: stated tolerance in
+// include/hfnet_hip.h), but bit-identical to the oracle's restatement of THIS formula (hfo_db_scores_gemm).
+// A workgroup owns 128 database rows x (NT * 32) queries x one EIGHTH of the descriptor length: the split along k gives
+// 10 000 rows 632 workgroups instead of 79.  Both operands are staged through LDS in 64-float chunks with coalesced
+// 256-byte row segments (a lane of the MFMA can only load its own row: 32 lines of 32 bytes per instruction straight from
+// memory made the address path, not the matrix cores, the limit); a wave multiplies its 32 rows against all query tiles.
+// Summation order: eight partial sums over k ascending inside each eighth, combined as a binary tree in k_db_combine.
+#define DBG_PARTS 8
+template <int NT>
+__global__ __launch_bounds__(256) void k_db_gemm(const float* __restrict__ q, int n_queries, int q0, const float* __restrict__ db, int n, int dim,
+                                                 float* __restrict__ partial /* [DBG_PARTS][NT*32][n] */) {
+    constexpr int LD = 68, QB = NT * 32;                      // (LDS rows: even k in floats [0, 32), odd k in [32, 64) -- see gemm_abt_tile128)
+    __shared__ __attribute__((aligned(16))) float As[128 * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[QB * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+    const int m0 = blockIdx.x * 128, part = blockIdx.y;
+    const int kw = dim / DBG_PARTS, kbase = part * kw;
+    const int lc = tid & 15, arow = (tid >> 4) * 8, brow = (tid >> 4) * (NT * 2);
+    const float* ag[8];
+    const float* bg[NT * 2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ag[j] = db + (long long)min(m0 + arow + j, n - 1) * dim + kbase + lc * 4;
+#pragma unroll
+    for (int j = 0; j < NT * 2; ++j) bg[j] = q + (long long)min(q0 + brow + j, n_queries - 1) * dim + kbase + lc * 4;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
+    f32x4 sa[8], sb[NT * 2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sa[j] = *(const f32x4*)(ag[j]);
+#pragma unroll
+    for (int j = 0; j < NT * 2; ++j) sb[j] = *(const f32x4*)(bg[j]);
+    for (int k0 = 0; k0 < kw; k0 += 64) {
+        __syncthreads();                                     // previous chunk fully consumed
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float* ap = As + (arow + j) * LD + lc * 2;
+            *(float2*)(ap) = float2{sa[j][0], sa[j][2]}; *(float2*)(ap + 32) = float2{sa[j][1], sa[j][3]};
+        }
+#pragma unroll
+        for (int j = 0; j < NT * 2; ++j) {
+            float* bp = Bs + (brow + j) * LD + lc * 2;
+            *(float2*)(bp) = float2{sb[j][0], sb[j][2]}; *(float2*)(bp + 32) = float2{sb[j][1], sb[j][3]};
+        }
+        __syncthreads();
+        if (k0 + 64 < kw) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sa[j] = *(const f32x4*)(ag[j] + k0 + 64);
+#pragma unroll
+            for (int j = 0; j < NT * 2; ++j) sb[j] = *(const f32x4*)(bg[j] + k0 + 64);
+        }
+        const float* ap = As + (wave * 32 + r) * LD + half * 32;
+        const float* bp = Bs + r * LD + half * 32;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const f32x4 av = *(const f32x4*)(ap + 4 * m);
+            f32x4 bv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = *(const f32x4*)(bp + nt * 32 * LD + 4 * m);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], acc[nt], 0, 0, 0);
+        }
+    }
+    // partial sums -> [part][query][row]: through LDS so that a half-wave writes 32 consecutive rows of one query
+    __syncthreads();
+    float* tp = As + wave * (32 * 33);                        // wave-private [query column][row], 33 floats apart (one query tile at a time)
+    const int i = m0 + wave * 32 + r;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) tp[r * 33 + (reg & 3) + 8 * (reg >> 2) + 4 * half] = acc[nt][reg];
+        asm volatile("" ::: "memory");                        // (LDS operations of one wave execute in order)
+        for (int c = half; c < 32; c += 2)
+            if (i < n) partial[((long long)part * QB + nt * 32 + c) * n + i] = tp[c * 33 + r];
+        asm volatile("" ::: "memory");
+    }
+}
+
+// partial sums of the eight parts -> scores; one thread per (query, row), rows along the lanes
+__global__ __launch_bounds__(256) void k_db_combine(const float* __restrict__ partial, int qb, int n_queries, int q0, const float* __restrict__ qnorm,
+                                                    const float* __restrict__ dnorm, const unsigned char* __restrict__ occupied, int n,
+                                                    float* __restrict__ scores, unsigned int* __restrict__ best_partial, int n_partials) {
+    const int i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, qi = q0 + c;
+    float score = 0.0f;                                       // (scores are >= 0: neutral for the maximum)
+    if (i < n) {
+        float p[DBG_PARTS];
+#pragma unroll
+        for (int w = 0; w < DBG_PARTS; ++w) p[w] = partial[((long long)w * qb + c) * n + i];
+        const float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        if (occupied[i]) {
+            const float t = qnorm[qi] + dnorm[i];
+            const float d2 = fmaxf(fmaf(-2.0f, s, t), 0.0f);
+            const float sc = 1.0f - sqrtf(d2);
+            score = sc > 0.f ? sc : 0.f;
+            scores[(long long)qi * n + i] = score;
+        } else {
+            scores[(long long)qi * n + i] = -1.0f;
+        }
+    }
+    float best = score;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off, 64));
+    if ((threadIdx.x & 63) == 0) best_partial[(long long)qi * n_partials + blockIdx.x * 4 + (threadIdx.x >> 6)] = __float_as_uint(best);
+}
+
+// |x|^2 in tree256 order for n_rows vectors (one wave each): query norms per call, database norms when a row is added
+__global__ __launch_bounds__(256) void k_sumsq_rows(const float* __restrict__ x, int n_rows, int dim, float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    const float* v = x + (long long)row * dim;
+    f32x4 p = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < dim; k += 256) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = k + lane * 4 + c;
+            if (i < dim) p[c] = fmaf(v[i], v[i], p[c]);
+        }
+    }
+    const float ss = tree256_wave4(p);
+    if (lane == 0) out[row] = ss;
+}
+
+hipError_t launch_sumsq_rows(const float* x, int n_rows, int dim, float* out, hipStream_t s) {
+    if (n_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sumsq_rows, dim3((n_rows + 3) / 4), dim3(256), 0, s, x, n_rows, dim, out);
+    return hipGetLastError();
+}
+
+int db_gemm_partials(int n) { return 4 * ((n + 255) / 256); }
+size_t db_gemm_scratch_floats(int n, int n_queries) { return (size_t)DBG_PARTS * (size_t)std::min(128, (n_queries + 31) / 32 * 32) * (size_t)n; }
+
+hipError_t launch_db_gemm(const float* q, int n_queries, const float* qnorm, const float* db, const float* dnorm, const unsigned char* occupied,
+                          int n, int dim, float* scores, unsigned int* best_partial, float* scratch, hipStream_t s) {
+    if (n <= 0 || n_queries <= 0) return hipSuccess;
+    if (dim % (DBG_PARTS * 64)) return hipErrorInvalidValue;
+    const dim3 grid((n + 127) / 128, DBG_PARTS);
+    for (int q0 = 0; q0 < n_queries; q0 += 128) {
+        const int nt = (std::min(128, n_queries - q0) + 31) / 32, qb = nt * 32, nq = std::min(qb, n_queries - q0);
+        switch (nt) {
+            case 1: hipLaunchKernelGGL((k_db_gemm<1>), grid, dim3(256), 0, s, q, n_queries, q0, db, n, dim, scratch); break;
+            case 2: hipLaunchKernelGGL((k_db_gemm<2>), grid, dim3(256), 0, s, q, n_queries, q0, db, n, dim, scratch); break;
+            case 3: hipLaunchKernelGGL((k_db_gemm<3>), grid, dim3(256), 0, s, q, n_queries, q0, db, n, dim, scratch); break;
+            default: hipLaunchKernelGGL((k_db_gemm<4>), grid, dim3(256), 0, s, q, n_queries, q0, db, n, dim, scratch); break;
+        }
+        hipLaunchKernelGGL(k_db_combine, dim3((n + 255) / 256, nq), dim3(256), 0, s, scratch, qb, n_queries, q0, qnorm, dnorm, occupied, n, scores,
+                           best_partial, db_gemm_partials(n));
+    }
+    return hipGetLastError();
 }
 
 // keep slots with score > 0.8*best (mode 0) / > max(0.5, 0.8*best) (mode 1), ascending slot order

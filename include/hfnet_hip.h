@@ -80,7 +80,8 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *   "dense_desc" (0)    1: dense descriptor head instead of the taps of the selected keypoints
  *   "two_streams" (3)   0 one stream; 1 fork after layer 7; 2 fork after the detector conv; 3 = 2 + deferred join
  *   "graph" (1), "pinned_frames" (4): host-pointer extractor calls
- * Every setting produces the same bits (tests/test_gpu_parity.py). */
+ *   "db_gemm_min_queries" (8): hfnet_db_query_batch switches to the MFMA form of the scores from this many queries on
+ * Every setting of the extractor switches produces the same bits (tests/test_gpu_parity.py). */
 int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value);
 int hfnet_engine_get_option(hfnet_engine* e, const char* name, int* value);
 int hfnet_engine_synchronize(hfnet_engine* e);
@@ -215,10 +216,17 @@ int hfnet_db_clear(hfnet_db* db);
 int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slot, float* cand_score,
                    int* n_cand, float* best_score, float* scores_all);
 /* The same scan for n_queries descriptors at once (a burst of keyframes at loop closing / relocalisation,
- * BASELINE config 5): the database crosses HBM once per 8 queries instead of once per query; per query the
- * results equal hfnet_db_query's bit for bit.  queries: [n_queries][dim]; cand_slot / cand_score:
- * [n_queries][capacity] (row q holds n_cand[q] entries); best_score: [n_queries] or NULL; scores_all:
- * [n_queries][capacity] or NULL. */
+ * BASELINE config 5).  queries: [n_queries][dim]; cand_slot / cand_score: [n_queries][capacity] (row q holds n_cand[q]
+ * entries); best_score: [n_queries] or NULL; scores_all: [n_queries][capacity] or NULL.
+ *  - fewer than "db_gemm_min_queries" (8) queries: the exact scan, the database crosses HBM once per 8 queries; per query
+ *    the results equal hfnet_db_query's bit for bit (dim <= 4096);
+ *  - otherwise: S = DB * Q^T on the matrix cores (the database crosses HBM once per 128 queries) and
+ *    score = max(0, 1 - sqrt(max(0, |q|^2 + |d|^2 - 2 S))), the same quantity in its inner-product form (dim % 512 == 0).
+ *    Tolerance against hfnet_db_query: |score difference| <= 1e-6 / max(||q - d||, 2e-3) (the rounding of the three terms
+ *    is ~1e-7 in the squared distance; the square root amplifies it for near-identical descriptors: 5e-6 at a distance of
+ *    0.2, 5e-4 for a descriptor scanned against itself); a slot within that distance of the 0.8 * best threshold may fall
+ *    on the other side.  Bit-exact against the oracle's restatement of
+ *    this formula (hfo_db_scores_gemm). */
 int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int mode, int32_t* cand_slot,
                          float* cand_score, int32_t* n_cand, float* best_score, float* scores_all);
 

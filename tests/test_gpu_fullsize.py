@@ -112,11 +112,13 @@ def test_loop_closure_stress_10k_database(engine):
         assert np.array_equal(cs, ridx) and best == rbest
         cs1, _, _, _ = db.query(q, 1)
         assert cs1.tolist() == [planted]
-    # config 5, Q = 64 (not a multiple of the 8-query tile + an erased slot): batched == single-query == oracle
+    # config 5, Q = 67 (not a multiple of any tile + an erased slot)
     db.erase(17)
     planted = rng.integers(0, n, 67)
     qs = rows[planted] + 0.003 * rng.standard_normal((67, dim)).astype(np.float32)
     qs = (qs / np.linalg.norm(qs, axis=1, keepdims=True)).astype(np.float32)
+    # (a) the exact batched scan (engine option db_gemm_min_queries above Q): batched == single-query == oracle, bit for bit
+    engine.set_option("db_gemm_min_queries", 1 << 20)
     for mode in (0, 1):
         cands, best, scores = db.query_batch(qs, mode, want_scores=True)
         for i in (0, 7, 8, 33, 66):
@@ -126,4 +128,28 @@ def test_loop_closure_stress_10k_database(engine):
         ref = O.db_scores(qs[5], rows)
         ref[17] = -1.0
         assert np.array_equal(scores[5], ref)
+    # (b) the default for >= 8 queries: S = DB * Q^T on the matrix cores, score = 1 - sqrt(|q|^2 + |d|^2 - 2 S).
+    #     Bit-exact against the oracle's restatement of that formula; against the exact scan within the stated tolerance
+    #     1e-6 / max(||q - d||, 2e-3); candidate sets equal except slots that close to the 0.8 * best threshold.
+    engine.set_option("db_gemm_min_queries", 8)
+    ref_g = O.db_scores_gemm(qs, rows)
+    ref_g[:, 17] = -1.0
+    near = 0
+    for mode in (0, 1):
+        cands, best, scores = db.query_batch(qs, mode, want_scores=True)
+        assert np.array_equal(scores, ref_g), f"{np.count_nonzero(scores != ref_g)} scores differ from hfo_db_scores_gemm"
+        for i in range(67):
+            ridx, rbest = O.db_candidates(ref_g[i], mode)
+            assert best[i] == rbest and np.array_equal(cands[i][0], ridx) and np.array_equal(cands[i][1], ref_g[i][ridx])
+        for i in (0, 5, 33, 66):
+            exact = O.db_scores(qs[i], rows); exact[17] = -1.0
+            dist = np.maximum(1.0 - np.maximum(exact, 0.0), 2e-3)
+            err = np.abs(scores[i].astype(np.float64) - exact)
+            assert np.all(err <= 1e-6 / dist), f"query {i}: max err {err.max():.2e} (x dist {np.max(err * dist):.2e})"
+            eidx, ebest = O.db_candidates(exact, mode)
+            thr = max(0.5, 0.8 * ebest) if mode else 0.8 * ebest
+            diff = set(eidx.tolist()) ^ set(cands[i][0].tolist())
+            assert all(abs(exact[j] - thr) <= 1e-4 for j in diff), diff
+            near += len(diff)
+    print(f"db gemm: {near} candidate(s) within tolerance of the threshold fell on the other side")
     db.close()
