@@ -608,3 +608,29 @@ def test_store_put_extracted_matches_host_round_trip(engine, oracle_model):
     with pytest.raises(capi.HfnetError):
         small.put_extracted(0, x, 0)
     small.close(); store.close(); x.close()
+
+
+def test_container_without_memberships_gamma(oracle_model, weights_path, tmp_path):
+    """a real HF-Net checkpoint has no BatchNorm gamma for the NetVLAD memberships conv (slim.batch_norm scale=False): the
+    library reads the missing tensor as 1 -- same bits as a container that stores ones, and as the oracle on either"""
+    from hfnet_slam_amd import capi, weights
+    from oracle import oracle as O
+    w = weights.load(weights_path)
+    gname = "global_head/vlad/memberships/BatchNorm/gamma"
+    without = {k: v for k, v in w.items() if k != gname}
+    ones = dict(w); ones[gname] = np.ones_like(w[gname])
+    pa, pb = str(tmp_path / "without.hfw"), str(tmp_path / "ones.hfw")
+    weights.save(pa, without); weights.save(pb, ones)
+    img = synth_image(96, 128, 21)
+    res = []
+    for p in (pa, pb):
+        e = capi.Engine(p, 0)
+        m = capi.Model(e, capi.MODE_LOCAL_AND_GLOBAL, 96, 128, 200)
+        st, kps, desc, g = m.detect(img, 150, 0.01)
+        assert st == capi.OK, capi.last_error()
+        res.append(g.copy())
+        m.close(); e.close()
+    _eq("global: missing gamma == ones", res[0], res[1])
+    ok, _, _, rg = O.Model(pa).detect(img, O.MODE_LOCAL_AND_GLOBAL, 150, 0.01)
+    assert ok
+    _eq("global vs oracle", res[0], rg)

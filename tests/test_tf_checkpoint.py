@@ -70,3 +70,60 @@ def test_import_hfnet_checkpoint(tmp_path):
     T.write_bundle(prefix, ck, data_crc=False)
     with pytest.raises(ValueError, match="missing"):
         T.import_hfnet(prefix)
+
+
+def test_reader_on_an_independently_written_bundle():
+    """tests/golden/tf_bundle/ was written by tests/golden/make_tf_bundle.py, a second implementation of the table / bundle
+    formats that shares no code with tf_checkpoint.py (shortened index separators, several data blocks with a second
+    restart point, proto3 default omission, a scalar, a DT_STRING tensor, optimizer slots): the reader must decode the
+    committed bytes to the values the generator derives from the tensor index."""
+    import os
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, here)
+    try:
+        import make_tf_bundle as M
+    finally:
+        sys.path.remove(here)
+    prefix = os.path.join(here, "tf_bundle", "model.ckpt-7")
+    index = T.read_index(prefix + ".index")
+    want = M.tensors()
+    assert index[""]["num_shards"] == 1
+    assert sorted(k for k in index if k) == sorted(list(want) + ["_CHECKPOINTABLE_OBJECT_GRAPH"])
+    assert index["_CHECKPOINTABLE_OBJECT_GRAPH"]["dtype"] == 7 and index["global_step"]["shape"] == []
+    first = sorted(want)[0]
+    assert index[first]["offset"] == 0 and index[first]["shard_id"] == 0          # fields the writer omitted (proto3 defaults)
+    got = T.read_checkpoint(prefix, verify_data_crc=True)
+    assert "_CHECKPOINTABLE_OBJECT_GRAPH" not in got                              # strings are not weights
+    for k, v in want.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape and np.array_equal(got[k], v), k
+    assert got["global_head/vlad/clusters"].shape == (1, 1, 1, 2, 32) and int(got["global_step"]) == 83096
+
+
+def test_checkpoint_without_memberships_gamma(tmp_path):
+    """slim.batch_norm defaults to scale=False and the NetVLAD memberships conv is built outside the mobilenet arg_scope
+    (hfnet/models/utils/layers.py:71-76): a real checkpoint has no gamma there.  The importer passes the tensor set on
+    without it and the oracle (like the HIP library, tests/test_gpu_parity.py) reads the missing gamma as 1."""
+    from oracle import oracle as O
+    spec = net_spec(0.75, 8, 64)
+    ref = W.synthetic_weights(3, spec)
+    gname = "global_head/vlad/memberships/BatchNorm/gamma"
+    ck = {n: (a.reshape(1, 1, 1, *a.shape) if n == "global_head/vlad/clusters" else a) for n, a in ref.items() if n != gname}
+    prefix = str(tmp_path / "model.ckpt-83096")
+    T.write_bundle(prefix, ck, data_crc=False)
+    got = T.import_hfnet(prefix)
+    assert gname not in got and len(got) == len(ref) - 1
+    p_without, p_ones = str(tmp_path / "a.hfw"), str(tmp_path / "b.hfw")
+    W.save(p_without, got)
+    ones = dict(ref); ones[gname] = np.ones_like(ref[gname])
+    W.save(p_ones, ones)
+    O.build()
+    img = np.random.default_rng(4).integers(0, 256, (64, 96), dtype=np.uint8)
+    a = O.Model(p_without).run_local(img, want_global=True)
+    b = O.Model(p_ones).run_local(img, want_global=True)
+    assert np.array_equal(a["global"], b["global"])
+    # any other missing BatchNorm tensor is still an error
+    del ck["global_head/vlad/memberships/BatchNorm/beta"]
+    T.write_bundle(prefix, ck, data_crc=False)
+    with pytest.raises(ValueError, match="missing"):
+        T.import_hfnet(prefix)
