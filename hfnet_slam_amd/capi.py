@@ -29,7 +29,7 @@ SYMBOLS = [
     "hfnet_extractor_create", "hfnet_extractor_destroy", "hfnet_extractor_tables",
     "hfnet_extractor_extract", "hfnet_extractor_extract_batch",
     "hfnet_descriptor_distance", "hfnet_resampler", "hfnet_match_search_by_bow", "hfnet_match_search_by_bow_batch", "hfnet_match_search_for_triangulation", "hfnet_match_search_for_triangulation_batch",
-    "hfnet_store_create", "hfnet_store_destroy", "hfnet_store_put", "hfnet_store_put_extracted", "hfnet_store_rows", "hfnet_store_set_flags", "hfnet_store_search_by_bow",
+    "hfnet_extractor_attach_store", "hfnet_store_create", "hfnet_store_destroy", "hfnet_store_put", "hfnet_store_put_extracted", "hfnet_store_rows", "hfnet_store_set_flags", "hfnet_store_search_by_bow",
     "hfnet_store_search_for_triangulation",
     "hfnet_db_create", "hfnet_db_destroy", "hfnet_db_add", "hfnet_db_erase", "hfnet_db_clear", "hfnet_db_query", "hfnet_db_query_batch",
     "hfnet_profile_enable", "hfnet_profile_reset", "hfnet_profile_filter", "hfnet_profile_count", "hfnet_profile_get",
@@ -317,6 +317,10 @@ class Extractor:
         _chk(lib().hfnet_extractor_extract_batch(self.h, f, _p(imgs), imgs.strides[1], C.c_size_t(imgs.strides[0]), _p(kps), _p(desc),
                                                  _p(g), _p(n), 0))
         return n, kps, desc, g
+
+    def attach_store(self, store, first_slot: int = 0):
+        """every following host-pointer extraction also leaves frame f in slot (first_slot + f) % n_sets of `store`"""
+        _chk(lib().hfnet_extractor_attach_store(self.h, store.h if store is not None else None, int(first_slot)))
 
     def extract_batch_device(self, n_frames, d_images, row_stride, frame_stride, d_kps, d_desc, d_global, d_n):
         """All pointers are raw device addresses (ints); only enqueues work on the engine's GPU."""

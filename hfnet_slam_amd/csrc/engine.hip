@@ -771,6 +771,13 @@ void hfnet_extractor_destroy(hfnet_extractor* x) {
     for (auto& kv : x->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : x->allocs) (void)hipFree(p);
     if (x->h_pin) (void)hipHostFree(x->h_pin);
+    for (int s = 0; s < 2; ++s) {
+        if (x->pipe.h_in[s]) (void)hipHostFree(x->pipe.h_in[s]);
+        if (x->pipe.h_out[s]) (void)hipHostFree(x->pipe.h_out[s]);
+        for (hipEvent_t ev : {x->pipe.ev_up[s], x->pipe.ev_comp[s], x->pipe.ev_down[s]}) if (ev) (void)hipEventDestroy(ev);
+    }
+    if (x->pipe.s_up) (void)hipStreamDestroy(x->pipe.s_up);
+    if (x->pipe.s_down) (void)hipStreamDestroy(x->pipe.s_down);
     delete x;
 }
 
@@ -868,6 +875,131 @@ static int extract_chunk_graphed(hfnet_extractor* x, int nb, bool pinned) {
     return HFNET_OK;
 }
 
+// device copies of a host-pointer chunk for the attached store (hfnet_extractor_attach_store), on the extractor's stream
+static int copy_chunk_to_store(hfnet_extractor* x, int first_frame, int nb, const float* d_desc, const int* d_n, hipStream_t st) {
+    hfnet_store* s = x->att_store;
+    if (!s) return HFNET_OK;
+    for (int f = 0; f < nb; ++f) {
+        const int slot = (x->att_first + first_frame + f) % s->n_sets;
+        const int rows = std::min(x->n_features, s->max_rows);
+        HF_HIP(hipMemcpyAsync(s->d_desc + (size_t)slot * s->max_rows * s->dim, d_desc + (size_t)f * x->n_features * HFNET_DESC_DIM,
+                              sizeof(float) * (size_t)rows * s->dim, hipMemcpyDeviceToDevice, st));
+        HF_HIP(hipMemcpyAsync(s->d_rows + slot, d_n + f, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        HF_HIP(hipMemsetAsync(s->d_flags + (size_t)slot * s->max_rows, 0, (size_t)s->max_rows, st));
+    }
+    return HFNET_OK;
+}
+
+static int host_pipe_init(hfnet_extractor* x) {
+    hfnet_extractor::HostPipe& p = x->pipe;
+    if (p.ready) return HFNET_OK;
+    Engine& eng = x->eng->impl;
+    const size_t B = (size_t)x->max_batch, img = (size_t)x->width * x->height, G = (size_t)eng.w.global_dim;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    size_t off = 0;
+    p.o_n = off; off += up(sizeof(int) * B);
+    p.o_nl = off; off += up(sizeof(int) * B * x->n_levels);
+    p.o_g = off; off += up(sizeof(float) * B * G);
+    p.o_k = off; off += up(sizeof(hfnet_keypoint) * B * x->n_features);
+    p.o_d = off; off += up(sizeof(float) * HFNET_DESC_DIM * B * x->n_features);
+    p.out_bytes = off;
+    for (int s = 0; s < 2; ++s) {
+        HF_HIP(hipHostMalloc((void**)&p.h_in[s], B * img, hipHostMallocDefault));
+        HF_HIP(hipHostMalloc((void**)&p.h_out[s], p.out_bytes, hipHostMallocDefault));
+        HF_HIP(hipEventCreateWithFlags(&p.ev_up[s], hipEventDisableTiming));
+        HF_HIP(hipEventCreateWithFlags(&p.ev_comp[s], hipEventDisableTiming));
+        HF_HIP(hipEventCreateWithFlags(&p.ev_down[s], hipEventDisableTiming));
+        HF_TRY(dalloc(x->allocs, &p.d_glob[s], B * G));
+    }
+    p.d_in[0] = x->d_pyr[0]; p.d_kps[0] = x->d_kps; p.d_desc[0] = x->d_desc; p.d_n[0] = x->d_n; p.d_nl[0] = x->d_n_level;
+    HF_TRY(dalloc(x->allocs, &p.d_in[1], B * img));
+    HF_TRY(dalloc(x->allocs, &p.d_kps[1], B * x->n_features));
+    HF_TRY(dalloc(x->allocs, &p.d_desc[1], B * x->n_features * HFNET_DESC_DIM));
+    HF_TRY(dalloc(x->allocs, &p.d_n[1], B));
+    HF_TRY(dalloc(x->allocs, &p.d_nl[1], B * x->n_levels));
+    HF_HIP(hipStreamCreateWithFlags(&p.s_up, hipStreamNonBlocking));
+    HF_HIP(hipStreamCreateWithFlags(&p.s_down, hipStreamNonBlocking));
+    p.ready = true;
+    return HFNET_OK;
+}
+
+// host buffers in and out, frames [f0, n_frames): chunk c computes on the extractor's streams while chunk c + 1's images go
+// up (pinned block -> device, copy stream 1) and chunk c - 1's results come down (device -> pinned block, copy stream 2) and
+// are handed to the caller's buffers by this thread
+static int extract_host_pipelined(hfnet_extractor* x, int f0, int n_frames, const uint8_t* images, int row_stride, size_t frame_stride,
+                                  hfnet_keypoint* kps, float* local_desc, float* global_desc, int* n_out) {
+    HF_TRY(host_pipe_init(x));
+    hfnet_extractor::HostPipe& p = x->pipe;
+    Engine& eng = x->eng->impl;
+    hipStream_t st = x->net.stream;
+    const size_t img = (size_t)x->width * x->height, G = (size_t)eng.w.global_dim, NF = (size_t)x->n_features;
+    const int n_chunks = (n_frames - f0 + x->max_batch - 1) / x->max_batch;
+    auto drain = [&](int c) -> int {
+        const int s = c & 1, c0 = f0 + c * x->max_batch, nb = std::min(x->max_batch, n_frames - c0);
+        HF_HIP(hipEventSynchronize(p.ev_down[s]));
+        const unsigned char* h = p.h_out[s];
+        const int* hn = (const int*)(h + p.o_n);
+        for (int f = 0; f < nb; ++f) {
+            const int n = hn[f];
+            n_out[c0 + f] = n;
+            if (global_desc) std::memcpy(global_desc + (size_t)(c0 + f) * G, h + p.o_g + sizeof(float) * (size_t)f * G, sizeof(float) * G);
+            if (x->att_store) x->att_store->rows[(x->att_first + c0 + f) % x->att_store->n_sets] = std::min(n, x->att_store->max_rows);
+            if (n <= 0) continue;
+            std::memcpy(kps + (size_t)(c0 + f) * NF, h + p.o_k + sizeof(hfnet_keypoint) * (size_t)f * NF, sizeof(hfnet_keypoint) * n);
+            std::memcpy(local_desc + (size_t)(c0 + f) * NF * HFNET_DESC_DIM, h + p.o_d + sizeof(float) * HFNET_DESC_DIM * (size_t)f * NF,
+                        sizeof(float) * HFNET_DESC_DIM * n);
+        }
+        if (c == n_chunks - 1) {                      // what hfnet_store_put_extracted / n_per_level see: the last chunk
+            std::fill(x->last_n.begin(), x->last_n.end(), -1);
+            for (int f = 0; f < nb; ++f) x->last_n[f] = hn[f];
+            x->last_desc = p.d_desc[s]; x->last_cnt = p.d_n[s];
+            if (x->h_pin && x->pinned_frames >= 1) std::memcpy(x->h_pin + x->pin_nl, h + p.o_nl, sizeof(int) * x->n_levels);
+            else HF_HIP(hipMemcpy(x->d_n_level, p.d_nl[s], sizeof(int) * x->n_levels, hipMemcpyDeviceToDevice));
+        }
+        return HFNET_OK;
+    };
+    for (int c = 0; c < n_chunks; ++c) {
+        const int s = c & 1, c0 = f0 + c * x->max_batch, nb = std::min(x->max_batch, n_frames - c0);
+        // (slot s is free: chunk c - 2 was drained -- its download, hence its compute and upload, are complete)
+        for (int f = 0; f < nb; ++f) {
+            const uint8_t* src = images + (size_t)(c0 + f) * frame_stride;
+            unsigned char* dst = p.h_in[s] + (size_t)f * img;
+            if (row_stride == x->width) std::memcpy(dst, src, img);
+            else for (int y = 0; y < x->height; ++y) std::memcpy(dst + (size_t)y * x->width, src + (size_t)y * row_stride, (size_t)x->width);
+        }
+        HF_HIP(hipMemcpyAsync(p.d_in[s], p.h_in[s], img * nb, hipMemcpyHostToDevice, p.s_up));
+        HF_HIP(hipEventRecord(p.ev_up[s], p.s_up));
+        HF_HIP(hipStreamWaitEvent(st, p.ev_up[s], 0));
+        HF_TRY(extract_chunk(x, nb, p.d_in[s], x->width, (long long)img, p.d_kps[s], p.d_desc[s], p.d_glob[s], p.d_n[s], p.d_nl[s]));
+        HF_TRY(copy_chunk_to_store(x, c0, nb, p.d_desc[s], p.d_n[s], st));
+        HF_HIP(hipEventRecord(p.ev_comp[s], st));
+        HF_HIP(hipStreamWaitEvent(p.s_down, p.ev_comp[s], 0));
+        unsigned char* h = p.h_out[s];
+        HF_HIP(hipMemcpyAsync(h + p.o_n, p.d_n[s], sizeof(int) * nb, hipMemcpyDeviceToHost, p.s_down));
+        HF_HIP(hipMemcpyAsync(h + p.o_nl, p.d_nl[s], sizeof(int) * (size_t)x->n_levels * nb, hipMemcpyDeviceToHost, p.s_down));
+        HF_HIP(hipMemcpyAsync(h + p.o_g, p.d_glob[s], sizeof(float) * (size_t)nb * G, hipMemcpyDeviceToHost, p.s_down));
+        HF_HIP(hipMemcpyAsync(h + p.o_k, p.d_kps[s], sizeof(hfnet_keypoint) * (size_t)nb * NF, hipMemcpyDeviceToHost, p.s_down));
+        HF_HIP(hipMemcpyAsync(h + p.o_d, p.d_desc[s], sizeof(float) * HFNET_DESC_DIM * (size_t)nb * NF, hipMemcpyDeviceToHost, p.s_down));
+        HF_HIP(hipEventRecord(p.ev_down[s], p.s_down));
+        if (c >= 1) HF_TRY(drain(c - 1));
+    }
+    HF_TRY(drain(n_chunks - 1));
+    return HFNET_OK;
+}
+
+int hfnet_extractor_attach_store(hfnet_extractor* x, hfnet_store* s, int first_slot) {
+    API_GUARD(x, "extractor");
+    std::lock_guard<std::mutex> lk(x->mu);
+    if (s) {
+        if (s->eng != x->eng) { set_error("store and extractor belong to different engines"); return HFNET_ERR_INVALID_ARG; }
+        if (s->dim != HFNET_DESC_DIM) { set_error("store: descriptor width %d, extractor produces %d", s->dim, HFNET_DESC_DIM); return HFNET_ERR_SHAPE; }
+        if (s->max_rows < x->n_features) { set_error("store: %d rows per slot < the extractor's %d features", s->max_rows, x->n_features); return HFNET_ERR_CAPACITY; }
+        if (first_slot < 0 || first_slot >= s->n_sets) { set_error("store: first_slot %d outside [0, %d)", first_slot, s->n_sets); return HFNET_ERR_INVALID_ARG; }
+    }
+    x->att_store = s; x->att_first = s ? first_slot : 0;
+    return HFNET_OK;
+}
+
 int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_t* images, int row_stride, size_t frame_stride,
                                   hfnet_keypoint* kps, float* local_desc, float* global_desc, int* n_out, int on_device) {
     API_GUARD(x, "extractor");
@@ -899,12 +1031,15 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
                 else for (int y = 0; y < x->height; ++y) std::memcpy(dst + (size_t)y * x->width, src + (size_t)y * row_stride, (size_t)x->width);
             }
             HF_TRY(extract_chunk_graphed(x, nb, true));
+            HF_TRY(copy_chunk_to_store(x, f0, nb, x->d_desc, x->d_n, st));
             HF_HIP(hipStreamSynchronize(st));
+            x->last_desc = x->d_desc; x->last_cnt = x->d_n;
             const int* hn = (const int*)(x->h_pin + x->pin_n);
             for (int f = 0; f < nb; ++f) {
                 const int n = hn[f];
                 n_out[f0 + f] = n;
                 x->last_n[f] = n;
+                if (x->att_store) x->att_store->rows[(x->att_first + f0 + f) % x->att_store->n_sets] = std::min(n, x->att_store->max_rows);
                 if (global_desc) std::memcpy(global_desc + (size_t)(f0 + f) * G, x->h_pin + x->pin_g + sizeof(float) * (size_t)f * G, sizeof(float) * G);
                 if (n <= 0) continue;
                 std::memcpy(kps + (size_t)(f0 + f) * x->n_features, x->h_pin + x->pin_k + sizeof(hfnet_keypoint) * (size_t)f * x->n_features, sizeof(hfnet_keypoint) * n);
@@ -912,22 +1047,9 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
                             x->h_pin + x->pin_d + sizeof(float) * HFNET_DESC_DIM * (size_t)f * x->n_features, sizeof(float) * HFNET_DESC_DIM * n);
             }
         } else {
-            for (int f = 0; f < nb; ++f)
-                HF_HIP(hipMemcpy2DAsync(x->d_pyr[0] + (size_t)f * x->width * x->height, x->width, images + (size_t)(f0 + f) * frame_stride, row_stride,
-                                        x->width, x->height, hipMemcpyHostToDevice, st));
-            HF_TRY(extract_chunk_graphed(x, nb, false));
-            HF_HIP(hipMemcpyAsync(n_out + f0, x->d_n, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
-            if (global_desc) HF_HIP(hipMemcpyAsync(global_desc + (size_t)f0 * G, x->net.global_out, sizeof(float) * (size_t)nb * G, hipMemcpyDeviceToHost, st));
-            HF_HIP(hipStreamSynchronize(st));
-            for (int f = 0; f < nb; ++f) {
-                const int n = n_out[f0 + f];
-                x->last_n[f] = n;
-                if (n <= 0) continue;
-                HF_HIP(hipMemcpyAsync(kps + (size_t)(f0 + f) * x->n_features, x->d_kps + (size_t)f * x->n_features, sizeof(hfnet_keypoint) * n, hipMemcpyDeviceToHost, st));
-                HF_HIP(hipMemcpyAsync(local_desc + (size_t)(f0 + f) * x->n_features * HFNET_DESC_DIM, x->d_desc + (size_t)f * x->n_features * HFNET_DESC_DIM,
-                                      sizeof(float) * HFNET_DESC_DIM * n, hipMemcpyDeviceToHost, st));
-            }
-            HF_HIP(hipStreamSynchronize(st));
+            // everything that is left, as a double-buffered pipeline over its chunks
+            HF_TRY(extract_host_pipelined(x, f0, n_frames, images, row_stride, frame_stride, kps, local_desc, global_desc, n_out));
+            break;
         }
     }
     if (on_device) HF_HIP(eng.note_extract(st));
@@ -1171,9 +1293,11 @@ int hfnet_store_put_extracted(hfnet_store* st, int slot, hfnet_extractor* x, int
     HF_HIP(hipSetDevice(e.device));
     // the extraction that filled the staging buffers was synchronised by its host-pointer call; the copies are ordered
     // before later matches by the engine stream, and before the next extraction by the synchronisation below
-    if (n) HF_HIP(hipMemcpyAsync(st->d_desc + (size_t)slot * st->max_rows * st->dim, x->d_desc + (size_t)frame * x->n_features * HFNET_DESC_DIM,
+    const float* src_desc = x->last_desc ? x->last_desc : x->d_desc;
+    const int* src_n = x->last_cnt ? x->last_cnt : x->d_n;
+    if (n) HF_HIP(hipMemcpyAsync(st->d_desc + (size_t)slot * st->max_rows * st->dim, src_desc + (size_t)frame * x->n_features * HFNET_DESC_DIM,
                                  sizeof(float) * (size_t)n * st->dim, hipMemcpyDeviceToDevice, e.stream));
-    HF_HIP(hipMemcpyAsync(st->d_rows + slot, x->d_n + frame, sizeof(int32_t), hipMemcpyDeviceToDevice, e.stream));
+    HF_HIP(hipMemcpyAsync(st->d_rows + slot, src_n + frame, sizeof(int32_t), hipMemcpyDeviceToDevice, e.stream));
     HF_HIP(hipMemsetAsync(st->d_flags + (size_t)slot * st->max_rows, 0, (size_t)st->max_rows, e.stream));
     HF_HIP(hipStreamSynchronize(e.stream));
     st->rows[slot] = n;

@@ -168,6 +168,27 @@ struct hfnet_extractor {
     std::vector<int> last_n;             // keypoint counts of the last host-pointer call per staging frame (-1: unknown)
     int pinned_frames = 0;
     size_t pin_n = 0, pin_nl = 0, pin_g = 0, pin_k = 0, pin_d = 0;   // byte offsets of the sections
+    // Larger host-pointer calls run as a double-buffered pipeline over their chunks: while chunk c computes, chunk c + 1's
+    // images go up and chunk c - 1's results come down through pinned blocks on two copy streams (built on first use).
+    // Slot 0 of the device side is the staging above (d_pyr[0], d_kps, d_desc, d_n, d_n_level).
+    struct HostPipe {
+        bool ready = false;
+        unsigned char* h_in[2] = {nullptr, nullptr};
+        unsigned char* h_out[2] = {nullptr, nullptr};         // [n | n_level | global | keypoints | descriptors] at full capacity
+        size_t o_n = 0, o_nl = 0, o_g = 0, o_k = 0, o_d = 0, out_bytes = 0;
+        uint8_t* d_in[2] = {nullptr, nullptr};
+        hfnet_keypoint* d_kps[2] = {nullptr, nullptr};
+        float* d_desc[2] = {nullptr, nullptr};
+        float* d_glob[2] = {nullptr, nullptr};
+        int* d_n[2] = {nullptr, nullptr};
+        int* d_nl[2] = {nullptr, nullptr};
+        hipStream_t s_up = nullptr, s_down = nullptr;
+        hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
+    } pipe;
+    const float* last_desc = nullptr;    // device descriptors / counts of the last host-pointer chunk (hfnet_store_put_extracted)
+    const int* last_cnt = nullptr;
+    hfnet_store* att_store = nullptr;    // hfnet_extractor_attach_store: device copies of every host-pointer frame
+    int att_first = 0;
     std::mutex mu;
 };
 

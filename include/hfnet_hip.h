@@ -133,7 +133,9 @@ int hfnet_extractor_extract(hfnet_extractor* x, const uint8_t* image, int row_st
  * height x row_stride bytes, `frame_stride` bytes apart; outputs are n_frames slots of n_features
  * rows each.  `on_device` != 0: every pointer is a device pointer on the engine's GPU and the call
  * only enqueues work (use hfnet_engine_synchronize; the matcher entry points order themselves behind it, see
- * hfnet_engine_fence).  The global descriptors of such a call are produced on a second stream that may still run
+ * hfnet_engine_fence).  `on_device` == 0 with more frames than the extractor's max_batch: the chunks run as a
+ * double-buffered pipeline (pinned staging, two copy streams): chunk c + 1 goes up and chunk c - 1 comes down while chunk c
+ * computes.  The global descriptors of such a call are produced on a second stream that may still run
  * while the next call's backbone executes: they are complete after hfnet_engine_synchronize. */
 int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_t* images,
                                   int row_stride, size_t frame_stride, hfnet_keypoint* kps,
@@ -188,6 +190,11 @@ int hfnet_store_put(hfnet_store* s, int slot, const float* rows, int n_rows);
 /* the descriptors of staging frame `frame` of the extractor's last host-pointer call, device to device: the block of a
  * frame that was just extracted never travels back up (slot flags are cleared, like hfnet_store_put) */
 int hfnet_store_put_extracted(hfnet_store* s, int slot, hfnet_extractor* x, int frame);
+/* Host pipelines that also match on the device: after this call, frame f of every host-pointer extraction
+ * (hfnet_extractor_extract / _extract_batch with on_device == 0) additionally lands, device to device, in slot
+ * (first_slot + f) % n_sets of `store` (flags cleared), so a whole batch can be matched by slot without its descriptors
+ * going back up.  store == NULL detaches. */
+int hfnet_extractor_attach_store(hfnet_extractor* x, hfnet_store* s, int first_slot);
 int hfnet_store_rows(const hfnet_store* s, int slot);            /* rows of a slot, -1 for a bad slot */
 int hfnet_store_set_flags(hfnet_store* s, int slot, const uint8_t* flags, int n_rows);
 int hfnet_store_search_by_bow(hfnet_store* s, int n_pairs, const int32_t* query_set, const int32_t* train_set,

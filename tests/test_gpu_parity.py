@@ -634,3 +634,42 @@ def test_container_without_memberships_gamma(oracle_model, weights_path, tmp_pat
     ok, _, _, rg = O.Model(pa).detect(img, O.MODE_LOCAL_AND_GLOBAL, 150, 0.01)
     assert ok
     _eq("global vs oracle", res[0], rg)
+
+
+def test_host_pipeline_and_attached_store(engine, oracle_model):
+    """host-pointer batch call over several chunks (the double-buffered pipeline: 7 frames through a max_batch=2 extractor,
+    an odd tail, strided input) == per-frame oracle; the attached store receives every frame's block device to device, and
+    matching by slot equals the oracle's SearchByBoW on the downloaded descriptors"""
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    w, h, nf, nl, F = 160, 120, 250, 3, 7
+    x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, nl, max_batch=2)
+    store = capi.Store(engine, 8, nf)
+    x.attach_store(store, 3)                                   # frame f -> slot (3 + f) % 8
+    big = np.stack([synth_image(h + 6, w + 10, 700 + i, "natural" if i % 2 else "uniform") for i in range(F)])
+    imgs = big[:, 2:2 + h, 4:4 + w]                            # non-contiguous rows: row stride w + 10
+    kps = np.zeros((F, nf), capi.KP_DTYPE); desc = np.zeros((F, nf, 256), np.float32)
+    g = np.zeros((F, engine.global_dim), np.float32); n = np.zeros((F,), np.int32)
+    import ctypes as C
+    st = capi.lib().hfnet_extractor_extract_batch(x.h, F, C.c_void_p(imgs.ctypes.data), imgs.strides[1], C.c_size_t(imgs.strides[0]),
+                                                  C.c_void_p(kps.ctypes.data), C.c_void_p(desc.ctypes.data), C.c_void_p(g.ctypes.data),
+                                                  C.c_void_p(n.ctypes.data), 0)
+    assert st == capi.OK, capi.last_error()
+    ref = [oracle_model.extract(np.ascontiguousarray(imgs[i]), nf, 0.01, nl, 1.2) for i in range(F)]
+    for i, (rn, rk, rd, rg, _) in enumerate(ref):
+        assert n[i] == rn
+        _eq(f"kps {i}", kps[i, :rn], rk); _eq(f"desc {i}", desc[i, :rn], rd); _eq(f"global {i}", g[i], rg)
+        assert store.rows((3 + i) % 8) == rn
+    pairs = [((3 + i - 1) % 8, (3 + i) % 8) for i in range(1, F)]
+    cnt, match, dist = store.search_by_bow(pairs, 0.6)
+    for p, i in enumerate(range(1, F)):
+        rc, rm, rdist = O.search_by_bow(ref[i - 1][2], ref[i][2], 0.6)
+        assert cnt[p] == rc
+        _eq(f"match {i}", match[p, :ref[i - 1][0]], rm); _eq(f"dist {i}", dist[p, :ref[i - 1][0]], rdist)
+    # the last chunk is what put_extracted sees (one frame: F is odd)
+    store.put_extracted(2, x, 0)                               # (slot 2 is not one of the attached frames' slots)
+    assert store.rows(2) == ref[F - 1][0]
+    cnt2, m2, _ = store.search_by_bow([((3 + F - 2) % 8, 2)], 0.6)
+    assert cnt2[0] == cnt[-1] and np.array_equal(m2[0], match[-1])
+    x.attach_store(None)
+    store.close(); x.close()
