@@ -354,12 +354,12 @@ def config_host_io(capi, eng, chunk, chunks_per_call=4, reps=5):
     store = capi.Store(eng, n, N_FEAT)
     ext.attach_store(store, 0)
     imgs = make_frames(n, 0)
-    ext.extract_batch(imgs)
+    out = ext.extract_batch(imgs)                              # (the result arrays are reused: a caller's buffers are paged in)
     pairs = [(f - 1, f) for f in range(1, n)]
     t_e, t_all = [], []
     for r in range(reps):
         t0 = time.perf_counter()
-        ext.extract_batch(imgs)
+        ext.extract_batch(imgs, out)
         t1 = time.perf_counter()
         for p0 in range(0, len(pairs), chunk):
             store.search_by_bow(pairs[p0:p0 + chunk], TH_LOW)

@@ -306,14 +306,19 @@ class Extractor:
         _chk(lib().hfnet_extractor_extract(self.h, _p(img), img.strides[0], _p(kps), _p(desc), _p(g), C.byref(n), _p(npl)))
         return n.value, kps[:max(n.value, 0)].copy(), desc[:max(n.value, 0)].copy(), g, npl
 
-    def extract_batch(self, imgs: np.ndarray):
-        """imgs: [F, H, W] uint8 (host).  Returns (n[F], kps[F, n_features], desc[F, n_features, 256], global[F, G])."""
+    def extract_batch(self, imgs: np.ndarray, out=None):
+        """imgs: [F, H, W] uint8 (host).  Returns (n[F], kps[F, n_features], desc[F, n_features, 256], global[F, G]).
+        out: the tuple a previous call returned, to write into the same (already paged-in) arrays again."""
         imgs = np.ascontiguousarray(imgs, np.uint8)
         f = imgs.shape[0]
-        kps = np.zeros((f, self.n_features), KP_DTYPE)
-        desc = np.zeros((f, self.n_features, DESC_DIM), np.float32)
-        g = np.zeros((f, self.engine.global_dim), np.float32)
-        n = np.zeros((f,), np.int32)
+        if out is not None:
+            n, kps, desc, g = out
+            assert kps.shape == (f, self.n_features) and desc.shape == (f, self.n_features, DESC_DIM)
+        else:
+            kps = np.zeros((f, self.n_features), KP_DTYPE)
+            desc = np.zeros((f, self.n_features, DESC_DIM), np.float32)
+            g = np.zeros((f, self.engine.global_dim), np.float32)
+            n = np.zeros((f,), np.int32)
         _chk(lib().hfnet_extractor_extract_batch(self.h, f, _p(imgs), imgs.strides[1], C.c_size_t(imgs.strides[0]), _p(kps), _p(desc),
                                                  _p(g), _p(n), 0))
         return n, kps, desc, g

@@ -1098,9 +1098,10 @@ int hfnet_descriptor_distance(hfnet_engine* eh, const float* a, const float* b, 
 }
 
 // scratch for n_pairs x (max_rows x max_rows) similarity matrices, norms, keys and the pair descriptors
-static int bow_scratch(Engine& e, int n_pairs, int max_rows) {
+// SearchByBoW keeps candidate slots per train row (no n x m matrix); SearchForTriangulation still selects from S
+static int bow_scratch(Engine& e, int n_pairs, int max_rows, bool triangulation) {
     const size_t np = (size_t)std::max(n_pairs, 1), mr = (size_t)std::max(max_rows, 1);
-    HF_TRY(e.m_s.ensure(sizeof(float) * np * mr * mr));
+    HF_TRY(e.m_s.ensure(triangulation ? sizeof(float) * np * mr * mr : bow_scratch_bytes((int)np, (int)mr)));
     HF_TRY(e.m_qn.ensure(sizeof(float) * np * mr));
     HF_TRY(e.m_tn.ensure(sizeof(float) * np * mr));
     HF_TRY(e.m_key.ensure(sizeof(unsigned long long) * np * mr));
@@ -1122,7 +1123,7 @@ int hfnet_match_search_by_bow(hfnet_engine* eh, const float* query, int n_query,
     HF_TRY(stage_rows(e, e.m_a, query, (size_t)n_query * dim, on_device, &dq));
     HF_TRY(stage_rows(e, e.m_b, train, (size_t)n_train * dim, on_device, &dt));
     const int max_rows = std::max(n_query, n_train);
-    HF_TRY(bow_scratch(e, 1, max_rows));
+    HF_TRY(bow_scratch(e, 1, max_rows, false));
     int32_t* d_match = match_q2t; float* d_dist = dist; int* d_cnt = n_matches;
     if (!on_device) {
         HF_TRY(e.m_i0.ensure(sizeof(int32_t) * n_query)); HF_TRY(e.m_f0.ensure(sizeof(float) * n_query)); HF_TRY(e.m_cnt.ensure(sizeof(int)));
@@ -1133,7 +1134,7 @@ int hfnet_match_search_by_bow(hfnet_engine* eh, const float* query, int n_query,
     P.match = d_match; P.dist = d_dist; P.cnt = d_cnt; P.nq = n_query; P.nt = n_train;
     HF_HIP(hipMemcpyAsync(e.m_pairs.p, &P, sizeof P, hipMemcpyHostToDevice, e.stream));
     HF_HIP(hipStreamSynchronize(e.stream));     // P lives on this stack frame
-    HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), 1, max_rows, dim, th_low, e.stream));
+    HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), 1, max_rows, dim, th_low, e.m_s.p, e.stream));
     if (!on_device) {
         HF_HIP(hipMemcpyAsync(match_q2t, d_match, sizeof(int32_t) * n_query, hipMemcpyDeviceToHost, e.stream));
         HF_HIP(hipMemcpyAsync(dist, d_dist, sizeof(float) * n_query, hipMemcpyDeviceToHost, e.stream));
@@ -1157,7 +1158,7 @@ static int match_pairs_batch(hfnet_engine* eh, int n_pairs, const float* desc_ba
     std::lock_guard<std::mutex> lk(e.mu);
     HF_HIP(hipSetDevice(e.device));
     if (on_device) HF_HIP(e.wait_extract());
-    HF_TRY(bow_scratch(e, n_pairs, max_rows));
+    HF_TRY(bow_scratch(e, n_pairs, max_rows, triangulation));
     const float* d_base = desc_base; const int32_t *d_rows = n_rows, *d_qs = query_set, *d_ts = train_set;
     int32_t* d_match = match_q2t; float* d_dist = dist ? dist : (float*)match_q2t; int32_t* d_cnt = n_matches;
     if (!on_device) {
@@ -1188,7 +1189,7 @@ static int match_pairs_batch(hfnet_engine* eh, int n_pairs, const float* desc_ba
         const float threshold = (float)(-0.5 * th * th + 1);   // Matcher.cc:851
         HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, threshold, e.stream));
     } else {
-        HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, th, e.stream));
+        HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, th, e.m_s.p, e.stream));
     }
     if (!on_device) {
         HF_HIP(hipMemcpyAsync(match_q2t, d_match, sizeof(int32_t) * (size_t)n_pairs * max_rows, hipMemcpyDeviceToHost, e.stream));
@@ -1339,7 +1340,7 @@ static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const 
     const int nc = (int)c_slot.size();
     host.insert(host.end(), qsel.begin(), qsel.end()); host.insert(host.end(), tsel.begin(), tsel.end());
     host.insert(host.end(), c_slot.begin(), c_slot.end()); host.insert(host.end(), c_filter.begin(), c_filter.end());
-    HF_TRY(bow_scratch(e, n_pairs, mr));
+    HF_TRY(bow_scratch(e, n_pairs, mr, triangulation));
     // m_b: [qsel | tsel | c_slot | c_filter | c_rows | map nc*mr | inv nc*mr]
     HF_TRY(e.m_b.ensure(sizeof(int32_t) * (2 * (size_t)n_pairs + 3 * (size_t)nc + 2 * (size_t)nc * mr)));
     HF_TRY(e.m_i0.ensure(sizeof(int32_t) * (size_t)n_pairs * mr)); HF_TRY(e.m_f0.ensure(sizeof(float) * (size_t)n_pairs * mr));
@@ -1363,7 +1364,7 @@ static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const 
         const float threshold = (float)(-0.5 * th * th + 1);       // Matcher.cc:851
         HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, threshold, e.stream));
     } else {
-        HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, th, e.stream));
+        HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, th, e.m_s.p, e.stream));
     }
     if (nc)
         HF_LAUNCH(&e, e.stream, "store_remap",
@@ -1483,7 +1484,7 @@ int hfnet_db_add(hfnet_db* db, int slot, const float* descriptor) {
     // on the stream the scans run on (created non-blocking: the null stream would not order with it)
     HF_HIP(hipMemcpyAsync(db->d_db + (size_t)slot * db->dim, descriptor, sizeof(float) * db->dim, hipMemcpyHostToDevice, e.stream));
     HF_HIP(hipMemsetAsync(db->d_occ + slot, 1, 1, e.stream));
-    HF_LAUNCH(&e, e.stream, "db_norm", launch_sumsq_rows(db->d_db + (size_t)slot * db->dim, 1, db->dim, db->d_norm + slot, e.stream));
+    db->norm_dirty = true;
     HF_HIP(hipStreamSynchronize(e.stream));                          // the host buffer may go away
     return HFNET_OK;
 }
@@ -1567,6 +1568,10 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
     unsigned int* d_bits = e.m_key.as<unsigned int>();
     HF_HIP(hipMemcpyAsync(d_q, queries, sizeof(float) * Q * db->dim, hipMemcpyHostToDevice, e.stream));
     if (gemm) {
+        if (db->norm_dirty) {
+            HF_LAUNCH(&e, e.stream, "db_norm", launch_sumsq_rows(db->d_db, db->capacity, db->dim, db->d_norm, e.stream));
+            db->norm_dirty = false;
+        }
         HF_LAUNCH(&e, e.stream, "db_qnorm", launch_sumsq_rows(d_q, n_queries, db->dim, e.m_tn.as<float>(), e.stream));
         HF_LAUNCH(&e, e.stream, "db_gemm", launch_db_gemm(d_q, n_queries, e.m_tn.as<float>(), db->d_db, db->d_norm, db->d_occ, db->capacity, db->dim,
                                                        d_scores, d_bits, e.m_b.as<float>(), e.stream));

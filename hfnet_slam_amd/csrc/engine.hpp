@@ -209,7 +209,8 @@ struct hfnet_db {
     float* d_db = nullptr;
     unsigned char* d_occ = nullptr;
     float *d_q = nullptr, *d_scores = nullptr, *d_cand_score = nullptr, *d_best = nullptr;
-    float* d_norm = nullptr;       // |d|^2 per slot (tree256 order), computed when a row is added: the GEMM form of the scores needs it
+    float* d_norm = nullptr;       // |d|^2 per slot (tree256 order) for the GEMM form of the scores: refreshed in one launch
+    bool norm_dirty = true;        // by the first batched query after rows were added
     int32_t* d_cand_slot = nullptr;
     int* d_n = nullptr;
     unsigned int* d_best_bits = nullptr;

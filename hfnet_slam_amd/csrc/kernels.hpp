@@ -119,7 +119,9 @@ hipError_t launch_store_remap(int n_pairs, const int* qsel, const int* tsel, con
                               hipStream_t s);
 // SearchForTriangulation over the same pair descriptors (q = set 1, t = set 2; dist / qn / qkey unused)
 hipError_t launch_tri_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float threshold, hipStream_t s);
-hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, hipStream_t s);
+// scratch: bow_scratch_bytes(n_pairs, max_rows) bytes (candidate slots per train row and 64-query tile; no n x m matrix)
+size_t bow_scratch_bytes(int n_pairs, int max_rows);
+hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, void* scratch, hipStream_t s);
 hipError_t launch_descriptor_distance(const float* a, const float* b, int dim, float* out, hipStream_t s);
 // KeyFrameDatabase scan (KeyFrameDatabase.cc:86-104, 178-197)
 // best_partial: one word per wave of the scan (db_scan_workgroups(n) * 4, resp. db_batch_workgroups(n) * 4 per query);

@@ -156,12 +156,6 @@ __device__ __forceinline__ void gemm_abt_tile128(const float* __restrict__ d1, i
             }
         }
 }
-// batched over descriptor-set pairs: St[p] = train[p] * query[p]^T
-__global__ __launch_bounds__(256) void k_gemm_abt_pairs(const BowPair* __restrict__ pairs, int dim) {
-    const BowPair P = pairs[blockIdx.z];
-    gemm_abt_tile128(P.t, P.nt, P.q, P.nq, dim, P.St);
-}
-
 hipError_t launch_gemm_abt(const float* d1, int n1, const float* d2, int n2, int dim, float* S, hipStream_t s) {
     if (n1 <= 0 || n2 <= 0) return hipSuccess;
     if (dim % 64) return hipErrorInvalidValue;
@@ -335,74 +329,202 @@ __device__ float cv_l2_wave(const float* a, const float* b, int dim, int lane) {
     return sqrtf(s);
 }
 
-__global__ __launch_bounds__(256) void k_bow_train_pass(const BowPair* __restrict__ pairs, int dim, float band) {
+// ---- SearchByBoW without the similarity matrix.  S = Q * T^T is computed tile by tile on the matrix cores (128 queries x
+// 128 train rows per workgroup, 64 x 64 per wave, operands staged through LDS exactly as gemm_abt_tile128) and never
+// stored: with the TRAIN rows along the MFMA columns a lane holds, for its train row, 32 of the wave tile's 64 query
+// scores in registers, so the pre-selection of k_bow_train_pass -- "queries whose lower bound of |t|^2 + |q|^2 - 2 S is
+// below the smallest upper bound" -- runs in the epilogue against the tile-local smallest upper bound (a superset of the
+// final candidates: the global bound can only be smaller).  Per (train row, 64-query tile, half-wave) BOW_SLOTS candidate
+// slots {lower bound, query} go to HBM: 1 KB per train row instead of the 4 KB row of S, written once and read once.
+// Slot 0 holds the half tile's smallest lower bound.  More candidates than slots in one half tile (descriptors closer than
+// the rounding band, e.g. duplicates) are counted in a byte per half tile; k_bow_candidates then evaluates all 32 queries
+// of that half tile exactly -- if its smallest lower bound can compete at all.
+struct BowCand { unsigned int lo_bits; int q; };
+#define BOW_SLOTS 4
+__global__ __launch_bounds__(256) void k_bow_gemm_cand(const BowPair* __restrict__ pairs, int dim, float band, BowCand* __restrict__ cand,
+                                                       unsigned char* __restrict__ overflow, int max_rows, int n_qt) {
     const BowPair P = pairs[blockIdx.z];
-    const float* __restrict__ q = P.q; const float* __restrict__ t = P.t; const float* __restrict__ St = P.St;   // St: [nt x nq]
-    const int nq = P.nq, nt = P.nt;
-    const float* __restrict__ qn = P.qn; const float* __restrict__ tn = P.tn; unsigned long long* __restrict__ qkey = P.qkey;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= nt || nq <= 0) return;            // (an empty query set would make every padded lane a candidate)
-    const int lane = threadIdx.x & 63;
-    const float* srow = St + (long long)j * nq;
-    const float tnj = tn[j];
-    // d2 ~ |q|^2 + |t|^2 - 2 q.t agrees with the exactly evaluated form up to +-band * (|q|^2 + |t|^2): the
-    // rounding of a dim-term dot / difference sum is below ~4 * dim * 2^-24 of the norms; band = 4e-6 * dim + 1e-4
-    // (1.1e-3 for dim 256) keeps a > 15x margin.
-    // Every query whose lower bound is below the smallest upper bound may be the exact minimiser.
-    float bd = FLT_MAX;
-    int bi = -1;
-    const float* trow = t + (long long)j * dim;
-    if (nq <= 1024) {
-        // one sweep: every lane keeps its <= 16 (lower bound, upper bound) pairs in registers
-        float lo[16];
-        float umin = FLT_MAX;
+    const float* __restrict__ d1 = P.q; const float* __restrict__ d2 = P.t;
+    const int n1 = P.nq, n2 = P.nt;
+    constexpr int LD = 68;
+    __shared__ __attribute__((aligned(16))) float As[128 * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[128 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+    const int row0 = blockIdx.y * 128, col0 = blockIdx.x * 128;
+    if (row0 >= n1 || col0 >= n2) return;                     // workgroup-uniform
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+    const int lc = tid & 15, lrow = (tid >> 4) * 8;
+    long long aoff[8], boff[8];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int i = u * 64 + lane;
-            lo[u] = FLT_MAX;
-            if (i < nq) {
-                const float nn = qn[i] + tnj, d2 = nn - 2.0f * srow[i];
-                lo[u] = d2 - band * nn;
-                umin = fminf(umin, d2 + band * nn);
-            }
+    for (int j = 0; j < 8; ++j) {
+        aoff[j] = (long long)min(row0 + lrow + j, n1 - 1) * dim + lc * 4;
+        boff[j] = (long long)min(col0 + lrow + j, n2 - 1) * dim + lc * 4;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    f32x4 sa[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sa[j] = *(const f32x4*)(d1 + aoff[j]); sb[j] = *(const f32x4*)(d2 + boff[j]); }
+    for (int k0 = 0; k0 < dim; k0 += 64) {
+        __syncthreads();                                     // previous chunk fully consumed
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float* ap = As + (lrow + j) * LD + lc * 2;
+            float* bp = Bs + (lrow + j) * LD + lc * 2;
+            *(float2*)(ap) = float2{sa[j][0], sa[j][2]}; *(float2*)(ap + 32) = float2{sa[j][1], sa[j][3]};
+            *(float2*)(bp) = float2{sb[j][0], sb[j][2]}; *(float2*)(bp + 32) = float2{sb[j][1], sb[j][3]};
         }
+        __syncthreads();
+        if (k0 + 64 < dim) {
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) umin = fminf(umin, __shfl_xor(umin, off, 64));
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            unsigned long long mask = __ballot(lo[u] <= umin);
-            while (mask) {
-                const int b = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const int qi = u * 64 + b;
-                const float d = (dim == 256) ? cv_l2_wave256(trow, q + (long long)qi * dim, lane) : cv_l2_wave(trow, q + (long long)qi * dim, dim, lane);
-                if (d < bd) { bd = d; bi = qi; }
-            }
+            for (int j = 0; j < 8; ++j) { sa[j] = *(const f32x4*)(d1 + aoff[j] + k0 + 64); sb[j] = *(const f32x4*)(d2 + boff[j] + k0 + 64); }
         }
-    } else {
-        float umin = FLT_MAX;
-        for (int i = lane; i < nq; i += 64) {
-            const float nn = qn[i] + tnj;
-            umin = fminf(umin, (nn - 2.0f * srow[i]) + band * nn);
-        }
+        const float* ap = As + (wr + r) * LD + half * 32;
+        const float* bp = Bs + (wc + r) * LD + half * 32;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) umin = fminf(umin, __shfl_xor(umin, off, 64));
-        for (int i0 = 0; i0 < nq; i0 += 64) {
-            const int i = i0 + lane;
-            bool c = false;
-            if (i < nq) { const float nn = qn[i] + tnj; c = ((nn - 2.0f * srow[i]) - band * nn) <= umin; }
-            unsigned long long mask = __ballot(c);
-            while (mask) {
-                const int b = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const int qi = i0 + b;
-                const float d = (dim == 256) ? cv_l2_wave256(trow, q + (long long)qi * dim, lane) : cv_l2_wave(trow, q + (long long)qi * dim, dim, lane);
-                if (d < bd) { bd = d; bi = qi; }
+        for (int m = 0; m < 8; ++m) {
+            const f32x4 a0 = *(const f32x4*)(ap + 4 * m), a1 = *(const f32x4*)(ap + 32 * LD + 4 * m);
+            const f32x4 b0 = *(const f32x4*)(bp + 4 * m), b1 = *(const f32x4*)(bp + 32 * LD + 4 * m);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
             }
         }
     }
-    if (lane == 0 && bi >= 0)
-        atomicMin(&qkey[bi], ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned int)j);
+    // ---- epilogue: the |q|^2 of the workgroup's 128 queries through LDS, then bounds and candidates per train column
+    __syncthreads();
+    float* qns = As;                                          // [128]
+    if (tid < 128) qns[tid] = row0 + tid < n1 ? P.qn[row0 + tid] : 0.0f;
+    __syncthreads();
+    const long long pair_rows = (long long)blockIdx.z * max_rows;
+    const int qt = (row0 + wr) >> 6;                          // 64-query tile index of this wave
+    if (row0 + wr >= n1) return;                              // (wave-uniform, no barrier below) a tile past the last query has no slots
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int tj = col0 + wc + j * 32 + r;
+        const float tnj = P.tn[min(tj, n2 - 1)];
+        float lo[2][16];
+        float hmin = FLT_MAX;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int rr = wr + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;      // query row inside the workgroup tile
+                const bool ok = row0 + rr < n1;
+                const float nn = qns[rr] + tnj;
+                const float dd = fmaf(-2.0f, acc[i][j][reg], nn);
+                lo[i][reg] = ok ? dd - band * nn : __builtin_inff();      // (+inf never passes the <= test below)
+                hmin = fminf(hmin, ok ? dd + band * nn : FLT_MAX);
+            }
+        hmin = fminf(hmin, __shfl_xor(hmin, 32, 64));          // over the wave tile's 64 queries of this train column
+        // this lane's smallest lower bound first (slot 0), then the other candidates in register order
+        float lmin = __builtin_inff();
+        int imin = -1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                if (lo[i][reg] < lmin) { lmin = lo[i][reg]; imin = i * 16 + reg; }
+        BowCand c[BOW_SLOTS];
+#pragma unroll
+        for (int k = 0; k < BOW_SLOTS; ++k) c[k] = BowCand{0x7f800000u, -1};
+        int count = 0;
+        if (imin >= 0 && lmin <= hmin) {
+            c[0] = BowCand{__float_as_uint(lmin), row0 + wr + (imin >> 4) * 32 + (imin & 3) + 8 * ((imin & 15) >> 2) + 4 * half};
+            count = 1;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                if (lo[i][reg] <= hmin && i * 16 + reg != imin) {
+                    const int qi = row0 + wr + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+#pragma unroll
+                    for (int k = 1; k < BOW_SLOTS; ++k)
+                        if (count == k) c[k] = BowCand{__float_as_uint(lo[i][reg]), qi};
+                    ++count;
+                }
+            }
+        if (tj < n2) {
+            const long long hs = ((pair_rows + tj) * n_qt + qt) * 2 + half;                  // half-tile index
+            BowCand* dst = cand + hs * BOW_SLOTS;
+#pragma unroll
+            for (int k = 0; k < BOW_SLOTS; ++k) dst[k] = c[k];
+            overflow[hs] = (unsigned char)min(count, 255);
+        }
+    }
+}
+
+// every train row: the candidates of all its query tiles -> exact OpenCV distances -> nearest query (first minimum in
+// query order: ties go to the smaller index) -> the per-query key, as k_bow_train_pass.  One wave per train row.
+__global__ __launch_bounds__(256) void k_bow_candidates(const BowPair* __restrict__ pairs, int dim, float band, const BowCand* __restrict__ cand,
+                                                        const unsigned char* __restrict__ overflow, int max_rows, int n_qt) {
+    const BowPair P = pairs[blockIdx.z];
+    const float* __restrict__ q = P.q; const float* __restrict__ t = P.t;
+    const int nq = P.nq, nt = P.nt;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= nt || nq <= 0) return;
+    const int lane = threadIdx.x & 63;
+    const long long prow = (long long)blockIdx.z * max_rows + j;
+    const float* trow = t + (long long)j * dim;
+    const float tnj = P.tn[j];
+    float bd = FLT_MAX;
+    int bi = 0x7fffffff;
+    auto exact = [&](int qi) {
+        const float d = (dim == 256) ? cv_l2_wave256(trow, q + (long long)qi * dim, lane) : cv_l2_wave(trow, q + (long long)qi * dim, dim, lane);
+        if (d < bd || (d == bd && qi < bi)) { bd = d; bi = qi; }
+    };
+    const int live_halves = ((nq + 63) >> 6) * 2, n_live = live_halves * BOW_SLOTS;      // half tiles / slots this pair has
+    const BowCand* __restrict__ slots = cand + prow * n_qt * 2 * BOW_SLOTS;
+    const unsigned char* __restrict__ counts = overflow + prow * n_qt * 2;
+    // smallest upper bound over all half tiles, from their smallest lower bounds (slot 0): hi = lo + 2 band (|q|^2 + |t|^2),
+    // taken generously (x 2.5: rounding of the reconstruction must never shrink the candidate set; a larger bound only adds
+    // exact evaluations)
+    float umin = FLT_MAX;
+    for (int h0 = 0; h0 < live_halves; h0 += 64) {
+        const int hh = h0 + lane;
+        if (hh < live_halves) {
+            const BowCand c = slots[hh * BOW_SLOTS];
+            if (c.q >= 0) umin = fminf(umin, __uint_as_float(c.lo_bits) + 2.5f * band * (P.qn[c.q] + tnj));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) umin = fminf(umin, __shfl_xor(umin, off, 64));
+    // half tiles with more candidates than slots whose best lower bound can compete: all their 32 queries, exactly
+    for (int h0 = 0; h0 < live_halves; h0 += 64) {
+        const int hh = h0 + lane;
+        bool over = false;
+        if (hh < live_halves) over = counts[hh] > BOW_SLOTS && __uint_as_float(slots[hh * BOW_SLOTS].lo_bits) <= umin;
+        unsigned long long mask = __ballot(over);
+        while (mask) {
+            const int b = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int hb = h0 + b, q0 = (hb >> 1) * 64 + (hb & 1) * 4;            // rows of a half: 4 h + {0..3} + 8 k
+            for (int k = 0; k < 8; ++k)
+                for (int e = 0; e < 4; ++e) { const int qi = q0 + 8 * k + e; if (qi < nq) exact(qi); }
+        }
+    }
+    for (int s0 = 0; s0 < n_live; s0 += 64) {
+        const int sl = s0 + lane;
+        BowCand c = {0x7f800000u, -1};
+        if (sl < n_live) c = slots[sl];
+        unsigned long long mask = __ballot(c.q >= 0 && __uint_as_float(c.lo_bits) <= umin);
+        while (mask) {
+            const int b = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            exact(__shfl(c.q, b, 64));
+        }
+    }
+    if (lane == 0 && bi != 0x7fffffff)
+        atomicMin(&P.qkey[bi], ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned int)j);
 }
 
 __global__ __launch_bounds__(256) void k_bow_finalize(const BowPair* __restrict__ pairs, float th_low) {
@@ -567,12 +689,25 @@ hipError_t launch_store_remap(int n_pairs, const int* qsel, const int* tsel, con
 
 // all pairs in four launches (prep, GEMM, train pass, finalize); grids are sized for max_rows, workgroups
 // beyond a pair's row counts exit at once
-hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, hipStream_t s) {
+size_t bow_scratch_bytes(int n_pairs, int max_rows) {
+    const size_t n_qt = (size_t)(max_rows + 63) / 64;
+    return (size_t)n_pairs * max_rows * n_qt * 2 * (BOW_SLOTS * sizeof(BowCand) + 1);
+}
+
+hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, void* scratch, hipStream_t s) {
     if (n_pairs <= 0 || max_rows <= 0) return hipSuccess;
     if (dim % 64) return hipErrorInvalidValue;
+    // d2 ~ |q|^2 + |t|^2 - 2 q.t agrees with the exactly evaluated form up to +-band * (|q|^2 + |t|^2): the rounding of a
+    // dim-term dot / difference sum is below ~4 * dim * 2^-24 of the norms; band = 4e-6 * dim + 1e-4 (1.1e-3 for dim 256)
+    // keeps a > 15x margin
+    const float band = 4e-6f * (float)dim + 1e-4f;
+    const int n_qt = (max_rows + 63) / 64;
+    BowCand* cand = (BowCand*)scratch;
+    unsigned char* overflow = (unsigned char*)scratch + (size_t)n_pairs * max_rows * n_qt * 2 * BOW_SLOTS * sizeof(BowCand);   // candidate counts per half tile
     hipLaunchKernelGGL(k_bow_prep, dim3((2 * max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim);
-    hipLaunchKernelGGL(k_gemm_abt_pairs, dim3((max_rows + 127) / 128, (max_rows + 127) / 128, n_pairs), dim3(256), 0, s, pairs, dim);
-    hipLaunchKernelGGL(k_bow_train_pass, dim3((max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim, 4e-6f * (float)dim + 1e-4f);
+    hipLaunchKernelGGL(k_bow_gemm_cand, dim3((max_rows + 127) / 128, (max_rows + 127) / 128, n_pairs), dim3(256), 0, s, pairs, dim, band, cand, overflow,
+                       max_rows, n_qt);
+    hipLaunchKernelGGL(k_bow_candidates, dim3((max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim, band, cand, overflow, max_rows, n_qt);
     hipLaunchKernelGGL(k_bow_finalize, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, th_low);
     return hipGetLastError();
 }
