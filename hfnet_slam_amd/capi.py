@@ -29,6 +29,7 @@ SYMBOLS = [
     "hfnet_extractor_create", "hfnet_extractor_destroy", "hfnet_extractor_tables",
     "hfnet_extractor_extract", "hfnet_extractor_extract_batch",
     "hfnet_descriptor_distance", "hfnet_resampler", "hfnet_match_search_by_bow", "hfnet_match_search_by_bow_batch", "hfnet_match_search_for_triangulation", "hfnet_match_search_for_triangulation_batch",
+    "hfnet_match_candidates", "hfnet_distinctive_descriptors",
     "hfnet_extractor_attach_store", "hfnet_store_create", "hfnet_store_destroy", "hfnet_store_put", "hfnet_store_put_extracted", "hfnet_store_rows", "hfnet_store_set_flags", "hfnet_store_search_by_bow",
     "hfnet_store_search_for_triangulation",
     "hfnet_db_create", "hfnet_db_destroy", "hfnet_db_add", "hfnet_db_erase", "hfnet_db_clear", "hfnet_db_query", "hfnet_db_query_batch",
@@ -177,6 +178,24 @@ class Engine:
         _chk(lib().hfnet_match_search_for_triangulation(self.h, _p(d1), d1.shape[0], _p(d2), d2.shape[0], dim,
                                                         C.c_float(th_high), _p(match), C.byref(n), 0))
         return n.value, match
+
+    def match_candidates(self, query, train, train_level, cand_offsets, cand_index):
+        """the candidate loop of the windowed matchers; returns (best_idx, best_dist, best_level, second_dist, second_level)"""
+        q = np.ascontiguousarray(query, np.float32); t = np.ascontiguousarray(train, np.float32)
+        lv = None if train_level is None else np.ascontiguousarray(train_level, np.int32)
+        off = np.ascontiguousarray(cand_offsets, np.int32); idx = np.ascontiguousarray(cand_index, np.int32)
+        n = q.shape[0]
+        dim = q.shape[1] if q.ndim == 2 and n else (t.shape[1] if t.ndim == 2 else 256)
+        bi = np.full(n, -7, np.int32); bd = np.zeros(n, np.float32); bl = np.full(n, -7, np.int32); sd = np.zeros(n, np.float32); sl = np.full(n, -7, np.int32)
+        _chk(lib().hfnet_match_candidates(self.h, _p(q), n, _p(t), t.shape[0], _p(lv), dim, _p(off), _p(idx) if idx.size else None, _p(bi), _p(bd), _p(bl),
+                                          _p(sd), _p(sl), 0))
+        return bi, bd, bl, sd, sl
+
+    def distinctive_descriptors(self, desc, set_offsets):
+        d = np.ascontiguousarray(desc, np.float32); off = np.ascontiguousarray(set_offsets, np.int32)
+        best = np.full(len(off) - 1, -7, np.int32)
+        _chk(lib().hfnet_distinctive_descriptors(self.h, _p(d), _p(off), len(off) - 1, d.shape[1], _p(best)))
+        return best
 
     def resampler(self, data, warp):
         """Resampler(data [B,H,W,C], warp [B,N,2]) -> [B,N,C]  (BaseModel.cc:491-562)"""

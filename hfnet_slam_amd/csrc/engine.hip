@@ -1419,6 +1419,77 @@ int hfnet_match_search_for_triangulation(hfnet_engine* eh, const float* d1, int 
     return HFNET_OK;
 }
 
+int hfnet_match_candidates(hfnet_engine* eh, const float* query, int n_query, const float* train, int n_train, const int32_t* train_level, int dim,
+                           const int32_t* cand_offsets, const int32_t* cand_index, int32_t* best_idx, float* best_dist, int32_t* best_level,
+                           float* second_dist, int32_t* second_level, int on_device) {
+    API_GUARD(eh, "engine");
+    if (n_query < 0 || n_train < 0 || dim <= 0 || dim % 4) { set_error("match_candidates: bad sizes (dim must be a multiple of 4)"); return HFNET_ERR_INVALID_ARG; }
+    if (n_query == 0) return HFNET_OK;
+    API_GUARD(query, "query"); API_GUARD(cand_offsets, "cand_offsets");
+    API_GUARD(best_idx, "best_idx"); API_GUARD(best_dist, "best_dist"); API_GUARD(best_level, "best_level"); API_GUARD(second_dist, "second_dist"); API_GUARD(second_level, "second_level");
+    Engine& e = eh->impl;
+    std::lock_guard<std::mutex> lk(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    if (on_device) {
+        HF_HIP(e.wait_extract());
+        HF_LAUNCH(&e, e.stream, "match_candidates", launch_match_candidates(query, n_query, train, train_level, dim, cand_offsets, cand_index, best_idx,
+                                                                       best_dist, best_level, second_dist, second_level, e.stream));
+        return HFNET_OK;
+    }
+    const int total = cand_offsets[n_query];
+    if (cand_offsets[0] != 0 || total < 0) { set_error("match_candidates: cand_offsets must start at 0 and be non-decreasing"); return HFNET_ERR_INVALID_ARG; }
+    for (int i = 0; i < n_query; ++i) if (cand_offsets[i + 1] < cand_offsets[i]) { set_error("match_candidates: cand_offsets decrease at %d", i); return HFNET_ERR_INVALID_ARG; }
+    if (total && (!cand_index || !train)) { set_error("match_candidates: null candidate list / train matrix"); return HFNET_ERR_INVALID_ARG; }
+    for (int c = 0; c < total; ++c) if (cand_index[c] < 0 || cand_index[c] >= n_train) { set_error("match_candidates: candidate %d names row %d outside [0, %d)", c, cand_index[c], n_train); return HFNET_ERR_INVALID_ARG; }
+    const float *dq, *dt;
+    HF_TRY(stage_rows(e, e.m_a, query, (size_t)n_query * dim, 0, &dq));
+    HF_TRY(stage_rows(e, e.m_b, train, (size_t)n_train * dim, 0, &dt));
+    // [offsets n_query+1 | index total | level n_train] and the five outputs
+    HF_TRY(e.m_i0.ensure(sizeof(int32_t) * ((size_t)n_query + 1 + (size_t)total + (size_t)n_train)));
+    HF_TRY(e.m_i1.ensure(sizeof(int32_t) * 3 * (size_t)n_query)); HF_TRY(e.m_f0.ensure(sizeof(float) * 2 * (size_t)n_query));
+    int32_t* ib = e.m_i0.as<int32_t>();
+    HF_HIP(hipMemcpyAsync(ib, cand_offsets, sizeof(int32_t) * ((size_t)n_query + 1), hipMemcpyHostToDevice, e.stream));
+    if (total) HF_HIP(hipMemcpyAsync(ib + n_query + 1, cand_index, sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, e.stream));
+    int32_t* d_level = nullptr;
+    if (train_level && n_train) { d_level = ib + n_query + 1 + total; HF_HIP(hipMemcpyAsync(d_level, train_level, sizeof(int32_t) * (size_t)n_train, hipMemcpyHostToDevice, e.stream)); }
+    int32_t* oi = e.m_i1.as<int32_t>(); float* of = e.m_f0.as<float>();
+    HF_LAUNCH(&e, e.stream, "match_candidates", launch_match_candidates(dq, n_query, dt, d_level, dim, ib, ib + n_query + 1, oi, of, oi + n_query, of + n_query,
+                                                                   oi + 2 * (size_t)n_query, e.stream));
+    HF_HIP(hipMemcpyAsync(best_idx, oi, sizeof(int32_t) * n_query, hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipMemcpyAsync(best_level, oi + n_query, sizeof(int32_t) * n_query, hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipMemcpyAsync(second_level, oi + 2 * (size_t)n_query, sizeof(int32_t) * n_query, hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipMemcpyAsync(best_dist, of, sizeof(float) * n_query, hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipMemcpyAsync(second_dist, of + n_query, sizeof(float) * n_query, hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));
+    return HFNET_OK;
+}
+
+int hfnet_distinctive_descriptors(hfnet_engine* eh, const float* desc, const int32_t* set_offsets, int n_sets, int dim, int32_t* best) {
+    API_GUARD(eh, "engine");
+    if (n_sets < 0 || dim <= 0 || dim % 4) { set_error("distinctive_descriptors: bad sizes (dim must be a multiple of 4)"); return HFNET_ERR_INVALID_ARG; }
+    if (n_sets == 0) return HFNET_OK;
+    API_GUARD(set_offsets, "set_offsets"); API_GUARD(best, "best");
+    if (set_offsets[0] != 0) { set_error("distinctive_descriptors: set_offsets must start at 0"); return HFNET_ERR_INVALID_ARG; }
+    for (int s = 0; s < n_sets; ++s) {
+        const int n = set_offsets[s + 1] - set_offsets[s];
+        if (n < 0) { set_error("distinctive_descriptors: set_offsets decrease at %d", s); return HFNET_ERR_INVALID_ARG; }
+        if (n > distinctive_max_rows()) { set_error("distinctive_descriptors: set %d has %d rows (> %d)", s, n, distinctive_max_rows()); return HFNET_ERR_CAPACITY; }
+    }
+    const int total = set_offsets[n_sets];
+    if (total) API_GUARD(desc, "desc");
+    Engine& e = eh->impl;
+    std::lock_guard<std::mutex> lk(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    const float* dd;
+    HF_TRY(stage_rows(e, e.m_a, desc, (size_t)total * dim, 0, &dd));
+    HF_TRY(e.m_i0.ensure(sizeof(int32_t) * ((size_t)n_sets + 1))); HF_TRY(e.m_i1.ensure(sizeof(int32_t) * (size_t)n_sets));
+    HF_HIP(hipMemcpyAsync(e.m_i0.p, set_offsets, sizeof(int32_t) * ((size_t)n_sets + 1), hipMemcpyHostToDevice, e.stream));
+    HF_LAUNCH(&e, e.stream, "distinctive", launch_distinctive(dd, e.m_i0.as<int>(), n_sets, dim, e.m_i1.as<int>(), e.stream));
+    HF_HIP(hipMemcpyAsync(best, e.m_i1.p, sizeof(int32_t) * (size_t)n_sets, hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));
+    return HFNET_OK;
+}
+
 int hfnet_resampler(hfnet_engine* eh, const float* data, const float* warp, float* output, int batch_size, int data_height, int data_width,
                     int data_channels, int num_sampling_points) {
     API_GUARD(eh, "engine"); API_GUARD(data, "data"); API_GUARD(output, "output");

