@@ -1,0 +1,30 @@
+# usage (on the GPU box, via gpurun):  bash tools/gpu_profiles.sh <round tag, e.g. r02>
+# Writes gpurun_out/<tag>_profiles/: the bench line, rocprofv3 kernel stats of the same command, SQ counter passes and the
+# FETCH_SIZE / WRITE_SIZE passes folded into <tag>_traffic_b32.json.  Copy what is to be judged into profiles/.
+set -x
+TAG=$1
+cd $GRAFT_REPO_ROOT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_profiles
+mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+cd /tmp
+rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --configs none --no-cpu-baseline > $OUT/kt.log 2>&1
+cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_bench_kernel_stats.csv
+P1="SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"
+P2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU"
+i=1
+for P in "$P1" "$P2"; do
+  rm -rf /tmp/pmc$i
+  timeout 600 rocprofv3 --pmc $P --kernel-trace --output-format csv -d /tmp/pmc$i -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --configs none --no-cpu-baseline > $OUT/pmc$i.log 2>&1
+  python $GRAFT_REPO_ROOT/tools/pmc_summary.py $(find /tmp/pmc$i -name '*counter_collection.csv' | head -1) > $OUT/${TAG}_pmc_$( [ $i = 1 ] && echo sq || echo instmix )_b32.txt
+  i=$((i+1))
+done
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$C
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --configs none --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+done
+python $GRAFT_REPO_ROOT/tools/make_traffic.py $(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) 32 $OUT/${TAG}_traffic_b32.json > $OUT/traffic.log 2>&1
+rm -f $OUT/*.log
+ls -la $OUT
+head -c 1500 $OUT/${TAG}_bench.json

@@ -12,15 +12,17 @@ LAUNCHES = {
     "conv3x3_det": ("void hfnet::k_conv3x3<4, false>", 0),
     "conv3x3_desc_taps": ("void hfnet::k_conv3x3<4, true>", 0),
     "stem_block_L02": ("void hfnet::k_stem_block2<24, 16>", 0),
-    "block_L02": ("void hfnet::k_block_noexpand<24, 16>", 0),
-    "block_L03": ("void hfnet::k_block_fused2<2, 1, 2, true, 8>", 0),
-    "block_L04": ("void hfnet::k_block_fused2<1, 1, 3, true, 16>", 0),
-    "block_L05": ("void hfnet::k_block_fused2<2, 1, 3, true, 8>", 0),
-    "block_L06": ("void hfnet::k_block_fused2<1, 2, 3, true, 16>", 0),
-    "block_L07": ("void hfnet::k_block_fused2<1, 3, 6, true, 16>", 0),
-    "stem": ("void hfnet::k_stem_c<24>", 0),
+    "block_L03": ("void hfnet::k_block_fused4<2, 1, 2, false", 0),
+    "block_L04": ("void hfnet::k_block_fused4<1, 1, 3, true", 0),
+    "block_L05": ("void hfnet::k_block_fused4<2, 1, 3, false", 0),
+    "block_L06": ("void hfnet::k_block_fused4<1, 2, 3, false", 0),
+    "block_L07": ("void hfnet::k_block_fused4<1, 3, 6, false", 0),
+    "block_L08": ("void hfnet::k_block_fused2<2, 2, 12, true, 8>", 0),
+    "pointwise_desc_taps": ("void hfnet::k_pointwise<4>", 0),
+    "fc": ("void hfnet::k_fc_mfma<16>", 0),
     "nms_select": ("hfnet::k_nms_select", 0),
-    "match_gemm": ("hfnet::k_gemm_abt_pairs", 0),
+    "match_gemm": ("hfnet::k_bow_gemm_cand", 0),
+    "match_candidates": ("hfnet::k_bow_candidates", 0),
 }
 
 
@@ -41,8 +43,8 @@ def pick(acc, prefix, rank):
 
 
 fetch, write = per_launch(sys.argv[1]), per_launch(sys.argv[2])
-out = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) around `python bench.py --steps 2 --warmup 1 "
-                      "--batch %s --no-cpu-baseline` on MI355X; per-launch means in KB as reported; bench.py applies MI355X_MICROARCH.md's gfx950 "
+out = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) around `python bench.py --steps 1 --warmup 1 "
+                      "--chunk %s --configs none --no-cpu-baseline` on MI355X; per-launch means in KB as reported; bench.py applies MI355X_MICROARCH.md's gfx950 "
                       "correction: HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Made by tools/make_traffic.py." % sys.argv[3],
        "batch": int(sys.argv[3]), "kernels": {}}
 for name, (prefix, rank) in LAUNCHES.items():
