@@ -260,7 +260,7 @@ class Pipeline:
         self.eng.fence()
         if qset is None:
             qset, tset, n_pairs = self._default_pairs(s0, n_frames)
-        if n_pairs:
+        if n_pairs and not os.environ.get("BENCH_DEV_NO_MATCH"):      # (development switch: such a line is marked invalid below)
             st = self.L.hfnet_match_search_by_bow_batch(self.eng.h, n_pairs, C.c_void_p(self.desc.data_ptr()), C.c_size_t(N_FEAT * 256),
                                                         C.c_void_p(self.n_rows.data_ptr()), self.n_buf * B, C.c_void_p(qset.data_ptr()),
                                                         C.c_void_p(tset.data_ptr()), N_FEAT, 256, C.c_float(TH_LOW), C.c_void_p(self.match.data_ptr()),
@@ -631,6 +631,8 @@ def main() -> None:
                        "frames_per_step_per_gpu": args.batch, "frames_per_call": B, "parallelism": f"replicas x{world} (no collective)"},
             "roofline": roof, "build_id": capi.build_id(), "options": eng.options(),
         }
+        if os.environ.get("BENCH_DEV_NO_MATCH"):
+            out["invalid"] = "development run: the matcher was skipped (BENCH_DEV_NO_MATCH)"
 
     # ---- the other BASELINE configs (sub-records) ------------------------------------------------
     configs = {}

@@ -401,6 +401,17 @@ static hipError_t launch_block_fused2_t(const FusedArgs& a, const Geom& g, hipSt
 // SIMD, so one wave's LDS round trips, weight fetches and VALU stretches are covered by the others' MFMA chains.  Price:
 // the halo of a 32-pixel tile is relatively larger (stride 1: 2.0 instead of 1.5 expansion rows per output pixel).
 // The tile's input fragments stay in registers for all chunks; weights come from L1 / L2 one phase ahead.
+// base + uniform byte offset, pinned to scalar registers: a load through it is "scalar base + 32-bit lane offset" and costs
+// no vector instruction for its address (left alone the compiler folds the uniform part into 64-bit vector adds)
+typedef const __attribute__((address_space(1))) char* gbase_t;
+typedef const __attribute__((address_space(1))) f32x4* gvec4_t;
+typedef const __attribute__((address_space(1))) float* gf32_t;
+__device__ __forceinline__ gbase_t sgpr_base(const void* base, unsigned uniform_bytes) {
+    gbase_t p = (gbase_t)(const char*)base + uniform_bytes;
+    asm("" : "+s"(p));
+    return p;
+}
+
 template <int S> struct F4Geo {
     static constexpr int TH = 4, TW = 8, IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, NPOS = IH * IW, MT_IN = (NPOS + 31) / 32;
     static constexpr int EP = MT_IN * 32 + 4;        // channel stride of ET in floats: EP / 4 odd -> conflict-free 16-byte accesses
@@ -467,10 +478,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void k_block_fused4(FusedArgs a, G
     const int n_chunks = min(a.ex_nt_total, (a.cexp + 31) >> 5);  // skip all-padding column tiles
     f32x4 bfrag[KQT];
     float ebias;
+    // weight loads: uniform (scalar) base + a 32-bit lane offset, so that no vector instruction goes into their addresses
+    // (vector ALU instructions and f32 MFMAs share the issue port)
+    const unsigned lane16 = (unsigned)lane * 16u, r4 = (unsigned)r * 4u;
     auto load_b = [&](int chunk) {
 #pragma unroll
-        for (int kq = 0; kq < KQT; ++kq) bfrag[kq] = a.Wex[((size_t)kq * a.ex_nt_total + chunk) * 64 + lane];
-        ebias = a.ex_bias[chunk * 32 + r];
+        for (int kq = 0; kq < KQT; ++kq)
+            bfrag[kq] = *(gvec4_t)(sgpr_base(a.Wex, (unsigned)(kq * a.ex_nt_total + chunk) * 1024u) + lane16);
+        ebias = *(gf32_t)(sgpr_base(a.ex_bias, (unsigned)chunk * 128u) + r4);
     };
     load_b(0);
     const int rh = half;                                           // depthwise role: channel r, output rows 2 rh, 2 rh + 1
@@ -482,12 +497,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void k_block_fused4(FusedArgs a, G
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq)
 #pragma unroll
-            for (int nt = 0; nt < NTO; ++nt) pfrag[kq][nt] = a.Wpr[((size_t)(chunk * 4 + min(kq, kqc - 1)) * a.pr_nt_total + nt) * 64 + lane];
-        const int dch = min(ch0 + r, a.cexp - 1);
+            for (int nt = 0; nt < NTO; ++nt)
+                pfrag[kq][nt] = *(gvec4_t)(sgpr_base(a.Wpr, (unsigned)((chunk * 4 + min(kq, kqc - 1)) * a.pr_nt_total + nt) * 1024u) + lane16);
+        const unsigned dch4 = (unsigned)min(r, a.cexp - 1 - ch0) * 4u;      // (channels past cexp: clamped, never consumed)
         float dwt[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) dwt[t] = a.Wdw[t * a.cexp + dch];
-        const float dwb = a.dw_bias[dch];
+        for (int t = 0; t < 9; ++t) dwt[t] = *(gf32_t)(sgpr_base(a.Wdw, (unsigned)(t * a.cexp + ch0) * 4u) + dch4);
+        const float dwb = *(gf32_t)(sgpr_base(a.dw_bias, (unsigned)ch0 * 4u) + dch4);
         // ---- expansion
         {
             f32x16 bias16;
