@@ -466,6 +466,7 @@ def config_loop_closure(capi, eng, reps=10):
     sets = np.stack([a, b]).astype(np.float32)
     nr = np.array([1000, 1000], np.int32)
     db.query(qs[0]); db.query_batch(qs); eng.search_by_bow_batch(sets, nr, [(0, 1)] * 32, TH_LOW)       # warm-up
+    eng.search_for_triangulation_batch(sets, nr, [(0, 1)] * 32, 0.75)
     eng.synchronize()
     eng.profile_reset(); eng.profile_filter(None); eng.profile_enable(True)
     t0 = time.perf_counter()
@@ -476,18 +477,22 @@ def config_loop_closure(capi, eng, reps=10):
         db.query_batch(qs)
     for _ in range(reps):
         eng.search_by_bow_batch(sets, nr, [(0, 1)] * 32, TH_LOW)
+    for _ in range(reps):
+        eng.search_for_triangulation_batch(sets, nr, [(0, 1)] * 32, 0.75)
     eng.synchronize()
     prof = eng.profile(); eng.profile_enable(False)
     db.close()
     ms = lambda p, k: p[k][1] / max(p[k][0], 1) if k in p else float("nan")
     q64 = next((k for k in ("db_gemm", "db_scores_batch") if k in prof), "db_scores_batch")
-    out = {"workload": "10000 x 4096 f32 database resident in HBM; 1000 x 1000 x 256 SearchByBoW x 32 pairs",
+    out = {"workload": "10000 x 4096 f32 database resident in HBM; 1000 x 1000 x 256 SearchByBoW and SearchForTriangulation x 32 pairs",
            "db_q1_warm_us": ms(prof, "db_scores") * 1e3, "db_q1_warm_GBps": N * DIM * 4 / (ms(prof, "db_scores") * 1e-3) / 1e9,
            "db_q1_call_us_incl_copies": t_q1_call * 1e6,
            "db_q64_kernel": q64, "db_q64_us": ms(prof, q64) * 1e3, "db_q64_TFLOPs": 64 * N * DIM * 2 / (ms(prof, q64) * 1e-3) / 1e12,
            "db_q64_frac_mfma_f32": 64 * N * DIM * 2 / (ms(prof, q64) * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
            "match_32_pairs_us": ms(prof, "match_bow") * 1e3, "match_TFLOPs": 32 * 2 * 1000 * 1000 * 256 / (ms(prof, "match_bow") * 1e-3) / 1e12,
-           "match_frac_mfma_f32": 32 * 2 * 1000 * 1000 * 256 / (ms(prof, "match_bow") * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
+           "match_frac_mfma_f32": 32 * 2 * 1000 * 1000 * 256 / (ms(prof, "match_bow") * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+           "triangulation_32_pairs_us": ms(prof, "match_tri") * 1e3,
+           "triangulation_frac_mfma_f32": 32 * 2 * 1000 * 1000 * 256 / (ms(prof, "match_tri") * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
     # cold: a 1 GB database (4x the Infinity Cache): every scan streams it from HBM
     NC = 65536
     dbc = capi.Database(eng, NC, DIM)

@@ -1098,10 +1098,11 @@ int hfnet_descriptor_distance(hfnet_engine* eh, const float* a, const float* b, 
 }
 
 // scratch for n_pairs x (max_rows x max_rows) similarity matrices, norms, keys and the pair descriptors
-// SearchByBoW keeps candidate slots per train row (no n x m matrix); SearchForTriangulation still selects from S
+// neither matcher stores an n x m matrix: SearchByBoW keeps candidate slots per train row, SearchForTriangulation
+// (maximum, index) partials per row / column and 64-wide tile
 static int bow_scratch(Engine& e, int n_pairs, int max_rows, bool triangulation) {
     const size_t np = (size_t)std::max(n_pairs, 1), mr = (size_t)std::max(max_rows, 1);
-    HF_TRY(e.m_s.ensure(triangulation ? sizeof(float) * np * mr * mr : bow_scratch_bytes((int)np, (int)mr)));
+    HF_TRY(e.m_s.ensure(triangulation ? sizeof(float) * np * tri_scratch_floats((int)mr) : bow_scratch_bytes((int)np, (int)mr)));
     HF_TRY(e.m_qn.ensure(sizeof(float) * np * mr));
     HF_TRY(e.m_tn.ensure(sizeof(float) * np * mr));
     HF_TRY(e.m_key.ensure(sizeof(unsigned long long) * np * mr));
@@ -1184,7 +1185,7 @@ static int match_pairs_batch(hfnet_engine* eh, int n_pairs, const float* desc_ba
     }
     HF_LAUNCH(&e, e.stream, "match_bow_setup",
               launch_bow_setup(e.m_pairs.as<BowPair>(), n_pairs, d_base, (long long)set_stride, d_rows, d_qs, d_ts, max_rows, e.m_s.as<float>(),
-                               e.m_qn.as<float>(), e.m_tn.as<float>(), e.m_key.as<unsigned long long>(), d_match, d_dist, d_cnt, max_rows, e.stream));
+                               triangulation ? (long long)tri_scratch_floats(max_rows) : 0, e.m_qn.as<float>(), e.m_tn.as<float>(), e.m_key.as<unsigned long long>(), d_match, d_dist, d_cnt, max_rows, e.stream));
     if (triangulation) {
         const float threshold = (float)(-0.5 * th * th + 1);   // Matcher.cc:851
         HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, threshold, e.stream));
@@ -1358,8 +1359,8 @@ static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const 
                                        e.m_a.as<float>(), e.stream));
     HF_LAUNCH(&e, e.stream, "store_setup",
               launch_store_setup(e.m_pairs.as<BowPair>(), n_pairs, st->d_desc, e.m_a.as<float>(), stride, st->d_rows, d_crows, d_qsel, d_tsel, mr,
-                                 e.m_s.as<float>(), e.m_qn.as<float>(), e.m_tn.as<float>(), e.m_key.as<unsigned long long>(), w_match, w_dist, d_cnt,
-                                 e.stream));
+                                 e.m_s.as<float>(), triangulation ? (long long)tri_scratch_floats(mr) : 0, e.m_qn.as<float>(), e.m_tn.as<float>(),
+                                 e.m_key.as<unsigned long long>(), w_match, w_dist, d_cnt, e.stream));
     if (triangulation) {
         const float threshold = (float)(-0.5 * th * th + 1);       // Matcher.cc:851
         HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, threshold, e.stream));
@@ -1400,17 +1401,20 @@ int hfnet_match_search_for_triangulation(hfnet_engine* eh, const float* d1, int 
     const float *da, *db;
     HF_TRY(stage_rows(e, e.m_a, d1, (size_t)n1 * dim, on_device, &da));
     HF_TRY(stage_rows(e, e.m_b, d2, (size_t)n2 * dim, on_device, &db));
-    HF_TRY(e.m_s.ensure(sizeof(float) * std::max<size_t>((size_t)n1 * n2, 1)));
-    HF_TRY(e.m_i1.ensure(sizeof(int) * std::max(n2, 1)));
+    const int max_rows = std::max(n1, n2);
+    HF_TRY(bow_scratch(e, 1, max_rows, true));
     int32_t* d_match = match12; int* d_cnt = n_matches;
     if (!on_device) {
         HF_TRY(e.m_i0.ensure(sizeof(int32_t) * n1)); HF_TRY(e.m_cnt.ensure(sizeof(int)));
         d_match = e.m_i0.as<int32_t>(); d_cnt = e.m_cnt.as<int>();
     }
-    HF_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int), e.stream));
-    HF_LAUNCH(&e, e.stream, "match_gemm", launch_gemm_abt(da, n1, db, n2, dim, e.m_s.as<float>(), e.stream));
+    BowPair P;
+    P.q = da; P.t = db; P.St = e.m_s.as<float>(); P.qn = e.m_qn.as<float>(); P.tn = e.m_tn.as<float>(); P.qkey = e.m_key.as<unsigned long long>();
+    P.match = d_match; P.dist = nullptr; P.cnt = d_cnt; P.nq = n1; P.nt = n2;
+    HF_HIP(hipMemcpyAsync(e.m_pairs.p, &P, sizeof P, hipMemcpyHostToDevice, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));     // P lives on this stack frame
     const float threshold = (float)(-0.5 * th_high * th_high + 1);   // Matcher.cc:851
-    HF_LAUNCH(&e, e.stream, "match_tri_select", launch_tri_select(e.m_s.as<float>(), n1, n2, threshold, e.m_i1.as<int>(), d_match, d_cnt, e.stream));
+    HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), 1, max_rows, dim, threshold, e.stream));
     if (!on_device) {
         HF_HIP(hipMemcpyAsync(match12, d_match, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, e.stream));
         HF_HIP(hipMemcpyAsync(n_matches, d_cnt, sizeof(int), hipMemcpyDeviceToHost, e.stream));

@@ -90,11 +90,6 @@ hipError_t launch_vlad(const float* feat /*phys layout [frames x P x D]*/, const
 hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* y_raw, float* out, int frames, hipStream_t s);
 
 // ---- kernels_match.hip --------------------------------------------------------------------------
-// S[n1 x n2] = D1 * D2^T, fused multiply-add chain over k = 0..dim-1 (Matcher.cc:845-849)
-hipError_t launch_gemm_abt(const float* d1, int n1, const float* d2, int n2, int dim, float* S, hipStream_t s);
-// SearchForTriangulation selection (Matcher.cc:851-889)
-hipError_t launch_tri_select(const float* S, int n1, int n2, float threshold, int* col_best, int32_t* match12,
-                             int* n_matches, hipStream_t s);
 // BFMatcher(NORM_L2, crossCheck) + distance < th_low (Matcher.cc:229-260), batched over descriptor-set pairs.
 // One BowPair per (query set, train set); launch_bow_setup fills them on the device (row counts may be
 // device-resident), launch_bow_pairs runs prep / GEMM / train pass / finalize for all pairs in four launches.
@@ -105,19 +100,22 @@ struct BowPair {
     int nq, nt;
 };
 hipError_t launch_bow_setup(BowPair* pairs, int n_pairs, const float* base, long long set_stride, const int* n_rows, const int* qset,
-                            const int* tset, int max_rows, float* St, float* qn, float* tn, unsigned long long* qkey, int32_t* match, float* dist,
-                            int* cnt, long long out_stride, hipStream_t s);
+                            const int* tset, int max_rows, float* St, long long st_stride, float* qn, float* tn, unsigned long long* qkey, int32_t* match,
+                            float* dist, int* cnt, long long out_stride, hipStream_t s);
 // row-filtered matching over a descriptor store (flag byte per row; sel >= 0 store slot, sel < 0 compacted set ~sel)
 hipError_t launch_store_compact(const float* base, const unsigned char* flags, long long set_stride, const int* store_rows, int n_compact,
                                 const int* c_slot, const int* c_filter, int max_rows, int dim, int* map, int* inv, int* c_rows, float* comp,
                                 hipStream_t s);
 hipError_t launch_store_setup(BowPair* pairs, int n_pairs, const float* base, const float* comp, long long set_stride, const int* store_rows,
-                              const int* c_rows, const int* qsel, const int* tsel, int max_rows, float* St, float* qn, float* tn,
+                              const int* c_rows, const int* qsel, const int* tsel, int max_rows, float* St, long long st_stride, float* qn, float* tn,
                               unsigned long long* qkey, int32_t* match, float* dist, int* cnt, hipStream_t s);
 hipError_t launch_store_remap(int n_pairs, const int* qsel, const int* tsel, const int* c_slot, const int* store_rows, const int* map,
                               const int* inv, int max_rows, const int32_t* c_match, const float* c_dist, int32_t* match, float* dist,
                               hipStream_t s);
-// SearchForTriangulation over the same pair descriptors (q = set 1, t = set 2; dist / qn / qkey unused)
+// SearchForTriangulation over the same pair descriptors (q = set 1, t = set 2; dist / qn / qkey unused): S = D1 * D2^T as
+// fused multiply-add chains over k = 0..dim-1 (Matcher.cc:845-849) with the mutual arg-max (Matcher.cc:851-889) in the GEMM
+// epilogue.  Scratch per pair (BowPair::St): tri_scratch_floats(max_rows) floats of (maximum, index) partials, no n x m matrix.
+size_t tri_scratch_floats(int max_rows);
 hipError_t launch_tri_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float threshold, hipStream_t s);
 // scratch: bow_scratch_bytes(n_pairs, max_rows) bytes (candidate slots per train row and 64-query tile; no n x m matrix)
 size_t bow_scratch_bytes(int n_pairs, int max_rows);

@@ -16,85 +16,34 @@ namespace hfnet {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// =========================================================================== S = D1 * D2^T
-// One wave per 32x32 tile of S on v_mfma_f32_32x32x2_f32; each accumulator is the fused
-// multiply-add chain over k = 0, 1, 2, ... (the oracle's order).
-// Workgroup = 64 x 64 tile of S (4 waves, one 32x32 MFMA tile each); K is consumed in chunks of 64 that
-// are staged through LDS with coalesced 256-byte row segments (a lane's own row is 1 KB away from its
-// neighbour's, so direct fragment loads thrash L1).
-__device__ __forceinline__ void gemm_abt_tile(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int dim,
-                                              float* __restrict__ S) {
-    constexpr int LD = 68;                                    // even k in floats [0, 32), odd k in [32, 64) of a row (see the 128 x 128 tile)
-    __shared__ __attribute__((aligned(16))) float As[64 * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[64 * LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
-    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
-    if (row0 >= n1 || col0 >= n2) return;                     // workgroup-uniform (batched launches are sized for the largest pair)
-    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-    const int lc = tid & 15, lrow = (tid >> 4) * 4;          // staging: 16 threads per 256-byte row chunk, rows (tid / 16) * 4 + j
-    long long aoff[4], boff[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        aoff[j] = (long long)min(row0 + lrow + j, n1 - 1) * dim + lc * 4;
-        boff[j] = (long long)min(col0 + lrow + j, n2 - 1) * dim + lc * 4;
-    }
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    f32x4 sa[4], sb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { sa[j] = *(const f32x4*)(d1 + aoff[j]); sb[j] = *(const f32x4*)(d2 + boff[j]); }
-    for (int k0 = 0; k0 < dim; k0 += 64) {
-        __syncthreads();                                     // previous chunk fully consumed
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float* ap = As + (lrow + j) * LD + lc * 2;
-            float* bp = Bs + (lrow + j) * LD + lc * 2;
-            *(float2*)(ap) = float2{sa[j][0], sa[j][2]}; *(float2*)(ap + 32) = float2{sa[j][1], sa[j][3]};
-            *(float2*)(bp) = float2{sb[j][0], sb[j][2]}; *(float2*)(bp + 32) = float2{sb[j][1], sb[j][3]};
-        }
-        __syncthreads();
-        if (k0 + 64 < dim) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { sa[j] = *(const f32x4*)(d1 + aoff[j] + k0 + 64); sb[j] = *(const f32x4*)(d2 + boff[j] + k0 + 64); }
-        }
-        const float* ap = As + (wr + r) * LD + half * 32;
-        const float* bp = Bs + (wc + r) * LD + half * 32;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const f32x4 av = *(const f32x4*)(ap + 4 * m), bv = *(const f32x4*)(bp + 4 * m);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
-        }
-    }
-    const int col = col0 + wc + r;
-    if (col >= n2) return;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int row = row0 + wr + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-        if (row < n1) S[(long long)row * n2 + col] = acc[reg];
-    }
-}
+// =========================================================================== SearchForTriangulation
+// S = D1 * D2^T on v_mfma_f32_32x32x2_f32 -- each accumulator is the fused multiply-add chain over k = 0, 1, 2, ... (the
+// oracle's order, so the products are the oracle's bits) -- followed by the mutual arg-max of Matcher.cc:860-893.  S is
+// never stored: the epilogue of a 128 x 128 workgroup tile reduces every wave's 64 x 64 part to (first maximum, index)
+// per row and per column, 8 bytes per row / column and 64-wide tile instead of 256; two small kernels finish the
+// reduction over the tiles in ascending order (strict >: the first maximum wins, as in the reference's loops) and do
+// the cross-check.
+//
+// GEMM part: 128 x 128 tile per workgroup, 64 x 64 (2 x 2 MFMA tiles) per wave: every LDS fragment feeds two MFMAs.  K is
+// consumed in chunks of 64 staged through LDS with coalesced 256-byte row segments (a lane's own row is 1 KB away from
+// its neighbour's, so direct fragment loads thrash L1).  The LDS rows hold the even k of a chunk in their first half and
+// the odd k in the second, so a half-wave (which supplies the even resp. odd k of every MFMA step) reads the operands of
+// four consecutive steps with one 16-byte read and no select (VALU instructions and f32 MFMAs share the issue pipe).
+// Rows are 68 floats apart: 16-byte reads of 16 consecutive rows cover all 64 banks once.
+struct TriPart { float v; int idx; };
+__host__ __device__ static inline int tri_tiles(int n) { return (n + 63) / 64; }
+size_t tri_scratch_floats(int max_rows) { return (size_t)4 * (size_t)max_rows * tri_tiles(max_rows); }   // two directions x 8 bytes
 
-__global__ __launch_bounds__(256) void k_gemm_abt(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int dim,
-                                                  float* __restrict__ S) {
-    gemm_abt_tile(d1, n1, d2, n2, dim, S);
-}
-
-// 128 x 128 tile per workgroup, 64 x 64 (2 x 2 MFMA tiles) per wave: every LDS fragment feeds two MFMAs.  The LDS
-// rows hold the even k of a 64-float chunk in their first half and the odd k in the second, so a half-wave (which
-// supplies the even resp. odd k of every MFMA step) reads the operands of four consecutive steps with one 16-byte
-// read and no select (VALU instructions and f32 MFMAs share the issue pipe).  Same per-accumulator order
-// (k ascending), so the same bits as the 64 x 64 kernel.  Rows are 68 floats apart: 16-byte reads of 16 consecutive
-// rows cover all 64 banks once.
-__device__ __forceinline__ void gemm_abt_tile128(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int dim,
-                                                 float* __restrict__ S) {
+__global__ __launch_bounds__(256) void k_tri_gemm_argmax(const BowPair* __restrict__ pairs, int dim, int max_rows) {
+    const BowPair P = pairs[blockIdx.z];
+    const float* __restrict__ d1 = P.q; const float* __restrict__ d2 = P.t;
+    const int n1 = P.nq, n2 = P.nt;
     constexpr int LD = 68;
     __shared__ __attribute__((aligned(16))) float As[128 * LD];
     __shared__ __attribute__((aligned(16))) float Bs[128 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
     const int row0 = blockIdx.y * 128, col0 = blockIdx.x * 128;
-    if (row0 >= n1 || col0 >= n2) return;                     // workgroup-uniform
+    if (row0 >= n1 || col0 >= n2) return;                     // workgroup-uniform (launches are sized for the largest pair)
     const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
     // staging: 16 threads cover the 256 contiguous bytes of a row chunk; a thread handles rows (tid / 16) * 8 + j
     const int lc = tid & 15, lrow = (tid >> 4) * 8;
@@ -143,131 +92,100 @@ __device__ __forceinline__ void gemm_abt_tile128(const float* __restrict__ d1, i
             }
         }
     }
+    __syncthreads();                                          // the operand tiles are dead: every wave takes a quarter of the LDS
+    if (row0 + wr >= n1 || col0 + wc >= n2) return;           // (wave-uniform, no barrier below) nothing of this 64 x 64 part is inside
+    const int nt = tri_tiles(max_rows);
+    TriPart* __restrict__ colpart = (TriPart*)P.St;           // [row tile of 64][max_rows]
+    TriPart* __restrict__ rowpart = colpart + (size_t)nt * max_rows;   // [max_rows][column tile of 64]
+    const int rv = min(64, n1 - row0 - wr), cv = min(64, n2 - col0 - wc);   // valid rows / columns of the part (uniform)
+    // ---- column direction: a lane holds, for its column, 32 of the part's 64 rows (ascending with i, reg); the other
+    //      half-wave holds the rows in between
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float best = -__builtin_inff();
+        int bi = -1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int rl = i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                const float v = acc[i][j][reg];
+                if (rl < rv && v > best) { best = v; bi = rl; }
+            }
+        const float ob = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(bi, 32, 64);
+        if (oi >= 0 && (ob > best || bi < 0 || (ob == best && oi < bi))) { best = ob; bi = oi; }
+        const int cl = j * 32 + r;
+        if (half == 0 && cl < cv) colpart[(size_t)((row0 + wr) >> 6) * max_rows + col0 + wc + cl] = TriPart{best, bi < 0 ? -1 : row0 + wr + bi};
+    }
+    // ---- row direction: the part goes through LDS once so that a lane owns one row and scans its 64 columns in order
+    float* T = As + wave * (64 * LD);                         // (As and Bs are contiguous: 4 x 64 x 68 floats)
+    if (wave >= 2) T = Bs + (wave - 2) * (64 * LD);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = col0 + wc + j * 32 + r;
-            if (col >= n2) continue;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = row0 + wr + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                if (row < n1) S[(long long)row * n2 + col] = acc[i][j][reg];
-            }
+            for (int reg = 0; reg < 16; ++reg) T[(i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half) * LD + j * 32 + r] = acc[i][j][reg];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private slice: program order is enough
+    {
+        const float* tp = T + lane * LD;
+        float best = -__builtin_inff();
+        int bj = -1;
+#pragma unroll
+        for (int c4 = 0; c4 < 16; ++c4) {
+            const f32x4 v = *(const f32x4*)(tp + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c4 * 4 + e < cv && v[e] > best) { best = v[e]; bj = c4 * 4 + e; }
         }
-}
-hipError_t launch_gemm_abt(const float* d1, int n1, const float* d2, int n2, int dim, float* S, hipStream_t s) {
-    if (n1 <= 0 || n2 <= 0) return hipSuccess;
-    if (dim % 64) return hipErrorInvalidValue;
-    dim3 grid((n2 + 63) / 64, (n1 + 63) / 64);
-    hipLaunchKernelGGL(k_gemm_abt, grid, dim3(256), 0, s, d1, n1, d2, n2, dim, S);
-    return hipGetLastError();
-}
-
-// =========================================================================== SearchForTriangulation
-// column pass: first arg-max over rows with value > threshold (Matcher.cc:877-889)
-__global__ __launch_bounds__(256) void k_col_argmax(const float* __restrict__ S, int n1, int n2, float threshold, int* __restrict__ col_best) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n2) return;
-    float best = threshold;
-    int bi = -1;
-    for (int i = 0; i < n1; ++i) {
-        const float d = S[(long long)i * n2 + j];
-        if (d > best) { best = d; bi = i; }
-    }
-    col_best[j] = bi;
-}
-// row pass: first arg-max over columns with value > threshold, then the cross-check (Matcher.cc:860-893)
-__global__ __launch_bounds__(256) void k_row_match(const float* __restrict__ S, int n1, int n2, float threshold, const int* __restrict__ col_best,
-                                                   int32_t* __restrict__ match12, int* __restrict__ n_matches) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n1) return;
-    const int lane = threadIdx.x & 63;
-    float best = threshold;
-    int bj = 0x7fffffff;
-    for (int j = lane; j < n2; j += 64) {
-        const float d = S[(long long)i * n2 + j];
-        if (d > best) { best = d; bj = j; }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ob = __shfl_xor(best, off, 64);
-        const int oj = __shfl_xor(bj, off, 64);
-        if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
-    }
-    if (lane == 0) {
-        int m = -1;
-        if (bj != 0x7fffffff && col_best[bj] == i) { m = bj; atomicAdd(n_matches, 1); }
-        match12[i] = m;
+        if (lane < rv) rowpart[(size_t)(row0 + wr + lane) * nt + ((col0 + wc) >> 6)] = TriPart{best, bj < 0 ? -1 : col0 + wc + bj};
     }
 }
 
-hipError_t launch_tri_select(const float* S, int n1, int n2, float threshold, int* col_best, int32_t* match12, int* n_matches,
-                             hipStream_t s) {
-    if (n1 <= 0) return hipSuccess;
-    if (n2 > 0) hipLaunchKernelGGL(k_col_argmax, dim3((n2 + 255) / 256), dim3(256), 0, s, S, n1, n2, threshold, col_best);
-    hipLaunchKernelGGL(k_row_match, dim3((n1 + 3) / 4), dim3(256), 0, s, S, n1, n2, threshold, col_best, match12, n_matches);
-    return hipGetLastError();
-}
-
-// ---- the same over many descriptor-set pairs (blockIdx.z = pair): LocalMapping matches a new keyframe against its
-// ~30 covisible neighbours (LocalMapping.cc:516-520) -- one GEMM launch and two selection launches for all of them.
-// Scratch per pair: St = S [n1 x n2], tn reinterpreted as the column arg-max.
-__global__ __launch_bounds__(256) void k_gemm_abt_pairs_qt(const BowPair* __restrict__ pairs, int dim) {
+// column j: first row with the largest product above the threshold (Matcher.cc:877-889) -> P.tn (as int); resets the counter
+__global__ __launch_bounds__(256) void k_tri_cols(const BowPair* __restrict__ pairs, float threshold, int max_rows) {
     const BowPair P = pairs[blockIdx.z];
-    gemm_abt_tile128(P.q, P.nq, P.t, P.nt, dim, P.St);
-}
-__global__ __launch_bounds__(256) void k_col_argmax_pairs(const BowPair* __restrict__ pairs, float threshold) {
-    const BowPair P = pairs[blockIdx.z];
-    const int n1 = P.nq, n2 = P.nt;
     if (blockIdx.x == 0 && threadIdx.x == 0) *P.cnt = 0;
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n2) return;
+    if (j >= P.nt) return;
+    const TriPart* __restrict__ colpart = (const TriPart*)P.St;
+    const int nrt = tri_tiles(P.nq);
     float best = threshold;
     int bi = -1;
-    for (int i = 0; i < n1; ++i) {
-        const float d = P.St[(long long)i * n2 + j];
-        if (d > best) { best = d; bi = i; }
+    for (int t = 0; t < nrt; ++t) {
+        const TriPart c = colpart[(size_t)t * max_rows + j];
+        if (c.idx >= 0 && c.v > best) { best = c.v; bi = c.idx; }
     }
     ((int*)P.tn)[j] = bi;
 }
-__global__ __launch_bounds__(256) void k_row_match_pairs(const BowPair* __restrict__ pairs, float threshold) {
-    __shared__ int wg_count;
+// row i: first column with the largest product above the threshold, then the cross-check (Matcher.cc:860-893)
+__global__ __launch_bounds__(256) void k_tri_rows(const BowPair* __restrict__ pairs, float threshold, int max_rows) {
     const BowPair P = pairs[blockIdx.z];
-    const int n1 = P.nq, n2 = P.nt;
-    if (blockIdx.x * 4 >= n1) return;                          // workgroup-uniform
-    if (threadIdx.x == 0) wg_count = 0;
-    __syncthreads();
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (i < n1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= P.nq) return;                     // workgroup-uniform
+    int m = -1;
+    if (i < P.nq) {
+        const int nt = tri_tiles(max_rows), nct = tri_tiles(P.nt);
+        const TriPart* __restrict__ rowpart = (const TriPart*)P.St + (size_t)nt * max_rows + (size_t)i * nt;
         float best = threshold;
-        int bj = 0x7fffffff;
-        for (int j = lane; j < n2; j += 64) {
-            const float d = P.St[(long long)i * n2 + j];
-            if (d > best) { best = d; bj = j; }
+        int bj = -1;
+        for (int t = 0; t < nct; ++t) {
+            const TriPart c = rowpart[t];
+            if (c.idx >= 0 && c.v > best) { best = c.v; bj = c.idx; }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ob = __shfl_xor(best, off, 64);
-            const int oj = __shfl_xor(bj, off, 64);
-            if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
-        }
-        if (lane == 0) {
-            int m = -1;
-            if (bj != 0x7fffffff && ((const int*)P.tn)[bj] == i) { m = bj; atomicAdd(&wg_count, 1); }
-            P.match[i] = m;
-        }
+        if (bj >= 0 && ((const int*)P.tn)[bj] == i) m = bj;
+        P.match[i] = m;
     }
-    __syncthreads();
-    if (threadIdx.x == 0 && wg_count) atomicAdd(P.cnt, wg_count);
+    const unsigned long long hit = __ballot(m >= 0);
+    if ((threadIdx.x & 63) == 0 && hit) atomicAdd(P.cnt, __popcll(hit));
 }
 hipError_t launch_tri_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float threshold, hipStream_t s) {
     if (n_pairs <= 0 || max_rows <= 0) return hipSuccess;
     if (dim % 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_gemm_abt_pairs_qt, dim3((max_rows + 127) / 128, (max_rows + 127) / 128, n_pairs), dim3(256), 0, s, pairs, dim);
-    hipLaunchKernelGGL(k_col_argmax_pairs, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, threshold);
-    hipLaunchKernelGGL(k_row_match_pairs, dim3((max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, threshold);
+    hipLaunchKernelGGL(k_tri_gemm_argmax, dim3((max_rows + 127) / 128, (max_rows + 127) / 128, n_pairs), dim3(256), 0, s, pairs, dim, max_rows);
+    hipLaunchKernelGGL(k_tri_cols, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, threshold, max_rows);
+    hipLaunchKernelGGL(k_tri_rows, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, threshold, max_rows);
     return hipGetLastError();
 }
 
@@ -554,23 +472,23 @@ __global__ __launch_bounds__(256) void k_bow_finalize(const BowPair* __restrict_
 // bring them to the host), scratch is sliced per pair
 __global__ void k_bow_setup(BowPair* __restrict__ pairs, int n_pairs, const float* __restrict__ base, long long set_stride,
                             const int* __restrict__ n_rows, const int* __restrict__ qset, const int* __restrict__ tset, int max_rows, float* St,
-                            float* qn, float* tn, unsigned long long* qkey, int32_t* match, float* dist, int* cnt, long long out_stride) {
+                            long long st_stride, float* qn, float* tn, unsigned long long* qkey, int32_t* match, float* dist, int* cnt, long long out_stride) {
     const int p = blockIdx.x * 64 + threadIdx.x;
     if (p >= n_pairs) return;
     BowPair P;
     const int qs = qset[p], ts = tset[p];
     P.q = base + (long long)qs * set_stride; P.t = base + (long long)ts * set_stride;
     P.nq = min(max(n_rows[qs], 0), max_rows); P.nt = min(max(n_rows[ts], 0), max_rows);
-    P.St = St + (long long)p * max_rows * max_rows;
+    P.St = St + (long long)p * st_stride;
     P.qn = qn + (long long)p * max_rows; P.tn = tn + (long long)p * max_rows; P.qkey = qkey + (long long)p * max_rows;
     P.match = match + (long long)p * out_stride; P.dist = dist + (long long)p * out_stride; P.cnt = cnt + p;
     pairs[p] = P;
 }
 
 hipError_t launch_bow_setup(BowPair* pairs, int n_pairs, const float* base, long long set_stride, const int* n_rows, const int* qset,
-                            const int* tset, int max_rows, float* St, float* qn, float* tn, unsigned long long* qkey, int32_t* match, float* dist,
-                            int* cnt, long long out_stride, hipStream_t s) {
-    hipLaunchKernelGGL(k_bow_setup, dim3((n_pairs + 63) / 64), dim3(64), 0, s, pairs, n_pairs, base, set_stride, n_rows, qset, tset, max_rows, St, qn,
+                            const int* tset, int max_rows, float* St, long long st_stride, float* qn, float* tn, unsigned long long* qkey, int32_t* match,
+                            float* dist, int* cnt, long long out_stride, hipStream_t s) {
+    hipLaunchKernelGGL(k_bow_setup, dim3((n_pairs + 63) / 64), dim3(64), 0, s, pairs, n_pairs, base, set_stride, n_rows, qset, tset, max_rows, St, st_stride, qn,
                        tn, qkey, match, dist, cnt, out_stride);
     return hipGetLastError();
 }
@@ -623,8 +541,8 @@ __global__ __launch_bounds__(256) void k_store_compact_copy(const float* __restr
 
 __global__ void k_store_setup(BowPair* __restrict__ pairs, int n_pairs, const float* __restrict__ base, const float* __restrict__ comp,
                               long long set_stride, const int* __restrict__ store_rows, const int* __restrict__ c_rows,
-                              const int* __restrict__ qsel, const int* __restrict__ tsel, int max_rows, float* St, float* qn, float* tn,
-                              unsigned long long* qkey, int32_t* match, float* dist, int* cnt) {
+                              const int* __restrict__ qsel, const int* __restrict__ tsel, int max_rows, float* St, long long st_stride, float* qn,
+                              float* tn, unsigned long long* qkey, int32_t* match, float* dist, int* cnt) {
     const int p = blockIdx.x * 64 + threadIdx.x;
     if (p >= n_pairs) return;
     BowPair P;
@@ -633,7 +551,7 @@ __global__ void k_store_setup(BowPair* __restrict__ pairs, int n_pairs, const fl
     P.t = ts >= 0 ? base + (long long)ts * set_stride : comp + (long long)(~ts) * set_stride;
     P.nq = min(max(qs >= 0 ? store_rows[qs] : c_rows[~qs], 0), max_rows);
     P.nt = min(max(ts >= 0 ? store_rows[ts] : c_rows[~ts], 0), max_rows);
-    P.St = St + (long long)p * max_rows * max_rows;
+    P.St = St + (long long)p * st_stride;
     P.qn = qn + (long long)p * max_rows; P.tn = tn + (long long)p * max_rows; P.qkey = qkey + (long long)p * max_rows;
     P.match = match + (long long)p * max_rows; P.dist = dist + (long long)p * max_rows; P.cnt = cnt + p;
     pairs[p] = P;
@@ -673,10 +591,10 @@ hipError_t launch_store_compact(const float* base, const unsigned char* flags, l
     return hipGetLastError();
 }
 hipError_t launch_store_setup(BowPair* pairs, int n_pairs, const float* base, const float* comp, long long set_stride, const int* store_rows,
-                              const int* c_rows, const int* qsel, const int* tsel, int max_rows, float* St, float* qn, float* tn,
+                              const int* c_rows, const int* qsel, const int* tsel, int max_rows, float* St, long long st_stride, float* qn, float* tn,
                               unsigned long long* qkey, int32_t* match, float* dist, int* cnt, hipStream_t s) {
     hipLaunchKernelGGL(k_store_setup, dim3((n_pairs + 63) / 64), dim3(64), 0, s, pairs, n_pairs, base, comp, set_stride, store_rows, c_rows, qsel,
-                       tsel, max_rows, St, qn, tn, qkey, match, dist, cnt);
+                       tsel, max_rows, St, st_stride, qn, tn, qkey, match, dist, cnt);
     return hipGetLastError();
 }
 hipError_t launch_store_remap(int n_pairs, const int* qsel, const int* tsel, const int* c_slot, const int* store_rows, const int* map,
