@@ -5,8 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Headline = BASELINE config 2.  One "step" = one batch of `--batch` (512) synthetic 752x480 frames through the whole
-front end on one GPU, in chunks of `--chunk` (32) frames: 4-level pyramid (x1.2), HF-Net (MobileNetV2 backbone,
+Headline = BASELINE config 2.  One "step" = one batch of `--batch` (768) synthetic 752x480 frames through the whole
+front end on one GPU, in chunks of `--chunk` (64) frames: 4-level pyramid (x1.2), HF-Net (MobileNetV2 backbone,
 detector + descriptor heads, NetVLAD on level 0), NMS, per-level top-K (budget 322/268/224/186), bilinear descriptor
 sampling, then one SearchByBoW-style brute-force match (1000 x 1000 x 256, L2 cross-check, < 0.6) of every frame
 against its predecessor.  Inputs are resident in HBM before the timed region; outputs stay in HBM.  Frames are
@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 W_IMG, H_IMG, N_FEAT, N_LEVELS, SCALE, THRESH, TH_LOW, TH_HIGH = 752, 480, 1000, 4, 1.2, 0.01, 0.6, 0.75
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4)
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic_b32.json")
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic_b{batch}.json")     # one file per frames-per-call value
 ALL_CONFIGS = ["2-latency", "2-host-io", "3", "4", "5"]
 
 
@@ -146,7 +146,7 @@ def hbm_traffic(launch_name: str, batch: int):
     (FETCH_SIZE counts 128-byte requests as 64 bytes -> doubled).  None when no pass exists for this kernel / chunk size.
     NOT a measurement of the present run: rocprofv3 cannot run inside the timed process."""
     try:
-        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
+        with open(os.path.join(ROOT, TRAFFIC_FILE.format(batch=batch))) as f:
             t = json.load(f)
         k = t["kernels"][launch_name]
         if t["batch"] != batch:
@@ -520,8 +520,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="frames per step and GPU")
-    ap.add_argument("--chunk", type=int, default=32, help="frames per extract / match call (the extractor's batch)")
+    ap.add_argument("--batch", type=int, default=768, help="frames per step and GPU")
+    ap.add_argument("--chunk", type=int, default=64, help="frames per extract / match call (the extractor's batch)")
     ap.add_argument("--frames", choices=["uniform", "natural"], default="uniform", help="synthetic frame distribution (SURVEY.md 8d)")
     ap.add_argument("--configs", default="all", help="comma list of sub-records to measure besides the headline: " + ",".join(ALL_CONFIGS) + " | all | none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -559,7 +559,7 @@ def main() -> None:
         eng.set_option(k, int(v))
     B, chunks_per_step = args.chunk, args.batch // args.chunk
     pipe = Pipeline(torch, capi, eng, dev, W_IMG, H_IMG, B)
-    n_sets = 2
+    n_sets = max(chunks_per_step, 2)      # every frame of a step is a different image (the same step is replayed K times)
     frames = [torch.from_numpy(make_frames(B, (rank * n_sets + s) * B, args.frames)).to(dev) for s in range(n_sets)]
     torch.cuda.synchronize()
     state = {"i": 0}
@@ -616,7 +616,7 @@ def main() -> None:
         avg_s = dom[1] / max(dom[0], 1) * 1e-3
         roof = roofline_entry(flop / launches_per_chunk, byts / launches_per_chunk, avg_s)
         roof.update({"traffic": hbm_traffic(dominant, B),
-                     "traffic_source": f"{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at chunk {B} (committed; not measured in this run)",
+                     "traffic_source": f"{TRAFFIC_FILE.format(batch=B)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at chunk {B} (committed; not measured in this run)",
                      "kernel": dominant, "avg_launch_us": avg_s * 1e6, "launches": dom[0],
                      "selection": "largest launch name by time in the single-stream profiling pass; timed live (HIP events on its stream) over the timed region"})
         chunk_s = elapsed / args.steps / chunks_per_step

@@ -1,8 +1,9 @@
 # usage (on the GPU box, via gpurun):  bash tools/gpu_profiles.sh <round tag, e.g. r02>
 # Writes gpurun_out/<tag>_profiles/: the bench line, rocprofv3 kernel stats of the same command, SQ counter passes and the
-# FETCH_SIZE / WRITE_SIZE passes folded into <tag>_traffic_b32.json.  Copy what is to be judged into profiles/.
+# FETCH_SIZE / WRITE_SIZE passes folded into <tag>_traffic_b<chunk>.json (chunk = bench.py's default frames per call).  Copy what is to be judged into profiles/.
 set -x
 TAG=$1
+CH=64   # bench.py default --chunk
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_profiles
 mkdir -p $OUT
@@ -17,14 +18,14 @@ i=1
 for P in "$P1" "$P2"; do
   rm -rf /tmp/pmc$i
   timeout 600 rocprofv3 --pmc $P --kernel-trace --output-format csv -d /tmp/pmc$i -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --configs none --no-cpu-baseline > $OUT/pmc$i.log 2>&1
-  python $GRAFT_REPO_ROOT/tools/pmc_summary.py $(find /tmp/pmc$i -name '*counter_collection.csv' | head -1) > $OUT/${TAG}_pmc_$( [ $i = 1 ] && echo sq || echo instmix )_b32.txt
+  python $GRAFT_REPO_ROOT/tools/pmc_summary.py $(find /tmp/pmc$i -name '*counter_collection.csv' | head -1) > $OUT/${TAG}_pmc_$( [ $i = 1 ] && echo sq || echo instmix )_b${CH}.txt
   i=$((i+1))
 done
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --configs none --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
 done
-python $GRAFT_REPO_ROOT/tools/make_traffic.py $(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) 32 $OUT/${TAG}_traffic_b32.json > $OUT/traffic.log 2>&1
+python $GRAFT_REPO_ROOT/tools/make_traffic.py $(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) $CH $OUT/${TAG}_traffic_b${CH}.json > $OUT/traffic.log 2>&1
 rm -f $OUT/*.log
 ls -la $OUT
 head -c 1500 $OUT/${TAG}_bench.json
