@@ -340,7 +340,7 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
             for (int l = 0; l < NL; ++l) kmaxb = std::max(kmaxb, std::min(budget.k[l], cfg.max_keypoints));
             const long long rows = ((long long)(NL * cfg.batch - 1) * cfg.max_keypoints + kmaxb) * 4;
             HF_LAUNCH(e, stream, "conv3x3_desc_taps", launch_conv3x3_taps(act[7], w.desc1, rows_hidden, 1, kps_level, n_level, cfg.max_keypoints, budget.k, gt, stream));
-            HF_LAUNCH(e, stream, "pointwise_desc_taps", launch_pointwise(rows_hidden, w.desc2, nullptr, rows_raw, rows, 0, stream));
+            HF_LAUNCH(e, stream, "pointwise_desc_taps", launch_pointwise(rows_hidden, w.desc2, nullptr, rows_raw, rows, 0, stream, n_level, 4 * cfg.max_keypoints, 4));
         } else {
             HF_TRY(run_dense_desc());
         }

@@ -13,9 +13,11 @@ hipError_t launch_resize_u8(const uint8_t* src, int sw, int sh, int s_row, long 
                             int batch, hipStream_t s);
 // image prep + stem conv 3x3/2 + BN + ReLU6 (HFNetTFModelV2.cc:204-208, layers.py:6-7, hf_net.py:30,188-190)
 hipError_t launch_stem(const ImageSet& imgs, const float* w, const float* bias, int cout, float* out, const Geom& g, hipStream_t s);
-// 1x1 convolution on the matrix cores: out[P x n] = epilogue(A[P x cin] * W)
+// 1x1 convolution on the matrix cores: out[P x n] = epilogue(A[P x cin] * W).  slot_units (optional, device): the rows are
+// slots of slot_rows rows per image of which only the first slot_units[image] * rows_per_unit are in use (tap rows of the
+// sparse descriptor head); 32-row tiles in the unused part are skipped, their output rows are left untouched.
 hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* residual, float* out, long long P,
-                            int relu6, hipStream_t s);
+                            int relu6, hipStream_t s, const int* slot_units = nullptr, int slot_rows = 0, int rows_per_unit = 0);
 // dense 3x3 stride-1 convolution (implicit GEMM on the matrix cores), per-image tiles
 hipError_t launch_conv3x3(const float* A, const ConvPack& cp, float* out, int relu6, const Geom& g, hipStream_t s);
 // the same convolution evaluated only at the 4 bilinear taps of every selected keypoint ("sparse

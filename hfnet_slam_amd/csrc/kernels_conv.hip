@@ -208,7 +208,22 @@ struct ConvArgs {
     int nt_total;
     int relu6;
     int level_tiles[HFNET_MAX_LEVELS];   // 3x3 kernel: 128-row tiles launched per image of each level (exact 1-D grid)
+    // pointwise on slotted rows (the tap rows of the sparse descriptor head: slot_rows rows per image, of which the first
+    // slot_units[image] * rows_per_unit are in use): 32-row tiles that lie in the unused part of a slot are skipped
+    const int* slot_units;
+    int slot_rows, rows_per_unit;
 };
+
+// does the 32-row tile starting at row0 touch a used row? (wave-uniform)
+__device__ __forceinline__ bool tile_in_use(const ConvArgs& a, long long row0, int rows = 32) {
+    if (!a.slot_units) return true;
+    const long long last = min(row0 + rows, a.P) - 1;
+    const int i0 = (int)(row0 / a.slot_rows), i1 = (int)(last / a.slot_rows);
+    if ((int)(row0 - (long long)i0 * a.slot_rows) < a.slot_units[i0] * a.rows_per_unit) return true;
+    for (int i = i0 + 1; i <= i1; ++i)
+        if (a.slot_units[i] > 0) return true;
+    return false;
+}
 
 // (ReLU6) (+ residual) and store of a wave's 32 x (NT*32) accumulator tile (BatchNorm: folded weights, the accumulators
 // started at the folded bias -- conv_acc_init).  VALU instructions compete
@@ -281,7 +296,7 @@ template <int NT>
 __global__ __launch_bounds__(256, 2) void k_pointwise(ConvArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
     const long long row0 = (long long)blockIdx.x * 128 + wave * 32;
-    if (row0 >= a.P) return;
+    if (row0 >= a.P || !tile_in_use(a, row0)) return;
     const int nt0 = blockIdx.y * NT;
     long long row = row0 + r;
     if (row >= a.P) row = a.P - 1;
@@ -316,6 +331,77 @@ __global__ __launch_bounds__(256, 2) void k_pointwise(ConvArgs a) {
         for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
     }
     conv_epilogue<NT>(a, acc, nt0, row0, a.P, half, r);
+}
+
+// GEMM-shaped 1x1 convolutions with more weights than L1 holds (256 -> 256 on the descriptor head's tap rows: 256 KB):
+// every wave of k_pointwise fetches its own copy of the weight fragments from L2, 4 KB per k-step and wave, and the
+// ~10 bytes per clock a CU gets from L2 bound the kernel at half the MFMA rate.  Here the workgroup stages the weight
+// slab of four k-steps (NT x 4 KB) through LDS once -- one coalesced 16-byte load per thread and k-step, double buffered,
+// one barrier per slab -- and its four waves read their fragments from there; the activation rows (a wave's own) still
+// come straight from memory one k-step ahead.  Same chains, same bits.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_pointwise_wlds(ConvArgs a) {
+    constexpr int KS = 4;                                     // k-steps (of 8 channels) per slab
+    __shared__ __attribute__((aligned(16))) f32x4 wl[2][KS][NT][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+    const long long row0 = (long long)blockIdx.x * 128 + wave * 32;
+    const int nt0 = blockIdx.y * NT;
+    if (!tile_in_use(a, (long long)blockIdx.x * 128, 128)) return;   // (workgroup-uniform: before any barrier)
+    const bool active = row0 < a.P && tile_in_use(a, row0);   // (waves without rows still help staging)
+    const float* ap = a.A + min(row0 + r, a.P - 1) * a.cin + half * 4;
+    const int KQ = a.cin >> 3, n_slabs = (KQ + KS - 1) / KS;
+    const size_t wstep = (size_t)a.nt_total * 64;
+    // staging role: thread -> (column tile, lane) of one k-step's NT KB (NT * 64 pieces of 16 bytes; 256 threads)
+    constexpr int PIECES = NT * 64, PER_T = (PIECES + 255) / 256;
+    auto fetch = [&](int slab, f32x4 (&st)[KS][PER_T]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kq = min(slab * KS + ks, KQ - 1);
+#pragma unroll
+            for (int j = 0; j < PER_T; ++j) {
+                const int piece = min(tid + j * 256, PIECES - 1);
+                st[ks][j] = a.W[(size_t)kq * wstep + (size_t)nt0 * 64 + piece];
+            }
+        }
+    };
+    auto stash = [&](int buf, const f32x4 (&st)[KS][PER_T]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < PER_T; ++j)
+                if (tid + j * 256 < PIECES) (&wl[buf][ks][0][0])[tid + j * 256] = st[ks][j];
+    };
+    f32x16 acc[NT];
+    conv_acc_init<NT>(a, acc, nt0, r);
+    f32x4 st[KS][PER_T];
+    fetch(0, st);
+    stash(0, st);
+    __syncthreads();
+    f32x4 av = *(const f32x4*)(ap);
+    for (int slab = 0; slab < n_slabs; ++slab) {
+        const int buf = slab & 1;
+        if (slab + 1 < n_slabs) fetch(slab + 1, st);           // next slab: in flight while this one is multiplied
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kq = slab * KS + ks;
+            if (kq < KQ) {                                    // uniform
+                const f32x4 an = *(const f32x4*)(ap + min(kq + 1, KQ - 1) * 8);
+                f32x4 bv[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = wl[buf][ks][nt][lane];
+                if (active) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], acc[nt], 0, 0, 0);
+                }
+                av = an;
+            }
+        }
+        if (slab + 1 < n_slabs) stash(buf ^ 1, st);
+        __syncthreads();
+    }
+    if (active) conv_epilogue<NT>(a, acc, nt0, row0, a.P, half, r);
 }
 
 // Low-latency 1x1 convolution for launches that cannot fill the GPU (single frames: the projections of the 30x47 / 15x24
@@ -555,6 +641,7 @@ static ConvArgs make_args(const float* A, const ConvPack& cp, const float* res, 
     a.A = A; a.W = (const f32x4*)cp.w; a.bias = cp.bias; a.res = res; a.out = out;
     a.P = P; a.cin = cp.cin; a.n = cp.n; a.nt_total = cp.nt_total; a.relu6 = relu6;
     for (int l = 0; l < HFNET_MAX_LEVELS; ++l) a.level_tiles[l] = 1;
+    a.slot_units = nullptr; a.slot_rows = 0; a.rows_per_unit = 0;
     return a;
 }
 
@@ -571,16 +658,27 @@ static int pick_nt(int nt_total, int nt_pref, long long m_tiles) {
 }
 
 hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* residual, float* out, long long P, int relu6,
-                            hipStream_t s) {
+                            hipStream_t s, const int* slot_units, int slot_rows, int rows_per_unit) {
     if (P <= 0) return hipSuccess;
-    const ConvArgs a = make_args(A, cp, residual, out, P, relu6);
+    ConvArgs a = make_args(A, cp, residual, out, P, relu6);
+    if (slot_units && slot_rows > 0) { a.slot_units = slot_units; a.slot_rows = slot_rows; a.rows_per_unit = rows_per_unit; }
     const int nt = pick_nt(cp.nt_total, cp.nt_per_block, (P + 31) / 32);
     // long k chains on few tiles: latency-bound, see k_pointwise_deep
     constexpr long long lowlat_waves = 1024;
+    constexpr long long wlds_min_weight_bytes = 128 * 1024;
     if (nt <= 2 && cp.cin >= 192 && (P + 31) / 32 * cp.nt_total < lowlat_waves) {
         dim3 grid((unsigned)((P + 127) / 128), cp.nt_total / nt);
         if (nt == 1) hipLaunchKernelGGL((k_pointwise_deep<1, 8>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_pointwise_deep<2, 8>), grid, dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
+    // more weights than L1 holds on a GEMM-shaped launch: weight slabs through LDS (see k_pointwise_wlds)
+    if ((size_t)cp.cin * cp.nt_total * 32 * sizeof(float) >= (size_t)wlds_min_weight_bytes && (P + 127) / 128 * (cp.nt_total / nt) >= 1024 &&
+        nt >= 2 && nt <= 4) {
+        dim3 gw((unsigned)((P + 127) / 128), cp.nt_total / nt);
+        if (nt == 2) hipLaunchKernelGGL(k_pointwise_wlds<2>, gw, dim3(256), 0, s, a);
+        else if (nt == 3) hipLaunchKernelGGL(k_pointwise_wlds<3>, gw, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_pointwise_wlds<4>, gw, dim3(256), 0, s, a);
         return hipGetLastError();
     }
     dim3 grid((unsigned)((P + 127) / 128), cp.nt_total / nt);
