@@ -17,7 +17,8 @@ int* Options::find(const char* name) {
     if (!name) return nullptr;
     const struct { const char* n; int* p; } tab[] = {{"fuse_blocks", &fuse_blocks}, {"fuse_max_layer", &fuse_max_layer}, {"fused_variant", &fused_variant},
                                                        {"fuse_stem", &fuse_stem}, {"dense_desc", &dense_desc}, {"two_streams", &two_streams},
-                                                       {"graph", &graph}, {"pinned_frames", &pinned_frames}, {"db_gemm_min_queries", &db_gemm_min_queries}};
+                                                       {"graph", &graph}, {"pinned_frames", &pinned_frames}, {"db_gemm_min_queries", &db_gemm_min_queries},
+                                                       {"conv_wlds", &conv_wlds}};
     for (const auto& t : tab) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -116,7 +117,7 @@ int Net::build(Engine* eng, const NetConfig& c) {
     cfg = c;
     // A/B and diagnostics switches of the engine (hfnet_engine_set_option), fixed for the lifetime of this network
     fuse_blocks = e->opt.fuse_blocks; fuse_max_layer = e->opt.fuse_max_layer; fused_variant = e->opt.fused_variant;
-    force_dense = e->opt.dense_desc; fuse_stem = e->opt.fuse_stem;
+    force_dense = e->opt.dense_desc; fuse_stem = e->opt.fuse_stem; conv_wlds = e->opt.conv_wlds;
     const DeviceWeights& w = e->w;
     if (c.n_levels < 1 || c.n_levels > HFNET_MAX_LEVELS || c.batch < 1) { set_error("net: bad level / batch count"); return HFNET_ERR_INVALID_ARG; }
     if (c.from_intermediate && (c.n_levels != 1 || !c.global)) { set_error("net: intermediate input needs one level and the global head"); return HFNET_ERR_INVALID_ARG; }
@@ -307,7 +308,7 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         const long long pc = pix_cell[HFNET_MAX_LEVELS];
         Geom gh = geom(7, 7, 0, NL);
         for (int l = 0; l < NL; ++l) { gh.lv[l].pt = gh.lv[l].pl = 1; gh.lv[l].out_off = pix_cell[l]; }
-        HF_LAUNCH(e, stream, "conv3x3_det", launch_conv3x3(act[7], w.det1, det_hidden, 1, gh, stream));
+        HF_LAUNCH(e, stream, "conv3x3_det", launch_conv3x3(act[7], w.det1, det_hidden, 1, gh, conv_wlds, stream));
         if (fork && two_streams >= 2) {
             // the global branch starts after the (chip-filling, MFMA-bound) detector conv: it overlaps the long tail of
             // small kernels (softmax, NMS, top-K, sparse descriptor head) instead of time-sharing with that conv
@@ -339,7 +340,7 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
             int kmaxb = 0;
             for (int l = 0; l < NL; ++l) kmaxb = std::max(kmaxb, std::min(budget.k[l], cfg.max_keypoints));
             const long long rows = ((long long)(NL * cfg.batch - 1) * cfg.max_keypoints + kmaxb) * 4;
-            HF_LAUNCH(e, stream, "conv3x3_desc_taps", launch_conv3x3_taps(act[7], w.desc1, rows_hidden, 1, kps_level, n_level, cfg.max_keypoints, budget.k, gt, stream));
+            HF_LAUNCH(e, stream, "conv3x3_desc_taps", launch_conv3x3_taps(act[7], w.desc1, rows_hidden, 1, kps_level, n_level, cfg.max_keypoints, budget.k, gt, conv_wlds, stream));
             HF_LAUNCH(e, stream, "pointwise_desc_taps", launch_pointwise(rows_hidden, w.desc2, nullptr, rows_raw, rows, 0, stream, n_level, 4 * cfg.max_keypoints, 4));
         } else {
             HF_TRY(run_dense_desc());
@@ -368,7 +369,7 @@ int Net::run_dense_desc() {
     const long long pc = pix_cell[HFNET_MAX_LEVELS];
     Geom gh = geom(7, 7, 0, cfg.n_levels);
     for (int l = 0; l < cfg.n_levels; ++l) { gh.lv[l].pt = gh.lv[l].pl = 1; gh.lv[l].out_off = pix_cell[l]; }
-    HF_LAUNCH(e, stream, "conv3x3_desc", launch_conv3x3(act[7], w.desc1, desc_hidden, 1, gh, stream));
+    HF_LAUNCH(e, stream, "conv3x3_desc", launch_conv3x3(act[7], w.desc1, desc_hidden, 1, gh, conv_wlds, stream));
     HF_LAUNCH(e, stream, "pointwise_desc", launch_pointwise(desc_hidden, w.desc2, nullptr, desc_raw, pc, 0, stream));
     HF_LAUNCH(e, stream, "l2norm_desc", launch_l2norm256(desc_raw, desc_norm, pc, stream));
     dense_valid = true;

@@ -25,6 +25,7 @@ struct Options {
     int two_streams = 3;      // 0 one stream; 1 fork after layer 7; 2 fork after the detector conv; 3 = 2 + deferred join
     int graph = 1;            // host-pointer extractor calls replay a captured graph
     int pinned_frames = 4;    // chunks up to this many frames move through one pinned block inside that graph
+    int conv_wlds = 1;        // 3x3 heads: weights staged through LDS once per workgroup (0: every wave reads them from L1 / L2)
     int db_gemm_min_queries = 8;   // hfnet_db_query_batch: from this many queries on, the scores come from the MFMA GEMM form
     int* find(const char* name);
 };
@@ -95,6 +96,7 @@ struct Net {
     int fuse_max_layer = 14;
     int fused_variant = 4;
     int fuse_stem = 1;             // stem + layer_2 in one launch: the stem tensor is not materialised (its tap recomputes it on demand)
+    int conv_wlds = 1;             // 3x3 heads with LDS-staged weights
     ImageSet last_imgs;            // input of the last forward (for that tap)
     bool stem_valid = false;
     size_t stem_elems_max = 0;     // size of the stem tensor at the configured (largest) batch

@@ -18,13 +18,15 @@ hipError_t launch_stem(const ImageSet& imgs, const float* w, const float* bias, 
 // sparse descriptor head); 32-row tiles in the unused part are skipped, their output rows are left untouched.
 hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* residual, float* out, long long P,
                             int relu6, hipStream_t s, const int* slot_units = nullptr, int slot_rows = 0, int rows_per_unit = 0);
-// dense 3x3 stride-1 convolution (implicit GEMM on the matrix cores), per-image tiles
-hipError_t launch_conv3x3(const float* A, const ConvPack& cp, float* out, int relu6, const Geom& g, hipStream_t s);
+// dense 3x3 stride-1 convolution (implicit GEMM on the matrix cores), per-image tiles; wlds != 0: weights staged through LDS
+// once per workgroup (k_conv3x3_wlds) where the shape allows it
+hipError_t launch_conv3x3(const float* A, const ConvPack& cp, float* out, int relu6, const Geom& g, int wlds, hipStream_t s);
 // the same convolution evaluated only at the 4 bilinear taps of every selected keypoint ("sparse
 // descriptor head"): row (image*kps_stride + i)*4 + t of `out` is tap t of keypoint i.  Geom: H, W =
 // score-map size, Ho, Wo = cell grid, in_off = first cell of the level.
 hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, int relu6, const hfnet_keypoint* kps, const int* n_in,
-                               long long kps_stride, const int* level_keypoints /* upper bound of n_in per level */, const Geom& g, hipStream_t s);
+                               long long kps_stride, const int* level_keypoints /* upper bound of n_in per level */, const Geom& g, int wlds,
+                               hipStream_t s);
 // depthwise 3x3 (stride 1 / 2) + BN + ReLU6
 hipError_t launch_depthwise(const float* in, const DwPack& dp, int stride, float* out, const Geom& g, hipStream_t s);
 // whole inverted-residual block (expand -> depthwise -> project [+ residual]) in one launch; the expanded

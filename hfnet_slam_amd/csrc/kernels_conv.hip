@@ -626,6 +626,136 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g, TapArgs 
     conv_epilogue<NT>(a, acc, nt0, out_base + p0, out_base + nrows, half, r);
 }
 
+// The same convolution with the weights staged through LDS (k_pointwise_wlds' scheme): the workgroup's four waves share
+// every weight fragment, so a slab of four k-steps (NT x 4 KB, one coalesced 16-byte load per thread and k-step) crosses
+// L2 -> L1 once instead of four times, and the only per-lane global loads left are the activation rows, requested a whole
+// slab (64 MFMAs, ~4000 cycles) ahead.  cin % 32 == 0 (a slab never straddles two taps).  Same chains, same bits.
+template <int NT, bool GATHER>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_wlds(ConvArgs a, Geom g, TapArgs ta) {
+    constexpr int KS = 4;
+    __shared__ __attribute__((aligned(16))) f32x4 wl[2][KS][NT][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+    const int G = a.nt_total / NT;
+    int level = 0, rest = blockIdx.x;
+    for (; level < g.n_levels - 1; ++level) {
+        const int per = g.batch * G * a.level_tiles[level];
+        if (rest < per) break;
+        rest -= per;
+    }
+    const int tl = a.level_tiles[level];
+    const int frame = rest / (G * tl);
+    rest -= frame * G * tl;
+    const int grp = rest / tl, tile = rest - grp * tl;
+    const int image = level * g.batch + frame;
+    const LevelGeom lv = g.lv[level];
+    const int Hc = GATHER ? lv.Ho : lv.H, Wc = GATHER ? lv.Wo : lv.W;
+    const int nrows = GATHER ? ta.n_in[image] * 4 : Hc * Wc;
+    const int T = (nrows + 127) >> 7;
+    if (tile >= T) return;                                      // workgroup-uniform
+    const int nt0 = grp * NT;
+    const int p0 = tile * 128 + wave * 32;
+    const bool active = p0 < nrows;                             // (a wave without rows still helps staging)
+    int y, x;
+    bool pvalid;
+    long long in_base, out_base;
+    if (GATHER) {
+        const int n = nrows >> 2;
+        const int row = p0 + r, i = row >> 2, t = row & 3;
+        pvalid = active && i < n;
+        const hfnet_keypoint kp = ta.kps[(long long)image * ta.kps_stride + (pvalid ? i : 0)];
+        // identical float expressions to k_sample (HFNetTFModelV2.cc:119-120, BaseModel.cc:534-539)
+        const float sw = ((float)Wc - 1.f) / (float)((float)lv.W - 1.f);
+        const float sh = ((float)Hc - 1.f) / (float)((float)lv.H - 1.f);
+        const float xf = sw * kp.x, yf = sh * kp.y;
+        const int fx = (int)floorf(xf), fy = (int)floorf(yf);
+        x = fx + ((t == 1 || t == 3) ? 1 : 0);
+        y = fy + ((t == 1 || t == 2) ? 1 : 0);
+        pvalid = pvalid && x >= 0 && x < Wc && y >= 0 && y < Hc;
+        if (!pvalid) { x = 0; y = 0; }
+        in_base = lv.in_off + (long long)frame * Hc * Wc;
+        out_base = (long long)image * ta.kps_stride * 4;
+    } else {
+        pvalid = (p0 + r) < nrows;
+        const int p = pvalid ? p0 + r : nrows - 1;
+        y = p / Wc; x = p - y * Wc;
+        in_base = lv.in_off + (long long)frame * nrows;
+        out_base = lv.out_off + (long long)frame * nrows;
+    }
+    const int KQ = a.cin >> 3, SPT = KQ / KS, n_slabs = 9 * SPT;   // slabs per tap
+    const size_t wstep = (size_t)a.nt_total * 64;
+    constexpr int PIECES = NT * 64, PER_T = (PIECES + 255) / 256;
+    auto fetch = [&](int slab, f32x4 (&st)[KS][PER_T]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < PER_T; ++j)
+                st[ks][j] = a.W[(size_t)(slab * KS + ks) * wstep + (size_t)nt0 * 64 + min(tid + j * 256, PIECES - 1)];
+    };
+    auto stash = [&](int buf, const f32x4 (&st)[KS][PER_T]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < PER_T; ++j)
+                if (tid + j * 256 < PIECES) (&wl[buf][ks][0][0])[tid + j * 256] = st[ks][j];
+    };
+    f32x16 acc[NT];
+    conv_acc_init<NT>(a, acc, nt0, r);
+    // per-tap source pointer / validity of this lane's pixel (an out-of-image tap points at a valid pixel and is zeroed
+    // when used: fma(0, w, acc) == acc, exactly as the oracle skips it)
+    const float* tap_ptr[9];
+    bool tap_ok[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int iy = y + ky - 1, ix = x + kx - 1;
+        tap_ok[tap] = pvalid && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc;
+        tap_ptr[tap] = a.A + (in_base + (long long)(tap_ok[tap] ? iy * Wc + ix : 0)) * a.cin + half * 4;
+    }
+    f32x4 st[KS][PER_T];
+    fetch(0, st);
+    stash(0, st);
+    f32x4 av[KS], an[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) av[ks] = *(const f32x4*)(tap_ptr[0] + ks * 8);
+    __syncthreads();
+    int slab = 0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int tn = tap < 8 ? tap + 1 : 8;
+        for (int sl = 0; sl < SPT; ++sl, ++slab) {
+            const int buf = slab & 1;
+            const bool wrap = sl + 1 == SPT;
+            if (slab + 1 < n_slabs) fetch(slab + 1, st);
+            {
+                const float* tpn = wrap ? tap_ptr[tn] : tap_ptr[tap];
+                const int kn = wrap ? 0 : (sl + 1) * KS;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) an[ks] = *(const f32x4*)(tpn + (kn + ks) * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const bool ok = tap_ok[tap];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                f32x4 bv[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = wl[buf][ks][nt][lane];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float xv = ok ? av[ks][t] : 0.0f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, bv[nt][t], acc[nt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) av[ks] = an[ks];
+            if (slab + 1 < n_slabs) stash(buf ^ 1, st);
+            __syncthreads();
+        }
+    }
+    if (active) conv_epilogue<NT>(a, acc, nt0, out_base + p0, out_base + nrows, half, r);
+}
+
 template <int NT>
 static void launch_pw_nt(const ConvArgs& a, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL(k_pointwise<NT>, grid, dim3(256), 0, s, a);
@@ -634,6 +764,10 @@ template <int NT>
 static void launch_c3_nt(const ConvArgs& a, const Geom& g, const TapArgs* ta, dim3 grid, hipStream_t s) {
     if (ta) hipLaunchKernelGGL((k_conv3x3<NT, true>), grid, dim3(256), 0, s, a, g, *ta);
     else { TapArgs none = {nullptr, nullptr, 0}; hipLaunchKernelGGL((k_conv3x3<NT, false>), grid, dim3(256), 0, s, a, g, none); }
+}
+static void launch_c3_wlds4(const ConvArgs& a, const Geom& g, const TapArgs* ta, dim3 grid, hipStream_t s) {
+    if (ta) hipLaunchKernelGGL((k_conv3x3_wlds<4, true>), grid, dim3(256), 0, s, a, g, *ta);
+    else { TapArgs none = {nullptr, nullptr, 0}; hipLaunchKernelGGL((k_conv3x3_wlds<4, false>), grid, dim3(256), 0, s, a, g, none); }
 }
 
 static ConvArgs make_args(const float* A, const ConvPack& cp, const float* res, float* out, long long P, int relu6) {
@@ -697,7 +831,7 @@ hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* res
 }
 
 static hipError_t launch_conv3x3_any(const float* A, const ConvPack& cp, float* out, int relu6, const Geom& g, const TapArgs* ta,
-                                     const int* level_rows, hipStream_t s) {
+                                     const int* level_rows, int wlds, hipStream_t s) {
     ConvArgs a = make_args(A, cp, nullptr, out, 0, relu6);
     int ntb = cp.nt_per_block;
     if (ta && cp.nt_total % 4 == 0) ntb = 4;           // gathered rows: four column tiles per wave
@@ -717,6 +851,7 @@ static hipError_t launch_conv3x3_any(const float* A, const ConvPack& cp, float* 
     const long long wgs = tiles * (cp.nt_total / ntb);
     if (wgs <= 0 || wgs > 0x7fffffffll) return hipErrorInvalidValue;
     dim3 grid((unsigned)wgs, 1, 1);
+    if (wlds && ntb == 4 && cp.cin % 32 == 0) { launch_c3_wlds4(a, g, ta, grid, s); return hipGetLastError(); }
     switch (ntb) {
         case 1: launch_c3_nt<1>(a, g, ta, grid, s); break;
         case 2: launch_c3_nt<2>(a, g, ta, grid, s); break;
@@ -731,18 +866,18 @@ static hipError_t launch_conv3x3_any(const float* A, const ConvPack& cp, float* 
     return hipGetLastError();
 }
 
-hipError_t launch_conv3x3(const float* A, const ConvPack& cp, float* out, int relu6, const Geom& g, hipStream_t s) {
+hipError_t launch_conv3x3(const float* A, const ConvPack& cp, float* out, int relu6, const Geom& g, int wlds, hipStream_t s) {
     int rows[HFNET_MAX_LEVELS] = {0};
     for (int l = 0; l < g.n_levels; ++l) rows[l] = g.lv[l].H * g.lv[l].W;
-    return launch_conv3x3_any(A, cp, out, relu6, g, nullptr, rows, s);
+    return launch_conv3x3_any(A, cp, out, relu6, g, nullptr, rows, wlds, s);
 }
 
 hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, int relu6, const hfnet_keypoint* kps, const int* n_in,
-                               long long kps_stride, const int* level_keypoints, const Geom& g, hipStream_t s) {
+                               long long kps_stride, const int* level_keypoints, const Geom& g, int wlds, hipStream_t s) {
     const TapArgs ta = {kps, n_in, kps_stride};
     int rows[HFNET_MAX_LEVELS] = {0};
     for (int l = 0; l < g.n_levels; ++l) rows[l] = 4 * (int)std::min<long long>(level_keypoints[l], kps_stride);
-    return launch_conv3x3_any(A, cp, out, relu6, g, &ta, rows, s);
+    return launch_conv3x3_any(A, cp, out, relu6, g, &ta, rows, wlds, s);
 }
 
 // =========================================================================== depthwise 3x3

@@ -79,6 +79,7 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *   "fuse_max_layer" (14), "fused_variant" (4: wave-autonomous tiles, 2: barrier-phased kernel), "fuse_stem" (1)
  *   "dense_desc" (0)    1: dense descriptor head instead of the taps of the selected keypoints
  *   "two_streams" (3)   0 one stream; 1 fork after layer 7; 2 fork after the detector conv; 3 = 2 + deferred join
+ *   "conv_wlds" (1)     3x3 head convolutions: weights staged through LDS once per workgroup (0: every wave reads them)
  *   "graph" (1), "pinned_frames" (4): host-pointer extractor calls
  *   "db_gemm_min_queries" (8): hfnet_db_query_batch switches to the MFMA form of the scores from this many queries on
  * Every setting of the extractor switches produces the same bits (tests/test_gpu_parity.py). */
