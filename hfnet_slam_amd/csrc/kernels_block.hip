@@ -414,7 +414,10 @@ __device__ __forceinline__ gbase_t sgpr_base(const void* base, unsigned uniform_
 
 template <int S> struct F4Geo {
     static constexpr int TH = 4, TW = 8, IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, NPOS = IH * IW, MT_IN = (NPOS + 31) / 32;
-    static constexpr int EP = MT_IN * 32 + 4;        // channel stride of ET in floats: EP / 4 odd -> conflict-free 16-byte accesses
+    // channel stride of ET in floats: the halo positions rounded up to an odd number of 16-byte pieces (conflict-free
+    // 16-byte accesses); the pieces of the last M tile that lie past it are not written.  Stride 2: 156 floats, 19.5 KB per
+    // wave, so that eight one-wave workgroups (two per SIMD) fit the CU's LDS -- with 164 it was seven
+    static constexpr int EP = ((NPOS + 3) / 4) % 2 == 1 ? (NPOS + 3) / 4 * 4 : (NPOS + 3) / 4 * 4 + 4;
     static constexpr int CEP = 36;                    // pixel stride of D
     static_assert((EP / 4) % 2 == 1, "ET channel stride");
 };
@@ -522,7 +525,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void k_block_fused4(FusedArgs a, G
                     f32x4 v;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = relu6f(acc[4 * q + i]);
-                    *(f32x4*)(ET + r * EP + m * 32 + 8 * q + 4 * half) = v;
+                    if (m * 32 + 8 * q + 8 <= EP) *(f32x4*)(ET + r * EP + m * 32 + 8 * q + 4 * half) = v;
+                    else if (m * 32 + 8 * q + 4 <= EP) { if (half == 0) *(f32x4*)(ET + r * EP + m * 32 + 8 * q) = v; }
                 }
             }
         }
