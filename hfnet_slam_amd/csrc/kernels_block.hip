@@ -32,8 +32,31 @@ struct FusedArgs {
     const f32x4* Wpr; const float* pr_bias; int pr_nt_total;
     float* out;
     int cin, cexp, cout, residual, has_expand;
+    int level_wgs[HFNET_MAX_LEVELS];   // k_block_fused4: workgroups launched per image of each level (a multiple of 8; exact 1-D grid)
 };
 
+
+// exact 1-D grids over the ragged pyramid batch, order [level][frame][tile]: workgroup b -> (level, frame, tile).  (A 2-D
+// grid sized for the largest level launches up to half of its workgroups only to exit; dispatching them costs real time.)
+template <int TH, int TW>
+__device__ __forceinline__ void decode_tile_grid(const Geom& g, int b, int& level, int& frame, int& tile, int& tiles_x) {
+    level = 0;
+    int tiles = 0;
+    for (;; ++level) {
+        tiles_x = (g.lv[level].Wo + TW - 1) / TW;
+        tiles = tiles_x * ((g.lv[level].Ho + TH - 1) / TH);
+        if (level == g.n_levels - 1 || b < g.batch * tiles) break;
+        b -= g.batch * tiles;
+    }
+    frame = b / tiles;
+    tile = b - frame * tiles;
+}
+template <int TH, int TW>
+static long long tile_grid_size(const Geom& g) {
+    long long total = 0;
+    for (int l = 0; l < g.n_levels; ++l) total += (long long)g.batch * ((g.lv[l].Wo + TW - 1) / TW) * ((g.lv[l].Ho + TH - 1) / TH);
+    return total;
+}
 
 // ---- v2 of the fused block for the shapes of the high-resolution layers (cin = 8*KQT known at
 // compile time).  Differences to the generic kernel above:
@@ -102,11 +125,10 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, r = lane & 31;
     const int mt_first = wave == 0 ? 0 : wave == 1 ? MTC0 : wave == 2 ? MTC0 + MTC1 : MTC0 + MTC1 + MTC2;
     int mt_count = wave == 0 ? MTC0 : wave == 1 ? MTC1 : wave == 2 ? MTC2 : MTC3;
-    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
+    int level, frame, tile_id, tiles_x;
+    decode_tile_grid<TH, TW>(g, blockIdx.x, level, frame, tile_id, tiles_x);
     const LevelGeom lv = g.lv[level];
-    const int tiles_x = (lv.Wo + TW - 1) / TW, tiles_y = (lv.Ho + TH - 1) / TH;
-    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int tyi = tile_id / tiles_x, txi = tile_id - tyi * tiles_x;
     const int oy0 = tyi * TH, ox0 = txi * TW;
     const int iy0 = oy0 * STRIDE - lv.pt, ix0 = ox0 * STRIDE - lv.pl;
     const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= lv.H && ix0 + IW <= lv.W;
@@ -377,9 +399,9 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
 template <int STRIDE, int NTO, int KQT, bool HAS_EXPAND, int TW = (STRIDE == 1 ? 16 : 8)>
 static hipError_t launch_block_fused2_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
     constexpr int TH = 8;
-    int maxtiles = 0;
-    for (int l = 0; l < g.n_levels; ++l) maxtiles = max(maxtiles, ((g.lv[l].Wo + TW - 1) / TW) * ((g.lv[l].Ho + TH - 1) / TH));
-    dim3 grid(maxtiles, g.n_levels * g.batch);
+    const long long total = tile_grid_size<TH, TW>(g);
+    if (total <= 0 || total > 0x7fffffffll) return hipErrorInvalidValue;
+    dim3 grid((unsigned)total);
     hipLaunchKernelGGL((k_block_fused2<STRIDE, NTO, KQT, HAS_EXPAND, TW>), grid, dim3(256), 0, s, a, g);
     return hipGetLastError();
 }
@@ -430,14 +452,25 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void k_block_fused4(FusedArgs a, G
     const int lane = threadIdx.x & 63, half = lane >> 5, r = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* const ET = lds_all[wave];
-    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
+    // exact 1-D grid, order [level][frame][workgroup]: an image of level l owns level_wgs[l] consecutive workgroups (its
+    // own count rounded up to 8).  (A 2-D grid sized for the largest level launched half of the stride-2 kernels'
+    // workgroups only to exit -- dispatching them costs real time.)
+    int level = 0, bx = blockIdx.x;
+    for (; level < g.n_levels - 1; ++level) {
+        const int per = g.batch * a.level_wgs[level];
+        if (bx < per) break;
+        bx -= per;
+    }
+    const int frame = bx / a.level_wgs[level];
+    bx -= frame * a.level_wgs[level];
+    const int image = level * g.batch + frame;
     const LevelGeom lv = g.lv[level];
     const int tiles_x = (lv.Wo + TW - 1) / TW, ntiles = tiles_x * ((lv.Ho + TH - 1) / TH);
-    // workgroup b runs on XCD b % 8 (observed; speed only): every XCD gets one contiguous run of THIS image's tiles (an
-    // eighth of them: the pyramid levels differ in size, the grid is sized for the largest), so that the halo rows shared
-    // by vertical neighbours meet in one L2 and every XCD carries the same load
+    // workgroup b runs on XCD b % 8 (observed; speed only; an image's run starts at a multiple of 8): every XCD gets one
+    // contiguous run of THIS image's tiles, so that the halo rows shared by vertical neighbours meet in one L2 and every
+    // XCD carries the same load
     const int nwg = (ntiles + WAVES - 1) / WAVES, q = nwg >> 3, rem = nwg & 7;
-    const int xr = (blockIdx.x + image) & 7, slot = blockIdx.x >> 3;  // (the XCDs that take the remainder rotate with the image)
+    const int xr = (bx + image) & 7, slot = bx >> 3;           // (the XCDs that take the remainder rotate with the image)
     if (slot >= q + (xr < rem ? 1 : 0)) return;
     const int wg = xr * q + min(xr, rem) + slot;
     const int tile = wg * WAVES + wave;
@@ -625,12 +658,19 @@ template <int STRIDE, int NTO, int KQT, int OCC, int WAVES = 4>
 static hipError_t launch_block_fused4_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
     using G = F4Geo<STRIDE>;
     if (a.residual && (STRIDE != 1 || a.cin != a.cout)) return hipErrorInvalidValue;
-    int maxtiles = 0;
-    for (int l = 0; l < g.n_levels; ++l) maxtiles = max(maxtiles, ((g.lv[l].Wo + G::TW - 1) / G::TW) * ((g.lv[l].Ho + G::TH - 1) / G::TH));
-    const int wgs = (((maxtiles + WAVES - 1) / WAVES + 7) / 8) * 8;  // multiple of 8: see the XCD mapping in the kernel
-    dim3 grid(wgs, g.n_levels * g.batch);
-    if (a.residual) hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, true, OCC, WAVES>), grid, dim3(WAVES * 64), 0, s, a, g);
-    else hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, false, OCC, WAVES>), grid, dim3(WAVES * 64), 0, s, a, g);
+    FusedArgs b = a;
+    long long total = 0;
+    for (int l = 0; l < HFNET_MAX_LEVELS; ++l) {
+        b.level_wgs[l] = 8;
+        if (l >= g.n_levels) continue;
+        const int tiles = ((g.lv[l].Wo + G::TW - 1) / G::TW) * ((g.lv[l].Ho + G::TH - 1) / G::TH);
+        b.level_wgs[l] = max(8, (((tiles + WAVES - 1) / WAVES + 7) / 8) * 8);   // multiple of 8: see the XCD mapping in the kernel
+        total += (long long)b.level_wgs[l] * g.batch;
+    }
+    if (total <= 0 || total > 0x7fffffffll) return hipErrorInvalidValue;
+    dim3 grid((unsigned)total);
+    if (a.residual) hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, true, OCC, WAVES>), grid, dim3(WAVES * 64), 0, s, b, g);
+    else hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, false, OCC, WAVES>), grid, dim3(WAVES * 64), 0, s, b, g);
     return hipGetLastError();
 }
 
@@ -791,11 +831,10 @@ __global__ __launch_bounds__(256) void k_stem_block2(ImageSet imgs, const float*
     constexpr int T = 16, SH = T + 2, SP = SH * SH, CP = CS + 4, CH = CS / 2;
     static_assert(CS == 24 && COUT == 16, "written for the 0.75-width network");
     __shared__ __attribute__((aligned(16))) float tile[SP * CP];
-    const int image = blockIdx.y, level = image / gs.batch, frame = image - level * gs.batch;
+    int level, frame, tile_id, tiles_x;
+    decode_tile_grid<T, T>(gb, blockIdx.x, level, frame, tile_id, tiles_x);
     const LevelGeom ls = gs.lv[level], lb = gb.lv[level];     // ls: H,W image (cropped), Ho,Wo stem; lb: H,W stem, Ho,Wo out (same size)
-    const int tiles_x = (lb.Wo + T - 1) / T;
-    if ((int)blockIdx.x >= tiles_x * ((lb.Ho + T - 1) / T)) return;
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int tyi = tile_id / tiles_x, txi = tile_id - tyi * tiles_x;
     const int oy0 = tyi * T, ox0 = txi * T;
     const int sy0 = oy0 - lb.pt, sx0 = ox0 - lb.pl;            // first stem row / col of the halo tile
     const uint8_t* img = imgs.ptr[level] + (long long)frame * imgs.frame_stride[level];
@@ -880,9 +919,9 @@ bool stem_block_fusable(int stem_out, const BlockPack& b) {
 
 hipError_t launch_stem_block(const ImageSet& imgs, const float* stem_w, const float* stem_bias, const BlockPack& b, float* out, const Geom& g_stem,
                              const Geom& g_block, hipStream_t s) {
-    int maxtiles = 0;
-    for (int l = 0; l < g_block.n_levels; ++l) maxtiles = max(maxtiles, ((g_block.lv[l].Wo + 15) / 16) * ((g_block.lv[l].Ho + 15) / 16));
-    hipLaunchKernelGGL((k_stem_block2<24, 16>), dim3(maxtiles, g_block.n_levels * g_block.batch), dim3(256), 0, s, imgs, stem_w, stem_bias, b.dw.w,
+    const long long total = tile_grid_size<16, 16>(g_block);
+    if (total <= 0 || total > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_stem_block2<24, 16>), dim3((unsigned)total), dim3(256), 0, s, imgs, stem_w, stem_bias, b.dw.w,
                        b.dw.bias, b.pr_logical, b.pr.bias, out, g_stem, g_block);
     return hipGetLastError();
 }
