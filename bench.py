@@ -59,16 +59,24 @@ def layer_work(batch: int, width: int = W_IMG, height: int = H_IMG, n_feat: int 
         f, b, x = work.get(name, (0.0, 0.0, 0.0))
         work[name] = (f + flop, b + byts, x + (flop if executed is None else executed))
 
+    V4_SHAPES = {(1, 3, 1), (1, 3, 2), (1, 6, 2), (1, 6, 3), (1, 9, 3), (2, 2, 1), (2, 3, 1)}   # (stride, cin / 8, cout tiles): kernels_block.hip
+
     def fused_executed(b, oh, ow):
-        """FLOP the fused block kernel issues for one image: wave tiles of 4 x 8 outputs, expansion of the
-        (3 s + 3) x (7 s + 3) halo in M-tiles of 32 positions, 32-channel chunks (kernels_block.hip)"""
+        """FLOP the fused block kernel issues for one image.  k_block_fused4 (wave tiles of 4 x 8 outputs, expansion of
+        the (3 s + 3) x (7 s + 3) halo in M-tiles of 32 positions, 32-channel chunks) where it is instantiated, otherwise
+        k_block_fused2 (workgroup tiles of 8 x 8 (stride 2) / 8 x 16 outputs, halo shared by the four waves)"""
         s = b.stride
-        tiles = -(-oh // 4) * -(-ow // 8)
-        mt_in = -(-((3 * s + 3) * (7 * s + 3)) // 32)
         chunks = -(-b.expand // 32)
         nto = -(-b.cout // 32)
-        mfma = tiles * (chunks * mt_in * (b.cin // 2) + (b.expand // 8) * 4 * nto)       # v_mfma_f32_32x32x2_f32: 4096 FLOP
-        return mfma * 4096.0 + 2.0 * 9 * b.expand * tiles * 32
+        if (s, b.cin // 8, nto) in V4_SHAPES:
+            th, tw = 4, 8
+        else:
+            th, tw = 8, (8 if s == 2 else 16)
+        tiles = -(-oh // th) * -(-ow // tw)
+        mt_in = -(-(((th - 1) * s + 3) * ((tw - 1) * s + 3)) // 32)
+        mt_out = th * tw // 32
+        mfma = tiles * (chunks * mt_in * (b.cin // 2) + (b.expand // 8) * 4 * nto * mt_out)       # v_mfma_f32_32x32x2_f32: 4096 FLOP
+        return mfma * 4096.0 + 2.0 * 9 * b.expand * tiles * th * tw
 
     for lvl, (w, h) in enumerate(sizes):
         hc, wc = S.cropped(h), S.cropped(w)
@@ -123,9 +131,10 @@ def layer_work(batch: int, width: int = W_IMG, height: int = H_IMG, n_feat: int 
     work["pointwise_desc_taps"] = (2.0 * 256 * 256 * rows, 4.0 * (rows * 512 + 256 * 256), 2.0 * 256 * 256 * rows)
     work["sample"] = (8.0 * 256 * n_feat * batch, 4.0 * (rows * 256 + n_feat * batch * 260), 8.0 * 256 * n_feat * batch)
     work["topk"] = (0.0, 8.0 * 4 * n_feat * batch * 16, 0.0)
-    # matcher: all frame pairs of a chunk in one batched call (prep + GEMM + train pass + finalize)
+    # matcher: all frame pairs of a chunk in one batched call (prep + GEMM with candidate epilogue + exact refinement + finalize);
+    # no similarity matrix: two descriptor sets in, one (match, distance) pair per query out
     mm = batch * 2.0 * n_feat * n_feat * 256
-    work["match_bow"] = (mm, batch * 4.0 * (2 * n_feat * 256 + 2 * n_feat * n_feat), batch * 2.0 * 1024 * 1024 * 256)
+    work["match_bow"] = (mm, batch * (4.0 * 2 * n_feat * 256 + 8.0 * n_feat), batch * 2.0 * 1024 * 1024 * 256)
     return work
 
 

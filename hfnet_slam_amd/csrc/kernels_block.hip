@@ -684,12 +684,11 @@ static hipError_t launch_block_fused4_t(const FusedArgs& a, const Geom& g, hipSt
 // wave-uniform scalar loads with compile-time offsets (SGPR fma operands).  Left alone, the scheduler hoists all ~650 of
 // them to the top and spills them to VGPR lanes (v_writelane / v_readlane: more VALU work than the convolution itself), so
 // they are fetched one step ahead of their use and scheduling barriers keep each batch where it is.
-template <int CIN, int COUT, int T>
-__device__ __forceinline__ void dw_project_tail(const float* tile, int ty, int tx, const float* __restrict__ wd /*[9][CIN] phys, BN folded*/,
-                                                const float* __restrict__ dbias, const float* __restrict__ wp /*[CIN logical][COUT phys], BN folded*/,
-                                                const float* __restrict__ pbias, float (&acc)[COUT]) {
+// depthwise 3x3 + folded BN + ReLU6 of one pixel from the LDS halo tile: d[physical channel]
+template <int CIN, int T>
+__device__ __forceinline__ void depthwise_from_tile(const float* tile, int ty, int tx, const float* __restrict__ wd /*[9][CIN] phys, BN folded*/,
+                                                    const float* __restrict__ dbias, float (&d)[CIN]) {
     constexpr int SH = T + 2, CP = CIN + 4;
-    float d[CIN];
 #pragma unroll
     for (int c = 0; c < CIN; ++c) d[c] = dbias[c];         // accumulators start at the folded bias
     float wc[CIN], wn[CIN];
@@ -717,6 +716,14 @@ __device__ __forceinline__ void dw_project_tail(const float* tile, int ty, int t
     }
 #pragma unroll
     for (int c = 0; c < CIN; ++c) d[c] = relu6f(d[c]);
+}
+
+template <int CIN, int COUT, int T>
+__device__ __forceinline__ void dw_project_tail(const float* tile, int ty, int tx, const float* __restrict__ wd /*[9][CIN] phys, BN folded*/,
+                                                const float* __restrict__ dbias, const float* __restrict__ wp /*[CIN logical][COUT phys], BN folded*/,
+                                                const float* __restrict__ pbias, float (&acc)[COUT]) {
+    float d[CIN];
+    depthwise_from_tile<CIN, T>(tile, ty, tx, wd, dbias, d);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int n = 0; n < COUT; ++n) acc[n] = pbias[n];
@@ -908,9 +915,65 @@ __global__ __launch_bounds__(256) void k_stem_block2(ImageSet imgs, const float*
     if (interior) stem_passes(std::true_type{}); else stem_passes(std::false_type{});
     __syncthreads();
     const int ty = threadIdx.x / T, tx = threadIdx.x - ty * T;
-    float acc[COUT];
-    dw_project_tail<CS, COUT, T>(tile, ty, tx, wd, dbias, wp, pbias, acc);
-    store_tile_via_lds<COUT, T>(tile, acc, out + (lb.out_off + (long long)frame * lb.Ho * lb.Wo) * COUT, oy0, ox0, lb.Ho, lb.Wo);
+    float d[CS];
+    depthwise_from_tile<CS, T>(tile, ty, tx, wd, dbias, d);
+    // ---- 1x1 projection CS -> COUT on the matrix cores: v_mfma_f32_16x16x4_f32, one M tile per tile row of 16 pixels (a wave
+    //      owns four rows), k = the logical channels in ascending order, four per instruction, accumulators starting at the
+    //      folded bias: the oracle's fma chain (tools/micro/mfma_order.hip).  The pixel-per-thread depthwise results go
+    //      through LDS once, stored so that lane (i, g) of the MFMA finds its A values  k = 4 j + g, j = 0..3  in one
+    //      16-byte piece and  k = 16 + 4 j + g, j = 0, 1  in one 8-byte piece of pixel i's row.
+    constexpr int DP = CS + 4;                                  // 28 floats per pixel: 16 consecutive rows cover all banks once
+    __syncthreads();                                            // every thread is done with the stem tile
+    {
+        auto phys = [](int k) { return (k & ~7) | ((k & 1) << 2) | ((k & 7) >> 1); };   // slot of logical channel k in a pixel
+        float* dp = tile + threadIdx.x * DP;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = d[phys(4 * j + g)];
+            *(f32x4*)(dp + 4 * g) = v;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *(float2*)(dp + 16 + 2 * g) = float2{d[phys(16 + g)], d[phys(20 + g)]};
+    }
+    const int li = lane & 15, lg = lane >> 4;
+    float bw[CS / 4];
+#pragma unroll
+    for (int j = 0; j < CS / 4; ++j) bw[j] = wp[(4 * j + lg) * COUT + li];
+    const float pb = pbias[li];
+    f32x4 pacc[4];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // a wave reads only the rows its own lanes wrote
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float* ap = tile + ((wave * 4 + m) * T + li) * DP;
+        const f32x4 a0 = *(const f32x4*)(ap + 4 * lg);
+        const float2 a1 = *(const float2*)(ap + 16 + 2 * lg);
+        f32x4 c = {pb, pb, pb, pb};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bw[j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bw[4], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bw[5], c, 0, 0, 0);
+        pacc[m] = c;
+    }
+    // ---- output: D[pixel 4 g + i of the row][channel lane % 16] -> LDS [pixel][COUT + 4] -> 16-byte pieces of contiguous rows
+    constexpr int OP = COUT + 4;
+    __syncthreads();                                            // every wave has read its A rows
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tile[((wave * 4 + m) * T + 4 * lg + i) * OP + li] = pacc[m][i];
+    __syncthreads();
+    float* obase = out + (lb.out_off + (long long)frame * lb.Ho * lb.Wo) * COUT;
+    const int cols = min(T, lb.Wo - ox0);
+#pragma unroll
+    for (int k = 0; k < COUT / 4; ++k) {
+        const int q = threadIdx.x + k * 256;
+        const int row = q / (T * COUT / 4), rem = q - row * (T * COUT / 4);
+        const int px = rem / (COUT / 4), part = rem - px * (COUT / 4);
+        if (oy0 + row < lb.Ho && px < cols)
+            *(f32x4*)(obase + ((long long)(oy0 + row) * lb.Wo + ox0 + px) * COUT + part * 4) = *(const f32x4*)(tile + (row * T + px) * OP + part * 4);
+    }
 }
 
 bool stem_block_fusable(int stem_out, const BlockPack& b) {
