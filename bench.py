@@ -259,14 +259,18 @@ class Pipeline:
         self._pairs = {}
         self.L = capi.lib()
 
-    def run_chunk(self, d_images, n_frames, qset=None, tset=None, n_pairs=None):
+    def run_chunk(self, d_images, n_frames, qset=None, tset=None, n_pairs=None, isolate=False):
         """d_images: device tensor [>= n_frames, h, w] u8.  qset / tset: device int32 slot lists of the match pairs
-        (default: every frame against its predecessor, the first one against the previous chunk's last frame)."""
+        (default: every frame against its predecessor, the first one against the previous chunk's last frame).
+        isolate: host-synchronise between the extraction and the match and after it (profiling pass only: the matcher has
+        its own stream and would otherwise share the GPU with the next chunk's first kernels)."""
         B, s0 = self.B, self.cur * self.B
         self.ext.extract_batch_device(n_frames, d_images.data_ptr(), self.w, self.w * self.h, self.kps[s0].data_ptr(), self.desc[s0].data_ptr(),
                                       self.glob.data_ptr(), self.n_rows[s0:].data_ptr())
         # the next extraction overwrites the buffer the PREVIOUS chunk's matches still read: fence it behind them
         self.eng.fence()
+        if isolate:
+            self.eng.synchronize()
         if qset is None:
             qset, tset, n_pairs = self._default_pairs(s0, n_frames)
         if n_pairs and not os.environ.get("BENCH_DEV_NO_MATCH"):      # (development switch: such a line is marked invalid below)
@@ -276,6 +280,8 @@ class Pipeline:
                                                         C.c_void_p(self.mdist.data_ptr()), C.c_void_p(self.mcnt.data_ptr()), 1)
             if st != 0:
                 raise RuntimeError(self.capi.last_error())
+        if isolate:
+            self.eng.synchronize()
         self.cur = (self.cur + 1) % self.n_buf
         return self.n_rows[s0:s0 + n_frames]
 
@@ -290,13 +296,14 @@ class Pipeline:
         self.ext.close()
 
 
-def profile_pass(eng, pipe, frames, chunk, reps=2):
+def profile_pass(eng, pipe, frames, chunk, reps=3):
     """dedicated profiling pass: HIP events around EVERY launch, one stream (the engine serialises the global branch while
-    an unfiltered profile is on), so no kernel shares the GPU with another.  Returns {name: (launches, total_ms)} per chunk."""
+    an unfiltered profile is on) and a host synchronisation around the matcher call (it has its own stream), so no kernel
+    shares the GPU with another.  Returns {name: (launches, total_ms)} per chunk."""
     eng.synchronize()
     eng.profile_reset(); eng.profile_filter(None); eng.profile_enable(True)
     for i in range(reps):
-        pipe.run_chunk(frames[i % len(frames)], chunk)
+        pipe.run_chunk(frames[i % len(frames)], chunk, isolate=True)
     eng.synchronize()
     prof = eng.profile()
     eng.profile_enable(False)

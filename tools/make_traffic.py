@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/rNN_traffic_b32.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace):
+"""profiles/rNN_traffic_b<chunk>.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace):
 
     make_traffic.py fetch_counter_collection.csv write_counter_collection.csv batch out.json
 
@@ -9,8 +9,8 @@ import collections, csv, json, sys
 
 # launch name -> (kernel name prefix, rank of the grid size among that kernel's launches, 0 = largest)
 LAUNCHES = {
-    "conv3x3_det": ("void hfnet::k_conv3x3<4, false>", 0),
-    "conv3x3_desc_taps": ("void hfnet::k_conv3x3<4, true>", 0),
+    "conv3x3_det": ("void hfnet::k_conv3x3_wlds<4, false>", 0),
+    "conv3x3_desc_taps": ("void hfnet::k_conv3x3_wlds<4, true>", 0),
     "stem_block_L02": ("void hfnet::k_stem_block2<24, 16>", 0),
     "block_L03": ("void hfnet::k_block_fused4<2, 1, 2, false", 0),
     "block_L04": ("void hfnet::k_block_fused4<1, 1, 3, true", 0),
@@ -18,7 +18,8 @@ LAUNCHES = {
     "block_L06": ("void hfnet::k_block_fused4<1, 2, 3, false", 0),
     "block_L07": ("void hfnet::k_block_fused4<1, 3, 6, false", 0),
     "block_L08": ("void hfnet::k_block_fused2<2, 2, 12, true, 8>", 0),
-    "pointwise_desc_taps": ("void hfnet::k_pointwise<4>", 0),
+    "pointwise_desc_taps": ("void hfnet::k_pointwise_wlds<4>", 0),
+    "pointwise_det": ("void hfnet::k_pointwise<3>", 0),
     "fc": ("void hfnet::k_fc_mfma<16>", 0),
     "nms_select": ("hfnet::k_nms_select", 0),
     "match_gemm": ("hfnet::k_bow_gemm_cand", 0),
