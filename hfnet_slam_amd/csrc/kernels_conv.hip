@@ -881,44 +881,65 @@ hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, i
 }
 
 // =========================================================================== depthwise 3x3
-// One thread per (output pixel, 4 channels).  HBM / L2-bound: 9 (stride 1) or 2.25 (stride 2)
-// cached reads and one write per output element.
+// One thread = 4 channels x a vertical strip of R output pixels of one column: the (R s + 2) x 3 input pieces and the nine
+// weight pieces are loaded once and serve R outputs (a thread per output re-read every input piece up to nine times
+// through L1, which bounded the kernel).  Consecutive threads take consecutive channel quads of a pixel: 16-byte pieces
+// of one contiguous row.  Out-of-image taps contribute fma(0, w, acc) == acc: the oracle skips them.  Per output the
+// chain is bias, then the taps in (ky, kx) order.
+template <int STRIDE, int R>
 __global__ __launch_bounds__(256) void k_depthwise(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
-                                                   float* __restrict__ out, int C, int stride, Geom g) {
+                                                   float* __restrict__ out, int C, Geom g) {
     const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
     const LevelGeom lv = g.lv[level];
-    const int c4 = C >> 2;
+    const int c4 = C >> 2, strips = (lv.Ho + R - 1) / R;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)lv.Ho * lv.Wo * c4) return;
-    const int op = (int)(idx / c4), cq = (int)(idx - (long long)op * c4);
-    const int oy = op / lv.Wo, ox = op - oy * lv.Wo;
+    if (idx >= (long long)strips * lv.Wo * c4) return;
+    const int sp = (int)(idx / c4), cq = (int)(idx - (long long)sp * c4);
+    const int st = sp / lv.Wo, ox = sp - st * lv.Wo, oy0 = st * R;
     const float* ip = in + (lv.in_off + (long long)frame * lv.H * lv.W) * C + cq * 4;
-    f32x4 acc = *(const f32x4*)(bias + cq * 4);
+    constexpr int NR = (R - 1) * STRIDE + 3;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 x[NR][3];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy * stride - lv.pt + ky;
-        if (iy < 0 || iy >= lv.H) continue;
+    for (int ry = 0; ry < NR; ++ry) {
+        const int iy = oy0 * STRIDE - lv.pt + ry;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox * stride - lv.pl + kx;
-            if (ix < 0 || ix >= lv.W) continue;
-            const f32x4 xv = *(const f32x4*)(ip + (long long)(iy * lv.W + ix) * C);
-            const f32x4 wv = *(const f32x4*)(w + (ky * 3 + kx) * C + cq * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = fmaf(xv[j], wv[j], acc[j]);
+            const int ix = ox * STRIDE - lv.pl + kx;
+            const bool ok = iy >= 0 && iy < lv.H && ix >= 0 && ix < lv.W;
+            x[ry][kx] = ok ? *(const f32x4*)(ip + (long long)(iy * lv.W + ix) * C) : zero;
         }
     }
-    f32x4 o;
+    f32x4 wv[9];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = relu6f(acc[j]);
-    *(f32x4*)(out + (lv.out_off + (long long)frame * lv.Ho * lv.Wo + op) * C + cq * 4) = o;
+    for (int t = 0; t < 9; ++t) wv[t] = *(const f32x4*)(w + t * C + cq * 4);
+    const f32x4 bv = *(const f32x4*)(bias + cq * 4);
+    float* op = out + (lv.out_off + (long long)frame * lv.Ho * lv.Wo) * C + cq * 4;
+#pragma unroll
+    for (int o = 0; o < R; ++o) {
+        if (oy0 + o >= lv.Ho) break;
+        f32x4 acc = bv;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(x[o * STRIDE + ky][kx][j], wv[ky * 3 + kx][j], acc[j]);
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = relu6f(acc[j]);
+        *(f32x4*)(op + (long long)((oy0 + o) * lv.Wo + ox) * C) = r;
+    }
 }
 
 hipError_t launch_depthwise(const float* in, const DwPack& dp, int stride, float* out, const Geom& g, hipStream_t s) {
+    constexpr int R = 5;                                      // (15-row maps of the global branch: three strips)
     long long maxwork = 0;
-    for (int l = 0; l < g.n_levels; ++l) maxwork = max(maxwork, (long long)g.lv[l].Ho * g.lv[l].Wo * (dp.c / 4));
+    for (int l = 0; l < g.n_levels; ++l) maxwork = max(maxwork, (long long)((g.lv[l].Ho + R - 1) / R) * g.lv[l].Wo * (dp.c / 4));
     dim3 grid((unsigned)((maxwork + 255) / 256), g.n_levels * g.batch);
-    hipLaunchKernelGGL(k_depthwise, grid, dim3(256), 0, s, in, dp.w, dp.bias, out, dp.c, stride, g);
+    if (stride == 1) hipLaunchKernelGGL((k_depthwise<1, R>), grid, dim3(256), 0, s, in, dp.w, dp.bias, out, dp.c, g);
+    else if (stride == 2) hipLaunchKernelGGL((k_depthwise<2, R>), grid, dim3(256), 0, s, in, dp.w, dp.bias, out, dp.c, g);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
