@@ -52,6 +52,22 @@ def test_full_size_frame_vs_oracle_and_properties(engine, oracle_model, cfg):
     x.close()
 
 
+def test_bench_sized_call_vs_oracle(engine, oracle_model):
+    """64 full-size frames in ONE call -- bench.py's default call size, at which the GEMM-shaped layers switch kernels (weight
+    slabs through LDS for the 120 -> 720 expansions with their 15 = 3 * 4 + 3 k-steps, skipped keypoint-slot tiles in the
+    descriptor head) -- against the oracle on frames from the start, the middle and the end of the batch."""
+    from hfnet_slam_amd import capi
+    w, h, nf, B = 752, 480, 1000, 64
+    x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, 4, max_batch=B)
+    imgs = np.stack([synth_image(h, w, 3000 + i, "natural" if i % 5 == 0 else "uniform") for i in range(B)])
+    nb, kb, db, gb = x.extract_batch(imgs)
+    for i in (0, 21, 40, 63):
+        rn, rk, rd, rg, _ = oracle_model.extract(imgs[i], nf, 0.01, 4, 1.2)
+        assert nb[i] == rn, i
+        assert np.array_equal(kb[i, :rn], rk) and np.array_equal(db[i, :rn], rd) and np.array_equal(gb[i], rg), i
+    x.close()
+
+
 def test_monocular_initialisation_extractor_5x_features(engine, oracle_model):
     """Tracking.cc:693 builds the initialisation extractor with 5 * nFeatures on the same models; with the 8-level pyramid
     of the monocular yaml files the small levels run out of candidates before their budget is met."""
