@@ -833,18 +833,18 @@ static int extract_chunk(hfnet_extractor* x, int nb, const uint8_t* d_images, in
     return HFNET_OK;
 }
 
-// host-pointer path: the chunk's launches always use the extractor's own staging buffers, so they are captured once per
-// chunk size into a graph (both streams: the global branch forks and joins inside it) and replayed afterwards
-static int extract_chunk_graphed(hfnet_extractor* x, int nb, bool pinned) {
+// host-pointer latency path (chunks of up to pinned_frames frames through the pinned block): the chunk's copies and launches
+// always use the extractor's own staging buffers, so they are captured once per chunk size into a graph (both streams: the global branch forks and joins inside it) and replayed afterwards
+static int extract_chunk_graphed(hfnet_extractor* x, int nb) {
     Engine& eng = x->eng->impl;
     Net& net = x->net;
     hipStream_t st = net.stream;
     const int G = eng.w.global_dim;
     auto direct = [&]() -> int {
         const size_t img_bytes = (size_t)x->width * x->height;
-        if (pinned) HF_HIP(hipMemcpyAsync(x->d_pyr[0], x->h_pin, img_bytes * nb, hipMemcpyHostToDevice, st));
+        HF_HIP(hipMemcpyAsync(x->d_pyr[0], x->h_pin, img_bytes * nb, hipMemcpyHostToDevice, st));
         HF_TRY(extract_chunk(x, nb, x->d_pyr[0], x->width, (long long)img_bytes, x->d_kps, x->d_desc, nullptr, x->d_n, x->d_n_level));
-        if (pinned) {                                              // results of the whole chunk at full capacity: sizes are static
+        {                                                          // results of the whole chunk at full capacity: sizes are static
             HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_n, x->d_n, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
             HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_nl, x->d_n_level, sizeof(int) * (size_t)x->n_levels * nb, hipMemcpyDeviceToHost, st));
             if (net.cfg.global) HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_g, net.global_out, sizeof(float) * (size_t)nb * G, hipMemcpyDeviceToHost, st));
@@ -855,7 +855,7 @@ static int extract_chunk_graphed(hfnet_extractor* x, int nb, bool pinned) {
     };
     if (!x->use_graph || eng.prof.enabled) return direct();
     if (net.join_pending) { HF_HIP(hipStreamWaitEvent(st, net.ev_join, 0)); net.join_pending = false; }   // (not capturable: recorded outside)
-    const int key = pinned ? -nb : nb;
+    const int key = nb;
     auto it = x->graphs.find(key);
     if (it == x->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -1031,7 +1031,7 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
                 if (row_stride == x->width) std::memcpy(dst, src, img_bytes);
                 else for (int y = 0; y < x->height; ++y) std::memcpy(dst + (size_t)y * x->width, src + (size_t)y * row_stride, (size_t)x->width);
             }
-            HF_TRY(extract_chunk_graphed(x, nb, true));
+            HF_TRY(extract_chunk_graphed(x, nb));
             HF_TRY(copy_chunk_to_store(x, f0, nb, x->d_desc, x->d_n, st));
             HF_HIP(hipStreamSynchronize(st));
             x->last_desc = x->d_desc; x->last_cnt = x->d_n;
