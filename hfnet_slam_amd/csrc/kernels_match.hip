@@ -615,10 +615,13 @@ size_t bow_scratch_bytes(int n_pairs, int max_rows) {
 hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, void* scratch, hipStream_t s) {
     if (n_pairs <= 0 || max_rows <= 0) return hipSuccess;
     if (dim % 64) return hipErrorInvalidValue;
-    // d2 ~ |q|^2 + |t|^2 - 2 q.t agrees with the exactly evaluated form up to +-band * (|q|^2 + |t|^2): the rounding of a
-    // dim-term dot / difference sum is below ~4 * dim * 2^-24 of the norms; band = 4e-6 * dim + 1e-4 (1.1e-3 for dim 256)
-    // keeps a > 15x margin
-    const float band = 4e-6f * (float)dim + 1e-4f;
+    // G = |q|^2 + |t|^2 - 2 q.t (norms and the MFMA chain in fp32) against the exactly evaluated form X (OpenCV's order): with
+    // u = 2^-24 and g = dim u (the bound of a dim-term fp32 sum),  |G - d^2| <= (2 g + 2 u)(|q|^2 + |t|^2)  (two norms, the dot
+    // product bounded by half the norms, two roundings) and  |X - d^2| <= g d^2 <= 2 g (|q|^2 + |t|^2):  together
+    // 4.1 dim u (|q|^2 + |t|^2) = 6.2e-5 for dim 256.  band = 5e-7 dim (1.28e-4 for dim 256) is twice that worst case; measured
+    // differences are two orders of magnitude smaller.  (Round 1 used 1.1e-3: every query within 8e-3 of a row's nearest was
+    // re-evaluated exactly -- three per train row on descriptors of one scene instead of one.)
+    const float band = 5e-7f * (float)dim;
     const int n_qt = (max_rows + 63) / 64;
     BowCand* cand = (BowCand*)scratch;
     unsigned char* overflow = (unsigned char*)scratch + (size_t)n_pairs * max_rows * n_qt * 2 * BOW_SLOTS * sizeof(BowCand);   // candidate counts per half tile

@@ -228,6 +228,33 @@ def test_matcher_duplicates_and_ties(engine):
     assert engine.descriptor_distance(x, y) == O.descriptor_distance(x, y)
 
 
+@pytest.mark.parametrize("seed,spread,scale", [(21, 3e-4, 1.0), (22, 3e-5, 1.0), (23, 2e-6, 1.0), (24, 1e-4, 7.5), (25, 1e-4, 0.05)])
+def test_matcher_near_ties_inside_the_rounding_band(engine, seed, spread, scale):
+    """Adversarial for the pre-selection of SearchByBoW: clusters of descriptors whose mutual distances differ by less than
+    the rounding band of the MFMA form of the distance (kernels_match.hip: band = 5e-7 * dim relative to |q|^2 + |t|^2), down to
+    differences of a few ulp, with non-unit norms as well -- the exact re-evaluation must still pick the oracle's match and
+    distance bit for bit."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    centres = _unit_rows(rng, 12)
+    q = np.repeat(centres, 40, axis=0) + spread * rng.standard_normal((480, 256)).astype(np.float32)
+    t = np.repeat(centres, 35, axis=0) + spread * rng.standard_normal((420, 256)).astype(np.float32)
+    q = (scale * q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    t = (scale * t / np.linalg.norm(t, axis=1, keepdims=True)).astype(np.float32)
+    t[7] = q[3]; t[100] = q[3]; q[200] = q[3]                       # exact duplicates on both sides
+    th = 0.6 * scale
+    n, m, d = engine.search_by_bow(q, t, th)
+    rn, rm, rd = O.search_by_bow(q, t, th)
+    assert n == rn
+    _eq("near-tie bow match", m, rm); _eq("near-tie bow dist", d, rd)
+    cnt, mb, db = engine.search_by_bow_batch(np.stack([q, np.pad(t, ((0, 60), (0, 0)))]), np.array([480, 420], np.int32),
+                                            [(0, 1), (1, 0)], th)
+    _eq("batched near-tie match", mb[0][:480], rm); _eq("batched near-tie dist", db[0][:480], rd)
+    rn2, rm2, rd2 = O.search_by_bow(t, q, th)
+    assert cnt[1] == rn2
+    _eq("batched reverse match", mb[1][:420], rm2); _eq("batched reverse dist", db[1][:420], rd2)
+
+
 def test_database(engine):
     from hfnet_slam_amd import capi
     from oracle import oracle as O
