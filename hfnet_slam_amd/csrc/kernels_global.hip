@@ -140,10 +140,10 @@ template <int N, class F>
 __device__ __forceinline__ void fc_static_for(F&& f) { fc_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 template <int NBUF>
-__global__ __launch_bounds__(128) void k_fc_mfma(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                  float* __restrict__ y, int frames, int n_in, int n_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ctiles = n_out >> 4, ct = blockIdx.x, rt = blockIdx.y * 2 + wave;
+    const int ctiles = n_out >> 4, ct = blockIdx.x, rt = blockIdx.y * 4 + wave;   // up to four row tiles share a weight panel through L1
     if (rt * 16 >= frames) return;
     const int row = min(rt * 16 + (lane & 15), frames - 1);
     const f32x4* __restrict__ ap = (const f32x4*)(x + (long long)row * n_in) + (lane >> 4);
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_l2norm_vec(const float* __restrict__ in
 hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* y_raw, float* out, int frames, hipStream_t s) {
     if (frames <= 0) return hipSuccess;
     if (fc.n_in % 16 || fc.n_out % 16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_fc_mfma<16>, dim3(fc.n_out / 16, (frames + 31) / 32), dim3(128), 0, s, x, fc.w, fc.bias, y_raw, frames, fc.n_in, fc.n_out);
+    hipLaunchKernelGGL(k_fc_mfma<16>, dim3(fc.n_out / 16, (frames + 63) / 64), dim3(frames > 32 ? 256 : 128), 0, s, x, fc.w, fc.bias, y_raw, frames, fc.n_in, fc.n_out);
     hipLaunchKernelGGL(k_l2norm_vec, dim3(frames), dim3(256), 0, s, y_raw, out, fc.n_out);
     return hipGetLastError();
 }
