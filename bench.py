@@ -360,7 +360,7 @@ def config_latency(capi, eng, n=60):
             "frames_per_s_unpipelined": 1e3 / med(t_dev[1:])}
 
 
-def config_host_io(capi, eng, chunk, chunks_per_call=4, reps=5):
+def config_host_io(capi, eng, chunk, chunks_per_call=8, reps=4):
     """the batch path with host buffers on both sides: images go up, keypoints + descriptors + global descriptors come
     down (what the reference's extraction time includes, HFNetRTModel.cc:128,134).  A call of several chunks runs as a
     double-buffered pipeline (pinned staging, copies overlap the compute).  The frame-to-frame match runs on device copies

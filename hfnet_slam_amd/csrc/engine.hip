@@ -880,13 +880,18 @@ static int extract_chunk_graphed(hfnet_extractor* x, int nb) {
 static int copy_chunk_to_store(hfnet_extractor* x, int first_frame, int nb, const float* d_desc, const int* d_n, hipStream_t st) {
     hfnet_store* s = x->att_store;
     if (!s) return HFNET_OK;
-    for (int f = 0; f < nb; ++f) {
+    const int rows = std::min(x->n_features, s->max_rows);
+    // consecutive frames go to consecutive slots (modulo the store size): when a store row block is exactly a frame's
+    // descriptor block, a run of frames is ONE copy (64 frames per chunk: 3 calls instead of 192 on the compute stream)
+    const bool same_shape = s->max_rows == x->n_features && s->dim == HFNET_DESC_DIM;
+    for (int f = 0; f < nb;) {
         const int slot = (x->att_first + first_frame + f) % s->n_sets;
-        const int rows = std::min(x->n_features, s->max_rows);
+        const int run = same_shape ? std::min(nb - f, s->n_sets - slot) : 1;
         HF_HIP(hipMemcpyAsync(s->d_desc + (size_t)slot * s->max_rows * s->dim, d_desc + (size_t)f * x->n_features * HFNET_DESC_DIM,
-                              sizeof(float) * (size_t)rows * s->dim, hipMemcpyDeviceToDevice, st));
-        HF_HIP(hipMemcpyAsync(s->d_rows + slot, d_n + f, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-        HF_HIP(hipMemsetAsync(s->d_flags + (size_t)slot * s->max_rows, 0, (size_t)s->max_rows, st));
+                              sizeof(float) * (size_t)(same_shape ? run * s->max_rows : rows) * s->dim, hipMemcpyDeviceToDevice, st));
+        HF_HIP(hipMemcpyAsync(s->d_rows + slot, d_n + f, sizeof(int32_t) * run, hipMemcpyDeviceToDevice, st));
+        HF_HIP(hipMemsetAsync(s->d_flags + (size_t)slot * s->max_rows, 0, (size_t)s->max_rows * run, st));
+        f += run;
     }
     return HFNET_OK;
 }
@@ -920,6 +925,10 @@ static int host_pipe_init(hfnet_extractor* x) {
     HF_TRY(dalloc(x->allocs, &p.d_nl[1], B * x->n_levels));
     HF_HIP(hipStreamCreateWithFlags(&p.s_up, hipStreamNonBlocking));
     HF_HIP(hipStreamCreateWithFlags(&p.s_down, hipStreamNonBlocking));
+    {
+        const unsigned hc = std::thread::hardware_concurrency();
+        p.pool.reset(new hfnet::CopyPool(hc >= 8 ? 3 : hc >= 4 ? 1 : 0));
+    }
     p.ready = true;
     return HFNET_OK;
 }
@@ -940,16 +949,17 @@ static int extract_host_pipelined(hfnet_extractor* x, int f0, int n_frames, cons
         HF_HIP(hipEventSynchronize(p.ev_down[s]));
         const unsigned char* h = p.h_out[s];
         const int* hn = (const int*)(h + p.o_n);
-        for (int f = 0; f < nb; ++f) {
+        p.pool->run(nb, [&](int f) {
             const int n = hn[f];
             n_out[c0 + f] = n;
             if (global_desc) std::memcpy(global_desc + (size_t)(c0 + f) * G, h + p.o_g + sizeof(float) * (size_t)f * G, sizeof(float) * G);
-            if (x->att_store) x->att_store->rows[(x->att_first + c0 + f) % x->att_store->n_sets] = std::min(n, x->att_store->max_rows);
-            if (n <= 0) continue;
+            if (n <= 0) return;
             std::memcpy(kps + (size_t)(c0 + f) * NF, h + p.o_k + sizeof(hfnet_keypoint) * (size_t)f * NF, sizeof(hfnet_keypoint) * n);
             std::memcpy(local_desc + (size_t)(c0 + f) * NF * HFNET_DESC_DIM, h + p.o_d + sizeof(float) * HFNET_DESC_DIM * (size_t)f * NF,
                         sizeof(float) * HFNET_DESC_DIM * n);
-        }
+        });
+        if (x->att_store)
+            for (int f = 0; f < nb; ++f) x->att_store->rows[(x->att_first + c0 + f) % x->att_store->n_sets] = std::min(hn[f], x->att_store->max_rows);
         if (c == n_chunks - 1) {                      // what hfnet_store_put_extracted / n_per_level see: the last chunk
             std::fill(x->last_n.begin(), x->last_n.end(), -1);
             for (int f = 0; f < nb; ++f) x->last_n[f] = hn[f];
@@ -962,12 +972,12 @@ static int extract_host_pipelined(hfnet_extractor* x, int f0, int n_frames, cons
     for (int c = 0; c < n_chunks; ++c) {
         const int s = c & 1, c0 = f0 + c * x->max_batch, nb = std::min(x->max_batch, n_frames - c0);
         // (slot s is free: chunk c - 2 was drained -- its download, hence its compute and upload, are complete)
-        for (int f = 0; f < nb; ++f) {
+        p.pool->run(nb, [&](int f) {
             const uint8_t* src = images + (size_t)(c0 + f) * frame_stride;
             unsigned char* dst = p.h_in[s] + (size_t)f * img;
             if (row_stride == x->width) std::memcpy(dst, src, img);
             else for (int y = 0; y < x->height; ++y) std::memcpy(dst + (size_t)y * x->width, src + (size_t)y * row_stride, (size_t)x->width);
-        }
+        });
         HF_HIP(hipMemcpyAsync(p.d_in[s], p.h_in[s], img * nb, hipMemcpyHostToDevice, p.s_up));
         HF_HIP(hipEventRecord(p.ev_up[s], p.s_up));
         HF_HIP(hipStreamWaitEvent(st, p.ev_up[s], 0));

@@ -2,10 +2,68 @@
 #pragma once
 #include "kernels.hpp"
 
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <memory>
+#include <thread>
 
 namespace hfnet {
+
+// A few helper threads for the pageable <-> pinned copies of the host-pointer batch pipeline (one memcpy thread moves
+// ~7 GB/s; a 64-frame call stages 23 MB in and 67 MB out, as long as the GPU needs to compute it).  run(n, fn) calls
+// fn(0..n-1) on the helpers and the caller and returns when all are done.
+class CopyPool {
+public:
+    explicit CopyPool(int helpers) {
+        for (int i = 0; i < helpers; ++i) th_.emplace_back([this] { worker(); });
+    }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void run(int n, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        if (th_.empty() || n == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+        { std::lock_guard<std::mutex> lk(m_); fn_ = &fn; n_ = n; next_.store(0); pending_.store(n); ++gen_; }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_.load() == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void drain() {
+        for (;;) {
+            const int i = next_.fetch_add(1);
+            if (i >= n_) return;
+            (*fn_)(i);
+            if (pending_.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(m_); done_.notify_all(); }
+        }
+    }
+    void worker() {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+            }
+            drain();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int n_ = 0;
+    std::atomic<int> next_{0}, pending_{0};
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
+};
 
 struct DevMem {
     void* p = nullptr;
@@ -186,6 +244,7 @@ struct hfnet_extractor {
         int* d_nl[2] = {nullptr, nullptr};
         hipStream_t s_up = nullptr, s_down = nullptr;
         hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
+        std::unique_ptr<hfnet::CopyPool> pool;                       // helpers for the staging copies
     } pipe;
     const float* last_desc = nullptr;    // device descriptors / counts of the last host-pointer chunk (hfnet_store_put_extracted)
     const int* last_cnt = nullptr;
