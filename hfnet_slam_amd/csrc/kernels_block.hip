@@ -579,31 +579,42 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void k_block_fused4(FusedArgs a, G
         // ---- depthwise: channel r, output rows 2 rh and 2 rh + 1 (input rows 2 rh s .. 2 rh s + s + 2)
         {
             constexpr int NR = STRIDE + 3;                         // input rows for two output rows
-            float row[NR][IW];
+            // input rows one at a time: row i feeds output row ro with ky = i - ro * STRIDE, so every output still adds its
+            // taps in (ky, kx) order while only ONE row of the channel is held in registers besides the 2 x TW accumulators
+            // (all NR rows at once cost 40 / 85 VGPRs more and one occupancy step on the narrow kernels)
             const float* rp = ET + r * EP + rh * 2 * STRIDE * IW;
-            if constexpr ((NR * IW) % 4 == 0 && (2 * STRIDE * IW) % 4 == 0) {
-#pragma unroll
-                for (int qx = 0; qx < NR * IW / 4; ++qx) {
-                    const f32x4 v = *(const f32x4*)(rp + qx * 4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) row[(qx * 4 + j) / IW][(qx * 4 + j) % IW] = v[j];
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NR * IW; ++i) row[i / IW][i % IW] = rp[i];
-            }
             float o[2][TW];
 #pragma unroll
             for (int ro = 0; ro < 2; ++ro)
 #pragma unroll
-                for (int ox = 0; ox < TW; ++ox) {
-                    float acc = dwb;
+                for (int ox = 0; ox < TW; ++ox) o[ro][ox] = dwb;
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
+            for (int i = 0; i < NR; ++i) {
+                float row[IW];
+                if constexpr (IW % 2 == 0 && (2 * STRIDE * IW) % 2 == 0) {
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) acc = fmaf(row[ro * STRIDE + ky][ox * STRIDE + kx], dwt[ky * 3 + kx], acc);
-                    o[ro][ox] = relu6f(acc);
+                    for (int x2 = 0; x2 < IW / 2; ++x2) {
+                        const float2 v = *(const float2*)(rp + i * IW + x2 * 2);
+                        row[2 * x2] = v.x; row[2 * x2 + 1] = v.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int x = 0; x < IW; ++x) row[x] = rp[i * IW + x];
                 }
+#pragma unroll
+                for (int ro = 0; ro < 2; ++ro) {
+                    const int ky = i - ro * STRIDE;
+                    if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                    for (int ox = 0; ox < TW; ++ox)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) o[ro][ox] = fmaf(row[ox * STRIDE + kx], dwt[ky * 3 + kx], o[ro][ox]);
+                }
+            }
+#pragma unroll
+            for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+                for (int ox = 0; ox < TW; ++ox) o[ro][ox] = relu6f(o[ro][ox]);
             asm volatile("" ::: "memory");                         // every ET read is issued before D overwrites the slice
 #pragma unroll
             for (int ro = 0; ro < 2; ++ro)
@@ -1022,7 +1033,7 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
             return hipGetLastError();
         }
         case FUSED_V4:
-            if (st == 1 && kq == 3 && nto == 1) return launch_block_fused4_t<1, 1, 3, 2>(a, g, s);
+            if (st == 1 && kq == 3 && nto == 1) return launch_block_fused4_t<1, 1, 3, 4>(a, g, s);
             if (st == 1 && kq == 3 && nto == 2) return launch_block_fused4_t<1, 2, 3, 2>(a, g, s);
             if (st == 1 && kq == 6 && nto == 2) return launch_block_fused4_t<1, 2, 6, 2>(a, g, s);
             if (st == 1 && kq == 6 && nto == 3) return launch_block_fused4_t<1, 3, 6, 2>(a, g, s);
