@@ -27,7 +27,9 @@ public:
     void run(int n, const std::function<void(int)>& fn) {
         if (n <= 0) return;
         if (th_.empty() || n == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
-        { std::lock_guard<std::mutex> lk(m_); fn_ = &fn; n_ = n; next_.store(0); pending_.store(n); ++gen_; }
+        // next_ is the publication point: a helper that is still leaving the previous run may win an index of this one the
+        // moment next_ is reset, so everything it then reads (fn_, n_, pending_) is written before that store
+        { std::lock_guard<std::mutex> lk(m_); fn_ = &fn; n_ = n; pending_.store(n); next_.store(0); ++gen_; }
         cv_.notify_all();
         drain();
         std::unique_lock<std::mutex> lk(m_);
