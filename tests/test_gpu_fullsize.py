@@ -68,6 +68,24 @@ def test_bench_sized_call_vs_oracle(engine, oracle_model):
     x.close()
 
 
+@pytest.mark.parametrize("size", [(752, 480), (640, 360)])
+def test_mid_sized_call_every_frame_vs_oracle(engine, oracle_model, size):
+    """9 frames per call: enough 128-row tiles for the heads to take four column tiles per wave (the LDS-weight kernels), few
+    enough to compare EVERY frame with the oracle; the second size has level widths that are not multiples of 8 (ragged
+    tiles in every kernel)."""
+    from hfnet_slam_amd import capi
+    w, h = size
+    nf, B = 1000, 9
+    x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, 4, max_batch=B)
+    imgs = np.stack([synth_image(h, w, 4000 + i, "natural" if i % 2 else "uniform") for i in range(B)])
+    nb, kb, db, gb = x.extract_batch(imgs)
+    for i in range(B):
+        rn, rk, rd, rg, _ = oracle_model.extract(imgs[i], nf, 0.01, 4, 1.2)
+        assert nb[i] == rn, i
+        assert np.array_equal(kb[i, :rn], rk) and np.array_equal(db[i, :rn], rd) and np.array_equal(gb[i], rg), i
+    x.close()
+
+
 def test_monocular_initialisation_extractor_5x_features(engine, oracle_model):
     """Tracking.cc:693 builds the initialisation extractor with 5 * nFeatures on the same models; with the 8-level pyramid
     of the monocular yaml files the small levels run out of candidates before their budget is met."""
