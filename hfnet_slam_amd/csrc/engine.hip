@@ -1239,8 +1239,13 @@ int hfnet_store_create(hfnet_engine* eh, int n_sets, int max_rows, int dim, hfne
     HF_HIP(hipMalloc((void**)&st->d_desc, sizeof(float) * (size_t)n_sets * max_rows * dim));
     if (hipMalloc((void**)&st->d_rows, sizeof(int32_t) * n_sets) != hipSuccess) { (void)hipFree(st->d_desc); set_error("store: out of device memory"); return HFNET_ERR_DEVICE; }
     if (hipMalloc((void**)&st->d_flags, (size_t)n_sets * max_rows) != hipSuccess) { (void)hipFree(st->d_desc); (void)hipFree(st->d_rows); set_error("store: out of device memory"); return HFNET_ERR_DEVICE; }
-    HF_HIP(hipMemset(st->d_rows, 0, sizeof(int32_t) * n_sets));
-    HF_HIP(hipMemset(st->d_flags, 0, (size_t)n_sets * max_rows));
+    {   // on the engine's (non-blocking) stream, which every later put / match uses: see hfnet_db_create
+        Engine& e = eh->impl;
+        std::lock_guard<std::mutex> lk(e.mu);
+        HF_HIP(hipMemsetAsync(st->d_rows, 0, sizeof(int32_t) * n_sets, e.stream));
+        HF_HIP(hipMemsetAsync(st->d_flags, 0, (size_t)n_sets * max_rows, e.stream));
+        HF_HIP(hipStreamSynchronize(e.stream));
+    }
     *out = st.release();
     return HFNET_OK;
 }
@@ -1539,14 +1544,21 @@ int hfnet_db_create(hfnet_engine* eh, int capacity, int dim, hfnet_db** out) {
     HF_HIP(hipMalloc((void**)&db->d_occ, (size_t)capacity));
     HF_HIP(hipMalloc((void**)&db->d_q, sizeof(float) * dim));
     HF_HIP(hipMalloc((void**)&db->d_norm, sizeof(float) * capacity));
-    HF_HIP(hipMemset(db->d_norm, 0, sizeof(float) * capacity));
     HF_HIP(hipMalloc((void**)&db->d_scores, sizeof(float) * capacity));
     HF_HIP(hipMalloc((void**)&db->d_cand_score, sizeof(float) * capacity));
     HF_HIP(hipMalloc((void**)&db->d_cand_slot, sizeof(int32_t) * capacity));
     HF_HIP(hipMalloc((void**)&db->d_best, sizeof(float)));
     HF_HIP(hipMalloc((void**)&db->d_n, sizeof(int)));
     HF_HIP(hipMalloc((void**)&db->d_best_bits, sizeof(unsigned int) * 4 * (size_t)db_scan_workgroups(capacity)));   // per-wave partial maxima
-    HF_HIP(hipMemset(db->d_occ, 0, (size_t)capacity));
+    {
+        // on the stream the adds and scans use: it is non-blocking, i.e. NOT ordered with the null stream, and a hipMemset there
+        // is not host-synchronous -- it could land after the first hfnet_db_add had set its occupancy byte
+        Engine& e = eh->impl;
+        std::lock_guard<std::mutex> lk(e.mu);
+        HF_HIP(hipMemsetAsync(db->d_occ, 0, (size_t)capacity, e.stream));
+        HF_HIP(hipMemsetAsync(db->d_norm, 0, sizeof(float) * capacity, e.stream));
+        HF_HIP(hipStreamSynchronize(e.stream));
+    }
     *out = db.release();
     return HFNET_OK;
 }
