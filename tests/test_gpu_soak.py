@@ -1,0 +1,21 @@
+"""A short run of the randomised soak (tools/dev/soak.py): random extractor geometries / budgets / call sizes / engine
+options, single-frame graph calls, both matchers, the descriptor store with row filters and the database scans, all
+bit-exact against the oracle (the batched database query against its own oracle function).  Longer runs:
+`python tools/dev/soak.py 600 <seed>` on the GPU box (rounds of ~7000 cases; this is how the null-stream race of
+hfnet_db_create / hfnet_store_create was found)."""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_randomised_soak_20s():
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dev", "soak.py")
+    spec = importlib.util.spec_from_file_location("hfnet_soak", path)
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    cases, fails = soak.run(20.0, 20260928)
+    assert cases >= 20, cases
+    assert not fails, fails[:10]
