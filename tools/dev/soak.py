@@ -111,7 +111,46 @@ def run(budget_s: float, seed: int):
                             fails.append(("store", mr, S, pairs[pi], f1, f2, na, len(sets[b])))
                             break
                     store.close()
-                elif kind < 0.85:
+                elif kind < 0.77:
+                    # BaseModel mirror: the three Detect overloads
+                    h, w = 8 * int(rng.integers(5, 40)), 8 * int(rng.integers(5, 50))
+                    nk = int(rng.integers(1, 800)); thr = float(rng.choice([0.0, 0.01]))
+                    mode = int(rng.choice([capi.MODE_LOCAL_AND_GLOBAL, capi.MODE_LOCAL, capi.MODE_LOCAL_AND_INTERMEDIATE]))
+                    m = capi.Model(eng, mode, h, w, max_keypoints=nk)
+                    img = synth_image(h, w, int(rng.integers(1 << 30)), "natural" if rng.random() < 0.5 else "uniform")
+                    st, k, d, aux = m.detect(img, nk, thr)
+                    ok, rk, rd, raux = model.detect(img, mode, nk, thr)
+                    bad = (st == 0) != ok or not np.array_equal(k, rk) or not np.array_equal(d, rd) or (raux is not None and not np.array_equal(aux, raux))
+                    if not bad and mode == capi.MODE_LOCAL_AND_INTERMEDIATE:
+                        m2 = capi.Model(eng, capi.MODE_INTERMEDIATE_TO_GLOBAL, h // 8, w // 8)
+                        st2, g = m2.detect_global(aux)
+                        ok2, rg = model.detect_global(raux)
+                        bad = (st2 == 0) != ok2 or not np.array_equal(g, rg)
+                        m2.close()
+                    m.close()
+                    if bad:
+                        fails.append(("model", mode, h, w, nk, thr, opts))
+                elif kind < 0.81:
+                    # candidate loop of the windowed matchers + distinctive descriptors
+                    nq, nt = int(rng.integers(1, 600)), int(rng.integers(1, 900))
+                    t = unit(nt)
+                    q = t[rng.integers(0, nt, nq)] + float(rng.choice([0.0, 0.05])) * rng.standard_normal((nq, 256)).astype(np.float32)
+                    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+                    lv = rng.integers(0, 4, nt).astype(np.int32)
+                    lens = rng.integers(0, min(nt, 50) + 1, nq)
+                    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+                    idx = (np.concatenate([rng.choice(nt, l, replace=False) for l in lens]) if lens.sum() else np.zeros(0)).astype(np.int32)
+                    lvl = lv if rng.random() < 0.7 else None
+                    got = eng.match_candidates(q, t, lvl, off, idx)
+                    ref = O.match_candidates(q, t, lvl, off, idx)
+                    if any(not np.array_equal(a, b) for a, b in zip(got, ref)):
+                        fails.append(("candidates", nq, nt))
+                    sizes = rng.integers(0, 97, int(rng.integers(1, 120)))
+                    soff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+                    desc = unit(max(int(sizes.sum()), 1))[:int(sizes.sum())]
+                    if len(desc) and not np.array_equal(eng.distinctive_descriptors(desc, soff), O.distinctive_descriptors(desc, soff)):
+                        fails.append(("distinctive", len(sizes)))
+                elif kind < 0.88:
                     n1, n2 = int(rng.integers(0, 1300)), int(rng.integers(0, 1300))
                     a = unit(max(n1, 1))[:n1]
                     if n1 and n2 and rng.random() < 0.7:
@@ -136,19 +175,23 @@ def run(budget_s: float, seed: int):
                     db = capi.Database(eng, n + 5, dim)
                     for i in range(n):
                         db.add(i, rows[i])
+                    holes = [int(i) for i in rng.choice(n, int(rng.integers(0, max(n // 8, 1))), replace=False)] if n > 4 and rng.random() < 0.5 else []
+                    for i in holes:
+                        db.erase(i)
+                    keep = np.ones(n, bool); keep[holes] = False
                     nq = int(rng.choice([1, 3, 8, 20, 64]))
                     qs = rows[rng.integers(0, n, nq)] + float(rng.choice([0.0, 0.003, 0.02])) * rng.standard_normal((nq, dim)).astype(np.float32)
                     qs = (qs / np.linalg.norm(qs, axis=1, keepdims=True)).astype(np.float32)
                     mode = int(rng.integers(0, 2))
                     if nq == 1:
                         slots, sc, best, allsc = db.query(qs[0], mode, want_scores=True)
-                        ref = O.db_scores(qs[0], rows)
-                        ridx, rbest = O.db_candidates(ref, mode)
+                        ref = O.db_scores(qs[0], rows); ref[~keep] = -1         # (documented: -1 for empty slots)
+                        ridx, rbest = O.db_candidates(ref, mode); ridx = ridx[keep[ridx]]
                         if not np.array_equal(allsc[:n], ref) or best != rbest or not np.array_equal(np.sort(slots), np.sort(ridx)):
                             fails.append(("db_q1", n, mode))
                     else:
                         res, best, allsc = db.query_batch(qs, mode, want_scores=True)
-                        ref = O.db_scores_gemm(qs, rows) if nq >= 8 else np.stack([O.db_scores(q, rows) for q in qs])
+                        ref = O.db_scores_gemm(qs, rows) if nq >= 8 else np.stack([O.db_scores(q, rows) for q in qs]); ref[:, ~keep] = -1
                         if not np.array_equal(allsc[:, :n], ref):
                             fails.append(("db_batch", n, nq, mode))
                     db.close()
