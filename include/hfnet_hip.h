@@ -90,7 +90,10 @@ int hfnet_engine_synchronize(hfnet_engine* e);
  *  - matcher calls with on_device != 0 run after every on_device extraction enqueued before them
  *    (their inputs are the extractor's outputs);
  *  - hfnet_engine_fence: on_device extraction enqueued AFTER this call runs after all matcher work
- *    enqueued BEFORE it -- call it before re-using descriptor buffers a pending match still reads. */
+ *    enqueued BEFORE it -- call it before re-using descriptor buffers a pending match still reads;
+ *  - the library's streams are NOT ordered with the caller's: whatever the caller writes on the device (images, pair
+ *    lists, row counts it produces itself) must be complete before the call, and results are final only after
+ *    hfnet_engine_synchronize. */
 int hfnet_engine_fence(hfnet_engine* e);
 
 /* ---- BaseModel (include/Extractors/BaseModel.h:38-54; ctor HFNetTFModelV2.cc:12-60) ----------- */
