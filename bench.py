@@ -289,6 +289,7 @@ class Pipeline:
         if (s0, n) not in self._pairs:
             t = self.torch.arange(s0, s0 + n, dtype=self.torch.int32, device=self.dev)
             q = ((t.to(self.torch.int64) - 1) % (self.n_buf * self.B)).to(self.torch.int32)
+            self.torch.cuda.synchronize()                 # (torch's stream is not ordered with the library's: finish the lists first)
             self._pairs[(s0, n)] = (q, t, n)
         return self._pairs[(s0, n)]
 

@@ -11,11 +11,24 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _load(name):
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dev", name + ".py")
+    spec = importlib.util.spec_from_file_location("hfnet_" + name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def test_randomised_soak_20s():
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dev", "soak.py")
-    spec = importlib.util.spec_from_file_location("hfnet_soak", path)
-    soak = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(soak)
-    cases, fails = soak.run(20.0, 20260928)
+    cases, fails = _load("soak").run(20.0, 20260928)
     assert cases >= 20, cases
+    assert not fails, fails[:10]
+
+
+def test_device_pipeline_soak_12s():
+    """device-resident calls enqueued back to back without host synchronisation (random call sizes spanning several
+    chunks, pairs across call boundaries, random stream options): extraction, global descriptors and matches == oracle"""
+    pytest.importorskip("torch")
+    rounds, fails = _load("soak_pipeline").run(12.0, 20260929)
+    assert rounds >= 3, rounds
     assert not fails, fails[:10]
