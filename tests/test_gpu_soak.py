@@ -19,13 +19,13 @@ def _load(name):
     return mod
 
 
-def test_randomised_soak_20s():
+def test_randomised_soak_20s(engine):           # (the fixture initialises torch's HIP runtime before the library's: conftest.py)
     cases, fails = _load("soak").run(20.0, 20260928)
     assert cases >= 20, cases
     assert not fails, fails[:10]
 
 
-def test_device_pipeline_soak_12s():
+def test_device_pipeline_soak_12s(engine):
     """device-resident calls enqueued back to back without host synchronisation (random call sizes spanning several
     chunks, pairs across call boundaries, random stream options): extraction, global descriptors and matches == oracle"""
     pytest.importorskip("torch")
