@@ -32,3 +32,11 @@ def test_device_pipeline_soak_12s(engine):
     rounds, fails = _load("soak_pipeline").run(12.0, 20260929)
     assert rounds >= 3, rounds
     assert not fails, fails[:10]
+
+
+def test_three_host_threads_on_one_engine_10s(engine):
+    """Tracking (extractor + frame-to-frame match), LocalMapping (triangulation matches on the keyframe store) and
+    LoopClosing (database add / erase / query) as three host threads on ONE engine, every result against the oracle"""
+    counts, fails = _load("soak_threads").run(10.0, 20260930)
+    assert min(counts.values()) >= 5, counts
+    assert not fails, fails[:10]
