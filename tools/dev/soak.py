@@ -11,8 +11,8 @@ from conftest import synth_image
 
 
 
-def run(budget_s: float, seed: int):
-    """-> (cases, failures)"""
+def run(budget_s: float, seed: int, big_share: float = 0.02):
+    """-> (cases, failures); big_share: fraction of full-size multi-frame cases"""
     rng = np.random.default_rng(seed)
     wpath = os.path.join(tempfile.gettempdir(), f"hfnet_soak_{seed}.hfw")
     weights.save(wpath, weights.synthetic_weights(100 + seed))
@@ -40,7 +40,21 @@ def run(budget_s: float, seed: int):
             kind = rng.random()
             cases += 1
             try:
-                if kind < 0.5:
+                if kind < big_share:
+                    # full-size frames at a random call size: the kernel choices (column tiles per wave, LDS-weight kernels,
+                    # slot skipping, low-latency 1x1) switch with the number of tiles of a call
+                    w, h = (752, 480) if rng.random() < 0.6 else (512, 512)
+                    nf = int(rng.choice([1000, 850, 300])); B = int(rng.integers(1, 41))
+                    x = capi.Extractor(eng, w, h, nf, 0.01, 1.2, 4, max_batch=int(rng.choice([B, 8, 32])))
+                    imgs = np.stack([synth_image(h, w, int(rng.integers(1 << 30)), "natural" if rng.random() < 0.5 else "uniform") for _ in range(B)])
+                    nb, kb, db_, gb = x.extract_batch(imgs)
+                    for i in sorted(set(int(v) for v in rng.integers(0, B, 2))):
+                        rn, rk, rd, rg, _ = model.extract(imgs[i], nf, 0.01, 4, 1.2)
+                        if not (nb[i] == rn and np.array_equal(kb[i, :rn], rk) and np.array_equal(db_[i, :rn], rd) and np.array_equal(gb[i], rg)):
+                            fails.append(("extract_full", w, h, nf, B, i, opts))
+                            break
+                    x.close()
+                elif kind < 0.5:
                     w, h = int(rng.integers(40, 420)), int(rng.integers(40, 340))
                     nl = int(rng.integers(1, 6)); nf = int(rng.integers(8, 1500)); thr = float(rng.choice([0.0, 0.002, 0.01, 0.02]))
                     sf = float(rng.choice([1.2, 1.1, 1.5]))
@@ -202,7 +216,8 @@ def run(budget_s: float, seed: int):
 
 
 if __name__ == "__main__":
-    cases, fails = run(float(sys.argv[1]) if len(sys.argv) > 1 else 600.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    cases, fails = run(float(sys.argv[1]) if len(sys.argv) > 1 else 600.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+                       float(sys.argv[3]) if len(sys.argv) > 3 else 0.02)
     print(f"soak: {cases} cases, {len(fails)} failures")
     for f in fails[:20]:
         print("FAIL", f)
