@@ -360,7 +360,7 @@ int Net::forward_global(hipStream_t st) {
     HF_LAUNCH(e, st, "pointwise_memberships", launch_pointwise(act[18], w.memb, nullptr, memb, (long long)cfg.batch * P, 0, st));
     HF_LAUNCH(e, st, "softmax_memberships", launch_softmax_rows(memb, (long long)cfg.batch * P, w.n_clusters, w.n_clusters, st));
     HF_LAUNCH(e, st, "vlad", launch_vlad(act[18], memb, w.clusters, vlad_tap, vlad_out, vlad_raw, cfg.batch, P, w.c_global, w.n_clusters, st));
-    HF_LAUNCH(e, st, "fc_l2", launch_fc_l2(vlad_out, w.fc, fc_raw, global_out, cfg.batch, st));
+    HF_LAUNCH(e, st, "fc_l2", launch_fc_l2(vlad_out, w.fc, fc_raw, global_dst ? global_dst : global_out, cfg.batch, st));
     return HFNET_OK;
 }
 
@@ -752,11 +752,10 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
         if (pf > 0) {
             auto up = [](size_t b) { return (b + 255) / 256 * 256; };
             size_t off = up((size_t)pf * width * height);
-            x->pin_n = off; off += up(sizeof(int) * pf);
-            x->pin_nl = off; off += up(sizeof(int) * (size_t)pf * n_levels);
-            x->pin_g = off; off += up(sizeof(float) * (size_t)pf * e->impl.w.global_dim);
-            x->pin_k = off; off += up(sizeof(hfnet_keypoint) * (size_t)pf * n_features);
-            x->pin_d = off; off += up(sizeof(float) * HFNET_DESC_DIM * (size_t)pf * n_features);
+            x->pin_res = off;
+            const size_t res_bytes = x->result_offsets(pf, e->impl.w.global_dim).total;
+            off += res_bytes;
+            HF_TRY(dalloc(x->allocs, &x->d_blk, res_bytes));
             void* hp = nullptr;
             if (hipHostMalloc(&hp, off, hipHostMallocDefault) == hipSuccess) { x->h_pin = (unsigned char*)hp; x->pinned_frames = pf; }
             else (void)hipGetLastError();
@@ -843,14 +842,14 @@ static int extract_chunk_graphed(hfnet_extractor* x, int nb) {
     auto direct = [&]() -> int {
         const size_t img_bytes = (size_t)x->width * x->height;
         HF_HIP(hipMemcpyAsync(x->d_pyr[0], x->h_pin, img_bytes * nb, hipMemcpyHostToDevice, st));
-        HF_TRY(extract_chunk(x, nb, x->d_pyr[0], x->width, (long long)img_bytes, x->d_kps, x->d_desc, nullptr, x->d_n, x->d_n_level));
-        {                                                          // results of the whole chunk at full capacity: sizes are static
-            HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_n, x->d_n, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
-            HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_nl, x->d_n_level, sizeof(int) * (size_t)x->n_levels * nb, hipMemcpyDeviceToHost, st));
-            if (net.cfg.global) HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_g, net.global_out, sizeof(float) * (size_t)nb * G, hipMemcpyDeviceToHost, st));
-            HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_k, x->d_kps, sizeof(hfnet_keypoint) * (size_t)nb * x->n_features, hipMemcpyDeviceToHost, st));
-            HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_d, x->d_desc, sizeof(float) * HFNET_DESC_DIM * (size_t)nb * x->n_features, hipMemcpyDeviceToHost, st));
-        }
+        // results of the whole chunk at full capacity (sizes are static) into ONE device block laid out like the pinned one
+        const hfnet_extractor::ResOff o = x->result_offsets(nb, G);
+        net.global_dst = net.cfg.global ? (float*)(x->d_blk + o.g) : nullptr;
+        const int rc = extract_chunk(x, nb, x->d_pyr[0], x->width, (long long)img_bytes, (hfnet_keypoint*)(x->d_blk + o.k), (float*)(x->d_blk + o.d), nullptr,
+                                     (int*)(x->d_blk + o.n), (int*)(x->d_blk + o.nl));
+        net.global_dst = nullptr;
+        HF_TRY(rc);
+        HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_res, x->d_blk, o.total, hipMemcpyDeviceToHost, st));
         return HFNET_OK;
     };
     if (!x->use_graph || eng.prof.enabled) return direct();
@@ -964,7 +963,10 @@ static int extract_host_pipelined(hfnet_extractor* x, int f0, int n_frames, cons
             std::fill(x->last_n.begin(), x->last_n.end(), -1);
             for (int f = 0; f < nb; ++f) x->last_n[f] = hn[f];
             x->last_desc = p.d_desc[s]; x->last_cnt = p.d_n[s];
-            if (x->h_pin && x->pinned_frames >= 1) std::memcpy(x->h_pin + x->pin_nl, h + p.o_nl, sizeof(int) * x->n_levels);
+            if (x->h_pin && x->pinned_frames >= 1) {
+                x->pin_nl_last = x->pin_res + x->result_offsets(1, (int)G).nl;
+                std::memcpy(x->h_pin + x->pin_nl_last, h + p.o_nl, sizeof(int) * x->n_levels);
+            }
             else HF_HIP(hipMemcpy(x->d_n_level, p.d_nl[s], sizeof(int) * x->n_levels, hipMemcpyDeviceToDevice));
         }
         return HFNET_OK;
@@ -1042,20 +1044,25 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
                 else for (int y = 0; y < x->height; ++y) std::memcpy(dst + (size_t)y * x->width, src + (size_t)y * row_stride, (size_t)x->width);
             }
             HF_TRY(extract_chunk_graphed(x, nb));
-            HF_TRY(copy_chunk_to_store(x, f0, nb, x->d_desc, x->d_n, st));
+            const hfnet_extractor::ResOff o = x->result_offsets(nb, G);
+            const float* blk_desc = (const float*)(x->d_blk + o.d);
+            const int* blk_n = (const int*)(x->d_blk + o.n);
+            HF_TRY(copy_chunk_to_store(x, f0, nb, blk_desc, blk_n, st));
             HF_HIP(hipStreamSynchronize(st));
-            x->last_desc = x->d_desc; x->last_cnt = x->d_n;
-            const int* hn = (const int*)(x->h_pin + x->pin_n);
+            x->last_desc = blk_desc; x->last_cnt = blk_n;
+            const unsigned char* res = x->h_pin + x->pin_res;
+            x->pin_nl_last = x->pin_res + o.nl;
+            const int* hn = (const int*)(res + o.n);
             for (int f = 0; f < nb; ++f) {
                 const int n = hn[f];
                 n_out[f0 + f] = n;
                 x->last_n[f] = n;
                 if (x->att_store) x->att_store->rows[(x->att_first + f0 + f) % x->att_store->n_sets] = std::min(n, x->att_store->max_rows);
-                if (global_desc) std::memcpy(global_desc + (size_t)(f0 + f) * G, x->h_pin + x->pin_g + sizeof(float) * (size_t)f * G, sizeof(float) * G);
+                if (global_desc) std::memcpy(global_desc + (size_t)(f0 + f) * G, res + o.g + sizeof(float) * (size_t)f * G, sizeof(float) * G);
                 if (n <= 0) continue;
-                std::memcpy(kps + (size_t)(f0 + f) * x->n_features, x->h_pin + x->pin_k + sizeof(hfnet_keypoint) * (size_t)f * x->n_features, sizeof(hfnet_keypoint) * n);
+                std::memcpy(kps + (size_t)(f0 + f) * x->n_features, res + o.k + sizeof(hfnet_keypoint) * (size_t)f * x->n_features, sizeof(hfnet_keypoint) * n);
                 std::memcpy(local_desc + (size_t)(f0 + f) * x->n_features * HFNET_DESC_DIM,
-                            x->h_pin + x->pin_d + sizeof(float) * HFNET_DESC_DIM * (size_t)f * x->n_features, sizeof(float) * HFNET_DESC_DIM * n);
+                            res + o.d + sizeof(float) * HFNET_DESC_DIM * (size_t)f * x->n_features, sizeof(float) * HFNET_DESC_DIM * n);
             }
         } else {
             // everything that is left, as a double-buffered pipeline over its chunks
@@ -1077,7 +1084,7 @@ int hfnet_extractor_extract(hfnet_extractor* x, const uint8_t* image, int row_st
     *n_out = n;
     if (n_per_level) {
         std::lock_guard<std::mutex> lk(x->mu);
-        if (x->h_pin && x->pinned_frames >= 1) std::memcpy(n_per_level, x->h_pin + x->pin_nl, sizeof(int) * x->n_levels);   // came down with the frame
+        if (x->h_pin && x->pinned_frames >= 1) std::memcpy(n_per_level, x->h_pin + x->pin_nl_last, sizeof(int) * x->n_levels);   // came down with the frame
         else HF_HIP(hipMemcpy(n_per_level, x->d_n_level, sizeof(int) * x->n_levels, hipMemcpyDeviceToHost));
     }
     return HFNET_OK;

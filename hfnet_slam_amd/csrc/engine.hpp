@@ -161,6 +161,7 @@ struct Net {
     bool stem_valid = false;
     size_t stem_elems_max = 0;     // size of the stem tensor at the configured (largest) batch
     float *dense = nullptr, *nms = nullptr;
+    float* global_dst = nullptr;   // when set: forward_global() writes the global descriptors here instead of global_out
     unsigned *nms_mask = nullptr, *nms_flags = nullptr;   // bit-column masks of the NMS passes (max_mask, supp)
     unsigned long long* cand = nullptr;
     unsigned int* counters = nullptr;
@@ -229,7 +230,20 @@ struct hfnet_extractor {
     unsigned char* h_pin = nullptr;
     std::vector<int> last_n;             // keypoint counts of the last host-pointer call per staging frame (-1: unknown)
     int pinned_frames = 0;
-    size_t pin_n = 0, pin_nl = 0, pin_g = 0, pin_k = 0, pin_d = 0;   // byte offsets of the sections
+    // Result sections [n | n_level | global | keypoints | descriptors] packed for the frames of the call (offsets from pin_res;
+    // result_offsets()); the device side keeps the SAME layout in one block (d_blk), so a call's results come down with ONE copy
+    size_t pin_res = 0, pin_nl_last = 0;
+    unsigned char* d_blk = nullptr;
+    struct ResOff { size_t n, nl, g, k, d, total; };
+    ResOff result_offsets(int nb, int global_dim) const {
+        auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+        ResOff o;
+        o.n = 0; o.nl = up(sizeof(int) * nb); o.g = o.nl + up(sizeof(int) * (size_t)nb * n_levels);
+        o.k = o.g + up(sizeof(float) * (size_t)nb * global_dim);
+        o.d = o.k + up(sizeof(hfnet_keypoint) * (size_t)nb * n_features);
+        o.total = o.d + up(sizeof(float) * HFNET_DESC_DIM * (size_t)nb * n_features);
+        return o;
+    }
     // Larger host-pointer calls run as a double-buffered pipeline over their chunks: while chunk c computes, chunk c + 1's
     // images go up and chunk c - 1's results come down through pinned blocks on two copy streams (built on first use).
     // Slot 0 of the device side is the staging above (d_pyr[0], d_kps, d_desc, d_n, d_n_level).
