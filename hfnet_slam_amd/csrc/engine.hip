@@ -298,7 +298,10 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
     for (int L = 3; L <= 7 && front_fused; ++L) front_fused = block_fusable(w.blocks[L - 2], fused_variant);
     front_fused = front_fused && (block_fusable(w.blocks[0], fused_variant) || (fuse_stem && stem_block_fusable(w.stem_out, w.blocks[0])));
     const bool defer = defer_global && fork && two_streams == 3 && front_fused;
-    if (fork && two_streams == 1) {
+    // few frames per call: the global branch (a chain of ~40 small launches) is the critical path, the detector conv does not
+    // fill the chip -- fork right after layer 7 (0.852 -> 0.840 ms per 752x480 frame)
+    const bool fork_early = fork && (two_streams == 1 || (!defer && cfg.batch <= 4));
+    if (fork_early) {
         HF_HIP(hipEventRecord(ev_fork, stream));
         HF_HIP(hipStreamWaitEvent(stream_global, ev_fork, 0));
         HF_TRY(forward_global(stream_global));
@@ -309,7 +312,7 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         Geom gh = geom(7, 7, 0, NL);
         for (int l = 0; l < NL; ++l) { gh.lv[l].pt = gh.lv[l].pl = 1; gh.lv[l].out_off = pix_cell[l]; }
         HF_LAUNCH(e, stream, "conv3x3_det", launch_conv3x3(act[7], w.det1, det_hidden, 1, gh, conv_wlds, stream));
-        if (fork && two_streams >= 2) {
+        if (fork && !fork_early) {
             // the global branch starts after the (chip-filling, MFMA-bound) detector conv: it overlaps the long tail of
             // small kernels (softmax, NMS, top-K, sparse descriptor head) instead of time-sharing with that conv
             HF_HIP(hipEventRecord(ev_fork, stream));
