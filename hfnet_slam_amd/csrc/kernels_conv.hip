@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_stem(ImageSet imgs, const float* __rest
     __shared__ float sw[9 * 64];
     __shared__ float ssh[64];
     for (int i = threadIdx.x; i < 9 * cout; i += 256) sw[i] = w[i];
-    if (threadIdx.x < cout) ssh[threadIdx.x] = bias[threadIdx.x];
+    if ((int)threadIdx.x < cout) ssh[threadIdx.x] = bias[threadIdx.x];
     __syncthreads();
     const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
     const LevelGeom lv = g.lv[level];

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_tri_cols(const BowPair* __restrict__ pa
 __global__ __launch_bounds__(256) void k_tri_rows(const BowPair* __restrict__ pairs, float threshold, int max_rows) {
     const BowPair P = pairs[blockIdx.z];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x * 256 >= P.nq) return;                     // workgroup-uniform
+    if ((int)blockIdx.x * 256 >= P.nq) return;                     // workgroup-uniform
     int m = -1;
     if (i < P.nq) {
         const int nt = tri_tiles(max_rows), nct = tri_tiles(P.nt);
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void k_bow_finalize(const BowPair* __restrict_
     const int nq = P.nq;
     int32_t* __restrict__ match_q2t = P.match; float* __restrict__ dist = P.dist; int* __restrict__ n_matches = P.cnt;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x * 256 >= nq) return;                     // whole workgroup beyond this pair's queries
+    if ((int)blockIdx.x * 256 >= nq) return;                     // whole workgroup beyond this pair's queries
     int m = -1;
     float d = FLT_MAX;
     if (i < nq) {
