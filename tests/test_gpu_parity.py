@@ -740,3 +740,30 @@ def test_windowed_matcher_loop_and_distinctive_descriptors(engine):
     with pytest.raises(capi.HfnetError) as ei:
         engine.distinctive_descriptors(_unit_rows(rng, 97), np.array([0, 97], np.int32))
     assert ei.value.status == capi.ERR_CAPACITY
+
+
+def test_checkpoint_importer_end_to_end(tmp_path):
+    """SURVEY 8f rank 3 on the GPU: a full-width HF-Net checkpoint in TensorFlow's tensor-bundle format (as a real one:
+    no gamma on the memberships BatchNorm, clusters as [1, 1, 1, D, K], an optimiser slot and global_step next to the
+    weights) -> `python -m hfnet_slam_amd.tf_checkpoint` -> container -> engine; keypoints, descriptors and global
+    descriptor equal the oracle's on the same container."""
+    from hfnet_slam_amd import capi, tf_checkpoint as T, weights as W
+    from oracle import oracle as O
+    ref = W.synthetic_weights(11)
+    gname = "global_head/vlad/memberships/BatchNorm/gamma"
+    ck = {n: (a.reshape(1, 1, 1, *a.shape) if n == "global_head/vlad/clusters" else a) for n, a in ref.items() if n != gname}
+    ck["global_step"] = np.array(83096, np.int64)
+    ck["MobilenetV2/Conv/weights/RMSProp"] = np.zeros_like(ref["MobilenetV2/Conv/weights"])
+    prefix = str(tmp_path / "model.ckpt-83096")
+    T.write_bundle(prefix, ck)
+    out = str(tmp_path / "hfnet.hfw")
+    assert T.main([prefix, out]) == 0
+    eng = capi.Engine(out, 0)
+    model = O.Model(out)
+    x = capi.Extractor(eng, 200, 136, 150, 0.01, 1.2, 3, max_batch=1)
+    img = synth_image(136, 200, 77, "natural")
+    n, kps, desc, g, npl = x.extract(img)
+    rn, rk, rd, rg, rnpl = model.extract(img, 150, 0.01, 3, 1.2)
+    assert n == rn and np.array_equal(npl, rnpl)
+    _eq("importer kps", kps, rk); _eq("importer desc", desc, rd); _eq("importer global", g, rg)
+    x.close(); eng.close()
