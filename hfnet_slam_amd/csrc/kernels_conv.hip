@@ -636,7 +636,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wlds(ConvArgs a, Geom g, Tap
     __shared__ __attribute__((aligned(16))) f32x4 wl[2][KS][NT][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
     const int G = a.nt_total / NT;
-    int level = 0, rest = blockIdx.x;
+    // workgroup b runs on XCD b % 8 (observed; speed only): every XCD takes one contiguous eighth of the tile list, so that the
+    // halo rows a tile shares with its vertical neighbours are fetched into ONE L2 instead of three
+    // (time-neutral, but the gathered descriptor taps fetch 69 % less and the dense detector conv 9 % less from beyond L2)
+    const int q8 = (int)gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int level = 0, rest = slot < q8 ? xcd * q8 + slot : 8 * q8 + xcd;      // (the last gridDim.x % 8 workgroups keep their place)
     for (; level < g.n_levels - 1; ++level) {
         const int per = g.batch * G * a.level_tiles[level];
         if (rest < per) break;
