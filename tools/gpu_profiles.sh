@@ -8,6 +8,15 @@ cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_profiles
 mkdir -p $OUT
 export TMPDIR=/tmp
+# traffic passes first: the bench line quotes roofline.traffic from profiles/<tag>_traffic_b<chunk>.json of the SAME source state
+cd /tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$C
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --configs none --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+done
+python $GRAFT_REPO_ROOT/tools/make_traffic.py $(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) $CH $OUT/${TAG}_traffic_b${CH}.json > $OUT/traffic.log 2>&1
+cp $OUT/${TAG}_traffic_b${CH}.json $GRAFT_REPO_ROOT/profiles/
+cd $GRAFT_REPO_ROOT
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 cd /tmp
 rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --configs none --no-cpu-baseline > $OUT/kt.log 2>&1
@@ -21,11 +30,6 @@ for P in "$P1" "$P2"; do
   python $GRAFT_REPO_ROOT/tools/pmc_summary.py $(find /tmp/pmc$i -name '*counter_collection.csv' | head -1) > $OUT/${TAG}_pmc_$( [ $i = 1 ] && echo sq || echo instmix )_b${CH}.txt
   i=$((i+1))
 done
-for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$C
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --configs none --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
-done
-python $GRAFT_REPO_ROOT/tools/make_traffic.py $(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) $CH $OUT/${TAG}_traffic_b${CH}.json > $OUT/traffic.log 2>&1
 rm -f $OUT/*.log
 ls -la $OUT
 head -c 1500 $OUT/${TAG}_bench.json
