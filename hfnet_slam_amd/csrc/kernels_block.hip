@@ -419,9 +419,12 @@ static hipError_t launch_block_fused2_t(const FusedArgs& a, const Geom& g, hipSt
 //                    order: the oracle's chain)
 // f32 MFMA and VALU instructions share one issue port per SIMD, so what counts is that the port never
 // idles: v2 synchronises its four waves twice per chunk and its phases are too short to hide their start-up latencies
-// (measured: stage times add up exactly, expansion at 42 % of its MFMA rate).  Here nothing couples the 2-3 waves of a
+// (measured: stage times add up exactly, expansion at 42 % of its MFMA rate).  Here nothing couples the 2-4 waves of a
 // SIMD, so one wave's LDS round trips, weight fetches and VALU stretches are covered by the others' MFMA chains.  Price:
 // the halo of a 32-pixel tile is relatively larger (stride 1: 2.0 instead of 1.5 expansion rows per output pixel).
+// A workgroup IS one wave: a multi-wave workgroup gives its wave slots back only when its last wave is done, and with
+// four autonomous waves per workgroup the CUs ran at 6.5 of 8 (13 of 16) resident waves on average (SQ_WAVE_CYCLES /
+// SQ_BUSY_CU_CYCLES); one-wave workgroups refill every slot the moment it frees (7.2-7.5 of 8): 5-11 % per launch.
 // The tile's input fragments stay in registers for all chunks; weights come from L1 / L2 one phase ahead.
 // base + uniform byte offset, pinned to scalar registers: a load through it is "scalar base + 32-bit lane offset" and costs
 // no vector instruction for its address (left alone the compiler folds the uniform part into 64-bit vector adds)
@@ -444,14 +447,12 @@ template <int S> struct F4Geo {
     static_assert((EP / 4) % 2 == 1, "ET channel stride");
 };
 
-template <int STRIDE, int NTO, int KQT, bool RES, int OCC, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
+template <int STRIDE, int NTO, int KQT, bool RES, int OCC>
+__global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
     using G = F4Geo<STRIDE>;
     constexpr int TH = G::TH, TW = G::TW, IH = G::IH, IW = G::IW, NPOS = G::NPOS, MT_IN = G::MT_IN, EP = G::EP, CEP = G::CEP;
-    __shared__ __attribute__((aligned(16))) float lds_all[WAVES][32 * EP];
-    const int lane = threadIdx.x & 63, half = lane >> 5, r = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* const ET = lds_all[wave];
+    __shared__ __attribute__((aligned(16))) float ET[32 * EP];
+    const int lane = threadIdx.x, half = lane >> 5, r = lane & 31;
     // exact 1-D grid, order [level][frame][workgroup]: an image of level l owns level_wgs[l] consecutive workgroups (its
     // own count rounded up to 8).  (A 2-D grid sized for the largest level launched half of the stride-2 kernels'
     // workgroups only to exit -- dispatching them costs real time.)
@@ -469,12 +470,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void k_block_fused4(FusedArgs a, G
     // workgroup b runs on XCD b % 8 (observed; speed only; an image's run starts at a multiple of 8): every XCD gets one
     // contiguous run of THIS image's tiles, so that the halo rows shared by vertical neighbours meet in one L2 and every
     // XCD carries the same load
-    const int nwg = (ntiles + WAVES - 1) / WAVES, q = nwg >> 3, rem = nwg & 7;
+    const int q = ntiles >> 3, rem = ntiles & 7;
     const int xr = (bx + image) & 7, slot = bx >> 3;           // (the XCDs that take the remainder rotate with the image)
     if (slot >= q + (xr < rem ? 1 : 0)) return;
-    const int wg = xr * q + min(xr, rem) + slot;
-    const int tile = wg * WAVES + wave;
-    if (tile >= ntiles) return;                                    // (no workgroup barriers anywhere below)
+    const int tile = xr * q + min(xr, rem) + slot;
     const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
     const int oy0 = tyi * TH, ox0 = txi * TW;
     const int iy0 = oy0 * STRIDE - lv.pt, ix0 = ox0 * STRIDE - lv.pl;
@@ -665,7 +664,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void k_block_fused4(FusedArgs a, G
     }
 }
 
-template <int STRIDE, int NTO, int KQT, int OCC, int WAVES = 4>
+template <int STRIDE, int NTO, int KQT, int OCC>
 static hipError_t launch_block_fused4_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
     using G = F4Geo<STRIDE>;
     if (a.residual && (STRIDE != 1 || a.cin != a.cout)) return hipErrorInvalidValue;
@@ -675,13 +674,13 @@ static hipError_t launch_block_fused4_t(const FusedArgs& a, const Geom& g, hipSt
         b.level_wgs[l] = 8;
         if (l >= g.n_levels) continue;
         const int tiles = ((g.lv[l].Wo + G::TW - 1) / G::TW) * ((g.lv[l].Ho + G::TH - 1) / G::TH);
-        b.level_wgs[l] = max(8, (((tiles + WAVES - 1) / WAVES + 7) / 8) * 8);   // multiple of 8: see the XCD mapping in the kernel
+        b.level_wgs[l] = max(8, ((tiles + 7) / 8) * 8);           // multiple of 8: see the XCD mapping in the kernel
         total += (long long)b.level_wgs[l] * g.batch;
     }
     if (total <= 0 || total > 0x7fffffffll) return hipErrorInvalidValue;
     dim3 grid((unsigned)total);
-    if (a.residual) hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, true, OCC, WAVES>), grid, dim3(WAVES * 64), 0, s, b, g);
-    else hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, false, OCC, WAVES>), grid, dim3(WAVES * 64), 0, s, b, g);
+    if (a.residual) hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, true, OCC>), grid, dim3(64), 0, s, b, g);
+    else hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, false, OCC>), grid, dim3(64), 0, s, b, g);
     return hipGetLastError();
 }
 
@@ -1038,8 +1037,8 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
             if (st == 1 && kq == 6 && nto == 2) return launch_block_fused4_t<1, 2, 6, 2>(a, g, s);
             if (st == 1 && kq == 6 && nto == 3) return launch_block_fused4_t<1, 3, 6, 2>(a, g, s);
             if (st == 1 && kq == 9 && nto == 3) return launch_block_fused4_t<1, 3, 9, 2>(a, g, s);
-            if (st == 2 && kq == 2 && nto == 1) return launch_block_fused4_t<2, 1, 2, 2, 1>(a, g, s);
-            if (st == 2 && kq == 3 && nto == 1) return launch_block_fused4_t<2, 1, 3, 2, 1>(a, g, s);
+            if (st == 2 && kq == 2 && nto == 1) return launch_block_fused4_t<2, 1, 2, 2>(a, g, s);
+            if (st == 2 && kq == 3 && nto == 1) return launch_block_fused4_t<2, 1, 3, 2>(a, g, s);
             return hipErrorInvalidValue;
         case FUSED_V2:
             if (st == 2 && kq == 2 && nto == 1) return launch_block_fused2_t<2, 1, 2, true>(a, g, s);
