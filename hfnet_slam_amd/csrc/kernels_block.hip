@@ -447,7 +447,7 @@ template <int S> struct F4Geo {
     static_assert((EP / 4) % 2 == 1, "ET channel stride");
 };
 
-template <int STRIDE, int NTO, int KQT, bool RES, int OCC>
+template <int STRIDE, int NTO, int KQT, bool RES, int OCC, bool PF2>
 __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
     using G = F4Geo<STRIDE>;
     constexpr int TH = G::TH, TW = G::TW, IH = G::IH, IW = G::IW, NPOS = G::NPOS, MT_IN = G::MT_IN, EP = G::EP, CEP = G::CEP;
@@ -523,10 +523,20 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
         ebias = *(gf32_t)(sgpr_base(a.ex_bias, (unsigned)chunk * 128u) + r4);
     };
     load_b(0);
+    f32x4 bnext[KQT];
+    float enext = 0.f;
     const int rh = half;                                           // depthwise role: channel r, output rows 2 rh, 2 rh + 1
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const int ch0 = chunk * 32;
         const int kqc = min(4, (a.cexp - ch0) >> 3);               // (channels past cexp are never consumed: clamp, do not zero)
+        if (PF2) {                                                 // next chunk's expansion weights, requested two phases ahead
+            const int cn = min(chunk + 1, n_chunks - 1);
+#pragma unroll
+            for (int kq = 0; kq < KQT; ++kq)
+                bnext[kq] = *(gvec4_t)(sgpr_base(a.Wex, (unsigned)(kq * a.ex_nt_total + cn) * 1024u) + lane16);
+            enext = *(gf32_t)(sgpr_base(a.ex_bias, (unsigned)cn * 128u) + r4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // this chunk's projection weights and depthwise taps: requested now, used after the expansion
         f32x4 pfrag[4][NTO];
 #pragma unroll
@@ -573,7 +583,7 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
                 }
             }
         }
-        if (chunk + 1 < n_chunks) load_b(chunk + 1);               // next chunk's expansion weights: a whole phase ahead
+        if (!PF2) { if (chunk + 1 < n_chunks) load_b(chunk + 1); }  // next chunk's expansion weights: a whole phase ahead
         asm volatile("" ::: "memory");
         // ---- depthwise: channel r, output rows 2 rh and 2 rh + 1 (input rows 2 rh s .. 2 rh s + s + 2)
         {
@@ -633,6 +643,11 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
             }
         }
         asm volatile("" ::: "memory");
+        if (PF2) {
+#pragma unroll
+            for (int kq = 0; kq < KQT; ++kq) bfrag[kq] = bnext[kq];
+            ebias = enext;
+        }
     }
     // ---- output (+ residual): every 32-column tile goes through the LDS slice so that a lane moves 16 consecutive bytes
     float* __restrict__ ob = a.out + out_base * a.cout;                                // uniform
@@ -664,7 +679,7 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
     }
 }
 
-template <int STRIDE, int NTO, int KQT, int OCC>
+template <int STRIDE, int NTO, int KQT, int OCC, bool PF2>
 static hipError_t launch_block_fused4_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
     using G = F4Geo<STRIDE>;
     if (a.residual && (STRIDE != 1 || a.cin != a.cout)) return hipErrorInvalidValue;
@@ -679,8 +694,8 @@ static hipError_t launch_block_fused4_t(const FusedArgs& a, const Geom& g, hipSt
     }
     if (total <= 0 || total > 0x7fffffffll) return hipErrorInvalidValue;
     dim3 grid((unsigned)total);
-    if (a.residual) hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, true, OCC>), grid, dim3(64), 0, s, b, g);
-    else hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, false, OCC>), grid, dim3(64), 0, s, b, g);
+    if (a.residual) hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, true, OCC, PF2>), grid, dim3(64), 0, s, b, g);
+    else hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, false, OCC, PF2>), grid, dim3(64), 0, s, b, g);
     return hipGetLastError();
 }
 
@@ -1032,13 +1047,16 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
             return hipGetLastError();
         }
         case FUSED_V4:
-            if (st == 1 && kq == 3 && nto == 1) return launch_block_fused4_t<1, 1, 3, 4>(a, g, s);
-            if (st == 1 && kq == 3 && nto == 2) return launch_block_fused4_t<1, 2, 3, 2>(a, g, s);
-            if (st == 1 && kq == 6 && nto == 2) return launch_block_fused4_t<1, 2, 6, 2>(a, g, s);
-            if (st == 1 && kq == 6 && nto == 3) return launch_block_fused4_t<1, 3, 6, 2>(a, g, s);
-            if (st == 1 && kq == 9 && nto == 3) return launch_block_fused4_t<1, 3, 9, 2>(a, g, s);
-            if (st == 2 && kq == 2 && nto == 1) return launch_block_fused4_t<2, 1, 2, 2>(a, g, s);
-            if (st == 2 && kq == 3 && nto == 1) return launch_block_fused4_t<2, 1, 3, 2>(a, g, s);
+            // <stride, 32-column output tiles, cin / 8, waves per SIMD the register budget aims at, expansion weights two phases ahead>
+            // (the last two by measurement per shape: the early weight request costs cin / 2 registers and pays where the
+            //  dw + projection phases are too short to cover an L2 hit under load, 0.7-1 us)
+            if (st == 1 && kq == 3 && nto == 1) return launch_block_fused4_t<1, 1, 3, 4, false>(a, g, s);
+            if (st == 1 && kq == 3 && nto == 2) return launch_block_fused4_t<1, 2, 3, 2, true>(a, g, s);
+            if (st == 1 && kq == 6 && nto == 2) return launch_block_fused4_t<1, 2, 6, 2, false>(a, g, s);
+            if (st == 1 && kq == 6 && nto == 3) return launch_block_fused4_t<1, 3, 6, 2, true>(a, g, s);
+            if (st == 1 && kq == 9 && nto == 3) return launch_block_fused4_t<1, 3, 9, 2, true>(a, g, s);
+            if (st == 2 && kq == 2 && nto == 1) return launch_block_fused4_t<2, 1, 2, 2, true>(a, g, s);
+            if (st == 2 && kq == 3 && nto == 1) return launch_block_fused4_t<2, 1, 3, 2, true>(a, g, s);
             return hipErrorInvalidValue;
         case FUSED_V2:
             if (st == 2 && kq == 2 && nto == 1) return launch_block_fused2_t<2, 1, 2, true>(a, g, s);
