@@ -630,9 +630,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g, TapArgs 
 // every weight fragment, so a slab of four k-steps (NT x 4 KB, one coalesced 16-byte load per thread and k-step) crosses
 // L2 -> L1 once instead of four times, and the only per-lane global loads left are the activation rows, requested a whole
 // slab (64 MFMAs, ~4000 cycles) ahead.  cin % 32 == 0 (a slab never straddles two taps).  Same chains, same bits.
-template <int NT, bool GATHER>
+// SPT_T = slabs per tap when known at compile time (0: run-time loop): the slab loop is then fully unrolled and the "next"
+// activation registers simply become the current ones (16 v_mov per slab otherwise): -2.5 % (dense) / -3.5 % (gathered).
+// The per-value select of out-of-image taps (16 v_cndmask per 64 MFMAs) stays: both ways of getting the zeros from the
+// load itself were measured SLOWER -- out-of-range buffer loads +3 % (run-time loop) / +12 % (unrolled), a zero page in
+// memory +7-10 %: with the MFMA operands coming straight from load registers the compiler waits on every LDS weight
+// fragment right before its first MFMA (21 instead of 7 s_waitcnt per slab), and the MFMA pipe is what this kernel lives on.
+template <int NT, bool GATHER, int SPT_T>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_wlds(ConvArgs a, Geom g, TapArgs ta) {
-    constexpr int KS = 4;
+    constexpr int KS = 4, UNR = SPT_T > 0 ? SPT_T : 1;
     __shared__ __attribute__((aligned(16))) f32x4 wl[2][KS][NT][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
     const int G = a.nt_total / NT;
@@ -685,7 +691,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wlds(ConvArgs a, Geom g, Tap
         in_base = lv.in_off + (long long)frame * nrows;
         out_base = lv.out_off + (long long)frame * nrows;
     }
-    const int KQ = a.cin >> 3, SPT = KQ / KS, n_slabs = 9 * SPT;   // slabs per tap
+    const int KQ = a.cin >> 3, SPT = SPT_T > 0 ? SPT_T : KQ / KS, n_slabs = 9 * SPT;   // slabs per tap
     const size_t wstep = (size_t)a.nt_total * 64;
     constexpr int PIECES = NT * 64, PER_T = (PIECES + 255) / 256;
     auto fetch = [&](int slab, f32x4 (&st)[KS][PER_T]) {
@@ -704,16 +710,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wlds(ConvArgs a, Geom g, Tap
     };
     f32x16 acc[NT];
     conv_acc_init<NT>(a, acc, nt0, r);
-    // per-tap source pointer / validity of this lane's pixel (an out-of-image tap points at a valid pixel and is zeroed
-    // when used: fma(0, w, acc) == acc, exactly as the oracle skips it)
+    // per-tap source pointer of this lane's pixel (an out-of-image tap points at the zero page)
     const float* tap_ptr[9];
     bool tap_ok[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap - ky * 3;
         const int iy = y + ky - 1, ix = x + kx - 1;
-        tap_ok[tap] = pvalid && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc;
-        tap_ptr[tap] = a.A + (in_base + (long long)(tap_ok[tap] ? iy * Wc + ix : 0)) * a.cin + half * 4;
+        const bool ok = pvalid && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc;
+        tap_ok[tap] = ok;
+        tap_ptr[tap] = a.A + (in_base + (long long)(ok ? iy * Wc + ix : 0)) * a.cin + half * 4;
     }
     f32x4 st[KS][PER_T];
     fetch(0, st);
@@ -726,6 +732,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wlds(ConvArgs a, Geom g, Tap
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int tn = tap < 8 ? tap + 1 : 8;
+#pragma unroll UNR
         for (int sl = 0; sl < SPT; ++sl, ++slab) {
             const int buf = slab & 1;
             const bool wrap = sl + 1 == SPT;
@@ -770,8 +777,14 @@ static void launch_c3_nt(const ConvArgs& a, const Geom& g, const TapArgs* ta, di
     else { TapArgs none = {nullptr, nullptr, 0}; hipLaunchKernelGGL((k_conv3x3<NT, false>), grid, dim3(256), 0, s, a, g, none); }
 }
 static void launch_c3_wlds4(const ConvArgs& a, const Geom& g, const TapArgs* ta, dim3 grid, hipStream_t s) {
-    if (ta) hipLaunchKernelGGL((k_conv3x3_wlds<4, true>), grid, dim3(256), 0, s, a, g, *ta);
-    else { TapArgs none = {nullptr, nullptr, 0}; hipLaunchKernelGGL((k_conv3x3_wlds<4, false>), grid, dim3(256), 0, s, a, g, none); }
+    TapArgs none = {nullptr, nullptr, 0};
+    if (a.cin == 96) {                                           // both heads of the network: three slabs per tap, unrolled
+        if (ta) hipLaunchKernelGGL((k_conv3x3_wlds<4, true, 3>), grid, dim3(256), 0, s, a, g, *ta);
+        else hipLaunchKernelGGL((k_conv3x3_wlds<4, false, 3>), grid, dim3(256), 0, s, a, g, none);
+        return;
+    }
+    if (ta) hipLaunchKernelGGL((k_conv3x3_wlds<4, true, 0>), grid, dim3(256), 0, s, a, g, *ta);
+    else hipLaunchKernelGGL((k_conv3x3_wlds<4, false, 0>), grid, dim3(256), 0, s, a, g, none);
 }
 
 static ConvArgs make_args(const float* A, const ConvPack& cp, const float* res, float* out, long long P, int relu6) {
