@@ -9,8 +9,8 @@ import collections, csv, json, sys
 
 # launch name -> (kernel name prefix, rank of the grid size among that kernel's launches, 0 = largest)
 LAUNCHES = {
-    "conv3x3_det": ("void hfnet::k_conv3x3_wlds<4, false>", 0),
-    "conv3x3_desc_taps": ("void hfnet::k_conv3x3_wlds<4, true>", 0),
+    "conv3x3_det": ("void hfnet::k_conv3x3_wlds<4, false", 0),
+    "conv3x3_desc_taps": ("void hfnet::k_conv3x3_wlds<4, true", 0),
     "stem_block_L02": ("void hfnet::k_stem_block2<24, 16>", 0),
     "block_L03": ("void hfnet::k_block_fused4<2, 1, 2, false", 0),
     "block_L04": ("void hfnet::k_block_fused4<1, 1, 3, true", 0),
