@@ -220,8 +220,8 @@ def cpu_baseline(weights_path: str, budget_s: float = 24.0):
                 break
         return done, time.perf_counter() - t0
 
-    n_all, t_all = run(cores, 5, budget_s * 0.4)
-    n_4, t_4 = run(min(4, cores), 3, budget_s * 0.4)
+    n_all, t_all = run(cores, 16, budget_s * 0.4)             # ~20 core-seconds on a 16-core box
+    n_4, t_4 = run(min(4, cores), 4, budget_s * 0.4)
     half = max(cores // 2, 1)
     O.set_threads(half)
     rng = np.random.default_rng(11)
