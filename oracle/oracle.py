@@ -94,7 +94,10 @@ class Model:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().hfo_model_free(C.c_void_p(self.h))
+            try:
+                lib().hfo_model_free(C.c_void_p(self.h))
+            except TypeError:          # interpreter shutdown: the module globals are already gone
+                pass
             self.h = None
 
     # -- network -----------------------------------------------------------------------------

@@ -604,6 +604,32 @@ def test_random_geometries_match_oracle(engine, oracle_model):
         x.close()
 
 
+@pytest.mark.parametrize("mult,n_clusters,global_dim", [(1.0, 32, 4096), (0.5, 16, 256), (0.35, 8, 64), (0.75, 64, 1024), (1.4, 32, 512)])
+def test_other_network_widths(engine, tmp_path, mult, n_clusters, global_dim):
+    """the kernels are specialised for the depth multiplier 0.75 of the published model (hf_net.py:13-52); every other width,
+    cluster count and global dimension goes through the generic kernels (unfused blocks, run-time loops) with the same bits"""
+    from hfnet_slam_amd import capi, spec, weights
+    from oracle import oracle as O
+    p = str(tmp_path / "w.hfw")
+    weights.save(p, weights.synthetic_weights(11, spec.net_spec(mult, n_clusters, global_dim)))
+    m = O.Model(p)
+    e = capi.Engine(p, 0)
+    try:
+        for (w, h, nl, nf) in [(248, 168, 3, 300), (131, 121, 2, 150)]:
+            x = capi.Extractor(e, w, h, nf, 0.01, 1.2, nl, max_batch=2)
+            imgs = np.stack([synth_image(h, w, 51, "natural"), synth_image(h, w, 52)])
+            nb, kb, db, gb = x.extract_batch(imgs)
+            for f in range(2):
+                rn, rk, rd, rg, _ = m.extract(imgs[f], nf, 0.01, nl, 1.2)
+                assert nb[f] == rn, (mult, w, h, f)
+                assert np.array_equal(kb[f, :rn], rk), (mult, w, h, f)
+                _eq(f"desc x{mult} {w}x{h} frame {f}", db[f, :rn], rd)
+                _eq(f"global x{mult} {w}x{h} frame {f}", gb[f], rg)
+            x.close()
+    finally:
+        e.close()
+
+
 def test_store_put_extracted_matches_host_round_trip(engine, oracle_model):
     """frame-to-frame tracking without the descriptors leaving the GPU: extract, keep the block in a store slot, match by slot"""
     from hfnet_slam_amd import capi
