@@ -522,8 +522,12 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
     float ebias;
     // weight loads: uniform (scalar) base + a 32-bit lane offset, so that no vector instruction goes into their addresses
     // (vector ALU instructions and f32 MFMAs share the issue port)
-    const unsigned lane16 = (unsigned)lane * 16u, r4 = (unsigned)r * 4u;
+    const unsigned lane16_ = (unsigned)lane * 16u, r4_ = (unsigned)r * 4u;
+    // the lane offsets are re-"defined" where they are used: hoisted out of the chunk loop they are widened to 64 bits once
+    // and every load then pays a 64-bit vector add instead of using its scalar-base + 32-bit-offset form
+    auto fresh = [](unsigned v) { asm volatile("" : "+v"(v)); return v; };
     auto load_b = [&](int chunk) {
+        const unsigned lane16 = fresh(lane16_), r4 = fresh(r4_);
 #pragma unroll
         for (int kq = 0; kq < KQT; ++kq)
             bfrag[kq] = *(gvec4_t)(sgpr_base(a.Wex, (unsigned)(kq * a.ex_nt_total + chunk) * 1024u) + lane16);
@@ -536,8 +540,10 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const int ch0 = chunk * 32;
         const int kqc = min(4, (a.cexp - ch0) >> 3);               // (channels past cexp are never consumed: clamp, do not zero)
+        const unsigned lane16 = fresh(lane16_);
         if (PF2) {                                                 // next chunk's expansion weights, requested two phases ahead
             const int cn = min(chunk + 1, n_chunks - 1);
+            const unsigned r4 = fresh(r4_);
 #pragma unroll
             for (int kq = 0; kq < KQT; ++kq)
                 bnext[kq] = *(gvec4_t)(sgpr_base(a.Wex, (unsigned)(kq * a.ex_nt_total + cn) * 1024u) + lane16);
