@@ -58,6 +58,20 @@ static long long tile_grid_size(const Geom& g) {
     return total;
 }
 
+// base + uniform byte offset, pinned to scalar registers: a load through it is "scalar base + 32-bit lane offset" and costs
+// no vector instruction for its address (left alone the compiler folds the uniform part into 64-bit vector adds)
+typedef const __attribute__((address_space(1))) char* gbase_t;
+typedef const __attribute__((address_space(1))) f32x4* gvec4_t;
+typedef const __attribute__((address_space(1))) float* gf32_t;
+__device__ __forceinline__ gbase_t sgpr_base(const void* base, unsigned uniform_bytes) {
+    gbase_t p = (gbase_t)(const char*)base + uniform_bytes;
+    asm("" : "+s"(p));
+    return p;
+}
+// a lane offset re-"defined" where it is used: hoisted out of a loop it is widened to 64 bits once and every load through it
+// then pays a 64-bit vector add instead of using its scalar-base + 32-bit-offset form
+__device__ __forceinline__ unsigned fresh(unsigned v) { asm volatile("" : "+v"(v)); return v; }
+
 // ---- v2 of the fused block for the shapes of the high-resolution layers (cin = 8*KQT known at
 // compile time).  Differences to the generic kernel above:
 //  * the expanded halo tile is kept channel-major in LDS (ET[channel][padded position]); the MFMA
@@ -186,9 +200,10 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
     f32x4 bpre[KQA];
     float shpre = 0.f;
     auto fetch_b = [&](int chunk) {
+        const unsigned l16 = fresh((unsigned)lane * 16u), r4 = fresh((unsigned)r * 4u);
 #pragma unroll
-        for (int kq = 0; kq < KQA; ++kq) bpre[kq] = a.Wex[((size_t)kq * a.ex_nt_total + chunk) * 64 + lane];
-        shpre = a.ex_bias[chunk * 32 + r];
+        for (int kq = 0; kq < KQA; ++kq) bpre[kq] = *(gvec4_t)(sgpr_base(a.Wex, (unsigned)(kq * a.ex_nt_total + chunk) * 1024u) + l16);
+        shpre = *(gf32_t)(sgpr_base(a.ex_bias, (unsigned)chunk * 128u) + r4);
     };
     auto stage1 = [&](int chunk) {
         if (HAS_EXPAND) {
@@ -206,7 +221,8 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
                     f32x4 af[KQA];
 #pragma unroll
                     for (int kq = 0; kq < KQA; ++kq) {
-                        if (DIET) { const f32x4 v = *(const f32x4*)(aptr[m] + kq * 8); af[kq] = aok[m] ? v : zero4; }
+                        // (out-of-image positions read a valid pixel and are zeroed by zero_border(); padding positions are never read)
+                        if (DIET) af[kq] = *(const f32x4*)(aptr[m] + kq * 8);
                         else af[kq] = afrag[m][kq];
                     }
                     f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][0], bfrag[0][0], bias16, 0, 0, 0);
@@ -265,10 +281,10 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
         const bool dact = dch < a.cexp;
         float dwt[9], dsh = 0.f;
         if (dact) {
-            const float* wdp = a.Wdw + dch;
+            const unsigned dc4 = fresh((unsigned)dc * 4u);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) dwt[t] = wdp[t * a.cexp];
-            dsh = a.dw_bias[dch];
+            for (int t = 0; t < 9; ++t) dwt[t] = *(gf32_t)(sgpr_base(a.Wdw, (unsigned)(t * a.cexp + ch0) * 4u) + dc4);
+            dsh = *(gf32_t)(sgpr_base(a.dw_bias, (unsigned)ch0 * 4u) + dc4);
         } else {
 #pragma unroll
             for (int t = 0; t < 9; ++t) dwt[t] = 0.f;
@@ -276,11 +292,12 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
         const int kqc = min(4, (a.cexp - ch0) >> 3);
         f32x4 pfrag[4][NTO];
         auto fetch_p = [&]() {
+            const unsigned l16p = fresh((unsigned)lane * 16u);
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq)
 #pragma unroll
                 for (int nt = 0; nt < NTO; ++nt)
-                    pfrag[kq][nt] = kq < kqc ? a.Wpr[((size_t)(chunk * 4 + kq) * a.pr_nt_total + nt) * 64 + lane] : zero4;
+                    pfrag[kq][nt] = kq < kqc ? *(gvec4_t)(sgpr_base(a.Wpr, (unsigned)((chunk * 4 + kq) * a.pr_nt_total + nt) * 1024u) + l16p) : zero4;
         };
         if (out_live && !DIET) fetch_p();
         // ---- stage 2: thread = (channel dc, output row doy), ET -> D
@@ -426,17 +443,6 @@ static hipError_t launch_block_fused2_t(const FusedArgs& a, const Geom& g, hipSt
 // four autonomous waves per workgroup the CUs ran at 6.5 of 8 (13 of 16) resident waves on average (SQ_WAVE_CYCLES /
 // SQ_BUSY_CU_CYCLES); one-wave workgroups refill every slot the moment it frees (7.2-7.5 of 8): 5-11 % per launch.
 // The tile's input fragments stay in registers for all chunks; weights come from L1 / L2 one phase ahead.
-// base + uniform byte offset, pinned to scalar registers: a load through it is "scalar base + 32-bit lane offset" and costs
-// no vector instruction for its address (left alone the compiler folds the uniform part into 64-bit vector adds)
-typedef const __attribute__((address_space(1))) char* gbase_t;
-typedef const __attribute__((address_space(1))) f32x4* gvec4_t;
-typedef const __attribute__((address_space(1))) float* gf32_t;
-__device__ __forceinline__ gbase_t sgpr_base(const void* base, unsigned uniform_bytes) {
-    gbase_t p = (gbase_t)(const char*)base + uniform_bytes;
-    asm("" : "+s"(p));
-    return p;
-}
-
 template <int S> struct F4Geo {
     static constexpr int TH = 4, TW = 8, IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, NPOS = IH * IW, MT_IN = (NPOS + 31) / 32;
     // channel stride of ET in floats: the halo positions rounded up to an odd number of 16-byte pieces (conflict-free
@@ -523,9 +529,6 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
     // weight loads: uniform (scalar) base + a 32-bit lane offset, so that no vector instruction goes into their addresses
     // (vector ALU instructions and f32 MFMAs share the issue port)
     const unsigned lane16_ = (unsigned)lane * 16u, r4_ = (unsigned)r * 4u;
-    // the lane offsets are re-"defined" where they are used: hoisted out of the chunk loop they are widened to 64 bits once
-    // and every load then pays a 64-bit vector add instead of using its scalar-base + 32-bit-offset form
-    auto fresh = [](unsigned v) { asm volatile("" : "+v"(v)); return v; };
     auto load_b = [&](int chunk) {
         const unsigned lane16 = fresh(lane16_), r4 = fresh(r4_);
 #pragma unroll
