@@ -816,14 +816,14 @@ hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* res
     const int nt = pick_nt(cp.nt_total, cp.nt_per_block, (P + 31) / 32);
     // long k chains on few tiles: latency-bound, see k_pointwise_deep
     constexpr long long lowlat_waves = 1024;
-    constexpr long long wlds_min_weight_bytes = 128 * 1024;
+    constexpr long long wlds_min_weight_bytes = 32 * 1024;   // (measured: the detector's 128 -> 65 conv, 48 KB, 270 -> 232 us; it was 128 KB)
     if (nt <= 2 && cp.cin >= 192 && (P + 31) / 32 * cp.nt_total < lowlat_waves) {
         dim3 grid((unsigned)((P + 127) / 128), cp.nt_total / nt);
         if (nt == 1) hipLaunchKernelGGL((k_pointwise_deep<1, 8>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_pointwise_deep<2, 8>), grid, dim3(256), 0, s, a);
         return hipGetLastError();
     }
-    // more weights than L1 holds on a GEMM-shaped launch: weight slabs through LDS (see k_pointwise_wlds)
+    // a GEMM-shaped launch whose weights would crowd the activations out of L1 (32 KB): weight slabs through LDS (see k_pointwise_wlds)
     if ((size_t)cp.cin * cp.nt_total * 32 * sizeof(float) >= (size_t)wlds_min_weight_bytes && (P + 127) / 128 * (cp.nt_total / nt) >= 1024 &&
         nt >= 2 && nt <= 4) {
         dim3 gw((unsigned)((P + 127) / 128), cp.nt_total / nt);
