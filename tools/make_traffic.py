@@ -19,7 +19,7 @@ LAUNCHES = {
     "block_L07": ("void hfnet::k_block_fused4<1, 3, 6, false", 0),
     "block_L08": ("void hfnet::k_block_fused2<2, 2, 12, true, 8>", 0),
     "pointwise_desc_taps": ("void hfnet::k_pointwise_wlds<4>", 0),
-    "pointwise_det": ("void hfnet::k_pointwise<3>", 0),
+    "pointwise_det": ("void hfnet::k_pointwise_wlds<3>", 0),
     "fc": ("void hfnet::k_fc_mfma<16>", 0),
     "nms_select": ("hfnet::k_nms_select", 0),
     "match_gemm": ("hfnet::k_bow_gemm_cand", 0),
