@@ -453,7 +453,7 @@ template <int S> struct F4Geo {
     static_assert((EP / 4) % 2 == 1, "ET channel stride");
 };
 
-template <int STRIDE, int NTO, int KQT, bool RES, int OCC, bool PF2>
+template <int STRIDE, int NTO, int KQT, bool RES, int OCC>
 __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
     using G = F4Geo<STRIDE>;
     constexpr int TH = G::TH, TW = G::TW, IH = G::IH, IW = G::IW, NPOS = G::NPOS, MT_IN = G::MT_IN, EP = G::EP, CEP = G::CEP;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
         const int ch0 = chunk * 32;
         const int kqc = min(4, (a.cexp - ch0) >> 3);               // (channels past cexp are never consumed: clamp, do not zero)
         const unsigned lane16 = fresh(lane16_);
-        if (PF2) {                                                 // next chunk's expansion weights, requested two phases ahead
+        {                                                          // next chunk's expansion weights, requested two phases ahead
             const int cn = min(chunk + 1, n_chunks - 1);
             const unsigned r4 = fresh(r4_);
 #pragma unroll
@@ -599,7 +599,6 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
                 }
             }
         }
-        if (!PF2) { if (chunk + 1 < n_chunks) load_b(chunk + 1); }  // next chunk's expansion weights: a whole phase ahead
         asm volatile("" ::: "memory");
         // ---- depthwise: channel r, output rows 2 rh and 2 rh + 1 (input rows 2 rh s .. 2 rh s + s + 2)
         {
@@ -659,11 +658,9 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
             }
         }
         asm volatile("" ::: "memory");
-        if (PF2) {
 #pragma unroll
-            for (int kq = 0; kq < KQT; ++kq) bfrag[kq] = bnext[kq];
-            ebias = enext;
-        }
+        for (int kq = 0; kq < KQT; ++kq) bfrag[kq] = bnext[kq];
+        ebias = enext;
     }
     // ---- output (+ residual): every 32-column tile goes through the LDS slice so that a lane moves 16 consecutive bytes
     float* __restrict__ ob = a.out + out_base * a.cout;                                // uniform
@@ -695,7 +692,7 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
     }
 }
 
-template <int STRIDE, int NTO, int KQT, int OCC, bool PF2>
+template <int STRIDE, int NTO, int KQT, int OCC>
 static hipError_t launch_block_fused4_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
     using G = F4Geo<STRIDE>;
     if (a.residual && (STRIDE != 1 || a.cin != a.cout)) return hipErrorInvalidValue;
@@ -710,8 +707,8 @@ static hipError_t launch_block_fused4_t(const FusedArgs& a, const Geom& g, hipSt
     }
     if (total <= 0 || total > 0x7fffffffll) return hipErrorInvalidValue;
     dim3 grid((unsigned)total);
-    if (a.residual) hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, true, OCC, PF2>), grid, dim3(64), 0, s, b, g);
-    else hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, false, OCC, PF2>), grid, dim3(64), 0, s, b, g);
+    if (a.residual) hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, true, OCC>), grid, dim3(64), 0, s, b, g);
+    else hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, false, OCC>), grid, dim3(64), 0, s, b, g);
     return hipGetLastError();
 }
 
@@ -1063,16 +1060,14 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
             return hipGetLastError();
         }
         case FUSED_V4:
-            // <stride, 32-column output tiles, cin / 8, waves per SIMD the register budget aims at, expansion weights two phases ahead>
-            // (the last two by measurement per shape: the early weight request costs cin / 2 registers and pays where the
-            //  dw + projection phases are too short to cover an L2 hit under load, 0.7-1 us)
-            if (st == 1 && kq == 3 && nto == 1) return launch_block_fused4_t<1, 1, 3, 4, false>(a, g, s);
-            if (st == 1 && kq == 3 && nto == 2) return launch_block_fused4_t<1, 2, 3, 2, true>(a, g, s);
-            if (st == 1 && kq == 6 && nto == 2) return launch_block_fused4_t<1, 2, 6, 2, false>(a, g, s);
-            if (st == 1 && kq == 6 && nto == 3) return launch_block_fused4_t<1, 3, 6, 2, true>(a, g, s);
-            if (st == 1 && kq == 9 && nto == 3) return launch_block_fused4_t<1, 3, 9, 2, true>(a, g, s);
-            if (st == 2 && kq == 2 && nto == 1) return launch_block_fused4_t<2, 1, 2, 2, true>(a, g, s);
-            if (st == 2 && kq == 3 && nto == 1) return launch_block_fused4_t<2, 1, 3, 2, true>(a, g, s);
+            // <stride, 32-column output tiles, cin / 8, waves per SIMD the register budget aims at>
+            if (st == 1 && kq == 3 && nto == 1) return launch_block_fused4_t<1, 1, 3, 4>(a, g, s);
+            if (st == 1 && kq == 3 && nto == 2) return launch_block_fused4_t<1, 2, 3, 2>(a, g, s);
+            if (st == 1 && kq == 6 && nto == 2) return launch_block_fused4_t<1, 2, 6, 2>(a, g, s);
+            if (st == 1 && kq == 6 && nto == 3) return launch_block_fused4_t<1, 3, 6, 2>(a, g, s);
+            if (st == 1 && kq == 9 && nto == 3) return launch_block_fused4_t<1, 3, 9, 2>(a, g, s);
+            if (st == 2 && kq == 2 && nto == 1) return launch_block_fused4_t<2, 1, 2, 2>(a, g, s);
+            if (st == 2 && kq == 3 && nto == 1) return launch_block_fused4_t<2, 1, 3, 2>(a, g, s);
             return hipErrorInvalidValue;
         case FUSED_V2:
             if (st == 2 && kq == 2 && nto == 1) return launch_block_fused2_t<2, 1, 2, true>(a, g, s);
