@@ -18,7 +18,7 @@ int* Options::find(const char* name) {
     const struct { const char* n; int* p; } tab[] = {{"fuse_blocks", &fuse_blocks}, {"fuse_max_layer", &fuse_max_layer}, {"fused_variant", &fused_variant},
                                                        {"fuse_stem", &fuse_stem}, {"dense_desc", &dense_desc}, {"two_streams", &two_streams},
                                                        {"graph", &graph}, {"pinned_frames", &pinned_frames}, {"db_gemm_min_queries", &db_gemm_min_queries},
-                                                       {"conv_wlds", &conv_wlds}};
+                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}};
     for (const auto& t : tab) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -116,7 +116,7 @@ int Net::build(Engine* eng, const NetConfig& c) {
     e = eng;
     cfg = c;
     // A/B and diagnostics switches of the engine (hfnet_engine_set_option), fixed for the lifetime of this network
-    fuse_blocks = e->opt.fuse_blocks; fuse_max_layer = e->opt.fuse_max_layer; fused_variant = e->opt.fused_variant;
+    fuse_blocks = e->opt.fuse_blocks; fuse_max_layer = e->opt.fuse_max_layer; fused_variant = e->opt.fused_variant; fuse_min_wgs = e->opt.fuse_min_wgs;
     force_dense = e->opt.dense_desc; fuse_stem = e->opt.fuse_stem; conv_wlds = e->opt.conv_wlds;
     const DeviceWeights& w = e->w;
     if (c.n_levels < 1 || c.n_levels > HFNET_MAX_LEVELS || c.batch < 1) { set_error("net: bad level / batch count"); return HFNET_ERR_INVALID_ARG; }
@@ -243,7 +243,7 @@ static int run_block(Net& n, int L, int n_used, hipStream_t st) {   // layer L =
         const LevelPlan& p0 = n.lp[0];
         // (in 128-pixel tiles: 96 lose to three launches, 384 win)
         const long long wgs = (long long)((p0.w[L] + 15) / 16) * ((p0.h[L] + 7) / 8) * n.cfg.batch;
-        fuse = wgs >= 256;
+        fuse = wgs >= n.fuse_min_wgs;
     }
     if (fuse) {
         char fn[32];
@@ -543,13 +543,16 @@ int hfnet_engine_info(const hfnet_engine* e, int what) {
 
 int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value) {
     API_GUARD(e, "engine");
+    std::lock_guard<std::mutex> lk(e->impl.mu);              // (the database / matcher entry points read options under this lock)
     int* p = e->impl.opt.find(name);
     if (!p) { set_error("unknown engine option '%s'", name ? name : "(null)"); return HFNET_ERR_INVALID_ARG; }
+    if (value < 0) { set_error("engine option '%s': negative value %d", name, value); return HFNET_ERR_INVALID_ARG; }
     *p = value;
     return HFNET_OK;
 }
 int hfnet_engine_get_option(hfnet_engine* e, const char* name, int* value) {
     API_GUARD(e, "engine"); API_GUARD(value, "value");
+    std::lock_guard<std::mutex> lk(e->impl.mu);
     const int* p = e->impl.opt.find(name);
     if (!p) { set_error("unknown engine option '%s'", name ? name : "(null)"); return HFNET_ERR_INVALID_ARG; }
     *value = *p;

@@ -27,13 +27,20 @@ public:
     void run(int n, const std::function<void(int)>& fn) {
         if (n <= 0) return;
         if (th_.empty() || n == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
-        // next_ is the publication point: a helper that is still leaving the previous run may win an index of this one the
-        // moment next_ is reset, so everything it then reads (fn_, n_, pending_) is written before that store
-        { std::lock_guard<std::mutex> lk(m_); fn_ = &fn; n_ = n; pending_.store(n); next_.store(0); ++gen_; }
+        // A helper registers in active_ (under m_) before it enters drain() and leaves it the same way.  The run state (fn_, n_,
+        // pending_, next_) is only ever written while no helper is inside drain(), and run() only returns when none is:
+        // a helper that claimed an index past the end of one run can therefore never compare it with the next run's larger
+        // n_ (it would call that run's function with a stale index -- the index processed twice, pending_ decremented once
+        // too often, run() back in the caller while a staging copy is still in flight), and fn is never used after scope.
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            done_.wait(lk, [this] { return active_ == 0; });
+            fn_ = &fn; n_ = n; pending_.store(n); next_.store(0); ++gen_;
+        }
         cv_.notify_all();
         drain();
         std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [this] { return pending_.load() == 0; });
+        done_.wait(lk, [this] { return pending_.load() == 0 && active_ == 0; });
         fn_ = nullptr;
     }
 private:
@@ -53,8 +60,10 @@ private:
                 cv_.wait(lk, [&] { return gen_ != seen; });
                 seen = gen_;
                 if (stop_) return;
+                ++active_;
             }
             drain();
+            { std::lock_guard<std::mutex> lk(m_); if (--active_ == 0) done_.notify_all(); }
         }
     }
     std::vector<std::thread> th_;
@@ -64,6 +73,7 @@ private:
     int n_ = 0;
     std::atomic<int> next_{0}, pending_{0};
     unsigned long long gen_ = 0;
+    int active_ = 0;               // helpers inside drain() (under m_)
     bool stop_ = false;
 };
 
@@ -79,7 +89,7 @@ struct DevMem {
 struct Options {
     int fuse_blocks = 1;      // 0: expand / depthwise / project as three launches per block (the reference variant of the tests)
     int fuse_max_layer = 14;  // last layer that may use a fused block kernel
-    int fused_variant = 4;    // 4: wave-autonomous tiles where they exist; 2: the barrier-phased kernel everywhere
+    int fused_variant = 4;    // 4: wave-autonomous tiles where they exist (3: their three-waves-per-SIMD forms at any size); 2: the barrier-phased kernel everywhere
     int fuse_stem = 1;        // stem + layer_2 in one launch
     int dense_desc = 0;       // 1: always evaluate the dense descriptor head (default: only the taps of the selected keypoints)
     int two_streams = 3;      // 0 one stream; 1 fork after layer 7; 2 fork after the detector conv; 3 = 2 + deferred join
@@ -87,6 +97,7 @@ struct Options {
     int pinned_frames = 4;    // chunks up to this many frames move through one pinned block inside that graph
     int conv_wlds = 1;        // 3x3 heads: weights staged through LDS once per workgroup (0: every wave reads them from L1 / L2)
     int db_gemm_min_queries = 8;   // hfnet_db_query_batch: from this many queries on, the scores come from the MFMA GEMM form
+    int fuse_min_wgs = 256;   // layers 8-14 take their fused kernel from this many 128-pixel tiles per launch on (0: always; tests)
     int* find(const char* name);
 };
 
@@ -155,6 +166,7 @@ struct Net {
     int fuse_blocks = 1;           // fused inverted-residual kernel for layers <= fuse_max_layer
     int fuse_max_layer = 14;
     int fused_variant = 4;
+    int fuse_min_wgs = 256;
     int fuse_stem = 1;             // stem + layer_2 in one launch: the stem tensor is not materialised (its tap recomputes it on demand)
     int conv_wlds = 1;             // 3x3 heads with LDS-staged weights
     ImageSet last_imgs;            // input of the last forward (for that tap)

@@ -31,7 +31,8 @@ hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, i
 hipError_t launch_depthwise(const float* in, const DwPack& dp, int stride, float* out, const Geom& g, hipStream_t s);
 // whole inverted-residual block (expand -> depthwise -> project [+ residual]) in one launch; the expanded
 // tensor lives in LDS only.  block_fusable(): the block's shape has a fused kernel (kernels_block.hip).
-// variant: 4 = wave-autonomous tiles where available (default), 2 = the barrier-phased kernel everywhere (A/B of the tests)
+// variant: 4 = wave-autonomous tiles where available (default), 3 = the same with the three-waves-per-SIMD instantiations at any
+// launch size, 2 = the barrier-phased kernel everywhere (A/B of the tests)
 bool block_fusable(const BlockPack& b, int variant);
 hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, const Geom& g, int variant, hipStream_t s);
 // stem conv + layer_2 (no-expansion block) in one launch: the stem tensor stays in LDS

@@ -453,7 +453,13 @@ template <int S> struct F4Geo {
     static_assert((EP / 4) % 2 == 1, "ET channel stride");
 };
 
-template <int STRIDE, int NTO, int KQT, bool RES, int OCC>
+// KQO ("k outer"): the expansion walks the input channels in the outer loop with one accumulator per halo M-tile (MT_IN
+// independent MFMA chains in flight; the ReLU6 / LDS epilogue of one tile overlaps the last MFMAs of the others) and its
+// weights stream through a ring of PF 16-byte pieces requested PF steps ahead instead of being held for the whole chunk
+// (KQT * 4 registers, twice with the look-ahead copy).  It is what lets a 96-channel stride-2 block (layer 8: 240
+// registers of input fragments) run as a wave-autonomous tile at one wave per SIMD: its input crosses L2 once instead of
+// once per expansion chunk.
+template <int STRIDE, int NTO, int KQT, bool RES, int OCC, bool KQO = false>
 __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
     using G = F4Geo<STRIDE>;
     constexpr int TH = G::TH, TW = G::TW, IH = G::IH, IW = G::IW, NPOS = G::NPOS, MT_IN = G::MT_IN, EP = G::EP, CEP = G::CEP;
@@ -536,7 +542,16 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
             bfrag[kq] = *(gvec4_t)(sgpr_base(a.Wex, (unsigned)(kq * a.ex_nt_total + chunk) * 1024u) + lane16);
         ebias = *(gf32_t)(sgpr_base(a.ex_bias, (unsigned)chunk * 128u) + r4);
     };
-    load_b(0);
+    constexpr int PF = KQT < 3 ? KQT : 3;                          // KQO: pieces of expansion weights in flight
+    f32x4 bq[PF];
+    if constexpr (KQO) {
+        const unsigned lane16 = fresh(lane16_), r4 = fresh(r4_);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) bq[j] = *(gvec4_t)(sgpr_base(a.Wex, (unsigned)(j * a.ex_nt_total) * 1024u) + lane16);
+        ebias = *(gf32_t)(sgpr_base(a.ex_bias, 0u) + r4);
+    } else {
+        load_b(0);
+    }
     f32x4 bnext[KQT];
     float enext = 0.f;
     const int rh = half;                                           // depthwise role: channel r, output rows 2 rh, 2 rh + 1
@@ -544,7 +559,10 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
         const int ch0 = chunk * 32;
         const int kqc = min(4, (a.cexp - ch0) >> 3);               // (channels past cexp are never consumed: clamp, do not zero)
         const unsigned lane16 = fresh(lane16_);
-        {                                                          // next chunk's expansion weights, requested two phases ahead
+        if constexpr (KQO) {
+            const int cn = min(chunk + 1, n_chunks - 1);
+            enext = *(gf32_t)(sgpr_base(a.ex_bias, (unsigned)cn * 128u) + fresh(r4_));
+        } else {                                                   // next chunk's expansion weights, requested two phases ahead
             const int cn = min(chunk + 1, n_chunks - 1);
             const unsigned r4 = fresh(r4_);
 #pragma unroll
@@ -554,19 +572,57 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
             __builtin_amdgcn_sched_barrier(0);
         }
         // this chunk's projection weights and depthwise taps: requested now, used after the expansion
+        // (three waves per SIMD: the projection weights are requested after the depthwise arithmetic, into registers it frees)
+        constexpr bool P_LATE = KQO && OCC >= 3;
         f32x4 pfrag[4][NTO];
+        auto load_p = [&]() {
+            const unsigned l16 = fresh(lane16_);
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq)
+            for (int kq = 0; kq < 4; ++kq)
 #pragma unroll
-            for (int nt = 0; nt < NTO; ++nt)
-                pfrag[kq][nt] = *(gvec4_t)(sgpr_base(a.Wpr, (unsigned)((chunk * 4 + min(kq, kqc - 1)) * a.pr_nt_total + nt) * 1024u) + lane16);
+                for (int nt = 0; nt < NTO; ++nt)
+                    pfrag[kq][nt] = *(gvec4_t)(sgpr_base(a.Wpr, (unsigned)((chunk * 4 + min(kq, kqc - 1)) * a.pr_nt_total + nt) * 1024u) + l16);
+        };
+        if constexpr (!P_LATE) load_p();
         const unsigned dch4 = (unsigned)min(r, a.cexp - 1 - ch0) * 4u;      // (channels past cexp: clamped, never consumed)
         float dwt[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) dwt[t] = *(gf32_t)(sgpr_base(a.Wdw, (unsigned)(t * a.cexp + ch0) * 4u) + dch4);
         const float dwb = *(gf32_t)(sgpr_base(a.dw_bias, (unsigned)ch0 * 4u) + dch4);
         // ---- expansion
-        {
+        if constexpr (KQO) {
+            f32x16 acc[MT_IN];
+#pragma unroll
+            for (int m = 0; m < MT_IN; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][i] = ebias;
+            const int cn = min(chunk + 1, n_chunks - 1);
+#pragma unroll
+            for (int kq = 0; kq < KQT; ++kq) {
+                const f32x4 b = bq[kq % PF];
+                // the piece PF steps ahead (the next chunk's first pieces at the end: they arrive during the depthwise phase)
+                const int kn = kq + PF < KQT ? kq + PF : kq + PF - KQT;
+                const int cc = kq + PF < KQT ? chunk : cn;
+                const f32x4 bn = *(gvec4_t)(sgpr_base(a.Wex, (unsigned)(kn * a.ex_nt_total + cc) * 1024u) + fresh(lane16_));
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int m = 0; m < MT_IN; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][kq][t], b[t], acc[m], 0, 0, 0);
+                bq[kq % PF] = bn;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < MT_IN; ++m) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = relu6f(acc[m][4 * q + i]);
+                    if (m * 32 + 8 * q + 8 <= EP) *(f32x4*)(ET + r * EP + m * 32 + 8 * q + 4 * half) = v;
+                    else if (m * 32 + 8 * q + 4 <= EP) { if (half == 0) *(f32x4*)(ET + r * EP + m * 32 + 8 * q) = v; }
+                }
+            }
+        } else {
             f32x16 bias16;
 #pragma unroll
             for (int i = 0; i < 16; ++i) bias16[i] = ebias;
@@ -640,6 +696,7 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
 #pragma unroll
                 for (int ox = 0; ox < TW; ++ox) o[ro][ox] = relu6f(o[ro][ox]);
             asm volatile("" ::: "memory");                         // every ET read is issued before D overwrites the slice
+            if constexpr (P_LATE) load_p();
 #pragma unroll
             for (int ro = 0; ro < 2; ++ro)
 #pragma unroll
@@ -658,8 +715,10 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
             }
         }
         asm volatile("" ::: "memory");
+        if constexpr (!KQO) {
 #pragma unroll
-        for (int kq = 0; kq < KQT; ++kq) bfrag[kq] = bnext[kq];
+            for (int kq = 0; kq < KQT; ++kq) bfrag[kq] = bnext[kq];
+        }
         ebias = enext;
     }
     // ---- output (+ residual): every 32-column tile goes through the LDS slice so that a lane moves 16 consecutive bytes
@@ -692,7 +751,7 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
     }
 }
 
-template <int STRIDE, int NTO, int KQT, int OCC>
+template <int STRIDE, int NTO, int KQT, int OCC, bool KQO = false>
 static hipError_t launch_block_fused4_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
     using G = F4Geo<STRIDE>;
     if (a.residual && (STRIDE != 1 || a.cin != a.cout)) return hipErrorInvalidValue;
@@ -707,8 +766,8 @@ static hipError_t launch_block_fused4_t(const FusedArgs& a, const Geom& g, hipSt
     }
     if (total <= 0 || total > 0x7fffffffll) return hipErrorInvalidValue;
     dim3 grid((unsigned)total);
-    if (a.residual) hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, true, OCC>), grid, dim3(64), 0, s, b, g);
-    else hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, false, OCC>), grid, dim3(64), 0, s, b, g);
+    if (a.residual) hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, true, OCC, KQO>), grid, dim3(64), 0, s, b, g);
+    else hipLaunchKernelGGL((k_block_fused4<STRIDE, NTO, KQT, false, OCC, KQO>), grid, dim3(64), 0, s, b, g);
     return hipGetLastError();
 }
 
@@ -1051,6 +1110,8 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
     a.Wpr = (const f32x4*)b.pr.w; a.pr_bias = b.pr.bias; a.pr_nt_total = b.pr.nt_total;
     a.out = out; a.cin = b.cin; a.cexp = b.expand; a.cout = b.cout; a.residual = b.residual; a.has_expand = b.has_expand;
     const int nto = (b.cout + 31) / 32, kq = b.cin / 8, st = b.stride;
+    const long long n_tiles = tile_grid_size<4, 8>(g);             // wave tiles of the k_block_fused4 launch
+    const bool occ3 = n_tiles > 2048 || variant == 3;             // (variant 3: the three-waves-per-SIMD instantiations at any size -- tests)
     switch (fused_kind(b, variant)) {
         case FUSED_NOEXPAND: {
             int maxtiles = 0;
@@ -1063,9 +1124,15 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
             // <stride, 32-column output tiles, cin / 8, waves per SIMD the register budget aims at>
             if (st == 1 && kq == 3 && nto == 1) return launch_block_fused4_t<1, 1, 3, 4>(a, g, s);
             if (st == 1 && kq == 3 && nto == 2) return launch_block_fused4_t<1, 2, 3, 2>(a, g, s);
-            if (st == 1 && kq == 6 && nto == 2) return launch_block_fused4_t<1, 2, 6, 2>(a, g, s);
+            // the 30 x 47 layers of a 64-frame call are 3072 tiles: at two waves per SIMD (2048 slots) that is a full round and a half
+            // one; at three (KQO: streamed expansion weights, projection weights requested after the expansion) all of them are
+            // resident at once: layers 9-11 129 -> 105 us.  Launches that fit two waves per SIMD keep those.  (Layer 12, three column
+            // tiles, only fits with 16 spilled registers: 150 -> 128 us by itself, but a kernel with scratch memory that follows
+            // one without pays ~40 us at its first launch in the stream, so no spilled variant is kept.)
+            if (st == 1 && kq == 6 && nto == 2) return occ3 ? launch_block_fused4_t<1, 2, 6, 3, true>(a, g, s) : launch_block_fused4_t<1, 2, 6, 2>(a, g, s);
             if (st == 1 && kq == 6 && nto == 3) return launch_block_fused4_t<1, 3, 6, 2>(a, g, s);
-            if (st == 1 && kq == 9 && nto == 3) return launch_block_fused4_t<1, 3, 9, 2>(a, g, s);
+            // (KQO: 244 registers instead of 256 + 9 spilled: layer 13 304 -> 255 us)
+            if (st == 1 && kq == 9 && nto == 3) return launch_block_fused4_t<1, 3, 9, 2, true>(a, g, s);
             if (st == 2 && kq == 2 && nto == 1) return launch_block_fused4_t<2, 1, 2, 2>(a, g, s);
             if (st == 2 && kq == 3 && nto == 1) return launch_block_fused4_t<2, 1, 3, 2>(a, g, s);
             return hipErrorInvalidValue;

@@ -71,11 +71,15 @@ struct Folded { std::vector<float> scale, shift; };
 
 // slim.batch_norm (inference): y = x * scale + shift; the same float expressions as the oracle
 // (oracle/hfnet_oracle.c fold_bn): scale = gamma / sqrt(var + 1e-3), shift = beta - mean*scale.  The caller folds the
-// scale into the weights (w * scale, one f32 rounding) and starts the accumulators at the shift.  gamma is optional:
-// slim.batch_norm defaults to scale=False and the NetVLAD memberships conv is built outside the mobilenet arg_scope
-// (hfnet/models/utils/layers.py:71-76), so a real checkpoint has no gamma there.
+// scale into the weights (w * scale, one f32 rounding) and starts the accumulators at the shift.  gamma may be absent for
+// ONE scope only: slim.batch_norm defaults to scale=False and the NetVLAD memberships conv is built outside the mobilenet
+// arg_scope (hfnet/models/utils/layers.py:71-76), so a real checkpoint has no gamma there.  Anywhere else a missing gamma
+// means a truncated or mis-scoped container and is an error (it would silently load as 1).
+bool gamma_optional(const std::string& scope) { return scope == "global_head/vlad/memberships"; }
+
 int fold_bn(const WeightFile& wf, const std::string& scope, int c, Folded& out) {
     const HostTensor* g = wf.find(scope + "/BatchNorm/gamma");
+    if (!g && !gamma_optional(scope)) { set_error("weights: '%s/BatchNorm/gamma' missing", scope.c_str()); return HFNET_ERR_IO; }
     const HostTensor* b = wf.find(scope + "/BatchNorm/beta");
     const HostTensor* m = wf.find(scope + "/BatchNorm/moving_mean");
     const HostTensor* v = wf.find(scope + "/BatchNorm/moving_variance");

@@ -302,8 +302,9 @@ def import_hfnet(prefix: str, scope: str = "") -> "OrderedDict[str, np.ndarray]"
     src = {n: find(n) for n in want}
     # BatchNorm gamma is optional: slim.batch_norm defaults to scale=False, and the NetVLAD memberships conv is built outside
     # the mobilenet arg_scope that sets scale=True (hfnet/models/utils/layers.py:71-76) -- the checkpoint has no such
-    # variable there.  The HIP library and the oracle read a missing gamma as 1.
-    for n in [n for n, k in src.items() if k is None and n.endswith("/BatchNorm/gamma")]:
+    # variable there.  The HIP library and the oracle read that one missing gamma as 1; a MobileNet gamma that is missing
+    # means a truncated or mis-scoped checkpoint and stays an error (it falls into `missing` below).
+    for n in [n for n, k in src.items() if k is None and n == "global_head/vlad/memberships/BatchNorm/gamma"]:
         del src[n], want[n]
     missing = [n for n, k in src.items() if k is None]
     if missing:

@@ -75,9 +75,10 @@ static const float* tensor(const hfo_model* m, const char* name, const hfo_entry
 }
 
 /* slim.batch_norm inference: y = x * scale + shift with scale = gamma / sqrt(var + eps), shift = beta - mean * scale,
- * folded into the convolution: wf[k][c] = w[k][c] * scale[c], bias[c] = shift[c].  gamma is optional: slim.batch_norm
- * defaults to scale=False, and the NetVLAD memberships conv is built outside the mobilenet arg_scope
- * (hfnet/models/utils/layers.py:71-76), so a real checkpoint has no gamma there -> 1. */
+ * folded into the convolution: wf[k][c] = w[k][c] * scale[c], bias[c] = shift[c].  gamma may be absent for one scope only:
+ * slim.batch_norm defaults to scale=False, and the NetVLAD memberships conv is built outside the mobilenet arg_scope
+ * (hfnet/models/utils/layers.py:71-76), so a real checkpoint has no gamma there -> 1.  A missing gamma anywhere else is a
+ * truncated container: refuse it. */
 static int fold_bn(const hfo_model* m, const char* scope, const float* w, size_t rows, int c, hfo_convbn* out) {
     char nm[160];
     const float *g, *b, *mu, *var;
@@ -86,6 +87,7 @@ static int fold_bn(const hfo_model* m, const char* scope, const float* w, size_t
     snprintf(nm, sizeof nm, "%s/BatchNorm/moving_mean", scope);     mu = tensor(m, nm, NULL);
     snprintf(nm, sizeof nm, "%s/BatchNorm/moving_variance", scope); var = tensor(m, nm, NULL);
     if (!b || !mu || !var) return 0;
+    if (!g && strcmp(scope, "global_head/vlad/memberships") != 0) return 0;
     out->w = (float*)malloc(sizeof(float) * rows * (size_t)c);
     out->bias = (float*)malloc(sizeof(float) * c);
     for (int i = 0; i < c; ++i) {

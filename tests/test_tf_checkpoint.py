@@ -72,6 +72,7 @@ def test_import_hfnet_checkpoint(tmp_path):
         T.import_hfnet(prefix)
 
 
+
 def test_reader_on_an_independently_written_bundle():
     """tests/golden/tf_bundle/ was written by tests/golden/make_tf_bundle.py, a second implementation of the table / bundle
     formats that shares no code with tf_checkpoint.py (shortened index separators, several data blocks with a second
@@ -127,3 +128,14 @@ def test_checkpoint_without_memberships_gamma(tmp_path):
     T.write_bundle(prefix, ck, data_crc=False)
     with pytest.raises(ValueError, match="missing"):
         T.import_hfnet(prefix)
+    # ... and so is a missing gamma of any OTHER scope (a truncated / mis-scoped checkpoint must not load as gamma = 1):
+    # the importer refuses it, and so does the oracle's container reader
+    mb = "MobilenetV2/expanded_conv_3/depthwise/BatchNorm/gamma"
+    ck2 = {n: (a.reshape(1, 1, 1, *a.shape) if n == "global_head/vlad/clusters" else a) for n, a in ref.items() if n not in (gname, mb)}
+    T.write_bundle(prefix, ck2, data_crc=False)
+    with pytest.raises(ValueError, match="missing"):
+        T.import_hfnet(prefix)
+    p_bad = str(tmp_path / "c.hfw")
+    W.save(p_bad, {n: a for n, a in ref.items() if n != mb})
+    with pytest.raises(Exception):
+        O.Model(p_bad)
