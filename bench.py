@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 W_IMG, H_IMG, N_FEAT, N_LEVELS, SCALE, THRESH, TH_LOW, TH_HIGH = 752, 480, 1000, 4, 1.2, 0.01, 0.6, 0.75
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4)
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic_b{batch}.json")     # one file per frames-per-call value
+TRAFFIC_FILES = [os.path.join("profiles", r + "_traffic_b{batch}.json") for r in ("r03", "r02")]     # newest first; one file per frames-per-call value
 ALL_CONFIGS = ["2-latency", "2-host-io", "3", "4", "5"]
 
 
@@ -121,6 +121,7 @@ def layer_work(batch: int, width: int = W_IMG, height: int = H_IMG, n_feat: int 
         if lvl == 0:
             pg = ph * pw * batch
             add("pointwise_memberships", 2.0 * pg * sp.global_channels * sp.n_clusters, 4.0 * pg * (sp.global_channels + sp.n_clusters))
+            add("softmax_memberships", 4.0 * pg * sp.n_clusters, 8.0 * pg * sp.n_clusters)
             add("vlad", 3.0 * pg * sp.vlad_dim, 4.0 * (pg * (sp.global_channels + sp.n_clusters) + 3 * batch * sp.vlad_dim))
             add("fc_l2", 2.0 * batch * sp.vlad_dim * sp.global_dim, 4.0 * (sp.vlad_dim * sp.global_dim + batch * (sp.vlad_dim + 2 * sp.global_dim)),
                 2.0 * (-(-batch // 16) * 16) * sp.vlad_dim * sp.global_dim)
@@ -150,19 +151,21 @@ def roofline_entry(flop, byts, seconds):
 
 
 def hbm_traffic(launch_name: str, batch: int):
-    """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate
+    """(HBM bytes per launch, file) from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate
     runs of this command, folded by tools/make_traffic.py), with the gfx950 correction of MI355X_MICROARCH.md
-    (FETCH_SIZE counts 128-byte requests as 64 bytes -> doubled).  None when no pass exists for this kernel / chunk size.
-    NOT a measurement of the present run: rocprofv3 cannot run inside the timed process."""
-    try:
-        with open(os.path.join(ROOT, TRAFFIC_FILE.format(batch=batch))) as f:
-            t = json.load(f)
-        k = t["kernels"][launch_name]
-        if t["batch"] != batch:
-            return None
-        return (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0
-    except (OSError, KeyError, ValueError):
-        return None
+    (FETCH_SIZE counts 128-byte requests as 64 bytes -> doubled).  (None, None) when no pass exists for this kernel / chunk
+    size.  NOT a measurement of the present run: rocprofv3 cannot run inside the timed process."""
+    for pat in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, pat.format(batch=batch))) as f:
+                t = json.load(f)
+            k = t["kernels"][launch_name]
+            if t["batch"] != batch:
+                continue
+            return (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0, pat.format(batch=batch)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 # ------------------------------------------------------------------------------------------------ synthetic data
@@ -228,13 +231,21 @@ def cpu_baseline(weights_path: str, budget_s: float = 24.0):
     a = unit_rows(rng, 1000, 256); b = unit_rows(rng, 1000, 256)
     t0 = time.perf_counter(); O.search_by_bow(a, b, TH_LOW); t_match = time.perf_counter() - t0
     t0 = time.perf_counter(); O.search_for_triangulation(a, b, TH_HIGH); t_tri = time.perf_counter() - t0
-    db = unit_rows(rng, 2000, 4096)
-    t0 = time.perf_counter(); O.db_scores(db[0], db); t_db = (time.perf_counter() - t0) * 5.0      # scaled to 10 000 rows
+    db = unit_rows(rng, 10000, 4096)                              # 164 MB: does not fit the host's last-level cache, like the real scan
+    O.db_scores(db[0], db[:64])
+    t0 = time.perf_counter(); O.db_scores(db[0], db); t_db = time.perf_counter() - t0
+    wq = windowed_inputs()
+    O.set_threads(min(8, cores))
+    O.match_candidates(*wq)
+    t_w = []
+    for _ in range(20):
+        t0 = time.perf_counter(); O.match_candidates(*wq); t_w.append(time.perf_counter() - t0)
     return {"value": n_all / t_all, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{n_all} frames 752x480 extract (4 levels, 1000 kpts) + {max(n_all - 1, 0)} SearchByBoW matches, oracle/libhfnet_oracle.so, {cores} OpenMP threads",
             "variants": {"extract_match_4_threads_frames_per_s": n_4 / t_4, "threads_4": min(4, cores),
                          "search_by_bow_1000x1000_ms": t_match * 1e3, "search_for_triangulation_1000x1000_ms": t_tri * 1e3,
-                         "db_scan_10000x4096_ms": t_db * 1e3, "matcher_db_threads": half}}
+                         "db_scan_10000x4096_ms": t_db * 1e3, "matcher_db_threads": half,
+                         "windowed_candidates_8_threads_us": float(np.median(t_w)) * 1e6, "windowed_candidates_threads": min(8, cores)}}
 
 
 # ------------------------------------------------------------------------------------------------ headline pipeline
@@ -297,7 +308,7 @@ class Pipeline:
         self.ext.close()
 
 
-def profile_pass(eng, pipe, frames, chunk, reps=3):
+def profile_pass(eng, pipe, frames, chunk, reps=10):
     """dedicated profiling pass: HIP events around EVERY launch, one stream (the engine serialises the global branch while
     an unfiltered profile is on) and a host synchronisation around the matcher call (it has its own stream), so no kernel
     shares the GPU with another.  Returns {name: (launches, total_ms)} per chunk."""
@@ -311,20 +322,65 @@ def profile_pass(eng, pipe, frames, chunk, reps=3):
     return {k: (v[0] / reps, v[1] / reps) for k, v in prof.items()}
 
 
+def launch_class(name: str) -> str:
+    """what bounds a launch by construction: the classes of roofline.classes"""
+    if name.startswith("block_L") or name == "stem_block_L02":
+        return "fused_block"
+    if name.startswith(("conv3x3_", "pointwise_de")):
+        return "head_gemm"
+    if name.startswith(("expand_L", "project_L", "pointwise_memberships", "fc_l2")):
+        return "global_gemm"
+    if name.startswith("match_"):
+        return "match"
+    return "hbm_stream"      # depthwise_L15-18, nms, softmax_d2s, sample, pyramid_resize, topk, vlad, softmax_memberships, stem
+
+
 def roofline_table(prof, work, chunk_seconds_sum):
-    """time-weighted table of every launch name with >= 2 % of the profiled chunk time"""
+    """(table, classes).  classes: per launch class its share of the profiled chunk, time, algorithmic FLOP and bytes and the
+    fraction of the roof that bounds the class (hbm_stream: bytes once / time / 8 TB/s; the others: FLOP / time / f32 MFMA peak).
+    table: time-weighted rows of every launch in a class that carries >= 2 % of the chunk (own share >= 0.25 %), so the
+    memory-bound launches, each of which is small, are listed as well."""
+    cls = {}
+    for name, (launches, ms) in prof.items():
+        if name not in work or launches <= 0:
+            continue
+        c = cls.setdefault(launch_class(name), {"us": 0.0, "flop": 0.0, "bytes": 0.0, "executed": 0.0, "launches": 0.0})
+        flop, byts, executed = work[name]
+        c["us"] += ms * 1e3; c["flop"] += flop; c["bytes"] += byts; c["executed"] += executed; c["launches"] += launches
+    for k, c in cls.items():
+        sec = c["us"] * 1e-6
+        c["share"] = sec / chunk_seconds_sum
+        if k == "hbm_stream":
+            c.update({"bound": "hbm", "achieved": c["bytes"] / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"})
+        else:
+            c.update({"bound": "mfma", "achieved": c["flop"] / sec / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac_executed": c["executed"] / sec / 1e12 / MFMA_F32_PEAK_TFLOPS})
+        c["frac"] = c["achieved"] / c["peak"]
     rows = []
     for name, (launches, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
         share = ms * 1e-3 / chunk_seconds_sum
-        if share < 0.02 or name not in work or launches <= 0:
+        if name not in work or launches <= 0 or share < 0.0025 or cls[launch_class(name)]["share"] < 0.02:
             continue
         flop, byts, executed = work[name]
         sec = ms * 1e-3 / launches
         e = roofline_entry(flop / launches, byts / launches, sec)
-        e.update({"name": name, "us": sec * 1e6, "launches_per_chunk": launches, "share": share, "flop": flop / launches, "bytes": byts / launches,
-                  "frac_executed": (executed / launches) / sec / 1e12 / MFMA_F32_PEAK_TFLOPS if e["bound"] == "mfma" else None})
+        if launch_class(name) == "hbm_stream" and e["bound"] != "hbm":     # priced against the roof of its class
+            e = {"bound": "hbm", "achieved": byts / launches / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+            e["frac"] = e["achieved"] / e["peak"]
+        e.update({"name": name, "class": launch_class(name), "us": sec * 1e6, "launches_per_chunk": launches, "share": share, "flop": flop / launches,
+                  "bytes": byts / launches, "frac_executed": (executed / launches) / sec / 1e12 / MFMA_F32_PEAK_TFLOPS if e["bound"] == "mfma" else None})
         rows.append(e)
-    return rows
+    return rows, cls
+
+
+LAYER_GRANULAR = ("stem", "pyramid_resize", "expand_L", "depthwise_L", "project_L", "conv3x3_desc", "pointwise_desc", "l2norm_desc", "conv3x3_det",
+                  "pointwise_det", "softmax_d2s", "nms", "topk", "sample", "pointwise_memberships", "softmax_memberships", "vlad", "fc_l2")
+
+
+def extractor_algorithmic_bytes(work):
+    """bytes of the extractor when every LAYER reads its input once, writes its output once and reads its
+    weights once (the unfused, dense-head network; ~1 GB per 752x480 frame) -- the numerator of the extractor-level HBM fraction"""
+    return sum(v[1] for k, v in work.items() if k.startswith(LAYER_GRANULAR) and not k.endswith("_taps"))
 
 
 # ------------------------------------------------------------------------------------------------ sub-configs
@@ -426,7 +482,35 @@ def config_tracking(capi, eng, n_feat, frames_n=400):
             "frames": frames_n, "frames_per_s_whole_loop": frames_n / wall}
 
 
-def config_sequences(torch, pipe, dev, rank, world, dist, pool_frames=64):
+def windowed_inputs():
+    """Tracking-sized input of the windowed matchers' candidate loop: ~1000 MapPoint queries, each against the 5-40 keypoints
+    its grid lookup returned (Matcher.cc:40-210); seeded, shared by the device leg (configs["3"]) and the CPU leg (cpu_baseline)"""
+    rng = np.random.default_rng(21)
+    nq, nt = 1000, 1000
+    train = unit_rows(rng, nt, 256)
+    query = train[rng.integers(0, nt, nq)] + 0.05 * rng.standard_normal((nq, 256)).astype(np.float32)
+    counts = rng.integers(5, 41, nq)
+    off = np.zeros(nq + 1, np.int32); off[1:] = np.cumsum(counts)
+    idx = rng.integers(0, nt, int(off[-1])).astype(np.int32)
+    lvl = rng.integers(0, 4, nt).astype(np.int32)
+    return query, train, lvl, off, idx
+
+
+def config_windowed_candidates(capi, eng, reps=30):
+    """SURVEY.md 8f rank 4, the question DESIGN.md section 7 answers with this number: is the candidate loop of the windowed
+    matchers worth a device call?  hfnet_match_candidates through the host-pointer entry point (queries, train descriptors and
+    the ragged candidate lists go up, five result arrays come down); the CPU side of the comparison -- the oracle's restatement
+    of the reference loop on 8 host threads, same inputs -- is cpu_baseline.variants.windowed_candidates_8_threads_us."""
+    query, train, lvl, off, idx = windowed_inputs()
+    eng.match_candidates(query, train, lvl, off, idx)
+    t_dev = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); eng.match_candidates(query, train, lvl, off, idx); t_dev.append(time.perf_counter() - t0)
+    return {"workload": f"{len(query)} queries x 5-40 candidates of {len(train)} train rows x 256 ({int(off[-1])} distances), host pointers in and out",
+            "device_call_us_median": float(np.median(t_dev)) * 1e6}
+
+
+def config_sequences(torch, pipe, dev, rank, world, dist, pool_frames=64, dry=False):
     """config 4: the 11 EuRoC sequences (27 049 frames) assigned to the ranks longest-first (hfnet_slam_amd/shard.py), each
     rank walks its sequences in frame order in chunks of the pipeline's chunk size; frame i is matched against frame i - 1
     of the same sequence.  Frames come from a pool of synthetic frames resident in HBM."""
@@ -434,7 +518,7 @@ def config_sequences(torch, pipe, dev, rank, world, dist, pool_frames=64):
     B = pipe.B
     plan = shard.assign_sequences(shard.EUROC_SEQUENCES, world)
     chunks = shard.sequence_chunks(plan[rank], shard.EUROC_SEQUENCES, B)
-    pool = torch.from_numpy(make_frames(pool_frames + B, 10_000 * (rank + 1))).to(dev)
+    pool = None if dry else torch.from_numpy(make_frames(pool_frames + B, 10_000 * (rank + 1))).to(dev)
     # pair lists of every chunk, built before the timed region (slots rotate with the pipeline's buffers)
     cur, todo = pipe.cur, []
     for ci, (name, f0, n) in enumerate(chunks):
@@ -442,13 +526,16 @@ def config_sequences(torch, pipe, dev, rank, world, dist, pool_frames=64):
         q, t = shard.chunk_pairs(f0, n, s0, (s0 - 1) % (pipe.n_buf * B))
         todo.append((n, torch.tensor(q, dtype=torch.int32, device=dev), torch.tensor(t, dtype=torch.int32, device=dev), len(q), (ci * B) % pool_frames))
         cur = (cur + 1) % pipe.n_buf
-    torch.cuda.synchronize()
+    if not dry:
+        torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     for n, q, t, npairs, off in todo:
-        pipe.run_chunk(pool[off:], n, q, t, npairs)
-    pipe.eng.synchronize(); torch.cuda.synchronize()
+        pipe.run_chunk(None if dry else pool[off:], n, q, t, npairs)
+    pipe.eng.synchronize()
+    if not dry:
+        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     mine = sum(c[2] for c in chunks)
     if dist is not None:
@@ -532,6 +619,32 @@ def config_loop_closure(capi, eng, reps=10):
 
 
 # ------------------------------------------------------------------------------------------------ main
+class DryPipeline:
+    """--dry-ranks: the pipeline's interface with a timed no-op instead of the GPU work, so that the multi-rank control flow
+    of this file (rendezvous, per-rank frame blocks, config 4's sequence plan and pair lists, barriers, the MAX over ranks,
+    rank 0's JSON line) can be executed on a box without GPUs (tests/test_distributed.py).  Its numbers mean nothing."""
+
+    class _Eng:
+        def synchronize(self):
+            pass
+
+        def fence(self):
+            pass
+
+    def __init__(self, chunk, n_buf=3, seconds_per_frame=2e-5):
+        self.B, self.n_buf, self.cur, self.eng, self.spf = chunk, n_buf, 0, DryPipeline._Eng(), seconds_per_frame
+        self.frames_done = 0
+
+    def run_chunk(self, d_images, n_frames, qset=None, tset=None, n_pairs=None, isolate=False):
+        time.sleep(self.spf * n_frames)
+        self.frames_done += n_frames
+        self.cur = (self.cur + 1) % self.n_buf
+        return None
+
+    def close(self):
+        pass
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -544,105 +657,131 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="also print the per-launch timing table to stderr")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option (hfnet_engine_set_option), e.g. fused_variant=2")
+    ap.add_argument("--dry-ranks", type=int, default=0, metavar="N",
+                    help="no GPU: run the N-rank control flow (gloo, rendezvous from the environment like the real run) with a timed no-op "
+                         "instead of the kernels; the line is marked invalid")
     args = ap.parse_args()
     want = ALL_CONFIGS if args.configs == "all" else [] if args.configs == "none" else [c.strip() for c in args.configs.split(",")]
     if args.batch % args.chunk:
         raise SystemExit("--batch must be a multiple of --chunk")
+    dry = args.dry_ranks > 0
+    if dry and args.dry_ranks != args.gpus:
+        raise SystemExit("--dry-ranks N goes with --gpus N")
 
     import torch
-    from hfnet_slam_amd import capi, weights
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP front end has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP front end has no CPU fallback)")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} visible device(s)")
+        torch.cuda.set_device(local_rank)
+        # torch bundles its own HIP runtime: it has to be initialised on this rank's device BEFORE libhfnet_hip.so pulls in the
+        # system one (capi.lib() below), or the library sees no devices afterwards (same order as tests/conftest.py)
+        torch.cuda.init()
+        dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if dry:
+            dist_mod.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist = dist_mod
 
-    wpath = os.path.join(tempfile.gettempdir(), f"hfnet_synth_seed7_rank{rank}.hfw")
-    weights.save(wpath, weights.synthetic_weights(7))
-    eng = capi.Engine(wpath, local_rank)
-    for o in args.opt:
-        k, v = o.split("=")
-        eng.set_option(k, int(v))
+    def dev_sync():
+        if not dry:
+            torch.cuda.synchronize()
+
     B, chunks_per_step = args.chunk, args.batch // args.chunk
-    pipe = Pipeline(torch, capi, eng, dev, W_IMG, H_IMG, B)
     n_sets = max(chunks_per_step, 2)      # every frame of a step is a different image (the same step is replayed K times)
-    frames = [torch.from_numpy(make_frames(B, (rank * n_sets + s) * B, args.frames)).to(dev) for s in range(n_sets)]
-    torch.cuda.synchronize()
+    eng = capi = None
+    if dry:
+        pipe = DryPipeline(B)
+        frames = [None] * n_sets
+        wpath = None
+    else:
+        from hfnet_slam_amd import capi, weights
+        wpath = os.path.join(tempfile.gettempdir(), f"hfnet_synth_seed7_rank{rank}.hfw")
+        weights.save(wpath, weights.synthetic_weights(7))
+        eng = capi.Engine(wpath, local_rank)
+        # N replicas share one host: each takes its share of the cores for the staging copies of host-pointer batch calls
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        eng.set_option("copy_threads", max(0, min(3, cores // world - 1)))
+        for o in args.opt:
+            k, v = o.split("=")
+            eng.set_option(k, int(v))
+        pipe = Pipeline(torch, capi, eng, dev, W_IMG, H_IMG, B)
+        # rank r's frames: block r of the global frame index space (hfnet_slam_amd/shard.py: disjoint blocks, no collective)
+        frames = [torch.from_numpy(make_frames(B, (rank * n_sets + s) * B, args.frames)).to(dev) for s in range(n_sets)]
+        dev_sync()
     state = {"i": 0}
 
     def step():
+        n = None
         for _ in range(chunks_per_step):
             n = pipe.run_chunk(frames[state["i"] % n_sets], B)
             state["i"] += 1
         return n
 
     def sync_all():
-        eng.synchronize()
-        torch.cuda.synchronize()
+        pipe.eng.synchronize()
+        dev_sync()
         if dist is not None:
             dist.barrier()
 
-    # ---- warm-up, budget check, per-launch profile (single stream, every kernel alone) ---------
-    n = pipe.run_chunk(frames[0], B)
-    eng.synchronize()
-    n = n.cpu().numpy()
-    if int(n.min()) < N_FEAT and not os.environ.get("BENCH_NO_KP_CHECK"):
-        raise SystemExit(f"synthetic frames gave only {int(n.min())} keypoints (< {N_FEAT}): budget not exercised")
-    prof = profile_pass(eng, pipe, frames, B)
-    work = layer_work(B)
-    prof_sum_s = sum(v[1] for v in prof.values()) * 1e-3
-    if args.profile_all and rank == 0:
-        for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1]):
-            print(f"  {k:26s} launches {v[0]:5.1f}  avg {v[1] / max(v[0], 1e-9) * 1e3:9.1f} us  share {v[1] * 1e-3 / prof_sum_s * 100:5.1f}%", file=sys.stderr)
-    table = roofline_table(prof, work, prof_sum_s)
-    dominant = max((k for k in prof if k in work), key=lambda k: prof[k][1])      # largest by TIME in the single-stream pass
-    for _ in range(max(args.warmup - 1, 0)):
-        step()
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # ---- timed region: the dominant kernel is timed live with HIP events on its own stream ------
-    eng.profile_reset(); eng.profile_filter(dominant); eng.profile_enable(True)
+    # ---- warm-up, budget check; then the per-launch profile (single stream, every kernel alone) on a WARM chip -----
+    work = layer_work(B)
+    prof, table, classes, dominant, prof_sum_s = {}, [], {}, None, 0.0
+    if not dry:
+        n = pipe.run_chunk(frames[0], B)
+        eng.synchronize()
+        n = n.cpu().numpy()
+        if int(n.min()) < N_FEAT and not os.environ.get("BENCH_NO_KP_CHECK"):
+            raise SystemExit(f"synthetic frames gave only {int(n.min())} keypoints (< {N_FEAT}): budget not exercised")
+    for _ in range(args.warmup):
+        step()
+    if not dry:
+        prof = profile_pass(eng, pipe, frames, B)
+        prof_sum_s = sum(v[1] for v in prof.values()) * 1e-3
+        if args.profile_all and rank == 0:
+            for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+                print(f"  {k:26s} launches {v[0]:5.1f}  avg {v[1] / max(v[0], 1e-9) * 1e3:9.1f} us  share {v[1] * 1e-3 / prof_sum_s * 100:5.1f}%", file=sys.stderr)
+        table, classes = roofline_table(prof, work, prof_sum_s)
+        dominant = max((k for k in prof if k in work), key=lambda k: prof[k][1])      # largest by TIME in the single-stream pass
+        step()                                                                        # (back to the two-stream steady state)
+        # ---- timed region: the dominant kernel is timed live with HIP events on its own stream ------
+        eng.profile_reset(); eng.profile_filter(dominant); eng.profile_enable(True)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    dom = eng.profile().get(dominant, (0, 0.0))
-    eng.profile_enable(False); eng.profile_filter(None)
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    dom = (0, 0.0)
+    if not dry:
+        dom = eng.profile().get(dominant, (0, 0.0))
+        eng.profile_enable(False); eng.profile_filter(None)
 
     out = None
     if rank == 0:
         frames_total = world * args.batch * args.steps
-        flop, byts, executed = work[dominant]
-        launches_per_chunk = max(prof[dominant][0], 1.0)
-        avg_s = dom[1] / max(dom[0], 1) * 1e-3
-        roof = roofline_entry(flop / launches_per_chunk, byts / launches_per_chunk, avg_s)
-        roof.update({"traffic": hbm_traffic(dominant, B),
-                     "traffic_source": f"{TRAFFIC_FILE.format(batch=B)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at chunk {B} (committed; not measured in this run)",
-                     "kernel": dominant, "avg_launch_us": avg_s * 1e6, "launches": dom[0],
-                     "selection": "largest launch name by time in the single-stream profiling pass; timed live (HIP events on its stream) over the timed region"})
-        chunk_s = elapsed / args.steps / chunks_per_step
-        alg = sum(work[k][0] for k in prof if k in work)
-        exe = sum(work[k][2] for k in prof if k in work)
-        roof["step_frac_algorithmic"] = alg / chunk_s / 1e12 / MFMA_F32_PEAK_TFLOPS
-        roof["step_frac_executed"] = exe / chunk_s / 1e12 / MFMA_F32_PEAK_TFLOPS
-        roof["profiled_chunk_ms_single_stream"] = prof_sum_s * 1e3
-        roof["table"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in table]
         out = {
             "metric": "frames/sec HF-Net extract+match, 752x480, 1000 kpts",
             "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -651,18 +790,43 @@ def main() -> None:
             "config": {"workload": "EuRoC-size 752x480 mono, HF-Net extract (4 levels x1.2, budget 322/268/224/186, thr 0.01, "
                                    "level 0 incl. NetVLAD 4096-D) + SearchByBoW brute-force match vs previous frame",
                        "frames_per_step_per_gpu": args.batch, "frames_per_call": B, "parallelism": f"replicas x{world} (no collective)"},
-            "roofline": roof, "build_id": capi.build_id(), "options": eng.options(),
         }
+        if dry:
+            out["invalid"] = f"--dry-ranks {args.dry_ranks}: control flow only, a timed no-op stands in for the GPU work"
+        else:
+            flop, byts, executed = work[dominant]
+            launches_per_chunk = max(prof[dominant][0], 1.0)
+            avg_s = dom[1] / max(dom[0], 1) * 1e-3
+            roof = roofline_entry(flop / launches_per_chunk, byts / launches_per_chunk, avg_s)
+            traffic, traffic_file = hbm_traffic(dominant, B)
+            roof.update({"traffic": traffic,
+                         "traffic_source": f"{traffic_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at chunk {B} (committed; not measured in this run)" if traffic_file else None,
+                         "kernel": dominant, "avg_launch_us": avg_s * 1e6, "launches": dom[0],
+                         "profiled_us_single_stream": prof[dominant][1] / launches_per_chunk * 1e3,
+                         "selection": "largest launch name by time in the single-stream profiling pass (after the warm-up steps, 10 chunks); timed live (HIP events on its stream) over the timed region"})
+            chunk_s = elapsed / args.steps / chunks_per_step
+            alg = sum(work[k][0] for k in prof if k in work)
+            exe = sum(work[k][2] for k in prof if k in work)
+            roof["step_frac_algorithmic"] = alg / chunk_s / 1e12 / MFMA_F32_PEAK_TFLOPS
+            roof["step_frac_executed"] = exe / chunk_s / 1e12 / MFMA_F32_PEAK_TFLOPS
+            # extractor-level HBM fraction: layer-granular algorithmic bytes x frames/s over the HBM peak -- what
+            # the unfused network would have to move; the fused kernels move far less (roofline.classes, profiles/*traffic*)
+            roof["step_frac_hbm_algorithmic"] = extractor_algorithmic_bytes(work) / chunk_s / 1e9 / HBM_PEAK_GBS
+            roof["profiled_chunk_ms_single_stream"] = prof_sum_s * 1e3
+            rnd = lambda d: {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()}
+            roof["classes"] = {k: rnd(v) for k, v in sorted(classes.items(), key=lambda kv: -kv[1]["us"])}
+            roof["table"] = [rnd(r) for r in table]
+            out.update({"roofline": roof, "build_id": capi.build_id(), "options": eng.options()})
         if os.environ.get("BENCH_DEV_NO_MATCH"):
             out["invalid"] = "development run: the matcher was skipped (BENCH_DEV_NO_MATCH)"
 
     # ---- the other BASELINE configs (sub-records) ------------------------------------------------
     configs = {}
     if "4" in want:
-        r = config_sequences(torch, pipe, dev, rank, world, dist)
+        r = config_sequences(torch, pipe, dev, rank, world, dist, dry=dry)
         if rank == 0:
             configs["4"] = r
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not dry:
         if "2-latency" in want:
             configs["2-latency"] = config_latency(capi, eng)
         if "2-host-io" in want:
@@ -671,19 +835,22 @@ def main() -> None:
         if "3" in want:
             configs["3"] = {"workload": "TUM-VI-size 512x512 tracking loop, 4 levels, one frame per call, keyframe every 5th (database scan + 30 "
                                         "SearchForTriangulation pairs), device-resident keyframe store",
-                            "nFeatures_1000": config_tracking(capi, eng, 1000), "nFeatures_850": config_tracking(capi, eng, 850)}
+                            "nFeatures_1000": config_tracking(capi, eng, 1000), "nFeatures_850": config_tracking(capi, eng, 850),
+                            "windowed_candidates": config_windowed_candidates(capi, eng)}
         if "5" in want:
             configs["5"] = config_loop_closure(capi, eng)
     if rank == 0:
         out["configs"] = configs
         out["configs_not_run"] = [c for c in ALL_CONFIGS if c not in configs]
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(wpath)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    pipe.close(); eng.close()
+    pipe.close()
+    if eng is not None:
+        eng.close()
 
 
 if __name__ == "__main__":

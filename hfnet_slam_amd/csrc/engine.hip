@@ -18,7 +18,7 @@ int* Options::find(const char* name) {
     const struct { const char* n; int* p; } tab[] = {{"fuse_blocks", &fuse_blocks}, {"fuse_max_layer", &fuse_max_layer}, {"fused_variant", &fused_variant},
                                                        {"fuse_stem", &fuse_stem}, {"dense_desc", &dense_desc}, {"two_streams", &two_streams},
                                                        {"graph", &graph}, {"pinned_frames", &pinned_frames}, {"db_gemm_min_queries", &db_gemm_min_queries},
-                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}};
+                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}};
     for (const auto& t : tab) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -931,8 +931,11 @@ static int host_pipe_init(hfnet_extractor* x) {
     HF_HIP(hipStreamCreateWithFlags(&p.s_up, hipStreamNonBlocking));
     HF_HIP(hipStreamCreateWithFlags(&p.s_down, hipStreamNonBlocking));
     {
+        // helper threads of the pageable <-> pinned staging copies: engine option "copy_threads" (several replicas on one host
+        // share its cores: bench.py gives each rank cores / world), by default 3 on a host with >= 8 hardware threads
         const unsigned hc = std::thread::hardware_concurrency();
-        p.pool.reset(new hfnet::CopyPool(hc >= 8 ? 3 : hc >= 4 ? 1 : 0));
+        const int want = x->eng->impl.opt.copy_threads;
+        p.pool.reset(new hfnet::CopyPool(want < 64 ? want : hc >= 8 ? 3 : hc >= 4 ? 1 : 0));
     }
     p.ready = true;
     return HFNET_OK;

@@ -76,12 +76,16 @@ void hfnet_engine_destroy(hfnet_engine* e);
 int hfnet_engine_info(const hfnet_engine* e, int what);
 /* Diagnostics / A-B switches, read when a model or extractor is created from the engine (no environment variables):
  *   "fuse_blocks" (1)   0: every inverted-residual block as three launches (the tests' reference variant)
- *   "fuse_max_layer" (14), "fused_variant" (4: wave-autonomous tiles, 2: barrier-phased kernel), "fuse_stem" (1)
+ *   "fuse_max_layer" (14), "fused_variant" (4: wave-autonomous tiles, 3: their three-waves-per-SIMD forms at any launch size,
+ *                       2: barrier-phased kernel), "fuse_stem" (1)
+ *   "fuse_min_wgs" (256) layers 8-14 take their fused kernel from this many 128-pixel tiles per launch on (0: always)
  *   "dense_desc" (0)    1: dense descriptor head instead of the taps of the selected keypoints
  *   "two_streams" (3)   0 one stream; 1 fork after layer 7; 2 fork after the detector conv; 3 = 2 + deferred join
  *   "conv_wlds" (1)     3x3 head convolutions: weights staged through LDS once per workgroup (0: every wave reads them)
  *   "graph" (1), "pinned_frames" (4): host-pointer extractor calls
  *   "db_gemm_min_queries" (8): hfnet_db_query_batch switches to the MFMA form of the scores from this many queries on
+ *   "copy_threads" (64 = by core count): helper threads for the staging copies of host-pointer batch calls (replicas sharing a host)
+ * Values are >= 0.
  * Every setting of the extractor switches produces the same bits (tests/test_gpu_parity.py). */
 int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value);
 int hfnet_engine_get_option(hfnet_engine* e, const char* name, int* value);

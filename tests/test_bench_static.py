@@ -30,18 +30,43 @@ def test_layer_work_covers_the_launch_names():
 
 def test_traffic_file_matches_bench_lookup():
     import bench, glob, re
-    files = glob.glob(os.path.join(ROOT, bench.TRAFFIC_FILE.format(batch="*")))
+    files = [f for pat in bench.TRAFFIC_FILES for f in glob.glob(os.path.join(ROOT, pat.format(batch="*")))]
     if not files:
         import pytest
-        pytest.skip("no PMC traffic file committed for this round yet")
-    for path in files:
+        pytest.skip("no PMC traffic file committed yet")
+    seen = set()
+    for path in files:                                        # newest round first: the first file of a batch size is the one bench.py quotes
         b = int(re.search(r"_b(\d+)\.json$", path).group(1))
+        if b in seen:
+            continue
+        seen.add(b)
         t = json.load(open(path))
         assert t["batch"] == b and "conv3x3_det" in t["kernels"]
         k = t["kernels"]["conv3x3_det"]
-        assert bench.hbm_traffic("conv3x3_det", b) == (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0
-        assert bench.hbm_traffic("no_such_launch", b) is None
-    assert bench.hbm_traffic("conv3x3_det", 7) is None
+        val, src = bench.hbm_traffic("conv3x3_det", b)
+        assert val == (2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0 and os.path.join(ROOT, src) == path
+        assert bench.hbm_traffic("no_such_launch", b) == (None, None)
+    assert bench.hbm_traffic("conv3x3_det", 7) == (None, None)
+
+
+def test_roofline_classes_and_table():
+    """every launch name of a profile lands in a class; the memory-bound launches are priced against the HBM roof and listed
+    even though each one is small (the class carries >= 2 %)"""
+    import bench
+    w = bench.layer_work(64)
+    prof = {"conv3x3_det": (1.0, 1.6), "block_L07": (1.0, 1.05), "stem_block_L02": (1.0, 0.55), "nms": (1.0, 0.2), "softmax_d2s": (1.0, 0.1),
+            "sample": (1.0, 0.1), "pyramid_resize": (3.0, 0.09), "depthwise_L15": (1.0, 0.04), "expand_L16": (1.0, 0.06), "match_bow": (1.0, 0.44),
+            "topk": (1.0, 0.03), "fc_l2": (1.0, 0.09), "unknown_launch": (1.0, 0.01)}
+    total = sum(v[1] for v in prof.values()) * 1e-3
+    table, classes = bench.roofline_table(prof, w, total)
+    assert set(classes) == {"fused_block", "head_gemm", "global_gemm", "match", "hbm_stream"}
+    assert classes["hbm_stream"]["bound"] == "hbm" and 0 < classes["hbm_stream"]["frac"] < 1
+    assert abs(sum(c["share"] for c in classes.values()) - (total - 1e-5) / total) < 1e-6
+    names = {r["name"]: r for r in table}
+    for n in ("nms", "softmax_d2s", "sample", "pyramid_resize", "depthwise_L15"):
+        assert names[n]["bound"] == "hbm" and names[n]["class"] == "hbm_stream", n
+    assert names["conv3x3_det"]["bound"] == "mfma" and "unknown_launch" not in names
+    assert 0.9e9 < bench.extractor_algorithmic_bytes(bench.layer_work(1)) < 1.15e9      # SURVEY.md 8d: ~1 GB per 752x480 frame
 
 
 def test_roofline_entry_picks_the_binding_roof():

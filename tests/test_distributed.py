@@ -58,3 +58,30 @@ def test_sequence_assignment_is_balanced():
     assert shard.split_even(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
     with pytest.raises(ValueError):
         shard.frame_block(2, 2, 4)
+
+
+def test_bench_dry_ranks_runs_the_two_rank_control_flow(tmp_path):
+    """bench.py --gpus 2 --dry-ranks 2: the same main() the driver launches with torchrun -- rendezvous from the environment,
+    per-rank frame blocks, config 4's sequence plan, barriers, MAX over ranks, one JSON line from rank 0 -- with a timed no-op
+    in place of the GPU work (this box has no GPU; the N > 1 path cannot run otherwise)."""
+    import json
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-ranks", "2", "--steps", "2", "--warmup", "1",
+                                       "--batch", "128", "--configs", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    json_lines = lambda text: [l for l in text.splitlines() if l.startswith("{")]           # (gloo logs its rendezvous to stdout)
+    assert json_lines(outs[1][0]) == [] and len(json_lines(outs[0][0])) == 1, "rank 0 prints the one line"
+    line = json.loads(json_lines(outs[0][0])[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and "invalid" in line and line["scaling"] == "weak"
+    assert line["value"] > 0 and abs(line["value"] - 2 * 128 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    c4 = line["configs"]["4"]
+    assert c4["frames"] == 27049 and c4["gpus"] == 2 and c4["sequences"] == 11 and c4["frames_per_s"] > 0
+    # a world size that does not match --gpus is refused before anything is initialised
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-ranks", "2"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
