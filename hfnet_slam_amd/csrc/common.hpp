@@ -105,9 +105,15 @@ struct FcPack {
 };
 inline int fc_slot_of_logical(int i) { const int r = i & 15; return (i & ~15) | ((r & 3) << 2) | (r >> 2); }
 struct DwPack { int c = 0; float* w = nullptr; float* bias = nullptr; };  // [9][C] phys (BN folded)
+// a 1x1 convolution packed as v_mfma_f32_16x16x4_f32 B fragments for the single-frame kernels (kernels_tail.hip): MFMA m of
+// the chain consumes LOGICAL input channels 4m .. 4m+3 (lane / 16 picks one), a lane's 16 bytes are its operands of four
+// consecutive MFMAs, 16-wide column tiles in the PHYSICAL column order of the output tensor.  Same folded values as the
+// ConvPack of the layer (its bias array is shared).
+struct ConvPack16 { int cin = 0, n = 0, n16 = 0; float* w = nullptr; };   // device: [ceil(cin/16)][n16][64 lanes][4], zero padded
 struct BlockPack {
     int cin, expand, stride, cout, residual, has_expand;
     ConvPack ex; DwPack dw; ConvPack pr;
+    ConvPack16 pr16, ex16;         // projection / expansion for k_dwproject (layers 8-18 / 9-18)
     float* pr_logical = nullptr;   // projection weights [k logical][n physical] for the vector-ALU layer_2 kernel
 };
 
@@ -117,6 +123,7 @@ struct DeviceWeights {
     float* stem_bias = nullptr;
     BlockPack blocks[17];
     ConvPack desc1, desc2, det1, det2, memb;
+    ConvPack16 memb16;            // the memberships conv as the "next 1x1" of layer 18's k_dwproject
     float* clusters = nullptr;    // [K][D] logical
     FcPack fc;                    // dimensionality reduction 7680 -> 4096
     std::vector<void*> allocations;

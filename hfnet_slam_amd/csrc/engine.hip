@@ -18,7 +18,7 @@ int* Options::find(const char* name) {
     const struct { const char* n; int* p; } tab[] = {{"fuse_blocks", &fuse_blocks}, {"fuse_max_layer", &fuse_max_layer}, {"fused_variant", &fused_variant},
                                                        {"fuse_stem", &fuse_stem}, {"dense_desc", &dense_desc}, {"two_streams", &two_streams},
                                                        {"graph", &graph}, {"pinned_frames", &pinned_frames}, {"db_gemm_min_queries", &db_gemm_min_queries},
-                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}};
+                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}};
     for (const auto& t : tab) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -116,7 +116,7 @@ int Net::build(Engine* eng, const NetConfig& c) {
     e = eng;
     cfg = c;
     // A/B and diagnostics switches of the engine (hfnet_engine_set_option), fixed for the lifetime of this network
-    fuse_blocks = e->opt.fuse_blocks; fuse_max_layer = e->opt.fuse_max_layer; fused_variant = e->opt.fused_variant; fuse_min_wgs = e->opt.fuse_min_wgs;
+    fuse_blocks = e->opt.fuse_blocks; fuse_max_layer = e->opt.fuse_max_layer; fused_variant = e->opt.fused_variant; fuse_min_wgs = e->opt.fuse_min_wgs; tail_fuse = e->opt.tail_fuse;
     force_dense = e->opt.dense_desc; fuse_stem = e->opt.fuse_stem; conv_wlds = e->opt.conv_wlds;
     const DeviceWeights& w = e->w;
     if (c.n_levels < 1 || c.n_levels > HFNET_MAX_LEVELS || c.batch < 1) { set_error("net: bad level / batch count"); return HFNET_ERR_INVALID_ARG; }
@@ -163,7 +163,7 @@ int Net::build(Engine* eng, const NetConfig& c) {
     }
     // layers 8.. only cover level 0, but their input (layer 7) buffer spans all levels: size by level-0 pixels
     HF_TRY(dalloc(allocs, &exp_buf, exp_max));
-    HF_TRY(dalloc(allocs, &dw_buf, dw_max));
+    HF_TRY(dalloc(allocs, &dw_buf, std::max(dw_max, exp_max)));   // (the single-frame chain ping-pongs expanded tensors between the two)
     if (c.local) {
         const size_t pc = (size_t)pix_cell[HFNET_MAX_LEVELS], pi = (size_t)pix_img[HFNET_MAX_LEVELS];
         HF_TRY(dalloc(allocs, &desc_hidden, pc * HFNET_DESC_DIM));
@@ -196,6 +196,7 @@ int Net::build(Engine* eng, const NetConfig& c) {
         HF_TRY(dalloc(allocs, &vlad_tap, (size_t)c.batch * N));
         HF_TRY(dalloc(allocs, &vlad_out, (size_t)c.batch * N));
         HF_TRY(dalloc(allocs, &fc_raw, (size_t)c.batch * w.global_dim));
+        HF_TRY(dalloc(allocs, &fc_part, fc_scratch_floats(w.fc, c.batch)));
         HF_TRY(dalloc(allocs, &global_out, (size_t)c.batch * w.global_dim));
     }
     HF_TRY(dalloc(allocs, &inter_logical, (size_t)c.batch * lp[0].h[7] * lp[0].w[7] * w.c_local));
@@ -231,13 +232,10 @@ Geom Net::geom(int layer_in, int layer_out, int first_level, int n_used) const {
     return g;
 }
 
-static int run_block(Net& n, int L, int n_used, hipStream_t st) {   // layer L = block L-2, input act[L-1]
-    Engine* e = n.e;
-    const BlockPack& b = e->w.blocks[L - 2];
-    const long long p_in = n.pix[L - 1][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
-    const long long p_out = n.pix[L][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
-    // fused launch: always for the high-resolution layers; for the 30x47 layers only when the batch gives
-    // the launch enough workgroups to fill the chip (measured: 96 WGs lose to three launches, 384 win)
+// fused launch: always for the high-resolution layers; for the 30x47 layers only when the batch gives
+// the launch enough workgroups to fill the chip (measured: 96 WGs lose to three launches, 384 win)
+static bool block_runs_fused(const Net& n, int L) {
+    const BlockPack& b = n.e->w.blocks[L - 2];
     bool fuse = n.fuse_blocks && L <= n.fuse_max_layer && block_fusable(b, n.fused_variant);
     if (fuse && L > 7) {
         const LevelPlan& p0 = n.lp[0];
@@ -245,6 +243,15 @@ static int run_block(Net& n, int L, int n_used, hipStream_t st) {   // layer L =
         const long long wgs = (long long)((p0.w[L] + 15) / 16) * ((p0.h[L] + 7) / 8) * n.cfg.batch;
         fuse = wgs >= n.fuse_min_wgs;
     }
+    return fuse;
+}
+
+static int run_block(Net& n, int L, int n_used, hipStream_t st) {   // layer L = block L-2, input act[L-1]
+    Engine* e = n.e;
+    const BlockPack& b = e->w.blocks[L - 2];
+    const long long p_in = n.pix[L - 1][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
+    const long long p_out = n.pix[L][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
+    const bool fuse = block_runs_fused(n, L);
     if (fuse) {
         char fn[32];
         snprintf(fn, sizeof fn, "block_L%02d", L);
@@ -301,12 +308,10 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
     // few frames per call: the global branch (a chain of ~40 small launches) is the critical path, the detector conv does not
     // fill the chip -- fork right after layer 7 (0.852 -> 0.840 ms per 752x480 frame)
     const bool fork_early = fork && (two_streams == 1 || (!defer && cfg.batch <= 4));
-    if (fork_early) {
-        HF_HIP(hipEventRecord(ev_fork, stream));
-        HF_HIP(hipStreamWaitEvent(stream_global, ev_fork, 0));
-        HF_TRY(forward_global(stream_global));
-        HF_HIP(hipEventRecord(ev_join, stream_global));
-    }
+    // (The fork point is recorded here, but the branch itself is enqueued AFTER the local heads: a captured graph hands its
+    //  nodes to the queues in creation order at ~6 us per node, and with the ~35 launches of the global branch first the
+    //  local heads of a single frame started 200 us after layer 7 had finished -- both branches ended together at 620 us.)
+    if (fork_early) HF_HIP(hipEventRecord(ev_fork, stream));
     if (cfg.local) {
         const long long pc = pix_cell[HFNET_MAX_LEVELS];
         Geom gh = geom(7, 7, 0, NL);
@@ -349,6 +354,11 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
             HF_TRY(run_dense_desc());
         }
     }
+    if (fork_early) {
+        HF_HIP(hipStreamWaitEvent(stream_global, ev_fork, 0));
+        HF_TRY(forward_global(stream_global));
+        HF_HIP(hipEventRecord(ev_join, stream_global));
+    }
     if (cfg.global && fork && defer) join_pending = true;
     else if (cfg.global && fork) HF_HIP(hipStreamWaitEvent(stream, ev_join, 0));
     else if (cfg.global) HF_TRY(forward_global(stream));
@@ -356,14 +366,42 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
 }
 
 // layers 8-18, NetVLAD, dimensionality reduction on stream st
+// few frames per call (what Tracking does): the chain of ~35 small launches of layers 8-18 is the critical path of the call.
+// Single-frame kernels (kernels_tail.hip): one launch per block -- depthwise + projection (+ residual) + the NEXT block's
+// expansion, the NetVLAD memberships conv after layer 18 -- with every accumulation chain on the short-latency MFMA.
+bool Net::tail_chain() const {
+    const DeviceWeights& w = e->w;
+    if (!tail_fuse || cfg.batch > tail_fuse || !w.memb16.w || w.memb16.cin != w.blocks[16].cout) return false;
+    for (int L = 8; L <= 18; ++L) {
+        const BlockPack& b = w.blocks[L - 2];
+        if (!dwproject_supported(b) || block_runs_fused(*this, L) || (L > 8 && (!b.ex16.w || b.ex16.cin != w.blocks[L - 3].cout))) return false;
+    }
+    return true;
+}
+
 int Net::forward_global(hipStream_t st) {
     const DeviceWeights& w = e->w;
-    for (int L = 8; L <= 18; ++L) HF_TRY(run_block(*this, L, 1, st));
     const int P = lp[0].h[18] * lp[0].w[18];
-    HF_LAUNCH(e, st, "pointwise_memberships", launch_pointwise(act[18], w.memb, nullptr, memb, (long long)cfg.batch * P, 0, st));
+    if (tail_chain()) {
+        // expanded tensors ping-pong between exp_buf and dw_buf (the depthwise tensor itself never exists on this path)
+        float* ebuf[2] = {exp_buf, dw_buf};
+        HF_LAUNCH(e, st, "expand_L08", launch_pointwise(act[7], w.blocks[6].ex, nullptr, ebuf[0], pix[7][1], 1, st));
+        for (int L = 8; L <= 18; ++L) {
+            const BlockPack& b = w.blocks[L - 2];
+            const ConvPack16* next = L < 18 ? &w.blocks[L - 1].ex16 : &w.memb16;
+            const float* next_bias = L < 18 ? w.blocks[L - 1].ex.bias : w.memb.bias;
+            char fn[32];
+            snprintf(fn, sizeof fn, "tail_block_L%02d", L);
+            HF_LAUNCH(e, st, fn, launch_dwproject(ebuf[L & 1], b, b.residual ? act[L - 1] : nullptr, act[L], next, next_bias,
+                                                  L < 18 ? ebuf[(L + 1) & 1] : memb, L < 18 ? 1 : 0, geom(L - 1, L, 0, 1), st));
+        }
+    } else {
+        for (int L = 8; L <= 18; ++L) HF_TRY(run_block(*this, L, 1, st));
+        HF_LAUNCH(e, st, "pointwise_memberships", launch_pointwise(act[18], w.memb, nullptr, memb, (long long)cfg.batch * P, 0, st));
+    }
     HF_LAUNCH(e, st, "softmax_memberships", launch_softmax_rows(memb, (long long)cfg.batch * P, w.n_clusters, w.n_clusters, st));
     HF_LAUNCH(e, st, "vlad", launch_vlad(act[18], memb, w.clusters, vlad_tap, vlad_out, vlad_raw, cfg.batch, P, w.c_global, w.n_clusters, st));
-    HF_LAUNCH(e, st, "fc_l2", launch_fc_l2(vlad_out, w.fc, fc_raw, global_dst ? global_dst : global_out, cfg.batch, st));
+    HF_LAUNCH(e, st, "fc_l2", launch_fc_l2(vlad_out, w.fc, fc_part, fc_raw, global_dst ? global_dst : global_out, cfg.batch, st));
     return HFNET_OK;
 }
 

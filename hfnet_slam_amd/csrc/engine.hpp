@@ -97,6 +97,7 @@ struct Options {
     int pinned_frames = 4;    // chunks up to this many frames move through one pinned block inside that graph
     int conv_wlds = 1;        // 3x3 heads: weights staged through LDS once per workgroup (0: every wave reads them from L1 / L2)
     int db_gemm_min_queries = 8;   // hfnet_db_query_batch: from this many queries on, the scores come from the MFMA GEMM form
+    int tail_fuse = 4;        // calls of up to this many frames run layers 8-18 with the single-frame kernels (0: never)
     int copy_threads = 64;    // helper threads of the host-pointer batch pipeline's staging copies (>= 64: chosen from the core count)
     int fuse_min_wgs = 256;   // layers 8-14 take their fused kernel from this many 128-pixel tiles per launch on (0: always; tests)
     int* find(const char* name);
@@ -168,6 +169,7 @@ struct Net {
     int fuse_max_layer = 14;
     int fused_variant = 4;
     int fuse_min_wgs = 256;
+    int tail_fuse = 4;
     int fuse_stem = 1;             // stem + layer_2 in one launch: the stem tensor is not materialised (its tap recomputes it on demand)
     int conv_wlds = 1;             // 3x3 heads with LDS-staged weights
     ImageSet last_imgs;            // input of the last forward (for that tap)
@@ -181,7 +183,7 @@ struct Net {
     long long cand_stride = 0;
     hfnet_keypoint* kps_level = nullptr;       // [image][max_keypoints]
     int* n_level = nullptr;                    // [image]
-    float *memb = nullptr, *vlad_raw = nullptr, *vlad_tap = nullptr, *vlad_out = nullptr, *fc_raw = nullptr, *global_out = nullptr;
+    float *memb = nullptr, *vlad_raw = nullptr, *vlad_tap = nullptr, *vlad_out = nullptr, *fc_raw = nullptr, *fc_part = nullptr, *global_out = nullptr;
     float* inter_logical = nullptr;            // level-0 layer_7 map in logical order [batch x hd x wd x C]
     int build(Engine* eng, const NetConfig& c);
     void release();
@@ -194,6 +196,7 @@ struct Net {
     int tap(int id, std::vector<float>& out);
     int run_dense_desc();
     int forward_global(hipStream_t st);
+    bool tail_chain() const;       // layers 8-18 run as one launch per block (single-frame kernels)
     const float* sample_source() const { return last_sparse ? rows_raw : desc_norm; }   // sparse rows are normalised by k_sample
     ~Net() { release(); }
 };

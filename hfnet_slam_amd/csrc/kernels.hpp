@@ -42,6 +42,16 @@ hipError_t launch_stem_block(const ImageSet& imgs, const float* stem_w, const fl
 // channel-order conversion between the device layout and NHWC logical order (boundary tensors)
 hipError_t launch_permute_channels(const float* in, float* out, long long P, int C, int to_logical, hipStream_t s);
 
+// ---- kernels_tail.hip ---------------------------------------------------------------------------
+// single-frame path of layers 8-18: depthwise 3x3 + BN + ReLU6 and the 1x1 projection + BN [+ residual] in one launch, the
+// projection as v_mfma_f32_16x16x4_f32 chains (a quarter of the 32x32x2 chain's latency); `expanded`: the block's expanded
+// tensor (output of its expansion conv).  Same bits as launch_depthwise + launch_pointwise.
+bool dwproject_supported(const BlockPack& b);
+// next (optional): the 1x1 convolution that consumes the block's output -- the next block's expansion (next_relu 1) or the
+// NetVLAD memberships conv (0) -- evaluated in the same launch: next_out[pixel][next->n] = act(out[pixel] * W + next_bias)
+hipError_t launch_dwproject(const float* expanded, const BlockPack& b, const float* residual, float* out, const ConvPack16* next,
+                            const float* next_bias, float* next_out, int next_relu, const Geom& g, hipStream_t s);
+
 // ---- kernels_detect.hip -------------------------------------------------------------------------
 // softmax(65) -> drop dustbin -> depth_to_space(8) (hf_net.py:88-93); logits row stride ld
 hipError_t launch_softmax_d2s(const float* logits, int ld, float* dense, const Geom& g, hipStream_t s);
@@ -90,9 +100,11 @@ hipError_t launch_softmax_rows(float* x, long long rows, int n, int ld, hipStrea
 hipError_t launch_vlad(const float* feat /*phys layout [frames x P x D]*/, const float* memb /*[frames x P x K]*/,
                        const float* clusters, float* vlad_tap /*[frames x K*D] or null*/, float* out /*[frames x K*D]*/,
                        float* scratch /*[frames x K*D]*/, int frames, int P, int D, int K, hipStream_t s);
-// dimensionality reduction: FC + bias as one MFMA GEMM over the frames of the batch (weights cross HBM once) + L2
-// normalise (layers.py:98-108).  x: [frames][n_in] in the FC slot order (fc_slot_of_logical), pack: FcPack of weights.cpp
-hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* y_raw, float* out, int frames, hipStream_t s);
+// dimensionality reduction: FC + bias as one MFMA GEMM over the frames of the batch, split 16 ways along the inputs (weights
+// cross HBM once, 4096 workgroups stream them) + L2 normalise (layers.py:98-108).  x: [frames][n_in] in the FC slot order
+// (fc_slot_of_logical), pack: FcPack of weights.cpp; partial: fc_scratch_floats() floats
+size_t fc_scratch_floats(const FcPack& fc, int frames);
+hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* partial, float* y_raw, float* out, int frames, hipStream_t s);
 
 // ---- kernels_match.hip --------------------------------------------------------------------------
 // BFMatcher(NORM_L2, crossCheck) + distance < th_low (Matcher.cc:229-260), batched over descriptor-set pairs.

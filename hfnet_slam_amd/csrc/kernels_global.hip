@@ -2,6 +2,7 @@
 // The memberships 1x1 conv runs on the MFMA pointwise kernel; everything after it is here.
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <type_traits>
 #include <utility>
 
@@ -156,23 +157,24 @@ hipError_t launch_vlad(const float* feat, const float* memb, const float* cluste
     return hipGetLastError();
 }
 
-// y[f][j] = b[j] + sum_i x[f][i] * W[i][j], i ascending: slim.fully_connected (layers.py:99-107) as ONE GEMM over the
-// frames of the batch on v_mfma_f32_16x16x4_f32 (bit-for-bit the k-ordered fma chain from C = b[j], like every other
-// matmul of the path).  A wave owns 16 frames x 16 outputs and walks the whole chain: n_in / 4 dependent MFMAs (40 cycles
-// each) -- 32 us for 7680 inputs, about what streaming the 126 MB of weights from HBM takes; the 512 waves of a 32-frame
-// batch put one chain on every other SIMD.  Operands of four consecutive MFMAs are one 16-byte load per lane (FcPack,
-// common.hpp); NBUF groups are in flight per lane to cover the HBM latency.  A workgroup is the two 16-frame row tiles of
-// ONE column tile (two waves in step: the second wave's weight loads hit L1), one workgroup per column tile: the 126 MB of
-// weights cross HBM and every CU's load path once per 32 frames (a CU sustains ~10 B/clk of loads -- with four column
-// tiles per workgroup on half the CUs that alone took 80 us).
+// y[f][j] = b[j] + sum_i x[f][i] * W[i][j]: slim.fully_connected (layers.py:99-107) as ONE GEMM over the frames of the
+// batch on v_mfma_f32_16x16x4_f32, split FC_PARTS ways along the inputs: a wave owns 16 frames x 16 outputs x one input
+// range and walks its k-ascending fma chain from 0 (n_in / 64 dependent MFMAs); k_fc_combine_l2 adds the partial sums as
+// a balanced binary tree, then the bias -- the oracle's order (oracle/hfnet_oracle.c global_head), chosen for this kernel:
+// the single chain of round 2 was 1920 dependent MFMAs per output tile (33 us however many frames) and left one 480 KB
+// weight panel per workgroup in flight (256 workgroups: ~2 TB/s); 4096 workgroups of 30 KB each stream the 126 MB at the
+// rate HBM delivers them, for one frame as for 64.  Operands of four consecutive MFMAs are one 16-byte load per lane
+// (FcPack, common.hpp); NBUF groups are in flight per lane.  A workgroup is up to four 16-frame row tiles of ONE column
+// tile and input range (waves in step: the later waves' weight loads hit L1).
+#define FC_PARTS 16
 template <class F, int... I>
 __device__ __forceinline__ void fc_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F>
 __device__ __forceinline__ void fc_static_for(F&& f) { fc_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 template <int NBUF>
-__global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                 float* __restrict__ y, int frames, int n_in, int n_out) {
+__global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y /* [FC_PARTS][frames][n_out] */,
+                                                 int frames, int n_in, int n_out, int parts_per_wg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ctiles = n_out >> 4, ct = blockIdx.x, rt = blockIdx.y * 4 + wave;   // up to four row tiles share a weight panel through L1
     if (rt * 16 >= frames) return;
@@ -180,13 +182,17 @@ __global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ x, co
     const f32x4* __restrict__ ap = (const f32x4*)(x + (long long)row * n_in) + (lane >> 4);
     const f32x4* __restrict__ wp = (const f32x4*)w + (size_t)ct * 64 + lane;
     const size_t wstep = (size_t)ctiles * 64;
-    const int KG = n_in >> 4;
-    const float b = bias[ct * 16 + (lane & 15)];
-    f32x4 acc = {b, b, b, b};
+    const int KG_all = n_in >> 4, gp = (KG_all + FC_PARTS - 1) / FC_PARTS;
+    const int col = ct * 16 + (lane & 15);
     f32x4 av[NBUF], bv[NBUF];
+    // (many frames per call: a workgroup walks several input ranges one after the other -- fewer, longer-lived workgroups
+    //  stream the weights better than 4096 short ones next to the other stream's kernels; one accumulator chain per range)
+    for (int part = blockIdx.z * parts_per_wg; part < (int)(blockIdx.z + 1) * parts_per_wg; ++part) {
+    const int kg0 = min(part * gp, KG_all), KG = min((part + 1) * gp, KG_all);      // this part's groups of 16 inputs: [kg0, KG)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     auto load = [&](int kg, auto buf_tag) {
         constexpr int buf = decltype(buf_tag)::value;
-        kg = min(kg, KG - 1);                          // unconditional (see k_pointwise_deep)
+        kg = min(kg, KG_all - 1);                      // unconditional (see k_pointwise_deep)
         av[buf] = ap[kg * 4];
         bv[buf] = wp[(size_t)kg * wstep];
     };
@@ -197,8 +203,8 @@ __global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ x, co
             for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][t], bv[buf][t], acc, 0, 0, 0);
         }
     };
-    fc_static_for<NBUF - 1>([&](auto i) { load(decltype(i)::value, i); });
-    for (int kg = 0; kg < KG; kg += NBUF) {
+    fc_static_for<NBUF - 1>([&](auto i) { load(kg0 + decltype(i)::value, i); });
+    for (int kg = kg0; kg < KG; kg += NBUF) {
         fc_static_for<NBUF>([&](auto i) {
             constexpr int I = decltype(i)::value;
             load(kg + I + NBUF - 1, std::integral_constant<int, (I + NBUF - 1) % NBUF>{});
@@ -207,14 +213,43 @@ __global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ x, co
             __builtin_amdgcn_sched_barrier(0);
         });
     }
-    const int col = ct * 16 + (lane & 15);
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int rr = rt * 16 + (lane >> 4) * 4 + reg;
-        if (rr < frames) y[(long long)rr * n_out + col] = acc[reg];
+        if (rr < frames) y[((long long)part * frames + rr) * n_out + col] = acc[reg];
+    }
     }
 }
 
+__device__ __forceinline__ float fc_combine_one(const float* __restrict__ partial, const float* __restrict__ bias, int frames, int n, int f, int i) {
+    float p[FC_PARTS];
+#pragma unroll
+    for (int q = 0; q < FC_PARTS; ++q) p[q] = partial[((long long)q * frames + f) * n + i];
+#pragma unroll
+    for (int m = FC_PARTS; m > 1; m >>= 1)
+#pragma unroll
+        for (int q = 0; q < m / 2; ++q) p[q] = p[2 * q] + p[2 * q + 1];
+    return p[0] + bias[i];
+}
+
+// partial sums [FC_PARTS][frames][n] -> y = tree + bias (kept in y_raw), then the L2 normalisation of layers.py:108.
+// One launch for the single-frame path (a workgroup per frame) ...
+__global__ __launch_bounds__(256) void k_fc_combine_l2(const float* __restrict__ partial, const float* __restrict__ bias, float* __restrict__ y_raw,
+                                                       float* __restrict__ out, int frames, int n) {
+    __shared__ float red[256];
+    const int f = blockIdx.x;
+    float* v = y_raw + (long long)f * n;
+    for (int i = threadIdx.x; i < n; i += 256) v[i] = fc_combine_one(partial, bias, frames, n, f, i);
+    __syncthreads();
+    const float ss = block_sumsq_tree256(v, n, red);
+    const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+    for (int i = threadIdx.x; i < n; i += 256) out[(long long)f * n + i] = v[i] * inv;
+}
+// ... two for many frames (the 17 MB of partial sums of a 64-frame call want more than 64 workgroups)
+__global__ __launch_bounds__(256) void k_fc_combine(const float* __restrict__ partial, const float* __restrict__ bias, float* __restrict__ y_raw, int frames, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (i < n) y_raw[(long long)f * n + i] = fc_combine_one(partial, bias, frames, n, f, i);
+}
 __global__ __launch_bounds__(256) void k_l2norm_vec(const float* __restrict__ in, float* __restrict__ out, int n) {
     __shared__ float red[256];
     const float* v = in + (long long)blockIdx.x * n;
@@ -223,11 +258,20 @@ __global__ __launch_bounds__(256) void k_l2norm_vec(const float* __restrict__ in
     for (int i = threadIdx.x; i < n; i += 256) out[(long long)blockIdx.x * n + i] = v[i] * inv;
 }
 
-hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* y_raw, float* out, int frames, hipStream_t s) {
+size_t fc_scratch_floats(const FcPack& fc, int frames) { return (size_t)FC_PARTS * (size_t)frames * (size_t)fc.n_out; }
+
+hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* partial, float* y_raw, float* out, int frames, hipStream_t s) {
     if (frames <= 0) return hipSuccess;
     if (fc.n_in % 16 || fc.n_out % 16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_fc_mfma<16>, dim3(fc.n_out / 16, (frames + 63) / 64), dim3(frames > 32 ? 256 : 128), 0, s, x, fc.w, fc.bias, y_raw, frames, fc.n_in, fc.n_out);
-    hipLaunchKernelGGL(k_l2norm_vec, dim3(frames), dim3(256), 0, s, y_raw, out, fc.n_out);
+    const int waves = std::min(4, (frames + 15) / 16);
+    const int ppw = frames > 16 ? 4 : 1;
+    hipLaunchKernelGGL(k_fc_mfma<16>, dim3(fc.n_out / 16, (frames + 63) / 64, FC_PARTS / ppw), dim3(64 * waves), 0, s, x, fc.w, partial, frames, fc.n_in, fc.n_out, ppw);
+    if (frames <= 4) {
+        hipLaunchKernelGGL(k_fc_combine_l2, dim3(frames), dim3(256), 0, s, partial, fc.bias, y_raw, out, frames, fc.n_out);
+    } else {
+        hipLaunchKernelGGL(k_fc_combine, dim3((fc.n_out + 255) / 256, frames), dim3(256), 0, s, partial, fc.bias, y_raw, frames, fc.n_out);
+        hipLaunchKernelGGL(k_l2norm_vec, dim3(frames), dim3(256), 0, s, y_raw, out, fc.n_out);
+    }
     return hipGetLastError();
 }
 

@@ -121,7 +121,7 @@ static int upload(DeviceWeights& dw, const std::vector<float>& h, float** out) {
 // W: HWIO [taps][cin][n] in logical channel order.  Input channels are consumed in the physical
 // order of common.hpp; output columns are emitted in physical order when `out_phys`.
 static int pack_conv(DeviceWeights& dw, const float* W, int taps, int cin, int n, const float* scale_l,
-                     const float* shift_l, bool out_phys, ConvPack& cp) {
+                     const float* shift_l, bool out_phys, ConvPack& cp, ConvPack16* p16 = nullptr) {
     if (cin % 8 != 0 || (out_phys && n % 8 != 0)) { set_error("pack_conv: channel count not a multiple of 8 (cin=%d n=%d)", cin, n); return HFNET_ERR_IO; }
     cp.taps = taps; cp.cin = cin; cp.n = n;
     const int tiles = (n + 31) / 32;
@@ -148,17 +148,37 @@ static int pack_conv(DeviceWeights& dw, const float* W, int taps, int cin, int n
     }
     HF_TRY(upload(dw, w, &cp.w));
     HF_TRY(upload(dw, sh, &cp.bias));
+    if (p16 && taps == 1) {
+        // the same folded values as 16x16x4 B fragments (ConvPack16, common.hpp); an input width that is not a multiple of 16
+        // is padded with zero weights (the kernels pad the activations with zeros: fma(0, 0, acc) == acc)
+        const int n16 = (n + 15) / 16, kb16 = (cin + 15) / 16;
+        std::vector<float> w16((size_t)kb16 * n16 * 64 * 4, 0.f);
+        for (int kb = 0; kb < kb16; ++kb)
+            for (int nt = 0; nt < n16; ++nt)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int j = nt * 16 + (lane & 15), g = lane >> 4;
+                    if (j >= n) continue;
+                    const int nl = out_phys ? logical_of_phys(j) : j;
+                    for (int t = 0; t < 4; ++t) {
+                        const int k = kb * 16 + 4 * t + g;
+                        if (k < cin) w16[(((size_t)kb * n16 + nt) * 64 + lane) * 4 + t] = W[(size_t)k * n + nl] * scale_l[nl];
+                    }
+                }
+        p16->cin = cin; p16->n = n; p16->n16 = n16;
+        HF_TRY(upload(dw, w16, &p16->w));
+    }
     return HFNET_OK;
 }
 
-static int pack_conv_bn(DeviceWeights& dw, const WeightFile& wf, const std::string& scope, bool out_phys, ConvPack& cp, int* n_out) {
+static int pack_conv_bn(DeviceWeights& dw, const WeightFile& wf, const std::string& scope, bool out_phys, ConvPack& cp, int* n_out,
+                        ConvPack16* p16 = nullptr) {
     const HostTensor* w = wf.find(scope + "/weights");
     if (!w || w->ndim != 4) { set_error("weights: '%s/weights' missing", scope.c_str()); return HFNET_ERR_IO; }
     const int taps = w->dims[0] * w->dims[1], cin = w->dims[2], n = w->dims[3];
     Folded f;
     HF_TRY(fold_bn(wf, scope, n, f));
     if (n_out) *n_out = n;
-    return pack_conv(dw, w->data, taps, cin, n, f.scale.data(), f.shift.data(), out_phys, cp);
+    return pack_conv(dw, w->data, taps, cin, n, f.scale.data(), f.shift.data(), out_phys, cp, p16);
 }
 
 // 1x1 conv with biases and no normaliser (hf_net.py:66-72): scale 1 (w * 1.0f is exact), accumulators start at b
@@ -218,10 +238,10 @@ int DeviceWeights::build(const WeightFile& wf) {
         b.stride = kStrides[i];
         b.has_expand = wf.find(scope + "/expand/weights") != nullptr;
         b.expand = cin;
-        if (b.has_expand) HF_TRY(pack_conv_bn(*this, wf, scope + "/expand", true, b.ex, &b.expand));
+        if (b.has_expand) HF_TRY(pack_conv_bn(*this, wf, scope + "/expand", true, b.ex, &b.expand, i >= 7 ? &b.ex16 : nullptr));   // (layers 9-18)
         HF_TRY(pack_dw(*this, wf, scope + "/depthwise", b.dw));
         if (b.dw.c != b.expand) { set_error("block %d: depthwise width %d != expansion %d", i, b.dw.c, b.expand); return HFNET_ERR_IO; }
-        HF_TRY(pack_conv_bn(*this, wf, scope + "/project", true, b.pr, &b.cout));
+        HF_TRY(pack_conv_bn(*this, wf, scope + "/project", true, b.pr, &b.cout, i >= 6 ? &b.pr16 : nullptr));   // (layers 8-18: single-frame kernels)
         if (b.pr.cin != b.expand || (b.has_expand && b.ex.cin != cin)) { set_error("block %d: channel mismatch", i); return HFNET_ERR_IO; }
         b.residual = (b.stride == 1 && b.cin == b.cout);   // conv_blocks.py:304-311
         if (!b.has_expand) {
@@ -248,7 +268,7 @@ int DeviceWeights::build(const WeightFile& wf) {
     HF_TRY(pack_conv_bn(*this, wf, "local_head/detector/Conv", true, det1, &det_hidden));
     HF_TRY(pack_conv_bias(*this, wf, "local_head/detector/Conv_1", det2, &n));
     if (n != 65 || det2.cin != det_hidden) { set_error("detector head shape mismatch"); return HFNET_ERR_IO; }
-    HF_TRY(pack_conv_bn(*this, wf, "global_head/vlad/memberships", false, memb, &n_clusters));
+    HF_TRY(pack_conv_bn(*this, wf, "global_head/vlad/memberships", false, memb, &n_clusters, &memb16));
     if (memb.cin != c_global) { set_error("memberships conv width mismatch"); return HFNET_ERR_IO; }
     const HostTensor* cl = wf.find("global_head/vlad/clusters");
     const HostTensor* fw = wf.find("global_head/dimensionality_reduction/weights");

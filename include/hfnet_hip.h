@@ -84,6 +84,8 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *   "conv_wlds" (1)     3x3 head convolutions: weights staged through LDS once per workgroup (0: every wave reads them)
  *   "graph" (1), "pinned_frames" (4): host-pointer extractor calls
  *   "db_gemm_min_queries" (8): hfnet_db_query_batch switches to the MFMA form of the scores from this many queries on
+ *   "tail_fuse" (4)     calls of up to this many frames run layers 8-18 with the single-frame kernels (depthwise + projection
+ *                       in one launch, short-latency MFMA chains); 0: never
  *   "copy_threads" (64 = by core count): helper threads for the staging copies of host-pointer batch calls (replicas sharing a host)
  * Values are >= 0.
  * Every setting of the extractor switches produces the same bits (tests/test_gpu_parity.py). */

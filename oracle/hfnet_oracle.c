@@ -27,6 +27,8 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+
+#define HFO_FC_PARTS 16   /* partial chains of the dimensionality-reduction FC (see global_head) */
 #endif
 
 #define HFO_BN_EPS 1e-3f
@@ -425,15 +427,27 @@ static void global_head(const hfo_model* m, const float* feat, int h, int w, flo
     l2_normalize_vec(v, K * D);                                     /* layers.py:92 (flatten is K-major) */
     tap_copy(taps, HFO_TAP_VLAD, v, (size_t)K * D);
     l2_normalize_vec(v, K * D);                                     /* layers.py:97 */
-    const int G = m->global_dim, N = K * D;                         /* layers.py:99-107: x @ W + b as a matmul like any
-                                                                       other: accumulator from b[j], fma over i = 0..N-1 */
+    const int G = m->global_dim, N = K * D;                         /* layers.py:99-107: x @ W + b.  The reference leaves the order of
+                                                                       this 7680-term sum to Eigen; the canonical order here is the one a
+                                                                       GEMM split 16 ways along the inputs produces: HFO_FC_PARTS partial
+                                                                       fma chains from 0 (part p: the inputs of groups-of-16
+                                                                       [p * gp, (p + 1) * gp), gp = ceil(N / 16 / 16), ascending), added
+                                                                       as a balanced binary tree, then + b[j] */
     const float* wt = fc_weights_t(m);
+    const int gp = ((N + 15) / 16 + HFO_FC_PARTS - 1) / HFO_FC_PARTS;
 #pragma omp parallel for schedule(static)
     for (int j = 0; j < G; ++j) {
         const float* wr = wt + (size_t)j * N;
-        float acc = m->fc_b[j];
-        for (int i = 0; i < N; ++i) acc = fmaf(v[i], wr[i], acc);
-        out[j] = acc;
+        float part[HFO_FC_PARTS];
+        for (int p = 0; p < HFO_FC_PARTS; ++p) {
+            const int i0 = p * gp * 16 < N ? p * gp * 16 : N, i1 = (p + 1) * gp * 16 < N ? (p + 1) * gp * 16 : N;
+            float acc = 0.0f;
+            for (int i = i0; i < i1; ++i) acc = fmaf(v[i], wr[i], acc);
+            part[p] = acc;
+        }
+        for (int n = HFO_FC_PARTS; n > 1; n >>= 1)
+            for (int p = 0; p < n / 2; ++p) part[p] = part[2 * p] + part[2 * p + 1];
+        out[j] = part[0] + m->fc_b[j];
     }
     l2_normalize_vec(out, G);                                       /* layers.py:108 */
     free(mem); free(v);
