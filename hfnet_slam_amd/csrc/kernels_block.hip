@@ -1112,7 +1112,12 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
     const int nto = (b.cout + 31) / 32, kq = b.cin / 8, st = b.stride;
     const long long n_tiles = tile_grid_size<4, 8>(g);             // wave tiles of the k_block_fused4 launch
     const bool occ3 = n_tiles > 2048 || variant == 3;             // (variant 3: the three-waves-per-SIMD instantiations at any size -- tests)
-    switch (fused_kind(b, variant)) {
+    // A single frame has fewer wave tiles than the chip has SIMDs at two waves each: every wave of k_block_fused4 then runs
+    // alone and pays the latency of each of its phases in full, while the barrier-phased kernel puts four waves on a tile
+    // (752x480, one frame: layer 5 49 -> 20 us, layers 3-7 together 200 -> 150 us).  Same bits either way.
+    FusedKind kind = fused_kind(b, variant);
+    if (kind == FUSED_V4 && variant == 4 && n_tiles < 2048 && fused_kind(b, 2) == FUSED_V2) kind = FUSED_V2;
+    switch (kind) {
         case FUSED_NOEXPAND: {
             int maxtiles = 0;
             for (int l = 0; l < g.n_levels; ++l) maxtiles = max(maxtiles, ((g.lv[l].Wo + 15) / 16) * ((g.lv[l].Ho + 15) / 16));

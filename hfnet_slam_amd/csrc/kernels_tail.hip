@@ -97,6 +97,19 @@ __global__ __launch_bounds__(512) void k_dwproject(DwProjArgs a, Geom g) {
         ovalid[t] = oy < lv.Ho && ox < lv.Wo;
         orow[t] = obase + (long long)min(oy, lv.Ho - 1) * lv.Wo + min(ox, lv.Wo - 1);
     }
+    const float pb_first = a.pr_bias[min(nt_first, a.n16 - 1) * 16 + j];
+    // NEXT: this wave's first column tile of the next convolution -- bias and all weight pieces (cout <= 256: at most 16)
+    const int per = NEXT ? (a.nx_n16 + a.nsplit - 1) / a.nsplit : 0, xt_first = split * per + wave, xt_end = NEXT ? min((split + 1) * per, a.nx_n16) : 0;
+    const size_t xstep = (size_t)a.nx_n16 * 64;
+    constexpr int XVN = STRIDE == 2 ? 8 : 16;                    // (the stride-2 blocks have <= 128 output channels and many halo registers)
+    f32x4 xv[XVN];
+    float xb_first = 0.f;
+    if (NEXT) {
+        const f32x4* __restrict__ xp = a.Wnx + ((size_t)min(xt_first, a.nx_n16 - 1) * 64 + lane);
+#pragma unroll
+        for (int kb = 0; kb < XVN; ++kb) if (kb < KB2) xv[kb] = xp[(size_t)kb * xstep];
+        xb_first = a.nx_bias[min(xt_first, a.nx_n16 - 1) * 16 + j];
+    }
     float rv[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.R && nt_first < a.n16 && nt_first * 16 + j < a.cout) {
 #pragma unroll
@@ -173,7 +186,7 @@ __global__ __launch_bounds__(512) void k_dwproject(DwProjArgs a, Geom g) {
                 for (int t = 0; t < 4; ++t) rv[t] = a.R[orow[t] * a.cout + nt * 16 + j];
             }
         }
-        const float pb = a.pr_bias[nt * 16 + j];
+        const float pb = nt == nt_first ? pb_first : a.pr_bias[nt * 16 + j];
         f32x4 acc = {pb, pb, pb, pb};
         const float* __restrict__ ap = D + j * DP + 4 * gq;       // A: row = pixel j of the tile, lane group gq
         for (int kb = 0; kb < KB; kb += PF) {
@@ -205,22 +218,22 @@ __global__ __launch_bounds__(512) void k_dwproject(DwProjArgs a, Geom g) {
 
     // ---- phase 3: this workgroup's share of the next convolution's column tiles
     __syncthreads();
-    const int per = (a.nx_n16 + a.nsplit - 1) / a.nsplit, t_end = min((split + 1) * per, a.nx_n16);
-    const size_t xstep = (size_t)a.nx_n16 * 64;
-    for (int xt = split * per + wave; xt < t_end; xt += 8) {
-        const f32x4* __restrict__ xp = a.Wnx + ((size_t)xt * 64 + lane);
-        const float xb = a.nx_bias[xt * 16 + j];
+    for (int xt = xt_first; xt < xt_end; xt += 8) {
+        float xb = xb_first;
+        if (xt != xt_first) {
+            const f32x4* __restrict__ xp = a.Wnx + ((size_t)xt * 64 + lane);
+#pragma unroll
+            for (int kb = 0; kb < XVN; ++kb) if (kb < KB2) xv[kb] = xp[(size_t)kb * xstep];
+            xb = a.nx_bias[xt * 16 + j];
+        }
         f32x4 acc = {xb, xb, xb, xb};
         const float* __restrict__ ap = P + j * PP + 4 * gq;
-        f32x4 bv[16];                                            // cout <= 256: all of this tile's weight pieces at once
 #pragma unroll
-        for (int kb = 0; kb < 16; ++kb) if (kb < KB2) bv[kb] = xp[(size_t)kb * xstep];
-#pragma unroll
-        for (int kb = 0; kb < 16; ++kb) {
+        for (int kb = 0; kb < XVN; ++kb) {
             if (kb < KB2) {                                      // uniform
                 const f32x4 av = *(const f32x4*)(ap + kb * 16);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[kb][t], acc, 0, 0, 0);
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], xv[kb][t], acc, 0, 0, 0);
             }
         }
         const int col = xt * 16 + j;
@@ -238,7 +251,7 @@ static size_t dwproject_lds_bytes(const BlockPack& b, bool next) {
 }
 
 bool dwproject_supported(const BlockPack& b) {
-    return b.has_expand && b.pr16.w != nullptr && b.expand % 16 == 0 && b.cout % 8 == 0 && b.cout <= 256 && (b.stride == 1 || b.stride == 2) &&
+    return b.has_expand && b.pr16.w != nullptr && b.expand % 16 == 0 && b.cout % 8 == 0 && b.cout <= (b.stride == 2 ? 128 : 256) && (b.stride == 1 || b.stride == 2) &&
            b.expand <= 768 && dwproject_lds_bytes(b, true) <= 160 * 1024;
 }
 
