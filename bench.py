@@ -384,18 +384,21 @@ def extractor_algorithmic_bytes(work):
 
 
 # ------------------------------------------------------------------------------------------------ sub-configs
-def config_latency(capi, eng, n=60):
+def config_latency(capi, eng, n=100):
     """config 2, per-frame view: one HFextractor call through the host-pointer entry point (upload, 4 levels + global
-    descriptor, download, host sync), then SearchByBoW against the previous frame."""
+    descriptor, download, host sync), then SearchByBoW against the previous frame.  The caller owns the result buffers and
+    reuses them from frame to frame, the way a C++ caller of the ABI holds its cv::Mat headers (two sets: the previous
+    frame's descriptors are the matcher's query)."""
     ext = capi.Extractor(eng, W_IMG, H_IMG, N_FEAT, THRESH, SCALE, N_LEVELS, max_batch=1)
     frames = make_frames(8, 0)
-    for f in frames[:3]:
-        ext.extract(f)
+    bufs = [ext.output_buffers(), ext.output_buffers()]
+    for i, f in enumerate(frames[:4]):
+        ext.extract(f, bufs[i & 1])
     t_ext, t_both, prev = [], [], None
     for i in range(n):
         f = frames[i % len(frames)]
         t0 = time.perf_counter()
-        nk, _, desc, _, _ = ext.extract(f)
+        nk, _, desc, _, _ = ext.extract(f, bufs[i & 1])
         t1 = time.perf_counter()
         if prev is not None:
             eng.search_by_bow(prev, desc, TH_LOW)
@@ -405,14 +408,14 @@ def config_latency(capi, eng, n=60):
     t_dev = []
     for i in range(n):
         t0 = time.perf_counter()
-        ext.extract(frames[i % len(frames)])
+        ext.extract(frames[i % len(frames)], bufs[i & 1])
         store.put_extracted(i & 1, ext, 0)
         if i:
             store.search_by_bow([(1 - (i & 1), i & 1)], TH_LOW)
         t_dev.append(time.perf_counter() - t0)
     store.close(); ext.close()
     med = lambda v: float(np.median(v)) * 1e3
-    return {"workload": "752x480, 4 levels, 1000 keypoints, one frame per call, host pointers", "extract_ms_median": med(t_ext),
+    return {"workload": "752x480, 4 levels, 1000 keypoints, one frame per call, host pointers, caller-owned result buffers", "extract_ms_median": med(t_ext),
             "extract_plus_match_ms_median": med(t_both[1:]), "extract_plus_store_match_ms_median": med(t_dev[1:]), "keypoints": int(nk),
             "frames_per_s_unpipelined": 1e3 / med(t_dev[1:])}
 
@@ -454,13 +457,14 @@ def config_tracking(capi, eng, n_feat, frames_n=400):
     store = capi.Store(eng, frames_n // 5 + 8, n_feat)       # keyframe slots; the last two slots hold the current / previous frame
     F0 = frames_n // 5 + 6
     imgs = make_frames(16, 0, w=W, h=H)
+    bufs = [ext.output_buffers(), ext.output_buffers()]
     for i in range(3):
-        ext.extract(imgs[i])
+        ext.extract(imgs[i], bufs[i & 1])
     t_frame, t_kf, n_kf = [], [], 0
     t_all0 = time.perf_counter()
     for i in range(frames_n):
         t0 = time.perf_counter()
-        _, _, _, g, _ = ext.extract(imgs[i % len(imgs)])
+        _, _, _, g, _ = ext.extract(imgs[i % len(imgs)], bufs[i & 1])
         store.put_extracted(F0 + (i & 1), ext, 0)
         if i:
             store.search_by_bow([(F0 + 1 - (i & 1), F0 + (i & 1))], TH_LOW)

@@ -312,18 +312,32 @@ class Extractor:
         _chk(lib().hfnet_extractor_tables(self.h, _p(sf), _p(fpl), _p(lw), _p(lh)))
         return sf, fpl, lw, lh
 
-    def extract(self, img: np.ndarray):
-        """HFextractor::operator().  Returns (n, kps, desc, global, n_per_level)."""
+    def extract(self, img: np.ndarray, out=None):
+        """HFextractor::operator().  Returns (n, kps, desc, global, n_per_level).
+        out: (kps[n_features], desc[n_features, 256], global[G], n_per_level[n_levels]) caller-owned buffers to fill (what a C++
+        caller of the ABI passes); the returned kps / desc are then views of their first n rows instead of fresh copies."""
         img = np.asarray(img)
         if img.dtype != np.uint8 or img.ndim != 2 or img.strides[1] != 1:
             img = np.ascontiguousarray(img, np.uint8)
-        kps = np.zeros((self.n_features,), KP_DTYPE)
-        desc = np.zeros((self.n_features, DESC_DIM), np.float32)
-        g = np.zeros((self.engine.global_dim,), np.float32)
-        npl = np.zeros((self.n_levels,), np.int32)
+        if out is None:
+            kps = np.zeros((self.n_features,), KP_DTYPE)
+            desc = np.zeros((self.n_features, DESC_DIM), np.float32)
+            g = np.zeros((self.engine.global_dim,), np.float32)
+            npl = np.zeros((self.n_levels,), np.int32)
+        else:
+            kps, desc, g, npl = out
+            assert kps.shape == (self.n_features,) and desc.shape == (self.n_features, DESC_DIM) and desc.dtype == np.float32
         n = C.c_int(0)
         _chk(lib().hfnet_extractor_extract(self.h, _p(img), img.strides[0], _p(kps), _p(desc), _p(g), C.byref(n), _p(npl)))
-        return n.value, kps[:max(n.value, 0)].copy(), desc[:max(n.value, 0)].copy(), g, npl
+        k = max(n.value, 0)
+        if out is None:
+            return n.value, kps[:k].copy(), desc[:k].copy(), g, npl
+        return n.value, kps[:k], desc[:k], g, npl
+
+    def output_buffers(self):
+        """caller-owned result buffers for extract(img, out=...)"""
+        return (np.zeros((self.n_features,), KP_DTYPE), np.zeros((self.n_features, DESC_DIM), np.float32),
+                np.zeros((self.engine.global_dim,), np.float32), np.zeros((self.n_levels,), np.int32))
 
     def extract_batch(self, imgs: np.ndarray, out=None):
         """imgs: [F, H, W] uint8 (host).  Returns (n[F], kps[F, n_features], desc[F, n_features, 256], global[F, G]).

@@ -7,6 +7,8 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -275,7 +277,7 @@ static int run_block(Net& n, int L, int n_used, hipStream_t st) {   // layer L =
     return HFNET_OK;
 }
 
-int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget, bool defer_global) {
+int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget, bool defer_global, bool caller_joins) {
     const DeviceWeights& w = e->w;
     const int NL = cfg.n_levels;
     if (!cfg.from_intermediate) {
@@ -359,7 +361,8 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         HF_TRY(forward_global(stream_global));
         HF_HIP(hipEventRecord(ev_join, stream_global));
     }
-    if (cfg.global && fork && defer) join_pending = true;
+    if (cfg.global && fork_early && caller_joins) join_pending = true;
+    else if (cfg.global && fork && defer) join_pending = true;
     else if (cfg.global && fork) HF_HIP(hipStreamWaitEvent(stream, ev_join, 0));
     else if (cfg.global) HF_TRY(forward_global(stream));
     return HFNET_OK;
@@ -799,9 +802,13 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
             x->pin_res = off;
             const size_t res_bytes = x->result_offsets(pf, e->impl.w.global_dim).total;
             off += res_bytes;
+            x->pin_flag = off;
+            off += 256;
             HF_TRY(dalloc(x->allocs, &x->d_blk, res_bytes));
+            HF_TRY(dalloc(x->allocs, &x->d_seq, 1));
+            HF_HIP(hipMemset(x->d_seq, 0, sizeof(int)));
             void* hp = nullptr;
-            if (hipHostMalloc(&hp, off, hipHostMallocDefault) == hipSuccess) { x->h_pin = (unsigned char*)hp; x->pinned_frames = pf; }
+            if (hipHostMalloc(&hp, off, hipHostMallocDefault) == hipSuccess) { x->h_pin = (unsigned char*)hp; x->pinned_frames = pf; *(volatile int*)(x->h_pin + x->pin_flag) = 0; }
             else (void)hipGetLastError();
         }
     }
@@ -838,7 +845,7 @@ int hfnet_extractor_tables(const hfnet_extractor* x, float* scale_factors, int* 
 
 // one chunk of nb <= max_batch frames; all pointers device pointers except when host_* is given
 static int extract_chunk(hfnet_extractor* x, int nb, const uint8_t* d_images, int row_stride, long long frame_stride, hfnet_keypoint* d_kps,
-                         float* d_desc, float* d_global, int* d_n, int* d_n_level) {
+                         float* d_desc, float* d_global, int* d_n, int* d_n_level, bool caller_joins = false) {
     Net& net = x->net;
     Engine& eng = x->eng->impl;
     if (net.cfg.batch != nb) { net.cfg.batch = nb; compute_offsets(net, nb); }
@@ -857,7 +864,7 @@ static int extract_chunk(hfnet_extractor* x, int nb, const uint8_t* d_images, in
     std::memset(&budget, 0, sizeof budget);
     for (int l = 0; l < x->n_levels; ++l) budget.k[l] = x->features_per_level[l];
     const bool defer = d_n_level == nullptr;      // device-resident call: nothing of the global branch is needed on this stream
-    HF_TRY(net.forward(imgs, x->threshold, budget, defer));
+    HF_TRY(net.forward(imgs, x->threshold, budget, defer, caller_joins));
     SampleArgs sa;
     std::memset(&sa, 0, sizeof sa);
     sa.desc_map = net.sample_source(); sa.sparse = net.last_sparse ? 1 : 0; sa.kps_in = net.kps_level; sa.n_in = net.n_level; sa.kps_stride = net.cfg.max_keypoints;
@@ -890,10 +897,16 @@ static int extract_chunk_graphed(hfnet_extractor* x, int nb) {
         const hfnet_extractor::ResOff o = x->result_offsets(nb, G);
         net.global_dst = net.cfg.global ? (float*)(x->d_blk + o.g) : nullptr;
         const int rc = extract_chunk(x, nb, x->d_pyr[0], x->width, (long long)img_bytes, (hfnet_keypoint*)(x->d_blk + o.k), (float*)(x->d_blk + o.d), nullptr,
-                                     (int*)(x->d_blk + o.n), (int*)(x->d_blk + o.nl));
+                                     (int*)(x->d_blk + o.n), (int*)(x->d_blk + o.nl), /*caller_joins=*/true);
         net.global_dst = nullptr;
         HF_TRY(rc);
-        HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_res, x->d_blk, o.total, hipMemcpyDeviceToHost, st));
+        // the local results come down as soon as the sampler is done, followed by the "they are down" counter; the global
+        // descriptors follow when the global branch -- the longer one for a single frame -- has joined
+        HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_res, x->d_blk, o.g, hipMemcpyDeviceToHost, st));
+        HF_LAUNCH(&eng, st, "bump_seq", launch_bump_seq(x->d_seq, st));
+        HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_flag, x->d_seq, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (net.join_pending) { HF_HIP(hipStreamWaitEvent(st, net.ev_join, 0)); net.join_pending = false; }
+        if (net.cfg.global) HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_res + o.g, x->d_blk + o.g, o.total - o.g, hipMemcpyDeviceToHost, st));
         return HFNET_OK;
     };
     if (!x->use_graph || eng.prof.enabled) return direct();
@@ -1090,12 +1103,25 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
                 if (row_stride == x->width) std::memcpy(dst, src, img_bytes);
                 else for (int y = 0; y < x->height; ++y) std::memcpy(dst + (size_t)y * x->width, src + (size_t)y * row_stride, (size_t)x->width);
             }
+            const int expected = ++x->seq_host;
             HF_TRY(extract_chunk_graphed(x, nb));
             const hfnet_extractor::ResOff o = x->result_offsets(nb, G);
             const float* blk_desc = (const float*)(x->d_blk + o.d);
             const int* blk_n = (const int*)(x->d_blk + o.n);
             HF_TRY(copy_chunk_to_store(x, f0, nb, blk_desc, blk_n, st));
-            HF_HIP(hipStreamSynchronize(st));
+            // the keypoints and descriptors (1 MB per frame) are unpacked while the GPU is still busy with the global branch:
+            // spin until the counter that follows them into the pinned block shows this call's number (bounded; a call that
+            // never sees it simply waits for the stream)
+            volatile int* flag = (volatile int*)(x->h_pin + x->pin_flag);
+            {
+                const auto t_spin = std::chrono::steady_clock::now();
+                for (unsigned it = 0; *flag != expected; ++it) {
+                    __builtin_ia32_pause();
+                    if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(20)) break;
+                }
+                if (*flag != expected) HF_HIP(hipStreamSynchronize(st));
+                std::atomic_thread_fence(std::memory_order_acquire);
+            }
             x->last_desc = blk_desc; x->last_cnt = blk_n;
             const unsigned char* res = x->h_pin + x->pin_res;
             x->pin_nl_last = x->pin_res + o.nl;
@@ -1105,12 +1131,15 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
                 n_out[f0 + f] = n;
                 x->last_n[f] = n;
                 if (x->att_store) x->att_store->rows[(x->att_first + f0 + f) % x->att_store->n_sets] = std::min(n, x->att_store->max_rows);
-                if (global_desc) std::memcpy(global_desc + (size_t)(f0 + f) * G, res + o.g + sizeof(float) * (size_t)f * G, sizeof(float) * G);
                 if (n <= 0) continue;
                 std::memcpy(kps + (size_t)(f0 + f) * x->n_features, res + o.k + sizeof(hfnet_keypoint) * (size_t)f * x->n_features, sizeof(hfnet_keypoint) * n);
                 std::memcpy(local_desc + (size_t)(f0 + f) * x->n_features * HFNET_DESC_DIM,
                             res + o.d + sizeof(float) * HFNET_DESC_DIM * (size_t)f * x->n_features, sizeof(float) * HFNET_DESC_DIM * n);
             }
+            HF_HIP(hipStreamSynchronize(st));
+            x->seq_host = *flag;                                  // (re-synchronise the numbering, whatever happened)
+            if (global_desc)
+                for (int f = 0; f < nb; ++f) std::memcpy(global_desc + (size_t)(f0 + f) * G, res + o.g + sizeof(float) * (size_t)f * G, sizeof(float) * G);
         } else {
             // everything that is left, as a double-buffered pipeline over its chunks
             HF_TRY(extract_host_pipelined(x, f0, n_frames, images, row_stride, frame_stride, kps, local_desc, global_desc, n_out));

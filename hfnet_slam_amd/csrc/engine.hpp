@@ -191,7 +191,9 @@ struct Net {
     // enqueue the whole forward pass; imgs: per-level u8 sources (ignored when from_intermediate)
     // defer_global: do not wait for the global branch at the end; the caller consumes global_out on stream_global and the
     // next forward() waits for it before layer 7 is overwritten
-    int forward(const ImageSet& imgs, float threshold, const TopkBudget& budget, bool defer_global = false);
+    // caller_joins: (few frames per call) the global branch forks right after layer 7 and forward() does NOT wait for it:
+    // join_pending is set, the caller finishes its work on the local results first and then waits for ev_join itself
+    int forward(const ImageSet& imgs, float threshold, const TopkBudget& budget, bool defer_global = false, bool caller_joins = false);
     bool join_pending = false;
     int tap(int id, std::vector<float>& out);
     int run_dense_desc();
@@ -242,22 +244,28 @@ struct hfnet_extractor {
     int use_graph = 1;
     // Small chunks (<= pinned_frames) also move their input and results through one pinned block inside the same graph:
     // one launch and one host synchronisation per call instead of three blocking pageable copies.
-    // [images | n | n_level | global | keypoints | descriptors] for pinned_frames frames
+    // [images | n | n_level | keypoints | descriptors | global | flag] for pinned_frames frames
     unsigned char* h_pin = nullptr;
     std::vector<int> last_n;             // keypoint counts of the last host-pointer call per staging frame (-1: unknown)
     int pinned_frames = 0;
-    // Result sections [n | n_level | global | keypoints | descriptors] packed for the frames of the call (offsets from pin_res;
+    // Result sections [n | n_level | keypoints | descriptors | global] packed for the frames of the call (offsets from pin_res;
     // result_offsets()); the device side keeps the SAME layout in one block (d_blk), so a call's results come down with ONE copy
-    size_t pin_res = 0, pin_nl_last = 0;
+    size_t pin_res = 0, pin_nl_last = 0, pin_flag = 0;
+    // "the local results are down": a device counter the graph bumps and copies into the pinned block right after them; the
+    // host spins on it, unpacks keypoints and descriptors while the global branch is still running, then waits for the rest
+    int* d_seq = nullptr;
+    int seq_host = 0;
     unsigned char* d_blk = nullptr;
     struct ResOff { size_t n, nl, g, k, d, total; };
     ResOff result_offsets(int nb, int global_dim) const {
         auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+        // the local results first and contiguous ([0, g): they come down as soon as the local heads are done), the global
+        // descriptors last (they follow when the global branch has joined)
         ResOff o;
-        o.n = 0; o.nl = up(sizeof(int) * nb); o.g = o.nl + up(sizeof(int) * (size_t)nb * n_levels);
-        o.k = o.g + up(sizeof(float) * (size_t)nb * global_dim);
+        o.n = 0; o.nl = up(sizeof(int) * nb); o.k = o.nl + up(sizeof(int) * (size_t)nb * n_levels);
         o.d = o.k + up(sizeof(hfnet_keypoint) * (size_t)nb * n_features);
-        o.total = o.d + up(sizeof(float) * HFNET_DESC_DIM * (size_t)nb * n_features);
+        o.g = o.d + up(sizeof(float) * HFNET_DESC_DIM * (size_t)nb * n_features);
+        o.total = o.g + up(sizeof(float) * (size_t)nb * global_dim);
         return o;
     }
     // Larger host-pointer calls run as a double-buffered pipeline over their chunks: while chunk c computes, chunk c + 1's

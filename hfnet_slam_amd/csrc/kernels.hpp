@@ -70,6 +70,8 @@ struct TopkBudget { int k[HFNET_MAX_LEVELS]; };
 hipError_t launch_topk(const unsigned long long* cand, const unsigned int* counters, long long cand_stride,
                        const TopkBudget& kmax_per_level, hfnet_keypoint* kps, long long kps_stride, int* n_out,
                        const Geom& g, hipStream_t s);
+// *seq += 1 (one thread): the "results are down" counter of the single-frame host path (engine.hip)
+hipError_t launch_bump_seq(int* seq, hipStream_t s);
 // per-pixel L2 normalisation of the dense descriptor map (hf_net.py:80)
 hipError_t launch_l2norm256(const float* in, float* out, long long P, hipStream_t s);
 // bilinear Resampler + cv::normalize + keypoint rescale / concat (HFNetTFModelV2.cc:153-167,

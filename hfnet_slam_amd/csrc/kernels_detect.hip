@@ -564,4 +564,10 @@ hipError_t launch_sample(const SampleArgs& a, const Geom& g, hipStream_t s) {
     return hipGetLastError();
 }
 
+__global__ void k_bump_seq(int* seq) { *seq = *seq + 1; }
+hipError_t launch_bump_seq(int* seq, hipStream_t s) {
+    hipLaunchKernelGGL(k_bump_seq, dim3(1), dim3(1), 0, s, seq);
+    return hipGetLastError();
+}
+
 }  // namespace hfnet

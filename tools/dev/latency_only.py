@@ -14,9 +14,10 @@ for o in sys.argv[2:]:
 ext = capi.Extractor(eng, 752, 480, 1000, 0.01, 1.2, 4, max_batch=1)
 imgs = [synth_image(480, 752, 100 + i) for i in range(4)]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+bufs = ext.output_buffers()
 for i in range(10):
-    ext.extract(imgs[i % 4])
+    ext.extract(imgs[i % 4], bufs)
 ts = []
 for i in range(n):
-    t0 = time.perf_counter(); ext.extract(imgs[i % 4]); ts.append(time.perf_counter() - t0)
+    t0 = time.perf_counter(); ext.extract(imgs[i % 4], bufs); ts.append(time.perf_counter() - t0)
 print("ms per frame: median %.4f  mean %.4f" % (float(np.median(ts)) * 1e3, float(np.mean(ts)) * 1e3), sys.argv[2:])
