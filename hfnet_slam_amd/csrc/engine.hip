@@ -20,7 +20,7 @@ int* Options::find(const char* name) {
     const struct { const char* n; int* p; } tab[] = {{"fuse_blocks", &fuse_blocks}, {"fuse_max_layer", &fuse_max_layer}, {"fused_variant", &fused_variant},
                                                        {"fuse_stem", &fuse_stem}, {"dense_desc", &dense_desc}, {"two_streams", &two_streams},
                                                        {"graph", &graph}, {"pinned_frames", &pinned_frames}, {"db_gemm_min_queries", &db_gemm_min_queries},
-                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}};
+                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}};
     for (const auto& t : tab) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -118,7 +118,7 @@ int Net::build(Engine* eng, const NetConfig& c) {
     e = eng;
     cfg = c;
     // A/B and diagnostics switches of the engine (hfnet_engine_set_option), fixed for the lifetime of this network
-    fuse_blocks = e->opt.fuse_blocks; fuse_max_layer = e->opt.fuse_max_layer; fused_variant = e->opt.fused_variant; fuse_min_wgs = e->opt.fuse_min_wgs; tail_fuse = e->opt.tail_fuse;
+    fuse_blocks = e->opt.fuse_blocks; fuse_max_layer = e->opt.fuse_max_layer; fused_variant = e->opt.fused_variant; fuse_min_wgs = e->opt.fuse_min_wgs; tail_fuse = e->opt.tail_fuse; dedupe_taps = e->opt.dedupe_taps;
     force_dense = e->opt.dense_desc; fuse_stem = e->opt.fuse_stem; conv_wlds = e->opt.conv_wlds;
     const DeviceWeights& w = e->w;
     if (c.n_levels < 1 || c.n_levels > HFNET_MAX_LEVELS || c.batch < 1) { set_error("net: bad level / batch count"); return HFNET_ERR_INVALID_ARG; }
@@ -189,6 +189,14 @@ int Net::build(Engine* eng, const NetConfig& c) {
         HF_TRY(dalloc(allocs, &rows_hidden, rows * HFNET_DESC_DIM));
         HF_TRY(dalloc(allocs, &rows_raw, rows * HFNET_DESC_DIM));
         HF_TRY(dalloc(allocs, &n_level, images));
+        // distinct tap cells of the sparse descriptor head (launch_tap_cells); the flags start (and are left) clean
+        cell_stride = 0;
+        for (int l = 0; l < c.n_levels; ++l) cell_stride = std::max(cell_stride, (long long)lp[l].h[7] * lp[l].w[7]);
+        HF_TRY(dalloc(allocs, &tap_flags, images * (size_t)cell_stride));
+        HF_HIP(hipMemset(tap_flags, 0, images * (size_t)cell_stride));
+        HF_TRY(dalloc(allocs, &tap_cell_row, images * (size_t)cell_stride));
+        HF_TRY(dalloc(allocs, &tap_cells, rows));
+        HF_TRY(dalloc(allocs, &tap_nrows, images));
     }
     if (c.global) {
         const size_t pg = (size_t)c.batch * lp[0].h[18] * lp[0].w[18];
@@ -350,8 +358,16 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
             int kmaxb = 0;
             for (int l = 0; l < NL; ++l) kmaxb = std::max(kmaxb, std::min(budget.k[l], cfg.max_keypoints));
             const long long rows = ((long long)(NL * cfg.batch - 1) * cfg.max_keypoints + kmaxb) * 4;
-            HF_LAUNCH(e, stream, "conv3x3_desc_taps", launch_conv3x3_taps(act[7], w.desc1, rows_hidden, 1, kps_level, n_level, cfg.max_keypoints, budget.k, gt, conv_wlds, stream));
-            HF_LAUNCH(e, stream, "pointwise_desc_taps", launch_pointwise(rows_hidden, w.desc2, nullptr, rows_raw, rows, 0, stream, n_level, 4 * cfg.max_keypoints, 4));
+            last_dedupe = dedupe_taps != 0;
+            if (last_dedupe) {
+                // taps shared by neighbouring keypoints are evaluated once: the rows of an image are its DISTINCT tap cells
+                HF_LAUNCH(e, stream, "tap_cells", launch_tap_cells(kps_level, n_level, cfg.max_keypoints, tap_flags, tap_cell_row, tap_cells, tap_nrows, cell_stride, gt, stream));
+                HF_LAUNCH(e, stream, "conv3x3_desc_taps", launch_conv3x3_taps(act[7], w.desc1, rows_hidden, 1, kps_level, n_level, cfg.max_keypoints, budget.k, gt, conv_wlds, stream, tap_cells, tap_nrows));
+                HF_LAUNCH(e, stream, "pointwise_desc_taps", launch_pointwise(rows_hidden, w.desc2, nullptr, rows_raw, rows, 0, stream, tap_nrows, 4 * cfg.max_keypoints, 1));
+            } else {
+                HF_LAUNCH(e, stream, "conv3x3_desc_taps", launch_conv3x3_taps(act[7], w.desc1, rows_hidden, 1, kps_level, n_level, cfg.max_keypoints, budget.k, gt, conv_wlds, stream));
+                HF_LAUNCH(e, stream, "pointwise_desc_taps", launch_pointwise(rows_hidden, w.desc2, nullptr, rows_raw, rows, 0, stream, n_level, 4 * cfg.max_keypoints, 4));
+            }
         } else {
             HF_TRY(run_dense_desc());
         }
@@ -682,7 +698,7 @@ int hfnet_model_detect(hfnet_model* m, const uint8_t* image, int row_stride, int
     HF_TRY(net.forward(imgs, threshold, budget));
     SampleArgs sa;
     std::memset(&sa, 0, sizeof sa);
-    sa.desc_map = net.sample_source(); sa.sparse = net.last_sparse ? 1 : 0; sa.kps_in = net.kps_level; sa.n_in = net.n_level; sa.kps_stride = net.cfg.max_keypoints;
+    sa.desc_map = net.sample_source(); sa.sparse = net.last_sparse ? 1 : 0; sa.cell_row = net.last_sparse && net.last_dedupe ? net.tap_cell_row : nullptr; sa.cell_stride = net.cell_stride; sa.kps_in = net.kps_level; sa.n_in = net.n_level; sa.kps_stride = net.cfg.max_keypoints;
     sa.kps_out = m->d_kps; sa.desc_out = m->d_desc; sa.n_out_frame = m->d_n; sa.n_out_level = nullptr;
     sa.out_frame_stride = m->max_keypoints; sa.scale_factor[0] = 1.0f; sa.set_octave = 0;
     Geom gs = net.geom(7, 7, 0, 1);
@@ -867,7 +883,7 @@ static int extract_chunk(hfnet_extractor* x, int nb, const uint8_t* d_images, in
     HF_TRY(net.forward(imgs, x->threshold, budget, defer, caller_joins));
     SampleArgs sa;
     std::memset(&sa, 0, sizeof sa);
-    sa.desc_map = net.sample_source(); sa.sparse = net.last_sparse ? 1 : 0; sa.kps_in = net.kps_level; sa.n_in = net.n_level; sa.kps_stride = net.cfg.max_keypoints;
+    sa.desc_map = net.sample_source(); sa.sparse = net.last_sparse ? 1 : 0; sa.cell_row = net.last_sparse && net.last_dedupe ? net.tap_cell_row : nullptr; sa.cell_stride = net.cell_stride; sa.kps_in = net.kps_level; sa.n_in = net.n_level; sa.kps_stride = net.cfg.max_keypoints;
     sa.kps_out = d_kps; sa.desc_out = d_desc; sa.n_out_frame = d_n; sa.n_out_level = d_n_level;
     sa.out_frame_stride = x->n_features; sa.set_octave = 1;
     for (int l = 0; l < x->n_levels; ++l) sa.scale_factor[l] = x->scale_factors[l];

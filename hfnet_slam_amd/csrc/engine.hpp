@@ -97,6 +97,7 @@ struct Options {
     int pinned_frames = 4;    // chunks up to this many frames move through one pinned block inside that graph
     int conv_wlds = 1;        // 3x3 heads: weights staged through LDS once per workgroup (0: every wave reads them from L1 / L2)
     int db_gemm_min_queries = 8;   // hfnet_db_query_batch: from this many queries on, the scores come from the MFMA GEMM form
+    int dedupe_taps = 1;      // sparse descriptor head: taps shared by neighbouring keypoints are evaluated once
     int tail_fuse = 4;        // calls of up to this many frames run layers 8-18 with the single-frame kernels (0: never)
     int copy_threads = 64;    // helper threads of the host-pointer batch pipeline's staging copies (>= 64: chosen from the core count)
     int fuse_min_wgs = 256;   // layers 8-14 take their fused kernel from this many 128-pixel tiles per launch on (0: always; tests)
@@ -161,6 +162,11 @@ struct Net {
     // sparse descriptor head: rows (image*max_keypoints + i)*4 + tap, see launch_conv3x3_taps
     float *rows_hidden = nullptr, *rows_raw = nullptr;
     bool last_sparse = false;      // which descriptor path the last forward() took
+    bool last_dedupe = false;      // ... with de-duplicated tap rows (tap_cell_row is then the sampler's row lookup)
+    int dedupe_taps = 1;
+    unsigned char* tap_flags = nullptr;        // [image][cell_stride] scratch of launch_tap_cells
+    int *tap_cell_row = nullptr, *tap_cells = nullptr, *tap_nrows = nullptr;
+    long long cell_stride = 0;
     bool dense_valid = false;      // dense descriptor tensors match the last forward()
     bool nms_valid = false;        // the suppressed score map (tap 25) matches the last forward()
     float last_threshold = 0.f;

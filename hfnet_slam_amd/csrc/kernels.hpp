@@ -24,9 +24,11 @@ hipError_t launch_conv3x3(const float* A, const ConvPack& cp, float* out, int re
 // the same convolution evaluated only at the 4 bilinear taps of every selected keypoint ("sparse
 // descriptor head"): row (image*kps_stride + i)*4 + t of `out` is tap t of keypoint i.  Geom: H, W =
 // score-map size, Ho, Wo = cell grid, in_off = first cell of the level.
+// cells / n_rows (optional, launch_tap_cells): keypoints at least 5 pixels apart on an 8-pixel cell grid share taps -- the rows of an
+// image are then its n_rows[image] DISTINCT tap cells (row r of the slot is cell cells[image * kps_stride * 4 + r]).
 hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, int relu6, const hfnet_keypoint* kps, const int* n_in,
                                long long kps_stride, const int* level_keypoints /* upper bound of n_in per level */, const Geom& g, int wlds,
-                               hipStream_t s);
+                               hipStream_t s, const int* cells = nullptr, const int* n_rows = nullptr);
 // depthwise 3x3 (stride 1 / 2) + BN + ReLU6
 hipError_t launch_depthwise(const float* in, const DwPack& dp, int stride, float* out, const Geom& g, hipStream_t s);
 // whole inverted-residual block (expand -> depthwise -> project [+ residual]) in one launch; the expanded
@@ -76,8 +78,15 @@ hipError_t launch_bump_seq(int* seq, hipStream_t s);
 hipError_t launch_l2norm256(const float* in, float* out, long long P, hipStream_t s);
 // bilinear Resampler + cv::normalize + keypoint rescale / concat (HFNetTFModelV2.cc:153-167,
 // BaseModel.cc:491-562, HFextractor.cc:267-281)
+// the distinct tap cells of every image's selected keypoints, in ascending cell order (Geom as launch_conv3x3_taps):
+//   flags   [images][cell_stride] bytes, scratch     cell_row [images][cell_stride]: row of a cell in the image's slot (or -1)
+//   cells   [images][kps_stride * 4]: cell of a row   n_rows   [images]
+hipError_t launch_tap_cells(const hfnet_keypoint* kps, const int* n_in, long long kps_stride, unsigned char* flags, int* cell_row, int* cells,
+                            int* n_rows, long long cell_stride, const Geom& g, hipStream_t s);
 struct SampleArgs {
     const float* desc_map;        // dense: normalised [pixels x 256]; sparse: RAW tap rows [image][kps_stride*4][256] (normalised on the fly)
+    const int* cell_row;          // sparse, de-duplicated taps: row of cell (y * Wo + x) in the image's slot; null: rows 4 i .. 4 i + 3
+    long long cell_stride;
     int sparse;
     const hfnet_keypoint* kps_in; // per image slot of kps_stride entries (level coordinates)
     const int* n_in;              // per image count

@@ -473,7 +473,9 @@ __global__ __launch_bounds__(256) void k_pointwise_deep(ConvArgs a) {
 // contribute fma(0, w, acc) == acc, i.e. they are skipped exactly as the oracle skips them.
 // GATHER: the 32 rows of a tile are the bilinear taps of 8 selected keypoints instead of consecutive
 // pixels (sparse descriptor head); everything else is identical, so results are bit-identical per cell.
-struct TapArgs { const hfnet_keypoint* kps; const int* n_in; long long kps_stride; };
+// cells != null: the rows of an image are its de-duplicated tap cells (launch_tap_cells: cells[image * kps_stride * 4 + row] =
+// y * Wc + x, n_rows[image] of them) instead of four taps per keypoint
+struct TapArgs { const hfnet_keypoint* kps; const int* n_in; long long kps_stride; const int* cells; const int* n_rows; };
 
 template <int NT, bool GATHER>
 __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g, TapArgs ta) {
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g, TapArgs 
     const int image = level * g.batch + frame;
     const LevelGeom lv = g.lv[level];
     const int Hc = GATHER ? lv.Ho : lv.H, Wc = GATHER ? lv.Wo : lv.W;
-    const int nrows = GATHER ? ta.n_in[image] * 4 : Hc * Wc;
+    const int nrows = GATHER ? (ta.cells ? ta.n_rows[image] : ta.n_in[image] * 4) : Hc * Wc;
     // (An XCD-aware order -- contiguous runs of row tiles per XCD, both column groups adjacent -- cut this kernel's HBM
     // fetches by 43 % but ran 5-50 % slower: the kernel is issue-bound, not HBM-bound.)
     const int T = (nrows + 127) >> 7;
@@ -505,7 +507,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g, TapArgs 
     bool pvalid;
     long long in_base, out_base;
     if (p0 >= nrows) return;
-    if (GATHER) {
+    if (GATHER && ta.cells) {
+        pvalid = p0 + r < nrows;
+        const int cell = ta.cells[(long long)image * ta.kps_stride * 4 + (pvalid ? p0 + r : 0)];
+        y = cell / Wc; x = cell - y * Wc;
+        in_base = lv.in_off + (long long)frame * Hc * Wc;
+        out_base = (long long)image * ta.kps_stride * 4;
+    } else if (GATHER) {
         const int n = nrows >> 2;
         const int row = p0 + r, i = row >> 2, t = row & 3;
         pvalid = i < n;
@@ -659,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wlds(ConvArgs a, Geom g, Tap
     const int image = level * g.batch + frame;
     const LevelGeom lv = g.lv[level];
     const int Hc = GATHER ? lv.Ho : lv.H, Wc = GATHER ? lv.Wo : lv.W;
-    const int nrows = GATHER ? ta.n_in[image] * 4 : Hc * Wc;
+    const int nrows = GATHER ? (ta.cells ? ta.n_rows[image] : ta.n_in[image] * 4) : Hc * Wc;
     const int T = (nrows + 127) >> 7;
     if (tile >= T) return;                                      // workgroup-uniform
     const int nt0 = grp * NT;
@@ -668,7 +676,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wlds(ConvArgs a, Geom g, Tap
     int y, x;
     bool pvalid;
     long long in_base, out_base;
-    if (GATHER) {
+    if (GATHER && ta.cells) {
+        pvalid = active && p0 + r < nrows;
+        const int cell = ta.cells[(long long)image * ta.kps_stride * 4 + (pvalid ? p0 + r : 0)];
+        y = cell / Wc; x = cell - y * Wc;
+        in_base = lv.in_off + (long long)frame * Hc * Wc;
+        out_base = (long long)image * ta.kps_stride * 4;
+    } else if (GATHER) {
         const int n = nrows >> 2;
         const int row = p0 + r, i = row >> 2, t = row & 3;
         pvalid = active && i < n;
@@ -774,10 +788,10 @@ static void launch_pw_nt(const ConvArgs& a, dim3 grid, hipStream_t s) {
 template <int NT>
 static void launch_c3_nt(const ConvArgs& a, const Geom& g, const TapArgs* ta, dim3 grid, hipStream_t s) {
     if (ta) hipLaunchKernelGGL((k_conv3x3<NT, true>), grid, dim3(256), 0, s, a, g, *ta);
-    else { TapArgs none = {nullptr, nullptr, 0}; hipLaunchKernelGGL((k_conv3x3<NT, false>), grid, dim3(256), 0, s, a, g, none); }
+    else { TapArgs none = {nullptr, nullptr, 0, nullptr, nullptr}; hipLaunchKernelGGL((k_conv3x3<NT, false>), grid, dim3(256), 0, s, a, g, none); }
 }
 static void launch_c3_wlds4(const ConvArgs& a, const Geom& g, const TapArgs* ta, dim3 grid, hipStream_t s) {
-    TapArgs none = {nullptr, nullptr, 0};
+    TapArgs none = {nullptr, nullptr, 0, nullptr, nullptr};
     if (a.cin == 96) {                                           // both heads of the network: three slabs per tap, unrolled
         if (ta) hipLaunchKernelGGL((k_conv3x3_wlds<4, true, 3>), grid, dim3(256), 0, s, a, g, *ta);
         else hipLaunchKernelGGL((k_conv3x3_wlds<4, false, 3>), grid, dim3(256), 0, s, a, g, none);
@@ -890,8 +904,9 @@ hipError_t launch_conv3x3(const float* A, const ConvPack& cp, float* out, int re
 }
 
 hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, int relu6, const hfnet_keypoint* kps, const int* n_in,
-                               long long kps_stride, const int* level_keypoints, const Geom& g, int wlds, hipStream_t s) {
-    const TapArgs ta = {kps, n_in, kps_stride};
+                               long long kps_stride, const int* level_keypoints, const Geom& g, int wlds, hipStream_t s, const int* cells,
+                               const int* n_rows) {
+    const TapArgs ta = {kps, n_in, kps_stride, cells, cells ? n_rows : nullptr};
     int rows[HFNET_MAX_LEVELS] = {0};
     for (int l = 0; l < g.n_levels; ++l) rows[l] = 4 * (int)std::min<long long>(level_keypoints[l], kps_stride);
     return launch_conv3x3_any(A, cp, out, relu6, g, &ta, rows, wlds, s);

@@ -475,12 +475,21 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a, Geom g) {
         const bool fxin = fx >= 0 && fx <= dw - 1, cxin = cx >= 0 && cx <= dw - 1;
         const bool fyin = fy >= 0 && fy <= dh - 1, cyin = cy >= 0 && cy <= dh - 1;
         f32x4 vff, vcc, vfc, vcf;
-        if (a.sparse) {   // rows 4i..4i+3 of the image slot hold the taps (fx,fy) (cx,cy) (fx,cy) (cx,fy)
+        if (a.sparse && a.cell_row) {   // de-duplicated taps: the row of every cell is looked up
+            const float* d = a.desc_map + ((long long)image * a.kps_stride * 4) * 256 + lane * 4;
+            const int* cr = a.cell_row + (long long)image * a.cell_stride;
+            vff = (fxin && fyin) ? *(const f32x4*)(d + (long long)cr[fy * dw + fx] * 256) : zero;
+            vcc = (cxin && cyin) ? *(const f32x4*)(d + (long long)cr[cy * dw + cx] * 256) : zero;
+            vfc = (fxin && cyin) ? *(const f32x4*)(d + (long long)cr[cy * dw + fx] * 256) : zero;
+            vcf = (cxin && fyin) ? *(const f32x4*)(d + (long long)cr[fy * dw + cx] * 256) : zero;
+        } else if (a.sparse) {   // rows 4i..4i+3 of the image slot hold the taps (fx,fy) (cx,cy) (fx,cy) (cx,fy)
             const float* d = a.desc_map + (((long long)image * a.kps_stride + i) * 4) * 256 + lane * 4;
             vff = (fxin && fyin) ? *(const f32x4*)(d) : zero;
             vcc = (cxin && cyin) ? *(const f32x4*)(d + 256) : zero;
             vfc = (fxin && cyin) ? *(const f32x4*)(d + 512) : zero;
             vcf = (cxin && fyin) ? *(const f32x4*)(d + 768) : zero;
+        }
+        if (a.sparse) {
             // the rows come straight from the 1x1 conv: tf.nn.l2_normalize of each (hf_net.py:80) here instead of in a
             // separate pass over them -- same expressions as k_l2norm256 (a skipped tap stays zero)
             auto l2n = [](f32x4& v) {
@@ -561,6 +570,66 @@ hipError_t launch_sample(const SampleArgs& a, const Geom& g, hipStream_t s) {
     // grid.x covers the largest per-level budget; the caller stores it in kps_stride
     dim3 grid((unsigned)((a.kps_stride + 3) / 4), g.n_levels * g.batch);
     hipLaunchKernelGGL(k_sample, grid, dim3(256), 0, s, a, g);
+    return hipGetLastError();
+}
+
+// ---- distinct tap cells of the selected keypoints (sparse descriptor head).  Keypoints are >= 5 pixels apart (NMS radius
+// 4) on an 8-pixel cell grid, so neighbouring keypoints share bilinear taps; real scenes cluster them far more than noise.
+// Pass 1 marks the cells any keypoint samples (the same float expressions as k_sample / the gathered conv), pass 2 numbers
+// the marked cells of an image in ascending cell order (a spatially sorted row list: good for the conv's L2 reuse too).
+__global__ __launch_bounds__(256) void k_tap_mark(const hfnet_keypoint* __restrict__ kps, const int* __restrict__ n_in, long long kps_stride,
+                                                  unsigned char* __restrict__ flags, long long cell_stride, Geom g) {
+    const int image = blockIdx.y, level = image / g.batch;
+    const LevelGeom lv = g.lv[level];                            // H, W: score map; Ho, Wo: cell grid
+    const int row = blockIdx.x * 256 + threadIdx.x, i = row >> 2, t = row & 3;
+    if (i >= n_in[image]) return;
+    const hfnet_keypoint kp = kps[(long long)image * kps_stride + i];
+    const int Wc = lv.Wo, Hc = lv.Ho;
+    const float sw = ((float)Wc - 1.f) / (float)((float)lv.W - 1.f);
+    const float sh = ((float)Hc - 1.f) / (float)((float)lv.H - 1.f);
+    const float xf = sw * kp.x, yf = sh * kp.y;
+    const int fx = (int)floorf(xf), fy = (int)floorf(yf);
+    const int x = fx + ((t == 1 || t == 3) ? 1 : 0), y = fy + ((t == 1 || t == 2) ? 1 : 0);
+    if (x >= 0 && x < Wc && y >= 0 && y < Hc) flags[(long long)image * cell_stride + y * Wc + x] = 1;
+}
+
+__global__ __launch_bounds__(1024) void k_tap_compact(unsigned char* __restrict__ flags, int* __restrict__ cell_row, int* __restrict__ cells,
+                                                      int* __restrict__ n_rows, long long cell_stride, long long kps_stride, Geom g) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int image = blockIdx.x, level = image / g.batch;
+    const int ncell = g.lv[level].Ho * g.lv[level].Wo;
+    unsigned char* f = flags + (long long)image * cell_stride;
+    int* cr = cell_row + (long long)image * cell_stride;
+    int* cl = cells + (long long)image * kps_stride * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < ncell; c0 += 1024) {
+        const int c = c0 + tid;
+        const bool on = c < ncell && f[c] != 0;
+        if (c < ncell) f[c] = 0;                                  // (left clean for the next call)
+        const unsigned long long mask = __ballot(on);
+        const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(mask);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int row = base + woff + prefix;
+        if (c < ncell) cr[c] = on ? row : -1;
+        if (on) cl[row] = c;
+        __syncthreads();
+        if (tid == 0) { int tot = 0; for (int w = 0; w < 16; ++w) tot += wsum[w]; base += tot; }
+        __syncthreads();
+    }
+    if (tid == 0) n_rows[image] = base;
+}
+
+hipError_t launch_tap_cells(const hfnet_keypoint* kps, const int* n_in, long long kps_stride, unsigned char* flags, int* cell_row, int* cells,
+                            int* n_rows, long long cell_stride, const Geom& g, hipStream_t s) {
+    const int images = g.n_levels * g.batch;
+    hipLaunchKernelGGL(k_tap_mark, dim3((unsigned)((kps_stride * 4 + 255) / 256), images), dim3(256), 0, s, kps, n_in, kps_stride, flags, cell_stride, g);
+    hipLaunchKernelGGL(k_tap_compact, dim3(images), dim3(1024), 0, s, flags, cell_row, cells, n_rows, cell_stride, kps_stride, g);
     return hipGetLastError();
 }
 

@@ -80,6 +80,7 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *                       2: barrier-phased kernel), "fuse_stem" (1)
  *   "fuse_min_wgs" (256) layers 8-14 take their fused kernel from this many 128-pixel tiles per launch on (0: always)
  *   "dense_desc" (0)    1: dense descriptor head instead of the taps of the selected keypoints
+ *   "dedupe_taps" (1)   sparse descriptor head: taps shared by neighbouring keypoints are evaluated once
  *   "two_streams" (3)   0 one stream; 1 fork after layer 7; 2 fork after the detector conv; 3 = 2 + deferred join
  *   "conv_wlds" (1)     3x3 head convolutions: weights staged through LDS once per workgroup (0: every wave reads them)
  *   "graph" (1), "pinned_frames" (4): host-pointer extractor calls
