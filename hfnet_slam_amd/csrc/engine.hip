@@ -1759,7 +1759,10 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
     HF_TRY(e.m_qn.ensure(sizeof(float) * Q));
     const int parts = gemm ? db_gemm_partials(db->capacity) : 4 * db_batch_workgroups(db->capacity);
     HF_TRY(e.m_key.ensure(sizeof(unsigned int) * Q * parts));
-    if (gemm) { HF_TRY(e.m_tn.ensure(sizeof(float) * Q)); HF_TRY(e.m_b.ensure(sizeof(float) * db_gemm_scratch_floats(db->capacity, n_queries))); }
+    if (gemm) {
+        HF_TRY(e.m_tn.ensure(sizeof(float) * Q)); HF_TRY(e.m_b.ensure(sizeof(float) * db_gemm_scratch_floats(db->capacity, n_queries)));
+        HF_TRY(e.m_f1.ensure(sizeof(float) * Q * parts * 2));
+    }
     float* d_q = e.m_a.as<float>(); float* d_scores = e.m_s.as<float>(); float* d_cs = e.m_f0.as<float>();
     int32_t* d_slot = e.m_i0.as<int32_t>(); int* d_n = e.m_cnt.as<int>(); float* d_best = e.m_qn.as<float>();
     unsigned int* d_bits = e.m_key.as<unsigned int>();
@@ -1771,7 +1774,8 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
         }
         HF_LAUNCH(&e, e.stream, "db_qnorm", launch_sumsq_rows(d_q, n_queries, db->dim, e.m_tn.as<float>(), e.stream));
         HF_LAUNCH(&e, e.stream, "db_gemm", launch_db_gemm(d_q, n_queries, e.m_tn.as<float>(), db->d_db, db->d_norm, db->d_occ, db->capacity, db->dim,
-                                                       d_scores, d_bits, e.m_b.as<float>(), e.stream));
+                                                       mode, d_scores, d_bits, e.m_b.as<float>(), e.m_f1.as<float>(), e.m_f1.as<float>() + Q * parts,
+                                                       e.stream));
     } else {
         HF_LAUNCH(&e, e.stream, "db_scores_batch", launch_db_scores_batch(d_q, n_queries, db->d_db, db->d_occ, db->capacity, db->dim, d_scores, d_bits, e.stream));
     }

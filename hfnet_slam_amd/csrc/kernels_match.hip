@@ -921,12 +921,13 @@ __global__ __launch_bounds__(256) void k_db_gemm(const float* __restrict__ q, in
     }
 }
 
-// partial sums of the eight parts -> scores; one thread per (query, row), rows along the lanes
+// partial sums of the eight parts -> u = 1 - sqrt(|q|^2 + |d|^2 - 2 S), NOT yet clamped at 0 (the refinement below selects on
+// it); empty slots: -infinity.  One thread per (query, row), rows along the lanes; per-wave maxima for the refinement.
 __global__ __launch_bounds__(256) void k_db_combine(const float* __restrict__ partial, int qb, int n_queries, int q0, const float* __restrict__ qnorm,
                                                     const float* __restrict__ dnorm, const unsigned char* __restrict__ occupied, int n,
-                                                    float* __restrict__ scores, unsigned int* __restrict__ best_partial, int n_partials) {
+                                                    float* __restrict__ scores, float* __restrict__ umax_partial, int n_partials) {
     const int i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, qi = q0 + c;
-    float score = 0.0f;                                       // (scores are >= 0: neutral for the maximum)
+    float u = -INFINITY;
     if (i < n) {
         float p[DBG_PARTS];
 #pragma unroll
@@ -935,17 +936,91 @@ __global__ __launch_bounds__(256) void k_db_combine(const float* __restrict__ pa
         if (occupied[i]) {
             const float t = qnorm[qi] + dnorm[i];
             const float d2 = fmaxf(fmaf(-2.0f, s, t), 0.0f);
-            const float sc = 1.0f - sqrtf(d2);
-            score = sc > 0.f ? sc : 0.f;
-            scores[(long long)qi * n + i] = score;
-        } else {
-            scores[(long long)qi * n + i] = -1.0f;
+            u = 1.0f - sqrtf(d2);
         }
+        scores[(long long)qi * n + i] = u;
     }
-    float best = score;
+    float best = u;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off, 64));
-    if ((threadIdx.x & 63) == 0) best_partial[(long long)qi * n_partials + blockIdx.x * 4 + (threadIdx.x >> 6)] = __float_as_uint(best);
+    if ((threadIdx.x & 63) == 0) umax_partial[(long long)qi * n_partials + blockIdx.x * 4 + (threadIdx.x >> 6)] = best;
+}
+
+// ---- "screen on the matrix cores, decide with the exact arithmetic" (the rule of the matcher's rounding band): the inner-
+// product form above loses digits where it matters most -- near-identical descriptors, i.e. the revisit a loop closure is
+// about (5e-4 for a descriptor scanned against itself) -- so every slot whose value can decide something is re-scored with
+// the exact chain of k_db_scores (||q - d|| in tree256 order):
+//   pass A  the slots within 1e-3 of the largest screened value: the exact BEST score comes out of them (a slot further
+//           below cannot overtake: the screening error is <= 5e-4, include/hfnet_hip.h)
+//   pass B  the slots from 5e-5 below the candidate threshold (0.8 * best, resp. max(0.5, 0.8 * best): distance >= 0.2 there,
+//           screening error <= 5e-6) upwards that pass A has not done: every candidate's score is exact, and so is the
+//           candidate set.
+// What is left approximate are the scores of non-candidates (error <= 5e-6).  Pass B also clamps at 0, writes -1 for empty
+// slots and leaves the per-wave maxima k_db_filter reduces.
+__device__ __forceinline__ float db_exact_u(const float* __restrict__ q, const float* __restrict__ d, int dim, int lane) {
+    f32x4 p = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < dim; k0 += 256) {                    // per (lane, component): one chain, k ascending -- k_db_scores' order
+        const f32x4 dv = *(const f32x4*)(d + k0 + lane * 4), qv = *(const f32x4*)(q + k0 + lane * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float df = qv[c] - dv[c]; p[c] = fmaf(df, df, p[c]); }
+    }
+    return 1 - sqrtf(tree256_wave4(p));
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void k_db_refine(const float* __restrict__ q, const float* __restrict__ db, int n, int dim, int mode,
+                                                   float* __restrict__ scores, const float* __restrict__ part_in, float* __restrict__ part_out,
+                                                   unsigned int* __restrict__ best_bits, int n_partials) {
+    __shared__ float red[4];
+    __shared__ int list[256];
+    __shared__ int n_list;
+    const int qi = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = -INFINITY;
+    for (int k = tid; k < n_partials; k += 256) m = fmaxf(m, part_in[(long long)qi * n_partials + k]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) red[wave] = m;
+    if (tid == 0) n_list = 0;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    // pass A: part_in = screened maxima -> lo = max(m, 0) - 1e-3, no upper bound
+    // pass B: part_in = maxima after pass A (the exact best, m) -> threshold T; everything from T - 5e-5 up that lies below
+    //         pass A's bound (= what pass A re-scored: those values are already exact; re-scoring one again is harmless)
+    float lo, hi = INFINITY;
+    if (PASS == 0) {
+        lo = fmaxf(m, 0.0f) - 1e-3f;
+    } else {
+        const float best = fmaxf(m, 0.0f);
+        float thr = best * 0.8f;
+        if (mode == 1) thr = fmaxf(0.5f, thr);
+        lo = thr - 5e-5f;
+        hi = best - 1e-3f + 5e-4f;                              // (pass A covered >= screened best - 1e-3 >= exact best - 1.5e-3; overlap is fine)
+        if (hi < lo) hi = lo;
+    }
+    const int i = blockIdx.x * 256 + tid;
+    float u = i < n ? scores[(long long)qi * n + i] : -INFINITY;
+    if (u >= lo && u < hi && u > -INFINITY) { const int k = atomicAdd(&n_list, 1); list[k] = i; }
+    __syncthreads();
+    const int cnt = n_list;
+    for (int k = wave; k < cnt; k += 4) {
+        const int slot = list[k];
+        const float e = db_exact_u(q + (long long)qi * dim, db + (long long)slot * dim, dim, lane);
+        if (lane == 0) scores[(long long)qi * n + slot] = e;
+    }
+    __syncthreads();
+    if (i < n) u = scores[(long long)qi * n + i];
+    if (PASS == 1 && i < n) {
+        u = u == -INFINITY ? -1.0f : fmaxf(u, 0.0f);
+        scores[(long long)qi * n + i] = u;
+    }
+    float best = i < n ? u : -INFINITY;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off, 64));
+    if (lane == 0) {
+        const long long o = (long long)qi * n_partials + blockIdx.x * 4 + wave;
+        if (PASS == 0) part_out[o] = best;
+        else best_bits[o] = __float_as_uint(fmaxf(best, 0.0f));
+    }
 }
 
 // |x|^2 in tree256 order for n_rows vectors (one wave each): query norms per call, database norms when a row is added
@@ -975,10 +1050,12 @@ int db_gemm_partials(int n) { return 4 * ((n + 255) / 256); }
 size_t db_gemm_scratch_floats(int n, int n_queries) { return (size_t)DBG_PARTS * (size_t)std::min(128, (n_queries + 31) / 32 * 32) * (size_t)n; }
 
 hipError_t launch_db_gemm(const float* q, int n_queries, const float* qnorm, const float* db, const float* dnorm, const unsigned char* occupied,
-                          int n, int dim, float* scores, unsigned int* best_partial, float* scratch, hipStream_t s) {
+                          int n, int dim, int mode, float* scores, unsigned int* best_partial, float* scratch, float* umax_a, float* umax_b,
+                          hipStream_t s) {
     if (n <= 0 || n_queries <= 0) return hipSuccess;
     if (dim % (DBG_PARTS * 64)) return hipErrorInvalidValue;
     const dim3 grid((n + 127) / 128, DBG_PARTS);
+    const int parts = db_gemm_partials(n);
     for (int q0 = 0; q0 < n_queries; q0 += 128) {
         const int nt = (std::min(128, n_queries - q0) + 31) / 32, qb = nt * 32, nq = std::min(qb, n_queries - q0);
         switch (nt) {
@@ -988,8 +1065,11 @@ hipError_t launch_db_gemm(const float* q, int n_queries, const float* qnorm, con
             default: hipLaunchKernelGGL((k_db_gemm<4>), grid, dim3(256), 0, s, q, n_queries, q0, db, n, dim, scratch); break;
         }
         hipLaunchKernelGGL(k_db_combine, dim3((n + 255) / 256, nq), dim3(256), 0, s, scratch, qb, n_queries, q0, qnorm, dnorm, occupied, n, scores,
-                           best_partial, db_gemm_partials(n));
+                           umax_a, parts);
     }
+    const dim3 rg((n + 255) / 256, n_queries);
+    hipLaunchKernelGGL((k_db_refine<0>), rg, dim3(256), 0, s, q, db, n, dim, mode, scores, umax_a, umax_b, best_partial, parts);
+    hipLaunchKernelGGL((k_db_refine<1>), rg, dim3(256), 0, s, q, db, n, dim, mode, scores, umax_b, umax_b, best_partial, parts);
     return hipGetLastError();
 }
 
