@@ -15,7 +15,7 @@
  * Numeric contract: fp32 end to end (f32 MFMA, fused multiply-add chains in the order fixed by
  * the CPU oracle, oracle/hfnet_oracle.h) -- keypoint coordinates / match indices / candidate
  * indices are bit-exact against the oracle, float outputs are bit-exact; the one exception is the
- * batched database scan for >= 8 queries (hfnet_db_query_batch), stated there.
+ * scores of non-candidate slots of the batched database scan for >= 8 queries (hfnet_db_query_batch), stated there.
  */
 #ifndef HFNET_HIP_H
 #define HFNET_HIP_H
@@ -255,14 +255,14 @@ int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slo
  * BASELINE config 5).  queries: [n_queries][dim]; cand_slot / cand_score: [n_queries][capacity] (row q holds n_cand[q]
  * entries); best_score: [n_queries] or NULL; scores_all: [n_queries][capacity] or NULL.
  *  - fewer than "db_gemm_min_queries" (8) queries: the exact scan, the database crosses HBM once per 8 queries; per query
- *    the results equal hfnet_db_query's bit for bit (dim <= 4096);
- *  - otherwise: S = DB * Q^T on the matrix cores (the database crosses HBM once per 128 queries) and
- *    score = max(0, 1 - sqrt(max(0, |q|^2 + |d|^2 - 2 S))), the same quantity in its inner-product form (dim % 512 == 0).
- *    Tolerance against hfnet_db_query: |score difference| <= 1e-6 / max(||q - d||, 2e-3) (the rounding of the three terms
- *    is ~1e-7 in the squared distance; the square root amplifies it for near-identical descriptors: 5e-6 at a distance of
- *    0.2, 5e-4 for a descriptor scanned against itself); a slot within that distance of the 0.8 * best threshold may fall
- *    on the other side.  Bit-exact against the oracle's restatement of
- *    this formula (hfo_db_scores_gemm). */
+ *    EVERY result equals hfnet_db_query's bit for bit (dim <= 4096);
+ *  - otherwise (dim % 512 == 0): S = DB * Q^T on the matrix cores (the database crosses HBM once per 128 queries) screens
+ *    max(0, 1 - sqrt(max(0, |q|^2 + |d|^2 - 2 S))) for every slot -- the same quantity in its inner-product form, which
+ *    loses digits exactly where a loop closure looks (up to 5e-4 for a descriptor scanned against itself) -- and every
+ *    slot whose value can decide something is then re-scored with hfnet_db_query's exact chain: the slots within 1e-3
+ *    of the largest screened value (-> the exact best score), and the slots from 5e-5 below the candidate threshold
+ *    upwards (-> every candidate).  best_score, the candidate set and cand_score equal hfnet_db_query's bit for bit
+ *    whatever the burst size; what stays approximate are the entries of scores_all of NON-candidates (|error| <= 5e-6). */
 int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int mode, int32_t* cand_slot,
                          float* cand_score, int32_t* n_cand, float* best_score, float* scores_all);
 

@@ -21,7 +21,16 @@ LAUNCHES = {
     "pointwise_desc_taps": ("void hfnet::k_pointwise_wlds<4>", 0),
     "pointwise_det": ("void hfnet::k_pointwise_wlds<3>", 0),
     "fc": ("void hfnet::k_fc_mfma<16>", 0),
+    "block_L09": ("void hfnet::k_block_fused4<1, 2, 6, true", 0),
+    "block_L12": ("void hfnet::k_block_fused4<1, 3, 6, false", 1),
+    "block_L13": ("void hfnet::k_block_fused4<1, 3, 9, true", 0),
+    "nms_mask": ("hfnet::k_nms_mask", 0),
     "nms_select": ("hfnet::k_nms_select", 0),
+    "softmax_d2s": ("hfnet::k_softmax_d2s", 0),
+    "sample": ("hfnet::k_sample", 0),
+    "pyramid_resize": ("hfnet::k_resize_u8", 0),
+    "depthwise_L16": ("void hfnet::k_depthwise<1, 5>", 0),
+    "vlad_aggregate": ("hfnet::k_vlad_aggregate", 0),
     "match_gemm": ("hfnet::k_bow_gemm_cand", 0),
     "match_candidates": ("hfnet::k_bow_candidates", 0),
 }
