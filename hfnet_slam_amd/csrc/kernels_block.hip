@@ -1116,7 +1116,8 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
     // alone and pays the latency of each of its phases in full, while the barrier-phased kernel puts four waves on a tile
     // (752x480, one frame: layer 5 49 -> 20 us, layers 3-7 together 200 -> 150 us).  Same bits either way.
     FusedKind kind = fused_kind(b, variant);
-    if (kind == FUSED_V4 && variant == 4 && n_tiles < 2048 && fused_kind(b, 2) == FUSED_V2) kind = FUSED_V2;
+    const bool small_launch = n_tiles < 2048;
+    if (kind == FUSED_V4 && variant == 4 && small_launch && fused_kind(b, 2) == FUSED_V2) kind = FUSED_V2;
     switch (kind) {
         case FUSED_NOEXPAND: {
             int maxtiles = 0;
@@ -1142,6 +1143,12 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
             if (st == 2 && kq == 3 && nto == 1) return launch_block_fused4_t<2, 1, 3, 2>(a, g, s);
             return hipErrorInvalidValue;
         case FUSED_V2:
+            // a single frame does not even give every CU one 8 x 16 tile: 8 x 8 tiles (twice the workgroups, half the work each)
+            if (small_launch && variant == 4) {
+                if (st == 1 && kq == 3 && nto == 1) return launch_block_fused2_t<1, 1, 3, true, 8>(a, g, s);
+                if (st == 1 && kq == 3 && nto == 2) return launch_block_fused2_t<1, 2, 3, true, 8>(a, g, s);
+                if (st == 1 && kq == 6 && nto == 3) return launch_block_fused2_t<1, 3, 6, true, 8>(a, g, s);
+            }
             if (st == 2 && kq == 2 && nto == 1) return launch_block_fused2_t<2, 1, 2, true>(a, g, s);
             if (st == 1 && kq == 3 && nto == 1) return launch_block_fused2_t<1, 1, 3, true>(a, g, s);
             if (st == 2 && kq == 3 && nto == 1) return launch_block_fused2_t<2, 1, 3, true>(a, g, s);
