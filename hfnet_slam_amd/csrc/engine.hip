@@ -390,7 +390,7 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
 // expansion, the NetVLAD memberships conv after layer 18 -- with every accumulation chain on the short-latency MFMA.
 bool Net::tail_chain() const {
     const DeviceWeights& w = e->w;
-    if (!tail_fuse || cfg.batch > tail_fuse || !w.memb16.w || w.memb16.cin != w.blocks[16].cout) return false;
+    if (!tail_fuse || cfg.batch > tail_fuse || !w.memb16.w || w.memb16.cin != w.blocks[16].cout || w.n_clusters > 64) return false;
     for (int L = 8; L <= 18; ++L) {
         const BlockPack& b = w.blocks[L - 2];
         if (!dwproject_supported(b) || block_runs_fused(*this, L) || (L > 8 && (!b.ex16.w || b.ex16.cin != w.blocks[L - 3].cout))) return false;
@@ -401,6 +401,7 @@ bool Net::tail_chain() const {
 int Net::forward_global(hipStream_t st) {
     const DeviceWeights& w = e->w;
     const int P = lp[0].h[18] * lp[0].w[18];
+    bool tail = false;
     if (tail_chain()) {
         // expanded tensors ping-pong between exp_buf and dw_buf (the depthwise tensor itself never exists on this path)
         float* ebuf[2] = {exp_buf, dw_buf};
@@ -412,13 +413,14 @@ int Net::forward_global(hipStream_t st) {
             char fn[32];
             snprintf(fn, sizeof fn, "tail_block_L%02d", L);
             HF_LAUNCH(e, st, fn, launch_dwproject(ebuf[L & 1], b, b.residual ? act[L - 1] : nullptr, act[L], next, next_bias,
-                                                  L < 18 ? ebuf[(L + 1) & 1] : memb, L < 18 ? 1 : 0, geom(L - 1, L, 0, 1), st));
+                                                  L < 18 ? ebuf[(L + 1) & 1] : memb, L < 18 ? 1 : 0, L < 18 ? 0 : 1, geom(L - 1, L, 0, 1), st));
         }
+        tail = true;                                             // (layer 18's launch leaves the SOFTMAXED memberships)
     } else {
         for (int L = 8; L <= 18; ++L) HF_TRY(run_block(*this, L, 1, st));
         HF_LAUNCH(e, st, "pointwise_memberships", launch_pointwise(act[18], w.memb, nullptr, memb, (long long)cfg.batch * P, 0, st));
     }
-    HF_LAUNCH(e, st, "softmax_memberships", launch_softmax_rows(memb, (long long)cfg.batch * P, w.n_clusters, w.n_clusters, st));
+    if (!tail) HF_LAUNCH(e, st, "softmax_memberships", launch_softmax_rows(memb, (long long)cfg.batch * P, w.n_clusters, w.n_clusters, st));
     HF_LAUNCH(e, st, "vlad", launch_vlad(act[18], memb, w.clusters, vlad_tap, vlad_out, vlad_raw, cfg.batch, P, w.c_global, w.n_clusters, st));
     HF_LAUNCH(e, st, "fc_l2", launch_fc_l2(vlad_out, w.fc, fc_part, fc_raw, global_dst ? global_dst : global_out, cfg.batch, st));
     return HFNET_OK;

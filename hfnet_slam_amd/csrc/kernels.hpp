@@ -51,8 +51,9 @@ hipError_t launch_permute_channels(const float* in, float* out, long long P, int
 bool dwproject_supported(const BlockPack& b);
 // next (optional): the 1x1 convolution that consumes the block's output -- the next block's expansion (next_relu 1) or the
 // NetVLAD memberships conv (0) -- evaluated in the same launch: next_out[pixel][next->n] = act(out[pixel] * W + next_bias)
+// next_softmax: the rows of next_out are softmaxed as launch_softmax_rows would (memberships; next->n <= 64)
 hipError_t launch_dwproject(const float* expanded, const BlockPack& b, const float* residual, float* out, const ConvPack16* next,
-                            const float* next_bias, float* next_out, int next_relu, const Geom& g, hipStream_t s);
+                            const float* next_bias, float* next_out, int next_relu, int next_softmax, const Geom& g, hipStream_t s);
 
 // ---- kernels_detect.hip -------------------------------------------------------------------------
 // softmax(65) -> drop dustbin -> depth_to_space(8) (hf_net.py:88-93); logits row stride ld

@@ -103,10 +103,13 @@ __global__ __launch_bounds__(256) void k_vlad_aggregate(const float* __restrict_
 }
 
 // block-wide tree256 sum of squares of v[0..n): partial tid accumulates elements tid + 256 j
+// (workgroups may be larger than 256 threads: the 256 partials and their tree are the definition, the extra threads only wait)
 __device__ __forceinline__ float block_sumsq_tree256(const float* v, int n, float* red) {
-    float p = 0.0f;
-    for (int i = threadIdx.x; i < n; i += 256) p = fmaf(v[i], v[i], p);
-    red[threadIdx.x] = p;
+    if (threadIdx.x < 256) {
+        float p = 0.0f;
+        for (int i = threadIdx.x; i < n; i += 256) p = fmaf(v[i], v[i], p);
+        red[threadIdx.x] = p;
+    }
     __syncthreads();
     for (int off = 128; off >= 1; off >>= 1) {
         if ((int)threadIdx.x < off) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + off];
@@ -118,16 +121,16 @@ __device__ __forceinline__ float block_sumsq_tree256(const float* v, int n, floa
 }
 
 // intra-normalisation over clusters (layers.py:89), flatten (K-major), L2, [tap], L2 (layers.py:92,97)
-__global__ __launch_bounds__(256) void k_vlad_norm(const float* __restrict__ raw, float* __restrict__ vlad_tap, float* __restrict__ out,
-                                                   int D, int K) {
+__global__ __launch_bounds__(1024) void k_vlad_norm(const float* __restrict__ raw, float* __restrict__ vlad_tap, float* __restrict__ out,
+                                                    int D, int K) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* v = smem;            // K*D
     float* red = smem + K * D;  // 256
-    const int frame = blockIdx.x, N = K * D;
+    const int frame = blockIdx.x, N = K * D, T = blockDim.x;
     const float* src = raw + (long long)frame * N;
-    for (int i = threadIdx.x; i < N; i += 256) v[i] = src[i];
+    for (int i = threadIdx.x; i < N; i += T) v[i] = src[i];
     __syncthreads();
-    for (int d = threadIdx.x; d < D; d += 256) {
+    for (int d = threadIdx.x; d < D; d += T) {
         float ss = 0.0f;
         for (int k = 0; k < K; ++k) ss = fmaf(v[k * D + d], v[k * D + d], ss);
         const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
@@ -136,13 +139,13 @@ __global__ __launch_bounds__(256) void k_vlad_norm(const float* __restrict__ raw
     __syncthreads();
     float ss = block_sumsq_tree256(v, N, red);
     float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
-    for (int i = threadIdx.x; i < N; i += 256) v[i] = v[i] * inv;
+    for (int i = threadIdx.x; i < N; i += T) v[i] = v[i] * inv;
     __syncthreads();
-    if (vlad_tap) for (int i = threadIdx.x; i < N; i += 256) vlad_tap[(long long)frame * N + i] = v[i];
+    if (vlad_tap) for (int i = threadIdx.x; i < N; i += T) vlad_tap[(long long)frame * N + i] = v[i];
     ss = block_sumsq_tree256(v, N, red);
     inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
     // handed to the FC kernel in its slot order within every group of 16 inputs (FcPack, common.hpp)
-    for (int i = threadIdx.x; i < N; i += 256) {
+    for (int i = threadIdx.x; i < N; i += T) {
         const int rr = i & 15;
         out[(long long)frame * N + ((i & ~15) | ((rr & 3) << 2) | (rr >> 2))] = v[i] * inv;
     }
@@ -153,7 +156,7 @@ hipError_t launch_vlad(const float* feat, const float* memb, const float* cluste
     if (frames <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_vlad_aggregate, dim3((K * D + 255) / 256, frames), dim3(256), 0, s, feat, memb, clusters, scratch, P, D, K);
     const size_t lds = (size_t)(K * D + 256) * sizeof(float);
-    hipLaunchKernelGGL(k_vlad_norm, dim3(frames), dim3(256), lds, s, scratch, vlad_tap, out, D, K);
+    hipLaunchKernelGGL(k_vlad_norm, dim3(frames), dim3(1024), lds, s, scratch, vlad_tap, out, D, K);
     return hipGetLastError();
 }
 
@@ -234,16 +237,16 @@ __device__ __forceinline__ float fc_combine_one(const float* __restrict__ partia
 
 // partial sums [FC_PARTS][frames][n] -> y = tree + bias (kept in y_raw), then the L2 normalisation of layers.py:108.
 // One launch for the single-frame path (a workgroup per frame) ...
-__global__ __launch_bounds__(256) void k_fc_combine_l2(const float* __restrict__ partial, const float* __restrict__ bias, float* __restrict__ y_raw,
-                                                       float* __restrict__ out, int frames, int n) {
+__global__ __launch_bounds__(1024) void k_fc_combine_l2(const float* __restrict__ partial, const float* __restrict__ bias, float* __restrict__ y_raw,
+                                                        float* __restrict__ out, int frames, int n) {
     __shared__ float red[256];
     const int f = blockIdx.x;
     float* v = y_raw + (long long)f * n;
-    for (int i = threadIdx.x; i < n; i += 256) v[i] = fc_combine_one(partial, bias, frames, n, f, i);
+    for (int i = threadIdx.x; i < n; i += 1024) v[i] = fc_combine_one(partial, bias, frames, n, f, i);
     __syncthreads();
     const float ss = block_sumsq_tree256(v, n, red);
     const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
-    for (int i = threadIdx.x; i < n; i += 256) out[(long long)f * n + i] = v[i] * inv;
+    for (int i = threadIdx.x; i < n; i += 1024) out[(long long)f * n + i] = v[i] * inv;
 }
 // ... two for many frames (the 17 MB of partial sums of a 64-frame call want more than 64 workgroups)
 __global__ __launch_bounds__(256) void k_fc_combine(const float* __restrict__ partial, const float* __restrict__ bias, float* __restrict__ y_raw, int frames, int n) {
@@ -267,7 +270,7 @@ hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* partial, float*
     const int ppw = frames > 16 ? 4 : 1;
     hipLaunchKernelGGL(k_fc_mfma<16>, dim3(fc.n_out / 16, (frames + 63) / 64, FC_PARTS / ppw), dim3(64 * waves), 0, s, x, fc.w, partial, frames, fc.n_in, fc.n_out, ppw);
     if (frames <= 4) {
-        hipLaunchKernelGGL(k_fc_combine_l2, dim3(frames), dim3(256), 0, s, partial, fc.bias, y_raw, out, frames, fc.n_out);
+        hipLaunchKernelGGL(k_fc_combine_l2, dim3(frames), dim3(1024), 0, s, partial, fc.bias, y_raw, out, frames, fc.n_out);
     } else {
         hipLaunchKernelGGL(k_fc_combine, dim3((fc.n_out + 255) / 256, frames), dim3(256), 0, s, partial, fc.bias, y_raw, frames, fc.n_out);
         hipLaunchKernelGGL(k_l2norm_vec, dim3(frames), dim3(256), 0, s, y_raw, out, fc.n_out);

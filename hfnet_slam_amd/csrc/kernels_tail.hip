@@ -23,6 +23,21 @@ namespace hfnet {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float relu6t(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f); }
+__device__ __forceinline__ float hf_expf_t(float x) {   // == oracle hfo_expf (as in kernels_global.hip / kernels_detect.hip)
+    x = fminf(fmaxf(x, -87.0f), 88.0f);
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    const float y = fmaf(p, r2, r) + 1.0f;
+    return ldexpf(y, (int)n);
+}
 __device__ __forceinline__ int d_logical_of_phys(int p) { const int r = p & 7; return (p & ~7) | (r < 4 ? 2 * r : 2 * (r - 4) + 1); }
 // slot of logical channel l inside its group of 16: lane group g = l % 4 of the 16x16x4 MFMA finds channels g, 4 + g, 8 + g, 12 + g
 // (its operands of four consecutive MFMAs) in slots 4 g .. 4 g + 3
@@ -43,6 +58,7 @@ struct DwProjArgs {
     const float* nx_bias;
     float* nx_out;           // [pixels of the block output][nx_ld]
     int nx_n, nx_n16, nx_ld, nx_relu;
+    int nx_softmax;          // the rows of nx_out are softmaxed (the NetVLAD memberships, layers.py:75; nx_n <= 64, one workgroup per tile)
 };
 
 // TH x 8 output pixels per workgroup (16: one MFMA row tile), 8 waves.
@@ -239,8 +255,27 @@ __global__ __launch_bounds__(512) void k_dwproject(DwProjArgs a, Geom g) {
         const int col = xt * 16 + j;
         if (col < a.nx_n) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (ovalid[t]) a.nx_out[orow[t] * a.nx_ld + col] = a.nx_relu ? relu6t(acc[t]) : acc[t];
+            for (int t = 0; t < 4; ++t) {
+                if (a.nx_softmax) H[(4 * gq + t) * 68 + col] = acc[t];                 // (the halo buffer is free by now)
+                else if (ovalid[t]) a.nx_out[orow[t] * a.nx_ld + col] = a.nx_relu ? relu6t(acc[t]) : acc[t];
+            }
+        }
+    }
+    if (a.nx_softmax) {
+        // softmax over the nx_n columns of every pixel of the tile, the sum left to right (k_softmax_rows' expressions): one
+        // thread per pixel -- 16 short serial chains instead of a launch of its own
+        __syncthreads();
+        if (tid < TP) {
+            const int oy = oy0 + tid / TW, ox = ox0 + tid % TW;
+            if (oy < lv.Ho && ox < lv.Wo) {
+                float* r = H + tid * 68;
+                float mx = r[0];
+                for (int k = 1; k < a.nx_n; ++k) mx = fmaxf(mx, r[k]);
+                float sum = 0.0f;
+                for (int k = 0; k < a.nx_n; ++k) { r[k] = hf_expf_t(r[k] - mx); sum = sum + r[k]; }
+                float* o = a.nx_out + (obase + (long long)oy * lv.Wo + ox) * a.nx_ld;
+                for (int k = 0; k < a.nx_n; ++k) o[k] = r[k] / sum;
+            }
         }
     }
 }
@@ -256,17 +291,18 @@ bool dwproject_supported(const BlockPack& b) {
 }
 
 hipError_t launch_dwproject(const float* expanded, const BlockPack& b, const float* residual, float* out, const ConvPack16* next,
-                            const float* next_bias, float* next_out, int next_relu, const Geom& g, hipStream_t s) {
+                            const float* next_bias, float* next_out, int next_relu, int next_softmax, const Geom& g, hipStream_t s) {
     if (!dwproject_supported(b) || (residual && (b.stride != 1 || b.cin != b.cout))) return hipErrorInvalidValue;
     DwProjArgs a;
     a.E = expanded; a.Wdw = b.dw.w; a.dw_bias = b.dw.bias; a.Wpr = (const f32x4*)b.pr16.w; a.pr_bias = b.pr.bias; a.R = residual; a.out = out;
     a.cexp = b.expand; a.cout = b.cout; a.n16 = b.pr16.n16;
-    a.Wnx = nullptr; a.nx_bias = nullptr; a.nx_out = nullptr; a.nx_n = a.nx_n16 = a.nx_ld = a.nx_relu = 0;
+    a.Wnx = nullptr; a.nx_bias = nullptr; a.nx_out = nullptr; a.nx_n = a.nx_n16 = a.nx_ld = a.nx_relu = a.nx_softmax = 0;
     if (b.pr.nt_total * 32 < a.n16 * 16) return hipErrorInvalidValue;          // (the shared bias array covers the padded columns)
     if (next) {
         if (next->cin != b.cout || !next->w || !next_bias || !next_out) return hipErrorInvalidValue;
         a.Wnx = (const f32x4*)next->w; a.nx_bias = next_bias; a.nx_out = next_out; a.nx_n = next->n; a.nx_n16 = next->n16; a.nx_ld = next->n;
-        a.nx_relu = next_relu;
+        a.nx_relu = next_relu; a.nx_softmax = next_softmax;
+        if (next_softmax && (next->n > 64 || next->n16 > 8)) return hipErrorInvalidValue;
         a.nsplit = (next->n16 + 15) / 16;                                      // at most two column tiles of the next conv per wave
     } else {
         a.nsplit = (b.pr16.n16 + 7) / 8;
