@@ -20,7 +20,7 @@ int* Options::find(const char* name) {
     const struct { const char* n; int* p; } tab[] = {{"fuse_blocks", &fuse_blocks}, {"fuse_max_layer", &fuse_max_layer}, {"fused_variant", &fused_variant},
                                                        {"fuse_stem", &fuse_stem}, {"dense_desc", &dense_desc}, {"two_streams", &two_streams},
                                                        {"graph", &graph}, {"pinned_frames", &pinned_frames}, {"db_gemm_min_queries", &db_gemm_min_queries},
-                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}};
+                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}};
     for (const auto& t : tab) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -870,7 +870,22 @@ static int extract_chunk(hfnet_extractor* x, int nb, const uint8_t* d_images, in
     ImageSet imgs;
     std::memset(&imgs, 0, sizeof imgs);
     imgs.ptr[0] = d_images; imgs.row_stride[0] = row_stride; imgs.frame_stride[0] = frame_stride;
-    for (int l = 1; l < x->n_levels; ++l) {
+    // calls of a few frames: the pyramid chain as ONE launch (three dependent 7 us launches otherwise)
+    const bool chain = nb <= 4 && eng.opt.pyramid_fuse && x->n_levels >= 2 && pyramid_chain_supported(x->n_levels - 1, x->level_w, x->level_h);
+    if (chain) {
+        uint8_t* dst[HFNET_MAX_LEVELS] = {nullptr};
+        int d_row[HFNET_MAX_LEVELS] = {0};
+        long long d_frame[HFNET_MAX_LEVELS] = {0};
+        for (int l = 1; l < x->n_levels; ++l) {
+            const int dwp = (x->level_w[l] + 3) & ~3;
+            dst[l] = x->d_pyr[l]; d_row[l] = dwp; d_frame[l] = (long long)dwp * x->level_h[l];
+            imgs.ptr[l] = x->d_pyr[l]; imgs.row_stride[l] = dwp; imgs.frame_stride[l] = d_frame[l];
+        }
+        HF_LAUNCH(&eng, net.stream, "pyramid_resize",
+                  launch_pyramid_chain(d_images, row_stride, frame_stride, x->n_levels - 1, x->level_w, x->level_h, dst, d_row, d_frame, x->d_xofs,
+                                       x->d_ialpha, x->d_yofs, x->d_ibeta, nb, net.stream));
+    }
+    for (int l = 1; l < x->n_levels && !chain; ++l) {
         const int sw = x->level_w[l - 1], sh = x->level_h[l - 1], dw = x->level_w[l], dh = x->level_h[l];
         const int dwp = (dw + 3) & ~3;              // pyramid rows are padded to 4 bytes (packed stores)
         HF_LAUNCH(&eng, net.stream, "pyramid_resize",

@@ -97,6 +97,7 @@ struct Options {
     int pinned_frames = 4;    // chunks up to this many frames move through one pinned block inside that graph
     int conv_wlds = 1;        // 3x3 heads: weights staged through LDS once per workgroup (0: every wave reads them from L1 / L2)
     int db_gemm_min_queries = 8;   // hfnet_db_query_batch: from this many queries on, the scores come from the MFMA GEMM form
+    int pyramid_fuse = 1;     // calls of up to four frames: the pyramid chain as one launch
     int dedupe_taps = 1;      // sparse descriptor head: taps shared by neighbouring keypoints are evaluated once
     int tail_fuse = 4;        // calls of up to this many frames run layers 8-18 with the single-frame kernels (0: never)
     int copy_threads = 64;    // helper threads of the host-pointer batch pipeline's staging copies (>= 64: chosen from the core count)

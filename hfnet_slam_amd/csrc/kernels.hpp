@@ -11,6 +11,12 @@ hipError_t launch_resize_u8(const uint8_t* src, int sw, int sh, int s_row, long 
                             uint8_t* dst, int dw, int dh, int d_row, long long d_frame,
                             const int* xofs, const short* ialpha, const int* yofs, const short* ibeta,
                             int batch, hipStream_t s);
+// the whole chain level 0 -> 1 -> .. -> n (n <= 3) in one launch, same bytes (arrays indexed by level, [0] of dst / tables unused);
+// d_row: padded row length of a produced level (the padding repeats the last column, as launch_resize_u8 leaves it)
+bool pyramid_chain_supported(int n, const int* w, const int* h);
+hipError_t launch_pyramid_chain(const uint8_t* src, int s_row, long long s_frame, int n, const int* w, const int* h, uint8_t* const* dst,
+                                const int* d_row, const long long* d_frame, const int* const* xofs, const short* const* ialpha,
+                                const int* const* yofs, const short* const* ibeta, int batch, hipStream_t s);
 // image prep + stem conv 3x3/2 + BN + ReLU6 (HFNetTFModelV2.cc:204-208, layers.py:6-7, hf_net.py:30,188-190)
 hipError_t launch_stem(const ImageSet& imgs, const float* w, const float* bias, int cout, float* out, const Geom& g, hipStream_t s);
 // 1x1 convolution on the matrix cores: out[P x n] = epilogue(A[P x cin] * W).  slot_units (optional, device): the rows are

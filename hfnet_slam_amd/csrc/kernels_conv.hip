@@ -87,6 +87,94 @@ hipError_t launch_resize_u8(const uint8_t* src, int sw, int sh, int s_row, long 
     return hipGetLastError();
 }
 
+// ---- the whole pyramid chain in ONE launch (calls of a few frames, where three dependent 7 us launches are 3 % of the
+// call).  A workgroup owns PYR_BAND rows of the LAST level and everything above them: it works out which rows of each
+// intermediate level those rows descend from (the same yofs tables), computes them level by level from the input image --
+// intermediate levels stay in LDS as the next level's source -- and writes every row it computed (rows at band borders are
+// written by two workgroups with the same bytes).  Bands tile every level without gaps while a row step of the tables
+// is at most 2 (scale < 2).  Per pixel the arithmetic is k_resize_u8's.
+#define PYR_BAND 4
+struct PyrArgs {
+    const uint8_t* src; int s_row; long long s_frame;
+    int n;                                            // transitions (levels 1 .. n are produced)
+    int w[4], h[4];                                   // sizes of levels 0 .. n
+    uint8_t* dst[4]; int d_row[4]; long long d_frame[4];          // [l]: level l, l = 1 .. n
+    const int* xofs[4]; const short* ialpha[4]; const int* yofs[4]; const short* ibeta[4];
+    int lds_off[4], lds_rows[4];                      // [l]: byte offset / row capacity of level l's band in LDS (l = 1 .. n - 1)
+};
+__global__ __launch_bounds__(1024) void k_pyramid_chain(PyrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pyr_lds[];
+    __shared__ int lo[4], hi[4];
+    const int band = blockIdx.x, frame = blockIdx.y, n = a.n;
+    if (threadIdx.x == 0) {
+        const int last = (int)gridDim.x - 1;
+        lo[n] = band * PYR_BAND; hi[n] = min(lo[n] + PYR_BAND, a.h[n]) - 1;
+        for (int l = n; l >= 2; --l) {
+            int l0 = min(max(a.yofs[l][lo[l]], 0), a.h[l - 1] - 1), h0 = min(max(a.yofs[l][hi[l]] + 1, 0), a.h[l - 1] - 1);
+            if (band == 0) l0 = 0;
+            if (band == last) h0 = a.h[l - 1] - 1;
+            lo[l - 1] = l0; hi[l - 1] = min(h0, l0 + a.lds_rows[l - 1] - 1);   // (the capacity is sized so that this never cuts)
+        }
+    }
+    __syncthreads();
+    const uint8_t* sp0 = a.src + (long long)frame * a.s_frame;
+    for (int l = 1; l <= n; ++l) {
+        const int sw = a.w[l - 1], sh = a.h[l - 1], dw = a.w[l];
+        const uint8_t* sp = l == 1 ? sp0 : pyr_lds + a.lds_off[l - 1];
+        const int srow = l == 1 ? a.s_row : sw, sbase = l == 1 ? 0 : lo[l - 1];
+        uint8_t* keep = l < n ? pyr_lds + a.lds_off[l] : nullptr;
+        uint8_t* gp = a.dst[l] + (long long)frame * a.d_frame[l];
+        const int r0 = lo[l], r1 = hi[l], cols = a.d_row[l];
+#pragma unroll 2
+        for (int idx = threadIdx.x; idx < (r1 - r0 + 1) * cols; idx += 1024) {
+            const int ry = idx / cols, dxp = idx - ry * cols, dy = r0 + ry, dx = min(dxp, dw - 1);
+            const int sy = a.yofs[l][dy];
+            const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
+            const int b0 = a.ibeta[l][2 * dy], b1 = a.ibeta[l][2 * dy + 1];
+            const int sx = a.xofs[l][dx], sx1 = min(sx + 1, sw - 1);
+            const int a0 = a.ialpha[l][2 * dx], a1 = a.ialpha[l][2 * dx + 1];
+            const uint8_t* p0 = sp + (long long)(y0 - sbase) * srow;
+            const uint8_t* p1 = sp + (long long)(y1 - sbase) * srow;
+            const int h0 = p0[sx] * a0 + p0[sx1] * a1, h1 = p1[sx] * a0 + p1[sx1] * a1;
+            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+            gp[(long long)dy * cols + dxp] = (uint8_t)v;                   // (columns past dw repeat the last one: the row padding)
+            if (keep && dxp < dw) keep[ry * dw + dxp] = (uint8_t)v;
+        }
+        __syncthreads();
+    }
+}
+
+// sizes[l] = (w, h) of level l = 0 .. n; false when the chain does not fit (more than three transitions, a row step above 2, LDS)
+bool pyramid_chain_supported(int n, const int* w, const int* h) {
+    if (n < 1 || n > 3) return false;
+    for (int l = 1; l <= n; ++l) if (h[l - 1] >= 2 * h[l] || w[l] < 1) return false;
+    return true;
+}
+hipError_t launch_pyramid_chain(const uint8_t* src, int s_row, long long s_frame, int n, const int* w, const int* h, uint8_t* const* dst,
+                                const int* d_row, const long long* d_frame, const int* const* xofs, const short* const* ialpha,
+                                const int* const* yofs, const short* const* ibeta, int batch, hipStream_t s) {
+    if (!pyramid_chain_supported(n, w, h)) return hipErrorInvalidValue;
+    PyrArgs a;
+    a.src = src; a.s_row = s_row; a.s_frame = s_frame; a.n = n;
+    for (int l = 0; l <= n; ++l) { a.w[l] = w[l]; a.h[l] = h[l]; }
+    size_t lds = 0;
+    int rows = PYR_BAND;
+    for (int l = n; l >= 1; --l) {
+        a.dst[l] = dst[l]; a.d_row[l] = d_row[l]; a.d_frame[l] = d_frame[l];
+        a.xofs[l] = xofs[l]; a.ialpha[l] = ialpha[l]; a.yofs[l] = yofs[l]; a.ibeta[l] = ibeta[l];
+        a.lds_off[l] = 0; a.lds_rows[l] = 0;
+        if (l < n) {                                                           // rows of level l that `rows` rows of level l + 1 can need
+            rows = (int)((long long)rows * h[l] / h[l + 1]) + 6;
+            a.lds_rows[l] = rows; a.lds_off[l] = (int)lds;
+            lds += ((size_t)rows * w[l] + 15) / 16 * 16;
+        }
+    }
+    if (lds > 60 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_pyramid_chain, dim3((h[n] + PYR_BAND - 1) / PYR_BAND, batch), dim3(1024), lds, s, a);
+    return hipGetLastError();
+}
+
 // =========================================================================== stem
 // u8 -> (x-128)/128 -> crop to multiples of 8 (Geom carries the cropped size) -> conv 3x3 stride 2
 // 1 -> cout, BN, ReLU6.  One thread per output pixel, weights in LDS.  HBM-bound on the output write.

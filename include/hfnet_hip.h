@@ -87,6 +87,7 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *   "db_gemm_min_queries" (8): hfnet_db_query_batch switches to the MFMA form of the scores from this many queries on
  *   "tail_fuse" (4)     calls of up to this many frames run layers 8-18 with the single-frame kernels (depthwise + projection
  *                       in one launch, short-latency MFMA chains); 0: never
+ *   "pyramid_fuse" (1)  calls of up to four frames: the pyramid resize chain as one launch
  *   "copy_threads" (64 = by core count): helper threads for the staging copies of host-pointer batch calls (replicas sharing a host)
  * Values are >= 0.
  * Every setting of the extractor switches produces the same bits (tests/test_gpu_parity.py). */

@@ -9,7 +9,7 @@ f = glob.glob('/tmp/ktl/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 first = rows[0]["Kernel_Name"]
 # frames start with the first kernel name of the script's steady state: take the last complete frame
-starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("hfnet::k_resize_u8") or "k_resize_u8" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "k_resize_u8" in r["Kernel_Name"] or "k_pyramid_chain" in r["Kernel_Name"]]
 # three resizes per frame: a frame starts at the first of a group
 grp = [i for j, i in enumerate(starts) if j == 0 or i - starts[j - 1] > 3]
 a = grp[-2]; b = grp[-1]
