@@ -45,9 +45,17 @@ Engine::~Engine() {
     for (auto ev : prof.pool) (void)hipEventDestroy(ev);
     for (DevMem* m : {&m_a, &m_b, &m_s, &m_qn, &m_tn, &m_key, &m_i0, &m_i1, &m_f0, &m_f1, &m_cnt, &m_pairs}) m->release();
     w.release();
+    if (h_res) (void)hipHostFree(h_res);
     if (ev_extract) (void)hipEventDestroy(ev_extract);
     if (ev_match) (void)hipEventDestroy(ev_match);
     if (stream) (void)hipStreamDestroy(stream);
+}
+
+bool Engine::pinned_results(size_t bytes) {
+    constexpr size_t cap = 1 << 20;
+    if (bytes > cap) return false;
+    if (!h_res) { void* p = nullptr; if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; } h_res = (unsigned char*)p; }
+    return true;
 }
 
 hipError_t Engine::note_extract(hipStream_t net_stream) {
@@ -1118,7 +1126,8 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
     HF_HIP(hipSetDevice(eng.device));
     hipStream_t st = x->net.stream;
     const int G = eng.w.global_dim;
-    if (on_device) { HF_HIP(eng.wait_fence(st)); std::fill(x->last_n.begin(), x->last_n.end(), -1); }
+    HF_HIP(eng.wait_fence(st));          // (device-resident callers' hfnet_engine_fence; hfnet_store_put_extracted's copies out of the staging block)
+    if (on_device) std::fill(x->last_n.begin(), x->last_n.end(), -1);
     for (int f0 = 0; f0 < n_frames; f0 += x->max_batch) {
         const int nb = std::min(x->max_batch, n_frames - f0);
         if (!on_device) std::fill(x->last_n.begin() + nb, x->last_n.end(), -1);   // staging frames this chunk does not write
@@ -1433,7 +1442,14 @@ int hfnet_store_put_extracted(hfnet_store* st, int slot, hfnet_extractor* x, int
                                  sizeof(float) * (size_t)n * st->dim, hipMemcpyDeviceToDevice, e.stream));
     HF_HIP(hipMemcpyAsync(st->d_rows + slot, src_n + frame, sizeof(int32_t), hipMemcpyDeviceToDevice, e.stream));
     HF_HIP(hipMemsetAsync(st->d_flags + (size_t)slot * st->max_rows, 0, (size_t)st->max_rows, e.stream));
-    HF_HIP(hipStreamSynchronize(e.stream));
+    // no host synchronisation: later matches follow on the same stream, and the next extraction (which overwrites the staging
+    // block these copies read) waits for this point by event, like hfnet_engine_fence
+    {
+        std::lock_guard<std::mutex> lk3(e.ev_mu);
+        if (!e.ev_match) HF_HIP(hipEventCreateWithFlags(&e.ev_match, hipEventDisableTiming));
+        HF_HIP(hipEventRecord(e.ev_match, e.stream));
+        e.ev_match_set = true;
+    }
     st->rows[slot] = n;
     return HFNET_OK;
 }
@@ -1503,9 +1519,23 @@ static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const 
         HF_LAUNCH(&e, e.stream, "store_remap",
                   launch_store_remap(n_pairs, d_qsel, d_tsel, d_cslot, st->d_rows, d_map, d_inv, mr, w_match, triangulation ? nullptr : w_dist, d_match,
                                      triangulation ? nullptr : d_dist, e.stream));
-    HF_HIP(hipMemcpyAsync(match, d_match, sizeof(int32_t) * (size_t)n_pairs * mr, hipMemcpyDeviceToHost, e.stream));
-    if (!triangulation) HF_HIP(hipMemcpyAsync(dist, d_dist, sizeof(float) * (size_t)n_pairs * mr, hipMemcpyDeviceToHost, e.stream));
-    HF_HIP(hipMemcpyAsync(n_matches, d_cnt, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToHost, e.stream));
+    // results: through the engine's pinned block when they fit (copies into pageable memory are staged and synchronous one by one)
+    const size_t b_match = sizeof(int32_t) * (size_t)n_pairs * mr, b_dist = triangulation ? 0 : sizeof(float) * (size_t)n_pairs * mr,
+                 b_cnt = sizeof(int32_t) * (size_t)n_pairs;
+    if (e.pinned_results(b_match + b_dist + b_cnt)) {
+        unsigned char* hp = e.h_res;
+        HF_HIP(hipMemcpyAsync(hp, d_match, b_match, hipMemcpyDeviceToHost, e.stream));
+        if (b_dist) HF_HIP(hipMemcpyAsync(hp + b_match, d_dist, b_dist, hipMemcpyDeviceToHost, e.stream));
+        HF_HIP(hipMemcpyAsync(hp + b_match + b_dist, d_cnt, b_cnt, hipMemcpyDeviceToHost, e.stream));
+        HF_HIP(hipStreamSynchronize(e.stream));
+        std::memcpy(match, hp, b_match);
+        if (b_dist) std::memcpy(dist, hp + b_match, b_dist);
+        std::memcpy(n_matches, hp + b_match + b_dist, b_cnt);
+        return HFNET_OK;
+    }
+    HF_HIP(hipMemcpyAsync(match, d_match, b_match, hipMemcpyDeviceToHost, e.stream));
+    if (!triangulation) HF_HIP(hipMemcpyAsync(dist, d_dist, b_dist, hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipMemcpyAsync(n_matches, d_cnt, b_cnt, hipMemcpyDeviceToHost, e.stream));
     HF_HIP(hipStreamSynchronize(e.stream));
     return HFNET_OK;
 }

@@ -118,6 +118,8 @@ struct Engine {
     std::mutex ev_mu;
     hipEvent_t ev_extract = nullptr, ev_match = nullptr;   // last on_device extraction / last hfnet_engine_fence
     bool ev_extract_set = false, ev_match_set = false;
+    unsigned char* h_res = nullptr;                         // 1 MB pinned block for the small results of the store matchers (under mu)
+    bool pinned_results(size_t bytes);                      // the block exists and holds `bytes`
     hipError_t note_extract(hipStream_t net_stream);        // record: extraction enqueued up to here
     hipError_t wait_extract();                              // matcher stream waits for it
     hipError_t wait_fence(hipStream_t net_stream);          // extractor stream waits for the last fence
