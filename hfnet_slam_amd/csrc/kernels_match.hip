@@ -932,7 +932,11 @@ __global__ __launch_bounds__(256) void k_db_combine(const float* __restrict__ pa
         float p[DBG_PARTS];
 #pragma unroll
         for (int w = 0; w < DBG_PARTS; ++w) p[w] = partial[((long long)w * qb + c) * n + i];
-        const float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+#pragma unroll
+        for (int m = DBG_PARTS; m > 1; m >>= 1)
+#pragma unroll
+            for (int w = 0; w < m / 2; ++w) p[w] = p[2 * w] + p[2 * w + 1];
+        const float s = p[0];
         if (occupied[i]) {
             const float t = qnorm[qi] + dnorm[i];
             const float d2 = fmaxf(fmaf(-2.0f, s, t), 0.0f);
