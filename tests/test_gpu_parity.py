@@ -159,11 +159,17 @@ def test_response_ties(weights_ties_path):
     m.close(); e.close()
 
 
-@pytest.mark.parametrize("fuse_stem", [0, 1])
+# the single-frame path's own pieces on and off: pyramid chain in one launch, distinct tap cells, one launch per block for layers
+# 8-18, and the caller-owned result buffers of the wrapper
+EXTRACTOR_VARIANTS = {"default": {}, "unfused_stem": {"fuse_stem": 0}, "separate_launches": {"pyramid_fuse": 0, "dedupe_taps": 0, "tail_fuse": 0},
+                      "no_graph": {"graph": 0, "pinned_frames": 0}}
+
+
+@pytest.mark.parametrize("variant", list(EXTRACTOR_VARIANTS))
 @pytest.mark.parametrize("cfg", [(160, 120, 300, 3), (200, 152, 500, 4), (96, 96, 64, 1)])
-def test_extractor_matches_oracle(engine, oracle_model, cfg, fuse_stem, engine_options):
+def test_extractor_matches_oracle(engine, oracle_model, cfg, variant, engine_options):
     from hfnet_slam_amd import capi
-    engine_options({"fuse_stem": fuse_stem})
+    engine_options(EXTRACTOR_VARIANTS[variant])
     w, h, nf, nl = cfg
     x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, nl, max_batch=2)
     sf, fpl, lw, lh = x.tables()
@@ -175,6 +181,12 @@ def test_extractor_matches_oracle(engine, oracle_model, cfg, fuse_stem, engine_o
     rn, rk, rd, rg, rnpl = oracle_model.extract(imgs[0], nf, 0.01, nl, 1.2)
     assert n == rn
     _eq("n per level", npl, rnpl); _eq("kps", kps, rk); _eq("desc", desc, rd); _eq("global", g, rg)
+    # the same call into caller-owned buffers, twice (the second call's results must not depend on what the first left behind)
+    bufs = x.output_buffers()
+    for img in (imgs[1], imgs[0]):
+        n2, k2, d2, g2, npl2 = x.extract(img, bufs)
+    assert n2 == rn and d2.base is bufs[1]
+    _eq("n per level (own buffers)", npl2, rnpl); _eq("kps (own buffers)", k2, rk); _eq("desc (own buffers)", d2, rd); _eq("global (own buffers)", g2, rg)
     # batched (3 frames through a max_batch=2 extractor -> two chunks)
     nb, kb, db, gb = x.extract_batch(imgs)
     for i in range(3):
