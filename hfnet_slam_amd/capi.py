@@ -27,7 +27,7 @@ SYMBOLS = [
     "hfnet_model_create", "hfnet_model_destroy", "hfnet_model_is_valid", "hfnet_model_mode",
     "hfnet_model_detect", "hfnet_model_detect_global", "hfnet_model_tap",
     "hfnet_extractor_create", "hfnet_extractor_destroy", "hfnet_extractor_tables",
-    "hfnet_extractor_extract", "hfnet_extractor_extract_batch",
+    "hfnet_extractor_extract", "hfnet_extractor_extract_batch", "hfnet_extractor_last_timing",
     "hfnet_descriptor_distance", "hfnet_resampler", "hfnet_match_search_by_bow", "hfnet_match_search_by_bow_batch", "hfnet_match_search_for_triangulation", "hfnet_match_search_for_triangulation_batch",
     "hfnet_match_candidates", "hfnet_distinctive_descriptors",
     "hfnet_extractor_attach_store", "hfnet_store_create", "hfnet_store_destroy", "hfnet_store_put", "hfnet_store_put_extracted", "hfnet_store_rows", "hfnet_store_set_flags", "hfnet_store_search_by_bow",
@@ -121,7 +121,7 @@ class Engine:
         _chk(lib().hfnet_engine_get_option(self.h, name.encode(), C.byref(v)))
         return v.value
 
-    OPTIONS = ("fuse_blocks", "fuse_max_layer", "fused_variant", "fuse_stem", "dense_desc", "conv_wlds", "two_streams", "graph", "pinned_frames", "db_gemm_min_queries", "fuse_min_wgs", "copy_threads", "tail_fuse", "dedupe_taps", "pyramid_fuse")
+    OPTIONS = ("fuse_blocks", "fuse_max_layer", "fused_variant", "fuse_stem", "dense_desc", "conv_wlds", "two_streams", "graph", "pinned_frames", "db_gemm_min_queries", "fuse_min_wgs", "copy_threads", "tail_fuse", "dedupe_taps", "pyramid_fuse", "interleave", "host_global")
 
     def options(self) -> dict:
         return {n: self.get_option(n) for n in self.OPTIONS}
@@ -311,6 +311,13 @@ class Extractor:
         fpl, lw, lh = (np.zeros(self.n_levels, np.int32) for _ in range(3))
         _chk(lib().hfnet_extractor_tables(self.h, _p(sf), _p(fpl), _p(lw), _p(lh)))
         return sf, fpl, lw, lh
+
+    def last_timing(self):
+        """host-side stamps (us since entry) of the last latency-path call: image staged, enqueued, local results seen,
+        unpacked, stream drained, return"""
+        t = np.zeros(6, np.float64)
+        _chk(lib().hfnet_extractor_last_timing(self.h, _p(t), 6))
+        return t
 
     def extract(self, img: np.ndarray, out=None):
         """HFextractor::operator().  Returns (n, kps, desc, global, n_per_level).

@@ -20,7 +20,7 @@ int* Options::find(const char* name) {
     const struct { const char* n; int* p; } tab[] = {{"fuse_blocks", &fuse_blocks}, {"fuse_max_layer", &fuse_max_layer}, {"fused_variant", &fused_variant},
                                                        {"fuse_stem", &fuse_stem}, {"dense_desc", &dense_desc}, {"two_streams", &two_streams},
                                                        {"graph", &graph}, {"pinned_frames", &pinned_frames}, {"db_gemm_min_queries", &db_gemm_min_queries},
-                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}};
+                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}, {"interleave", &interleave}, {"host_global", &host_global}};
     for (const auto& t : tab) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -126,7 +126,7 @@ int Net::build(Engine* eng, const NetConfig& c) {
     e = eng;
     cfg = c;
     // A/B and diagnostics switches of the engine (hfnet_engine_set_option), fixed for the lifetime of this network
-    fuse_blocks = e->opt.fuse_blocks; fuse_max_layer = e->opt.fuse_max_layer; fused_variant = e->opt.fused_variant; fuse_min_wgs = e->opt.fuse_min_wgs; tail_fuse = e->opt.tail_fuse; dedupe_taps = e->opt.dedupe_taps;
+    fuse_blocks = e->opt.fuse_blocks; fuse_max_layer = e->opt.fuse_max_layer; fused_variant = e->opt.fused_variant; fuse_min_wgs = e->opt.fuse_min_wgs; tail_fuse = e->opt.tail_fuse; dedupe_taps = e->opt.dedupe_taps; interleave = e->opt.interleave;
     force_dense = e->opt.dense_desc; fuse_stem = e->opt.fuse_stem; conv_wlds = e->opt.conv_wlds;
     const DeviceWeights& w = e->w;
     if (c.n_levels < 1 || c.n_levels > HFNET_MAX_LEVELS || c.batch < 1) { set_error("net: bad level / batch count"); return HFNET_ERR_INVALID_ARG; }
@@ -329,12 +329,27 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
     // (The fork point is recorded here, but the branch itself is enqueued AFTER the local heads: a captured graph hands its
     //  nodes to the queues in creation order at ~6 us per node, and with the ~35 launches of the global branch first the
     //  local heads of a single frame started 200 us after layer 7 had finished -- both branches ended together at 620 us.)
-    if (fork_early) HF_HIP(hipEventRecord(ev_fork, stream));
+    // Few frames per call: the global branch is the critical path, and a captured graph hands its nodes to the queues in
+    // creation order at ~6 us per node -- whichever branch is captured second starts that much later per node of the first
+    // (global first: the local heads of a single frame started 200 us after layer 7; local first: the global branch started
+    // 85 us after it).  So the steps of the global branch are enqueued BETWEEN the launches of the local heads.
+    int g_next = 0, g_total = 1;
+    auto pump_global = [&](int n) -> int {
+        if (!fork_early || !interleave || g_next >= g_total) return HFNET_OK;
+        HF_TRY(forward_global(stream_global, g_next, n, &g_total));
+        g_next += n;
+        return HFNET_OK;
+    };
+    if (fork_early) {
+        HF_HIP(hipEventRecord(ev_fork, stream));
+        HF_HIP(hipStreamWaitEvent(stream_global, ev_fork, 0));
+    }
     if (cfg.local) {
         const long long pc = pix_cell[HFNET_MAX_LEVELS];
         Geom gh = geom(7, 7, 0, NL);
         for (int l = 0; l < NL; ++l) { gh.lv[l].pt = gh.lv[l].pl = 1; gh.lv[l].out_off = pix_cell[l]; }
         HF_LAUNCH(e, stream, "conv3x3_det", launch_conv3x3(act[7], w.det1, det_hidden, 1, gh, conv_wlds, stream));
+        HF_TRY(pump_global(interleave));
         if (fork && !fork_early) {
             // the global branch starts after the (chip-filling, MFMA-bound) detector conv: it overlaps the long tail of
             // small kernels (softmax, NMS, top-K, sparse descriptor head) instead of time-sharing with that conv
@@ -344,14 +359,18 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
             HF_HIP(hipEventRecord(ev_join, stream_global));
         }
         HF_LAUNCH(e, stream, "pointwise_det", launch_pointwise(det_hidden, w.det2, nullptr, logits, pc, 0, stream));
+        HF_TRY(pump_global(1));
         Geom gd = geom(7, 7, 0, NL);
         for (int l = 0; l < NL; ++l) { gd.lv[l].Ho = lp[l].Hc; gd.lv[l].Wo = lp[l].Wc; gd.lv[l].in_off = pix_cell[l]; gd.lv[l].out_off = pix_img[l]; }
         HF_LAUNCH(e, stream, "softmax_d2s", launch_softmax_d2s(logits, 65, dense, gd, stream));
+        HF_TRY(pump_global(1));
         Geom gn = gd;
         for (int l = 0; l < NL; ++l) { gn.lv[l].H = lp[l].Hc; gn.lv[l].W = lp[l].Wc; gn.lv[l].in_off = pix_img[l]; }
         HF_HIP(hipMemsetAsync(counters, 0, sizeof(unsigned int) * (size_t)NL * cfg.batch * HFNET_COUNTER_STRIDE, stream));
         HF_LAUNCH(e, stream, "nms", launch_nms(dense, nullptr, nms_mask, nms_flags, cand, counters, cand_stride, threshold, gn, stream));
+        HF_TRY(pump_global(2));
         HF_LAUNCH(e, stream, "topk", launch_topk(cand, counters, cand_stride, budget, kps_level, cfg.max_keypoints, n_level, gn, stream));
+        HF_TRY(pump_global(1));
         // Descriptor head.  Only the 4 bilinear taps of every selected keypoint are ever read
         // (HFNetTFModelV2.cc:153-167), so unless the budget covers most of the cell grid the head is
         // evaluated at those taps only (same arithmetic per cell -> bit-identical descriptors).
@@ -370,7 +389,9 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
             if (last_dedupe) {
                 // taps shared by neighbouring keypoints are evaluated once: the rows of an image are its DISTINCT tap cells
                 HF_LAUNCH(e, stream, "tap_cells", launch_tap_cells(kps_level, n_level, cfg.max_keypoints, tap_flags, tap_cell_row, tap_cells, tap_nrows, cell_stride, gt, stream));
+                HF_TRY(pump_global(1));
                 HF_LAUNCH(e, stream, "conv3x3_desc_taps", launch_conv3x3_taps(act[7], w.desc1, rows_hidden, 1, kps_level, n_level, cfg.max_keypoints, budget.k, gt, conv_wlds, stream, tap_cells, tap_nrows));
+                HF_TRY(pump_global(2));
                 HF_LAUNCH(e, stream, "pointwise_desc_taps", launch_pointwise(rows_hidden, w.desc2, nullptr, rows_raw, rows, 0, stream, tap_nrows, 4 * cfg.max_keypoints, 1));
             } else {
                 HF_LAUNCH(e, stream, "conv3x3_desc_taps", launch_conv3x3_taps(act[7], w.desc1, rows_hidden, 1, kps_level, n_level, cfg.max_keypoints, budget.k, gt, conv_wlds, stream));
@@ -381,8 +402,7 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         }
     }
     if (fork_early) {
-        HF_HIP(hipStreamWaitEvent(stream_global, ev_fork, 0));
-        HF_TRY(forward_global(stream_global));
+        HF_TRY(forward_global(stream_global, g_next, 1 << 20, nullptr));   // whatever is left of the branch
         HF_HIP(hipEventRecord(ev_join, stream_global));
     }
     if (cfg.global && fork_early && caller_joins) join_pending = true;
@@ -406,31 +426,42 @@ bool Net::tail_chain() const {
     return true;
 }
 
-int Net::forward_global(hipStream_t st) {
+int Net::forward_global(hipStream_t st, int first, int count, int* total) {
     const DeviceWeights& w = e->w;
     const int P = lp[0].h[18] * lp[0].w[18];
+    // a "step" is one launch group; [first, first + count) are enqueued by this call (forward() interleaves the steps of
+    // this branch with the launches of the local heads when both go into one captured graph, see there)
+    int step = 0;
+    const long long last = (long long)first + count;
+#define HF_GSTEP(...)                                          \
+    do {                                                       \
+        if (step >= first && step < last) { __VA_ARGS__; }     \
+        ++step;                                                \
+    } while (0)
     bool tail = false;
     if (tail_chain()) {
         // expanded tensors ping-pong between exp_buf and dw_buf (the depthwise tensor itself never exists on this path)
         float* ebuf[2] = {exp_buf, dw_buf};
-        HF_LAUNCH(e, st, "expand_L08", launch_pointwise(act[7], w.blocks[6].ex, nullptr, ebuf[0], pix[7][1], 1, st));
+        HF_GSTEP(HF_LAUNCH(e, st, "expand_L08", launch_pointwise(act[7], w.blocks[6].ex, nullptr, ebuf[0], pix[7][1], 1, st)));
         for (int L = 8; L <= 18; ++L) {
             const BlockPack& b = w.blocks[L - 2];
             const ConvPack16* next = L < 18 ? &w.blocks[L - 1].ex16 : &w.memb16;
             const float* next_bias = L < 18 ? w.blocks[L - 1].ex.bias : w.memb.bias;
             char fn[32];
             snprintf(fn, sizeof fn, "tail_block_L%02d", L);
-            HF_LAUNCH(e, st, fn, launch_dwproject(ebuf[L & 1], b, b.residual ? act[L - 1] : nullptr, act[L], next, next_bias,
-                                                  L < 18 ? ebuf[(L + 1) & 1] : memb, L < 18 ? 1 : 0, L < 18 ? 0 : 1, geom(L - 1, L, 0, 1), st));
+            HF_GSTEP(HF_LAUNCH(e, st, fn, launch_dwproject(ebuf[L & 1], b, b.residual ? act[L - 1] : nullptr, act[L], next, next_bias,
+                                                           L < 18 ? ebuf[(L + 1) & 1] : memb, L < 18 ? 1 : 0, L < 18 ? 0 : 1, geom(L - 1, L, 0, 1), st)));
         }
         tail = true;                                             // (layer 18's launch leaves the SOFTMAXED memberships)
     } else {
-        for (int L = 8; L <= 18; ++L) HF_TRY(run_block(*this, L, 1, st));
-        HF_LAUNCH(e, st, "pointwise_memberships", launch_pointwise(act[18], w.memb, nullptr, memb, (long long)cfg.batch * P, 0, st));
+        for (int L = 8; L <= 18; ++L) HF_GSTEP(HF_TRY(run_block(*this, L, 1, st)));
+        HF_GSTEP(HF_LAUNCH(e, st, "pointwise_memberships", launch_pointwise(act[18], w.memb, nullptr, memb, (long long)cfg.batch * P, 0, st)));
     }
-    if (!tail) HF_LAUNCH(e, st, "softmax_memberships", launch_softmax_rows(memb, (long long)cfg.batch * P, w.n_clusters, w.n_clusters, st));
-    HF_LAUNCH(e, st, "vlad", launch_vlad(act[18], memb, w.clusters, vlad_tap, vlad_out, vlad_raw, cfg.batch, P, w.c_global, w.n_clusters, st));
-    HF_LAUNCH(e, st, "fc_l2", launch_fc_l2(vlad_out, w.fc, fc_part, fc_raw, global_dst ? global_dst : global_out, cfg.batch, st));
+    if (!tail) HF_GSTEP(HF_LAUNCH(e, st, "softmax_memberships", launch_softmax_rows(memb, (long long)cfg.batch * P, w.n_clusters, w.n_clusters, st)));
+    HF_GSTEP(HF_LAUNCH(e, st, "vlad", launch_vlad(act[18], memb, w.clusters, vlad_tap, vlad_out, vlad_raw, cfg.batch, P, w.c_global, w.n_clusters, st)));
+    HF_GSTEP(HF_LAUNCH(e, st, "fc_l2", launch_fc_l2(vlad_out, w.fc, fc_part, fc_raw, global_dst ? global_dst : global_out, cfg.batch, st, global_host)));
+#undef HF_GSTEP
+    if (total) *total = step;
     return HFNET_OK;
 }
 
@@ -797,6 +828,7 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
     NetConfig c;
     c.n_levels = n_levels; c.batch = max_batch; c.local = true; c.global = true; c.from_intermediate = false;
     x->use_graph = e->impl.opt.graph;
+    x->host_global = e->impl.opt.host_global;
     c.max_keypoints = 1;
     for (int l = 0; l < n_levels; ++l) { c.width[l] = x->level_w[l]; c.height[l] = x->level_h[l]; c.max_keypoints = std::max(c.max_keypoints, x->features_per_level[l]); }
     HF_TRY(x->net.build(&e->impl, c));
@@ -831,10 +863,10 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
             x->pin_flag = off;
             off += 256;
             HF_TRY(dalloc(x->allocs, &x->d_blk, res_bytes));
-            HF_TRY(dalloc(x->allocs, &x->d_seq, 1));
-            HF_HIP(hipMemset(x->d_seq, 0, sizeof(int)));
+            HF_TRY(dalloc(x->allocs, &x->d_seq, 3));
+            HF_HIP(hipMemset(x->d_seq, 0, 3 * sizeof(int)));
             void* hp = nullptr;
-            if (hipHostMalloc(&hp, off, hipHostMallocDefault) == hipSuccess) { x->h_pin = (unsigned char*)hp; x->pinned_frames = pf; *(volatile int*)(x->h_pin + x->pin_flag) = 0; }
+            if (hipHostMalloc(&hp, off, hipHostMallocDefault) == hipSuccess) { x->h_pin = (unsigned char*)hp; x->pinned_frames = pf; *(volatile int*)(x->h_pin + x->pin_flag) = 0; *(volatile int*)(x->h_pin + x->pin_flag + 128) = 0; }
             else (void)hipGetLastError();
         }
     }
@@ -845,6 +877,9 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
 void hfnet_extractor_destroy(hfnet_extractor* x) {
     if (!x) return;
     (void)hipSetDevice(x->eng->impl.device);
+    // (a single-frame call returns when its results are in the caller's buffers, which is before its graph has retired)
+    if (x->net.stream) (void)hipStreamSynchronize(x->net.stream);
+    if (x->net.stream_global) (void)hipStreamSynchronize(x->net.stream_global);
     for (auto& kv : x->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : x->allocs) (void)hipFree(p);
     if (x->h_pin) (void)hipHostFree(x->h_pin);
@@ -937,9 +972,12 @@ static int extract_chunk_graphed(hfnet_extractor* x, int nb) {
         // results of the whole chunk at full capacity (sizes are static) into ONE device block laid out like the pinned one
         const hfnet_extractor::ResOff o = x->result_offsets(nb, G);
         net.global_dst = net.cfg.global ? (float*)(x->d_blk + o.g) : nullptr;
+        const bool host_global = x->global_to_host(nb);
+        if (host_global) net.global_host = FcHostOut{(float*)(x->h_pin + x->pin_res + o.g), (int*)(x->h_pin + x->pin_flag + 128), x->d_seq + 1};
         const int rc = extract_chunk(x, nb, x->d_pyr[0], x->width, (long long)img_bytes, (hfnet_keypoint*)(x->d_blk + o.k), (float*)(x->d_blk + o.d), nullptr,
                                      (int*)(x->d_blk + o.n), (int*)(x->d_blk + o.nl), /*caller_joins=*/true);
         net.global_dst = nullptr;
+        net.global_host = FcHostOut();
         HF_TRY(rc);
         // the local results come down as soon as the sampler is done, followed by the "they are down" counter; the global
         // descriptors follow when the global branch -- the longer one for a single frame -- has joined
@@ -947,7 +985,7 @@ static int extract_chunk_graphed(hfnet_extractor* x, int nb) {
         HF_LAUNCH(&eng, st, "bump_seq", launch_bump_seq(x->d_seq, st));
         HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_flag, x->d_seq, sizeof(int), hipMemcpyDeviceToHost, st));
         if (net.join_pending) { HF_HIP(hipStreamWaitEvent(st, net.ev_join, 0)); net.join_pending = false; }
-        if (net.cfg.global) HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_res + o.g, x->d_blk + o.g, o.total - o.g, hipMemcpyDeviceToHost, st));
+        if (net.cfg.global && !host_global) HF_HIP(hipMemcpyAsync(x->h_pin + x->pin_res + o.g, x->d_blk + o.g, o.total - o.g, hipMemcpyDeviceToHost, st));
         return HFNET_OK;
     };
     if (!x->use_graph || eng.prof.enabled) return direct();
@@ -1138,6 +1176,8 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
         } else if (nb <= x->pinned_frames && x->h_pin) {
             // latency path: image -> pinned block (CPU), one graph (upload, ~75 kernels on two streams, downloads), one sync,
             // pinned block -> caller's buffers (CPU, only the rows that exist)
+            const auto t_enter = std::chrono::steady_clock::now();
+            auto stamp = [&](int i) { x->t_last[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count(); };
             const size_t img_bytes = (size_t)x->width * x->height;
             for (int f = 0; f < nb; ++f) {
                 const uint8_t* src = images + (size_t)(f0 + f) * frame_stride;
@@ -1145,12 +1185,14 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
                 if (row_stride == x->width) std::memcpy(dst, src, img_bytes);
                 else for (int y = 0; y < x->height; ++y) std::memcpy(dst + (size_t)y * x->width, src + (size_t)y * row_stride, (size_t)x->width);
             }
+            stamp(0);
             const int expected = ++x->seq_host;
             HF_TRY(extract_chunk_graphed(x, nb));
             const hfnet_extractor::ResOff o = x->result_offsets(nb, G);
             const float* blk_desc = (const float*)(x->d_blk + o.d);
             const int* blk_n = (const int*)(x->d_blk + o.n);
             HF_TRY(copy_chunk_to_store(x, f0, nb, blk_desc, blk_n, st));
+            stamp(1);
             // the keypoints and descriptors (1 MB per frame) are unpacked while the GPU is still busy with the global branch:
             // spin until the counter that follows them into the pinned block shows this call's number (bounded; a call that
             // never sees it simply waits for the stream)
@@ -1164,6 +1206,7 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
                 if (*flag != expected) HF_HIP(hipStreamSynchronize(st));
                 std::atomic_thread_fence(std::memory_order_acquire);
             }
+            stamp(2);
             x->last_desc = blk_desc; x->last_cnt = blk_n;
             const unsigned char* res = x->h_pin + x->pin_res;
             x->pin_nl_last = x->pin_res + o.nl;
@@ -1178,10 +1221,28 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
                 std::memcpy(local_desc + (size_t)(f0 + f) * x->n_features * HFNET_DESC_DIM,
                             res + o.d + sizeof(float) * HFNET_DESC_DIM * (size_t)f * x->n_features, sizeof(float) * HFNET_DESC_DIM * n);
             }
-            HF_HIP(hipStreamSynchronize(st));
+            stamp(3);
+            if (x->global_to_host(nb)) {
+                // the global descriptors arrive the same way: written into the pinned block by the last kernel of the branch,
+                // followed by the call's number (no copy after the join, no stream synchronisation on the way out)
+                volatile int* gflag = (volatile int*)(x->h_pin + x->pin_flag + 128);
+                const int gexpected = ++x->gseq_host;
+                const auto t_spin = std::chrono::steady_clock::now();
+                for (unsigned it = 0; *gflag != gexpected; ++it) {
+                    __builtin_ia32_pause();
+                    if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(20)) break;
+                }
+                if (*gflag != gexpected) HF_HIP(hipStreamSynchronize(st));   // (the graph / the join event bring the branch's stream in)
+                std::atomic_thread_fence(std::memory_order_acquire);
+                x->gseq_host = *gflag;
+            } else {
+                HF_HIP(hipStreamSynchronize(st));
+            }
+            stamp(4);
             x->seq_host = *flag;                                  // (re-synchronise the numbering, whatever happened)
             if (global_desc)
                 for (int f = 0; f < nb; ++f) std::memcpy(global_desc + (size_t)(f0 + f) * G, res + o.g + sizeof(float) * (size_t)f * G, sizeof(float) * G);
+            stamp(5);
         } else {
             // everything that is left, as a double-buffered pipeline over its chunks
             HF_TRY(extract_host_pipelined(x, f0, n_frames, images, row_stride, frame_stride, kps, local_desc, global_desc, n_out));
@@ -1189,6 +1250,14 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
         }
     }
     if (on_device) HF_HIP(eng.note_extract(st));
+    return HFNET_OK;
+}
+
+int hfnet_extractor_last_timing(hfnet_extractor* x, double* us, int n) {
+    API_GUARD(x, "extractor"); API_GUARD(us, "us");
+    std::lock_guard<std::mutex> lk(x->mu);
+    if (x->t_last[5] < 0) { set_error("no latency-path call yet"); return HFNET_ERR_INVALID_ARG; }
+    for (int i = 0; i < n && i < 6; ++i) us[i] = x->t_last[i];
     return HFNET_OK;
 }
 

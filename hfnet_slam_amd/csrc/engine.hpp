@@ -98,6 +98,9 @@ struct Options {
     int conv_wlds = 1;        // 3x3 heads: weights staged through LDS once per workgroup (0: every wave reads them from L1 / L2)
     int db_gemm_min_queries = 8;   // hfnet_db_query_batch: from this many queries on, the scores come from the MFMA GEMM form
     int pyramid_fuse = 1;     // calls of up to four frames: the pyramid chain as one launch
+    int host_global = 1;      // host-pointer calls of up to four frames: the global descriptors are written into the pinned block by the branch's last kernel
+    int interleave = 3;       // calls of up to four frames: launch groups of the global branch enqueued between the local heads' launches,
+                              // this many right after the detector conv (0: the whole branch after the local heads)
     int dedupe_taps = 1;      // sparse descriptor head: taps shared by neighbouring keypoints are evaluated once
     int tail_fuse = 4;        // calls of up to this many frames run layers 8-18 with the single-frame kernels (0: never)
     int copy_threads = 64;    // helper threads of the host-pointer batch pipeline's staging copies (>= 64: chosen from the core count)
@@ -179,6 +182,7 @@ struct Net {
     int fused_variant = 4;
     int fuse_min_wgs = 256;
     int tail_fuse = 4;
+    int interleave = 3;
     int fuse_stem = 1;             // stem + layer_2 in one launch: the stem tensor is not materialised (its tap recomputes it on demand)
     int conv_wlds = 1;             // 3x3 heads with LDS-staged weights
     ImageSet last_imgs;            // input of the last forward (for that tap)
@@ -186,6 +190,7 @@ struct Net {
     size_t stem_elems_max = 0;     // size of the stem tensor at the configured (largest) batch
     float *dense = nullptr, *nms = nullptr;
     float* global_dst = nullptr;   // when set: forward_global() writes the global descriptors here instead of global_out
+    FcHostOut global_host;         // when set: ... and into the caller's pinned block, followed by the call's number
     unsigned *nms_mask = nullptr, *nms_flags = nullptr;   // bit-column masks of the NMS passes (max_mask, supp)
     unsigned long long* cand = nullptr;
     unsigned int* counters = nullptr;
@@ -206,7 +211,7 @@ struct Net {
     bool join_pending = false;
     int tap(int id, std::vector<float>& out);
     int run_dense_desc();
-    int forward_global(hipStream_t st);
+    int forward_global(hipStream_t st, int first = 0, int count = 1 << 20, int* total = nullptr);   // launch groups [first, first + count)
     bool tail_chain() const;       // layers 8-18 run as one launch per block (single-frame kernels)
     const float* sample_source() const { return last_sparse ? rows_raw : desc_norm; }   // sparse rows are normalised by k_sample
     ~Net() { release(); }
@@ -260,10 +265,14 @@ struct hfnet_extractor {
     // Result sections [n | n_level | keypoints | descriptors | global] packed for the frames of the call (offsets from pin_res;
     // result_offsets()); the device side keeps the SAME layout in one block (d_blk), so a call's results come down with ONE copy
     size_t pin_res = 0, pin_nl_last = 0, pin_flag = 0;
+    // single-frame calls: the last kernel of the global branch writes the descriptors into the pinned block itself
+    bool global_to_host(int nb) const { return net.cfg.global && h_pin && host_global && hfnet::fc_host_out_supported(nb); }
+    int host_global = 1;           // (engine option of the same name, read at creation)
+    double t_last[6] = {-1, -1, -1, -1, -1, -1};   // hfnet_extractor_last_timing
     // "the local results are down": a device counter the graph bumps and copies into the pinned block right after them; the
     // host spins on it, unpacks keypoints and descriptors while the global branch is still running, then waits for the rest
-    int* d_seq = nullptr;
-    int seq_host = 0;
+    int* d_seq = nullptr;          // [0] calls whose local results are down, [1..2] the same for the global descriptors (FcHostOut::seq)
+    int seq_host = 0, gseq_host = 0;
     unsigned char* d_blk = nullptr;
     struct ResOff { size_t n, nl, g, k, d, total; };
     ResOff result_offsets(int nb, int global_dim) const {

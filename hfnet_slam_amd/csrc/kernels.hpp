@@ -122,7 +122,11 @@ hipError_t launch_vlad(const float* feat /*phys layout [frames x P x D]*/, const
 // cross HBM once, 4096 workgroups stream them) + L2 normalise (layers.py:98-108).  x: [frames][n_in] in the FC slot order
 // (fc_slot_of_logical), pack: FcPack of weights.cpp; partial: fc_scratch_floats() floats
 size_t fc_scratch_floats(const FcPack& fc, int frames);
-hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* partial, float* y_raw, float* out, int frames, hipStream_t s);
+// optional second destination of the global descriptors in host-visible (pinned) memory: `out` rows, then the call number
+// (seq[0], kept on the device; seq[1] counts the workgroups that are done) into `flag`; calls of up to four frames only
+struct FcHostOut { float* out = nullptr; int* flag = nullptr; int* seq = nullptr; };
+bool fc_host_out_supported(int frames);
+hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* partial, float* y_raw, float* out, int frames, hipStream_t s, FcHostOut host = FcHostOut());
 
 // ---- kernels_match.hip --------------------------------------------------------------------------
 // BFMatcher(NORM_L2, crossCheck) + distance < th_low (Matcher.cc:229-260), batched over descriptor-set pairs.

@@ -238,7 +238,7 @@ __device__ __forceinline__ float fc_combine_one(const float* __restrict__ partia
 // partial sums [FC_PARTS][frames][n] -> y = tree + bias (kept in y_raw), then the L2 normalisation of layers.py:108.
 // One launch for the single-frame path (a workgroup per frame) ...
 __global__ __launch_bounds__(1024) void k_fc_combine_l2(const float* __restrict__ partial, const float* __restrict__ bias, float* __restrict__ y_raw,
-                                                        float* __restrict__ out, int frames, int n) {
+                                                        float* __restrict__ out, int frames, int n, FcHostOut host) {
     __shared__ float red[256];
     const int f = blockIdx.x;
     float* v = y_raw + (long long)f * n;
@@ -247,6 +247,20 @@ __global__ __launch_bounds__(1024) void k_fc_combine_l2(const float* __restrict_
     const float ss = block_sumsq_tree256(v, n, red);
     const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
     for (int i = threadIdx.x; i < n; i += 1024) out[(long long)f * n + i] = v[i] * inv;
+    if (host.out) {
+        // the caller of a single-frame call waits for exactly these 16 KB: they go straight into its pinned block, followed
+        // by the call's number (written by the workgroup that finishes last), instead of through a copy after the join
+        for (int i = threadIdx.x; i < n; i += 1024) host.out[(long long)f * n + i] = v[i] * inv;
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(host.seq + 1, 1) == frames - 1) {
+            host.seq[1] = 0;
+            const int call = host.seq[0] + 1;
+            host.seq[0] = call;
+            __threadfence_system();
+            __hip_atomic_store(host.flag, call, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 // ... two for many frames (the 17 MB of partial sums of a 64-frame call want more than 64 workgroups)
 __global__ __launch_bounds__(256) void k_fc_combine(const float* __restrict__ partial, const float* __restrict__ bias, float* __restrict__ y_raw, int frames, int n) {
@@ -263,14 +277,17 @@ __global__ __launch_bounds__(256) void k_l2norm_vec(const float* __restrict__ in
 
 size_t fc_scratch_floats(const FcPack& fc, int frames) { return (size_t)FC_PARTS * (size_t)frames * (size_t)fc.n_out; }
 
-hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* partial, float* y_raw, float* out, int frames, hipStream_t s) {
+bool fc_host_out_supported(int frames) { return frames >= 1 && frames <= 4; }
+
+hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* partial, float* y_raw, float* out, int frames, hipStream_t s, FcHostOut host) {
     if (frames <= 0) return hipSuccess;
     if (fc.n_in % 16 || fc.n_out % 16) return hipErrorInvalidValue;
     const int waves = std::min(4, (frames + 15) / 16);
     const int ppw = frames > 16 ? 4 : 1;
     hipLaunchKernelGGL(k_fc_mfma<16>, dim3(fc.n_out / 16, (frames + 63) / 64, FC_PARTS / ppw), dim3(64 * waves), 0, s, x, fc.w, partial, frames, fc.n_in, fc.n_out, ppw);
+    if (host.out && !fc_host_out_supported(frames)) return hipErrorInvalidValue;
     if (frames <= 4) {
-        hipLaunchKernelGGL(k_fc_combine_l2, dim3(frames), dim3(1024), 0, s, partial, fc.bias, y_raw, out, frames, fc.n_out);
+        hipLaunchKernelGGL(k_fc_combine_l2, dim3(frames), dim3(1024), 0, s, partial, fc.bias, y_raw, out, frames, fc.n_out, host);
     } else {
         hipLaunchKernelGGL(k_fc_combine, dim3((fc.n_out + 255) / 256, frames), dim3(256), 0, s, partial, fc.bias, y_raw, frames, fc.n_out);
         hipLaunchKernelGGL(k_l2norm_vec, dim3(frames), dim3(256), 0, s, y_raw, out, fc.n_out);

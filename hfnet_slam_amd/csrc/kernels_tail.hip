@@ -82,7 +82,7 @@ __global__ __launch_bounds__(512) void k_dwproject(DwProjArgs a, Geom g) {
     float* H = lds + TP * DP;                                    // [NPOS][HP]
     float* Wl = H + NPOS * HP;                                   // [10][cexp]: depthwise taps and bias
     float* P = Wl + 10 * a.cexp;                                 // NEXT: [TP][PP] projected tile (+ residual), slot order, zero padded
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: weight addresses stay scalar)
     const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
     const LevelGeom lv = g.lv[level];
     const int tiles_x = (lv.Wo + TW - 1) / TW;
@@ -97,14 +97,18 @@ __global__ __launch_bounds__(512) void k_dwproject(DwProjArgs a, Geom g) {
 
     // projection tiles of this wave: NEXT: every workgroup needs the whole projected tile (wave, wave + 8, ...); otherwise
     // the workgroups of a pixel tile split them.  The first tile's weights and residual values are requested before phase 1.
-    constexpr int PF = 8;
+    // The weights come from HBM (last used a frame ago) at ~2 us per dependent load, the chain of a 720-channel projection is
+    // 2.5 us: the number of weight pieces a wave has in flight is what phase 2 takes.  PF pieces ride in registers: PF0 of them
+    // requested here, the others once phase 1 has released its staging registers; a wave with two tiles (layer 18) walks them
+    // as one stream (positions of a tile padded to a multiple of PF, so that a piece's ring slot is a compile-time index).
+    constexpr int PF = 16, PF0 = 8;
     const int nt_first = NEXT ? wave : split * 8 + wave, nt_step = NEXT ? 8 : (1 << 20);
-    const int KB = a.cexp >> 4;
-    const size_t wstep = (size_t)a.n16 * 64;
-    const f32x4* __restrict__ wp = a.Wpr + ((size_t)min(nt_first, a.n16 - 1) * 64 + lane);
+    const int KB = a.cexp >> 4, KBP = (KB + PF - 1) / PF * PF;
+    const f32x4* __restrict__ wbase = a.Wpr + lane;
+    auto wpiece = [&](int nt, int kb) -> f32x4 { return wbase[((size_t)kb * a.n16 + nt) * 64]; };
     f32x4 bq[PF];
 #pragma unroll
-    for (int u = 0; u < PF; ++u) bq[u] = wp[(size_t)min(u, KB - 1) * wstep];
+    for (int u = 0; u < PF0; ++u) bq[u] = wpiece(min(nt_first, a.n16 - 1), min(u, KB - 1));
     long long orow[4];
     bool ovalid[4];
 #pragma unroll
@@ -192,26 +196,38 @@ __global__ __launch_bounds__(512) void k_dwproject(DwProjArgs a, Geom g) {
     __syncthreads();
 
     // ---- phase 2
+#pragma unroll
+    for (int u = PF0; u < PF; ++u) bq[u] = wpiece(min(nt_first, a.n16 - 1), min(u, KB - 1));
+    // (NEXT: the weights of this wave's SECOND column tile of the next convolution, into the registers phase 1 has released)
+    constexpr bool XV2 = false;
+    f32x4 xv2[XVN];
+    const bool second_xt = XV2 && NEXT && xt_first + 8 < xt_end;
+    if (second_xt) {
+        const f32x4* __restrict__ xp = a.Wnx + ((size_t)(xt_first + 8) * 64 + lane);
+#pragma unroll
+        for (int kb = 0; kb < XVN; ++kb) if (kb < KB2) xv2[kb] = xp[(size_t)kb * xstep];
+    }
     for (int nt = nt_first; nt < a.n16; nt += nt_step) {
-        if (nt != nt_first) {                                    // (a second tile per wave: only layer 18's 240 columns)
-            wp = a.Wpr + ((size_t)nt * 64 + lane);
+        if (nt != nt_first && a.R && nt * 16 + j < a.cout) {      // (a second tile per wave: only layer 18's 240 columns)
 #pragma unroll
-            for (int u = 0; u < PF; ++u) bq[u] = wp[(size_t)min(u, KB - 1) * wstep];
-            if (a.R && nt * 16 + j < a.cout) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) rv[t] = a.R[orow[t] * a.cout + nt * 16 + j];
-            }
+            for (int t = 0; t < 4; ++t) rv[t] = a.R[orow[t] * a.cout + nt * 16 + j];
         }
         const float pb = nt == nt_first ? pb_first : a.pr_bias[nt * 16 + j];
         f32x4 acc = {pb, pb, pb, pb};
         const float* __restrict__ ap = D + j * DP + 4 * gq;       // A: row = pixel j of the tile, lane group gq
-        for (int kb = 0; kb < KB; kb += PF) {
+        const int nt_next = nt + nt_step < a.n16 ? nt + nt_step : -1;
+        for (int kb = 0; kb < KBP; kb += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
+                f32x4 av, bv;
                 if (kb + u < KB) {                               // uniform
-                    const f32x4 av = *(const f32x4*)(ap + (kb + u) * 16);
-                    const f32x4 bv = bq[u];
-                    bq[u] = wp[(size_t)min(kb + u + PF, KB - 1) * wstep];
+                    av = *(const f32x4*)(ap + (kb + u) * 16);
+                    bv = bq[u];
+                }
+                // the slot's next piece: PF positions ahead in this tile, or the start of this wave's next tile
+                if (kb + u + PF < KB) bq[u] = wpiece(nt, kb + u + PF);
+                else if (kb + PF >= KBP && nt_next >= 0 && u < KB) bq[u] = wpiece(nt_next, u);
+                if (kb + u < KB) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[t], acc, 0, 0, 0);
                 }
@@ -237,9 +253,14 @@ __global__ __launch_bounds__(512) void k_dwproject(DwProjArgs a, Geom g) {
     for (int xt = xt_first; xt < xt_end; xt += 8) {
         float xb = xb_first;
         if (xt != xt_first) {
-            const f32x4* __restrict__ xp = a.Wnx + ((size_t)xt * 64 + lane);
+            if (XV2) {
 #pragma unroll
-            for (int kb = 0; kb < XVN; ++kb) if (kb < KB2) xv[kb] = xp[(size_t)kb * xstep];
+                for (int kb = 0; kb < XVN; ++kb) xv[kb] = xv2[kb];
+            } else {
+                const f32x4* __restrict__ xp = a.Wnx + ((size_t)xt * 64 + lane);
+#pragma unroll
+                for (int kb = 0; kb < XVN; ++kb) if (kb < KB2) xv[kb] = xp[(size_t)kb * xstep];
+            }
             xb = a.nx_bias[xt * 16 + j];
         }
         f32x4 acc = {xb, xb, xb, xb};

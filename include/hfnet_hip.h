@@ -88,6 +88,10 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *   "tail_fuse" (4)     calls of up to this many frames run layers 8-18 with the single-frame kernels (depthwise + projection
  *                       in one launch, short-latency MFMA chains); 0: never
  *   "pyramid_fuse" (1)  calls of up to four frames: the pyramid resize chain as one launch
+ *   "interleave" (3)    calls of up to four frames: the launch groups of the global branch are enqueued between the launches
+ *                       of the local heads, this many right after the detector conv (0: the whole branch after the local heads)
+ *   "host_global" (1)   host-pointer calls of up to four frames: the last kernel of the global branch writes the descriptors
+ *                       into the pinned result block itself (no copy after the join, the call returns without draining the stream)
  *   "copy_threads" (64 = by core count): helper threads for the staging copies of host-pointer batch calls (replicas sharing a host)
  * Values are >= 0.
  * Every setting of the extractor switches produces the same bits (tests/test_gpu_parity.py). */
@@ -141,6 +145,11 @@ int hfnet_extractor_tables(const hfnet_extractor* x, float* scale_factors, int* 
 int hfnet_extractor_extract(hfnet_extractor* x, const uint8_t* image, int row_stride,
                             hfnet_keypoint* kps, float* local_desc, float* global_desc,
                             int* n_out, int* n_per_level /* n_levels or NULL */);
+/* Host-side time stamps of the last host-pointer call that went through the latency path (chunks of up to "pinned_frames"
+ * frames), in microseconds since the call was entered: [0] image in the pinned block, [1] everything enqueued, [2] local
+ * results seen on the host, [3] local results unpacked, [4] stream drained (global descriptor down), [5] return.
+ * Writes min(n, 6) values; returns HFNET_ERR_INVALID_ARG before the first such call. */
+int hfnet_extractor_last_timing(hfnet_extractor* x, double* us, int n);
 /* Batched form (independent frames, BASELINE config 4): images are n_frames buffers of
  * height x row_stride bytes, `frame_stride` bytes apart; outputs are n_frames slots of n_features
  * rows each.  `on_device` != 0: every pointer is a device pointer on the engine's GPU and the call

@@ -162,7 +162,8 @@ def test_response_ties(weights_ties_path):
 # the single-frame path's own pieces on and off: pyramid chain in one launch, distinct tap cells, one launch per block for layers
 # 8-18, and the caller-owned result buffers of the wrapper
 EXTRACTOR_VARIANTS = {"default": {}, "unfused_stem": {"fuse_stem": 0}, "separate_launches": {"pyramid_fuse": 0, "dedupe_taps": 0, "tail_fuse": 0},
-                      "no_graph": {"graph": 0, "pinned_frames": 0}}
+                      "no_graph": {"graph": 0, "pinned_frames": 0}, "plain_launches": {"graph": 0},
+                      "branch_after_heads": {"interleave": 0, "host_global": 0}}
 
 
 @pytest.mark.parametrize("variant", list(EXTRACTOR_VARIANTS))
@@ -186,6 +187,9 @@ def test_extractor_matches_oracle(engine, oracle_model, cfg, variant, engine_opt
     for img in (imgs[1], imgs[0]):
         n2, k2, d2, g2, npl2 = x.extract(img, bufs)
     assert n2 == rn and d2.base is bufs[1]
+    if EXTRACTOR_VARIANTS[variant].get("pinned_frames", 1):
+        t = x.last_timing()                       # host stamps of the latency path: monotone, all set
+        assert (t >= 0).all() and (np.diff(t) >= 0).all(), t
     _eq("n per level (own buffers)", npl2, rnpl); _eq("kps (own buffers)", k2, rk); _eq("desc (own buffers)", d2, rd); _eq("global (own buffers)", g2, rg)
     # batched (3 frames through a max_batch=2 extractor -> two chunks)
     nb, kb, db, gb = x.extract_batch(imgs)

@@ -17,7 +17,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 bufs = ext.output_buffers()
 for i in range(10):
     ext.extract(imgs[i % 4], bufs)
-ts = []
+ts, st = [], []
 for i in range(n):
     t0 = time.perf_counter(); ext.extract(imgs[i % 4], bufs); ts.append(time.perf_counter() - t0)
+    st.append(ext.last_timing())
+print("host stamps (us, median): staged %.1f  enqueued %.1f  local seen %.1f  unpacked %.1f  drained %.1f  return %.1f" % tuple(np.median(np.array(st), axis=0)))
 print("ms per frame: median %.4f  mean %.4f" % (float(np.median(ts)) * 1e3, float(np.mean(ts)) * 1e3), sys.argv[2:])
