@@ -20,7 +20,7 @@ int* Options::find(const char* name) {
     const struct { const char* n; int* p; } tab[] = {{"fuse_blocks", &fuse_blocks}, {"fuse_max_layer", &fuse_max_layer}, {"fused_variant", &fused_variant},
                                                        {"fuse_stem", &fuse_stem}, {"dense_desc", &dense_desc}, {"two_streams", &two_streams},
                                                        {"graph", &graph}, {"pinned_frames", &pinned_frames}, {"db_gemm_min_queries", &db_gemm_min_queries},
-                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}, {"interleave", &interleave}, {"host_global", &host_global}};
+                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}, {"interleave", &interleave}, {"host_global", &host_global}, {"det_fuse", &det_fuse}};
     for (const auto& t : tab) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -126,7 +126,7 @@ int Net::build(Engine* eng, const NetConfig& c) {
     e = eng;
     cfg = c;
     // A/B and diagnostics switches of the engine (hfnet_engine_set_option), fixed for the lifetime of this network
-    fuse_blocks = e->opt.fuse_blocks; fuse_max_layer = e->opt.fuse_max_layer; fused_variant = e->opt.fused_variant; fuse_min_wgs = e->opt.fuse_min_wgs; tail_fuse = e->opt.tail_fuse; dedupe_taps = e->opt.dedupe_taps; interleave = e->opt.interleave;
+    fuse_blocks = e->opt.fuse_blocks; fuse_max_layer = e->opt.fuse_max_layer; fused_variant = e->opt.fused_variant; fuse_min_wgs = e->opt.fuse_min_wgs; tail_fuse = e->opt.tail_fuse; dedupe_taps = e->opt.dedupe_taps; interleave = e->opt.interleave; det_fuse = e->opt.det_fuse;
     force_dense = e->opt.dense_desc; fuse_stem = e->opt.fuse_stem; conv_wlds = e->opt.conv_wlds;
     const DeviceWeights& w = e->w;
     if (c.n_levels < 1 || c.n_levels > HFNET_MAX_LEVELS || c.batch < 1) { set_error("net: bad level / batch count"); return HFNET_ERR_INVALID_ARG; }
@@ -358,12 +358,19 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
             HF_TRY(forward_global(stream_global));
             HF_HIP(hipEventRecord(ev_join, stream_global));
         }
-        HF_LAUNCH(e, stream, "pointwise_det", launch_pointwise(det_hidden, w.det2, nullptr, logits, pc, 0, stream));
-        HF_TRY(pump_global(1));
         Geom gd = geom(7, 7, 0, NL);
         for (int l = 0; l < NL; ++l) { gd.lv[l].Ho = lp[l].Hc; gd.lv[l].Wo = lp[l].Wc; gd.lv[l].in_off = pix_cell[l]; gd.lv[l].out_off = pix_img[l]; }
-        HF_LAUNCH(e, stream, "softmax_d2s", launch_softmax_d2s(logits, 65, dense, gd, stream));
-        HF_TRY(pump_global(1));
+        logits_valid = !(det_fuse && det_tail_supported(w.det2));
+        if (!logits_valid) {
+            // 1x1 conv + softmax + depth_to_space in one launch: the logits never reach HBM (their tap recomputes them on demand)
+            HF_LAUNCH(e, stream, "det_tail", launch_det_tail(det_hidden, w.det2, dense, gd, stream));
+            HF_TRY(pump_global(2));
+        } else {
+            HF_LAUNCH(e, stream, "pointwise_det", launch_pointwise(det_hidden, w.det2, nullptr, logits, pc, 0, stream));
+            HF_TRY(pump_global(1));
+            HF_LAUNCH(e, stream, "softmax_d2s", launch_softmax_d2s(logits, 65, dense, gd, stream));
+            HF_TRY(pump_global(1));
+        }
         Geom gn = gd;
         for (int l = 0; l < NL; ++l) { gn.lv[l].H = lp[l].Hc; gn.lv[l].W = lp[l].Wc; gn.lv[l].in_off = pix_img[l]; }
         HF_HIP(hipMemsetAsync(counters, 0, sizeof(unsigned int) * (size_t)NL * cfg.batch * HFNET_COUNTER_STRIDE, stream));
@@ -488,6 +495,10 @@ int Net::tap(int id, std::vector<float>& out) {
         nms_valid = true;
     }
     const DeviceWeights& w = e->w;
+    if (id == 21 && cfg.local && !logits_valid) {
+        HF_LAUNCH(e, stream, "pointwise_det_tap", launch_pointwise(det_hidden, w.det2, nullptr, logits, pix_cell[HFNET_MAX_LEVELS], 0, stream));
+        logits_valid = true;
+    }
     if (id == 0 && !cfg.from_intermediate && !stem_valid) {
         // the fused stem + layer_2 kernel never writes the stem tensor: produce it for the tap from the last input
         if (!act[1]) HF_TRY(dalloc(allocs, &act[1], stem_elems_max));

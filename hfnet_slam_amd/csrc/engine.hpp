@@ -98,6 +98,7 @@ struct Options {
     int conv_wlds = 1;        // 3x3 heads: weights staged through LDS once per workgroup (0: every wave reads them from L1 / L2)
     int db_gemm_min_queries = 8;   // hfnet_db_query_batch: from this many queries on, the scores come from the MFMA GEMM form
     int pyramid_fuse = 1;     // calls of up to four frames: the pyramid chain as one launch
+    int det_fuse = 1;         // detector tail (1x1 conv, softmax, depth_to_space) as one launch
     int host_global = 1;      // host-pointer calls of up to four frames: the global descriptors are written into the pinned block by the branch's last kernel
     int interleave = 3;       // calls of up to four frames: launch groups of the global branch enqueued between the local heads' launches,
                               // this many right after the detector conv (0: the whole branch after the local heads)
@@ -183,6 +184,8 @@ struct Net {
     int fuse_min_wgs = 256;
     int tail_fuse = 4;
     int interleave = 3;
+    int det_fuse = 1;
+    bool logits_valid = false;     // the logits tensor holds the last forward's values (the fused detector tail does not write it)
     int fuse_stem = 1;             // stem + layer_2 in one launch: the stem tensor is not materialised (its tap recomputes it on demand)
     int conv_wlds = 1;             // 3x3 heads with LDS-staged weights
     ImageSet last_imgs;            // input of the last forward (for that tap)

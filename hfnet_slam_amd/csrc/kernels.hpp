@@ -64,6 +64,9 @@ hipError_t launch_dwproject(const float* expanded, const BlockPack& b, const flo
 // ---- kernels_detect.hip -------------------------------------------------------------------------
 // softmax(65) -> drop dustbin -> depth_to_space(8) (hf_net.py:88-93); logits row stride ld
 hipError_t launch_softmax_d2s(const float* logits, int ld, float* dense, const Geom& g, hipStream_t s);
+// detector tail in one launch: 1x1 conv (65 outputs) + softmax + depth_to_space; same bits as launch_pointwise + launch_softmax_d2s
+bool det_tail_supported(const ConvPack& cp);
+hipError_t launch_det_tail(const float* hidden, const ConvPack& cp, float* dense, const Geom& g, hipStream_t s);
 // simple_nms(radius 4, 2 iterations) (layers.py:10-32) + candidate emission (score >= threshold,
 // HFNetTFModelV2.cc:127-140).  counters: one uint per image, zeroed by the caller.
 // counters: one uint per image, HFNET_COUNTER_STRIDE words apart (a cache line each: atomics on neighbouring words

@@ -492,6 +492,149 @@ __global__ __launch_bounds__(256, 2) void k_pointwise_wlds(ConvArgs a) {
     if (active) conv_epilogue<NT>(a, acc, nt0, row0, a.P, half, r);
 }
 
+// ---- detector tail in one launch: 1x1 conv 128 -> 65 (+bias) -> softmax over the 65 logits -> drop the dustbin -> depth_to_space
+// (hf_net.py:84-93).  The GEMM is k_pointwise_wlds<3>'s loop (same chains, same bits); the wave's 32 x 65 logits then go through
+// LDS instead of HBM (234 MB written and read back per 64 frames), two lanes per cell take its softmax -- exponentials of the
+// lower / upper 32 channels, the left-to-right sum handed from the lower lane to the upper one (k_softmax_d2s' expressions and
+// order) -- and store rows 0-3 / 4-7 of the cell's 8 x 8 pixel block.
+__device__ __forceinline__ float hf_expf_c(float x) {         // == oracle hfo_expf (as in kernels_detect.hip)
+    x = fminf(fmaxf(x, -87.0f), 88.0f);
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    const float y = fmaf(p, r2, r) + 1.0f;
+    return ldexpf(y, (int)n);
+}
+
+__global__ __launch_bounds__(256, 2) void k_det_tail(ConvArgs a, float* __restrict__ dense, Geom g) {
+    // 65 columns = two 32-column MFMA tiles + the dustbin.  A third tile would spend 64 MFMAs per 32 cells (a third of the
+    // kernel's matrix-core time) on one useful column: the dustbin's chain -- bias, then fma in ascending channel order,
+    // exactly what the matrix core does for a column -- runs on the vector ALU instead, 8 fma + 4 half-wave swaps per
+    // k-step (a lane's A fragment holds the even channels of its cell, its partner's the odd ones), in both lanes of a pair.
+    constexpr int NT = 2, NTW = 3, KS = 4, LP = 65;
+    __shared__ __attribute__((aligned(16))) f32x4 wl[2][KS][NTW][64];
+    __shared__ float lg[4][32 * LP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
+    const LevelGeom lv = g.lv[level];                           // H, W: cell grid; Ho, Wo: dense map (8H, 8W)
+    const int ncells = lv.H * lv.W;
+    if ((int)blockIdx.x * 128 >= ncells) return;                // workgroup-uniform
+    const int c0 = blockIdx.x * 128 + wave * 32;
+    const bool active = c0 < ncells;                            // (waves without cells still help staging)
+    const long long row_base = lv.in_off + (long long)frame * ncells;
+    const float* ap = a.A + (row_base + min(c0 + r, ncells - 1)) * a.cin + half * 4;
+    const int KQ = a.cin >> 3, n_slabs = (KQ + KS - 1) / KS;
+    const size_t wstep = (size_t)a.nt_total * 64;
+    constexpr int PIECES = NTW * 64, PER_T = (PIECES + 255) / 256;
+    auto fetch = [&](int slab, f32x4 (&st)[KS][PER_T]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kq = min(slab * KS + ks, KQ - 1);
+#pragma unroll
+            for (int j = 0; j < PER_T; ++j) st[ks][j] = a.W[(size_t)kq * wstep + min(tid + j * 256, PIECES - 1)];
+        }
+    };
+    auto stash = [&](int buf, const f32x4 (&st)[KS][PER_T]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < PER_T; ++j)
+                if (tid + j * 256 < PIECES) (&wl[buf][ks][0][0])[tid + j * 256] = st[ks][j];
+    };
+    f32x16 acc[NT];
+    conv_acc_init<NT>(a, acc, 0, r);
+    float dust = a.bias[64];
+    f32x4 st[KS][PER_T];
+    fetch(0, st);
+    stash(0, st);
+    __syncthreads();
+    f32x4 av = *(const f32x4*)(ap);
+    for (int slab = 0; slab < n_slabs; ++slab) {
+        const int buf = slab & 1;
+        if (slab + 1 < n_slabs) fetch(slab + 1, st);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kq = slab * KS + ks;
+            if (kq < KQ) {                                    // uniform
+                const f32x4 an = *(const f32x4*)(ap + min(kq + 1, KQ - 1) * 8);
+                f32x4 bv[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = wl[buf][ks][nt][lane];
+                // column 64's weights: the B fragment of the third tile's lanes 0 (even channels) and 32 (odd channels)
+                const f32x4 w_even = wl[buf][ks][2][0], w_odd = wl[buf][ks][2][32];
+                if (active) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], acc[nt], 0, 0, 0);
+                        const int x = __float_as_int(av[t]);
+                        const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);   // [0]: the lower half's value, [1]: the upper half's, in both
+                        dust = fmaf(__int_as_float(sw[0]), w_even[t], dust);
+                        dust = fmaf(__int_as_float(sw[1]), w_odd[t], dust);
+                    }
+                }
+                av = an;
+            }
+        }
+        if (slab + 1 < n_slabs) stash(buf ^ 1, st);
+        __syncthreads();
+    }
+    if (!active) return;                                        // (no barrier below: the logits of a wave stay in its own slice)
+    // D fragment of the 32x32 tile: column nt * 32 + r, rows (reg & 3) + 8 (reg >> 2) + 4 half
+    float* L = lg[wave];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = nt * 32 + r;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) L[((reg & 3) + 8 * (reg >> 2) + 4 * half) * LP + col] = acc[nt][reg];
+    }
+    if (!half) L[r * LP + 64] = dust;
+    // lane (r, half): cell c0 + r, channels 32 half .. 32 half + 31 (+ the dustbin, channel 64, with the upper half)
+    const float* row = L + r * LP + 32 * half;
+    float e[33];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) e[k] = row[k];
+    e[32] = half ? row[32] : e[31];                             // (lower half: a copy that changes no maximum and is never summed)
+    float mx = e[0];
+#pragma unroll
+    for (int k = 1; k < 33; ++k) mx = fmaxf(mx, e[k]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+    for (int k = 0; k < 33; ++k) e[k] = hf_expf_c(e[k] - mx);
+    // sum = (((0 + e0) + e1) + ... + e64): the lower lane's 32 terms first, then the upper lane continues
+    float sum = 0.0f;
+    if (!half) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) sum = sum + e[k];
+    }
+    sum = __shfl(sum, r, 64);
+    if (half) {
+#pragma unroll
+        for (int k = 0; k < 33; ++k) sum = sum + e[k];
+    }
+    sum = __shfl(sum, r + 32, 64);
+    const int cell = c0 + r;
+    if (cell < ncells) {
+        const int cy = cell / lv.W, cx = cell - cy * lv.W;
+        float* d = dense + lv.out_off + (long long)frame * lv.Ho * lv.Wo + (long long)(cy * 8 + 4 * half) * lv.Wo + cx * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 u, v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { u[j] = e[i * 8 + j] / sum; v[j] = e[i * 8 + 4 + j] / sum; }
+            *(f32x4*)(d + (long long)i * lv.Wo) = u;
+            *(f32x4*)(d + (long long)i * lv.Wo + 4) = v;
+        }
+    }
+}
+
 // Low-latency 1x1 convolution for launches that cannot fill the GPU (single frames: the projections of the 30x47 / 15x24
 // layers of the global branch are a few dozen workgroups with 288-720 input channels).  k_pointwise prefetches one
 // k-step ahead, which is right when other waves fill the gaps; alone on its SIMD a wave then pays one memory latency
@@ -946,6 +1089,19 @@ hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* res
         case 8: launch_pw_nt<8>(a, grid, s); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+bool det_tail_supported(const ConvPack& cp) { return cp.n == 65 && cp.nt_total == 3 && cp.cin % 8 == 0 && cp.cin >= 8; }
+
+// g: H, W = cell grid, Ho, Wo = dense map (8 H, 8 W), in_off = first cell of the level, out_off = first pixel (launch_softmax_d2s' geometry)
+hipError_t launch_det_tail(const float* hidden, const ConvPack& cp, float* dense, const Geom& g, hipStream_t s) {
+    if (!det_tail_supported(cp)) return hipErrorInvalidValue;
+    int maxcells = 0;
+    for (int l = 0; l < g.n_levels; ++l) maxcells = max(maxcells, g.lv[l].H * g.lv[l].W);
+    if (maxcells <= 0) return hipSuccess;
+    ConvArgs a = make_args(hidden, cp, nullptr, nullptr, 0, 0);
+    hipLaunchKernelGGL(k_det_tail, dim3((unsigned)((maxcells + 127) / 128), (unsigned)(g.n_levels * g.batch)), dim3(256), 0, s, a, dense, g);
     return hipGetLastError();
 }
 

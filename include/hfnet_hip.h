@@ -90,6 +90,7 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *   "pyramid_fuse" (1)  calls of up to four frames: the pyramid resize chain as one launch
  *   "interleave" (3)    calls of up to four frames: the launch groups of the global branch are enqueued between the launches
  *                       of the local heads, this many right after the detector conv (0: the whole branch after the local heads)
+ *   "det_fuse" (1)      detector tail (1x1 conv 128 -> 65, softmax, depth_to_space) as one launch: the logits stay in LDS
  *   "host_global" (1)   host-pointer calls of up to four frames: the last kernel of the global branch writes the descriptors
  *                       into the pinned result block itself (no copy after the join, the call returns without draining the stream)
  *   "copy_threads" (64 = by core count): helper threads for the staging copies of host-pointer batch calls (replicas sharing a host)
