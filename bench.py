@@ -60,6 +60,7 @@ def layer_work(batch: int, width: int = W_IMG, height: int = H_IMG, n_feat: int 
         work[name] = (f + flop, b + byts, x + (flop if executed is None else executed))
 
     V4_SHAPES = {(1, 3, 1), (1, 3, 2), (1, 6, 2), (1, 6, 3), (1, 9, 3), (2, 2, 1), (2, 3, 1)}   # (stride, cin / 8, cout tiles): kernels_block.hip
+    V6_SHAPES = {(1, 6, 3), (1, 12, 6), (1, 12, 3), (1, 12, 5), (1, 18, 5)}                      # (stride, cin / 4, 16-column tiles): k_block_fused6
 
     def fused_executed(b, oh, ow):
         """FLOP the fused block kernel issues for one image.  k_block_fused4 (wave tiles of 4 x 8 outputs, expansion of
@@ -68,6 +69,12 @@ def layer_work(batch: int, width: int = W_IMG, height: int = H_IMG, n_feat: int 
         s = b.stride
         chunks = -(-b.expand // 32)
         nto = -(-b.cout // 32)
+        if (s, b.cin // 4, -(-b.cout // 16)) in V6_SHAPES:
+            # k_block_fused6: 6 x 8 outputs, the 8 x 10 halo as five 16-row M tiles, 16-column tiles (v_mfma_f32_16x16x4_f32: 2048 FLOP)
+            tiles = -(-oh // 6) * -(-ow // 8)
+            n16e, n16p = -(-b.expand // 16), -(-b.cout // 16)
+            mfma16 = tiles * (5 * n16e * (b.cin // 4) + 3 * n16p * (b.expand // 4))
+            return mfma16 * 2048.0 + 2.0 * 9 * b.expand * tiles * 48
         if (s, b.cin // 8, nto) in V4_SHAPES:
             th, tw = 4, 8
         else:

@@ -89,7 +89,7 @@ struct DevMem {
 struct Options {
     int fuse_blocks = 1;      // 0: expand / depthwise / project as three launches per block (the reference variant of the tests)
     int fuse_max_layer = 14;  // last layer that may use a fused block kernel
-    int fused_variant = 4;    // 4: wave-autonomous tiles where they exist (3: their three-waves-per-SIMD forms at any size); 2: the barrier-phased kernel everywhere
+    int fused_variant = 4;    // 4: wave-autonomous tiles where they exist (5: the 4 x 8 form only, at any size; 3: its three-waves-per-SIMD forms at any size; 6 / 7: the 6 x 8 form at any size / everywhere); 2: the barrier-phased kernel everywhere
     int fuse_stem = 1;        // stem + layer_2 in one launch
     int dense_desc = 0;       // 1: always evaluate the dense descriptor head (default: only the taps of the selected keypoints)
     int two_streams = 3;      // 0 one stream; 1 fork after layer 7; 2 fork after the detector conv; 3 = 2 + deferred join

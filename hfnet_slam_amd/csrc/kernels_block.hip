@@ -30,6 +30,7 @@ struct FusedArgs {
     const f32x4* Wex; const float* ex_bias; int ex_nt_total;     // BatchNorm folded (weights.cpp): accumulators start at the bias
     const float* Wdw; const float* dw_bias;
     const f32x4* Wpr; const float* pr_bias; int pr_nt_total;
+    const f32x4* Wex16; const f32x4* Wpr16; int ex_n16, pr_n16;  // ConvPack16 forms (k_block_fused6)
     float* out;
     int cin, cexp, cout, residual, has_expand;
     int level_wgs[HFNET_MAX_LEVELS];   // k_block_fused4: workgroups launched per image of each level (a multiple of 8; exact 1-D grid)
@@ -771,6 +772,279 @@ static hipError_t launch_block_fused4_t(const FusedArgs& a, const Geom& g, hipSt
     return hipGetLastError();
 }
 
+// ---- v6 of the fused block (stride 1): the wave-autonomous scheme of v4 on v_mfma_f32_16x16x4_f32 with a 6 x 8 output tile.
+// What v4 pays for its autonomy is the halo: a 4 x 8 tile's 6 x 10 positions are two 32-row M tiles for one tile of outputs
+// (expansion executed 2.0x), and 32-column tiles pad cout = 48 / 72 to 64 / 96.  With 16-row / 16-column tiles a 6 x 8 tile's
+// 8 x 10 halo is exactly five M tiles for three tiles of outputs (1.67x) and the projection runs on 48 / 80 columns.  Same
+// flop rate per instruction (1024 fma in 8 passes against 2048 in 16), same chains (k ascending from the folded bias: the
+// channels of a group of 16 sit in "slot" order, lane group g of MFMA t reads logical channel 4 t + g -- ConvPack16, as
+// k_dwproject), same bits.  The block input is in the 32x32x2 kernels' channel order in HBM, so a lane gathers its A values as
+// single floats (once per tile, they stay in registers for all chunks).  30 x 47 maps: 30 tiles per frame -- a 64-frame call
+// is 1920 wave tiles, one round at two waves per SIMD (v4: 3072, a round and a half).
+struct F6Geo {
+    static constexpr int TH = 6, TW = 8, IH = 8, IW = 10, NPOS = 80, MT = 5, MO = 3;
+    static constexpr int EP = 84;                     // channel stride of ET in floats (21 pieces of 16 bytes: odd)
+    static constexpr int CEP = 36;                    // pixel stride of D
+};
+__device__ __forceinline__ int f6_slot_of_phys(int p) {          // chunk-local device position -> slot of its logical channel (k_dwproject's order)
+    const int r = p & 7, l = (p & ~7) | (r < 4 ? 2 * r : 2 * (r - 4) + 1);
+    return (l & ~15) | ((l & 3) << 2) | ((l & 15) >> 2);
+}
+
+template <int KT, int NT16, bool RES, int OCC>
+__global__ __launch_bounds__(64, OCC) void k_block_fused6(FusedArgs a, Geom g) {
+    using G = F6Geo;
+    constexpr int TH = G::TH, TW = G::TW, IH = G::IH, IW = G::IW, NPOS = G::NPOS, MT = G::MT, MO = G::MO, EP = G::EP, CEP = G::CEP;
+    constexpr int KB = (KT + 3) / 4;                              // groups of 16 input channels (the last one may hold 8)
+    __shared__ __attribute__((aligned(16))) float ET[32 * EP];
+    const int lane = threadIdx.x, j = lane & 15, gq = lane >> 4;
+    int level = 0, bx = blockIdx.x;
+    for (; level < g.n_levels - 1; ++level) {
+        const int per = g.batch * a.level_wgs[level];
+        if (bx < per) break;
+        bx -= per;
+    }
+    const int frame = bx / a.level_wgs[level];
+    bx -= frame * a.level_wgs[level];
+    const int image = level * g.batch + frame;
+    const LevelGeom lv = g.lv[level];
+    const int tiles_x = (lv.Wo + TW - 1) / TW, ntiles = tiles_x * ((lv.Ho + TH - 1) / TH);
+    const int q = ntiles >> 3, rem = ntiles & 7;                  // (XCD mapping: as k_block_fused4)
+    const int xr = (bx + image) & 7, slot = bx >> 3;
+    if (slot >= q + (xr < rem ? 1 : 0)) return;
+    const int tile = xr * q + min(xr, rem) + slot;
+    const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int oy0 = tyi * TH, ox0 = txi * TW;
+    const int iy0 = oy0 - lv.pt, ix0 = ox0 - lv.pl;
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= lv.H && ix0 + IW <= lv.W;
+    const long long in_base = lv.in_off + (long long)frame * lv.H * lv.W;
+    const long long out_base = lv.out_off + (long long)frame * lv.Ho * lv.Wo;
+    const char* __restrict__ xb = (const char*)(a.X + in_base * a.cin);      // uniform; lane offsets are 32-bit
+
+    // ---- block input: MFMA t of group kb wants logical channel 16 kb + 4 t + gq of halo position 16 m + j; in the tensor's
+    //      channel order (even channels of a group of 8 first) that is float 16 kb + 8 (t >> 1) + 2 (t & 1) + [4 (gq & 1) + (gq >> 1)]
+    float afrag[MT][KT];
+    const unsigned lane_c = (unsigned)(4 * (gq & 1) + (gq >> 1)) * 4u;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int pp = m * 16 + j;
+        const int hy = pp / IW, hx = pp - hy * IW;
+        const int iy = min(max(iy0 + hy, 0), lv.H - 1), ix = min(max(ix0 + hx, 0), lv.W - 1);
+        const unsigned off = (unsigned)(iy * lv.W + ix) * (unsigned)a.cin * 4u + lane_c;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+            afrag[m][kt] = *(const float*)(xb + off + (unsigned)(16 * (kt >> 2) + 8 * ((kt & 3) >> 1) + 2 * (kt & 1)) * 4u);
+    }
+    unsigned long long outside[2] = {0ull, 0ull};
+    if (!interior) {
+        const unsigned long long full = (1ull << IW) - 1;
+        const int clo = min(max(-ix0, 0), IW), chi = min(max(lv.W - ix0, 0), IW);          // columns [clo, chi) are inside
+        const unsigned long long cols = (((1ull << clo) - 1) | ~((1ull << chi) - 1)) & full;
+#pragma unroll
+        for (int hy = 0; hy < IH; ++hy) {
+            const unsigned long long bits = (iy0 + hy < 0 || iy0 + hy >= lv.H) ? full : cols;
+            const int pos = hy * IW, wd = pos >> 6, sh = pos & 63;
+            outside[wd] |= bits << sh;
+            if (sh + IW > 64) outside[wd + 1] |= bits >> (64 - sh);
+        }
+    }
+    f32x4 pacc[MO][NT16];
+#pragma unroll
+    for (int nt = 0; nt < NT16; ++nt) {
+        const float pb = a.pr_bias[nt * 16 + j];                   // (zero padded to pr_nt_total * 32 >= NT16 * 16)
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo) pacc[mo][nt] = f32x4{pb, pb, pb, pb};
+    }
+    const int ex_n16 = a.ex_n16, n_chunks = (ex_n16 + 1) >> 1;
+    const unsigned lane16_ = (unsigned)lane * 16u, j4_ = (unsigned)j * 4u;
+    // expansion weights: one 16-byte piece per (input group, column tile), streamed through a ring PF pieces deep
+    constexpr int NP = 2 * KB, PF = NP % 4 == 0 ? 4 : (NP % 3 == 0 ? 3 : (NP % 5 == 0 ? 5 : 2));   // (a divisor of NP: piece s of every chunk lives in slot s % PF)
+    static_assert(NP % PF == 0, "ring depth");
+    auto ex_piece = [&](int chunk, int s) -> f32x4 {              // s = kb * 2 + nt
+        const int nt = min(chunk * 2 + (s & 1), ex_n16 - 1);      // (a last chunk of 16 channels: the second tile repeats the first; never consumed)
+        return *(gvec4_t)(sgpr_base(a.Wex16, (unsigned)((s >> 1) * ex_n16 + nt) * 1024u) + fresh(lane16_));
+    };
+    f32x4 bq[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) bq[u] = ex_piece(0, u);
+    const int r = lane & 31, rh = lane >> 5;                      // depthwise role: channel r of the chunk, output rows 3 rh .. 3 rh + 2
+    const int dslot = f6_slot_of_phys(r);
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int ch0 = chunk * 32;
+        const int kbc = min(2, (a.cexp - ch0) >> 4);               // 16-channel groups of this chunk the projection consumes
+        const int cn = min(chunk + 1, n_chunks - 1);
+        float eb[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) eb[nt] = *(gf32_t)(sgpr_base(a.ex_bias, (unsigned)(min(chunk * 2 + nt, ex_n16 - 1) * 16) * 4u) + fresh(j4_));
+        const unsigned dch4 = (unsigned)min(r, a.cexp - 1 - ch0) * 4u;      // (channels past cexp: clamped, never consumed)
+        float dwt[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dwt[t] = *(gf32_t)(sgpr_base(a.Wdw, (unsigned)(t * a.cexp + ch0) * 4u) + dch4);
+        const float dwb = *(gf32_t)(sgpr_base(a.dw_bias, (unsigned)ch0 * 4u) + dch4);
+        // ---- expansion: ten independent chains (five halo M tiles x two column tiles), k outer
+        {
+            f32x4 acc[MT][2];
+            const f32x4 ebv[2] = {f32x4{eb[0], eb[0], eb[0], eb[0]}, f32x4{eb[1], eb[1], eb[1], eb[1]}};   // C operand of every chain's first MFMA
+#pragma unroll
+            for (int s = 0; s < NP; ++s) {
+                const f32x4 b = bq[s % PF];
+                // the piece PF steps ahead (the next chunk's first pieces at the end: they arrive during the depthwise phase)
+                bq[s % PF] = s + PF < NP ? ex_piece(chunk, s + PF) : ex_piece(cn, s + PF - NP);
+                const int kb = s >> 1, nt = s & 1;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (kb * 4 + t < KT) {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[m][kb * 4 + t], b[t], (kb == 0 && t == 0) ? ebv[nt] : acc[m][nt], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // D fragment: column (channel) nt * 16 + j, rows (halo positions) 16 m + 4 gq .. + 3
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = relu6f(acc[m][nt][i]);
+                    *(f32x4*)(ET + (nt * 16 + j) * EP + m * 16 + 4 * gq) = v;
+                }
+        }
+        if (!interior) {
+#pragma unroll
+            for (int wd = 0; wd < 2; ++wd) {
+                unsigned long long msk = outside[wd];                                  // uniform
+                while (msk) {
+                    const int pp = wd * 64 + (int)__builtin_ctzll(msk);
+                    msk &= msk - 1;
+                    if (lane < 32) ET[lane * EP + pp] = 0.0f;
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        // ---- depthwise: channel r, output rows 3 rh .. 3 rh + 2 (input rows 3 rh .. 3 rh + 4), one input row in registers at a time
+        f32x4 pfrag[2][NT16];
+        {
+            const float* rp = ET + r * EP + rh * 3 * IW;
+            float o[3][TW];
+#pragma unroll
+            for (int ro = 0; ro < 3; ++ro)
+#pragma unroll
+                for (int ox = 0; ox < TW; ++ox) o[ro][ox] = dwb;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                float row[IW];
+#pragma unroll
+                for (int x2 = 0; x2 < IW / 2; ++x2) {
+                    const float2 v = *(const float2*)(rp + i * IW + x2 * 2);
+                    row[2 * x2] = v.x; row[2 * x2 + 1] = v.y;
+                }
+#pragma unroll
+                for (int ro = 0; ro < 3; ++ro) {
+                    const int ky = i - ro;
+                    if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                    for (int ox = 0; ox < TW; ++ox)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) o[ro][ox] = fmaf(row[ox + kx], dwt[ky * 3 + kx], o[ro][ox]);
+                }
+            }
+#pragma unroll
+            for (int ro = 0; ro < 3; ++ro)
+#pragma unroll
+                for (int ox = 0; ox < TW; ++ox) o[ro][ox] = relu6f(o[ro][ox]);
+            asm volatile("" ::: "memory");                         // every ET read is issued before D overwrites the slice
+            // this chunk's projection weights: requested here, into registers the expansion has released (requesting them before
+            // the depthwise arithmetic, or a deeper ring for the expansion weights, changes nothing: measured)
+            {
+                const unsigned l16 = fresh(lane16_);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int nt = 0; nt < NT16; ++nt)
+                        pfrag[kb][nt] = *(gvec4_t)(sgpr_base(a.Wpr16, (unsigned)((chunk * 2 + min(kb, kbc - 1)) * a.pr_n16 + nt) * 1024u) + l16);
+            }
+#pragma unroll
+            for (int ro = 0; ro < 3; ++ro)
+#pragma unroll
+                for (int ox = 0; ox < TW; ++ox) ET[((rh * 3 + ro) * TW + ox) * CEP + dslot] = o[ro][ox];
+        }
+        asm volatile("" ::: "memory");
+        // ---- projection of this chunk's channels: A = D[pixel 16 mo + j][slots 16 kb + 4 gq ..]
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if (kb < kbc) {
+                f32x4 av[MO];
+#pragma unroll
+                for (int mo = 0; mo < MO; ++mo) av[mo] = *(const f32x4*)(ET + (mo * 16 + j) * CEP + kb * 16 + 4 * gq);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+                        for (int nt = 0; nt < NT16; ++nt) pacc[mo][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mo][t], pfrag[kb][nt][t], pacc[mo][nt], 0, 0, 0);
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    // ---- output (+ residual): two column tiles at a time through the LDS slice so that a lane moves 16 consecutive bytes
+    float* __restrict__ ob = a.out + out_base * a.cout;                                // uniform
+    const float* __restrict__ rb = a.X + in_base * a.cin;                              // residual: same size, cin == cout
+#pragma unroll
+    for (int np = 0; np < (NT16 + 1) / 2; ++np) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int nt = 2 * np + h;
+            if (nt < NT16) {
+#pragma unroll
+                for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ET[(mo * 16 + 4 * gq + i) * CEP + h * 16 + j] = pacc[mo][nt][i];
+            }
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int piece = lane + 64 * k, px = piece >> 3, c4 = piece & 7;
+            const int col = np * 32 + c4 * 4;
+            const int oy = oy0 + px / TW, ox = ox0 + px % TW;
+            f32x4 v = *(const f32x4*)(ET + px * CEP + c4 * 4);
+            if (col < a.cout && oy < lv.Ho && ox < lv.Wo) {
+                const unsigned off = (unsigned)(oy * lv.Wo + ox) * (unsigned)a.cout + (unsigned)col;
+                if (RES) {
+                    const f32x4 rv = *(const f32x4*)(rb + off);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] + rv[e];
+                }
+                *(f32x4*)(ob + off) = v;
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
+template <int KT, int NT16, int OCC>
+static hipError_t launch_block_fused6_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
+    using G = F6Geo;
+    if ((a.residual && a.cin != a.cout) || a.cin != KT * 4 || a.pr_n16 != NT16 || !a.Wex16 || !a.Wpr16) return hipErrorInvalidValue;
+    FusedArgs b = a;
+    long long total = 0;
+    for (int l = 0; l < HFNET_MAX_LEVELS; ++l) {
+        b.level_wgs[l] = 8;
+        if (l >= g.n_levels) continue;
+        const int tiles = ((g.lv[l].Wo + G::TW - 1) / G::TW) * ((g.lv[l].Ho + G::TH - 1) / G::TH);
+        b.level_wgs[l] = max(8, ((tiles + 7) / 8) * 8);
+        total += (long long)b.level_wgs[l] * g.batch;
+    }
+    if (total <= 0 || total > 0x7fffffffll) return hipErrorInvalidValue;
+    dim3 grid((unsigned)total);
+    if (a.residual) hipLaunchKernelGGL((k_block_fused6<KT, NT16, true, OCC>), grid, dim3(64), 0, s, b, g);
+    else hipLaunchKernelGGL((k_block_fused6<KT, NT16, false, OCC>), grid, dim3(64), 0, s, b, g);
+    return hipGetLastError();
+}
+
 // ---- layer_2 (expanded_conv with expansion factor 1: no expand conv, hf_net.py:31-33): depthwise 3x3 + BN + ReLU6 on
 // CIN channels, then the 1x1 projection CIN -> COUT + BN, stride 1.  Its tensors are the largest of the network (1/2
 // resolution) and its arithmetic the smallest: one thread per output pixel of a 16 x 16 tile on the vector ALUs, the
@@ -1108,6 +1382,7 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
     a.Wex = (const f32x4*)b.ex.w; a.ex_bias = b.ex.bias; a.ex_nt_total = b.ex.nt_total;
     a.Wdw = b.dw.w; a.dw_bias = b.dw.bias;
     a.Wpr = (const f32x4*)b.pr.w; a.pr_bias = b.pr.bias; a.pr_nt_total = b.pr.nt_total;
+    a.Wex16 = (const f32x4*)b.ex16.w; a.Wpr16 = (const f32x4*)b.pr16.w; a.ex_n16 = b.ex16.w ? b.ex16.n16 : 0; a.pr_n16 = b.pr16.w ? b.pr16.n16 : 0;
     a.out = out; a.cin = b.cin; a.cexp = b.expand; a.cout = b.cout; a.residual = b.residual; a.has_expand = b.has_expand;
     const int nto = (b.cout + 31) / 32, kq = b.cin / 8, st = b.stride;
     const long long n_tiles = tile_grid_size<4, 8>(g);             // wave tiles of the k_block_fused4 launch
@@ -1118,6 +1393,18 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
     FusedKind kind = fused_kind(b, variant);
     const bool small_launch = n_tiles < 2048;
     if (kind == FUSED_V4 && variant == 4 && small_launch && fused_kind(b, 2) == FUSED_V2) kind = FUSED_V2;
+    // v6 (6 x 8 tiles on the 16x16x4 MFMA): what a launch of k_block_fused4's size runs for the stride-1 blocks from layer 6 on
+    // (per 64 frames, v4 -> v6: layer 6 331 -> 303 us, 7 966 -> 957, 9-11 94 -> 87, 12 138 -> 98, 13 / 14 245 -> 168); layer 4 (four waves
+    // per SIMD in v4, three here: its LDS tile) is slower and stays (variant 7: everywhere, variant 6: at any launch size -- tests)
+    if (kind == FUSED_V4 && st == 1 && a.Wex16 && a.Wpr16 && (variant == 6 || variant == 7 || (variant == 4 && !small_launch))) {
+        const int kt = b.cin / 4, n16 = a.pr_n16;
+        if (kt == 6 && n16 == 3) return launch_block_fused6_t<6, 3, 2>(a, g, s);
+        if (kt == 12 && n16 == 6) return launch_block_fused6_t<12, 6, 2>(a, g, s);
+        if (kt == 12 && n16 == 3) return launch_block_fused6_t<12, 3, 2>(a, g, s);
+        if (kt == 12 && n16 == 5) return launch_block_fused6_t<12, 5, 2>(a, g, s);
+        if (kt == 18 && n16 == 5) return launch_block_fused6_t<18, 5, 2>(a, g, s);
+        if (variant == 7 && kt == 6 && n16 == 2) return launch_block_fused6_t<6, 2, 3>(a, g, s);
+    }
     switch (kind) {
         case FUSED_NOEXPAND: {
             int maxtiles = 0;

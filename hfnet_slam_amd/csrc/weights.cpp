@@ -238,10 +238,10 @@ int DeviceWeights::build(const WeightFile& wf) {
         b.stride = kStrides[i];
         b.has_expand = wf.find(scope + "/expand/weights") != nullptr;
         b.expand = cin;
-        if (b.has_expand) HF_TRY(pack_conv_bn(*this, wf, scope + "/expand", true, b.ex, &b.expand, i >= 7 ? &b.ex16 : nullptr));   // (layers 9-18)
+        if (b.has_expand) HF_TRY(pack_conv_bn(*this, wf, scope + "/expand", true, b.ex, &b.expand, i >= 2 ? &b.ex16 : nullptr));   // (k_dwproject: layers 9-18; k_block_fused6)
         HF_TRY(pack_dw(*this, wf, scope + "/depthwise", b.dw));
         if (b.dw.c != b.expand) { set_error("block %d: depthwise width %d != expansion %d", i, b.dw.c, b.expand); return HFNET_ERR_IO; }
-        HF_TRY(pack_conv_bn(*this, wf, scope + "/project", true, b.pr, &b.cout, i >= 6 ? &b.pr16 : nullptr));   // (layers 8-18: single-frame kernels)
+        HF_TRY(pack_conv_bn(*this, wf, scope + "/project", true, b.pr, &b.cout, i >= 2 ? &b.pr16 : nullptr));   // (k_dwproject: layers 8-18; k_block_fused6)
         if (b.pr.cin != b.expand || (b.has_expand && b.ex.cin != cin)) { set_error("block %d: channel mismatch", i); return HFNET_ERR_IO; }
         b.residual = (b.stride == 1 && b.cin == b.cout);   // conv_blocks.py:304-311
         if (!b.has_expand) {

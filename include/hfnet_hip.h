@@ -76,8 +76,10 @@ void hfnet_engine_destroy(hfnet_engine* e);
 int hfnet_engine_info(const hfnet_engine* e, int what);
 /* Diagnostics / A-B switches, read when a model or extractor is created from the engine (no environment variables):
  *   "fuse_blocks" (1)   0: every inverted-residual block as three launches (the tests' reference variant)
- *   "fuse_max_layer" (14), "fused_variant" (4: wave-autonomous tiles, 3: their three-waves-per-SIMD forms at any launch size,
- *                       2: barrier-phased kernel), "fuse_stem" (1)
+ *   "fuse_max_layer" (14), "fused_variant" (4: wave-autonomous tiles -- 6 x 8 on the 16x16x4 MFMA for the stride-1 blocks from
+ *                       layer 6 on, 4 x 8 on 32x32x2 otherwise; 5: the 4 x 8 form only, at any launch size; 3: their three-waves-per-SIMD forms at any
+ *                       launch size; 6 / 7: the 6 x 8 tiles at any launch size / for every stride-1 block; 2: barrier-phased
+ *                       kernel), "fuse_stem" (1)
  *   "fuse_min_wgs" (256) layers 8-14 take their fused kernel from this many 128-pixel tiles per launch on (0: always)
  *   "dense_desc" (0)    1: dense descriptor head instead of the taps of the selected keypoints
  *   "dedupe_taps" (1)   sparse descriptor head: taps shared by neighbouring keypoints are evaluated once

@@ -24,6 +24,11 @@ int main(int argc, char** argv) {
     b.dw.c = b.expand; b.dw.w = dev_rand(9 * b.expand, 0.3f); b.dw.bias = dev_rand(b.expand, 0.2f);
     b.pr.taps = 1; b.pr.cin = b.expand; b.pr.n = b.cout; b.pr.nt_total = (b.cout + 31) / 32;
     b.pr.w = dev_rand((size_t)b.expand / 8 * b.pr.nt_total * 256, 0.1f); b.pr.bias = dev_rand(b.pr.nt_total * 32, 0.2f);
+    // (ConvPack16 forms for k_block_fused6: [ceil(cin / 16)][n16][64][4])
+    b.ex16.cin = b.cin; b.ex16.n = b.expand; b.ex16.n16 = (b.expand + 15) / 16;
+    b.ex16.w = dev_rand((size_t)((b.cin + 15) / 16) * b.ex16.n16 * 256, 0.2f);
+    b.pr16.cin = b.expand; b.pr16.n = b.cout; b.pr16.n16 = (b.cout + 15) / 16;
+    b.pr16.w = dev_rand((size_t)((b.expand + 15) / 16) * b.pr16.n16 * 256, 0.1f);
     Geom g{};
     g.n_levels = L <= 7 ? 4 : 1; g.batch = frames;
     long long in_off = 0, out_off = 0;
