@@ -124,6 +124,9 @@ def layer_work(batch: int, width: int = W_IMG, height: int = H_IMG, n_feat: int 
                 add("conv3x3_det", 2.0 * 9 * c7 * 128 * cells, 4.0 * (cells * (c7 + 128) + 9 * c7 * 128))
                 add("pointwise_det", 2.0 * 128 * 65 * cells, 4.0 * (cells * (128 + 65) + 128 * 65), 2.0 * 128 * 96 * cells)
                 add("softmax_d2s", 4.0 * 65 * cells, 4.0 * cells * (65 + 64))
+                # the two as ONE launch (the default): hidden map in, score map out, the logits stay in LDS; executed = two 32-column
+                # MFMA tiles + the dustbin column and the softmax on the vector ALU
+                add("det_tail", (2.0 * 128 * 65 + 4.0 * 65) * cells, 4.0 * (cells * (128 + 64) + 128 * 65), (2.0 * 128 * 65 + 4.0 * 65) * cells)
                 add("nms", 2.0 * 3 * 18 * hc * wc * batch, 4.0 * 2 * hc * wc * batch)
         if lvl == 0:
             pg = ph * pw * batch
@@ -333,7 +336,7 @@ def launch_class(name: str) -> str:
     """what bounds a launch by construction: the classes of roofline.classes"""
     if name.startswith("block_L") or name == "stem_block_L02":
         return "fused_block"
-    if name.startswith(("conv3x3_", "pointwise_de")):
+    if name.startswith(("conv3x3_", "pointwise_de", "det_tail")):
         return "head_gemm"
     if name.startswith(("expand_L", "project_L", "pointwise_memberships", "fc_l2")):
         return "global_gemm"

@@ -15,18 +15,17 @@ LAUNCHES = {
     "block_L03": ("void hfnet::k_block_fused4<2, 1, 2, false", 0),
     "block_L04": ("void hfnet::k_block_fused4<1, 1, 3, true", 0),
     "block_L05": ("void hfnet::k_block_fused4<2, 1, 3, false", 0),
-    "block_L06": ("void hfnet::k_block_fused4<1, 2, 3, false", 0),
-    "block_L07": ("void hfnet::k_block_fused4<1, 3, 6, false", 0),
+    "block_L06": ("void hfnet::k_block_fused6<6, 3, false", 0),
+    "block_L07": ("void hfnet::k_block_fused6<12, 6, false", 0),
     "block_L08": ("void hfnet::k_block_fused2<2, 2, 12, true, 8>", 0),
     "pointwise_desc_taps": ("void hfnet::k_pointwise_wlds<4>", 0),
-    "pointwise_det": ("void hfnet::k_pointwise_wlds<3>", 0),
+    "det_tail": ("hfnet::k_det_tail", 0),
     "fc": ("void hfnet::k_fc_mfma<16>", 0),
-    "block_L09": ("void hfnet::k_block_fused4<1, 2, 6, true", 0),
-    "block_L12": ("void hfnet::k_block_fused4<1, 3, 6, false", 1),
-    "block_L13": ("void hfnet::k_block_fused4<1, 3, 9, true", 0),
+    "block_L09": ("void hfnet::k_block_fused6<12, 3, true", 0),
+    "block_L12": ("void hfnet::k_block_fused6<12, 5, false", 0),
+    "block_L13": ("void hfnet::k_block_fused6<18, 5, true", 0),
     "nms_mask": ("hfnet::k_nms_mask", 0),
     "nms_select": ("hfnet::k_nms_select", 0),
-    "softmax_d2s": ("hfnet::k_softmax_d2s", 0),
     "sample": ("hfnet::k_sample", 0),
     "pyramid_resize": ("hfnet::k_resize_u8", 0),
     "depthwise_L16": ("void hfnet::k_depthwise<1, 5>", 0),
