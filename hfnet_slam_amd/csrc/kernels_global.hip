@@ -224,6 +224,75 @@ __global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ x, co
     }
 }
 
+// Many frames per call (> 16): one workgroup per column tile, one wave per 16-frame row tile, and the 16 input ranges walked as ONE
+// stream of weight pieces (the ring of NBUF loads never drains at a range boundary: restarting it 16 times -- or writing and
+// re-reading 17 MB of partial sums -- is what made the split form slower than round 2's single chain at 64 frames).  At a range
+// boundary the accumulator goes to LDS and restarts from zero; at the end every lane adds its 16 partial sums as
+// fc_combine_one does (balanced binary tree, then the bias) and writes y_raw.  Same chains, same tree, same bits.
+template <int NBUF>
+__global__ __launch_bounds__(256) void k_fc_mfma_seq(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                     float* __restrict__ y_raw, int frames, int n_in, int n_out) {
+    __shared__ f32x4 part_acc[4][FC_PARTS][64];                   // 64 KB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ctiles = n_out >> 4, ct = blockIdx.x, rt = blockIdx.y * 4 + wave;
+    if (rt * 16 >= frames) return;
+    const int row = min(rt * 16 + (lane & 15), frames - 1);
+    const f32x4* __restrict__ ap = (const f32x4*)(x + (long long)row * n_in) + (lane >> 4);
+    const f32x4* __restrict__ wp = (const f32x4*)w + (size_t)ct * 64 + lane;
+    const size_t wstep = (size_t)ctiles * 64;
+    const int KG_all = n_in >> 4, gp = (KG_all + FC_PARTS - 1) / FC_PARTS;
+    const int col = ct * 16 + (lane & 15);
+    f32x4 av[NBUF], bv[NBUF];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int part = 0, boundary = gp;                                  // the current range is [part * gp, boundary)
+    auto load = [&](int kg, auto buf_tag) {
+        constexpr int buf = decltype(buf_tag)::value;
+        kg = min(kg, KG_all - 1);                      // unconditional (see k_pointwise_deep)
+        av[buf] = ap[kg * 4];
+        bv[buf] = wp[(size_t)kg * wstep];
+    };
+    auto compute = [&](int kg, auto buf_tag) {
+        constexpr int buf = decltype(buf_tag)::value;
+        if (kg < KG_all) {                             // uniform
+            if (kg == boundary) {                      // uniform: the range is complete
+                part_acc[wave][part][lane] = acc;
+                acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                ++part; boundary += gp;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][t], bv[buf][t], acc, 0, 0, 0);
+        }
+    };
+    fc_static_for<NBUF - 1>([&](auto i) { load(decltype(i)::value, i); });
+    for (int kg = 0; kg < KG_all; kg += NBUF) {
+        fc_static_for<NBUF>([&](auto i) {
+            constexpr int I = decltype(i)::value;
+            load(kg + I + NBUF - 1, std::integral_constant<int, (I + NBUF - 1) % NBUF>{});
+            __builtin_amdgcn_sched_barrier(0);
+            compute(kg + I, i);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    part_acc[wave][part][lane] = acc;
+    for (int q = part + 1; q < FC_PARTS; ++q) part_acc[wave][q][lane] = f32x4{0.f, 0.f, 0.f, 0.f};   // (ranges past the inputs: empty chains)
+    // (a lane reads back only what it wrote: no barrier)
+    f32x4 p[FC_PARTS];
+#pragma unroll
+    for (int q = 0; q < FC_PARTS; ++q) p[q] = part_acc[wave][q][lane];
+#pragma unroll
+    for (int m = FC_PARTS; m > 1; m >>= 1)
+#pragma unroll
+        for (int q = 0; q < m / 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[q][e] = p[2 * q][e] + p[2 * q + 1][e];
+    const float b = bias[col];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int rr = rt * 16 + (lane >> 4) * 4 + reg;
+        if (rr < frames) y_raw[(long long)rr * n_out + col] = p[0][reg] + b;
+    }
+}
+
 __device__ __forceinline__ float fc_combine_one(const float* __restrict__ partial, const float* __restrict__ bias, int frames, int n, int f, int i) {
     float p[FC_PARTS];
 #pragma unroll
@@ -283,9 +352,13 @@ hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* partial, float*
     if (frames <= 0) return hipSuccess;
     if (fc.n_in % 16 || fc.n_out % 16) return hipErrorInvalidValue;
     const int waves = std::min(4, (frames + 15) / 16);
-    const int ppw = frames > 16 ? 4 : 1;
-    hipLaunchKernelGGL(k_fc_mfma<16>, dim3(fc.n_out / 16, (frames + 63) / 64, FC_PARTS / ppw), dim3(64 * waves), 0, s, x, fc.w, partial, frames, fc.n_in, fc.n_out, ppw);
     if (host.out && !fc_host_out_supported(frames)) return hipErrorInvalidValue;
+    if (frames > 16) {
+        hipLaunchKernelGGL(k_fc_mfma_seq<16>, dim3(fc.n_out / 16, (frames + 63) / 64), dim3(64 * waves), 0, s, x, fc.w, fc.bias, y_raw, frames, fc.n_in, fc.n_out);
+        hipLaunchKernelGGL(k_l2norm_vec, dim3(frames), dim3(256), 0, s, y_raw, out, fc.n_out);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_fc_mfma<16>, dim3(fc.n_out / 16, (frames + 63) / 64, FC_PARTS), dim3(64 * waves), 0, s, x, fc.w, partial, frames, fc.n_in, fc.n_out, 1);
     if (frames <= 4) {
         hipLaunchKernelGGL(k_fc_combine_l2, dim3(frames), dim3(1024), 0, s, partial, fc.bias, y_raw, out, frames, fc.n_out, host);
     } else {

@@ -202,6 +202,21 @@ def test_extractor_matches_oracle(engine, oracle_model, cfg, variant, engine_opt
     x.close()
 
 
+def test_many_frames_per_call_global_descriptor(engine, oracle_model):
+    """calls of more than 16 frames take the FC form that walks the 16 input ranges as one stream (k_fc_mfma_seq), with a partial last
+    16-frame row tile here: every frame's global descriptor (and keypoints) must equal the oracle's"""
+    from hfnet_slam_amd import capi
+    w, h, nf, nl, B = 96, 96, 64, 2, 21
+    x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, nl, max_batch=B)
+    imgs = np.stack([synth_image(h, w, 4100 + i, "natural" if i % 3 else "uniform") for i in range(B)])
+    nb, kb, db, gb = x.extract_batch(imgs)
+    for i in range(B):
+        rn, rk, rd, rg, _ = oracle_model.extract(imgs[i], nf, 0.01, nl, 1.2)
+        assert nb[i] == rn
+        _eq(f"kps {i}", kb[i, :rn], rk); _eq(f"desc {i}", db[i, :rn], rd); _eq(f"global {i}", gb[i], rg)
+    x.close()
+
+
 def _unit_rows(rng, n, d=256):
     a = rng.standard_normal((n, d)).astype(np.float32)
     return (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
