@@ -1237,11 +1237,16 @@ __global__ __launch_bounds__(256) void k_stem_block2(ImageSet imgs, const float*
             const bool in = INT || (sy >= 0 && sy < ls.Ho && sx >= 0 && sx < ls.Wo);
             float px[9];
             if (INT) {
+                // a row's three bytes as ONE (unaligned) 4-byte load -- the fourth byte is the next pixel of a row that is never
+                // the image's last one here -- and (x - 128) / 128 as one fma: x / 128 - 1 is exact, the same value
                 const uint8_t* ip = img + (long long)(sy * 2 - ls.pt) * rs + (sx * 2 - ls.pl);
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                for (int ky = 0; ky < 3; ++ky) {
+                    unsigned wv;
+                    __builtin_memcpy(&wv, ip + ky * rs, 4);
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) px[ky * 3 + kx] = ((float)ip[ky * rs + kx] - 128.0f) * 0.0078125f;
+                    for (int kx = 0; kx < 3; ++kx) px[ky * 3 + kx] = fmaf((float)((wv >> (8 * kx)) & 0xffu), 0.0078125f, -1.0f);
+                }
             } else {
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)

@@ -331,17 +331,30 @@ __global__ __launch_bounds__(256) void k_bow_gemm_cand(const BowPair* __restrict
         const float tnj = P.tn[min(tj, n2 - 1)];
         float lo[2][16];
         float hmin = FLT_MAX;
+        if (row0 + 128 <= n1) {                                // (workgroup-uniform) every query row of the tile exists: no selects
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int rr = wr + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;      // query row inside the workgroup tile
-                const bool ok = row0 + rr < n1;
-                const float nn = qns[rr] + tnj;
-                const float dd = fmaf(-2.0f, acc[i][j][reg], nn);
-                lo[i][reg] = ok ? dd - band * nn : __builtin_inff();      // (+inf never passes the <= test below)
-                hmin = fminf(hmin, ok ? dd + band * nn : FLT_MAX);
-            }
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rr = wr + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    const float nn = qns[rr] + tnj;
+                    const float dd = fmaf(-2.0f, acc[i][j][reg], nn);
+                    lo[i][reg] = dd - band * nn;
+                    hmin = fminf(hmin, dd + band * nn);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rr = wr + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;      // query row inside the workgroup tile
+                    const bool ok = row0 + rr < n1;
+                    const float nn = qns[rr] + tnj;
+                    const float dd = fmaf(-2.0f, acc[i][j][reg], nn);
+                    lo[i][reg] = ok ? dd - band * nn : __builtin_inff();      // (+inf never passes the <= test below)
+                    hmin = fminf(hmin, ok ? dd + band * nn : FLT_MAX);
+                }
+        }
         hmin = fminf(hmin, __shfl_xor(hmin, 32, 64));          // over the wave tile's 64 queries of this train column
         // this lane's smallest lower bound first (slot 0), then the other candidates in register order
         float lmin = __builtin_inff();
@@ -355,22 +368,29 @@ __global__ __launch_bounds__(256) void k_bow_gemm_cand(const BowPair* __restrict
 #pragma unroll
         for (int k = 0; k < BOW_SLOTS; ++k) c[k] = BowCand{0x7f800000u, -1};
         int count = 0;
-        if (imin >= 0 && lmin <= hmin) {
-            c[0] = BowCand{__float_as_uint(lmin), row0 + wr + (imin >> 4) * 32 + (imin & 3) + 8 * ((imin & 15) >> 2) + 4 * half};
-            count = 1;
-        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                if (lo[i][reg] <= hmin && i * 16 + reg != imin) {
-                    const int qi = row0 + wr + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            for (int reg = 0; reg < 16; ++reg) count += lo[i][reg] <= hmin ? 1 : 0;
+        if (imin >= 0 && lmin <= hmin)
+            c[0] = BowCand{__float_as_uint(lmin), row0 + wr + (imin >> 4) * 32 + (imin & 3) + 8 * ((imin & 15) >> 2) + 4 * half};
+        // more than the nearest query inside the band is rare (near-ties, duplicates): only then the other candidates are
+        // put into slots 1.. in register order (a wave-uniform branch around 32 x 12 vector instructions)
+        if (__any(count > 1)) {
+            int filled = count > 0 ? 1 : 0;
 #pragma unroll
-                    for (int k = 1; k < BOW_SLOTS; ++k)
-                        if (count == k) c[k] = BowCand{__float_as_uint(lo[i][reg]), qi};
-                    ++count;
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    if (lo[i][reg] <= hmin && i * 16 + reg != imin) {
+                        const int qi = row0 + wr + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+#pragma unroll
+                        for (int k = 1; k < BOW_SLOTS; ++k)
+                            if (filled == k) c[k] = BowCand{__float_as_uint(lo[i][reg]), qi};
+                        ++filled;
+                    }
                 }
-            }
+        }
         if (tj < n2) {
             const long long hs = ((pair_rows + tj) * n_qt + qt) * 2 + half;                  // half-tile index
             BowCand* dst = cand + hs * BOW_SLOTS;
