@@ -373,7 +373,6 @@ __global__ __launch_bounds__(256, (fused2_min_blocks<STRIDE, NTO, KQT, TW>())) v
                     if (a.residual) {
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) {
-                            constexpr int dummy = 0; (void)dummy;
                             const int c = (reg & 3) + 8 * (reg >> 2), ry = c / TW, rx = c % TW;
                             const bool ok = full || (oyb + ry < lv.Ho && oxl + rx < lv.Wo);
                             rv[reg] = ok ? *(const float*)((const char*)rbase + lane_off + (unsigned)(ry * lv.Wo + rx) * cout4) : 0.0f;
@@ -517,7 +516,6 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused4(FusedArgs a, Geom g) {
 #pragma unroll
         for (int hy = 0; hy < IH; ++hy) {
             const unsigned long long bits = (iy0 + hy < 0 || iy0 + hy >= lv.H) ? full : cols;
-            constexpr int dummy = 0; (void)dummy;
             const int pos = hy * IW, wd = pos >> 6, sh = pos & 63;
             outside[wd] |= bits << sh;
             if (sh + IW > 64) outside[wd + 1] |= bits >> (64 - sh);
