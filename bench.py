@@ -6,7 +6,7 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 Headline = BASELINE config 2.  One "step" = one batch of `--batch` (768) synthetic 752x480 frames through the whole
-front end on one GPU, in chunks of `--chunk` (64) frames: 4-level pyramid (x1.2), HF-Net (MobileNetV2 backbone,
+front end on one GPU, in chunks of `--chunk` (128) frames: 4-level pyramid (x1.2), HF-Net (MobileNetV2 backbone,
 detector + descriptor heads, NetVLAD on level 0), NMS, per-level top-K (budget 322/268/224/186), bilinear descriptor
 sampling, then one SearchByBoW-style brute-force match (1000 x 1000 x 256, L2 cross-check, < 0.6) of every frame
 against its predecessor.  Inputs are resident in HBM before the timed region; outputs stay in HBM.  Frames are
@@ -665,7 +665,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=768, help="frames per step and GPU")
-    ap.add_argument("--chunk", type=int, default=64, help="frames per extract / match call (the extractor's batch)")
+    ap.add_argument("--chunk", type=int, default=128, help="frames per extract / match call (the extractor's batch)")
     ap.add_argument("--frames", choices=["uniform", "natural"], default="uniform", help="synthetic frame distribution (SURVEY.md 8d)")
     ap.add_argument("--configs", default="all", help="comma list of sub-records to measure besides the headline: " + ",".join(ALL_CONFIGS) + " | all | none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -702,7 +702,9 @@ def main() -> None:
         torch.cuda.init()
         dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1: take the process-group path with one rank too (the only way to execute the RCCL init, barrier and
+    # MAX-reduce of the N > 1 run on a one-GPU box)
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")

@@ -85,3 +85,22 @@ def test_bench_dry_ranks_runs_the_two_rank_control_flow(tmp_path):
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-ranks", "2"], env=env, capture_output=True, text=True)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_with_one_rank():
+    """the driver's launch line (torch.distributed.run, one rank per GPU) with the RCCL process group forced on for a
+    single rank: init_process_group("nccl"), the barriers, the MAX all-reduce and config 4's reductions execute on the GPU
+    (two ranks cannot share the one device of the test box)"""
+    import json
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "256",
+                        "--configs", "4", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["configs"]["4"]["frames"] == 27049
