@@ -419,6 +419,46 @@ __device__ __forceinline__ float tree256_wave(f32x4 p) {
     return a + b;
 }
 
+// Four tree256_wave sums at once (the four taps of a keypoint), same pairings and therefore the same bits: instead of every
+// lane keeping all 16 partial sums through all six butterfly steps (96 cross-lane moves), a lane hands the half of its values
+// its partner keeps to the partner and goes on with the other half (a + b == b + a bitwise, so it does not matter which of
+// the two lanes of a pair does the addition): 8 + 4 + 2 + 1 moves for the steps 32 / 16 / 8 / 4, then one value per lane for
+// the steps 2 / 1 and for (p0 + p2) + (p1 + p3), whose operands sit 8 and 4 lanes apart.  out[t] is wave-uniform.
+__device__ __forceinline__ void tree256_wave_x4(const f32x4 (&p)[4], int lane, float (&out)[4]) {
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+    float v8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                     // value index i = 4 tap + j; step 32 splits on the tap's upper bit
+        const float lo = p[k >> 2][k & 3], hi = p[2 + (k >> 2)][k & 3];
+        v8[k] = (b5 ? hi : lo) + __shfl_xor(b5 ? lo : hi, 32, 64);
+    }
+    float v4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v4[k] = (b4 ? v8[4 + k] : v8[k]) + __shfl_xor(b4 ? v8[k] : v8[4 + k], 16, 64);     // the tap's lower bit
+    float v2[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) v2[k] = (b3 ? v4[2 + k] : v4[k]) + __shfl_xor(b3 ? v4[k] : v4[2 + k], 8, 64);      // j's upper bit
+    float v = (b2 ? v2[1] : v2[0]) + __shfl_xor(b2 ? v2[0] : v2[1], 4, 64);                                       // j's lower bit
+    v = v + __shfl_xor(v, 2, 64);
+    v = v + __shfl_xor(v, 1, 64);                     // p[j] of tap (b5, b4), j = (b3, b2), summed over the wave
+    v = v + __shfl_xor(v, 8, 64);                     // p0 + p2 | p1 + p3
+    v = v + __shfl_xor(v, 4, 64);                     // (p0 + p2) + (p1 + p3)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16 * t));
+}
+// the same for the double-precision sum of cv::normalize: (p0 + p2) + (p1 + p3) of four butterfly sums, in every lane
+__device__ __forceinline__ double tree_wave_f64x4(const double (&p)[4], int lane) {
+    const bool b5 = lane & 32, b4 = lane & 16;
+    double v2[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) v2[k] = (b5 ? p[2 + k] : p[k]) + __shfl_xor(b5 ? p[k] : p[2 + k], 32, 64);
+    double v = (b4 ? v2[1] : v2[0]) + __shfl_xor(b4 ? v2[0] : v2[1], 16, 64);
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    v = v + __shfl_xor(v, 32, 64);                    // p0 + p2 | p1 + p3
+    return v + __shfl_xor(v, 16, 64);
+}
+
 __global__ __launch_bounds__(256) void k_l2norm256(const float* __restrict__ in, float* __restrict__ out, long long P) {
     const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pix >= P) return;
@@ -492,15 +532,15 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a, Geom g) {
         if (a.sparse) {
             // the rows come straight from the 1x1 conv: tf.nn.l2_normalize of each (hf_net.py:80) here instead of in a
             // separate pass over them -- same expressions as k_l2norm256 (a skipped tap stays zero)
-            auto l2n = [](f32x4& v) {
-                f32x4 sq;
+            f32x4 sq[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sq[j] = v[j] * v[j];
-                const float inv = 1.0f / sqrtf(fmaxf(tree256_wave(sq), 1e-12f));
+            for (int j = 0; j < 4; ++j) { sq[0][j] = vff[j] * vff[j]; sq[1][j] = vcc[j] * vcc[j]; sq[2][j] = vfc[j] * vfc[j]; sq[3][j] = vcf[j] * vcf[j]; }
+            float ss[4];
+            tree256_wave_x4(sq, lane, ss);
+            const float i0 = 1.0f / sqrtf(fmaxf(ss[0], 1e-12f)), i1 = 1.0f / sqrtf(fmaxf(ss[1], 1e-12f));
+            const float i2 = 1.0f / sqrtf(fmaxf(ss[2], 1e-12f)), i3 = 1.0f / sqrtf(fmaxf(ss[3], 1e-12f));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = v[j] * inv;
-            };
-            l2n(vff); l2n(vcc); l2n(vfc); l2n(vcf);
+            for (int j = 0; j < 4; ++j) { vff[j] = vff[j] * i0; vcc[j] = vcc[j] * i1; vfc[j] = vfc[j] * i2; vcf[j] = vcf[j] * i3; }
         } else {
             const float* d = a.desc_map + (lv.in_off + (long long)frame * dh * dw) * 256 + lane * 4;
             vff = (fxin && fyin) ? *(const f32x4*)(d + (long long)(fy * dw + fx) * 256) : zero;
@@ -518,12 +558,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a, Geom g) {
     double p[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[j] = (double)o[j] * (double)o[j];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) p[j] = p[j] + __shfl_xor(p[j], off, 64);
-    }
-    const double ssum = (p[0] + p[2]) + (p[1] + p[3]);
+    const double ssum = tree_wave_f64x4(p, lane);
     const double nrm = sqrt(ssum);
     const float sc = (float)(nrm > DBL_EPSILON ? 1.0 / nrm : 0.0);
     f32x4 r;
