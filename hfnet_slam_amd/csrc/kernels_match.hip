@@ -15,6 +15,17 @@ namespace hfnet {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// global-address-space loads through a scalar base + 32-bit lane offset (as kernels_block.hip): the operand pointers of the
+// GEMMs below come out of a descriptor in memory, so plain loads through them are FLAT loads with 64-bit vector addresses
+typedef const __attribute__((address_space(1))) char* gbase_t;
+typedef const __attribute__((address_space(1))) f32x4* gvec4_t;
+__device__ __forceinline__ gbase_t sgpr_base(const void* base, unsigned uniform_bytes) {
+    gbase_t p = (gbase_t)(const char*)base + uniform_bytes;
+    asm("" : "+s"(p));
+    return p;
+}
+// a lane offset re-"defined" where it is used (hoisted out of a loop it is widened to 64 bits and every load pays a 64-bit vector add)
+__device__ __forceinline__ unsigned fresh(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 
 // =========================================================================== SearchForTriangulation
 // S = D1 * D2^T on v_mfma_f32_32x32x2_f32 -- each accumulator is the fused multiply-add chain over k = 0, 1, 2, ... (the
@@ -47,11 +58,11 @@ __global__ __launch_bounds__(256) void k_tri_gemm_argmax(const BowPair* __restri
     const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
     // staging: 16 threads cover the 256 contiguous bytes of a row chunk; a thread handles rows (tid / 16) * 8 + j
     const int lc = tid & 15, lrow = (tid >> 4) * 8;
-    long long aoff[8], boff[8];
+    unsigned aoff[8], boff[8];                                // byte offsets of this thread's eight row pieces (sets stay below 4 GB: launch check)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        aoff[j] = (long long)min(row0 + lrow + j, n1 - 1) * dim + lc * 4;
-        boff[j] = (long long)min(col0 + lrow + j, n2 - 1) * dim + lc * 4;
+        aoff[j] = ((unsigned)min(row0 + lrow + j, n1 - 1) * (unsigned)dim + (unsigned)lc * 4u) * 4u;
+        boff[j] = ((unsigned)min(col0 + lrow + j, n2 - 1) * (unsigned)dim + (unsigned)lc * 4u) * 4u;
     }
     f32x16 acc[2][2];
 #pragma unroll
@@ -62,7 +73,7 @@ __global__ __launch_bounds__(256) void k_tri_gemm_argmax(const BowPair* __restri
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     f32x4 sa[8], sb[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sa[j] = *(const f32x4*)(d1 + aoff[j]); sb[j] = *(const f32x4*)(d2 + boff[j]); }
+    for (int j = 0; j < 8; ++j) { sa[j] = *(gvec4_t)(sgpr_base(d1, 0) + aoff[j]); sb[j] = *(gvec4_t)(sgpr_base(d2, 0) + boff[j]); }
     for (int k0 = 0; k0 < dim; k0 += 64) {
         __syncthreads();                                     // previous chunk fully consumed
 #pragma unroll
@@ -73,9 +84,13 @@ __global__ __launch_bounds__(256) void k_tri_gemm_argmax(const BowPair* __restri
             *(float2*)(bp) = float2{sb[j][0], sb[j][2]}; *(float2*)(bp + 32) = float2{sb[j][1], sb[j][3]};
         }
         __syncthreads();
-        if (k0 + 64 < dim) {
+        {   // the next chunk's pieces, unconditionally (the last pass re-reads its own chunk: a branch around the loads makes the
+            // compiler wait for them and copy them right here, in front of the MFMAs they are meant to hide behind)
+            const unsigned kn = (unsigned)min(k0 + 64, dim - 64) * 4u;
+            const gbase_t pa = sgpr_base(d1, kn), pb = sgpr_base(d2, kn);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { sa[j] = *(const f32x4*)(d1 + aoff[j] + k0 + 64); sb[j] = *(const f32x4*)(d2 + boff[j] + k0 + 64); }
+            for (int j = 0; j < 8; ++j) { sa[j] = *(gvec4_t)(pa + fresh(aoff[j])); sb[j] = *(gvec4_t)(pb + fresh(boff[j])); }
+            __builtin_amdgcn_sched_barrier(0);                // (left alone the scheduler sinks them below the MFMAs: nobody needs them before the next pass)
         }
         const float* ap = As + (wr + r) * LD + half * 32;
         const float* bp = Bs + (wc + r) * LD + half * 32;
@@ -182,7 +197,7 @@ __global__ __launch_bounds__(256) void k_tri_rows(const BowPair* __restrict__ pa
 }
 hipError_t launch_tri_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float threshold, hipStream_t s) {
     if (n_pairs <= 0 || max_rows <= 0) return hipSuccess;
-    if (dim % 64) return hipErrorInvalidValue;
+    if (dim % 64 || (long long)max_rows * dim * 4 >= (1ll << 32)) return hipErrorInvalidValue;   // (32-bit lane offsets inside a descriptor set)
     hipLaunchKernelGGL(k_tri_gemm_argmax, dim3((max_rows + 127) / 128, (max_rows + 127) / 128, n_pairs), dim3(256), 0, s, pairs, dim, max_rows);
     hipLaunchKernelGGL(k_tri_cols, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, threshold, max_rows);
     hipLaunchKernelGGL(k_tri_rows, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, threshold, max_rows);
@@ -272,11 +287,11 @@ __global__ __launch_bounds__(256) void k_bow_gemm_cand(const BowPair* __restrict
     if (row0 >= n1 || col0 >= n2) return;                     // workgroup-uniform
     const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
     const int lc = tid & 15, lrow = (tid >> 4) * 8;
-    long long aoff[8], boff[8];
+    unsigned aoff[8], boff[8];                                // byte offsets of this thread's eight row pieces (sets stay below 4 GB: launch check)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        aoff[j] = (long long)min(row0 + lrow + j, n1 - 1) * dim + lc * 4;
-        boff[j] = (long long)min(col0 + lrow + j, n2 - 1) * dim + lc * 4;
+        aoff[j] = ((unsigned)min(row0 + lrow + j, n1 - 1) * (unsigned)dim + (unsigned)lc * 4u) * 4u;
+        boff[j] = ((unsigned)min(col0 + lrow + j, n2 - 1) * (unsigned)dim + (unsigned)lc * 4u) * 4u;
     }
     f32x16 acc[2][2];
 #pragma unroll
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(256) void k_bow_gemm_cand(const BowPair* __restrict
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     f32x4 sa[8], sb[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sa[j] = *(const f32x4*)(d1 + aoff[j]); sb[j] = *(const f32x4*)(d2 + boff[j]); }
+    for (int j = 0; j < 8; ++j) { sa[j] = *(gvec4_t)(sgpr_base(d1, 0) + aoff[j]); sb[j] = *(gvec4_t)(sgpr_base(d2, 0) + boff[j]); }
     for (int k0 = 0; k0 < dim; k0 += 64) {
         __syncthreads();                                     // previous chunk fully consumed
 #pragma unroll
@@ -298,9 +313,13 @@ __global__ __launch_bounds__(256) void k_bow_gemm_cand(const BowPair* __restrict
             *(float2*)(bp) = float2{sb[j][0], sb[j][2]}; *(float2*)(bp + 32) = float2{sb[j][1], sb[j][3]};
         }
         __syncthreads();
-        if (k0 + 64 < dim) {
+        {   // the next chunk's pieces, unconditionally (the last pass re-reads its own chunk: a branch around the loads makes the
+            // compiler wait for them and copy them right here, in front of the MFMAs they are meant to hide behind)
+            const unsigned kn = (unsigned)min(k0 + 64, dim - 64) * 4u;
+            const gbase_t pa = sgpr_base(d1, kn), pb = sgpr_base(d2, kn);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { sa[j] = *(const f32x4*)(d1 + aoff[j] + k0 + 64); sb[j] = *(const f32x4*)(d2 + boff[j] + k0 + 64); }
+            for (int j = 0; j < 8; ++j) { sa[j] = *(gvec4_t)(pa + fresh(aoff[j])); sb[j] = *(gvec4_t)(pb + fresh(boff[j])); }
+            __builtin_amdgcn_sched_barrier(0);                // (left alone the scheduler sinks them below the MFMAs: nobody needs them before the next pass)
         }
         const float* ap = As + (wr + r) * LD + half * 32;
         const float* bp = Bs + (wc + r) * LD + half * 32;
@@ -463,6 +482,103 @@ __global__ __launch_bounds__(256) void k_bow_candidates(const BowPair* __restric
     }
     if (lane == 0 && bi != 0x7fffffff)
         atomicMin(&P.qkey[bi], ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned int)j);
+}
+
+// dim == 256: the same selection with the exact distances evaluated in batches.  cv_l2_wave256 ends in a 64-step serial sum
+// (OpenCV's accumulation order over the 64 groups of four) that one wave pays per candidate; here a wave owns BOWC_ROWS
+// consecutive train rows, every candidate's 64 group sums go into a wave-private LDS row (coalesced row loads, no waiting
+// between candidates), and once BOWC_EVALS of them are pending lane e adds up candidate e's row in the same order -- 64
+// serial sums side by side.  Per train row the nearest (distance, then query index) is kept by an LDS atomic minimum on the
+// packed key.  Same expressions, same order, same bits as k_bow_candidates.
+#define BOWC_ROWS 8
+#define BOWC_EVALS 32
+__global__ __launch_bounds__(256) void k_bow_candidates256(const BowPair* __restrict__ pairs, float band, const BowCand* __restrict__ cand,
+                                                           const unsigned char* __restrict__ overflow, int max_rows, int n_qt) {
+    constexpr int dim = 256, GP = 65;
+    __shared__ float gs_all[4][BOWC_EVALS * GP];
+    __shared__ int meta_q_all[4][BOWC_EVALS], meta_r_all[4][BOWC_EVALS];
+    __shared__ unsigned long long rowkey_all[4][BOWC_ROWS];
+    const BowPair P = pairs[blockIdx.z];
+    const float* __restrict__ q = P.q; const float* __restrict__ t = P.t;
+    const int nq = P.nq, nt = P.nt;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j0 = (blockIdx.x * 4 + wave) * BOWC_ROWS;
+    if (j0 >= nt || nq <= 0) return;                          // (wave-uniform; the LDS below is wave-private: no workgroup barrier anywhere)
+    float* gs = gs_all[wave];
+    int* meta_q = meta_q_all[wave]; int* meta_r = meta_r_all[wave];
+    unsigned long long* rowkey = rowkey_all[wave];
+    if (lane < BOWC_ROWS) rowkey[lane] = ~0ull;
+    int E = 0;                                                // pending evaluations (uniform)
+    auto flush = [&]() {
+        asm volatile("" ::: "memory");                        // (LDS operations of one wave execute in order)
+        float s = 0.0f;
+        const float* gp = gs + min(lane, BOWC_EVALS - 1) * GP;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) s += gp[i];
+        if (lane < E) {
+            const float d = sqrtf(s);
+            atomicMin(&rowkey[meta_r[lane]], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)meta_q[lane]);
+        }
+        asm volatile("" ::: "memory");
+        E = 0;
+    };
+    const int live_halves = ((nq + 63) >> 6) * 2, n_live = live_halves * BOW_SLOTS;
+    const int rows_here = min(BOWC_ROWS, nt - j0);
+    for (int rl = 0; rl < rows_here; ++rl) {
+        const int j = j0 + rl;
+        const long long prow = (long long)blockIdx.z * max_rows + j;
+        const f32x4 tv = *(const f32x4*)(t + (long long)j * dim + lane * 4);
+        const float tnj = P.tn[j];
+        auto enqueue = [&](int qi) {
+            const f32x4 bv = *(const f32x4*)(q + (long long)qi * dim + lane * 4);
+            const float v0 = tv[0] - bv[0], v1 = tv[1] - bv[1], v2 = tv[2] - bv[2], v3 = tv[3] - bv[3];
+            gs[E * GP + lane] = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+            if (lane == 0) { meta_q[E] = qi; meta_r[E] = rl; }
+            if (++E == BOWC_EVALS) flush();
+        };
+        const BowCand* __restrict__ slots = cand + prow * n_qt * 2 * BOW_SLOTS;
+        const unsigned char* __restrict__ counts = overflow + prow * n_qt * 2;
+        float umin = FLT_MAX;                                 // (as k_bow_candidates)
+        for (int h0 = 0; h0 < live_halves; h0 += 64) {
+            const int hh = h0 + lane;
+            if (hh < live_halves) {
+                const BowCand c = slots[hh * BOW_SLOTS];
+                if (c.q >= 0) umin = fminf(umin, __uint_as_float(c.lo_bits) + 2.5f * band * (P.qn[c.q] + tnj));
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) umin = fminf(umin, __shfl_xor(umin, off, 64));
+        for (int h0 = 0; h0 < live_halves; h0 += 64) {
+            const int hh = h0 + lane;
+            bool over = false;
+            if (hh < live_halves) over = counts[hh] > BOW_SLOTS && __uint_as_float(slots[hh * BOW_SLOTS].lo_bits) <= umin;
+            unsigned long long mask = __ballot(over);
+            while (mask) {
+                const int b = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int hb = h0 + b, q0 = (hb >> 1) * 64 + (hb & 1) * 4;
+                for (int k = 0; k < 8; ++k)
+                    for (int e = 0; e < 4; ++e) { const int qi = q0 + 8 * k + e; if (qi < nq) enqueue(qi); }
+            }
+        }
+        for (int s0 = 0; s0 < n_live; s0 += 64) {
+            const int sl = s0 + lane;
+            BowCand c = {0x7f800000u, -1};
+            if (sl < n_live) c = slots[sl];
+            unsigned long long mask = __ballot(c.q >= 0 && __uint_as_float(c.lo_bits) <= umin);
+            while (mask) {
+                const int b = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                enqueue(__shfl(c.q, b, 64));
+            }
+        }
+    }
+    if (E > 0) flush();
+    asm volatile("" ::: "memory");
+    if (lane < rows_here) {
+        const unsigned long long k = rowkey[lane];
+        if (k != ~0ull) atomicMin(&P.qkey[(unsigned int)k], (k & 0xffffffff00000000ull) | (unsigned int)(j0 + lane));
+    }
 }
 
 __global__ __launch_bounds__(256) void k_bow_finalize(const BowPair* __restrict__ pairs, float th_low) {
@@ -634,7 +750,7 @@ size_t bow_scratch_bytes(int n_pairs, int max_rows) {
 
 hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, void* scratch, hipStream_t s) {
     if (n_pairs <= 0 || max_rows <= 0) return hipSuccess;
-    if (dim % 64) return hipErrorInvalidValue;
+    if (dim % 64 || (long long)max_rows * dim * 4 >= (1ll << 32)) return hipErrorInvalidValue;   // (32-bit lane offsets inside a descriptor set)
     // G = |q|^2 + |t|^2 - 2 q.t (norms and the MFMA chain in fp32) against the exactly evaluated form X (OpenCV's order): with
     // u = 2^-24 and g = dim u (the bound of a dim-term fp32 sum),  |G - d^2| <= (2 g + 2 u)(|q|^2 + |t|^2)  (two norms, the dot
     // product bounded by half the norms, two roundings) and  |X - d^2| <= g d^2 <= 2 g (|q|^2 + |t|^2):  together
@@ -648,7 +764,10 @@ hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int
     hipLaunchKernelGGL(k_bow_prep, dim3((2 * max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim);
     hipLaunchKernelGGL(k_bow_gemm_cand, dim3((max_rows + 127) / 128, (max_rows + 127) / 128, n_pairs), dim3(256), 0, s, pairs, dim, band, cand, overflow,
                        max_rows, n_qt);
-    hipLaunchKernelGGL(k_bow_candidates, dim3((max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim, band, cand, overflow, max_rows, n_qt);
+    if (dim == 256)
+        hipLaunchKernelGGL(k_bow_candidates256, dim3((max_rows + 4 * BOWC_ROWS - 1) / (4 * BOWC_ROWS), 1, n_pairs), dim3(256), 0, s, pairs, band, cand, overflow, max_rows, n_qt);
+    else
+        hipLaunchKernelGGL(k_bow_candidates, dim3((max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim, band, cand, overflow, max_rows, n_qt);
     hipLaunchKernelGGL(k_bow_finalize, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, th_low);
     return hipGetLastError();
 }
@@ -877,12 +996,14 @@ __global__ __launch_bounds__(256) void k_db_gemm(const float* __restrict__ q, in
     const int m0 = blockIdx.x * 128, part = blockIdx.y;
     const int kw = dim / DBG_PARTS, kbase = part * kw;
     const int lc = tid & 15, arow = (tid >> 4) * 8, brow = (tid >> 4) * (NT * 2);
-    const float* ag[8];
-    const float* bg[NT * 2];
+    // (the database can exceed 4 GB: the workgroup's first row goes into the scalar base, lane offsets stay 32-bit)
+    const float* dbase = db + (long long)m0 * dim + kbase;
+    const float* qbase = q + (long long)q0 * dim + kbase;
+    unsigned ag[8], bg[NT * 2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ag[j] = db + (long long)min(m0 + arow + j, n - 1) * dim + kbase + lc * 4;
+    for (int j = 0; j < 8; ++j) ag[j] = ((unsigned)min(arow + j, n - 1 - m0) * (unsigned)dim + (unsigned)lc * 4u) * 4u;
 #pragma unroll
-    for (int j = 0; j < NT * 2; ++j) bg[j] = q + (long long)min(q0 + brow + j, n_queries - 1) * dim + kbase + lc * 4;
+    for (int j = 0; j < NT * 2; ++j) bg[j] = ((unsigned)min(brow + j, n_queries - 1 - q0) * (unsigned)dim + (unsigned)lc * 4u) * 4u;
     f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -890,9 +1011,9 @@ __global__ __launch_bounds__(256) void k_db_gemm(const float* __restrict__ q, in
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
     f32x4 sa[8], sb[NT * 2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sa[j] = *(const f32x4*)(ag[j]);
+    for (int j = 0; j < 8; ++j) sa[j] = *(gvec4_t)(sgpr_base(dbase, 0) + ag[j]);
 #pragma unroll
-    for (int j = 0; j < NT * 2; ++j) sb[j] = *(const f32x4*)(bg[j]);
+    for (int j = 0; j < NT * 2; ++j) sb[j] = *(gvec4_t)(sgpr_base(qbase, 0) + bg[j]);
     for (int k0 = 0; k0 < kw; k0 += 64) {
         __syncthreads();                                     // previous chunk fully consumed
 #pragma unroll
@@ -906,11 +1027,14 @@ __global__ __launch_bounds__(256) void k_db_gemm(const float* __restrict__ q, in
             *(float2*)(bp) = float2{sb[j][0], sb[j][2]}; *(float2*)(bp + 32) = float2{sb[j][1], sb[j][3]};
         }
         __syncthreads();
-        if (k0 + 64 < kw) {
+        {   // (unconditional: see k_tri_gemm_argmax)
+            const unsigned kn = (unsigned)min(k0 + 64, kw - 64) * 4u;
+            const gbase_t pa = sgpr_base(dbase, kn), pb = sgpr_base(qbase, kn);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sa[j] = *(const f32x4*)(ag[j] + k0 + 64);
+            for (int j = 0; j < 8; ++j) sa[j] = *(gvec4_t)(pa + fresh(ag[j]));
 #pragma unroll
-            for (int j = 0; j < NT * 2; ++j) sb[j] = *(const f32x4*)(bg[j] + k0 + 64);
+            for (int j = 0; j < NT * 2; ++j) sb[j] = *(gvec4_t)(pb + fresh(bg[j]));
+            __builtin_amdgcn_sched_barrier(0);
         }
         const float* ap = As + (wave * 32 + r) * LD + half * 32;
         const float* bp = Bs + r * LD + half * 32;
