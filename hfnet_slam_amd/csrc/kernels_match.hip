@@ -274,25 +274,29 @@ __device__ float cv_l2_wave(const float* a, const float* b, int dim, int lane) {
 // of that half tile exactly -- if its smallest lower bound can compete at all.
 struct BowCand { unsigned int lo_bits; int q; };
 #define BOW_SLOTS 4
-__global__ __launch_bounds__(256) void k_bow_gemm_cand(const BowPair* __restrict__ pairs, int dim, float band, BowCand* __restrict__ cand,
-                                                       unsigned char* __restrict__ overflow, int max_rows, int n_qt) {
+__global__ __launch_bounds__(256, 2) void k_bow_gemm_cand(const BowPair* __restrict__ pairs, int dim, float band, BowCand* __restrict__ cand,
+                                                       unsigned char* __restrict__ overflow, int max_rows, int n_qt, int ct) {
+    // A workgroup owns 128 queries and `ct` consecutive 128-row tiles of train rows: the k chunks of all its tiles are ONE
+    // software pipeline (the first chunk of the next tile is in flight during the last MFMAs and the epilogue of this one), so
+    // the load latency at the start of a tile -- 18 % of a 1000 x 1000 x 256 pair when every tile was its own workgroup -- is
+    // paid once per workgroup.  ct = 1 for launches that would not fill the chip otherwise (single pairs).
     const BowPair P = pairs[blockIdx.z];
     const float* __restrict__ d1 = P.q; const float* __restrict__ d2 = P.t;
     const int n1 = P.nq, n2 = P.nt;
     constexpr int LD = 68;
     __shared__ __attribute__((aligned(16))) float As[128 * LD];
     __shared__ __attribute__((aligned(16))) float Bs[128 * LD];
+    __shared__ float qns[128];                                // |q|^2 of the workgroup's queries
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
-    const int row0 = blockIdx.y * 128, col0 = blockIdx.x * 128;
-    if (row0 >= n1 || col0 >= n2) return;                     // workgroup-uniform
+    const int row0 = blockIdx.y * 128, ctile0 = blockIdx.x * ct;
+    if (row0 >= n1 || ctile0 * 128 >= n2) return;             // workgroup-uniform
+    const int n_ct = min(ct, (n2 - ctile0 * 128 + 127) >> 7); // column tiles of this workgroup that exist
     const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
     const int lc = tid & 15, lrow = (tid >> 4) * 8;
-    unsigned aoff[8], boff[8];                                // byte offsets of this thread's eight row pieces (sets stay below 4 GB: launch check)
+    unsigned aoff[8];                                         // byte offsets of this thread's eight row pieces (sets stay below 4 GB: launch check)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        aoff[j] = ((unsigned)min(row0 + lrow + j, n1 - 1) * (unsigned)dim + (unsigned)lc * 4u) * 4u;
-        boff[j] = ((unsigned)min(col0 + lrow + j, n2 - 1) * (unsigned)dim + (unsigned)lc * 4u) * 4u;
-    }
+    for (int j = 0; j < 8; ++j) aoff[j] = ((unsigned)min(row0 + lrow + j, n1 - 1) * (unsigned)dim + (unsigned)lc * 4u) * 4u;
+    if (tid < 128) qns[tid] = row0 + tid < n1 ? P.qn[row0 + tid] : 0.0f;      // (read after the first barrier of the chunk loop)
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -301,9 +305,22 @@ __global__ __launch_bounds__(256) void k_bow_gemm_cand(const BowPair* __restrict
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     f32x4 sa[8], sb[8];
+    const int KC = dim >> 6, n_chunks = n_ct * KC;            // chunks of 64 k per tile / of the workgroup
+    auto fetch = [&](int c) {                                 // chunk c of the workgroup's pipeline -> staging registers
+        const int tile = c / KC, kc = c - tile * KC;          // uniform
+        const unsigned kb = (unsigned)kc * 256u;
+        const gbase_t pa = sgpr_base(d1, kb), pb = sgpr_base(d2, kb);
+        const int c0 = (ctile0 + tile) * 128 + lrow;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sa[j] = *(gvec4_t)(sgpr_base(d1, 0) + aoff[j]); sb[j] = *(gvec4_t)(sgpr_base(d2, 0) + boff[j]); }
-    for (int k0 = 0; k0 < dim; k0 += 64) {
+        for (int j = 0; j < 8; ++j) {
+            sa[j] = *(gvec4_t)(pa + fresh(aoff[j]));
+            sb[j] = *(gvec4_t)(pb + ((unsigned)min(c0 + j, n2 - 1) * (unsigned)dim + (unsigned)lc * 4u) * 4u);
+        }
+    };
+    fetch(0);
+    const long long pair_rows = (long long)blockIdx.z * max_rows;
+    const int qt = (row0 + wr) >> 6;                          // 64-query tile index of this wave
+    for (int c = 0; c < n_chunks; ++c) {
         __syncthreads();                                     // previous chunk fully consumed
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -313,14 +330,10 @@ __global__ __launch_bounds__(256) void k_bow_gemm_cand(const BowPair* __restrict
             *(float2*)(bp) = float2{sb[j][0], sb[j][2]}; *(float2*)(bp + 32) = float2{sb[j][1], sb[j][3]};
         }
         __syncthreads();
-        {   // the next chunk's pieces, unconditionally (the last pass re-reads its own chunk: a branch around the loads makes the
-            // compiler wait for them and copy them right here, in front of the MFMAs they are meant to hide behind)
-            const unsigned kn = (unsigned)min(k0 + 64, dim - 64) * 4u;
-            const gbase_t pa = sgpr_base(d1, kn), pb = sgpr_base(d2, kn);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { sa[j] = *(gvec4_t)(pa + fresh(aoff[j])); sb[j] = *(gvec4_t)(pb + fresh(boff[j])); }
-            __builtin_amdgcn_sched_barrier(0);                // (left alone the scheduler sinks them below the MFMAs: nobody needs them before the next pass)
-        }
+        // the next chunk's pieces, unconditionally (the last pass re-reads its own chunk: a branch around the loads makes the
+        // compiler wait for them and copy them right here, in front of the MFMAs they are meant to hide behind)
+        fetch(min(c + 1, n_chunks - 1));
+        __builtin_amdgcn_sched_barrier(0);                    // (left alone the scheduler sinks them below the MFMAs: nobody needs them before the next pass)
         const float* ap = As + (wr + r) * LD + half * 32;
         const float* bp = Bs + (wc + r) * LD + half * 32;
 #pragma unroll
@@ -335,88 +348,91 @@ __global__ __launch_bounds__(256) void k_bow_gemm_cand(const BowPair* __restrict
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
             }
         }
-    }
-    // ---- epilogue: the |q|^2 of the workgroup's 128 queries through LDS, then bounds and candidates per train column
-    __syncthreads();
-    float* qns = As;                                          // [128]
-    if (tid < 128) qns[tid] = row0 + tid < n1 ? P.qn[row0 + tid] : 0.0f;
-    __syncthreads();
-    const long long pair_rows = (long long)blockIdx.z * max_rows;
-    const int qt = (row0 + wr) >> 6;                          // 64-query tile index of this wave
-    if (row0 + wr >= n1) return;                              // (wave-uniform, no barrier below) a tile past the last query has no slots
+        const int tile = c / KC;
+        if (c - tile * KC != KC - 1) continue;                // (uniform) the tile's last chunk: bounds and candidates per train column
+        const int col0 = (ctile0 + tile) * 128;
+        if (row0 + wr < n1) {                                 // (wave-uniform) a tile past the last query has no slots
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int tj = col0 + wc + j * 32 + r;
-        const float tnj = P.tn[min(tj, n2 - 1)];
-        float lo[2][16];
-        float hmin = FLT_MAX;
-        if (row0 + 128 <= n1) {                                // (workgroup-uniform) every query row of the tile exists: no selects
+            for (int j = 0; j < 2; ++j) {
+                const int tj = col0 + wc + j * 32 + r;
+                const float tnj = P.tn[min(tj, n2 - 1)];
+                float lo[2][16];
+                float hmin = FLT_MAX;
+                if (row0 + 128 <= n1) {                        // (workgroup-uniform) every query row of the tile exists: no selects
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int rr = wr + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                    const float nn = qns[rr] + tnj;
-                    const float dd = fmaf(-2.0f, acc[i][j][reg], nn);
-                    lo[i][reg] = dd - band * nn;
-                    hmin = fminf(hmin, dd + band * nn);
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int rr = wr + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                            const float nn = qns[rr] + tnj;
+                            const float dd = fmaf(-2.0f, acc[i][j][reg], nn);
+                            lo[i][reg] = dd - band * nn;
+                            hmin = fminf(hmin, dd + band * nn);
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int rr = wr + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;      // query row inside the workgroup tile
+                            const bool ok = row0 + rr < n1;
+                            const float nn = qns[rr] + tnj;
+                            const float dd = fmaf(-2.0f, acc[i][j][reg], nn);
+                            lo[i][reg] = ok ? dd - band * nn : __builtin_inff();      // (+inf never passes the <= test below)
+                            hmin = fminf(hmin, ok ? dd + band * nn : FLT_MAX);
+                        }
                 }
-        } else {
+                hmin = fminf(hmin, __shfl_xor(hmin, 32, 64));          // over the wave tile's 64 queries of this train column
+                // this lane's smallest lower bound first (slot 0), then the other candidates in register order
+                float lmin = __builtin_inff();
+                int imin = -1;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int rr = wr + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;      // query row inside the workgroup tile
-                    const bool ok = row0 + rr < n1;
-                    const float nn = qns[rr] + tnj;
-                    const float dd = fmaf(-2.0f, acc[i][j][reg], nn);
-                    lo[i][reg] = ok ? dd - band * nn : __builtin_inff();      // (+inf never passes the <= test below)
-                    hmin = fminf(hmin, ok ? dd + band * nn : FLT_MAX);
+                    for (int reg = 0; reg < 16; ++reg)
+                        if (lo[i][reg] < lmin) { lmin = lo[i][reg]; imin = i * 16 + reg; }
+                BowCand cs[BOW_SLOTS];
+#pragma unroll
+                for (int k = 0; k < BOW_SLOTS; ++k) cs[k] = BowCand{0x7f800000u, -1};
+                int count = 0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) count += lo[i][reg] <= hmin ? 1 : 0;
+                if (imin >= 0 && lmin <= hmin)
+                    cs[0] = BowCand{__float_as_uint(lmin), row0 + wr + (imin >> 4) * 32 + (imin & 3) + 8 * ((imin & 15) >> 2) + 4 * half};
+                // more than the nearest query inside the band is rare (near-ties, duplicates): only then the other candidates are
+                // put into slots 1.. in register order (a wave-uniform branch around 32 x 12 vector instructions)
+                if (__any(count > 1)) {
+                    int filled = count > 0 ? 1 : 0;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            if (lo[i][reg] <= hmin && i * 16 + reg != imin) {
+                                const int qi = row0 + wr + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+#pragma unroll
+                                for (int k = 1; k < BOW_SLOTS; ++k)
+                                    if (filled == k) cs[k] = BowCand{__float_as_uint(lo[i][reg]), qi};
+                                ++filled;
+                            }
+                        }
                 }
+                if (tj < n2) {
+                    const long long hs = ((pair_rows + tj) * n_qt + qt) * 2 + half;                  // half-tile index
+                    BowCand* dst = cand + hs * BOW_SLOTS;
+#pragma unroll
+                    for (int k = 0; k < BOW_SLOTS; ++k) dst[k] = cs[k];
+                    overflow[hs] = (unsigned char)min(count, 255);
+                }
+            }
         }
-        hmin = fminf(hmin, __shfl_xor(hmin, 32, 64));          // over the wave tile's 64 queries of this train column
-        // this lane's smallest lower bound first (slot 0), then the other candidates in register order
-        float lmin = __builtin_inff();
-        int imin = -1;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg)
-                if (lo[i][reg] < lmin) { lmin = lo[i][reg]; imin = i * 16 + reg; }
-        BowCand c[BOW_SLOTS];
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int k = 0; k < BOW_SLOTS; ++k) c[k] = BowCand{0x7f800000u, -1};
-        int count = 0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) count += lo[i][reg] <= hmin ? 1 : 0;
-        if (imin >= 0 && lmin <= hmin)
-            c[0] = BowCand{__float_as_uint(lmin), row0 + wr + (imin >> 4) * 32 + (imin & 3) + 8 * ((imin & 15) >> 2) + 4 * half};
-        // more than the nearest query inside the band is rare (near-ties, duplicates): only then the other candidates are
-        // put into slots 1.. in register order (a wave-uniform branch around 32 x 12 vector instructions)
-        if (__any(count > 1)) {
-            int filled = count > 0 ? 1 : 0;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    if (lo[i][reg] <= hmin && i * 16 + reg != imin) {
-                        const int qi = row0 + wr + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-#pragma unroll
-                        for (int k = 1; k < BOW_SLOTS; ++k)
-                            if (filled == k) c[k] = BowCand{__float_as_uint(lo[i][reg]), qi};
-                        ++filled;
-                    }
-                }
-        }
-        if (tj < n2) {
-            const long long hs = ((pair_rows + tj) * n_qt + qt) * 2 + half;                  // half-tile index
-            BowCand* dst = cand + hs * BOW_SLOTS;
-#pragma unroll
-            for (int k = 0; k < BOW_SLOTS; ++k) dst[k] = c[k];
-            overflow[hs] = (unsigned char)min(count, 255);
-        }
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     }
 }
 
@@ -762,8 +778,12 @@ hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int
     BowCand* cand = (BowCand*)scratch;
     unsigned char* overflow = (unsigned char*)scratch + (size_t)n_pairs * max_rows * n_qt * 2 * BOW_SLOTS * sizeof(BowCand);   // candidate counts per half tile
     hipLaunchKernelGGL(k_bow_prep, dim3((2 * max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim);
-    hipLaunchKernelGGL(k_bow_gemm_cand, dim3((max_rows + 127) / 128, (max_rows + 127) / 128, n_pairs), dim3(256), 0, s, pairs, dim, band, cand, overflow,
-                       max_rows, n_qt);
+    // column tiles per workgroup: as many (up to 4) as still leave the launch two workgroups per CU
+    const int t128 = (max_rows + 127) / 128;
+    int ct = 1;
+    while (ct < 4 && ct * 2 <= t128 && (long long)((t128 + 2 * ct - 1) / (2 * ct)) * t128 * n_pairs >= 512) ct *= 2;
+    hipLaunchKernelGGL(k_bow_gemm_cand, dim3((t128 + ct - 1) / ct, t128, n_pairs), dim3(256), 0, s, pairs, dim, band, cand, overflow,
+                       max_rows, n_qt, ct);
     if (dim == 256)
         hipLaunchKernelGGL(k_bow_candidates256, dim3((max_rows + 4 * BOWC_ROWS - 1) / (4 * BOWC_ROWS), 1, n_pairs), dim3(256), 0, s, pairs, band, cand, overflow, max_rows, n_qt);
     else
