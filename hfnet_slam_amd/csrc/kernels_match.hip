@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void k_bow_candidates(const BowPair* __restric
 #define BOWC_ROWS 8
 #define BOWC_EVALS 32
 __global__ __launch_bounds__(256) void k_bow_candidates256(const BowPair* __restrict__ pairs, float band, const BowCand* __restrict__ cand,
-                                                           const unsigned char* __restrict__ overflow, int max_rows, int n_qt) {
+                                                           const unsigned char* __restrict__ overflow, int max_rows, int n_qt, int rows_per_wave) {
     constexpr int dim = 256, GP = 65;
     __shared__ float gs_all[4][BOWC_EVALS * GP];
     __shared__ int meta_q_all[4][BOWC_EVALS], meta_r_all[4][BOWC_EVALS];
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void k_bow_candidates256(const BowPair* __rest
     const float* __restrict__ q = P.q; const float* __restrict__ t = P.t;
     const int nq = P.nq, nt = P.nt;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j0 = (blockIdx.x * 4 + wave) * BOWC_ROWS;
+    const int j0 = (blockIdx.x * 4 + wave) * rows_per_wave;   // (rows_per_wave <= BOWC_ROWS: fewer for launches of few pairs, which need the waves)
     if (j0 >= nt || nq <= 0) return;                          // (wave-uniform; the LDS below is wave-private: no workgroup barrier anywhere)
     float* gs = gs_all[wave];
     int* meta_q = meta_q_all[wave]; int* meta_r = meta_r_all[wave];
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void k_bow_candidates256(const BowPair* __rest
         E = 0;
     };
     const int live_halves = ((nq + 63) >> 6) * 2, n_live = live_halves * BOW_SLOTS;
-    const int rows_here = min(BOWC_ROWS, nt - j0);
+    const int rows_here = min(rows_per_wave, nt - j0);
     for (int rl = 0; rl < rows_here; ++rl) {
         const int j = j0 + rl;
         const long long prow = (long long)blockIdx.z * max_rows + j;
@@ -784,8 +784,11 @@ hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int
     while (ct < 4 && ct * 2 <= t128 && (long long)((t128 + 2 * ct - 1) / (2 * ct)) * t128 * n_pairs >= 512) ct *= 2;
     hipLaunchKernelGGL(k_bow_gemm_cand, dim3((t128 + ct - 1) / ct, t128, n_pairs), dim3(256), 0, s, pairs, dim, band, cand, overflow,
                        max_rows, n_qt, ct);
-    if (dim == 256)
-        hipLaunchKernelGGL(k_bow_candidates256, dim3((max_rows + 4 * BOWC_ROWS - 1) / (4 * BOWC_ROWS), 1, n_pairs), dim3(256), 0, s, pairs, band, cand, overflow, max_rows, n_qt);
+    if (dim == 256) {
+        int rpw = BOWC_ROWS;                                  // train rows per wave: 8 when the launch has waves to spare (measured: 32 pairs of 1000 rows 16 / 8 / 4 / 2 -> 30 / 20 / 23 / 25 us)
+        while (rpw > 1 && (long long)((max_rows + 4 * rpw - 1) / (4 * rpw)) * n_pairs < 512) rpw >>= 1;
+        hipLaunchKernelGGL(k_bow_candidates256, dim3((max_rows + 4 * rpw - 1) / (4 * rpw), 1, n_pairs), dim3(256), 0, s, pairs, band, cand, overflow, max_rows, n_qt, rpw);
+    }
     else
         hipLaunchKernelGGL(k_bow_candidates, dim3((max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim, band, cand, overflow, max_rows, n_qt);
     hipLaunchKernelGGL(k_bow_finalize, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, th_low);
