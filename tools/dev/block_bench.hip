@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
     if (!block_fusable(b, variant)) { printf("layer %d: no fused kernel for variant %d\n", L, variant); return 1; }
     hipStream_t s; hipStreamCreate(&s);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) launch_block_fused(X, b, Y, g, variant, s);
+    for (int i = 0; i < 200; ++i) launch_block_fused(X, b, Y, g, variant, s);   // (long enough for the clocks to settle where a running pipeline holds them: three launches after idle measured 10-15 % off)
     hipStreamSynchronize(s);
     float best = 1e30f, sum = 0.f;
     for (int i = 0; i < reps; ++i) {
