@@ -1069,7 +1069,7 @@ hipError_t launch_pointwise(const float* A, const ConvPack& cp, const float* res
         return hipGetLastError();
     }
     // a GEMM-shaped launch whose weights would crowd the activations out of L1 (32 KB): weight slabs through LDS (see k_pointwise_wlds)
-    if ((size_t)cp.cin * cp.nt_total * 32 * sizeof(float) >= (size_t)wlds_min_weight_bytes && (P + 127) / 128 * (cp.nt_total / nt) >= 1024 &&
+    if ((size_t)cp.cin * cp.nt_total * 32 * sizeof(float) >= (size_t)wlds_min_weight_bytes && (P + 127) / 128 * (cp.nt_total / nt) >= 512 &&
         nt >= 2 && nt <= 4) {
         dim3 gw((unsigned)((P + 127) / 128), cp.nt_total / nt);
         if (nt == 2) hipLaunchKernelGGL(k_pointwise_wlds<2>, gw, dim3(256), 0, s, a);
