@@ -12,6 +12,7 @@ namespace hfnet {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "device_util.hpp"      // sgpr_base / fresh / gvec4_t: scalar-base global loads
 
 __device__ __forceinline__ float relu6f(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f); }
 
@@ -58,20 +59,6 @@ static long long tile_grid_size(const Geom& g) {
     for (int l = 0; l < g.n_levels; ++l) total += (long long)g.batch * ((g.lv[l].Wo + TW - 1) / TW) * ((g.lv[l].Ho + TH - 1) / TH);
     return total;
 }
-
-// base + uniform byte offset, pinned to scalar registers: a load through it is "scalar base + 32-bit lane offset" and costs
-// no vector instruction for its address (left alone the compiler folds the uniform part into 64-bit vector adds)
-typedef const __attribute__((address_space(1))) char* gbase_t;
-typedef const __attribute__((address_space(1))) f32x4* gvec4_t;
-typedef const __attribute__((address_space(1))) float* gf32_t;
-__device__ __forceinline__ gbase_t sgpr_base(const void* base, unsigned uniform_bytes) {
-    gbase_t p = (gbase_t)(const char*)base + uniform_bytes;
-    asm("" : "+s"(p));
-    return p;
-}
-// a lane offset re-"defined" where it is used: hoisted out of a loop it is widened to 64 bits once and every load through it
-// then pays a 64-bit vector add instead of using its scalar-base + 32-bit-offset form
-__device__ __forceinline__ unsigned fresh(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 
 // ---- v2 of the fused block for the shapes of the high-resolution layers (cin = 8*KQT known at
 // compile time).  Differences to the generic kernel above:

@@ -15,17 +15,7 @@ namespace hfnet {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-// global-address-space loads through a scalar base + 32-bit lane offset (as kernels_block.hip): the operand pointers of the
-// GEMMs below come out of a descriptor in memory, so plain loads through them are FLAT loads with 64-bit vector addresses
-typedef const __attribute__((address_space(1))) char* gbase_t;
-typedef const __attribute__((address_space(1))) f32x4* gvec4_t;
-__device__ __forceinline__ gbase_t sgpr_base(const void* base, unsigned uniform_bytes) {
-    gbase_t p = (gbase_t)(const char*)base + uniform_bytes;
-    asm("" : "+s"(p));
-    return p;
-}
-// a lane offset re-"defined" where it is used (hoisted out of a loop it is widened to 64 bits and every load pays a 64-bit vector add)
-__device__ __forceinline__ unsigned fresh(unsigned v) { asm volatile("" : "+v"(v)); return v; }
+#include "device_util.hpp"      // sgpr_base / fresh / gvec4_t: the operand pointers of the GEMMs below come out of a descriptor in memory
 
 // =========================================================================== SearchForTriangulation
 // S = D1 * D2^T on v_mfma_f32_32x32x2_f32 -- each accumulator is the fused multiply-add chain over k = 0, 1, 2, ... (the
