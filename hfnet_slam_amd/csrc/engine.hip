@@ -20,7 +20,7 @@ int* Options::find(const char* name) {
     const struct { const char* n; int* p; } tab[] = {{"fuse_blocks", &fuse_blocks}, {"fuse_max_layer", &fuse_max_layer}, {"fused_variant", &fused_variant},
                                                        {"fuse_stem", &fuse_stem}, {"dense_desc", &dense_desc}, {"two_streams", &two_streams},
                                                        {"graph", &graph}, {"pinned_frames", &pinned_frames}, {"db_gemm_min_queries", &db_gemm_min_queries},
-                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}, {"interleave", &interleave}, {"host_global", &host_global}, {"det_fuse", &det_fuse}};
+                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}, {"interleave", &interleave}, {"host_global", &host_global}, {"det_fuse", &det_fuse}, {"match_screen_bf16", &match_screen_bf16}};
     for (const auto& t : tab) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -1316,9 +1316,9 @@ int hfnet_descriptor_distance(hfnet_engine* eh, const float* a, const float* b, 
 // scratch for n_pairs x (max_rows x max_rows) similarity matrices, norms, keys and the pair descriptors
 // neither matcher stores an n x m matrix: SearchByBoW keeps candidate slots per train row, SearchForTriangulation
 // (maximum, index) partials per row / column and 64-wide tile
-static int bow_scratch(Engine& e, int n_pairs, int max_rows, bool triangulation) {
+static int bow_scratch(Engine& e, int n_pairs, int max_rows, int dim, bool triangulation) {
     const size_t np = (size_t)std::max(n_pairs, 1), mr = (size_t)std::max(max_rows, 1);
-    HF_TRY(e.m_s.ensure(triangulation ? sizeof(float) * np * tri_scratch_floats((int)mr) : bow_scratch_bytes((int)np, (int)mr)));
+    HF_TRY(e.m_s.ensure(triangulation ? sizeof(float) * np * tri_scratch_floats((int)mr) : bow_scratch_bytes((int)np, (int)mr, std::max(dim, 4))));
     HF_TRY(e.m_qn.ensure(sizeof(float) * np * mr));
     HF_TRY(e.m_tn.ensure(sizeof(float) * np * mr));
     HF_TRY(e.m_key.ensure(sizeof(unsigned long long) * np * mr));
@@ -1340,7 +1340,7 @@ int hfnet_match_search_by_bow(hfnet_engine* eh, const float* query, int n_query,
     HF_TRY(stage_rows(e, e.m_a, query, (size_t)n_query * dim, on_device, &dq));
     HF_TRY(stage_rows(e, e.m_b, train, (size_t)n_train * dim, on_device, &dt));
     const int max_rows = std::max(n_query, n_train);
-    HF_TRY(bow_scratch(e, 1, max_rows, false));
+    HF_TRY(bow_scratch(e, 1, max_rows, dim, false));
     int32_t* d_match = match_q2t; float* d_dist = dist; int* d_cnt = n_matches;
     if (!on_device) {
         HF_TRY(e.m_i0.ensure(sizeof(int32_t) * n_query)); HF_TRY(e.m_f0.ensure(sizeof(float) * n_query)); HF_TRY(e.m_cnt.ensure(sizeof(int)));
@@ -1351,7 +1351,7 @@ int hfnet_match_search_by_bow(hfnet_engine* eh, const float* query, int n_query,
     P.match = d_match; P.dist = d_dist; P.cnt = d_cnt; P.nq = n_query; P.nt = n_train;
     HF_HIP(hipMemcpyAsync(e.m_pairs.p, &P, sizeof P, hipMemcpyHostToDevice, e.stream));
     HF_HIP(hipStreamSynchronize(e.stream));     // P lives on this stack frame
-    HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), 1, max_rows, dim, th_low, e.m_s.p, e.stream));
+    HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), 1, max_rows, dim, th_low, e.m_s.p, e.stream, e.opt.match_screen_bf16));
     if (!on_device) {
         HF_HIP(hipMemcpyAsync(match_q2t, d_match, sizeof(int32_t) * n_query, hipMemcpyDeviceToHost, e.stream));
         HF_HIP(hipMemcpyAsync(dist, d_dist, sizeof(float) * n_query, hipMemcpyDeviceToHost, e.stream));
@@ -1375,7 +1375,7 @@ static int match_pairs_batch(hfnet_engine* eh, int n_pairs, const float* desc_ba
     std::lock_guard<std::mutex> lk(e.mu);
     HF_HIP(hipSetDevice(e.device));
     if (on_device) HF_HIP(e.wait_extract());
-    HF_TRY(bow_scratch(e, n_pairs, max_rows, triangulation));
+    HF_TRY(bow_scratch(e, n_pairs, max_rows, dim, triangulation));
     const float* d_base = desc_base; const int32_t *d_rows = n_rows, *d_qs = query_set, *d_ts = train_set;
     int32_t* d_match = match_q2t; float* d_dist = dist ? dist : (float*)match_q2t; int32_t* d_cnt = n_matches;
     if (!on_device) {
@@ -1406,7 +1406,7 @@ static int match_pairs_batch(hfnet_engine* eh, int n_pairs, const float* desc_ba
         const float threshold = (float)(-0.5 * th * th + 1);   // Matcher.cc:851
         HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, threshold, e.stream));
     } else {
-        HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, th, e.m_s.p, e.stream));
+        HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, th, e.m_s.p, e.stream, e.opt.match_screen_bf16));
     }
     if (!on_device) {
         HF_HIP(hipMemcpyAsync(match_q2t, d_match, sizeof(int32_t) * (size_t)n_pairs * max_rows, hipMemcpyDeviceToHost, e.stream));
@@ -1569,7 +1569,7 @@ static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const 
     const int nc = (int)c_slot.size();
     host.insert(host.end(), qsel.begin(), qsel.end()); host.insert(host.end(), tsel.begin(), tsel.end());
     host.insert(host.end(), c_slot.begin(), c_slot.end()); host.insert(host.end(), c_filter.begin(), c_filter.end());
-    HF_TRY(bow_scratch(e, n_pairs, mr, triangulation));
+    HF_TRY(bow_scratch(e, n_pairs, mr, st->dim, triangulation));
     // m_b: [qsel | tsel | c_slot | c_filter | c_rows | map nc*mr | inv nc*mr]
     HF_TRY(e.m_b.ensure(sizeof(int32_t) * (2 * (size_t)n_pairs + 3 * (size_t)nc + 2 * (size_t)nc * mr)));
     HF_TRY(e.m_i0.ensure(sizeof(int32_t) * (size_t)n_pairs * mr)); HF_TRY(e.m_f0.ensure(sizeof(float) * (size_t)n_pairs * mr));
@@ -1593,7 +1593,7 @@ static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const 
         const float threshold = (float)(-0.5 * th * th + 1);       // Matcher.cc:851
         HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, threshold, e.stream));
     } else {
-        HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, th, e.m_s.p, e.stream));
+        HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, th, e.m_s.p, e.stream, e.opt.match_screen_bf16));
     }
     if (nc)
         HF_LAUNCH(&e, e.stream, "store_remap",
@@ -1644,7 +1644,7 @@ int hfnet_match_search_for_triangulation(hfnet_engine* eh, const float* d1, int 
     HF_TRY(stage_rows(e, e.m_a, d1, (size_t)n1 * dim, on_device, &da));
     HF_TRY(stage_rows(e, e.m_b, d2, (size_t)n2 * dim, on_device, &db));
     const int max_rows = std::max(n1, n2);
-    HF_TRY(bow_scratch(e, 1, max_rows, true));
+    HF_TRY(bow_scratch(e, 1, max_rows, dim, true));
     int32_t* d_match = match12; int* d_cnt = n_matches;
     if (!on_device) {
         HF_TRY(e.m_i0.ensure(sizeof(int32_t) * n1)); HF_TRY(e.m_cnt.ensure(sizeof(int)));

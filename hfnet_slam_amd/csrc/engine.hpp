@@ -103,6 +103,7 @@ struct Options {
     int interleave = 3;       // calls of up to four frames: launch groups of the global branch enqueued between the local heads' launches,
                               // this many right after the detector conv (0: the whole branch after the local heads)
     int dedupe_taps = 1;      // sparse descriptor head: taps shared by neighbouring keypoints are evaluated once
+    int match_screen_bf16 = 1;  // SearchByBoW pre-selection on the bf16 matrix pipe (split operands, wider band); 0: f32 MFMA.  The matches are the exact ones either way
     int tail_fuse = 4;        // calls of up to this many frames run layers 8-18 with the single-frame kernels (0: never)
     int copy_threads = 64;    // helper threads of the host-pointer batch pipeline's staging copies (>= 64: chosen from the core count)
     int fuse_min_wgs = 256;   // layers 8-14 take their fused kernel from this many 128-pixel tiles per launch on (0: always; tests)

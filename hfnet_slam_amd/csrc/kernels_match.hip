@@ -201,7 +201,18 @@ hipError_t launch_tri_pairs(const BowPair* pairs, int n_pairs, int max_rows, int
 // The MFMA dot products St[t][q] only pre-select: every query whose |t|^2+|q|^2-2St lies within a
 // rigorous rounding band of the column minimum is re-evaluated in the exact form, in ascending q.
 // one launch: |q|^2, |t|^2 (pre-filter only), reset of the per-query keys and of the match counter
-__global__ __launch_bounds__(256) void k_bow_prep(const BowPair* __restrict__ pairs, int dim) {
+// split != null: every row is also left as [k / 4][hi x 4, lo x 4] bf16 pieces (16 bytes per four k: the f32 row's size and
+// piece addresses) for the split-bf16 screening GEMM -- see split_bf16 below
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (__bf16)v[i];                                  // (v_cvt_pk_bf16_f32: round to nearest even)
+        lo[i] = (__bf16)(v[i] - (float)hi[i]);                 // (the difference is exact in fp32)
+    }
+}
+__global__ __launch_bounds__(256) void k_bow_prep(const BowPair* __restrict__ pairs, int dim, bf16x8* __restrict__ split, int max_rows) {
     const BowPair P = pairs[blockIdx.z];
     const float* __restrict__ q = P.q; const float* __restrict__ t = P.t;
     const int nq = P.nq, nt = P.nt;
@@ -211,11 +222,17 @@ __global__ __launch_bounds__(256) void k_bow_prep(const BowPair* __restrict__ pa
     if (blockIdx.x == 0 && threadIdx.x == 0) *P.cnt = 0;
     if (i >= nq + nt) return;
     const float* x = i < nq ? q + (long long)i * dim : t + (long long)(i - nq) * dim;
+    bf16x8* __restrict__ srow = split ? split + ((long long)(blockIdx.z * 2 + (i < nq ? 0 : 1)) * max_rows + (i < nq ? i : i - nq)) * (dim >> 2) : nullptr;
     float p = 0.0f;
     for (int k = lane * 4; k < dim; k += 256) {
         const f32x4 v = *(const f32x4*)(x + k);
 #pragma unroll
         for (int j = 0; j < 4; ++j) p = fmaf(v[j], v[j], p);
+        if (srow) {
+            bf16x4 h, l;
+            split_bf16(v, h, l);
+            srow[k >> 2] = bf16x8{h[0], h[1], h[2], h[3], l[0], l[1], l[2], l[3]};
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);
@@ -264,21 +281,52 @@ __device__ float cv_l2_wave(const float* a, const float* b, int dim, int lane) {
 // of that half tile exactly -- if its smallest lower bound can compete at all.
 struct BowCand { unsigned int lo_bits; int q; };
 #define BOW_SLOTS 4
+// SPLIT: the screening products on the bf16 matrix pipe.  S only pre-selects (every query inside the rounding band of a train
+// row's nearest is re-evaluated exactly), so it need not be the f32 chain: each f32 operand is split into two bf16 pieces
+// x = hi + lo + e, |e| <= 2^-18 |x| (both round-to-nearest-even), and q.t ~ qh.th + qh.tl + ql.th on v_mfma_f32_32x32x16_bf16 --
+// three instructions of 32 cycles per 16 k where the f32 form needs eight of 64 (the f32 MFMA IS the fp32 vector pipe; the bf16
+// matrix pipe is otherwise idle in this library and runs beside the vector work of other waves).  The bf16 x bf16 products are
+// exact in fp32; what is lost is  ql.tl + e-terms <= 3 * 2^-18 |q||t|  and the fp32 accumulation of 3 dim exact products in
+// the unit's own order (<= 2 * 3 dim * 2^-24 |q||t| even if its additions are only faithful): launch_bow_pairs widens the band.
+// The rows are split once per pair by k_bow_prep (which reads them anyway for the norms) into 16-byte pieces {hi x 4, lo x 4}
+// at the f32 pieces' addresses: this kernel's staging is the f32 form's, minus the k permutation.
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_bow_gemm_cand(const BowPair* __restrict__ pairs, int dim, float band, BowCand* __restrict__ cand,
-                                                       unsigned char* __restrict__ overflow, int max_rows, int n_qt, int ct) {
+                                                       unsigned char* __restrict__ overflow, int max_rows, int n_qt, int ct, const bf16x8* __restrict__ split,
+                                                       int a_gx, int a_gy, int a_n_pairs) {
     // A workgroup owns 128 queries and `ct` consecutive 128-row tiles of train rows: the k chunks of all its tiles are ONE
     // software pipeline (the first chunk of the next tile is in flight during the last MFMAs and the epilogue of this one), so
     // the load latency at the start of a tile -- 18 % of a 1000 x 1000 x 256 pair when every tile was its own workgroup -- is
     // paid once per workgroup.  ct = 1 for launches that would not fill the chip otherwise (single pairs).
-    const BowPair P = pairs[blockIdx.z];
-    const float* __restrict__ d1 = P.q; const float* __restrict__ d2 = P.t;
+    // 1-D grid of n_pairs * gx * gy workgroups.  Workgroup b runs on XCD b % 8 (observed; speed only): the workgroups of one
+    // pair all go to ONE XCD, so that the re-reads of its rows (every 128-row block is read by all tiles of its row / column)
+    // meet in that XCD's L2 -- spread over the eight L2s the split form ran at 7 TB/s of L2 misses and was bound by them
+    const int gx = a_gx, gy = a_gy, per_pair = gx * gy, n_pairs = a_n_pairs;
+    int pair, rest;
+    {
+        const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+        const int full = n_pairs >> 3;                          // rounds of eight pairs, one per XCD
+        if (slot < full * per_pair) { pair = (slot / per_pair) * 8 + xcd; rest = slot - (slot / per_pair) * per_pair; }
+        else {                                                  // the last n_pairs % 8 pairs: their workgroups in plain order
+            const int q = b - full * per_pair * 8;
+            pair = full * 8 + q / per_pair; rest = q - (q / per_pair) * per_pair;
+        }
+    }
+    if (pair >= n_pairs) return;
+    const int bx = rest % gx, by = rest / gx;
+    const BowPair P = pairs[pair];
+    // (split form: the pair's two row blocks of the split array -- same piece offsets as the f32 rows)
+    const float* __restrict__ d1 = SPLIT ? (const float*)(split + (long long)(pair * 2) * max_rows * (dim >> 2)) : P.q;
+    const float* __restrict__ d2 = SPLIT ? (const float*)(split + (long long)(pair * 2 + 1) * max_rows * (dim >> 2)) : P.t;
     const int n1 = P.nq, n2 = P.nt;
-    constexpr int LD = 68;
-    __shared__ __attribute__((aligned(16))) float As[128 * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[128 * LD];
+    constexpr int LD = 68;                                    // f32 form: floats per LDS row (see k_tri_gemm_argmax)
+    constexpr int LH = 72;                                    // split form: bf16 per LDS row (64 k + 16 bytes: 16-byte reads of 16 consecutive rows cover all banks once)
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SPLIT ? 4 * 128 * LH * 2 : 2 * 128 * LD * 4];
+    float* As = (float*)lds_raw; float* Bs = As + 128 * LD;                                        // f32 form
+    __bf16* Ah = (__bf16*)lds_raw; __bf16* Al = Ah + 128 * LH; __bf16* Bh = Al + 128 * LH; __bf16* Bl = Bh + 128 * LH;   // split form
     __shared__ float qns[128];                                // |q|^2 of the workgroup's queries
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
-    const int row0 = blockIdx.y * 128, ctile0 = blockIdx.x * ct;
+    const int row0 = by * 128, ctile0 = bx * ct;
     if (row0 >= n1 || ctile0 * 128 >= n2) return;             // workgroup-uniform
     const int n_ct = min(ct, (n2 - ctile0 * 128 + 127) >> 7); // column tiles of this workgroup that exist
     const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
@@ -308,34 +356,68 @@ __global__ __launch_bounds__(256, 2) void k_bow_gemm_cand(const BowPair* __restr
         }
     };
     fetch(0);
-    const long long pair_rows = (long long)blockIdx.z * max_rows;
+    const long long pair_rows = (long long)pair * max_rows;
     const int qt = (row0 + wr) >> 6;                          // 64-query tile index of this wave
     for (int c = 0; c < n_chunks; ++c) {
         __syncthreads();                                     // previous chunk fully consumed
+        if constexpr (SPLIT) {
+            // rows keep their k order: lane (r, half) of a 32x32x16 MFMA reads k = 8 half .. 8 half + 7 of a step as one 16-byte piece
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float* ap = As + (lrow + j) * LD + lc * 2;
-            float* bp = Bs + (lrow + j) * LD + lc * 2;
-            *(float2*)(ap) = float2{sa[j][0], sa[j][2]}; *(float2*)(ap + 32) = float2{sa[j][1], sa[j][3]};
-            *(float2*)(bp) = float2{sb[j][0], sb[j][2]}; *(float2*)(bp + 32) = float2{sb[j][1], sb[j][3]};
+            for (int j = 0; j < 8; ++j) {                     // a staged piece is {hi x 4, lo x 4}
+                *(float2*)(Ah + (lrow + j) * LH + lc * 4) = float2{sa[j][0], sa[j][1]}; *(float2*)(Al + (lrow + j) * LH + lc * 4) = float2{sa[j][2], sa[j][3]};
+                *(float2*)(Bh + (lrow + j) * LH + lc * 4) = float2{sb[j][0], sb[j][1]}; *(float2*)(Bl + (lrow + j) * LH + lc * 4) = float2{sb[j][2], sb[j][3]};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float* ap = As + (lrow + j) * LD + lc * 2;
+                float* bp = Bs + (lrow + j) * LD + lc * 2;
+                *(float2*)(ap) = float2{sa[j][0], sa[j][2]}; *(float2*)(ap + 32) = float2{sa[j][1], sa[j][3]};
+                *(float2*)(bp) = float2{sb[j][0], sb[j][2]}; *(float2*)(bp + 32) = float2{sb[j][1], sb[j][3]};
+            }
         }
         __syncthreads();
         // the next chunk's pieces, unconditionally (the last pass re-reads its own chunk: a branch around the loads makes the
         // compiler wait for them and copy them right here, in front of the MFMAs they are meant to hide behind)
         fetch(min(c + 1, n_chunks - 1));
         __builtin_amdgcn_sched_barrier(0);                    // (left alone the scheduler sinks them below the MFMAs: nobody needs them before the next pass)
-        const float* ap = As + (wr + r) * LD + half * 32;
-        const float* bp = Bs + (wc + r) * LD + half * 32;
+        if constexpr (SPLIT) {
+            const int ao = (wr + r) * LH + half * 8, bo = (wc + r) * LH + half * 8;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const f32x4 a0 = *(const f32x4*)(ap + 4 * m), a1 = *(const f32x4*)(ap + 32 * LD + 4 * m);
-            const f32x4 b0 = *(const f32x4*)(bp + 4 * m), b1 = *(const f32x4*)(bp + 32 * LD + 4 * m);
+            for (int m = 0; m < 4; ++m) {                     // four steps of 16 k
+                bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) {
+                    ah[i] = *(const bf16x8*)(Ah + ao + i * 32 * LH + 16 * m); al[i] = *(const bf16x8*)(Al + ao + i * 32 * LH + 16 * m);
+                    bh[i] = *(const bf16x8*)(Bh + bo + i * 32 * LH + 16 * m); bl[i] = *(const bf16x8*)(Bl + bo + i * 32 * LH + 16 * m);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            const float* ap = As + (wr + r) * LD + half * 32;
+            const float* bp = Bs + (wc + r) * LD + half * 32;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const f32x4 a0 = *(const f32x4*)(ap + 4 * m), a1 = *(const f32x4*)(ap + 32 * LD + 4 * m);
+                const f32x4 b0 = *(const f32x4*)(bp + 4 * m), b1 = *(const f32x4*)(bp + 32 * LD + 4 * m);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
+                }
             }
         }
         const int tile = c / KC;
@@ -749,12 +831,15 @@ hipError_t launch_store_remap(int n_pairs, const int* qsel, const int* tsel, con
 
 // all pairs in four launches (prep, GEMM, train pass, finalize); grids are sized for max_rows, workgroups
 // beyond a pair's row counts exit at once
-size_t bow_scratch_bytes(int n_pairs, int max_rows) {
+static size_t bow_cand_bytes(int n_pairs, int max_rows) {      // candidate slots + counts, rounded up to 16 bytes
     const size_t n_qt = (size_t)(max_rows + 63) / 64;
-    return (size_t)n_pairs * max_rows * n_qt * 2 * (BOW_SLOTS * sizeof(BowCand) + 1);
+    return ((size_t)n_pairs * max_rows * n_qt * 2 * (BOW_SLOTS * sizeof(BowCand) + 1) + 15) & ~(size_t)15;
+}
+size_t bow_scratch_bytes(int n_pairs, int max_rows, int dim) {  // + the split rows of both sets of every pair (split-bf16 screening)
+    return bow_cand_bytes(n_pairs, max_rows) + (size_t)n_pairs * 2 * max_rows * dim * sizeof(float);
 }
 
-hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, void* scratch, hipStream_t s) {
+hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, void* scratch, hipStream_t s, int screen_bf16) {
     if (n_pairs <= 0 || max_rows <= 0) return hipSuccess;
     if (dim % 64 || (long long)max_rows * dim * 4 >= (1ll << 32)) return hipErrorInvalidValue;   // (32-bit lane offsets inside a descriptor set)
     // G = |q|^2 + |t|^2 - 2 q.t (norms and the MFMA chain in fp32) against the exactly evaluated form X (OpenCV's order): with
@@ -763,17 +848,28 @@ hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int
     // 4.1 dim u (|q|^2 + |t|^2) = 6.2e-5 for dim 256.  band = 5e-7 dim (1.28e-4 for dim 256) is twice that worst case; measured
     // differences are two orders of magnitude smaller.  (Round 1 used 1.1e-3: every query within 8e-3 of a row's nearest was
     // re-evaluated exactly -- three per train row on descriptors of one scene instead of one.)
-    const float band = 5e-7f * (float)dim;
+    // Split-bf16 screening (k_bow_gemm_cand<true>): the dot product additionally loses 3 * 2^-18 |q||t| (dropped lo.lo and
+    // the splitting remainders) and is accumulated from 3 dim exact products in the matrix unit's own order: with additions that
+    // are at least faithful  |S~ - q.t| <= (1.5 * 2^-18 + 3 dim u)(|q|^2 + |t|^2),  twice that in G, plus the norms and X as
+    // above: 1.5e-4 for dim 256.  band = 1.25e-6 dim (3.2e-4) is again twice the worst case (tools/dev/match_band.py: the largest
+    // difference seen is 40 times smaller); the candidates stay one per train row on descriptors of one scene.
+    const float band = (screen_bf16 ? 1.25e-6f : 5e-7f) * (float)dim;
     const int n_qt = (max_rows + 63) / 64;
     BowCand* cand = (BowCand*)scratch;
     unsigned char* overflow = (unsigned char*)scratch + (size_t)n_pairs * max_rows * n_qt * 2 * BOW_SLOTS * sizeof(BowCand);   // candidate counts per half tile
-    hipLaunchKernelGGL(k_bow_prep, dim3((2 * max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim);
+    bf16x8* split = screen_bf16 ? (bf16x8*)((unsigned char*)scratch + bow_cand_bytes(n_pairs, max_rows)) : nullptr;
+    hipLaunchKernelGGL(k_bow_prep, dim3((2 * max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim, split, max_rows);
     // column tiles per workgroup: as many (up to 4) as still leave the launch two workgroups per CU
     const int t128 = (max_rows + 127) / 128;
     int ct = 1;
     while (ct < 4 && ct * 2 <= t128 && (long long)((t128 + 2 * ct - 1) / (2 * ct)) * t128 * n_pairs >= 512) ct *= 2;
-    hipLaunchKernelGGL(k_bow_gemm_cand, dim3((t128 + ct - 1) / ct, t128, n_pairs), dim3(256), 0, s, pairs, dim, band, cand, overflow,
-                       max_rows, n_qt, ct);
+    const int gx = (t128 + ct - 1) / ct;
+    if ((long long)gx * t128 * n_pairs > 0x7fffffffll) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(gx * t128 * n_pairs));
+    if (screen_bf16)
+        hipLaunchKernelGGL(k_bow_gemm_cand<true>, grid, dim3(256), 0, s, pairs, dim, band, cand, overflow, max_rows, n_qt, ct, split, gx, t128, n_pairs);
+    else
+        hipLaunchKernelGGL(k_bow_gemm_cand<false>, grid, dim3(256), 0, s, pairs, dim, band, cand, overflow, max_rows, n_qt, ct, nullptr, gx, t128, n_pairs);
     if (dim == 256) {
         int rpw = BOWC_ROWS;                                  // train rows per wave: 8 when the launch has waves to spare (measured: 32 pairs of 1000 rows 16 / 8 / 4 / 2 -> 30 / 20 / 23 / 25 us)
         while (rpw > 1 && (long long)((max_rows + 4 * rpw - 1) / (4 * rpw)) * n_pairs < 512) rpw >>= 1;
