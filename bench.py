@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 W_IMG, H_IMG, N_FEAT, N_LEVELS, SCALE, THRESH, TH_LOW, TH_HIGH = 752, 480, 1000, 4, 1.2, 0.01, 0.6, 0.75
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4)
+MFMA_BF16_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense bf16 MFMA (16 x the f32 rate); only the matcher's screening GEMM runs there
 TRAFFIC_FILES = [os.path.join("profiles", r + "_traffic_b{batch}.json") for r in ("r03", "r02")]     # newest first; one file per frames-per-call value
 ALL_CONFIGS = ["2-latency", "2-host-io", "3", "4", "5"]
 
@@ -345,7 +346,7 @@ def launch_class(name: str) -> str:
     return "hbm_stream"      # depthwise_L15-18, nms, softmax_d2s, sample, pyramid_resize, topk, vlad, softmax_memberships, stem
 
 
-def roofline_table(prof, work, chunk_seconds_sum):
+def roofline_table(prof, work, chunk_seconds_sum, match_bf16=False):
     """(table, classes).  classes: per launch class its share of the profiled chunk, time, algorithmic FLOP and bytes and the
     fraction of the roof that bounds the class (hbm_stream: bytes once / time / 8 TB/s; the others: FLOP / time / f32 MFMA peak).
     table: time-weighted rows of every launch in a class that carries >= 2 % of the chunk (own share >= 0.25 %), so the
@@ -362,6 +363,11 @@ def roofline_table(prof, work, chunk_seconds_sum):
         c["share"] = sec / chunk_seconds_sum
         if k == "hbm_stream":
             c.update({"bound": "hbm", "achieved": c["bytes"] / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"})
+        elif k == "match" and match_bf16:
+            # SearchByBoW screens on the bf16 matrix pipe: three bf16 products per f32 product (split operands), so the executed
+            # work is 3 x the padded f32 count, priced against the bf16 roof; "achieved" stays the algorithmic f32-equivalent rate
+            c.update({"bound": "mfma_bf16", "achieved": c["flop"] / sec / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac_executed": 3.0 * c["executed"] / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS})
         else:
             c.update({"bound": "mfma", "achieved": c["flop"] / sec / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                       "frac_executed": c["executed"] / sec / 1e12 / MFMA_F32_PEAK_TFLOPS})
@@ -377,8 +383,14 @@ def roofline_table(prof, work, chunk_seconds_sum):
         if launch_class(name) == "hbm_stream" and e["bound"] != "hbm":     # priced against the roof of its class
             e = {"bound": "hbm", "achieved": byts / launches / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
             e["frac"] = e["achieved"] / e["peak"]
+        if launch_class(name) == "match" and match_bf16:
+            e = {"bound": "mfma_bf16", "achieved": flop / launches / sec / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s"}
+            e["frac"] = e["achieved"] / e["peak"]
+            fx = 3.0 * (executed / launches) / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS
+        else:
+            fx = (executed / launches) / sec / 1e12 / MFMA_F32_PEAK_TFLOPS if e["bound"] == "mfma" else None
         e.update({"name": name, "class": launch_class(name), "us": sec * 1e6, "launches_per_chunk": launches, "share": share, "flop": flop / launches,
-                  "bytes": byts / launches, "frac_executed": (executed / launches) / sec / 1e12 / MFMA_F32_PEAK_TFLOPS if e["bound"] == "mfma" else None})
+                  "bytes": byts / launches, "frac_executed": fx})
         rows.append(e)
     return rows, cls
 
@@ -609,6 +621,7 @@ def config_loop_closure(capi, eng, reps=10):
            "db_q64_frac_mfma_f32": 64 * N * DIM * 2 / (ms(prof, q64) * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
            "match_32_pairs_us": ms(prof, "match_bow") * 1e3, "match_TFLOPs": 32 * 2 * 1000 * 1000 * 256 / (ms(prof, "match_bow") * 1e-3) / 1e12,
            "match_frac_mfma_f32": 32 * 2 * 1000 * 1000 * 256 / (ms(prof, "match_bow") * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+           "match_screening": "split bf16 x 3 on v_mfma_f32_32x32x16_bf16 (matches exact); match_frac_mfma_f32 is the f32-equivalent rate over the f32 roof" if eng.options().get("match_screen_bf16") else "f32 MFMA",
            "triangulation_32_pairs_us": ms(prof, "match_tri") * 1e3,
            "triangulation_frac_mfma_f32": 32 * 2 * 1000 * 1000 * 256 / (ms(prof, "match_tri") * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
     # cold: a 1 GB database (4x the Infinity Cache): every scan streams it from HBM
@@ -779,7 +792,8 @@ def main() -> None:
         if args.profile_all and rank == 0:
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1]):
                 print(f"  {k:26s} launches {v[0]:5.1f}  avg {v[1] / max(v[0], 1e-9) * 1e3:9.1f} us  share {v[1] * 1e-3 / prof_sum_s * 100:5.1f}%", file=sys.stderr)
-        table, classes = roofline_table(prof, work, prof_sum_s)
+        match_bf16 = bool(eng.options().get("match_screen_bf16"))
+        table, classes = roofline_table(prof, work, prof_sum_s, match_bf16)
         dominant = max((k for k in prof if k in work), key=lambda k: prof[k][1])      # largest by TIME in the single-stream pass
         step()                                                                        # (back to the two-stream steady state)
         # ---- timed region: the dominant kernel is timed live with HIP events on its own stream ------
@@ -821,8 +835,10 @@ def main() -> None:
                          "profiled_us_single_stream": prof[dominant][1] / launches_per_chunk * 1e3,
                          "selection": "largest launch name by time in the single-stream profiling pass (after the warm-up steps, 10 chunks); timed live (HIP events on its stream) over the timed region"})
             chunk_s = elapsed / args.steps / chunks_per_step
-            alg = sum(work[k][0] for k in prof if k in work)
-            exe = sum(work[k][2] for k in prof if k in work)
+            # (f32 pipe only: with the bf16 screening the matcher's GEMM is not on it)
+            on_f32 = [k for k in prof if k in work and not (match_bf16 and launch_class(k) == "match")]
+            alg = sum(work[k][0] for k in on_f32)
+            exe = sum(work[k][2] for k in on_f32)
             roof["step_frac_algorithmic"] = alg / chunk_s / 1e12 / MFMA_F32_PEAK_TFLOPS
             roof["step_frac_executed"] = exe / chunk_s / 1e12 / MFMA_F32_PEAK_TFLOPS
             # extractor-level HBM fraction: layer-granular algorithmic bytes x frames/s over the HBM peak -- what

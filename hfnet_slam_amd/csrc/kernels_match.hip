@@ -851,8 +851,8 @@ hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int
     // Split-bf16 screening (k_bow_gemm_cand<true>): the dot product additionally loses 3 * 2^-18 |q||t| (dropped lo.lo and
     // the splitting remainders) and is accumulated from 3 dim exact products in the matrix unit's own order: with additions that
     // are at least faithful  |S~ - q.t| <= (1.5 * 2^-18 + 3 dim u)(|q|^2 + |t|^2),  twice that in G, plus the norms and X as
-    // above: 1.5e-4 for dim 256.  band = 1.25e-6 dim (3.2e-4) is again twice the worst case (tools/dev/match_band.py: the largest
-    // difference seen is 40 times smaller); the candidates stay one per train row on descriptors of one scene.
+    // above: 1.5e-4 for dim 256.  band = 1.25e-6 dim (3.2e-4) is again twice the worst case (tools/dev/match_band.py, a numpy emulation:
+    // the largest difference seen is 100 times smaller); the candidates stay one per train row on descriptors of one scene.
     const float band = (screen_bf16 ? 1.25e-6f : 5e-7f) * (float)dim;
     const int n_qt = (max_rows + 63) / 64;
     BowCand* cand = (BowCand*)scratch;

@@ -95,9 +95,12 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *   "det_fuse" (1)      detector tail (1x1 conv 128 -> 65, softmax, depth_to_space) as one launch: the logits stay in LDS
  *   "host_global" (1)   host-pointer calls of up to four frames: the last kernel of the global branch writes the descriptors
  *                       into the pinned result block itself (no copy after the join, the call returns without draining the stream)
+ *   "match_screen_bf16" (1)  SearchByBoW pre-selects on the bf16 matrix pipe (operands split into two bf16 pieces, three products,
+ *                       a wider rounding band); 0: on the f32 MFMA.  Every candidate inside the band is re-evaluated exactly
+ *                       either way: matches and distances are the same bits
  *   "copy_threads" (64 = by core count): helper threads for the staging copies of host-pointer batch calls (replicas sharing a host)
  * Values are >= 0.
- * Every setting of the extractor switches produces the same bits (tests/test_gpu_parity.py). */
+ * Every setting of the extractor and matcher switches produces the same bits (tests/test_gpu_parity.py). */
 int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value);
 int hfnet_engine_get_option(hfnet_engine* e, const char* name, int* value);
 int hfnet_engine_synchronize(hfnet_engine* e);

@@ -263,12 +263,22 @@ def test_matcher_duplicates_and_ties(engine):
     assert engine.descriptor_distance(x, y) == O.descriptor_distance(x, y)
 
 
-@pytest.mark.parametrize("seed,spread,scale", [(21, 3e-4, 1.0), (22, 3e-5, 1.0), (23, 2e-6, 1.0), (24, 1e-4, 7.5), (25, 1e-4, 0.05)])
-def test_matcher_near_ties_inside_the_rounding_band(engine, seed, spread, scale):
+@pytest.fixture(params=[1, 0], ids=["screen_bf16", "screen_f32"])
+def screen(request, engine):
+    """engine option match_screen_bf16 for one test (the engine fixture lives for the session)"""
+    engine.set_option("match_screen_bf16", request.param)
+    yield request.param
+    engine.set_option("match_screen_bf16", 1)
+
+
+@pytest.mark.parametrize("seed,spread,scale", [(21, 3e-4, 1.0), (22, 3e-5, 1.0), (23, 2e-6, 1.0), (24, 1e-4, 7.5), (25, 1e-4, 0.05),
+                                               (26, 1e-3, 1.0), (27, 3e-3, 1.0), (28, 1e-3, 30.0)])
+def test_matcher_near_ties_inside_the_rounding_band(engine, seed, spread, scale, screen):
     """Adversarial for the pre-selection of SearchByBoW: clusters of descriptors whose mutual distances differ by less than
-    the rounding band of the MFMA form of the distance (kernels_match.hip: band = 5e-7 * dim relative to |q|^2 + |t|^2), down to
-    differences of a few ulp, with non-unit norms as well -- the exact re-evaluation must still pick the oracle's match and
-    distance bit for bit."""
+    the rounding band of the screening form of the distance (kernels_match.hip: band = 1.25e-6 * dim relative to |q|^2 + |t|^2
+    for the split-bf16 products on the bf16 matrix pipe, 5e-7 * dim for the f32 MFMA form -- engine option match_screen_bf16),
+    from differences of a few ulp up to several bands, with non-unit norms as well -- the exact re-evaluation must still pick
+    the oracle's match and distance bit for bit, whichever pipe screened."""
     from oracle import oracle as O
     rng = np.random.default_rng(seed)
     centres = _unit_rows(rng, 12)
