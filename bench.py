@@ -816,7 +816,11 @@ def main() -> None:
             "metric": "frames/sec HF-Net extract+match, 752x480, 1000 kpts",
             "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": f"synthetic (seeded {args.frames} u8 frames, seeded random-init weights of the reference architecture)",
+            "dtype": "f32",
+            "dtype_note": "every result (keypoints, descriptors, global descriptors, matches, distances) is the f32 fma chain's, bit-identical to the "
+                          "oracle; with engine option match_screen_bf16 (default) SearchByBoW's PRE-SELECTION -- not a result -- runs on split-bf16 "
+                          "products with a rigorous band, and every candidate inside it is re-evaluated exactly",
+            "data": f"synthetic (seeded {args.frames} u8 frames, seeded random-init weights of the reference architecture)",
             "config": {"workload": "EuRoC-size 752x480 mono, HF-Net extract (4 levels x1.2, budget 322/268/224/186, thr 0.01, "
                                    "level 0 incl. NetVLAD 4096-D) + SearchByBoW brute-force match vs previous frame",
                        "frames_per_step_per_gpu": args.batch, "frames_per_call": B, "parallelism": f"replicas x{world} (no collective)"},
