@@ -123,6 +123,38 @@ __device__ __forceinline__ float hmax9(float c) {
     q = fmaxf(c, lane_prev(q));                // [l-4, l]
     return fmaxf(r, q);
 }
+// The horizontal 9-max of all NMS_RB rows of a wave tile at once, through a wave-private LDS slice (NMS_RB x NMS_LP floats):
+// hmax9 costs nine vector instructions per value, eight of them DPP moves, and the three NMS passes are bound by exactly
+// those (0.85-0.95 of the vector issue port busy).  Transposed -- lane (r, h) takes row r, columns 24 h .. 24 h + 39 -- the
+// same maxima come out of the register strips the vertical pass uses: 88 max per 32 outputs and lane instead of 288, and the
+// transposition itself runs on the LDS port.  max is exact: same values.  o[j] in / out: lane = column, valid for lanes 4..59.
+#define NMS_LP 68          // floats per row of the slice: 16-byte reads of 16 consecutive rows cover all banks once
+__device__ __forceinline__ void hmax9_rows_lds(float (&o)[NMS_RB], float* __restrict__ slice, int lane) {
+    static_assert(NMS_RB == 32, "lane (r, h): 32 rows x two column halves");
+#pragma unroll
+    for (int j = 0; j < NMS_RB; ++j) slice[j * NMS_LP + lane] = o[j];
+    asm volatile("" ::: "memory");                              // (LDS operations of one wave execute in order)
+    const int r = lane & 31, c0 = (lane >> 5) * 24;
+    float in[40], out[32];
+    {
+        const float* rp = slice + r * NMS_LP + c0;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) {
+            const f32x4 v = *(const f32x4*)(rp + 4 * q);
+            in[4 * q] = v[0]; in[4 * q + 1] = v[1]; in[4 * q + 2] = v[2]; in[4 * q + 3] = v[3];
+        }
+    }
+    max9_strip_at<0>(in, out); max9_strip_at<8>(in, out + 8); max9_strip_at<16>(in, out + 16); max9_strip_at<24>(in, out + 24);
+    asm volatile("" ::: "memory");                              // every read of the slice is issued before it is overwritten
+    {
+        float* wp = slice + r * NMS_LP + c0 + 4;                // out[i] is the maximum centred on column c0 + 4 + i
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *(f32x4*)(wp + 4 * q) = f32x4{out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]};   // (columns 28..35 twice, same values)
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < NMS_RB; ++j) o[j] = slice[j * NMS_LP + lane];
+}
 __device__ __forceinline__ unsigned hor9(unsigned c) {
     unsigned r = c | (unsigned)lane_next_i((int)c);
     r = c | (unsigned)lane_next_i((int)r);
@@ -198,15 +230,17 @@ __device__ __forceinline__ unsigned nms_row_mask(const NmsTile& t) {     // rows
 
 // pass 1: max_mask = (scores == pool9x9(scores)) as bit columns
 __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ dense, unsigned* __restrict__ m0, Geom g) {
+    __shared__ __attribute__((aligned(16))) float nms_slice[4][NMS_RB * NMS_LP];      // wave-private: no workgroup barrier anywhere
     const NmsTile t = nms_tile(g);
     if (!t.ok) return;
     float v[NMS_RB + 8];
     nms_load_column(t, dense + t.base, v);
     float o[NMS_RB];
     max9_strip_at<0>(v, o); max9_strip_at<8>(v, o + 8); max9_strip_at<16>(v, o + 16); max9_strip_at<24>(v, o + 24);
+    hmax9_rows_lds(o, nms_slice[threadIdx.x >> 6], t.lane);
     unsigned bits = 0;
 #pragma unroll
-    for (int j = 0; j < NMS_RB; ++j) bits |= (v[j + 4] == hmax9(o[j]) ? 1u : 0u) << j;      // all lanes take part in the shifts
+    for (int j = 0; j < NMS_RB; ++j) bits |= (v[j + 4] == o[j] ? 1u : 0u) << j;
     if (t.lane_out) m0[t.wbase + t.ty * t.W + t.gx] = bits & nms_row_mask(t);
 }
 
@@ -227,6 +261,7 @@ __global__ __launch_bounds__(256) void k_nms_dilate(const unsigned* __restrict__
 __global__ __launch_bounds__(256) void k_nms_select(const float* __restrict__ dense, const unsigned* __restrict__ m0, const unsigned* __restrict__ supp,
                                                     float* __restrict__ nms, unsigned long long* __restrict__ cand,
                                                     unsigned int* __restrict__ counters, long long cand_stride, float threshold, Geom g) {
+    __shared__ __attribute__((aligned(16))) float nms_slice[4][NMS_RB * NMS_LP];      // wave-private: no workgroup barrier anywhere
     const NmsTile t = nms_tile(g);
     if (!t.ok) return;
     float v[NMS_RB + 8], sc[NMS_RB];
@@ -240,8 +275,7 @@ __global__ __launch_bounds__(256) void k_nms_select(const float* __restrict__ de
     for (int i = 0; i < NMS_RB + 8; ++i) v[i] = ((sw >> i) & 1ull) ? 0.0f : v[i];              // (-inf rows have no supp bit)
     float o[NMS_RB];
     max9_strip_at<0>(v, o); max9_strip_at<8>(v, o + 8); max9_strip_at<16>(v, o + 16); max9_strip_at<24>(v, o + 24);
-#pragma unroll
-    for (int j = 0; j < NMS_RB; ++j) o[j] = hmax9(o[j]);
+    hmax9_rows_lds(o, nms_slice[threadIdx.x >> 6], t.lane);
     // per-lane bit fields from here on (bit j = tile row j): nothing wave-wide stays alive
     unsigned newmax = 0;
 #pragma unroll
