@@ -582,6 +582,7 @@ def config_loop_closure(capi, eng, reps=10):
     """config 5: keyframe-database scans at 10 000 x 4096 (Q = 1 and Q = 64; warm: the 164 MB database stays in the 256 MB
     Infinity Cache between scans; cold: a 65 536-row = 1 GB database) and 32 SearchByBoW matches of 1000 x 1000 x 256.
     Kernel times are HIP-event times of the library's profiler."""
+    eng.set_option("tri_screen_bf16", eng.get_option("tri_screen_bf16"))      # (forget what config 3's descriptor sets taught the screened path)
     N, DIM = 10000, 4096
     rng = np.random.default_rng(13)
     rows = unit_rows(rng, N, DIM)
@@ -623,7 +624,9 @@ def config_loop_closure(capi, eng, reps=10):
            "match_frac_mfma_f32": 32 * 2 * 1000 * 1000 * 256 / (ms(prof, "match_bow") * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
            "match_screening": "split bf16 x 3 on v_mfma_f32_32x32x16_bf16 (matches exact); match_frac_mfma_f32 is the f32-equivalent rate over the f32 roof" if eng.options().get("match_screen_bf16") else "f32 MFMA",
            "triangulation_32_pairs_us": ms(prof, "match_tri") * 1e3,
-           "triangulation_frac_mfma_f32": 32 * 2 * 1000 * 1000 * 256 / (ms(prof, "match_tri") * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
+           "triangulation_frac_mfma_f32": 32 * 2 * 1000 * 1000 * 256 / (ms(prof, "match_tri") * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+           "triangulation_screening": "threshold screen, split bf16 x 3 on the bf16 matrix pipe + exact chains for the listed products (matches exact)"
+                                      if eng.options().get("tri_screen_bf16") else "none (f32 MFMA)"}
     # cold: a 1 GB database (4x the Infinity Cache): every scan streams it from HBM
     NC = 65536
     dbc = capi.Database(eng, NC, DIM)

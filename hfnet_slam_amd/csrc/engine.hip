@@ -20,7 +20,7 @@ int* Options::find(const char* name) {
     const struct { const char* n; int* p; } tab[] = {{"fuse_blocks", &fuse_blocks}, {"fuse_max_layer", &fuse_max_layer}, {"fused_variant", &fused_variant},
                                                        {"fuse_stem", &fuse_stem}, {"dense_desc", &dense_desc}, {"two_streams", &two_streams},
                                                        {"graph", &graph}, {"pinned_frames", &pinned_frames}, {"db_gemm_min_queries", &db_gemm_min_queries},
-                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}, {"interleave", &interleave}, {"host_global", &host_global}, {"det_fuse", &det_fuse}, {"match_screen_bf16", &match_screen_bf16}};
+                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}, {"interleave", &interleave}, {"host_global", &host_global}, {"det_fuse", &det_fuse}, {"match_screen_bf16", &match_screen_bf16}, {"tri_screen_bf16", &tri_screen_bf16}};
     for (const auto& t : tab) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -43,9 +43,11 @@ Engine::~Engine() {
     (void)hipSetDevice(device);
     prof.flush();
     for (auto ev : prof.pool) (void)hipEventDestroy(ev);
-    for (DevMem* m : {&m_a, &m_b, &m_s, &m_qn, &m_tn, &m_key, &m_i0, &m_i1, &m_f0, &m_f1, &m_cnt, &m_pairs}) m->release();
+    if (stream) (void)hipStreamSynchronize(stream);          // (the statistics copy of a screened SearchForTriangulation may still be in flight)
+    for (DevMem* m : {&m_a, &m_b, &m_s, &m_qn, &m_tn, &m_key, &m_i0, &m_i1, &m_f0, &m_f1, &m_cnt, &m_pairs, &m_tri_stat}) m->release();
     w.release();
     if (h_res) (void)hipHostFree(h_res);
+    if (h_tri_stat) (void)hipHostFree(h_tri_stat);
     if (ev_extract) (void)hipEventDestroy(ev_extract);
     if (ev_match) (void)hipEventDestroy(ev_match);
     if (stream) (void)hipStreamDestroy(stream);
@@ -657,6 +659,10 @@ int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value) {
     if (!p) { set_error("unknown engine option '%s'", name ? name : "(null)"); return HFNET_ERR_INVALID_ARG; }
     if (value < 0) { set_error("engine option '%s': negative value %d", name, value); return HFNET_ERR_INVALID_ARG; }
     *p = value;
+    if (std::strcmp(name, "tri_screen_bf16") == 0) {          // (writing the option also forgets what earlier calls found: Engine::tri_skip)
+        e->impl.tri_skip = 0;
+        if (e->impl.h_tri_stat) { (void)hipStreamSynchronize(e->impl.stream); e->impl.h_tri_stat[0] = 0; e->impl.h_tri_stat[1] = 0; }
+    }
     return HFNET_OK;
 }
 int hfnet_engine_get_option(hfnet_engine* e, const char* name, int* value) {
@@ -1316,9 +1322,33 @@ int hfnet_descriptor_distance(hfnet_engine* eh, const float* a, const float* b, 
 // scratch for n_pairs x (max_rows x max_rows) similarity matrices, norms, keys and the pair descriptors
 // neither matcher stores an n x m matrix: SearchByBoW keeps candidate slots per train row, SearchForTriangulation
 // (maximum, index) partials per row / column and 64-wide tile
+// the split-row scratch of the screened SearchForTriangulation, or null when this call takes the full path (see Engine::tri_skip);
+// resets the device statistics the call will add to
+static int tri_screen_begin(Engine& e, int n_pairs, int max_rows, void** split, int** stat) {
+    *split = nullptr; *stat = nullptr;
+    if (!e.opt.tri_screen_bf16 || n_pairs < 4) return HFNET_OK;
+    if (!e.h_tri_stat) {
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return HFNET_OK; }
+        e.h_tri_stat = (int*)hp; e.h_tri_stat[0] = 0; e.h_tri_stat[1] = 0;
+    }
+    HF_TRY(e.m_tri_stat.ensure(2 * sizeof(int)));
+    volatile int* h = e.h_tri_stat;
+    if (h[1] > 0 && h[0] * 4 >= h[1]) { e.tri_skip = 16; h[0] = 0; h[1] = 0; }
+    if (e.tri_skip > 0) { --e.tri_skip; return HFNET_OK; }
+    HF_HIP(hipMemsetAsync(e.m_tri_stat.p, 0, 2 * sizeof(int), e.stream));
+    *split = (unsigned char*)e.m_s.p + tri_split_offset_bytes(n_pairs, max_rows);
+    *stat = e.m_tri_stat.as<int>();
+    return HFNET_OK;
+}
+static int tri_screen_end(Engine& e, int* stat) {
+    if (stat) HF_HIP(hipMemcpyAsync(e.h_tri_stat, stat, 2 * sizeof(int), hipMemcpyDeviceToHost, e.stream));
+    return HFNET_OK;
+}
+
 static int bow_scratch(Engine& e, int n_pairs, int max_rows, int dim, bool triangulation) {
     const size_t np = (size_t)std::max(n_pairs, 1), mr = (size_t)std::max(max_rows, 1);
-    HF_TRY(e.m_s.ensure(triangulation ? sizeof(float) * np * tri_scratch_floats((int)mr) : bow_scratch_bytes((int)np, (int)mr, std::max(dim, 4))));
+    HF_TRY(e.m_s.ensure(triangulation ? tri_scratch_bytes((int)np, (int)mr, std::max(dim, 4)) : bow_scratch_bytes((int)np, (int)mr, std::max(dim, 4))));
     HF_TRY(e.m_qn.ensure(sizeof(float) * np * mr));
     HF_TRY(e.m_tn.ensure(sizeof(float) * np * mr));
     HF_TRY(e.m_key.ensure(sizeof(unsigned long long) * np * mr));
@@ -1404,7 +1434,10 @@ static int match_pairs_batch(hfnet_engine* eh, int n_pairs, const float* desc_ba
                                triangulation ? (long long)tri_scratch_floats(max_rows) : 0, e.m_qn.as<float>(), e.m_tn.as<float>(), e.m_key.as<unsigned long long>(), d_match, d_dist, d_cnt, max_rows, e.stream));
     if (triangulation) {
         const float threshold = (float)(-0.5 * th * th + 1);   // Matcher.cc:851
-        HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, threshold, e.stream));
+        void* split = nullptr; int* stat = nullptr;
+        HF_TRY(tri_screen_begin(e, n_pairs, max_rows, &split, &stat));
+        HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, threshold, e.stream, split, stat));
+        HF_TRY(tri_screen_end(e, stat));
     } else {
         HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, th, e.m_s.p, e.stream, e.opt.match_screen_bf16));
     }
@@ -1591,7 +1624,10 @@ static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const 
                                  e.m_key.as<unsigned long long>(), w_match, w_dist, d_cnt, e.stream));
     if (triangulation) {
         const float threshold = (float)(-0.5 * th * th + 1);       // Matcher.cc:851
-        HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, threshold, e.stream));
+        void* split = nullptr; int* stat = nullptr;
+        HF_TRY(tri_screen_begin(e, n_pairs, mr, &split, &stat));
+        HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, threshold, e.stream, split, stat));
+        HF_TRY(tri_screen_end(e, stat));
     } else {
         HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, th, e.m_s.p, e.stream, e.opt.match_screen_bf16));
     }
@@ -1656,7 +1692,7 @@ int hfnet_match_search_for_triangulation(hfnet_engine* eh, const float* d1, int 
     HF_HIP(hipMemcpyAsync(e.m_pairs.p, &P, sizeof P, hipMemcpyHostToDevice, e.stream));
     HF_HIP(hipStreamSynchronize(e.stream));     // P lives on this stack frame
     const float threshold = (float)(-0.5 * th_high * th_high + 1);   // Matcher.cc:851
-    HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), 1, max_rows, dim, threshold, e.stream));
+    HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), 1, max_rows, dim, threshold, e.stream, nullptr, nullptr));
     if (!on_device) {
         HF_HIP(hipMemcpyAsync(match12, d_match, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, e.stream));
         HF_HIP(hipMemcpyAsync(n_matches, d_cnt, sizeof(int), hipMemcpyDeviceToHost, e.stream));

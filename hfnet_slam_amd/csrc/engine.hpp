@@ -103,6 +103,7 @@ struct Options {
     int interleave = 3;       // calls of up to four frames: launch groups of the global branch enqueued between the local heads' launches,
                               // this many right after the detector conv (0: the whole branch after the local heads)
     int dedupe_taps = 1;      // sparse descriptor head: taps shared by neighbouring keypoints are evaluated once
+    int tri_screen_bf16 = 1;    // SearchForTriangulation (calls of >= 4 pairs): threshold screen on the bf16 matrix pipe + exact chains for the listed products; 0: full f32 GEMM
     int match_screen_bf16 = 1;  // SearchByBoW pre-selection on the bf16 matrix pipe (split operands, wider band); 0: f32 MFMA.  The matches are the exact ones either way
     int tail_fuse = 4;        // calls of up to this many frames run layers 8-18 with the single-frame kernels (0: never)
     int copy_threads = 64;    // helper threads of the host-pointer batch pipeline's staging copies (>= 64: chosen from the core count)
@@ -124,6 +125,13 @@ struct Engine {
     hipEvent_t ev_extract = nullptr, ev_match = nullptr;   // last on_device extraction / last hfnet_engine_fence
     bool ev_extract_set = false, ev_match_set = false;
     unsigned char* h_res = nullptr;                         // 1 MB pinned block for the small results of the store matchers (under mu)
+    // screened SearchForTriangulation (tri_screen_bf16) pays when few products exceed the threshold; on sets where most do, every pair
+    // overflows its list and runs the full path as well.  The screened path counts {overflowed pairs, pairs} on the device, the counts
+    // come down behind the call (no synchronisation: whatever has arrived by the next call is used), and after a call in which a
+    // quarter of the pairs overflowed the next tri_skip calls go straight to the full path.  The matches are the same either way.
+    DevMem m_tri_stat;
+    int* h_tri_stat = nullptr;                              // pinned {overflowed, pairs}
+    int tri_skip = 0;
     bool pinned_results(size_t bytes);                      // the block exists and holds `bytes`
     hipError_t note_extract(hipStream_t net_stream);        // record: extraction enqueued up to here
     hipError_t wait_extract();                              // matcher stream waits for it

@@ -158,7 +158,11 @@ hipError_t launch_store_remap(int n_pairs, const int* qsel, const int* tsel, con
 // fused multiply-add chains over k = 0..dim-1 (Matcher.cc:845-849) with the mutual arg-max (Matcher.cc:851-889) in the GEMM
 // epilogue.  Scratch per pair (BowPair::St): tri_scratch_floats(max_rows) floats of (maximum, index) partials, no n x m matrix.
 size_t tri_scratch_floats(int max_rows);
-hipError_t launch_tri_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float threshold, hipStream_t s);
+size_t tri_split_offset_bytes(int n_pairs, int max_rows);
+size_t tri_scratch_bytes(int n_pairs, int max_rows, int dim);
+// split_scratch: tri_scratch_bytes' second part (null: the full f32 path for every pair); stat: two device ints {pairs whose list
+// overflowed, pairs}, incremented by the screened path (may be null)
+hipError_t launch_tri_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float threshold, hipStream_t s, void* split_scratch, int* stat);
 // scratch: bow_scratch_bytes(n_pairs, max_rows, dim) bytes (candidate slots per train row and 64-query tile + the rows of every pair split
 // into bf16 pieces for the screening GEMM; no n x m matrix)
 size_t bow_scratch_bytes(int n_pairs, int max_rows, int dim);

@@ -35,8 +35,9 @@ struct TriPart { float v; int idx; };
 __host__ __device__ static inline int tri_tiles(int n) { return (n + 63) / 64; }
 size_t tri_scratch_floats(int max_rows) { return (size_t)4 * (size_t)max_rows * tri_tiles(max_rows); }   // two directions x 8 bytes
 
-__global__ __launch_bounds__(256) void k_tri_gemm_argmax(const BowPair* __restrict__ pairs, int dim, int max_rows) {
+__global__ __launch_bounds__(256) void k_tri_gemm_argmax(const BowPair* __restrict__ pairs, int dim, int max_rows, int only_flagged) {
     const BowPair P = pairs[blockIdx.z];
+    if (only_flagged && P.qkey[0] == 0ull) return;            // (after the screened path: only the pairs whose candidate list overflowed)
     const float* __restrict__ d1 = P.q; const float* __restrict__ d2 = P.t;
     const int n1 = P.nq, n2 = P.nt;
     constexpr int LD = 68;
@@ -149,8 +150,9 @@ __global__ __launch_bounds__(256) void k_tri_gemm_argmax(const BowPair* __restri
 }
 
 // column j: first row with the largest product above the threshold (Matcher.cc:877-889) -> P.tn (as int); resets the counter
-__global__ __launch_bounds__(256) void k_tri_cols(const BowPair* __restrict__ pairs, float threshold, int max_rows) {
+__global__ __launch_bounds__(256) void k_tri_cols(const BowPair* __restrict__ pairs, float threshold, int max_rows, int only_flagged) {
     const BowPair P = pairs[blockIdx.z];
+    if (only_flagged && P.qkey[0] == 0ull) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) *P.cnt = 0;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= P.nt) return;
@@ -165,8 +167,9 @@ __global__ __launch_bounds__(256) void k_tri_cols(const BowPair* __restrict__ pa
     ((int*)P.tn)[j] = bi;
 }
 // row i: first column with the largest product above the threshold, then the cross-check (Matcher.cc:860-893)
-__global__ __launch_bounds__(256) void k_tri_rows(const BowPair* __restrict__ pairs, float threshold, int max_rows) {
+__global__ __launch_bounds__(256) void k_tri_rows(const BowPair* __restrict__ pairs, float threshold, int max_rows, int only_flagged) {
     const BowPair P = pairs[blockIdx.z];
+    if (only_flagged && P.qkey[0] == 0ull) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if ((int)blockIdx.x * 256 >= P.nq) return;                     // workgroup-uniform
     int m = -1;
@@ -184,14 +187,6 @@ __global__ __launch_bounds__(256) void k_tri_rows(const BowPair* __restrict__ pa
     }
     const unsigned long long hit = __ballot(m >= 0);
     if ((threadIdx.x & 63) == 0 && hit) atomicAdd(P.cnt, __popcll(hit));
-}
-hipError_t launch_tri_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float threshold, hipStream_t s) {
-    if (n_pairs <= 0 || max_rows <= 0) return hipSuccess;
-    if (dim % 64 || (long long)max_rows * dim * 4 >= (1ll << 32)) return hipErrorInvalidValue;   // (32-bit lane offsets inside a descriptor set)
-    hipLaunchKernelGGL(k_tri_gemm_argmax, dim3((max_rows + 127) / 128, (max_rows + 127) / 128, n_pairs), dim3(256), 0, s, pairs, dim, max_rows);
-    hipLaunchKernelGGL(k_tri_cols, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, threshold, max_rows);
-    hipLaunchKernelGGL(k_tri_rows, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, threshold, max_rows);
-    return hipGetLastError();
 }
 
 // =========================================================================== SearchByBoW (BFMatcher)
@@ -269,6 +264,87 @@ __device__ float cv_l2_wave(const float* a, const float* b, int dim, int lane) {
     return sqrtf(s);
 }
 
+// ---- SearchForTriangulation, screened (engine option tri_screen_bf16; launches of several pairs).  Only products above
+// threshold = 1 - th^2 / 2 can be a row's or a column's best (Matcher.cc:851-889: both searches start from the threshold with a
+// strict >), and between descriptors of different scene points they are rare: the GEMM runs on the bf16 matrix pipe
+// (k_bow_gemm_cand<true, true>: split operands, three products) and lists every (row, column) whose product CAN exceed the
+// threshold (screened value + rigorous bound), k_tri_exact evaluates the listed products as the oracle's fma chains (k
+// ascending from 0) and keeps, per row and per column, the largest one above the threshold -- ties to the smaller index: the
+// reference's first maximum -- with a 64-bit atomic maximum on (product bits, ~index), k_tri_resolve does the cross-check.
+// The list lives in the pair's partial-maxima scratch (P.St); a pair whose list overflows (degenerate sets: most products
+// above the threshold) is flagged in P.qkey[0] and goes through the full f32 path afterwards (whose kernels return at once for
+// every other pair).  Same matches, bit for bit.
+struct TriCand { int i, j; };
+struct TriScreen { unsigned int* count; unsigned long long* rowkey; unsigned long long* colkey; TriCand* list; int cap; };
+__host__ __device__ static inline int tri_screen_cap(int max_rows) { return 2 * max_rows * (tri_tiles(max_rows) - 1) - 2; }
+__device__ __forceinline__ TriScreen tri_screen(float* St, int max_rows) {     // 16 + 16 max_rows + 8 cap bytes == the scratch of one pair
+    TriScreen t;
+    t.count = (unsigned int*)St;
+    t.rowkey = (unsigned long long*)(St + 4);
+    t.colkey = t.rowkey + max_rows;
+    t.list = (TriCand*)(t.colkey + max_rows);
+    t.cap = tri_screen_cap(max_rows);
+    return t;
+}
+__global__ __launch_bounds__(256) void k_tri_init(const BowPair* __restrict__ pairs, int max_rows) {
+    const BowPair P = pairs[blockIdx.z];
+    const TriScreen ts = tri_screen(P.St, max_rows);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *ts.count = 0u;
+    if (i < max_rows) { ts.rowkey[i] = 0ull; ts.colkey[i] = 0ull; }
+}
+// one thread per listed product: the oracle's chain, then the row's and the column's running best
+__global__ __launch_bounds__(64) void k_tri_exact(const BowPair* __restrict__ pairs, int dim, float thr, int max_rows) {
+    const BowPair P = pairs[blockIdx.z];
+    const TriScreen ts = tri_screen(P.St, max_rows);
+    const unsigned n = *ts.count;
+    if (n > (unsigned)ts.cap) return;                           // overflow: the full path takes this pair
+    const unsigned c = blockIdx.x * 64 + threadIdx.x;          // (one-wave workgroups: the few hundred waves of a launch spread over all CUs)
+    if (c >= n) return;
+    const TriCand e = ts.list[c];
+    const float* __restrict__ a = P.q + (long long)e.i * dim;
+    const float* __restrict__ b = P.t + (long long)e.j * dim;
+    float acc = 0.0f;
+    for (int k0 = 0; k0 < dim; k0 += 64) {                      // 32 row pieces in flight per lane (a lane walks its own two rows: latency, not bandwidth)
+        f32x4 av[16], bv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { av[q] = *(const f32x4*)(a + k0 + 4 * q); bv[q] = *(const f32x4*)(b + k0 + 4 * q); }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = fmaf(av[q][u], bv[q][u], acc);
+    }
+    if (acc > thr) {                                            // (thr > 0 in every use; guarded at launch: positive floats order like their bits)
+        const unsigned long long hi = (unsigned long long)__float_as_uint(acc) << 32;
+        atomicMax(&ts.rowkey[e.i], hi | (0xffffffffu - (unsigned)e.j));
+        atomicMax(&ts.colkey[e.j], hi | (0xffffffffu - (unsigned)e.i));
+    }
+}
+__global__ __launch_bounds__(256) void k_tri_resolve(const BowPair* __restrict__ pairs, int max_rows, int* __restrict__ stat) {
+    const BowPair P = pairs[blockIdx.z];
+    const TriScreen ts = tri_screen(P.St, max_rows);
+    const bool over = *ts.count > (unsigned)ts.cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        P.qkey[0] = over ? 1ull : 0ull;                         // read by the full path's kernels
+        if (stat) { if (over) atomicAdd(stat, 1); atomicAdd(stat + 1, 1); }      // {pairs that overflowed, pairs}: the engine's statistics
+    }
+    if (over) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if ((int)blockIdx.x * 256 >= P.nq) return;                  // workgroup-uniform
+    int m = -1;
+    if (i < P.nq) {
+        const unsigned long long rk = ts.rowkey[i];
+        if (rk) {
+            const int bj = (int)(0xffffffffu - (unsigned)rk);
+            const unsigned long long ck = ts.colkey[bj];       // (non-zero: (i, bj) itself raised it)
+            if ((int)(0xffffffffu - (unsigned)ck) == i) m = bj;
+        }
+        P.match[i] = m;
+    }
+    const unsigned long long hit = __ballot(m >= 0);
+    if ((threadIdx.x & 63) == 0 && hit) atomicAdd(P.cnt, __popcll(hit));
+}
+
 // ---- SearchByBoW without the similarity matrix.  S = Q * T^T is computed tile by tile on the matrix cores (128 queries x
 // 128 train rows per workgroup, 64 x 64 per wave, operands staged through LDS exactly as gemm_abt_tile128) and never
 // stored: with the TRAIN rows along the MFMA columns a lane holds, for its train row, 32 of the wave tile's 64 query
@@ -290,10 +366,12 @@ struct BowCand { unsigned int lo_bits; int q; };
 // the unit's own order (<= 2 * 3 dim * 2^-24 |q||t| even if its additions are only faithful): launch_bow_pairs widens the band.
 // The rows are split once per pair by k_bow_prep (which reads them anyway for the norms) into 16-byte pieces {hi x 4, lo x 4}
 // at the f32 pieces' addresses: this kernel's staging is the f32 form's, minus the k permutation.
-template <bool SPLIT>
+// TRI: the same GEMM as the screening pass of SearchForTriangulation (k_tri_* below): instead of candidate slots per train row
+// the epilogue appends every (row, column) whose product can exceed the similarity threshold `thr` to the pair's list.
+template <bool SPLIT, bool TRI = false>
 __global__ __launch_bounds__(256, 2) void k_bow_gemm_cand(const BowPair* __restrict__ pairs, int dim, float band, BowCand* __restrict__ cand,
                                                        unsigned char* __restrict__ overflow, int max_rows, int n_qt, int ct, const bf16x8* __restrict__ split,
-                                                       int a_gx, int a_gy, int a_n_pairs) {
+                                                       int a_gx, int a_gy, int a_n_pairs, float thr) {
     // A workgroup owns 128 queries and `ct` consecutive 128-row tiles of train rows: the k chunks of all its tiles are ONE
     // software pipeline (the first chunk of the next tile is in flight during the last MFMAs and the epilogue of this one), so
     // the load latency at the start of a tile -- 18 % of a 1000 x 1000 x 256 pair when every tile was its own workgroup -- is
@@ -313,6 +391,7 @@ __global__ __launch_bounds__(256, 2) void k_bow_gemm_cand(const BowPair* __restr
         }
     }
     if (pair >= n_pairs) return;
+    pair = __builtin_amdgcn_readfirstlane(pair); rest = __builtin_amdgcn_readfirstlane(rest);      // (uniform by construction: say so)
     const int bx = rest % gx, by = rest / gx;
     const BowPair P = pairs[pair];
     // (split form: the pair's two row blocks of the split array -- same piece offsets as the f32 rows)
@@ -423,6 +502,49 @@ __global__ __launch_bounds__(256, 2) void k_bow_gemm_cand(const BowPair* __restr
         const int tile = c / KC;
         if (c - tile * KC != KC - 1) continue;                // (uniform) the tile's last chunk: bounds and candidates per train column
         const int col0 = (ctile0 + tile) * 128;
+        if constexpr (TRI) {
+            const TriScreen ts = tri_screen(P.St, max_rows);
+            // (a pair whose list has overflowed is the full path's: stop counting -- on degenerate sets, where nearly every product
+            //  is above the threshold, a million atomics on one counter took 25 ms)
+            const bool full = __builtin_nontemporal_load(ts.count) > (unsigned)ts.cap;     // wave-uniform
+            if (row0 + wr < n1 && !full) {                    // (wave-uniform)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int tj = col0 + wc + j * 32 + r;
+                    const float tnj = P.tn[min(tj, n2 - 1)];
+                    // hits of this lane's column among the wave tile's 64 rows, as bits (i * 16 + reg): a compare and an OR per product
+                    unsigned hits = 0;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int rr = wr + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                            const float ub = fmaf(band, qns[rr] + tnj, acc[i][j][reg]);      // upper bound of the exact product
+                            hits |= (ub > thr && row0 + rr < n1 ? 1u : 0u) << (i * 16 + reg);
+                        }
+                    if (tj >= n2) hits = 0;
+                    if (__any(hits != 0)) {                    // (wave-uniform; a handful of hits per wave tile: one atomic per wave and column block)
+                        const unsigned n = (unsigned)__popc(hits);
+                        unsigned incl = n;
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) {
+                            const unsigned up = (unsigned)__shfl_up((int)incl, d, 64);
+                            if (lane >= d) incl += up;
+                        }
+                        unsigned base = 0;
+                        if (lane == 63) base = atomicAdd(ts.count, incl);
+                        base = (unsigned)__shfl((int)base, 63, 64) + incl - n;
+                        while (hits) {
+                            const int b = __builtin_ctz(hits);
+                            hits &= hits - 1;
+                            const int rr = wr + (b >> 4) * 32 + (b & 3) + 8 * ((b & 15) >> 2) + 4 * half;
+                            if (base < (unsigned)ts.cap) ts.list[base] = TriCand{row0 + rr, tj};
+                            ++base;
+                        }
+                    }
+                }
+            }
+        } else
         if (row0 + wr < n1) {                                 // (wave-uniform) a tile past the last query has no slots
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -506,6 +628,37 @@ __global__ __launch_bounds__(256, 2) void k_bow_gemm_cand(const BowPair* __restr
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     }
+}
+
+// SearchForTriangulation for all pairs.  split != null (engine option tri_screen_bf16, launches of several pairs): the screened path
+// described at k_tri_init, then the full f32 path for the pairs it flagged; otherwise the full path for every pair.
+hipError_t launch_tri_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float threshold, hipStream_t s, void* split_scratch, int* stat) {
+    if (n_pairs <= 0 || max_rows <= 0) return hipSuccess;
+    if (dim % 64 || (long long)max_rows * dim * 4 >= (1ll << 32)) return hipErrorInvalidValue;   // (32-bit lane offsets inside a descriptor set)
+    const int t128 = (max_rows + 127) / 128;
+    const bool screened = split_scratch && n_pairs >= 4 && tri_tiles(max_rows) >= 2 && threshold > 0.0f;
+    if (screened) {
+        // |S~ - S| for the exact chain S: the split loses 1.5 * 2^-18 (|a|^2 + |b|^2), the unit's accumulation of 3 dim exact
+        // products at most 3 dim u (|a|^2 + |b|^2) (faithful additions), the chain itself 0.5 dim u (...): 5.9e-5 for dim 256;
+        // the bound used is twice that
+        const float band = 5e-7f * (float)dim;
+        bf16x8* split = (bf16x8*)split_scratch;
+        hipLaunchKernelGGL(k_bow_prep, dim3((2 * max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim, split, max_rows);
+        hipLaunchKernelGGL(k_tri_init, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, max_rows);
+        int ct = 1;
+        while (ct < 4 && ct * 2 <= t128 && (long long)((t128 + 2 * ct - 1) / (2 * ct)) * t128 * n_pairs >= 512) ct *= 2;
+        const int gx = (t128 + ct - 1) / ct;
+        if ((long long)gx * t128 * n_pairs > 0x7fffffffll) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_bow_gemm_cand<true, true>), dim3((unsigned)(gx * t128 * n_pairs)), dim3(256), 0, s, pairs, dim, band, (BowCand*)nullptr,
+                           (unsigned char*)nullptr, max_rows, 0, ct, split, gx, t128, n_pairs, threshold);
+        hipLaunchKernelGGL(k_tri_exact, dim3((tri_screen_cap(max_rows) + 63) / 64, 1, n_pairs), dim3(64), 0, s, pairs, dim, threshold, max_rows);
+        hipLaunchKernelGGL(k_tri_resolve, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, max_rows, stat);
+    }
+    const int only_flagged = screened ? 1 : 0;
+    hipLaunchKernelGGL(k_tri_gemm_argmax, dim3(t128, t128, n_pairs), dim3(256), 0, s, pairs, dim, max_rows, only_flagged);
+    hipLaunchKernelGGL(k_tri_cols, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, threshold, max_rows, only_flagged);
+    hipLaunchKernelGGL(k_tri_rows, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, threshold, max_rows, only_flagged);
+    return hipGetLastError();
 }
 
 // every train row: the candidates of all its query tiles -> exact OpenCV distances -> nearest query (first minimum in
@@ -835,6 +988,10 @@ static size_t bow_cand_bytes(int n_pairs, int max_rows) {      // candidate slot
     const size_t n_qt = (size_t)(max_rows + 63) / 64;
     return ((size_t)n_pairs * max_rows * n_qt * 2 * (BOW_SLOTS * sizeof(BowCand) + 1) + 15) & ~(size_t)15;
 }
+size_t tri_split_offset_bytes(int n_pairs, int max_rows) { return ((size_t)n_pairs * tri_scratch_floats(max_rows) * sizeof(float) + 15) & ~(size_t)15; }
+size_t tri_scratch_bytes(int n_pairs, int max_rows, int dim) {   // partial maxima / candidate lists + the split rows of the screened path
+    return tri_split_offset_bytes(n_pairs, max_rows) + (size_t)n_pairs * 2 * max_rows * dim * sizeof(float);
+}
 size_t bow_scratch_bytes(int n_pairs, int max_rows, int dim) {  // + the split rows of both sets of every pair (split-bf16 screening)
     return bow_cand_bytes(n_pairs, max_rows) + (size_t)n_pairs * 2 * max_rows * dim * sizeof(float);
 }
@@ -867,9 +1024,9 @@ hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int
     if ((long long)gx * t128 * n_pairs > 0x7fffffffll) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(gx * t128 * n_pairs));
     if (screen_bf16)
-        hipLaunchKernelGGL(k_bow_gemm_cand<true>, grid, dim3(256), 0, s, pairs, dim, band, cand, overflow, max_rows, n_qt, ct, split, gx, t128, n_pairs);
+        hipLaunchKernelGGL(k_bow_gemm_cand<true>, grid, dim3(256), 0, s, pairs, dim, band, cand, overflow, max_rows, n_qt, ct, split, gx, t128, n_pairs, 0.0f);
     else
-        hipLaunchKernelGGL(k_bow_gemm_cand<false>, grid, dim3(256), 0, s, pairs, dim, band, cand, overflow, max_rows, n_qt, ct, nullptr, gx, t128, n_pairs);
+        hipLaunchKernelGGL(k_bow_gemm_cand<false>, grid, dim3(256), 0, s, pairs, dim, band, cand, overflow, max_rows, n_qt, ct, nullptr, gx, t128, n_pairs, 0.0f);
     if (dim == 256) {
         int rpw = BOWC_ROWS;                                  // train rows per wave: 8 when the launch has waves to spare (measured: 32 pairs of 1000 rows 16 / 8 / 4 / 2 -> 30 / 20 / 23 / 25 us)
         while (rpw > 1 && (long long)((max_rows + 4 * rpw - 1) / (4 * rpw)) * n_pairs < 512) rpw >>= 1;

@@ -98,6 +98,10 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *   "match_screen_bf16" (1)  SearchByBoW pre-selects on the bf16 matrix pipe (operands split into two bf16 pieces, three products,
  *                       a wider rounding band); 0: on the f32 MFMA.  Every candidate inside the band is re-evaluated exactly
  *                       either way: matches and distances are the same bits
+ *   "tri_screen_bf16" (1)  SearchForTriangulation, calls of >= 4 pairs: the products that can exceed the similarity threshold are
+ *                       found on the bf16 matrix pipe (split operands, rigorous bound) and evaluated as the exact fma chains; a pair
+ *                       with too many of them goes through the full f32 GEMM instead, and after a call in which a quarter of the
+ *                       pairs did, the next 16 calls skip the screen (writing the option resets that).  Same matches, bit for bit
  *   "copy_threads" (64 = by core count): helper threads for the staging copies of host-pointer batch calls (replicas sharing a host)
  * Values are >= 0.
  * Every setting of the extractor and matcher switches produces the same bits (tests/test_gpu_parity.py). */

@@ -428,6 +428,44 @@ def test_batched_triangulation_matches_per_pair_calls(engine):
             _eq("single", m1, rm)
 
 
+@pytest.mark.parametrize("tri_screen", [1, 0])
+def test_triangulation_screened_path(engine, tri_screen):
+    """SearchForTriangulation for several pairs with the threshold screen on the bf16 matrix pipe (engine option tri_screen_bf16)
+    against the full f32 path and the oracle: planted matches, exact duplicates on both sides (first-maximum ties), products a few
+    ulp around the threshold 1 - th^2 / 2, non-unit norms, ragged and empty sets, and a degenerate pair whose candidate list
+    overflows (every product above the threshold) and has to come back through the full path -- next to ordinary pairs."""
+    from oracle import oracle as O
+    engine.set_option("tri_screen_bf16", tri_screen)
+    try:
+        rng = np.random.default_rng(41)
+        mr, th = 320, 0.75
+        thr = np.float32(-0.5 * th * th + 1)
+        base = _unit_rows(rng, mr)
+        sets = np.zeros((8, mr, 256), np.float32)
+        n_rows = np.array([320, 301, 320, 7, 0, 320, 320, 200], np.int32)
+        for s_ in (0, 1, 2, 3, 7):
+            v = base[rng.permutation(mr)] + 0.02 * (s_ + 1) * rng.standard_normal((mr, 256)).astype(np.float32)
+            sets[s_] = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+        sets[1, 5] = sets[0, 9]; sets[1, 17] = sets[0, 9]; sets[0, 40] = sets[0, 9]        # duplicates: ties on rows and columns
+        # set 2: rows at products a few ulp around the threshold with set 0's rows (b = a * c + orthogonal rest)
+        for k in range(0, 60):
+            a = sets[0, k].astype(np.float64)
+            o = rng.standard_normal(256); o -= o.dot(a) * a; o /= np.linalg.norm(o)
+            c = float(thr) + (k - 30) * 3e-8
+            sets[2, k] = (c * a + np.sqrt(max(1 - c * c, 0.0)) * o).astype(np.float32)
+        sets[5] = np.repeat(base[:1], mr, axis=0) + 1e-4 * rng.standard_normal((mr, 256)).astype(np.float32)      # degenerate: all alike
+        sets[6] = 3.0 * sets[5]                                                                                   # ... at a norm of 3
+        pairs = [(0, 1), (1, 0), (0, 2), (2, 0), (0, 3), (3, 0), (0, 4), (4, 0), (5, 5), (5, 6), (0, 7), (7, 1), (5, 0), (2, 2)]
+        cnt, match = engine.search_for_triangulation_batch(sets, n_rows, pairs, th)
+        for p, (a, b) in enumerate(pairs):
+            d1, d2 = sets[a, :n_rows[a]], sets[b, :n_rows[b]]
+            rn, rm = O.search_for_triangulation(d1, d2, th)
+            assert cnt[p] == rn, (p, (a, b), cnt[p], rn)
+            _eq(f"pair {p} {(a, b)}", match[p, :n_rows[a]], rm)
+    finally:
+        engine.set_option("tri_screen_bf16", 1)
+
+
 @pytest.mark.parametrize("streams", [0, 1, 2, 3])
 def test_device_resident_pipeline_matches_host_path(engine, streams, engine_options):
     """bench.py's path: on_device extract_batch + batched SearchByBoW over consecutive steps, the global branch on its own
