@@ -18,5 +18,5 @@ srt = np.sort(D2, axis=1)
 print("nearest d^2: min %.3g med %.3g max %.3g" % (srt[:, 0].min(), np.median(srt[:, 0]), srt[:, 0].max()))
 print("gap 2nd-1st d^2: min %.3g med %.3g" % ((srt[:, 1] - srt[:, 0]).min(), np.median(srt[:, 1] - srt[:, 0])))
 print("mean d^2 %.3g  spread (std of all d^2) %.3g" % (D2.mean(), D2.std()))
-for band in (1e-5, 6e-5, 1e-4, 1e-3):
+for band in (1e-5, 6e-5, 1e-4, 1e-3, 1.3e-3, 4e-3, 1.6e-2, 3.2e-2):
     print("band", band, "avg candidates per row within band of the row minimum:", ((D2 <= srt[:, :1] + band).sum(1)).mean())
