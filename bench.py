@@ -44,6 +44,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA (v_mfma_f32
 MFMA_BF16_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense bf16 MFMA (16 x the f32 rate); only the matcher's screening GEMM runs there
 TRAFFIC_FILES = [os.path.join("profiles", r + "_traffic_b{batch}.json") for r in ("r03", "r02")]     # newest first; one file per frames-per-call value
 ALL_CONFIGS = ["2-latency", "2-host-io", "3", "4", "5"]
+DEFAULT_CHUNK = 128            # frames per extract / match call of the headline (tests/test_gpu_fullsize.py checks THIS size against the oracle)
+DEFAULT_BATCH = 768            # frames per step and GPU
 
 
 # ------------------------------------------------------------------------------------------------ work model
@@ -202,6 +204,26 @@ def make_frames(count: int, first_index: int, kind: str = "uniform", w: int = W_
     return out
 
 
+def make_natural_frames_device(torch, dev, count: int, first_index: int, w: int = W_IMG, h: int = H_IMG):
+    """make_frames(..., "natural") evaluated on the GPU (the numpy form takes 80 ms per frame on the host): the same seeded
+    noise grids, the same bilinear up-sampling in float64 -- equal to the host form up to the rounding of the interpolation.
+    Used for `value_natural` only; the frames that are compared with the oracle come from make_frames."""
+    out = torch.empty((count, h, w), dtype=torch.uint8, device=dev)
+    for i in range(count):
+        rng = np.random.default_rng(1000 + first_index + i)
+        acc = torch.zeros((h, w), dtype=torch.float64, device=dev)
+        for o in range(6):
+            gh, gw = 2 + (h >> (6 - o)), 2 + (w >> (6 - o))
+            g = torch.from_numpy(rng.random((gh, gw))).to(dev)
+            ys = torch.linspace(0, gh - 1.001, h, dtype=torch.float64, device=dev); xs = torch.linspace(0, gw - 1.001, w, dtype=torch.float64, device=dev)
+            y0 = ys.long(); x0 = xs.long(); fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+            up = (g[y0][:, x0] * (1 - fy) * (1 - fx) + g[y0][:, x0 + 1] * (1 - fy) * fx + g[y0 + 1][:, x0] * fy * (1 - fx) + g[y0 + 1][:, x0 + 1] * fy * fx)
+            acc += up * 0.5 ** (5 - o)
+        acc = (acc - acc.min()) / (acc.max() - acc.min())
+        out[i] = torch.clamp(acc * 1.2 * 255.0 - 25.0, 0, 255).to(torch.uint8)
+    return out
+
+
 def unit_rows(rng, n, d):
     a = rng.standard_normal((n, d)).astype(np.float32)
     return (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
@@ -257,6 +279,49 @@ def cpu_baseline(weights_path: str, budget_s: float = 24.0):
                          "search_by_bow_1000x1000_ms": t_match * 1e3, "search_for_triangulation_1000x1000_ms": t_tri * 1e3,
                          "db_scan_10000x4096_ms": t_db * 1e3, "matcher_db_threads": half,
                          "windowed_candidates_8_threads_us": float(np.median(t_w)) * 1e6, "windowed_candidates_threads": min(8, cores)}}
+
+
+def verify_last_chunk(torch, pipe, weights_path, cur_frames, prev_frames, which, threads):
+    """The checker, outside the timed region: outputs of the LAST TIMED chunk as the pipeline left them in HBM -- keypoints,
+    descriptors, global descriptor, and the SearchByBoW matches / distances / count against the predecessor frame -- compared bit
+    for bit with the oracle (oracle/, the CPU restatement) for the chunk frames `which`.  Frame 0's predecessor is the last frame
+    of the chunk before.  Returns {"frames", "equal", "checked", "mismatch"}; bench.py exits non-zero when equal is false."""
+    from oracle import oracle as O
+    O.build()
+    O.set_threads(threads)
+    m = O.Model(weights_path)
+    B, nb = pipe.B, pipe.n_buf
+    s0 = ((pipe.cur - 1) % nb) * B                       # buffer block the last run_chunk wrote
+    imgs = cur_frames.cpu().numpy()
+    prev_last = prev_frames[B - 1].cpu().numpy()
+    cache = {}
+
+    def ref(f):                                            # f = -1: the previous chunk's last frame
+        if f not in cache:
+            cache[f] = m.extract(prev_last if f < 0 else imgs[f], N_FEAT, THRESH, N_LEVELS, SCALE)
+        return cache[f]
+
+    bad = []
+    for f in which:
+        rn, rk, rd, rg, _ = ref(f)
+        slot = s0 + f
+        n = int(pipe.n_rows[slot].item())
+        k = pipe.kps[slot].cpu().numpy(); d = pipe.desc[slot].cpu().numpy(); g = pipe.glob[f].cpu().numpy()
+        ok = {"count": n == rn}
+        if n == rn:
+            ok["kps_xy_response"] = all(np.array_equal(k[:n, j], rk[name]) for j, name in enumerate(("x", "y", "response")))
+            ok["kps_octave"] = np.array_equal(k[:n, 3].view(np.int32), rk["octave"])
+            ok["descriptors"] = np.array_equal(d[:n], rd)
+        ok["global"] = np.array_equal(g, rg)
+        qn, _, qd, _, _ = ref(f - 1)                       # query = the predecessor frame (Pipeline._default_pairs)
+        rc, rm, rdist = O.search_by_bow(qd, rd, TH_LOW)
+        ok["match_count"] = int(pipe.mcnt[f].item()) == rc
+        ok["matches"] = np.array_equal(pipe.match[f].cpu().numpy()[:qn], rm)
+        ok["distances"] = np.array_equal(pipe.mdist[f].cpu().numpy()[:qn], rdist)
+        bad += [f"frame {f}: {name}" for name, v in ok.items() if not v]
+    return {"frames": list(which), "equal": not bad, "mismatch": bad,
+            "checked": "keypoints (x, y, response, octave), descriptors, global descriptor, SearchByBoW matches + distances + count vs the predecessor "
+                       "frame, np.array_equal against oracle/libhfnet_oracle.so, read from the device buffers of the last timed chunk"}
 
 
 # ------------------------------------------------------------------------------------------------ headline pipeline
@@ -680,11 +745,13 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=768, help="frames per step and GPU")
-    ap.add_argument("--chunk", type=int, default=128, help="frames per extract / match call (the extractor's batch)")
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="frames per step and GPU")
+    ap.add_argument("--chunk", type=int, default=DEFAULT_CHUNK, help="frames per extract / match call (the extractor's batch)")
     ap.add_argument("--frames", choices=["uniform", "natural"], default="uniform", help="synthetic frame distribution (SURVEY.md 8d)")
     ap.add_argument("--configs", default="all", help="comma list of sub-records to measure besides the headline: " + ",".join(ALL_CONFIGS) + " | all | none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-natural", action="store_true", help="skip value_natural (the headline workload on natural-ish frames)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of the last timed chunk's outputs (the line then says so)")
     ap.add_argument("--profile-all", action="store_true", help="also print the per-launch timing table to stderr")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option (hfnet_engine_set_option), e.g. fused_variant=2")
     ap.add_argument("--dry-ranks", type=int, default=0, metavar="N",
@@ -778,6 +845,15 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def per_rank(value):
+        """[value of rank 0, ..., value of rank N-1] on every rank (one SUM all-reduce of a one-hot vector: bookkeeping, not data path)"""
+        if dist is None:
+            return [float(value)]
+        t = torch.zeros((world,), dtype=torch.float64, device=dev)
+        t[rank] = float(value)
+        dist.all_reduce(t)
+        return [float(v) for v in t.cpu()]
+
     # ---- warm-up, budget check; then the per-launch profile (single stream, every kernel alone) on a WARM chip -----
     work = layer_work(B)
     prof, table, classes, dominant, prof_sum_s = {}, [], {}, None, 0.0
@@ -805,12 +881,43 @@ def main() -> None:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    pipe.eng.synchronize()
+    dev_sync()
+    own_elapsed = time.perf_counter() - t0               # this rank's own work, before it waits for the others
     sync_all()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    rank_fps = [args.batch * args.steps / max(t, 1e-12) for t in per_rank(own_elapsed)]
     dom = (0, 0.0)
+    verified = natural = None
     if not dry:
         dom = eng.profile().get(dominant, (0, 0.0))
         eng.profile_enable(False); eng.profile_filter(None)
+        if not args.no_verify and args.steps > 0:
+            # ---- outside the timed region: sampled outputs of the LAST TIMED chunk against the oracle, on every rank ----
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            last, before = frames[(state["i"] - 1) % n_sets], frames[(state["i"] - 2) % n_sets]
+            verified = verify_last_chunk(torch, pipe, wpath, last, before, sorted({0, 1, B - 1}), max(1, min(32, cores // world)))
+            if dist is not None:
+                okt = torch.tensor([1 if verified["equal"] else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                verified["equal_all_ranks"] = bool(okt.item())
+                verified["ranks"] = world
+        if args.frames == "uniform" and not args.no_natural:
+            # ---- the headline workload on the second synthetic distribution of SURVEY.md 8(d) ("natural-ish" frames) -------
+            nat = make_natural_frames_device(torch, dev, n_sets * B, rank * n_sets * B).view(n_sets, B, H_IMG, W_IMG)
+            dev_sync()
+            uni, frames = frames, [nat[s_] for s_ in range(n_sets)]
+            nat_steps = max(1, min(args.steps, 6))
+            i_keep = state["i"]
+            step(); sync_all()
+            tn = time.perf_counter()
+            for _ in range(nat_steps):
+                n_last = step()
+            sync_all()
+            natural = {"frames_per_s": world * args.batch * nat_steps / max_over_ranks(time.perf_counter() - tn), "steps": nat_steps,
+                       "min_keypoints": int(n_last.min().item())}
+            frames = uni
+            state["i"] = i_keep
 
     out = None
     if rank == 0:
@@ -856,6 +963,14 @@ def main() -> None:
             roof["classes"] = {k: rnd(v) for k, v in sorted(classes.items(), key=lambda kv: -kv[1]["us"])}
             roof["table"] = [rnd(r) for r in table]
             out.update({"roofline": roof, "build_id": capi.build_id(), "options": eng.options()})
+            if natural is not None:
+                out["value_natural"] = natural["frames_per_s"]
+                out["value_natural_min_keypoints"] = natural["min_keypoints"]
+                out["value_natural_note"] = (f"the headline workload on the 'natural-ish' frames of SURVEY.md 8(d) (six octaves of up-sampled noise), "
+                                             f"{natural['steps']} steps after one warm-up step; `value` is on iid uniform frames")
+            out["verified"] = verified if verified is not None else {"frames": [], "equal": None, "skipped": "--no-verify"}
+        if world > 1:
+            out["per_rank_frames_per_s"] = {"min": min(rank_fps), "max": max(rank_fps), "all": [round(v, 1) for v in rank_fps]}
         if os.environ.get("BENCH_DEV_NO_MATCH"):
             out["invalid"] = "development run: the matcher was skipped (BENCH_DEV_NO_MATCH)"
 
@@ -865,6 +980,16 @@ def main() -> None:
         r = config_sequences(torch, pipe, dev, rank, world, dist, dry=dry)
         if rank == 0:
             configs["4"] = r
+    if world > 1 and not dry and "2-host-io" in want:
+        # N replicas feed from ONE host: the host-fed rate is the number the ranks contend for (pageable staging)
+        dist.barrier()
+        r = config_host_io(capi, eng, B)
+        hio = per_rank(r["extract_plus_match_frames_per_s"])
+        if rank == 0:
+            r["per_rank_extract_plus_match_frames_per_s"] = {"min": min(hio), "max": max(hio), "all": [round(v, 1) for v in hio]}
+            r["note"] = "all ranks run this leg at the same time; value_host_io is the sum over ranks"
+            configs["2-host-io"] = r
+            out["value_host_io"] = sum(hio)
     if rank == 0 and world == 1 and not dry:
         if "2-latency" in want:
             configs["2-latency"] = config_latency(capi, eng)
@@ -890,6 +1015,8 @@ def main() -> None:
     pipe.close()
     if eng is not None:
         eng.close()
+    if verified is not None and not (verified["equal"] and verified.get("equal_all_ranks", True)):
+        raise SystemExit("bench.py: outputs of the timed run differ from the oracle: " + "; ".join(verified["mismatch"]))
 
 
 if __name__ == "__main__":

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace hfnet {
 
@@ -50,6 +51,7 @@ Engine::~Engine() {
     if (h_tri_stat) (void)hipHostFree(h_tri_stat);
     if (ev_extract) (void)hipEventDestroy(ev_extract);
     if (ev_match) (void)hipEventDestroy(ev_match);
+    if (ev_tri_stat) (void)hipEventDestroy(ev_tri_stat);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -76,6 +78,17 @@ hipError_t Engine::wait_extract() {
 hipError_t Engine::wait_fence(hipStream_t net_stream) {
     std::lock_guard<std::mutex> lk(ev_mu);
     return ev_match_set ? hipStreamWaitEvent(net_stream, ev_match, 0) : hipSuccess;
+}
+
+// one polite spin iteration of the host waits on the pinned flags (the pause intrinsic is x86-only)
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
 }
 
 template <class T>
@@ -661,7 +674,7 @@ int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value) {
     *p = value;
     if (std::strcmp(name, "tri_screen_bf16") == 0) {          // (writing the option also forgets what earlier calls found: Engine::tri_skip)
         e->impl.tri_skip = 0;
-        if (e->impl.h_tri_stat) { (void)hipStreamSynchronize(e->impl.stream); e->impl.h_tri_stat[0] = 0; e->impl.h_tri_stat[1] = 0; }
+        if (e->impl.h_tri_stat) { (void)hipStreamSynchronize(e->impl.stream); e->impl.tri_stat_pending = false; }
     }
     return HFNET_OK;
 }
@@ -883,7 +896,8 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
             HF_TRY(dalloc(x->allocs, &x->d_seq, 3));
             HF_HIP(hipMemset(x->d_seq, 0, 3 * sizeof(int)));
             void* hp = nullptr;
-            if (hipHostMalloc(&hp, off, hipHostMallocDefault) == hipSuccess) { x->h_pin = (unsigned char*)hp; x->pinned_frames = pf; *(volatile int*)(x->h_pin + x->pin_flag) = 0; *(volatile int*)(x->h_pin + x->pin_flag + 128) = 0; }
+            // (coherent: kernels write results and the call's number into this block while the host spins on it mid-graph)
+            if (hipHostMalloc(&hp, off, hipHostMallocCoherent) == hipSuccess) { x->h_pin = (unsigned char*)hp; x->pinned_frames = pf; *(volatile int*)(x->h_pin + x->pin_flag) = 0; *(volatile int*)(x->h_pin + x->pin_flag + 128) = 0; }
             else (void)hipGetLastError();
         }
     }
@@ -1204,23 +1218,28 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
             }
             stamp(0);
             const int expected = ++x->seq_host;
-            HF_TRY(extract_chunk_graphed(x, nb));
+            volatile int* flag = (volatile int*)(x->h_pin + x->pin_flag);
+            volatile int* gflag = (volatile int*)(x->h_pin + x->pin_flag + 128);
+            // an error between here and the waits below leaves the host's numbering ahead of the device's (the graph that bumps
+            // it may never have been enqueued): drain the stream and take the numbers the device really wrote, or the next
+            // call would spin its full 20 ms for a number that never comes
+            auto resync = [&]() { (void)hipStreamSynchronize(st); (void)hipGetLastError(); x->seq_host = *flag; x->gseq_host = *gflag; };
+            if (int rc = extract_chunk_graphed(x, nb)) { resync(); return rc; }
             const hfnet_extractor::ResOff o = x->result_offsets(nb, G);
             const float* blk_desc = (const float*)(x->d_blk + o.d);
             const int* blk_n = (const int*)(x->d_blk + o.n);
-            HF_TRY(copy_chunk_to_store(x, f0, nb, blk_desc, blk_n, st));
+            if (int rc = copy_chunk_to_store(x, f0, nb, blk_desc, blk_n, st)) { resync(); return rc; }
             stamp(1);
             // the keypoints and descriptors (1 MB per frame) are unpacked while the GPU is still busy with the global branch:
             // spin until the counter that follows them into the pinned block shows this call's number (bounded; a call that
             // never sees it simply waits for the stream)
-            volatile int* flag = (volatile int*)(x->h_pin + x->pin_flag);
             {
                 const auto t_spin = std::chrono::steady_clock::now();
                 for (unsigned it = 0; *flag != expected; ++it) {
-                    __builtin_ia32_pause();
+                    cpu_relax();
                     if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(20)) break;
                 }
-                if (*flag != expected) HF_HIP(hipStreamSynchronize(st));
+                if (*flag != expected && hipStreamSynchronize(st) != hipSuccess) { resync(); set_error("hipStreamSynchronize failed in the latency path"); return HFNET_ERR_DEVICE; }
                 std::atomic_thread_fence(std::memory_order_acquire);
             }
             stamp(2);
@@ -1242,11 +1261,10 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
             if (x->global_to_host(nb)) {
                 // the global descriptors arrive the same way: written into the pinned block by the last kernel of the branch,
                 // followed by the call's number (no copy after the join, no stream synchronisation on the way out)
-                volatile int* gflag = (volatile int*)(x->h_pin + x->pin_flag + 128);
                 const int gexpected = ++x->gseq_host;
                 const auto t_spin = std::chrono::steady_clock::now();
                 for (unsigned it = 0; *gflag != gexpected; ++it) {
-                    __builtin_ia32_pause();
+                    cpu_relax();
                     if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(20)) break;
                 }
                 if (*gflag != gexpected) HF_HIP(hipStreamSynchronize(st));   // (the graph / the join event bring the branch's stream in)
@@ -1333,8 +1351,20 @@ static int tri_screen_begin(Engine& e, int n_pairs, int max_rows, void** split, 
         e.h_tri_stat = (int*)hp; e.h_tri_stat[0] = 0; e.h_tri_stat[1] = 0;
     }
     HF_TRY(e.m_tri_stat.ensure(2 * sizeof(int)));
-    volatile int* h = e.h_tri_stat;
-    if (h[1] > 0 && h[0] * 4 >= h[1]) { e.tri_skip = 16; h[0] = 0; h[1] = 0; }
+    // the counts of the last screened call come down behind it without a synchronisation: they are looked at only once the event
+    // behind that copy has completed (the host never writes the pinned words, so it does not race the DMA engine).  A device-
+    // resident caller that runs ahead of the GPU simply decides one call later -- the matches are the same bits either way;
+    // worst case of the adaptive state: one call in 17 pays the screened path's overflow (the full f32 path re-run for the
+    // overflowed pairs, ~2x the call) on descriptor sets in which most products exceed the threshold.
+    if (e.tri_stat_pending) {
+        const hipError_t q = hipEventQuery(e.ev_tri_stat);
+        if (q == hipSuccess) {
+            e.tri_stat_pending = false;
+            volatile int* h = e.h_tri_stat;
+            if (h[1] > 0 && h[0] * 4 >= h[1]) e.tri_skip = 16;
+        } else if (q != hipErrorNotReady) HF_HIP(q);
+        else (void)hipGetLastError();
+    }
     if (e.tri_skip > 0) { --e.tri_skip; return HFNET_OK; }
     HF_HIP(hipMemsetAsync(e.m_tri_stat.p, 0, 2 * sizeof(int), e.stream));
     *split = (unsigned char*)e.m_s.p + tri_split_offset_bytes(n_pairs, max_rows);
@@ -1342,7 +1372,12 @@ static int tri_screen_begin(Engine& e, int n_pairs, int max_rows, void** split, 
     return HFNET_OK;
 }
 static int tri_screen_end(Engine& e, int* stat) {
-    if (stat) HF_HIP(hipMemcpyAsync(e.h_tri_stat, stat, 2 * sizeof(int), hipMemcpyDeviceToHost, e.stream));
+    if (stat) {
+        HF_HIP(hipMemcpyAsync(e.h_tri_stat, stat, 2 * sizeof(int), hipMemcpyDeviceToHost, e.stream));
+        if (!e.ev_tri_stat) HF_HIP(hipEventCreateWithFlags(&e.ev_tri_stat, hipEventDisableTiming));
+        HF_HIP(hipEventRecord(e.ev_tri_stat, e.stream));
+        e.tri_stat_pending = true;
+    }
     return HFNET_OK;
 }
 
@@ -1547,8 +1582,12 @@ int hfnet_store_put_extracted(hfnet_store* st, int slot, hfnet_extractor* x, int
     Engine& e = st->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
     HF_HIP(hipSetDevice(e.device));
-    // the extraction that filled the staging buffers was synchronised by its host-pointer call; the copies are ordered
-    // before later matches by the engine stream, and before the next extraction by the synchronisation below
+    // Invariant relied on (no stream drain any more: with host_global the host-pointer call returns while the global branch may
+    // still run): the LOCAL section of the extractor's device block (descriptors, counts) is complete once the host has seen the
+    // local-results flag -- the call does not return before that, and the flag follows the download of that section on the
+    // stream -- and nothing writes it again before the NEXT extraction, which waits for the event recorded below
+    // (Engine::wait_fence, unconditional at the top of every extraction).  Later matches are ordered behind these copies by the
+    // engine stream.
     const float* src_desc = x->last_desc ? x->last_desc : x->d_desc;
     const int* src_n = x->last_cnt ? x->last_cnt : x->d_n;
     if (n) HF_HIP(hipMemcpyAsync(st->d_desc + (size_t)slot * st->max_rows * st->dim, src_desc + (size_t)frame * x->n_features * HFNET_DESC_DIM,

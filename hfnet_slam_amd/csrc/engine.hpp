@@ -132,6 +132,8 @@ struct Engine {
     DevMem m_tri_stat;
     int* h_tri_stat = nullptr;                              // pinned {overflowed, pairs}
     int tri_skip = 0;
+    hipEvent_t ev_tri_stat = nullptr;                       // recorded behind the statistics copy of the last screened call
+    bool tri_stat_pending = false;                          // a copy into h_tri_stat has been enqueued and not been consumed yet
     bool pinned_results(size_t bytes);                      // the block exists and holds `bytes`
     hipError_t note_extract(hipStream_t net_stream);        // record: extraction enqueued up to here
     hipError_t wait_extract();                              // matcher stream waits for it

@@ -18,6 +18,7 @@
 #ifndef HFNETHIPMODEL_H
 #define HFNETHIPMODEL_H
 
+#include <algorithm>
 #include <iostream>
 #include <mutex>
 #include <string>
@@ -328,6 +329,15 @@ public:
         return true;
     }
 
+    // forget every resident block (called from KeyFrameDatabase::clear(), i.e. on Tracking::Reset / ResetActiveMap, after which
+    // keyframe ids start again at 0: the blocks stay allocated, the next use of an id uploads its descriptors afresh)
+    void Clear()
+    {
+        std::lock_guard<std::mutex> lock(mMutex);
+        mSlotOfId.clear();
+        std::fill(mvSlotUsed.begin(), mvSlotUsed.end(), 0ull);
+    }
+
 private:
     HIPKeyFrameStore() {}
     ~HIPKeyFrameStore() { hfnet_store_destroy(mpStore); }
@@ -343,7 +353,7 @@ private:
             mpStore = nullptr; mbOff = true;
             return false;
         }
-        mvSlotId.assign(mnSlots, 0); mvSlotUsed.assign(mnSlots, 0);
+        mvSlotId.assign(mnSlots, 0); mvSlotUsed.assign(mnSlots, 0); mvSlotPtr.assign(mnSlots, nullptr);
         return true;
     }
 
@@ -354,6 +364,15 @@ private:
             (int)vbHasPoint.size() < desc.rows) return -1;
         int slot;
         auto it = mSlotOfId.find(nId);
+        // a resident hit must still BE this keyframe: Tracking::Reset restarts KeyFrame::nNextId at 0 (src/Tracking.cc:3231), so an
+        // id can come back with other descriptors (Clear() below handles the reset; the row count and the address of the
+        // immutable descriptor block catch whatever reaches here without one)
+        if (it != mSlotOfId.end() && (hfnet_store_rows(mpStore, it->second) != desc.rows || mvSlotPtr[it->second] != (const void*)desc.ptr<float>()))
+        {
+            mvSlotUsed[it->second] = 0;
+            mSlotOfId.erase(it);
+            it = mSlotOfId.end();
+        }
         if (it != mSlotOfId.end()) slot = it->second;
         else
         {
@@ -362,7 +381,7 @@ private:
             if (mvSlotUsed[slot] == mnClock) return -1;                                           // every slot is part of this call
             if (mvSlotUsed[slot]) mSlotOfId.erase(mvSlotId[slot]);
             if (hfnet_store_put(mpStore, slot, desc.ptr<float>(), desc.rows) != HFNET_OK) return -1;
-            mSlotOfId[nId] = slot; mvSlotId[slot] = nId;
+            mSlotOfId[nId] = slot; mvSlotId[slot] = nId; mvSlotPtr[slot] = (const void*)desc.ptr<float>();
         }
         mvSlotUsed[slot] = mnClock;
         if (desc.rows > 0 && hfnet_store_set_flags(mpStore, slot, vbHasPoint.data(), desc.rows) != HFNET_OK) return -1;
@@ -375,6 +394,7 @@ private:
     const int mnSlots = 256, mnMaxRows = HFNET_MAX_KEYPOINTS;
     unsigned long long mnClock = 0;
     std::vector<unsigned long> mvSlotId;
+    std::vector<const void*> mvSlotPtr;          // descriptor block a slot was filled from
     std::vector<unsigned long long> mvSlotUsed;
     std::unordered_map<unsigned long, int> mSlotOfId;
 };

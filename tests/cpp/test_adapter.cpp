@@ -95,6 +95,14 @@ int main(int argc, char** argv) {
     const bool okStore2 = HIPKeyFrameStore::Get().SearchForTriangulation(100, dA, fA, {101}, {&dB}, {fB}, 0.75f, vv2);
     put_i(fo, (okStore ? 1 : 0) | (okStore2 ? 2 : 0));
     if (okStore && okStore2) { put(fo, vv[0].data(), (size_t)nA * 4); put(fo, vv[1].data(), (size_t)nA * 4); put(fo, vv2[0].data(), (size_t)nA * 4); }
+    // after Tracking::Reset keyframe ids start again at 0 (src/Tracking.cc:3231): the SAME ids now name other descriptor blocks.
+    // Once without Clear() (the resident-hit check must notice), once behind it (what the patched KeyFrameDatabase::clear() calls).
+    std::vector<std::vector<int32_t> > vv3, vv4;
+    const bool okStore3 = HIPKeyFrameStore::Get().SearchForTriangulation(100, dB, fB, {101}, {&dA}, {fA}, 0.75f, vv3);
+    HIPKeyFrameStore::Get().Clear();
+    const bool okStore4 = HIPKeyFrameStore::Get().SearchForTriangulation(101, dB, fB, {100}, {&dA}, {fA}, 0.75f, vv4);
+    put_i(fo, (okStore3 ? 1 : 0) | (okStore4 ? 2 : 0));
+    if (okStore3 && okStore4) { put(fo, vv3[0].data(), (size_t)nB * 4); put(fo, vv4[0].data(), (size_t)nB * 4); }
     fclose(fo);
     return 0;
 }

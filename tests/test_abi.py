@@ -46,7 +46,8 @@ def test_no_silent_cpu_fallback(tmp_path):
 
 
 def test_product_never_imports_the_oracle():
-    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/"""
+    """only tests/, __graft_entry__.smoke() and bench.py's two checker legs (cpu_baseline: the reported CPU number; verify_last_chunk: the
+    comparison of the timed run's own outputs, after the timed region) may touch oracle/ -- never the thing measured"""
     pkg = os.path.join(ROOT, "hfnet_slam_amd")
     pat = re.compile(r"libhfnet_oracle|from\s+oracle|import\s+oracle|#include\s*[<\"][^>\"]*hfnet_oracle\.h|dlopen")
     for dirpath, _, files in os.walk(pkg):
@@ -59,7 +60,10 @@ def test_product_never_imports_the_oracle():
     bench = open(os.path.join(ROOT, "bench.py")).read()
     lines = bench.splitlines()
     uses = [i for i, l in enumerate(lines) if re.search(r"from\s+oracle|import\s+oracle", l)]
-    assert len(uses) == 1
-    enclosing = [l for l in lines[:uses[0]] if l.startswith("def ")][-1]
-    assert enclosing.startswith("def cpu_baseline")
+    assert len(uses) == 2
+    enclosing = sorted([l for l in lines[:u] if l.startswith("def ")][-1].split("(")[0] for u in uses)
+    assert enclosing == ["def cpu_baseline", "def verify_last_chunk"]
+    # ... and the timed region of main() sits between two sync_all() calls that no oracle call is near
+    timed = bench[bench.index("    t0 = time.perf_counter()\n    for _ in range(args.steps):"):bench.index("    elapsed = max_over_ranks(")]
+    assert "oracle" not in timed and "verify" not in timed
     assert "from oracle" not in open(os.path.join(ROOT, "hfnet_slam_amd", "shard.py")).read()

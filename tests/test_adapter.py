@@ -166,5 +166,10 @@ def test_adapter_matches_oracle(adapter_exe, weights_path, oracle_model, tmp_pat
     f_a = np.arange(n_a) % 3 == 0; f_b = np.arange(n_b) % 4 == 0
     assert np.array_equal(take(np.int32, n_a), ref_tri(rd, f_a, rdb, f_b))
     assert np.array_equal(take(np.int32, n_a), ref_tri(rd, f_a, rd, f_a))
-    assert np.array_equal(take(np.int32, n_a), ref_tri(rd, np.arange(n_a) % 2 == 0, rdb, f_b))
+    f_a2 = np.arange(n_a) % 2 == 0
+    assert np.array_equal(take(np.int32, n_a), ref_tri(rd, f_a2, rdb, f_b))
+    # keyframe ids reused for other descriptor blocks (after a reset): resident-hit check, then HIPKeyFrameStore::Clear()
+    assert take(np.int32, 1)[0] == 3
+    assert np.array_equal(take(np.int32, n_b), ref_tri(rdb, f_b, rd, f_a2))
+    assert np.array_equal(take(np.int32, n_b), ref_tri(rdb, f_b, rd, f_a2))
     assert off == len(buf)

@@ -79,6 +79,8 @@ def test_bench_dry_ranks_runs_the_two_rank_control_flow(tmp_path):
     line = json.loads(json_lines(outs[0][0])[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and "invalid" in line and line["scaling"] == "weak"
     assert line["value"] > 0 and abs(line["value"] - 2 * 128 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    pr = line["per_rank_frames_per_s"]                                                      # the first real SCALE run explains itself
+    assert len(pr["all"]) == 2 and 0 < pr["min"] <= pr["max"] and pr["min"] * 2 >= line["value"] * 0.5
     c4 = line["configs"]["4"]
     assert c4["frames"] == 27049 and c4["gpus"] == 2 and c4["sequences"] == 11 and c4["frames_per_s"] > 0
     # a world size that does not match --gpus is refused before anything is initialised
@@ -104,3 +106,5 @@ def test_bench_rccl_path_with_one_rank():
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["configs"]["4"]["frames"] == 27049
+    v = line["verified"]                                       # the timed run checks its own last chunk against the oracle
+    assert v["equal"] is True and v["equal_all_ranks"] is True and v["frames"] == [0, 1, 127] and line["value_natural"] > 0

@@ -26,7 +26,7 @@ def _props(kps, desc, glob, n_per_level, budget, sizes, thr):
         assert len({(float(a), float(b)) for a, b in zip(k["x"], k["y"])}) == n, "duplicate keypoint"
 
 
-@pytest.mark.parametrize("cfg", [(752, 480, 1000), (512, 512, 850)])     # EuRoC.yaml / TUM-VI.yaml sizes
+@pytest.mark.parametrize("cfg", [(752, 480, 1000), (512, 512, 850), (512, 512, 1000)])     # EuRoC.yaml / TUM-VI.yaml sizes (+ config 3's second budget)
 def test_full_size_frame_vs_oracle_and_properties(engine, oracle_model, cfg):
     from hfnet_slam_amd import capi, spec
     w, h, nf = cfg
@@ -52,20 +52,78 @@ def test_full_size_frame_vs_oracle_and_properties(engine, oracle_model, cfg):
     x.close()
 
 
-def test_bench_sized_call_vs_oracle(engine, oracle_model):
-    """64 full-size frames in ONE call -- bench.py's default call size, at which the GEMM-shaped layers switch kernels (weight
-    slabs through LDS for the 120 -> 720 expansions with their 15 = 3 * 4 + 3 k-steps, skipped keypoint-slot tiles in the
-    descriptor head) -- against the oracle on frames from the start, the middle and the end of the batch."""
+def _bench_call_sizes():
+    import bench                                     # the measured call size is read from bench.py so this test cannot go stale
+    return sorted({64, bench.DEFAULT_CHUNK})
+
+
+@pytest.mark.parametrize("B", _bench_call_sizes())
+def test_bench_sized_call_vs_oracle(engine, oracle_model, B):
+    """A full call of bench.py's size (`bench.DEFAULT_CHUNK` frames, and 64) in ONE extract_batch -- where the GEMM-shaped layers
+    switch kernels (weight slabs through LDS for the 120 -> 720 expansions, skipped keypoint-slot tiles in the descriptor head), the
+    tile lists of the fused blocks double and the XCD slot arithmetic runs at its largest -- against the oracle on the first two
+    frames, the frames either side of the 64-frame boundary and the last one; natural and uniform frames mixed."""
     from hfnet_slam_amd import capi
-    w, h, nf, B = 752, 480, 1000, 64
+    w, h, nf = 752, 480, 1000
     x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, 4, max_batch=B)
     imgs = np.stack([synth_image(h, w, 3000 + i, "natural" if i % 5 == 0 else "uniform") for i in range(B)])
     nb, kb, db, gb = x.extract_batch(imgs)
-    for i in (0, 21, 40, 63):
+    for i in sorted({0, 1, 21, 63, 64, B - 1} & set(range(B))):
         rn, rk, rd, rg, _ = oracle_model.extract(imgs[i], nf, 0.01, 4, 1.2)
         assert nb[i] == rn, i
         assert np.array_equal(kb[i, :rn], rk) and np.array_equal(db[i, :rn], rd) and np.array_equal(gb[i], rg), i
     x.close()
+
+
+@pytest.mark.parametrize("nf", [1000, 850])
+def test_full_size_keyframe_step_vs_oracle(engine, oracle_model, nf):
+    """BASELINE config 3 at its real size (512 x 512, the yaml's 850 features and 1000): 31 keyframes go through the extractor
+    into the device-resident store (hfnet_store_put_extracted) and the database; the 32nd frame's keyframe step -- frame-to-frame
+    SearchByBoW, hfnet_db_query against all previous keyframes, SearchForTriangulation against its 30 most recent neighbours in
+    one batched call (LocalMapping.cc:516-520) -- is compared with the oracle, every pair."""
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    W = H = 512
+    n_kf = 31
+    x = capi.Extractor(engine, W, H, nf, 0.01, 1.2, 4, max_batch=1)
+    db = capi.Database(engine, n_kf + 1, engine.global_dim)
+    store = capi.Store(engine, n_kf + 1, nf)
+    ref = []
+    for k in range(n_kf + 1):
+        img = synth_image(H, W, 5000 + k, "natural" if k % 3 == 0 else "uniform")
+        n, kps, desc, g, _ = x.extract(img)
+        rn, rk, rd, rg, _ = oracle_model.extract(img, nf, 0.01, 4, 1.2)
+        assert n == rn and np.array_equal(kps, rk) and np.array_equal(desc, rd) and np.array_equal(g, rg), k
+        store.put_extracted(k, x, 0)
+        assert store.rows(k) == rn
+        if k < n_kf:
+            db.add(k, g)
+        ref.append((rd, rg))
+    last = n_kf
+    # frame-to-frame match on the store's copies (query = previous frame, as bench.py's config 3 calls it)
+    cnt, match, dist = store.search_by_bow([(last - 1, last)], 0.6)
+    rc, rm, rdist = O.search_by_bow(ref[last - 1][0], ref[last][0], 0.6)
+    assert cnt[0] == rc and np.array_equal(match[0, :len(rm)], rm) and np.array_equal(dist[0, :len(rm)], rdist)
+    # place recognition against all previous keyframes
+    for mode in (0, 1):
+        cs, sc, best, scores = db.query(ref[last][1], mode, want_scores=True)
+        rs = O.db_scores(ref[last][1], np.stack([r[1] for r in ref[:n_kf]]))
+        ridx, rbest = O.db_candidates(rs, mode)
+        assert np.array_equal(scores[:n_kf], rs) and best == rbest and np.array_equal(cs, ridx) and np.array_equal(sc, rs[ridx])
+    # 30 neighbours in one call, with the threshold screen on the bf16 pipe and without
+    pairs = [(last, j) for j in range(last - 30, last)]
+    want = [O.search_for_triangulation(ref[last][0], ref[j][0], 0.75) for _, j in pairs]
+    for screen in (1, 0):
+        engine.set_option("tri_screen_bf16", screen)
+        try:
+            for _ in range(2):                                    # (the second call sees the adaptive state the first one left)
+                cnt, match = store.search_for_triangulation(pairs, 0.75)
+                for p, (rc, rm) in enumerate(want):
+                    assert cnt[p] == rc, (screen, p, cnt[p], rc)
+                    assert np.array_equal(match[p, :len(rm)], rm), (screen, p)
+        finally:
+            engine.set_option("tri_screen_bf16", 1)
+    store.close(); db.close(); x.close()
 
 
 @pytest.mark.parametrize("size", [(752, 480), (640, 360)])

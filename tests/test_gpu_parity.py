@@ -746,6 +746,35 @@ def test_store_put_extracted_matches_host_round_trip(engine, oracle_model):
     small.close(); store.close(); x.close()
 
 
+@pytest.mark.parametrize("host_global", [1, 0])
+def test_put_extracted_then_immediate_extract_then_match(engine, oracle_model, engine_options, host_global):
+    """the invariant hfnet_store_put_extracted relies on since the latency path stopped draining its stream (engine option
+    host_global = 1: the call returns while the global branch may still run): the block's local section is complete once the host
+    has seen the local-results flag, and the NEXT extraction -- which overwrites the staging block the store's copies read -- waits
+    for those copies on the device.  put_extracted, an immediate extract and a match, back to back, eight times."""
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    engine_options({"host_global": host_global})
+    w, h, nf = 320, 240, 400
+    x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, 4, max_batch=1)
+    store = capi.Store(engine, 2, nf)
+    prev = None
+    for i in range(8):
+        img = synth_image(h, w, 8200 + i, "natural" if i % 2 else "uniform")
+        n, kps, desc, g, _ = x.extract(img)
+        store.put_extracted(i & 1, x, 0)
+        x.extract(synth_image(h, w, 8300 + i))                    # overwrites the staging block right behind the copies
+        rn, rk, rd, rg, _ = oracle_model.extract(img, nf, 0.01, 4, 1.2)
+        assert n == rn and np.array_equal(desc, rd) and np.array_equal(g, rg), i
+        if prev is not None:
+            cnt, match, dist = store.search_by_bow([(1 - (i & 1), i & 1)], 0.6)
+            rc, rm, rdist = O.search_by_bow(prev, rd, 0.6)
+            assert cnt[0] == rc, i
+            _eq(f"match {i}", match[0, :len(prev)], rm); _eq(f"dist {i}", dist[0, :len(prev)], rdist)
+        prev = rd
+    store.close(); x.close()
+
+
 def test_container_without_memberships_gamma(oracle_model, weights_path, tmp_path):
     """a real HF-Net checkpoint has no BatchNorm gamma for the NetVLAD memberships conv (slim.batch_norm scale=False): the
     library reads the missing tensor as 1 -- same bits as a container that stores ones, and as the oracle on either"""
