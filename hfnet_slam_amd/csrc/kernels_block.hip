@@ -757,6 +757,243 @@ static hipError_t launch_block_fused4_t(const FusedArgs& a, const Geom& g, hipSt
     return hipGetLastError();
 }
 
+// ---- v8 of the fused block (stride 2): the wave-autonomous tile of v4 with the expanded tensor kept in REGISTERS.
+// v4 stages the ReLU6'd expansion through the wave's LDS slice (channel-major ET, 19.5 KB per wave for the 9 x 17 halo of a
+// stride-2 tile: LDS, not registers, holds these kernels at two waves per SIMD) only to hand each lane the rows of its channel:
+// 20 ds_write_b128 + 85 ds_read_b32 per chunk and one of the two dependent LDS round trips of a chunk.  But the MFMA D fragment
+// already has lane = channel; only WHICH halo positions a lane half holds is wrong -- and the A-row -> position assignment is
+// free.  Here the depthwise stage is split by output COLUMNS (lane half h computes columns 4h .. 4h+3 of all four rows, which
+// read halo columns 8h .. 8h+8), and A row rho = 8 (i >> 2) + 4 h + (i & 3) of M tile m loads the position that half h wants in
+// accumulator slot s = 16 m + i:
+//     s < 72: halo (s >> 3, 8 h + (s & 7))           -- the half's own 9 x 8 block
+//     s >= 72: halo (h ? s - 72 : 8, 16)             -- column 16: rows 0-7 sit with half 1, row 8 with half 0 (153 = 80 + 73)
+// so every tap of every output is an accumulator register of the lane itself, except the ninth halo column of the half
+// (column 8 for half 0 -- half 1's slots 8 hy; column 16 for half 1 -- its own slots 72 + hy, row 8 from half 0), which
+// v_permlane32_swap moves: 20 vector instructions per chunk instead of 105 LDS instructions.  Out-of-image halo positions
+// (the depthwise conv's zero padding) cost nothing on interior tiles and one extra MFMA per M tile on border tiles: the chain of
+// such an A row starts with fma(1, -1e30, bias) instead of the bias (an in-image row's with fma(0, -1e30, bias) == bias exactly),
+// stays there and ReLU6 returns 0.  LDS per wave: the 32 x 36 depthwise tile only (4.6 KB); the chains, the (ky, kx) order of the
+// depthwise sums and the projection are v4's: same bits.
+template <int NTO, int KQT, bool RES, int OCC>
+__global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
+    constexpr int TH = 4, TW = 8, IH = 9, IW = 17, MT = 5, CEP = 36;
+    __shared__ __attribute__((aligned(16))) float ET[32 * CEP];
+    const int lane = threadIdx.x, half = lane >> 5, r = lane & 31;
+    int level = 0, bx = blockIdx.x;
+    for (; level < g.n_levels - 1; ++level) {
+        const int per = g.batch * a.level_wgs[level];
+        if (bx < per) break;
+        bx -= per;
+    }
+    const int frame = bx / a.level_wgs[level];
+    bx -= frame * a.level_wgs[level];
+    const int image = level * g.batch + frame;
+    const LevelGeom lv = g.lv[level];
+    const int tiles_x = (lv.Wo + TW - 1) / TW, ntiles = tiles_x * ((lv.Ho + TH - 1) / TH);
+    const int q = ntiles >> 3, rem = ntiles & 7;                  // (XCD mapping: as k_block_fused4)
+    const int xr = (bx + image) & 7, slot = bx >> 3;
+    if (slot >= q + (xr < rem ? 1 : 0)) return;
+    const int tile = xr * q + min(xr, rem) + slot;
+    const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int oy0 = tyi * TH, ox0 = txi * TW;
+    const int iy0 = oy0 * 2 - lv.pt, ix0 = ox0 * 2 - lv.pl;
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= lv.H && ix0 + IW <= lv.W;
+    const long long in_base = lv.in_off + (long long)frame * lv.H * lv.W;
+    const long long out_base = lv.out_off + (long long)frame * lv.Ho * lv.Wo;
+    const char* __restrict__ xb = (const char*)(a.X + in_base * a.cin);      // uniform; lane offsets are 32-bit
+
+    // ---- block input: A row r of M tile m is accumulator slot 16 m + ir of lane half hr
+    f32x4 afrag[MT][KQT];
+    float aflag[MT];                                              // 1 where this A row is an out-of-image position (k half 0 only)
+    {
+        const int hr = (r >> 2) & 1, ir = ((r >> 3) << 2) | (r & 3);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int s = 16 * m + ir;
+            int hy = s >> 3, hx = 8 * hr + (s & 7);
+            if (m == MT - 1 && ir >= 8) { hx = 16; hy = hr ? s - 72 : 8; }
+            const int iyr = iy0 + hy, ixr = ix0 + hx;
+            const bool outside = iyr < 0 || iyr >= lv.H || ixr < 0 || ixr >= lv.W;
+            aflag[m] = (outside && half == 0) ? 1.0f : 0.0f;
+            const int iy = min(max(iyr, 0), lv.H - 1), ix = min(max(ixr, 0), lv.W - 1);
+            const unsigned off = ((unsigned)(iy * lv.W + ix) * (unsigned)a.cin + (unsigned)(half * 4)) * 4u;
+#pragma unroll
+            for (int kq = 0; kq < KQT; ++kq) afrag[m][kq] = *(const f32x4*)(xb + off + kq * 32);
+        }
+    }
+    const float bneg = half == 0 ? -1.0e30f : 0.0f;
+    f32x16 pacc[NTO];
+#pragma unroll
+    for (int nt = 0; nt < NTO; ++nt) {
+        const float pb = a.pr_bias[nt * 32 + r];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pacc[nt][i] = pb;
+    }
+    const int n_chunks = min(a.ex_nt_total, (a.cexp + 31) >> 5);
+    const unsigned lane16_ = (unsigned)lane * 16u, r4_ = (unsigned)r * 4u;
+    constexpr int PF = KQT < 3 ? KQT : 3;                          // pieces of expansion weights in flight
+    f32x4 bq[PF];
+    float ebias;
+    {
+        const unsigned lane16 = fresh(lane16_), r4 = fresh(r4_);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) bq[j] = *(gvec4_t)(sgpr_base(a.Wex, (unsigned)(j * a.ex_nt_total) * 1024u) + lane16);
+        ebias = *(gf32_t)(sgpr_base(a.ex_bias, 0u) + r4);
+    }
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int ch0 = chunk * 32;
+        const int kqc = min(4, (a.cexp - ch0) >> 3);
+        const int cn = min(chunk + 1, n_chunks - 1);
+        const float enext = *(gf32_t)(sgpr_base(a.ex_bias, (unsigned)cn * 128u) + fresh(r4_));
+        const unsigned dch4 = (unsigned)min(r, a.cexp - 1 - ch0) * 4u;      // (channels past cexp: clamped, never consumed)
+        float dwt[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dwt[t] = *(gf32_t)(sgpr_base(a.Wdw, (unsigned)(t * a.cexp + ch0) * 4u) + dch4);
+        const float dwb = *(gf32_t)(sgpr_base(a.dw_bias, (unsigned)ch0 * 4u) + dch4);
+        // ---- expansion: five independent chains, k outer, weights through the ring
+        f32x16 acc[MT];
+        {
+            f32x16 bias16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bias16[i] = ebias;
+#pragma unroll
+            for (int kq = 0; kq < KQT; ++kq) {
+                const f32x4 b = bq[kq % PF];
+                const int kn = kq + PF < KQT ? kq + PF : kq + PF - KQT;
+                const int cc = kq + PF < KQT ? chunk : cn;
+                const f32x4 bn = *(gvec4_t)(sgpr_base(a.Wex, (unsigned)(kn * a.ex_nt_total + cc) * 1024u) + fresh(lane16_));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (kq == 0 && t == 0) {
+                        if (interior) {
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][0][0], b[0], bias16, 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+                                const f32x16 c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aflag[m], bneg, bias16, 0, 0, 0);
+                                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][0][0], b[0], c0, 0, 0, 0);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m][kq][t], b[t], acc[m], 0, 0, 0);
+                    }
+                }
+                bq[kq % PF] = bn;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][i] = relu6f(acc[m][i]);
+        // ---- the ninth halo column of this lane half: E[hy] = (half 0: column 8 = half 1's slot 8 hy | half 1: column 16)
+        // __builtin_amdgcn_permlane32_swap(x, y) = { (x.lower, y.lower), (x.upper, y.upper) } as (lower half, upper half)
+        float E[IH];
+        {
+            auto swp = [](float x, float y, int which) -> float {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+                return __builtin_bit_cast(float, (unsigned)sw[which]);
+            };
+            const float lo72 = swp(acc[4][8], acc[4][8], 0);       // half 0's halo (8, 16), in both halves
+            E[8] = swp(acc[4][0], lo72, 1);                        // (half 1's slot 64 = halo (8, 8), half 0's (8, 16))
+#pragma unroll
+            for (int hy = 0; hy < 8; ++hy) E[hy] = swp(acc[(hy * 8) >> 4][(hy * 8) & 15], acc[4][8 + hy], 1);
+        }
+        // ---- depthwise: channel r, output columns 4 half .. 4 half + 3 of all four rows, taps in (ky, kx) order
+        float o[TH][4];
+#pragma unroll
+        for (int oy = 0; oy < TH; ++oy)
+#pragma unroll
+            for (int ox = 0; ox < 4; ++ox) {
+                float v = dwb;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int hy = 2 * oy + ky, c = 2 * ox + kx;
+                        const float x = c < 8 ? acc[(hy * 8 + c) >> 4][(hy * 8 + c) & 15] : E[hy];
+                        v = fmaf(x, dwt[ky * 3 + kx], v);
+                    }
+                o[oy][ox] = relu6f(v);
+            }
+        // this chunk's projection weights: requested here, into registers the expansion has released
+        f32x4 pfrag[4][NTO];
+        {
+            const unsigned l16 = fresh(lane16_);
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt)
+                    pfrag[kq][nt] = *(gvec4_t)(sgpr_base(a.Wpr, (unsigned)((chunk * 4 + min(kq, kqc - 1)) * a.pr_nt_total + nt) * 1024u) + l16);
+        }
+#pragma unroll
+        for (int oy = 0; oy < TH; ++oy)
+#pragma unroll
+            for (int ox = 0; ox < 4; ++ox) ET[(oy * TW + 4 * half + ox) * CEP + r] = o[oy][ox];
+        asm volatile("" ::: "memory");
+        // ---- projection of this chunk's channels
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            if (kq < kqc) {
+                const f32x4 av = *(const f32x4*)(ET + r * CEP + kq * 8 + half * 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], pfrag[kq][nt][t], pacc[nt], 0, 0, 0);
+            }
+        }
+        asm volatile("" ::: "memory");
+        ebias = enext;
+    }
+    // ---- output (+ residual): as k_block_fused4
+    float* __restrict__ ob = a.out + out_base * a.cout;
+    const float* __restrict__ rb = a.X + in_base * a.cin;
+#pragma unroll
+    for (int nt = 0; nt < NTO; ++nt) {
+        if (nt * 32 < a.cout) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) ET[((reg & 3) + 8 * (reg >> 2) + 4 * half) * CEP + r] = pacc[nt][reg];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int piece = lane + 64 * k, px = piece >> 3, c4 = piece & 7;
+                const int col = nt * 32 + c4 * 4;
+                const int oy = oy0 + px / TW, ox = ox0 + px % TW;
+                f32x4 v = *(const f32x4*)(ET + px * CEP + c4 * 4);
+                if (col < a.cout && oy < lv.Ho && ox < lv.Wo) {
+                    const unsigned off = (unsigned)(oy * lv.Wo + ox) * (unsigned)a.cout + (unsigned)col;
+                    if (RES) {
+                        const f32x4 rv = *(const f32x4*)(rb + off);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] + rv[j];
+                    }
+                    *(f32x4*)(ob + off) = v;
+                }
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+}
+
+template <int NTO, int KQT, int OCC>
+static hipError_t launch_block_fused8_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
+    if (a.residual) return hipErrorInvalidValue;                  // (stride 2: no residual)
+    FusedArgs b = a;
+    long long total = 0;
+    for (int l = 0; l < HFNET_MAX_LEVELS; ++l) {
+        b.level_wgs[l] = 8;
+        if (l >= g.n_levels) continue;
+        const int tiles = ((g.lv[l].Wo + 7) / 8) * ((g.lv[l].Ho + 3) / 4);
+        b.level_wgs[l] = max(8, ((tiles + 7) / 8) * 8);
+        total += (long long)b.level_wgs[l] * g.batch;
+    }
+    if (total <= 0 || total > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_block_fused8<NTO, KQT, false, OCC>), dim3((unsigned)total), dim3(64), 0, s, b, g);
+    return hipGetLastError();
+}
+
 // ---- v6 of the fused block (stride 1): the wave-autonomous scheme of v4 on v_mfma_f32_16x16x4_f32 with a 6 x 8 output tile.
 // What v4 pays for its autonomy is the halo: a 4 x 8 tile's 6 x 10 positions are two 32-row M tiles for one tile of outputs
 // (expansion executed 2.0x), and 32-column tiles pad cout = 48 / 72 to 64 / 96.  With 16-row / 16-column tiles a 6 x 8 tile's
@@ -1394,6 +1631,12 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
         if (kt == 12 && n16 == 5) return launch_block_fused6_t<12, 5, 2>(a, g, s);
         if (kt == 18 && n16 == 5) return launch_block_fused6_t<18, 5, 2>(a, g, s);
         if (variant == 7 && kt == 6 && n16 == 2) return launch_block_fused6_t<6, 2, 3>(a, g, s);
+    }
+    // v8 (stride 2, expansion kept in registers): what a launch of k_block_fused4's size runs for the stride-2 blocks (per 128
+    // frames, v4 -> v8: layer 3 1803 -> 1599 us, layer 5 954 -> 833); variant 8: at any launch size (tests)
+    if (kind == FUSED_V4 && st == 2 && nto == 1 && (variant == 8 || (variant == 4 && !small_launch))) {
+        if (kq == 2) return launch_block_fused8_t<1, 2, 2>(a, g, s);
+        if (kq == 3) return launch_block_fused8_t<1, 3, 2>(a, g, s);
     }
     switch (kind) {
         case FUSED_NOEXPAND: {
