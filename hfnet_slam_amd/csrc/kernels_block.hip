@@ -774,9 +774,23 @@ static hipError_t launch_block_fused4_t(const FusedArgs& a, const Geom& g, hipSt
 // such an A row starts with fma(1, -1e30, bias) instead of the bias (an in-image row's with fma(0, -1e30, bias) == bias exactly),
 // stays there and ReLU6 returns 0.  LDS per wave: the 32 x 36 depthwise tile only (4.6 KB); the chains, the (ky, kx) order of the
 // depthwise sums and the projection are v4's: same bits.
-template <int NTO, int KQT, bool RES, int OCC>
+// Stride 1 (4 x 8 tile, 6 x 10 halo = 2 M tiles): the same scheme with five own columns per half (half 0: halo columns 0-4 in
+// slots 5 hy + k; half 1: columns 5-8 in k = 1..4 and column 9 in k = 0, so that local column c = 1..4 of the half's six-column
+// window 4 h .. 4 h + 5 is slot k = c in BOTH halves); local column 0 is (own column 0 | half 0's column 4) and local column 5
+// is (half 1's column 5 | own column 9): two v_permlane32_swap per halo row.
+template <int STRIDE> struct F8Geo {
+    static constexpr int TH = 4, TW = 8, IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
+    static constexpr int NC = STRIDE == 2 ? 8 : 5;                 // own halo columns of a lane half, per halo row
+    static constexpr int MT = STRIDE == 2 ? 5 : 2;                 // halo M tiles (accumulator slots per lane half = 16 MT)
+    static constexpr int CEP = 36;
+};
+// (Layer 8 -- 96 input channels, 240 registers of A fragments -- was tried in this form with the A pieces re-read from L1 / L2 per
+// chunk through a ring of three k-steps: 254 registers, two waves per SIMD, bit-identical, 1389 us per 128 frames against the
+// barrier kernel's 1270: every wave then pulls 60 KB of A per chunk for its own 4 x 8 tile, ~37 B/clk per CU from L2.  Not kept.)
+template <int STRIDE, int NTO, int KQT, bool RES, int OCC>
 __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
-    constexpr int TH = 4, TW = 8, IH = 9, IW = 17, MT = 5, CEP = 36;
+    using G = F8Geo<STRIDE>;
+    constexpr int TH = G::TH, TW = G::TW, IH = G::IH, IW = G::IW, NC = G::NC, MT = G::MT, CEP = G::CEP;
     __shared__ __attribute__((aligned(16))) float ET[32 * CEP];
     const int lane = threadIdx.x, half = lane >> 5, r = lane & 31;
     int level = 0, bx = blockIdx.x;
@@ -796,7 +810,7 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
     const int tile = xr * q + min(xr, rem) + slot;
     const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
     const int oy0 = tyi * TH, ox0 = txi * TW;
-    const int iy0 = oy0 * 2 - lv.pt, ix0 = ox0 * 2 - lv.pl;
+    const int iy0 = oy0 * STRIDE - lv.pt, ix0 = ox0 * STRIDE - lv.pl;
     const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= lv.H && ix0 + IW <= lv.W;
     const long long in_base = lv.in_off + (long long)frame * lv.H * lv.W;
     const long long out_base = lv.out_off + (long long)frame * lv.Ho * lv.Wo;
@@ -810,8 +824,16 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int s = 16 * m + ir;
-            int hy = s >> 3, hx = 8 * hr + (s & 7);
-            if (m == MT - 1 && ir >= 8) { hx = 16; hy = hr ? s - 72 : 8; }
+            int hy, hx;
+            if constexpr (STRIDE == 2) {
+                hy = s >> 3; hx = 8 * hr + (s & 7);
+                if (m == MT - 1 && ir >= 8) { hx = 16; hy = hr ? s - 72 : 8; }
+            } else {
+                const int sc = min(s, IH * NC - 1);               // (slots 30, 31: padding, never read)
+                hy = sc / NC;
+                const int k = sc - hy * NC;
+                hx = hr ? (k == 0 ? 9 : 4 + k) : k;
+            }
             const int iyr = iy0 + hy, ixr = ix0 + hx;
             const bool outside = iyr < 0 || iyr >= lv.H || ixr < 0 || ixr >= lv.W;
             aflag[m] = (outside && half == 0) ? 1.0f : 0.0f;
@@ -840,6 +862,10 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
         for (int j = 0; j < PF; ++j) bq[j] = *(gvec4_t)(sgpr_base(a.Wex, (unsigned)(j * a.ex_nt_total) * 1024u) + lane16);
         ebias = *(gf32_t)(sgpr_base(a.ex_bias, 0u) + r4);
     }
+    auto swp = [](float x, float y, int which) -> float {          // (x.lower, y.lower) [which = 0] / (x.upper, y.upper) [1] as (lower, upper) half
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+        return __builtin_bit_cast(float, (unsigned)sw[which]);
+    };
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const int ch0 = chunk * 32;
         const int kqc = min(4, (a.cexp - ch0) >> 3);
@@ -850,7 +876,7 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) dwt[t] = *(gf32_t)(sgpr_base(a.Wdw, (unsigned)(t * a.cexp + ch0) * 4u) + dch4);
         const float dwb = *(gf32_t)(sgpr_base(a.dw_bias, (unsigned)ch0 * 4u) + dch4);
-        // ---- expansion: five independent chains, k outer, weights through the ring
+        // ---- expansion: MT independent chains, k outer, weights through the ring
         f32x16 acc[MT];
         {
             f32x16 bias16;
@@ -888,36 +914,22 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][i] = relu6f(acc[m][i]);
-        // ---- the ninth halo column of this lane half: E[hy] = (half 0: column 8 = half 1's slot 8 hy | half 1: column 16)
-        // __builtin_amdgcn_permlane32_swap(x, y) = { (x.lower, y.lower), (x.upper, y.upper) } as (lower half, upper half)
-        float E[IH];
-        {
-            auto swp = [](float x, float y, int which) -> float {
-                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
-                return __builtin_bit_cast(float, (unsigned)sw[which]);
-            };
+        // ---- the halo columns of this lane half's window that sit with the other half
+        float E[IH], E0[STRIDE == 1 ? IH : 1];
+        if constexpr (STRIDE == 2) {
+            // E[hy] = (half 0: column 8 = half 1's slot 8 hy | half 1: column 16 = its slot 72 + hy, row 8 from half 0's slot 72)
             const float lo72 = swp(acc[4][8], acc[4][8], 0);       // half 0's halo (8, 16), in both halves
-            E[8] = swp(acc[4][0], lo72, 1);                        // (half 1's slot 64 = halo (8, 8), half 0's (8, 16))
+            E[8] = swp(acc[4][0], lo72, 1);
 #pragma unroll
             for (int hy = 0; hy < 8; ++hy) E[hy] = swp(acc[(hy * 8) >> 4][(hy * 8) & 15], acc[4][8 + hy], 1);
-        }
-        // ---- depthwise: channel r, output columns 4 half .. 4 half + 3 of all four rows, taps in (ky, kx) order
-        float o[TH][4];
+        } else {
 #pragma unroll
-        for (int oy = 0; oy < TH; ++oy)
-#pragma unroll
-            for (int ox = 0; ox < 4; ++ox) {
-                float v = dwb;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int hy = 2 * oy + ky, c = 2 * ox + kx;
-                        const float x = c < 8 ? acc[(hy * 8 + c) >> 4][(hy * 8 + c) & 15] : E[hy];
-                        v = fmaf(x, dwt[ky * 3 + kx], v);
-                    }
-                o[oy][ox] = relu6f(v);
+            for (int hy = 0; hy < IH; ++hy) {
+                const float a0 = acc[(hy * NC) >> 4][(hy * NC) & 15], a1 = acc[(hy * NC + 1) >> 4][(hy * NC + 1) & 15], a4 = acc[(hy * NC + 4) >> 4][(hy * NC + 4) & 15];
+                E[hy] = swp(a1, a0, 1);                            // local column 5: (half 1's column 5, own column 9)
+                E0[hy] = swp(a0, a4, 0);                           // local column 0: (own column 0, half 0's column 4)
             }
+        }
         // this chunk's projection weights: requested here, into registers the expansion has released
         f32x4 pfrag[4][NTO];
         {
@@ -928,10 +940,24 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
                 for (int nt = 0; nt < NTO; ++nt)
                     pfrag[kq][nt] = *(gvec4_t)(sgpr_base(a.Wpr, (unsigned)((chunk * 4 + min(kq, kqc - 1)) * a.pr_nt_total + nt) * 1024u) + l16);
         }
+        // ---- depthwise: channel r, output columns 4 half .. 4 half + 3 of all four rows, taps in (ky, kx) order
 #pragma unroll
         for (int oy = 0; oy < TH; ++oy)
 #pragma unroll
-            for (int ox = 0; ox < 4; ++ox) ET[(oy * TW + 4 * half + ox) * CEP + r] = o[oy][ox];
+            for (int ox = 0; ox < 4; ++ox) {
+                float v = dwb;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int hy = STRIDE * oy + ky, c = STRIDE * ox + kx;
+                        float x;
+                        if constexpr (STRIDE == 2) x = c < NC ? acc[(hy * NC + c) >> 4][(hy * NC + c) & 15] : E[hy];
+                        else x = c == 0 ? E0[hy] : c < NC ? acc[(hy * NC + c) >> 4][(hy * NC + c) & 15] : E[hy];
+                        v = fmaf(x, dwt[ky * 3 + kx], v);
+                    }
+                ET[(oy * TW + 4 * half + ox) * CEP + r] = relu6f(v);
+            }
         asm volatile("" ::: "memory");
         // ---- projection of this chunk's channels
 #pragma unroll
@@ -977,9 +1003,9 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
     }
 }
 
-template <int NTO, int KQT, int OCC>
+template <int STRIDE, int NTO, int KQT, int OCC>
 static hipError_t launch_block_fused8_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
-    if (a.residual) return hipErrorInvalidValue;                  // (stride 2: no residual)
+    if (a.residual && (STRIDE != 1 || a.cin != a.cout)) return hipErrorInvalidValue;
     FusedArgs b = a;
     long long total = 0;
     for (int l = 0; l < HFNET_MAX_LEVELS; ++l) {
@@ -990,7 +1016,8 @@ static hipError_t launch_block_fused8_t(const FusedArgs& a, const Geom& g, hipSt
         total += (long long)b.level_wgs[l] * g.batch;
     }
     if (total <= 0 || total > 0x7fffffffll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_block_fused8<NTO, KQT, false, OCC>), dim3((unsigned)total), dim3(64), 0, s, b, g);
+    if (a.residual) hipLaunchKernelGGL((k_block_fused8<STRIDE, NTO, KQT, true, OCC>), dim3((unsigned)total), dim3(64), 0, s, b, g);
+    else hipLaunchKernelGGL((k_block_fused8<STRIDE, NTO, KQT, false, OCC>), dim3((unsigned)total), dim3(64), 0, s, b, g);
     return hipGetLastError();
 }
 
@@ -1623,6 +1650,11 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
     // v6 (6 x 8 tiles on the 16x16x4 MFMA): what a launch of k_block_fused4's size runs for the stride-1 blocks from layer 6 on
     // (per 64 frames, v4 -> v6: layer 6 331 -> 303 us, 7 966 -> 957, 9-11 94 -> 87, 12 138 -> 98, 13 / 14 245 -> 168); layer 4 (four waves
     // per SIMD in v4, three here: its LDS tile) is slower and stays (variant 7: everywhere, variant 6: at any launch size -- tests)
+    // v8 in its stride-1 form beats v6 where the projection has no column padding to lose (layer 7, 48 -> 288 -> 96: 1858 -> 1798 us
+    // per 128 frames; everywhere else it is 1-7 % slower than v4 / v6: the lanes' exchange is vector work on a saturated port)
+    // (measured per 128 frames, v4 or v6 -> v8: layer 4 1710 -> 1732 us, layer 6 567 -> 602, layer 9 163 -> 165, layer 12 183 -> 188, layer 13
+    // 325 -> 347: those instantiations are not kept)
+    if (kind == FUSED_V4 && st == 1 && kq == 6 && nto == 3 && (variant == 8 || (variant == 4 && !small_launch))) return launch_block_fused8_t<1, 3, 6, 2>(a, g, s);
     if (kind == FUSED_V4 && st == 1 && a.Wex16 && a.Wpr16 && (variant == 6 || variant == 7 || (variant == 4 && !small_launch))) {
         const int kt = b.cin / 4, n16 = a.pr_n16;
         if (kt == 6 && n16 == 3) return launch_block_fused6_t<6, 3, 2>(a, g, s);
@@ -1635,8 +1667,8 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
     // v8 (stride 2, expansion kept in registers): what a launch of k_block_fused4's size runs for the stride-2 blocks (per 128
     // frames, v4 -> v8: layer 3 1803 -> 1599 us, layer 5 954 -> 833); variant 8: at any launch size (tests)
     if (kind == FUSED_V4 && st == 2 && nto == 1 && (variant == 8 || (variant == 4 && !small_launch))) {
-        if (kq == 2) return launch_block_fused8_t<1, 2, 2>(a, g, s);
-        if (kq == 3) return launch_block_fused8_t<1, 3, 2>(a, g, s);
+        if (kq == 2) return launch_block_fused8_t<2, 1, 2, 2>(a, g, s);
+        if (kq == 3) return launch_block_fused8_t<2, 1, 3, 2>(a, g, s);
     }
     switch (kind) {
         case FUSED_NOEXPAND: {
