@@ -27,7 +27,7 @@ SYMBOLS = [
     "hfnet_model_create", "hfnet_model_destroy", "hfnet_model_is_valid", "hfnet_model_mode",
     "hfnet_model_detect", "hfnet_model_detect_global", "hfnet_model_tap",
     "hfnet_extractor_create", "hfnet_extractor_destroy", "hfnet_extractor_tables",
-    "hfnet_extractor_extract", "hfnet_extractor_extract_batch", "hfnet_extractor_last_timing",
+    "hfnet_extractor_extract", "hfnet_extractor_extract_batch", "hfnet_extractor_last_timing", "hfnet_host_register", "hfnet_host_unregister",
     "hfnet_descriptor_distance", "hfnet_resampler", "hfnet_match_search_by_bow", "hfnet_match_search_by_bow_batch", "hfnet_match_search_for_triangulation", "hfnet_match_search_for_triangulation_batch",
     "hfnet_match_candidates", "hfnet_distinctive_descriptors",
     "hfnet_extractor_attach_store", "hfnet_store_create", "hfnet_store_destroy", "hfnet_store_put", "hfnet_store_put_extracted", "hfnet_store_rows", "hfnet_store_set_flags", "hfnet_store_search_by_bow",
@@ -85,6 +85,16 @@ def _chk(status: int) -> None:
 
 def _p(a):
     return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def host_register(a: np.ndarray) -> None:
+    """page-lock a (contiguous) array for DMA: host-pointer batch calls whose buffers are all registered skip the staging copies"""
+    assert a.flags["C_CONTIGUOUS"]
+    _chk(lib().hfnet_host_register(C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes)))
+
+
+def host_unregister(a: np.ndarray) -> None:
+    _chk(lib().hfnet_host_unregister(C.c_void_p(a.ctypes.data)))
 
 
 def build_id() -> str:

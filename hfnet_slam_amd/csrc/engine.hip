@@ -225,7 +225,7 @@ int Net::build(Engine* eng, const NetConfig& c) {
         const size_t pg = (size_t)c.batch * lp[0].h[18] * lp[0].w[18];
         const size_t N = (size_t)w.n_clusters * w.c_global;
         HF_TRY(dalloc(allocs, &memb, pg * w.n_clusters));
-        HF_TRY(dalloc(allocs, &vlad_raw, (size_t)c.batch * N));
+        HF_TRY(dalloc(allocs, &vlad_raw, (size_t)c.batch * N * vlad_scratch_parts()));
         HF_TRY(dalloc(allocs, &vlad_tap, (size_t)c.batch * N));
         HF_TRY(dalloc(allocs, &vlad_out, (size_t)c.batch * N));
         HF_TRY(dalloc(allocs, &fc_raw, (size_t)c.batch * w.global_dim));
@@ -480,7 +480,8 @@ int Net::forward_global(hipStream_t st, int first, int count, int* total) {
         HF_GSTEP(HF_LAUNCH(e, st, "pointwise_memberships", launch_pointwise(act[18], w.memb, nullptr, memb, (long long)cfg.batch * P, 0, st)));
     }
     if (!tail) HF_GSTEP(HF_LAUNCH(e, st, "softmax_memberships", launch_softmax_rows(memb, (long long)cfg.batch * P, w.n_clusters, w.n_clusters, st)));
-    HF_GSTEP(HF_LAUNCH(e, st, "vlad", launch_vlad(act[18], memb, w.clusters, vlad_tap, vlad_out, vlad_raw, cfg.batch, P, w.c_global, w.n_clusters, st)));
+    HF_GSTEP(HF_LAUNCH(e, st, "vlad", launch_vlad_aggregate(act[18], memb, w.clusters, vlad_raw, cfg.batch, P, w.c_global, w.n_clusters, st));
+             HF_LAUNCH(e, st, "vlad_norm", launch_vlad_norm(vlad_raw, vlad_tap, vlad_out, cfg.batch, w.c_global, w.n_clusters, st)));
     HF_GSTEP(HF_LAUNCH(e, st, "fc_l2", launch_fc_l2(vlad_out, w.fc, fc_part, fc_raw, global_dst ? global_dst : global_out, cfg.batch, st, global_host)));
 #undef HF_GSTEP
     if (total) *total = step;
@@ -1062,6 +1063,38 @@ static int copy_chunk_to_store(hfnet_extractor* x, int first_frame, int nb, cons
     return HFNET_OK;
 }
 
+// ---- caller memory registered for DMA (hfnet_host_register): process-wide, like the page locks themselves
+static std::mutex g_reg_mu;
+static std::map<uintptr_t, size_t> g_registered;                 // start -> bytes
+static bool host_range_registered(const void* p, size_t bytes) {
+    if (!p) return false;
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_registered.upper_bound((uintptr_t)p);
+    if (it == g_registered.begin()) return false;
+    --it;
+    return (uintptr_t)p + bytes <= it->first + it->second;
+}
+int hfnet_host_register(void* ptr, size_t bytes) {
+    if (!ptr || !bytes) { set_error("hfnet_host_register: null range"); return HFNET_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_registered.upper_bound((uintptr_t)ptr + bytes - 1);
+    if (it != g_registered.begin()) {
+        auto prev = std::prev(it);
+        if (prev->first + prev->second > (uintptr_t)ptr) { set_error("hfnet_host_register: range overlaps a registered one"); return HFNET_ERR_INVALID_ARG; }
+    }
+    HF_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    g_registered[(uintptr_t)ptr] = bytes;
+    return HFNET_OK;
+}
+int hfnet_host_unregister(void* ptr) {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_registered.find((uintptr_t)ptr);
+    if (it == g_registered.end()) { set_error("hfnet_host_unregister: not a registered range"); return HFNET_ERR_INVALID_ARG; }
+    g_registered.erase(it);
+    HF_HIP(hipHostUnregister(ptr));
+    return HFNET_OK;
+}
+
 static int host_pipe_init(hfnet_extractor* x) {
     hfnet_extractor::HostPipe& p = x->pipe;
     if (p.ready) return HFNET_OK;
@@ -1113,6 +1146,53 @@ static int extract_host_pipelined(hfnet_extractor* x, int f0, int n_frames, cons
     hipStream_t st = x->net.stream;
     const size_t img = (size_t)x->width * x->height, G = (size_t)eng.w.global_dim, NF = (size_t)x->n_features;
     const int n_chunks = (n_frames - f0 + x->max_batch - 1) / x->max_batch;
+    // registered caller memory (hfnet_host_register): the copy engines move every byte straight between the caller's buffers and
+    // the device -- the pinned staging blocks and the host's staging copies are not used
+    const size_t nf_all = (size_t)(n_frames - f0);
+    const bool direct = row_stride == x->width && frame_stride == img &&
+                        host_range_registered(images + (size_t)f0 * frame_stride, nf_all * img) &&
+                        host_range_registered(kps + (size_t)f0 * NF, nf_all * NF * sizeof(hfnet_keypoint)) &&
+                        host_range_registered(local_desc + (size_t)f0 * NF * HFNET_DESC_DIM, nf_all * NF * HFNET_DESC_DIM * sizeof(float)) &&
+                        host_range_registered(n_out + f0, nf_all * sizeof(int)) &&
+                        (!global_desc || host_range_registered(global_desc + (size_t)f0 * G, nf_all * G * sizeof(float)));
+    if (direct) {
+        auto finish = [&](int c) -> int {                    // chunk c's results are in the caller's buffers
+            const int s = c & 1, c0 = f0 + c * x->max_batch, nb = std::min(x->max_batch, n_frames - c0);
+            HF_HIP(hipEventSynchronize(p.ev_down[s]));
+            if (x->att_store)
+                for (int f = 0; f < nb; ++f) x->att_store->rows[(x->att_first + c0 + f) % x->att_store->n_sets] = std::min(n_out[c0 + f], x->att_store->max_rows);
+            if (c == n_chunks - 1) {
+                std::fill(x->last_n.begin(), x->last_n.end(), -1);
+                for (int f = 0; f < nb; ++f) x->last_n[f] = n_out[c0 + f];
+                x->last_desc = p.d_desc[s]; x->last_cnt = p.d_n[s];
+                if (x->h_pin && x->pinned_frames >= 1) {
+                    x->pin_nl_last = x->pin_res + x->result_offsets(1, (int)G).nl;
+                    HF_HIP(hipMemcpy(x->h_pin + x->pin_nl_last, p.d_nl[s], sizeof(int) * x->n_levels, hipMemcpyDeviceToHost));
+                }
+                else HF_HIP(hipMemcpy(x->d_n_level, p.d_nl[s], sizeof(int) * x->n_levels, hipMemcpyDeviceToDevice));
+            }
+            return HFNET_OK;
+        };
+        for (int c = 0; c < n_chunks; ++c) {
+            const int s = c & 1, c0 = f0 + c * x->max_batch, nb = std::min(x->max_batch, n_frames - c0);
+            // slot s: chunk c - 2's download has been waited for (finish(c - 2)), hence its compute and its upload are complete
+            HF_HIP(hipMemcpyAsync(p.d_in[s], images + (size_t)c0 * frame_stride, img * nb, hipMemcpyHostToDevice, p.s_up));
+            HF_HIP(hipEventRecord(p.ev_up[s], p.s_up));
+            HF_HIP(hipStreamWaitEvent(st, p.ev_up[s], 0));
+            HF_TRY(extract_chunk(x, nb, p.d_in[s], x->width, (long long)img, p.d_kps[s], p.d_desc[s], p.d_glob[s], p.d_n[s], p.d_nl[s]));
+            HF_TRY(copy_chunk_to_store(x, c0, nb, p.d_desc[s], p.d_n[s], st));
+            HF_HIP(hipEventRecord(p.ev_comp[s], st));
+            HF_HIP(hipStreamWaitEvent(p.s_down, p.ev_comp[s], 0));
+            HF_HIP(hipMemcpyAsync(n_out + c0, p.d_n[s], sizeof(int) * nb, hipMemcpyDeviceToHost, p.s_down));
+            if (global_desc) HF_HIP(hipMemcpyAsync(global_desc + (size_t)c0 * G, p.d_glob[s], sizeof(float) * (size_t)nb * G, hipMemcpyDeviceToHost, p.s_down));
+            HF_HIP(hipMemcpyAsync(kps + (size_t)c0 * NF, p.d_kps[s], sizeof(hfnet_keypoint) * (size_t)nb * NF, hipMemcpyDeviceToHost, p.s_down));
+            HF_HIP(hipMemcpyAsync(local_desc + (size_t)c0 * NF * HFNET_DESC_DIM, p.d_desc[s], sizeof(float) * HFNET_DESC_DIM * (size_t)nb * NF, hipMemcpyDeviceToHost, p.s_down));
+            HF_HIP(hipEventRecord(p.ev_down[s], p.s_down));
+            if (c >= 1) HF_TRY(finish(c - 1));
+        }
+        HF_TRY(finish(n_chunks - 1));
+        return HFNET_OK;
+    }
     auto drain = [&](int c) -> int {
         const int s = c & 1, c0 = f0 + c * x->max_batch, nb = std::min(x->max_batch, n_frames - c0);
         HF_HIP(hipEventSynchronize(p.ev_down[s]));

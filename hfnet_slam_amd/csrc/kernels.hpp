@@ -118,9 +118,10 @@ hipError_t launch_resampler(const float* data, const float* warp, float* out, in
 hipError_t launch_softmax_rows(float* x, long long rows, int n, int ld, hipStream_t s);
 // NetVLAD aggregation + intra-normalisation + both L2 normalisations (layers.py:77-97)
 // vlad_tap: logical order; out: the FC kernel's slot order within every group of 16 (fc_slot_of_logical)
-hipError_t launch_vlad(const float* feat /*phys layout [frames x P x D]*/, const float* memb /*[frames x P x K]*/,
-                       const float* clusters, float* vlad_tap /*[frames x K*D] or null*/, float* out /*[frames x K*D]*/,
-                       float* scratch /*[frames x K*D]*/, int frames, int P, int D, int K, hipStream_t s);
+int vlad_scratch_parts();      // partial sums per output the scratch tensor of launch_vlad holds ([frames][parts][K * D])
+hipError_t launch_vlad_aggregate(const float* feat /*phys layout [frames x P x D]*/, const float* memb /*[frames x P x K]*/, const float* clusters,
+                                 float* scratch /*[frames][parts][K * D]*/, int frames, int P, int D, int K, hipStream_t s);
+hipError_t launch_vlad_norm(const float* scratch, float* vlad_tap /*optional*/, float* out /*FC slot order*/, int frames, int D, int K, hipStream_t s);
 // dimensionality reduction: FC + bias as one MFMA GEMM over the frames of the batch, split 16 ways along the inputs (weights
 // cross HBM once, 4096 workgroups stream them) + L2 normalise (layers.py:98-108).  x: [frames][n_in] in the FC slot order
 // (fc_slot_of_logical), pack: FcPack of weights.cpp; partial: fc_scratch_floats() floats

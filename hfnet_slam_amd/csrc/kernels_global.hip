@@ -75,31 +75,56 @@ hipError_t launch_softmax_rows(float* x, long long rows, int n, int ld, hipStrea
     return hipGetLastError();
 }
 
-// desc[k][d] = sum_p (c[k][d] - f[p][d]) * m[p][k], pixels left to right (layers.py:82-87).
-// feat is in the device channel layout; thread handles physical slot pd == logical channel d.  The
-// chain over pixels is sequential by definition; the loads are unrolled 24 deep to hide their latency.
+// desc[k][d] = sum_p (c[k][d] - f[p][d]) * m[p][k] (layers.py:82-87).  Canonical order (oracle/hfnet_oracle.c global_head): the
+// pixels are split into VLAD_PARTS contiguous ranges of ceil(P / VLAD_PARTS), every range is one chain in pixel order from 0
+// (r = c - f; t = r * m; acc = acc + t), the partial sums are added as a balanced binary tree (k_vlad_norm).  Round 3's single
+// chain over all 360 pixels per output -- 7680 outputs per frame, each thread pulling its own f and m values through L1 -- took
+// 106 us per 128 frames.  Here a thread owns one channel d of one range and SIXTEEN clusters at a time: f[p][d] is loaded once
+// per 16 clusters (coalesced), the memberships m[p][k0 .. k0 + 15] are wave-uniform scalar loads.
+// feat is in the device channel layout; thread handles physical slot pd == logical channel d.
+#define VLAD_PARTS 8
+template <int KC>                                             // clusters per pass (K is a multiple of KC)
 __global__ __launch_bounds__(256) void k_vlad_aggregate(const float* __restrict__ feat, const float* __restrict__ memb,
-                                                        const float* __restrict__ clusters, float* __restrict__ out, int P, int D, int K) {
-    const int frame = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= K * D) return;
-    const int k = t / D, pd = t - k * D;
-    const int rr = pd & 7;
-    const int d = (pd & ~7) | (rr < 4 ? 2 * rr : 2 * (rr - 4) + 1);
-    const float c = clusters[k * D + d];
-    const float* f = feat + (long long)frame * P * D + pd;
-    const float* m = memb + (long long)frame * P * K + k;
-    float acc = 0.0f;
-    int p = 0;
-    for (; p + 24 <= P; p += 24) {                            // 24 pixels of loads in flight (the chain itself is 3 instructions per pixel)
-        float fv[24], mv[24];
+                                                        const float* __restrict__ clusters, float* __restrict__ out /* [frames][VLAD_PARTS][K * D] */,
+                                                        int P, int D, int K) {
+    typedef float mvec_t __attribute__((ext_vector_type(KC)));
+    const int frame = blockIdx.z, part = blockIdx.y;
+    const int pd = blockIdx.x * 256 + threadIdx.x;
+    const int pp = (P + VLAD_PARTS - 1) / VLAD_PARTS;
+    const int p0 = min(part * pp, P), p1 = min(p0 + pp, P);
+    const bool live = pd < D;
+    const int pdc = live ? pd : D - 1;
+    const int rr = pdc & 7;
+    const int d = (pdc & ~7) | (rr < 4 ? 2 * rr : 2 * (rr - 4) + 1);
+    const float* __restrict__ f = feat + (long long)frame * P * D + pdc;
+    const float* __restrict__ m = memb + (long long)frame * P * K;         // uniform: the memberships come through the scalar cache
+    float* __restrict__ o = out + ((long long)frame * VLAD_PARTS + part) * K * D;
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        float c[KC], acc[KC];
 #pragma unroll
-        for (int j = 0; j < 24; ++j) { fv[j] = f[(long long)(p + j) * D]; mv[j] = m[(long long)(p + j) * K]; }
+        for (int j = 0; j < KC; ++j) { c[j] = clusters[(k0 + j) * D + d]; acc[j] = 0.0f; }
+        int p = p0;
+        for (; p + 4 <= p1; p += 4) {                              // four pixels of loads in flight
+            float fv[4];
+            mvec_t mv[4];
 #pragma unroll
-        for (int j = 0; j < 24; ++j) { const float r = c - fv[j]; const float tt = r * mv[j]; acc = acc + tt; }
+            for (int u = 0; u < 4; ++u) { fv[u] = f[(long long)(p + u) * D]; mv[u] = *(const mvec_t*)(m + (long long)(p + u) * K + k0); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < KC; ++j) { const float r = c[j] - fv[u]; const float tt = r * mv[u][j]; acc[j] = acc[j] + tt; }
+        }
+        for (; p < p1; ++p) {
+            const float fv = f[(long long)p * D];
+            const mvec_t mv = *(const mvec_t*)(m + (long long)p * K + k0);
+#pragma unroll
+            for (int j = 0; j < KC; ++j) { const float r = c[j] - fv; const float tt = r * mv[j]; acc[j] = acc[j] + tt; }
+        }
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < KC; ++j) o[(k0 + j) * D + d] = acc[j];
+        }
     }
-    for (; p < P; ++p) { const float r = c - f[(long long)p * D]; const float tt = r * m[(long long)p * K]; acc = acc + tt; }
-    out[(long long)frame * K * D + k * D + d] = acc;
 }
 
 // block-wide tree256 sum of squares of v[0..n): partial tid accumulates elements tid + 256 j
@@ -127,8 +152,17 @@ __global__ __launch_bounds__(1024) void k_vlad_norm(const float* __restrict__ ra
     float* v = smem;            // K*D
     float* red = smem + K * D;  // 256
     const int frame = blockIdx.x, N = K * D, T = blockDim.x;
-    const float* src = raw + (long long)frame * N;
-    for (int i = threadIdx.x; i < N; i += T) v[i] = src[i];
+    const float* src = raw + (long long)frame * VLAD_PARTS * N;   // the VLAD_PARTS partial sums of every output: balanced binary tree
+    for (int i = threadIdx.x; i < N; i += T) {
+        float pt[VLAD_PARTS];
+#pragma unroll
+        for (int w = 0; w < VLAD_PARTS; ++w) pt[w] = src[(long long)w * N + i];
+#pragma unroll
+        for (int n = VLAD_PARTS; n > 1; n >>= 1)
+#pragma unroll
+            for (int w = 0; w < n / 2; ++w) pt[w] = pt[2 * w] + pt[2 * w + 1];
+        v[i] = pt[0];
+    }
     __syncthreads();
     for (int d = threadIdx.x; d < D; d += T) {
         float ss = 0.0f;
@@ -151,10 +185,18 @@ __global__ __launch_bounds__(1024) void k_vlad_norm(const float* __restrict__ ra
     }
 }
 
-hipError_t launch_vlad(const float* feat, const float* memb, const float* clusters, float* vlad_tap, float* out, float* scratch,
-                       int frames, int P, int D, int K, hipStream_t s) {
+int vlad_scratch_parts() { return VLAD_PARTS; }
+hipError_t launch_vlad_aggregate(const float* feat, const float* memb, const float* clusters, float* scratch, int frames, int P, int D, int K, hipStream_t s) {
     if (frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_vlad_aggregate, dim3((K * D + 255) / 256, frames), dim3(256), 0, s, feat, memb, clusters, scratch, P, D, K);
+    const dim3 grid((D + 255) / 256, VLAD_PARTS, frames);
+    if (K % 16 == 0) hipLaunchKernelGGL((k_vlad_aggregate<16>), grid, dim3(256), 0, s, feat, memb, clusters, scratch, P, D, K);
+    else if (K % 8 == 0) hipLaunchKernelGGL((k_vlad_aggregate<8>), grid, dim3(256), 0, s, feat, memb, clusters, scratch, P, D, K);
+    else if (K % 4 == 0) hipLaunchKernelGGL((k_vlad_aggregate<4>), grid, dim3(256), 0, s, feat, memb, clusters, scratch, P, D, K);
+    else hipLaunchKernelGGL((k_vlad_aggregate<1>), grid, dim3(256), 0, s, feat, memb, clusters, scratch, P, D, K);
+    return hipGetLastError();
+}
+hipError_t launch_vlad_norm(const float* scratch, float* vlad_tap, float* out, int frames, int D, int K, hipStream_t s) {
+    if (frames <= 0) return hipSuccess;
     const size_t lds = (size_t)(K * D + 256) * sizeof(float);
     hipLaunchKernelGGL(k_vlad_norm, dim3(frames), dim3(1024), lds, s, scratch, vlad_tap, out, D, K);
     return hipGetLastError();

@@ -171,6 +171,17 @@ int hfnet_extractor_last_timing(hfnet_extractor* x, double* us, int n);
 int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_t* images,
                                   int row_stride, size_t frame_stride, hfnet_keypoint* kps,
                                   float* local_desc, float* global_desc, int* n_out, int on_device);
+/* Caller memory registered for DMA (the H2D / D2H boundary of the reference's GPU back end: cudaMemcpy from / into the
+ * cv::Mat buffers, HFNetRTModel.cc:128,134).  A host-pointer hfnet_extractor_extract_batch call whose image block
+ * (frames contiguous: row_stride == width, frame_stride == width * height) and whose kps / local_desc / n_out
+ * (and global_desc, if given) buffers ALL lie inside registered ranges moves its data straight between the caller's memory
+ * and the GPU -- no pinned staging block, no staging memcpy on the host: the images of chunk c + 1 are read and the results of
+ * chunk c - 1 written by the copy engines while chunk c computes.  Such a call writes all n_features rows of every frame slot
+ * (rows from n_out[f] on are unspecified); results are the same bits.  Anything else takes the staged pipeline above.
+ * hfnet_host_register page-locks [ptr, ptr + bytes) (hipHostRegister); the range must stay allocated until
+ * hfnet_host_unregister(ptr).  Registering a range twice or unregistering an unknown pointer is HFNET_ERR_INVALID_ARG. */
+int hfnet_host_register(void* ptr, size_t bytes);
+int hfnet_host_unregister(void* ptr);
 
 /* ---- Matcher brute-force bodies (src/Matcher.cc) ------------------------------------------------ */
 /* Matcher::DescriptorDistance (Matcher.cc:1893-1900) */

@@ -29,6 +29,7 @@
 #include <omp.h>
 
 #define HFO_FC_PARTS 16   /* partial chains of the dimensionality-reduction FC (see global_head) */
+#define HFO_VLAD_PARTS 8  /* partial chains of the NetVLAD pixel sum (see global_head) */
 #endif
 
 #define HFO_BN_EPS 1e-3f
@@ -413,10 +414,23 @@ static void global_head(const hfo_model* m, const float* feat, int h, int w, flo
     float* v = (float*)malloc(sizeof(float) * (size_t)K * D);
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < K; ++k)
-        for (int d = 0; d < D; ++d) {                               /* sum_hw (c - f) * m   (layers.py:82-87) */
-            float acc = 0.0f, c = m->clusters[(size_t)k * D + d];
-            for (int p = 0; p < P; ++p) { float r = c - feat[(size_t)p * D + d]; float t = r * mem[(size_t)p * K + k]; acc = acc + t; }
-            v[(size_t)k * D + d] = acc;
+        for (int d = 0; d < D; ++d) {                               /* sum_hw (c - f) * m   (layers.py:82-87).  The reference leaves the
+                                                                       order of this sum to TensorFlow's reduce_sum; canonical here: the
+                                                                       pixels in HFO_VLAD_PARTS contiguous ranges of ceil(P / parts), one
+                                                                       chain in pixel order from 0 per range, the partial sums added as a
+                                                                       balanced binary tree */
+            const float c = m->clusters[(size_t)k * D + d];
+            const int pp = (P + HFO_VLAD_PARTS - 1) / HFO_VLAD_PARTS;
+            float part[HFO_VLAD_PARTS];
+            for (int s = 0; s < HFO_VLAD_PARTS; ++s) {
+                const int p0 = s * pp < P ? s * pp : P, p1 = p0 + pp < P ? p0 + pp : P;
+                float acc = 0.0f;
+                for (int p = p0; p < p1; ++p) { float r = c - feat[(size_t)p * D + d]; float t = r * mem[(size_t)p * K + k]; acc = acc + t; }
+                part[s] = acc;
+            }
+            for (int n = HFO_VLAD_PARTS; n > 1; n >>= 1)
+                for (int s = 0; s < n / 2; ++s) part[s] = part[2 * s] + part[2 * s + 1];
+            v[(size_t)k * D + d] = part[0];
         }
     for (int d = 0; d < D; ++d) {                                   /* l2_normalize(axis=1): over clusters (layers.py:89) */
         float ss = 0.0f;

@@ -20,14 +20,23 @@
  *     into the layer as inference engines do (w[..., c] *= gamma[c] / sqrt(var[c] + eps), one f32 rounding per weight;
  *     bias[c] = beta[c] - mean[c] * that scale); one accumulator per output, STARTED AT bias[c], updated with a fused
  *     multiply-add per term, terms in (ky, kx, cin) order; then ReLU6 where the layer has one.
- *   - short sums (softmax over 65 / 32 channels, NetVLAD over pixels, intra-norm over K):
- *     left to right.
+ *   - short sums (softmax over 65 / 32 channels, intra-norm over K): left to right.
+ *   - the NetVLAD sum over pixels: the pixels in 8 contiguous ranges of ceil(P / 8), one left-to-right chain per range from 0
+ *     (r = c - f; t = r * m; acc = acc + t), the eight partial sums added as a balanced binary tree (global_head).
+ *   - the dimensionality-reduction FC: sixteen partial fma chains over contiguous input ranges, balanced binary tree, + bias.
  *   - long vector reductions (L2 norms over 256 / 4096 / 7680 elements, descriptor distances): "tree256" --
  *     256 interleaved partial sums (element i goes to partial i % 256, in increasing i) followed
  *     by a binary tree (stride 128, 64, ..., 1).
  *   - exp() in the softmaxes is hfo_expf below (Cephes-style polynomial, the same family Eigen's
  *     pexp -- what TensorFlow's CPU softmax runs -- uses), so that it is reproducible.
  * Build with -ffp-contract=off: every fused operation is written as an explicit fmaf().
+ *
+ * Known deviations of this restatement from the third-party code it stands for (inside any fp32 tolerance, and exactly what
+ * "unpinned" means): (1) Eigen's GEMM / norm kernels sum in SIMD-lane order, not in the canonical orders above.  (2) cv_l2 (the
+ * distance behind cv::BFMatcher NORM_L2, hfnet_oracle.c) is OpenCV 4.2's GENERIC normL2Sqr template -- four-way unrolled, one
+ * accumulator: s += v0^2 + v1^2 + v2^2 + v3^2 -- while an x86 / NEON build of OpenCV dispatches to the SIMD normL2Sqr_ (four
+ * VECTOR accumulators updated with v_muladd, reduced at the end): another summation order, so a BFMatcher distance can differ in
+ * its last ulp and a first-minimum tie can fall on the other row.
  */
 #ifndef HFNET_ORACLE_H
 #define HFNET_ORACLE_H

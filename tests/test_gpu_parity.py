@@ -840,6 +840,62 @@ def test_host_pipeline_and_attached_store(engine, oracle_model):
     store.close(); x.close()
 
 
+def test_registered_host_buffers_take_the_direct_path(engine, oracle_model):
+    """hfnet_host_register: a host-pointer batch call whose image block and result buffers are all registered DMAs straight from /
+    into the caller's memory (no pinned staging, no staging memcpy); same bits as the staged pipeline and the oracle, with an
+    attached store, over several chunks incl. a ragged last one; a partly registered call falls back to the staged pipeline."""
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    w, h, nf, B, F = 176, 136, 220, 3, 8
+    x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, 3, max_batch=B)
+    store = capi.Store(engine, F, nf)
+    x.attach_store(store, 0)
+    imgs = np.stack([synth_image(h, w, 9900 + i, "natural" if i % 2 else "uniform") for i in range(F)])
+    ref = x.extract_batch(imgs)                                                  # pageable: staged pipeline
+    out = tuple(np.zeros_like(a) for a in ref)
+    bufs = [imgs, out[1], out[2], out[3], out[0]]
+    for b in bufs:
+        capi.host_register(b)
+    try:
+        with pytest.raises(capi.HfnetError):
+            capi.host_register(imgs)                                             # twice
+        got = x.extract_batch(imgs, out)
+        for f in range(F):
+            n = int(ref[0][f])
+            assert got[0][f] == n and np.array_equal(got[1][f, :n], ref[1][f, :n]) and np.array_equal(got[2][f, :n], ref[2][f, :n])
+            assert np.array_equal(got[3][f], ref[3][f])
+            rn, rk, rd, rg, _ = oracle_model.extract(imgs[f], nf, 0.01, 3, 1.2)
+            assert n == rn and np.array_equal(got[1][f, :n], rk) and np.array_equal(got[2][f, :n], rd) and np.array_equal(got[3][f], rg)
+            assert store.rows(f) == n
+        cnt, match, dist = store.search_by_bow([(f - 1, f) for f in range(1, F)], 0.6)
+        for p_, f in enumerate(range(1, F)):
+            rc, rm, rdist = O.search_by_bow(ref[2][f - 1, :ref[0][f - 1]], ref[2][f, :ref[0][f]], 0.6)
+            assert cnt[p_] == rc and np.array_equal(match[p_, :len(rm)], rm) and np.array_equal(dist[p_, :len(rm)], rdist)
+        # strided frames (a ROI per frame) cannot be DMAed as one block: staged path, same results
+        big = np.zeros((F, h + 4, w + 8), np.uint8); big[:, 2:2 + h, 4:4 + w] = imgs
+        capi.host_register(big)
+        try:
+            L = capi.lib()
+            import ctypes as C
+            kps2 = np.zeros_like(out[1]); desc2 = np.zeros_like(out[2]); g2 = np.zeros_like(out[3]); n2 = np.zeros_like(out[0])
+            roi = big[:, 2:2 + h, 4:4 + w]
+            st = L.hfnet_extractor_extract_batch(x.h, F, C.c_void_p(roi.ctypes.data), roi.strides[1], C.c_size_t(roi.strides[0]), C.c_void_p(kps2.ctypes.data),
+                                                 C.c_void_p(desc2.ctypes.data), C.c_void_p(g2.ctypes.data), C.c_void_p(n2.ctypes.data), 0)
+            assert st == capi.OK, capi.last_error()
+            for f in range(F):
+                n = int(ref[0][f])
+                assert n2[f] == n and np.array_equal(kps2[f, :n], ref[1][f, :n]) and np.array_equal(desc2[f, :n], ref[2][f, :n]) and np.array_equal(g2[f], ref[3][f])
+        finally:
+            capi.host_unregister(big)
+    finally:
+        for b in bufs:
+            capi.host_unregister(b)
+    with pytest.raises(capi.HfnetError):
+        capi.host_unregister(imgs)                                               # not registered any more
+    x.attach_store(None)
+    store.close(); x.close()
+
+
 def test_windowed_matcher_loop_and_distinctive_descriptors(engine):
     """the candidate loop of the windowed matchers (Matcher.cc:74-110 and siblings) and
     MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:366-400) on the device == oracle, bit for bit"""
