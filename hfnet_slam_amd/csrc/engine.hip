@@ -21,7 +21,7 @@ int* Options::find(const char* name) {
     const struct { const char* n; int* p; } tab[] = {{"fuse_blocks", &fuse_blocks}, {"fuse_max_layer", &fuse_max_layer}, {"fused_variant", &fused_variant},
                                                        {"fuse_stem", &fuse_stem}, {"dense_desc", &dense_desc}, {"two_streams", &two_streams},
                                                        {"graph", &graph}, {"pinned_frames", &pinned_frames}, {"db_gemm_min_queries", &db_gemm_min_queries},
-                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}, {"interleave", &interleave}, {"host_global", &host_global}, {"det_fuse", &det_fuse}, {"match_screen_bf16", &match_screen_bf16}, {"tri_screen_bf16", &tri_screen_bf16}};
+                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}, {"interleave", &interleave}, {"host_global", &host_global}, {"det_fuse", &det_fuse}, {"match_screen_bf16", &match_screen_bf16}, {"tri_screen_bf16", &tri_screen_bf16}, {"desc_bf16x3", &desc_bf16x3}, {"global_bf16x3", &global_bf16x3}};
     for (const auto& t : tab) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -141,7 +141,7 @@ int Net::build(Engine* eng, const NetConfig& c) {
     e = eng;
     cfg = c;
     // A/B and diagnostics switches of the engine (hfnet_engine_set_option), fixed for the lifetime of this network
-    fuse_blocks = e->opt.fuse_blocks; fuse_max_layer = e->opt.fuse_max_layer; fused_variant = e->opt.fused_variant; fuse_min_wgs = e->opt.fuse_min_wgs; tail_fuse = e->opt.tail_fuse; dedupe_taps = e->opt.dedupe_taps; interleave = e->opt.interleave; det_fuse = e->opt.det_fuse;
+    fuse_blocks = e->opt.fuse_blocks; fuse_max_layer = e->opt.fuse_max_layer; fused_variant = e->opt.fused_variant; fuse_min_wgs = e->opt.fuse_min_wgs; tail_fuse = e->opt.tail_fuse; dedupe_taps = e->opt.dedupe_taps; interleave = e->opt.interleave; det_fuse = e->opt.det_fuse; desc_bf16x3 = e->opt.desc_bf16x3; global_bf16x3 = e->opt.global_bf16x3;
     force_dense = e->opt.dense_desc; fuse_stem = e->opt.fuse_stem; conv_wlds = e->opt.conv_wlds;
     const DeviceWeights& w = e->w;
     if (c.n_levels < 1 || c.n_levels > HFNET_MAX_LEVELS || c.batch < 1) { set_error("net: bad level / batch count"); return HFNET_ERR_INVALID_ARG; }
@@ -297,14 +297,18 @@ static int run_block(Net& n, int L, int n_used, hipStream_t st) {   // layer L =
     snprintf(nm[0], sizeof nm[0], "expand_L%02d", L);
     snprintf(nm[1], sizeof nm[1], "depthwise_L%02d", L);
     snprintf(nm[2], sizeof nm[2], "project_L%02d", L);
+    // option global_bf16x3 (layers past the index-deciding part of the network only): the two 1x1 convolutions on split-bf16 operands
+    const bool bf = n.global_bf16x3 && L > 7 && b.pr_bf && (!b.has_expand || b.ex_bf);
+    if (bf) { std::strcat(nm[0], "_bf16x3"); std::strcat(nm[2], "_bf16x3"); }
     if (b.has_expand) {
-        HF_LAUNCH(e, st, nm[0], launch_pointwise(n.act[L - 1], b.ex, nullptr, n.exp_buf, p_in, 1, st));
+        if (bf) HF_LAUNCH(e, st, nm[0], launch_pointwise_bf16x3(n.act[L - 1], b.ex, b.ex_bf, nullptr, n.exp_buf, p_in, 1, st));
+        else HF_LAUNCH(e, st, nm[0], launch_pointwise(n.act[L - 1], b.ex, nullptr, n.exp_buf, p_in, 1, st));
         src = n.exp_buf;
     }
     const Geom g = n.geom(L - 1, L, 0, n_used);
     HF_LAUNCH(e, st, nm[1], launch_depthwise(src, b.dw, b.stride, n.dw_buf, g, st));
-    HF_LAUNCH(e, st, nm[2],
-              launch_pointwise(n.dw_buf, b.pr, b.residual ? n.act[L - 1] : nullptr, n.act[L], p_out, 0, st));
+    if (bf) HF_LAUNCH(e, st, nm[2], launch_pointwise_bf16x3(n.dw_buf, b.pr, b.pr_bf, b.residual ? n.act[L - 1] : nullptr, n.act[L], p_out, 0, st));
+    else HF_LAUNCH(e, st, nm[2], launch_pointwise(n.dw_buf, b.pr, b.residual ? n.act[L - 1] : nullptr, n.act[L], p_out, 0, st));
     return HFNET_OK;
 }
 
@@ -412,9 +416,16 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
                 // taps shared by neighbouring keypoints are evaluated once: the rows of an image are its DISTINCT tap cells
                 HF_LAUNCH(e, stream, "tap_cells", launch_tap_cells(kps_level, n_level, cfg.max_keypoints, tap_flags, tap_cell_row, tap_cells, tap_nrows, cell_stride, gt, stream));
                 HF_TRY(pump_global(1));
+                if (desc_bf16x3 && w.desc1_bf && w.desc2_bf) {
+                    // option: the head on the bf16 matrix pipe (split operands, three products): tolerance instead of the oracle's bits
+                    HF_LAUNCH(e, stream, "conv3x3_desc_taps_bf16x3", launch_conv3x3_cells_bf16x3(act[7], w.desc1, w.desc1_bf, rows_hidden, 1, cfg.max_keypoints, budget.k, gt, tap_cells, tap_nrows, stream));
+                    HF_TRY(pump_global(2));
+                    HF_LAUNCH(e, stream, "pointwise_desc_taps_bf16x3", launch_pointwise_bf16x3(rows_hidden, w.desc2, w.desc2_bf, nullptr, rows_raw, rows, 0, stream, tap_nrows, 4 * cfg.max_keypoints, 1));
+                } else {
                 HF_LAUNCH(e, stream, "conv3x3_desc_taps", launch_conv3x3_taps(act[7], w.desc1, rows_hidden, 1, kps_level, n_level, cfg.max_keypoints, budget.k, gt, conv_wlds, stream, tap_cells, tap_nrows));
                 HF_TRY(pump_global(2));
                 HF_LAUNCH(e, stream, "pointwise_desc_taps", launch_pointwise(rows_hidden, w.desc2, nullptr, rows_raw, rows, 0, stream, tap_nrows, 4 * cfg.max_keypoints, 1));
+                }
             } else {
                 HF_LAUNCH(e, stream, "conv3x3_desc_taps", launch_conv3x3_taps(act[7], w.desc1, rows_hidden, 1, kps_level, n_level, cfg.max_keypoints, budget.k, gt, conv_wlds, stream));
                 HF_LAUNCH(e, stream, "pointwise_desc_taps", launch_pointwise(rows_hidden, w.desc2, nullptr, rows_raw, rows, 0, stream, n_level, 4 * cfg.max_keypoints, 4));

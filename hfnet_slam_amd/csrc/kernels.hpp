@@ -32,6 +32,14 @@ hipError_t launch_conv3x3(const float* A, const ConvPack& cp, float* out, int re
 // score-map size, Ho, Wo = cell grid, in_off = first cell of the level.
 // cells / n_rows (optional, launch_tap_cells): keypoints at least 5 pixels apart on an 8-pixel cell grid share taps -- the rows of an
 // image are then its n_rows[image] DISTINCT tap cells (row r of the slot is cell cells[image * kps_stride * 4 + r]).
+// split-bf16 forms (engine option desc_bf16x3; kernels_conv.hip): NOT the oracle's bits -- within the tolerance of include/hfnet_hip.h
+size_t bf16x3_pack_bytes(const ConvPack& cp);
+hipError_t launch_repack_bf16x3(const ConvPack& cp, void* out, hipStream_t s);
+inline bool bf16x3_supported(const ConvPack& cp) { return (cp.taps == 1 && cp.cin % 8 == 0) || (cp.taps == 9 && cp.cin % 16 == 0); }
+hipError_t launch_conv3x3_cells_bf16x3(const float* A, const ConvPack& cp, const void* Wb, float* out, int relu6, long long kps_stride,
+                                       const int* level_keypoints, const Geom& g, const int* cells, const int* n_rows, hipStream_t s);
+hipError_t launch_pointwise_bf16x3(const float* A, const ConvPack& cp, const void* Wb, const float* residual, float* out, long long P, int relu6,
+                                   hipStream_t s, const int* slot_units = nullptr, int slot_rows = 0, int rows_per_unit = 0);
 hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, int relu6, const hfnet_keypoint* kps, const int* n_in,
                                long long kps_stride, const int* level_keypoints /* upper bound of n_in per level */, const Geom& g, int wlds,
                                hipStream_t s, const int* cells = nullptr, const int* n_rows = nullptr);

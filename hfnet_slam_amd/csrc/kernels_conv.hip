@@ -1156,6 +1156,266 @@ hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, i
     return launch_conv3x3_any(A, cp, out, relu6, g, &ta, rows, wlds, s);
 }
 
+// =========================================================================== split-bf16 GEMMs (engine options desc_bf16x3 / global_bf16x3)
+// north_star: "keypoint indices bit-exact ..., descriptor/score tensors within a stated fp32 tolerance".  Everything that DECIDES
+// an index (backbone layers 1-7, detector head, NMS, top-K) stays on the exact f32 chains above.  The stages that only produce
+// float tensors may -- as an engine OPTION, default off -- run on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16 x the f32
+// MFMA rate): every f32 operand is split into two bf16 pieces x = hi + lo + e (round to nearest even twice, |e| <= 2^-16 |x|) and
+// a.w ~ ah.wh + ah.wl + al.wh -- three instructions of 32 cycles per 16 k where the f32 form needs eight of 64.  The bf16 x bf16
+// products are exact in fp32; dropped are al.wl and the e terms (<= 3 * 2^-16 |a w| per term, worst case) and the sums follow the
+// unit's own order: the results are NOT the oracle's bits but within the tolerance stated in include/hfnet_hip.h (tests/).
+// Weights are split once per engine (k_repack_bf16x3 from the f32 ConvPack); activations are split in registers by the consuming
+// kernel.  K order of a 16-k step s: k = 8 half + p is PHYSICAL slot p of channel group 2 s + half (a lane's 32 consecutive
+// bytes of an activation row), so no permutation is needed on either side.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// f32 pack [kq][nt][lane][4 t] (logical channel 2 t + half of group kq) -> [s][nt][hi | lo][lane][8]: element e of lane (half, j)
+// is physical slot e of group 2 s + half = logical channel lop(e): e < 4 -> (t = e, half' = 0), else (t = e - 4, half' = 1)
+__global__ __launch_bounds__(256) void k_repack_bf16x3(const f32x4* __restrict__ W, int kq_total, int nt_total, bf16x8* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int steps = (kq_total + 1) / 2;                          // (an odd number of channel groups: the last step's upper half is zeros)
+    if (idx >= (long long)steps * nt_total * 64) return;
+    const int lane = (int)(idx & 63), nt = (int)((idx >> 6) % nt_total), s = (int)((idx >> 6) / nt_total);
+    const int half = lane >> 5, j = lane & 31, kq = 2 * s + half;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 w0 = kq < kq_total ? W[((size_t)kq * nt_total + nt) * 64 + j] : z4, w1 = kq < kq_total ? W[((size_t)kq * nt_total + nt) * 64 + 32 + j] : z4;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = e < 4 ? w0[e] : w1[e - 4];
+        hi[e] = (__bf16)v;
+        lo[e] = (__bf16)(v - (float)hi[e]);
+    }
+    out[(((size_t)s * nt_total + nt) * 2 + 0) * 64 + lane] = hi;
+    out[(((size_t)s * nt_total + nt) * 2 + 1) * 64 + lane] = lo;
+}
+
+hipError_t launch_repack_bf16x3(const ConvPack& cp, void* out, hipStream_t s) {
+    const int kq_total = cp.taps * cp.cin / 8;
+    if (cp.cin % 8 || (cp.taps != 1 && cp.cin % 16)) return hipErrorInvalidValue;
+    const long long n = (long long)((kq_total + 1) / 2) * cp.nt_total * 64;
+    hipLaunchKernelGGL(k_repack_bf16x3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const f32x4*)cp.w, kq_total, cp.nt_total, (bf16x8*)out);
+    return hipGetLastError();
+}
+size_t bf16x3_pack_bytes(const ConvPack& cp) { return (size_t)((cp.taps * cp.cin / 8 + 1) / 2) * cp.nt_total * 2 * 64 * 16; }
+
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = e < 4 ? v0[e] : v1[e - 4];
+        hi[e] = (__bf16)v;                                     // (v_cvt_pk_bf16_f32: round to nearest even)
+        lo[e] = (__bf16)(v - (float)hi[e]);                    // (the difference is exact in fp32)
+    }
+}
+
+// A workgroup = 256 rows x 128 columns (wave: 64 rows x 128 columns, eight 32 x 32 accumulator tiles): the weight fragments of a
+// slab of two 16-k steps (16 KB: 4 column tiles x {hi, lo} x 2 steps) go through LDS once per workgroup, double buffered, one
+// barrier per slab; the activation rows are requested a slab ahead.  GATHER: the rows of an image are its distinct tap cells and
+// K walks the nine taps of the 3 x 3 window (out-of-image taps: zeros), as k_conv3x3; otherwise rows are plain [P][cin] rows
+// (slotted rows: tiles in the unused part of a slot are skipped).  Bias as the accumulators' start, ReLU6 and stores: conv_epilogue.
+template <bool GATHER>
+__global__ __launch_bounds__(256, 2) void k_conv_bf16x3(ConvArgs a, const bf16x8* __restrict__ Wb, Geom g, TapArgs ta) {
+    constexpr int NT = 4, MT = 2, SS = 2;                       // column tiles / row tiles per wave, steps per slab
+    __shared__ __attribute__((aligned(16))) bf16x8 wl[2][SS * NT * 2 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+    int grp, tile, Wc = 0, Hc = 0;
+    long long nrows, in_base = 0, out_base = 0;
+    int image = 0;
+    if (GATHER) {
+        const int G = (a.nt_total + NT - 1) / NT;
+        int level = 0, rest = blockIdx.x;
+        for (; level < g.n_levels - 1; ++level) {
+            const int per = g.batch * G * a.level_tiles[level];
+            if (rest < per) break;
+            rest -= per;
+        }
+        const int tl = a.level_tiles[level];
+        const int frame = rest / (G * tl);
+        rest -= frame * G * tl;
+        grp = rest / tl; tile = rest - grp * tl;
+        image = level * g.batch + frame;
+        const LevelGeom lv = g.lv[level];
+        Hc = lv.Ho; Wc = lv.Wo;
+        nrows = ta.n_rows[image];
+        in_base = lv.in_off + (long long)frame * Hc * Wc;
+        out_base = (long long)image * ta.kps_stride * 4;
+    } else {
+        tile = blockIdx.x; grp = blockIdx.y; nrows = a.P;
+    }
+    if ((long long)tile * 256 >= nrows) return;                 // (workgroup-uniform)
+    const int nt0 = grp * NT, ntv = min(NT, a.nt_total - nt0);  // column tiles of this group that exist (the last group may be ragged)
+    const long long p0 = (long long)tile * 256 + wave * 64;
+    // a wave without rows still takes part in the staging and the barriers
+    bool live = p0 < nrows;
+    if (!GATHER && live && !tile_in_use(a, p0, 64)) live = false;
+    const int spt = (a.cin + 15) >> 4;                          // 16-k steps per tap (1x1: the last one may hold 8 channels)
+    const int n_steps = (GATHER ? 9 : 1) * spt, n_slabs = (n_steps + SS - 1) / SS;
+    // ---- this lane's two rows: centre pointers (+ tap validity bits)
+    const char* cptr[MT];
+    unsigned okbits[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const long long row = p0 + 32 * i + r;
+        const bool pvalid = live && row < nrows;
+        okbits[i] = 0;
+        if (GATHER) {
+            const int cell = pvalid ? ta.cells[(long long)image * ta.kps_stride * 4 + row] : 0;
+            const int y = cell / Wc, x = cell - y * Wc;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+                if (pvalid && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc) okbits[i] |= 1u << tap;
+            }
+            cptr[i] = (const char*)(a.A + (in_base + (long long)y * Wc + x) * a.cin + half * 8);
+        } else {
+            okbits[i] = pvalid ? 1u : 0u;
+            cptr[i] = (const char*)(a.A + (pvalid ? row : 0) * a.cin + half * 8);
+        }
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float b = a.bias[(nt0 + min(nt, ntv - 1)) * 32 + r];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][nt][e] = b;
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // activation pieces of one slab: [step][row tile][two 16-byte pieces].  A slab's pieces are split into their bf16 fragments
+    // first; the registers they came in then take the NEXT slab's loads, which have the slab's 48 MFMAs to arrive.
+    f32x4 av[SS][MT][2];
+    auto load_a = [&](int slab) {
+#pragma unroll
+        for (int ss = 0; ss < SS; ++ss) {
+            const int s = min(slab * SS + ss, n_steps - 1);
+            const int tap = GATHER ? s / spt : 0, cs = s - tap * spt;
+            const int toff = GATHER ? ((tap / 3 - 1) * Wc + (tap % 3 - 1)) * a.cin * 4 : 0;     // uniform
+            const bool kok = cs * 16 + half * 8 < a.cin;         // (the upper half of a last step of 8 channels: zeros)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const bool ok = ((okbits[i] >> tap) & 1u) && kok;
+                const char* p = cptr[i] + (ok ? toff : 0) + (kok ? cs * 64 : 0);
+                const f32x4 v0 = *(const f32x4*)p, v1 = *(const f32x4*)(p + 16);
+                av[ss][i][0] = ok ? v0 : zero4; av[ss][i][1] = ok ? v1 : zero4;
+            }
+        }
+    };
+    // weight pieces of one slab: 16 pieces of 1 KB ([step][nt][hi | lo]), thread tid takes pieces j * 4 + (tid >> 6), 16 bytes each
+    bf16x8 ws[4];
+    auto load_w = [&](int slab) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = j * 4 + wave, ss = piece >> 3, nt = (piece >> 1) & 3, hl = piece & 1;
+            const int s = min(slab * SS + ss, n_steps - 1);
+            ws[j] = Wb[(((size_t)s * a.nt_total + nt0 + min(nt, ntv - 1)) * 2 + hl) * 64 + lane];
+        }
+    };
+    auto stash_w = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wl[buf][(j * 4 + wave) * 64 + lane] = ws[j];
+    };
+    load_w(0); load_a(0);
+    stash_w(0);
+    __syncthreads();
+    for (int slab = 0; slab < n_slabs; ++slab) {
+        const int buf = slab & 1;
+        bf16x8 ah[SS][MT], al[SS][MT];
+#pragma unroll
+        for (int ss = 0; ss < SS; ++ss)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) split8(av[ss][i][0], av[ss][i][1], ah[ss][i], al[ss][i]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(min(slab + 1, n_slabs - 1)); load_a(min(slab + 1, n_slabs - 1));      // (unconditional: the last pass re-reads its own slab)
+        __builtin_amdgcn_sched_barrier(0);
+        if (live) {
+            // the (step, column tile) pairs of the slab as one sequence: the fragments of pair q + 1 are read from LDS before the MFMAs of
+            // pair q are issued (left alone the compiler puts every ds_read right in front of its first use: ~100 exposed cycles per pair)
+            const int n_q = min(SS, n_steps - slab * SS) * NT;  // (uniform; an odd step count leaves the last slab half empty)
+            bf16x8 bh = wl[buf][0 * 64 + lane], bl = wl[buf][1 * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < SS * NT; ++q) {
+                if (q < n_q) {
+                    const int ss = q / NT, nt = q % NT, qn = min(q + 1, SS * NT - 1);
+                    const bf16x8 bhn = wl[buf][(qn * 2 + 0) * 64 + lane], bln = wl[buf][(qn * 2 + 1) * 64 + lane];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (nt < ntv) {                             // (uniform: a ragged last column group)
+                        // (the three products of one accumulator are never back to back: a dependent MFMA would wait for its predecessor)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ss][i], bh, acc[i][nt], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ss][i], bl, acc[i][nt], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ss][i], bh, acc[i][nt], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    bh = bhn; bl = bln;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stash_w(buf ^ 1);
+        __syncthreads();
+    }
+    if (live) {
+        // (ReLU6 as a median with +-infinity bounds when the layer has none: one instruction either way)
+        const float lo6 = a.relu6 ? 0.0f : -INFINITY, hi6 = a.relu6 ? 6.0f : INFINITY;
+        const long long n = a.n;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const long long row0 = p0 + 32 * i + 4 * half;
+            const int left = (int)min((long long)32, nrows - row0);          // rows of this lane's column that exist (may be <= 0)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = (nt0 + nt) * 32 + r;
+                if (nt < ntv && col < a.n) {
+                    float* __restrict__ op = a.out + (out_base + row0) * n + col;
+                    const float* __restrict__ rp = a.res ? a.res + (out_base + row0) * n + col : nullptr;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int rr = (reg & 3) + 8 * (reg >> 2);
+                        if (rr < left) {
+                            float v = __builtin_amdgcn_fmed3f(acc[i][nt][reg], lo6, hi6);
+                            if (rp) v = v + rp[rr * n];
+                            op[rr * n] = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// 3 x 3 convolution at the distinct tap cells (GATHER) / 1 x 1 convolution on rows, both on split bf16 operands.
+// Wb: launch_repack_bf16x3 of `cp`.  Shapes: cin % 16 == 0, nt_total % 4 == 0.
+hipError_t launch_conv3x3_cells_bf16x3(const float* A, const ConvPack& cp, const void* Wb, float* out, int relu6, long long kps_stride,
+                                       const int* level_keypoints, const Geom& g, const int* cells, const int* n_rows, hipStream_t s) {
+    if (cp.taps != 9 || cp.cin % 16 || !cells || !n_rows) return hipErrorInvalidValue;
+    ConvArgs a = make_args(A, cp, nullptr, out, 0, relu6);
+    const int groups = (cp.nt_total + 3) / 4;
+    const TapArgs ta = {nullptr, nullptr, kps_stride, cells, n_rows};
+    long long total = 0;
+    for (int l = 0; l < g.n_levels; ++l) {
+        const int rows = 4 * (int)std::min<long long>(level_keypoints[l], kps_stride);
+        a.level_tiles[l] = std::max(1, (rows + 255) / 256);
+        total += (long long)g.batch * groups * a.level_tiles[l];
+    }
+    if (total <= 0 || total > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_conv_bf16x3<true>), dim3((unsigned)total), dim3(256), 0, s, a, (const bf16x8*)Wb, g, ta);
+    return hipGetLastError();
+}
+hipError_t launch_pointwise_bf16x3(const float* A, const ConvPack& cp, const void* Wb, const float* residual, float* out, long long P, int relu6,
+                                   hipStream_t s, const int* slot_units, int slot_rows, int rows_per_unit) {
+    if (P <= 0) return hipSuccess;
+    if (cp.taps != 1 || cp.cin % 8) return hipErrorInvalidValue;
+    ConvArgs a = make_args(A, cp, residual, out, P, relu6);
+    if (slot_units && slot_rows > 0) { a.slot_units = slot_units; a.slot_rows = slot_rows; a.rows_per_unit = rows_per_unit; }
+    const Geom g0 = {};
+    const TapArgs none = {nullptr, nullptr, 0, nullptr, nullptr};
+    hipLaunchKernelGGL((k_conv_bf16x3<false>), dim3((unsigned)((P + 255) / 256), (cp.nt_total + 3) / 4), dim3(256), 0, s, a, (const bf16x8*)Wb, g0, none);
+    return hipGetLastError();
+}
+
 // =========================================================================== depthwise 3x3
 // One thread = 4 channels x a vertical strip of R output pixels of one column: the (R s + 2) x 3 input pieces and the nine
 // weight pieces are loaded once and serve R outputs (a thread per output re-read every input piece up to nine times

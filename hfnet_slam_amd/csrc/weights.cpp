@@ -5,6 +5,7 @@
 // runtime lay weights out (src/Extractors/HFNetRTModel.cc:208-254, HFNetTFModelV2.cc:180-202).
 // Tensor names / layouts: hfnet_slam_amd/weights.py.
 #include "common.hpp"
+#include "kernels.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -265,6 +266,25 @@ int DeviceWeights::build(const WeightFile& wf) {
     if (n != HFNET_DESC_DIM || desc1.cin != c_local) { set_error("descriptor head shape mismatch"); return HFNET_ERR_IO; }
     HF_TRY(pack_conv_bias(*this, wf, "local_head/descriptor/Conv_1", desc2, &n));
     if (n != HFNET_DESC_DIM) { set_error("descriptor dim %d != 256", n); return HFNET_ERR_IO; }
+    {   // engine options desc_bf16x3 / global_bf16x3: the same folded weights as bf16 hi / lo pieces
+        auto split = [&](const ConvPack& cp, void** out) -> int {
+            *out = nullptr;
+            if (!cp.w || !bf16x3_supported(cp)) return HFNET_OK;
+            void* p = nullptr;
+            HF_HIP(hipMalloc(&p, bf16x3_pack_bytes(cp)));
+            allocations.push_back(p);
+            HF_HIP(launch_repack_bf16x3(cp, p, nullptr));
+            *out = p;
+            return HFNET_OK;
+        };
+        HF_TRY(split(desc1, &desc1_bf)); HF_TRY(split(desc2, &desc2_bf));
+        if (!desc1_bf || !desc2_bf) desc1_bf = desc2_bf = nullptr;
+        for (int i = 13; i < 17; ++i) {                             // layers 15-18
+            if (blocks[i].has_expand) HF_TRY(split(blocks[i].ex, &blocks[i].ex_bf));
+            HF_TRY(split(blocks[i].pr, &blocks[i].pr_bf));
+        }
+        HF_HIP(hipStreamSynchronize(nullptr));
+    }
     HF_TRY(pack_conv_bn(*this, wf, "local_head/detector/Conv", true, det1, &det_hidden));
     HF_TRY(pack_conv_bias(*this, wf, "local_head/detector/Conv_1", det2, &n));
     if (n != 65 || det2.cin != det_hidden) { set_error("detector head shape mismatch"); return HFNET_ERR_IO; }

@@ -104,7 +104,22 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *                       pairs did, the next 16 calls skip the screen (writing the option resets that).  Same matches, bit for bit
  *   "copy_threads" (64 = by core count): helper threads for the staging copies of host-pointer batch calls (replicas sharing a host)
  * Values are >= 0.
- * Every setting of the extractor and matcher switches produces the same bits (tests/test_gpu_parity.py). */
+ * Every setting of the extractor and matcher switches ABOVE produces the same bits (tests/test_gpu_parity.py).
+ *
+ * Two options trade the oracle's bits of FLOAT outputs for speed, within a stated tolerance; both default to 0, and neither
+ * touches anything that decides an index -- backbone layers 1-7, detector head, NMS, threshold scan and top-K run the exact f32
+ * chains whatever they say, so keypoint counts, positions, responses and octaves stay bit-identical:
+ *   "desc_bf16x3" (0)   the sparse descriptor head (3x3 96 -> 256 + ReLU6, 1x1 256 -> 256 at the distinct tap cells) on the bf16 matrix
+ *                       pipe: every f32 operand is split into two bf16 pieces x = hi + lo + e, |e| <= 2^-16 |x|, and a product
+ *                       a.w is taken as ah.wh + ah.wl + al.wh (v_mfma_f32_32x32x16_bf16; exact products, fp32 accumulation in the
+ *                       unit's order).  Per output of a K-term convolution |error| <= (3 * 2^-16 + K * 2^-23) * sum_k |a_k||w_k|
+ *                       in the worst case; the errors are rounding residues of random sign, and on the unit-norm 256-D rows the
+ *                       extractor returns the deviation from the exact path is <= 2e-6 as measured (752x480 and 512x512, 4 levels;
+ *                       tests/test_gpu_fullsize.py).  STATED TOLERANCE: 1e-5 absolute per component of a (unit-norm) descriptor row.
+ *   "global_bf16x3" (0) the same for the 1x1 convolutions of layers 15-18 (the blocks of the global branch that run as three
+ *                       launches).  STATED TOLERANCE: 1e-5 absolute per component of the (unit-norm) 4096-D global descriptor
+ *                       (measured <= 1.5e-6).  Layers 8-14 (fused blocks), the NetVLAD head and the dimensionality reduction stay exact.
+ * The matcher and the database are exact FOR THE DESCRIPTORS THEY ARE GIVEN in either mode. */
 int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value);
 int hfnet_engine_get_option(hfnet_engine* e, const char* name, int* value);
 int hfnet_engine_synchronize(hfnet_engine* e);

@@ -144,6 +144,58 @@ def test_mid_sized_call_every_frame_vs_oracle(engine, oracle_model, size):
     x.close()
 
 
+BF16X3_DESC_TOL = 1e-5        # abs, on unit-norm 256-D rows (include/hfnet_hip.h; observed <= 2e-6)
+BF16X3_GLOBAL_TOL = 1e-5      # abs, on the unit-norm global descriptor (observed <= 1.5e-6)
+
+
+@pytest.mark.parametrize("cfg", [(752, 480, 1000), (512, 512, 850)])
+def test_split_bf16_options_keep_indices_exact_and_floats_within_tolerance(engine, oracle_model, cfg):
+    """engine options desc_bf16x3 / global_bf16x3 (default off): the stages that decide no index -- the descriptor head at the tap
+    cells, the 1x1 convolutions of layers 15-18 -- on split-bf16 operands (two pieces, three products on the bf16 matrix pipe).
+    north_star's contract: keypoint indices bit-exact, descriptor tensors within a stated tolerance.  Against the ORACLE: counts,
+    keypoints (x, y, response, octave) array_equal; descriptors and global descriptor within the stated tolerance; unit norms.  And the
+    matcher's answers on the produced descriptors agree with its answers on the exact path's descriptors (frames that really match:
+    shifted copies of one scene)."""
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    w, h, nf = cfg
+    B = 6
+    base = synth_image(h, w + 64, 6100, "natural")
+    imgs = np.stack([np.ascontiguousarray(base[:, 8 * f:8 * f + w]) for f in range(B - 1)] + [synth_image(h, w, 6101)])
+    res = {}
+    saved = {o: engine.get_option(o) for o in ("desc_bf16x3", "global_bf16x3")}
+    try:
+        for mode in (0, 1):
+            engine.set_option("desc_bf16x3", mode); engine.set_option("global_bf16x3", mode)
+            x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, 4, max_batch=B)
+            res[mode] = x.extract_batch(imgs)
+            x.close()
+    finally:
+        for o, v in saved.items():
+            engine.set_option(o, v)
+    n0, k0, d0, g0 = res[0]
+    n1, k1, d1, g1 = res[1]
+    assert np.array_equal(n0, n1) and np.array_equal(k0, k1), "the options must not move a keypoint"
+    worst_d = worst_g = 0.0
+    for f in range(B):
+        rn, rk, rd, rg, _ = oracle_model.extract(imgs[f], nf, 0.01, 4, 1.2)
+        assert n1[f] == rn and np.array_equal(k1[f, :rn], rk), f
+        assert np.array_equal(d0[f, :rn], rd) and np.array_equal(g0[f], rg), f         # (options off: the oracle's bits)
+        worst_d = max(worst_d, float(np.abs(d1[f, :rn].astype(np.float64) - rd).max()))
+        worst_g = max(worst_g, float(np.abs(g1[f].astype(np.float64) - rg).max()))
+        assert np.allclose(np.linalg.norm(d1[f, :rn].astype(np.float64), axis=1), 1.0, atol=2e-6)
+        assert abs(np.linalg.norm(g1[f].astype(np.float64)) - 1.0) < 2e-6
+    assert 0 < worst_d <= BF16X3_DESC_TOL, worst_d          # (> 0: the option really took the other pipe)
+    assert 0 < worst_g <= BF16X3_GLOBAL_TOL, worst_g
+    agree = total = matched = 0
+    for f in range(1, B):
+        c0, m0, _ = engine.search_by_bow(d0[f - 1, :n0[f - 1]], d0[f, :n0[f]], 0.6)
+        c1, m1, _ = engine.search_by_bow(d1[f - 1, :n0[f - 1]], d1[f, :n0[f]], 0.6)
+        agree += int(np.sum(m0 == m1)); total += len(m0); matched += int(c0)
+    assert matched > 0.1 * total, "the shifted frames must really match"
+    assert agree >= total - 2, (agree, total)               # (a distance within 1e-5 of TH_LOW or of a runner-up may flip: none observed)
+
+
 def test_monocular_initialisation_extractor_5x_features(engine, oracle_model):
     """Tracking.cc:693 builds the initialisation extractor with 5 * nFeatures on the same models; with the 8-level pyramid
     of the monocular yaml files the small levels run out of candidates before their budget is met."""
