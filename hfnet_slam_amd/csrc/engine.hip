@@ -1936,6 +1936,7 @@ int hfnet_db_create(hfnet_engine* eh, int capacity, int dim, hfnet_db** out) {
     HF_HIP(hipMalloc((void**)&db->d_occ, (size_t)capacity));
     HF_HIP(hipMalloc((void**)&db->d_q, sizeof(float) * dim));
     HF_HIP(hipMalloc((void**)&db->d_norm, sizeof(float) * capacity));
+    HF_HIP(hipMalloc(&db->d_hi, (size_t)2 * capacity * dim));
     HF_HIP(hipMalloc((void**)&db->d_scores, sizeof(float) * capacity));
     HF_HIP(hipMalloc((void**)&db->d_cand_score, sizeof(float) * capacity));
     HF_HIP(hipMalloc((void**)&db->d_cand_slot, sizeof(int32_t) * capacity));
@@ -1959,7 +1960,7 @@ void hfnet_db_destroy(hfnet_db* db) {
     if (!db) return;
     (void)hipSetDevice(db->eng->impl.device);
     for (void* p : {(void*)db->d_db, (void*)db->d_occ, (void*)db->d_q, (void*)db->d_scores, (void*)db->d_cand_score, (void*)db->d_cand_slot,
-                    (void*)db->d_best, (void*)db->d_n, (void*)db->d_best_bits, (void*)db->d_norm})
+                    (void*)db->d_best, (void*)db->d_n, (void*)db->d_best_bits, (void*)db->d_norm, db->d_hi})
         if (p) (void)hipFree(p);
     delete db;
 }
@@ -2054,7 +2055,7 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
     HF_TRY(e.m_key.ensure(sizeof(unsigned int) * Q * parts));
     if (gemm) {
         HF_TRY(e.m_tn.ensure(sizeof(float) * Q)); HF_TRY(e.m_b.ensure(sizeof(float) * db_gemm_scratch_floats(db->capacity, n_queries)));
-        HF_TRY(e.m_f1.ensure(sizeof(float) * Q * parts * 2));
+        HF_TRY(e.m_f1.ensure((size_t)2 * Q * db->dim));             // bf16 copies of the queries
     }
     float* d_q = e.m_a.as<float>(); float* d_scores = e.m_s.as<float>(); float* d_cs = e.m_f0.as<float>();
     int32_t* d_slot = e.m_i0.as<int32_t>(); int* d_n = e.m_cnt.as<int>(); float* d_best = e.m_qn.as<float>();
@@ -2062,13 +2063,12 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
     HF_HIP(hipMemcpyAsync(d_q, queries, sizeof(float) * Q * db->dim, hipMemcpyHostToDevice, e.stream));
     if (gemm) {
         if (db->norm_dirty) {
-            HF_LAUNCH(&e, e.stream, "db_norm", launch_sumsq_rows(db->d_db, db->capacity, db->dim, db->d_norm, e.stream));
+            HF_LAUNCH(&e, e.stream, "db_norm", launch_db_prep_hi(db->d_db, db->capacity, db->dim, db->d_norm, db->d_hi, e.stream));
             db->norm_dirty = false;
         }
-        HF_LAUNCH(&e, e.stream, "db_qnorm", launch_sumsq_rows(d_q, n_queries, db->dim, e.m_tn.as<float>(), e.stream));
-        HF_LAUNCH(&e, e.stream, "db_gemm", launch_db_gemm(d_q, n_queries, e.m_tn.as<float>(), db->d_db, db->d_norm, db->d_occ, db->capacity, db->dim,
-                                                       mode, d_scores, d_bits, e.m_b.as<float>(), e.m_f1.as<float>(), e.m_f1.as<float>() + Q * parts,
-                                                       e.stream));
+        HF_LAUNCH(&e, e.stream, "db_qnorm", launch_db_prep_hi(d_q, n_queries, db->dim, e.m_tn.as<float>(), e.m_f1.p, e.stream));
+        HF_LAUNCH(&e, e.stream, "db_screen", launch_db_screen(d_q, e.m_f1.p, n_queries, e.m_tn.as<float>(), db->d_db, db->d_hi, db->d_norm, db->d_occ, db->capacity,
+                                                         db->dim, d_scores, d_bits, e.m_b.as<float>(), e.stream));
     } else {
         HF_LAUNCH(&e, e.stream, "db_scores_batch", launch_db_scores_batch(d_q, n_queries, db->d_db, db->d_occ, db->capacity, db->dim, d_scores, d_bits, e.stream));
     }

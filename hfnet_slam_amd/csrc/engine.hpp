@@ -347,7 +347,8 @@ struct hfnet_db {
     float* d_db = nullptr;
     unsigned char* d_occ = nullptr;
     float *d_q = nullptr, *d_scores = nullptr, *d_cand_score = nullptr, *d_best = nullptr;
-    float* d_norm = nullptr;       // |d|^2 per slot (tree256 order) for the GEMM form of the scores: refreshed in one launch
+    float* d_norm = nullptr;       // |d|^2 per slot (tree256 order) and
+    void* d_hi = nullptr;          // the bf16 copy of every row, for the screened batched query: both refreshed in one launch
     bool norm_dirty = true;        // by the first batched query after rows were added
     int32_t* d_cand_slot = nullptr;
     int* d_n = nullptr;

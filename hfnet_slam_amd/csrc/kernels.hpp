@@ -197,16 +197,15 @@ hipError_t launch_db_filter(const float* scores, int n, int mode, const unsigned
 // scores[q][slot] for n_queries queries (dim <= 4096): the database is read once per 8 queries
 hipError_t launch_db_scores_batch(const float* q, int n_queries, const float* db, const unsigned char* occupied, int n, int dim,
                                   float* scores, unsigned int* best_partial, hipStream_t s);
-// the same scan on the matrix cores (n_queries >= 8): S = DB * Q^T screens 1 - sqrt(|q|^2 + |d|^2 - 2 S) for every slot, then
-// every slot whose value can decide something (the best score, the candidates of `mode`) is re-scored with launch_db_scores'
-// exact chain: best score, candidate set and candidate scores equal the exact scan's bit for bit; the scores of
-// non-candidates are within 5e-6.  dnorm / qnorm from launch_sumsq_rows; best_partial: [n_queries][db_gemm_partials(n)];
-// scratch: db_gemm_scratch_floats(n, n_queries) floats; umax_a / umax_b: [n_queries][db_gemm_partials(n)] floats each
+// the same scan for many queries (n_queries >= 8), screened on the bf16 matrix pipe: a slot whose crude squared distance (bf16 copies of both
+// vectors, one product) is >= 1 + 9e-3 (|q|^2 + |d|^2) is at distance >= 1 whatever the rounding -- score exactly 0 --, every other occupied
+// slot is scored with launch_db_scores' exact chain: ALL outputs equal the exact scan's bit for bit (kernels_match.hip).
+// norm / hi: |x|^2 in tree256 order and the bf16 copy of every row (launch_db_prep_hi: the database's when rows were added, the queries' per
+// call); best_partial: [n_queries][db_gemm_partials(n)]; scratch: db_gemm_scratch_floats(n, n_queries) floats
 int db_gemm_partials(int n);
 size_t db_gemm_scratch_floats(int n, int n_queries);
-hipError_t launch_sumsq_rows(const float* x, int n_rows, int dim, float* out, hipStream_t s);
-hipError_t launch_db_gemm(const float* q, int n_queries, const float* qnorm, const float* db, const float* dnorm, const unsigned char* occupied,
-                          int n, int dim, int mode, float* scores, unsigned int* best_partial, float* scratch, float* umax_a, float* umax_b,
-                          hipStream_t s);
+hipError_t launch_db_prep_hi(const float* x, int n_rows, int dim, float* norm, void* hi, hipStream_t s);
+hipError_t launch_db_screen(const float* q, const void* qh, int n_queries, const float* qnorm, const float* db, const void* dbh, const float* dnorm,
+                            const unsigned char* occupied, int n, int dim, float* scores, unsigned int* best_partial, float* scratch, hipStream_t s);
 
 }  // namespace hfnet

@@ -1241,84 +1241,103 @@ __global__ __launch_bounds__(256) void k_db_scores_batch(const float* __restrict
     }
 }
 
-// ---- many queries at once on the matrix cores (loop-closure bursts, BASELINE config 5): S = DB * Q^T on
-// v_mfma_f32_32x32x2_f32, then  score = max(0, 1 - sqrt(max(0, |q|^2 + |d|^2 - 2 S)))  -- the same place-recognition
-// score in its inner-product form (KeyFrameDatabase.cc:93 computes the norm of the difference; for the unit-norm NetVLAD
-// descriptors both are 1 - sqrt(2 - 2 q.d)).  Not bit-identical to the scan above (different rounding: stated tolerance in
-// include/hfnet_hip.h), but bit-identical to the oracle's restatement of THIS formula (hfo_db_scores_gemm).
-// A workgroup owns 128 database rows x (NT * 32) queries x one EIGHTH of the descriptor length: the split along k gives
-// 10 000 rows 632 workgroups instead of 79.  Both operands are staged through LDS in 64-float chunks with coalesced
-// 256-byte row segments (a lane of the MFMA can only load its own row: 32 lines of 32 bytes per instruction straight from
-// memory made the address path, not the matrix cores, the limit); a wave multiplies its 32 rows against all query tiles.
-// Summation order: eight partial sums over k ascending inside each eighth, combined as a binary tree in k_db_combine.
+// ---- many queries at once (loop-closure bursts, BASELINE config 5): screen on the bf16 matrix pipe, decide with the exact chain.
+// The place-recognition score is max(0, 1 - ||q - d||) (KeyFrameDatabase.cc:93): EXACTLY 0 for every keyframe at distance >= 1 from
+// the query -- for descriptors of different places, nearly all of them.  So the batched query needs the exact chain of k_db_scores
+// only for the slots that can be closer than 1, and a crude product is enough to find those:
+//   d2~ = |q|^2 + |d|^2 - 2 q~.d~,   q~ = bf16(q), d~ = bf16(d) (round to nearest even: |x~ - x| <= 2^-8 |x|),
+//   |q~.d~ - q.d| <= (2^-7 + 2^-16) sum|q_i d_i| + 4096 * 2^-24 * 1.01 sum|q_i d_i|   (products of bf16 are exact in fp32; the second term
+//                    bounds the fp32 accumulation of <= 4096 of them in ANY order of merely faithful additions, the k split included)
+//                 <= 8.1e-3 |q||d| <= 4.05e-3 (|q|^2 + |d|^2)
+// => a slot with d2~ >= 1 + 9e-3 (|q|^2 + |d|^2) has a true squared distance >= 1 + 9e-4 (|q|^2 + |d|^2): the exact chain (relative error
+//    <= 2e-6) returns a distance >= 1 and the score 0 -- which is what is written for it.  Every other occupied slot is re-scored with the
+//    exact chain.  All outputs of hfnet_db_query_batch are therefore the exact scan's bits: scores of EVERY slot, best, candidates.
+// (Round 2-3's f32 MFMA form -- S on v_mfma_f32_32x32x2_f32, two exact re-scoring passes around the candidate threshold, non-candidates
+//  within 5e-6 -- took 89 us for 64 queries against 10 000 keyframes; it is deleted.)
+// The database keeps a bf16 copy of its rows for this (2 bytes per element, refreshed with the norms: k_db_prep_hi); the kernel below
+// is k_db_gemm's structure at half the bytes and a sixteenth of the matrix time: a workgroup owns 128 database rows x (NT * 32) queries
+// x one EIGHTH of the descriptor length, both operands staged through LDS in chunks of 64 k.
 #define DBG_PARTS 8
+typedef __bf16 dbh_t;
+// |x|^2 (tree256 order, as k_sumsq_rows) and the bf16 copy of n_rows vectors, one wave each
+__global__ __launch_bounds__(256) void k_db_prep_hi(const float* __restrict__ x, int n_rows, int dim, float* __restrict__ norm, dbh_t* __restrict__ hi) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    const float* v = x + (long long)row * dim;
+    dbh_t* h = hi + (long long)row * dim;
+    f32x4 p = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane * 4; k < dim; k += 256) {
+        const f32x4 xv = *(const f32x4*)(v + k);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p[c] = fmaf(xv[c], xv[c], p[c]);
+        bf16x4 hv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) hv[c] = (__bf16)xv[c];
+        *(bf16x4*)(h + k) = hv;
+    }
+    const float ss = tree256_wave4(p);
+    if (lane == 0) norm[row] = ss;
+}
+
 template <int NT>
-__global__ __launch_bounds__(256) void k_db_gemm(const float* __restrict__ q, int n_queries, int q0, const float* __restrict__ db, int n, int dim,
-                                                 float* __restrict__ partial /* [DBG_PARTS][NT*32][n] */) {
-    constexpr int LD = 68, QB = NT * 32;                      // (LDS rows: even k in floats [0, 32), odd k in [32, 64) -- see gemm_abt_tile128)
-    __shared__ __attribute__((aligned(16))) float As[128 * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[QB * LD];
+__global__ __launch_bounds__(256) void k_db_screen(const dbh_t* __restrict__ qh, int n_queries, int q0, const dbh_t* __restrict__ dbh, int n, int dim,
+                                                   float* __restrict__ partial /* [DBG_PARTS][NT*32][n] */) {
+    constexpr int LH = 72, QB = NT * 32;                      // bf16 per LDS row (64 k + 16 bytes: conflict-free 16-byte reads of 16 consecutive rows)
+    __shared__ __attribute__((aligned(16))) dbh_t As[128 * LH];
+    __shared__ __attribute__((aligned(16))) dbh_t Bs[QB * LH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
     const int m0 = blockIdx.x * 128, part = blockIdx.y;
     const int kw = dim / DBG_PARTS, kbase = part * kw;
-    const int lc = tid & 15, arow = (tid >> 4) * 8, brow = (tid >> 4) * (NT * 2);
-    // (the database can exceed 4 GB: the workgroup's first row goes into the scalar base, lane offsets stay 32-bit)
-    const float* dbase = db + (long long)m0 * dim + kbase;
-    const float* qbase = q + (long long)q0 * dim + kbase;
-    unsigned ag[8], bg[NT * 2];
+    // staging: a row's 64-k chunk is 128 bytes = 8 pieces of 16 bytes; thread (row = tid >> 3 (+ 32 j), piece = tid & 7)
+    const int pc = tid & 7, prow = tid >> 3;
+    const dbh_t* dbase = dbh + (long long)m0 * dim + kbase;
+    const dbh_t* qbase = qh + (long long)q0 * dim + kbase;
+    unsigned ag[4], bg[NT];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ag[j] = ((unsigned)min(arow + j, n - 1 - m0) * (unsigned)dim + (unsigned)lc * 4u) * 4u;
+    for (int j = 0; j < 4; ++j) ag[j] = ((unsigned)min(prow + 32 * j, n - 1 - m0) * (unsigned)dim + (unsigned)pc * 8u) * 2u;
 #pragma unroll
-    for (int j = 0; j < NT * 2; ++j) bg[j] = ((unsigned)min(brow + j, n_queries - 1 - q0) * (unsigned)dim + (unsigned)lc * 4u) * 4u;
+    for (int j = 0; j < NT; ++j) bg[j] = ((unsigned)min(prow + 32 * j, n_queries - 1 - q0) * (unsigned)dim + (unsigned)pc * 8u) * 2u;
     f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
-    f32x4 sa[8], sb[NT * 2];
+    f32x4 sa[4], sb[NT];                                      // (16-byte pieces of bf16, moved as f32x4)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sa[j] = *(gvec4_t)(sgpr_base(dbase, 0) + ag[j]);
+    for (int j = 0; j < 4; ++j) sa[j] = *(gvec4_t)(sgpr_base(dbase, 0) + ag[j]);
 #pragma unroll
-    for (int j = 0; j < NT * 2; ++j) sb[j] = *(gvec4_t)(sgpr_base(qbase, 0) + bg[j]);
+    for (int j = 0; j < NT; ++j) sb[j] = *(gvec4_t)(sgpr_base(qbase, 0) + bg[j]);
     for (int k0 = 0; k0 < kw; k0 += 64) {
         __syncthreads();                                     // previous chunk fully consumed
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float* ap = As + (arow + j) * LD + lc * 2;
-            *(float2*)(ap) = float2{sa[j][0], sa[j][2]}; *(float2*)(ap + 32) = float2{sa[j][1], sa[j][3]};
-        }
+        for (int j = 0; j < 4; ++j) *(f32x4*)(As + (prow + 32 * j) * LH + pc * 8) = sa[j];
 #pragma unroll
-        for (int j = 0; j < NT * 2; ++j) {
-            float* bp = Bs + (brow + j) * LD + lc * 2;
-            *(float2*)(bp) = float2{sb[j][0], sb[j][2]}; *(float2*)(bp + 32) = float2{sb[j][1], sb[j][3]};
-        }
+        for (int j = 0; j < NT; ++j) *(f32x4*)(Bs + (prow + 32 * j) * LH + pc * 8) = sb[j];
         __syncthreads();
         {   // (unconditional: see k_tri_gemm_argmax)
-            const unsigned kn = (unsigned)min(k0 + 64, kw - 64) * 4u;
+            const unsigned kn = (unsigned)min(k0 + 64, kw - 64) * 2u;
             const gbase_t pa = sgpr_base(dbase, kn), pb = sgpr_base(qbase, kn);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sa[j] = *(gvec4_t)(pa + fresh(ag[j]));
+            for (int j = 0; j < 4; ++j) sa[j] = *(gvec4_t)(pa + fresh(ag[j]));
 #pragma unroll
-            for (int j = 0; j < NT * 2; ++j) sb[j] = *(gvec4_t)(pb + fresh(bg[j]));
+            for (int j = 0; j < NT; ++j) sb[j] = *(gvec4_t)(pb + fresh(bg[j]));
             __builtin_amdgcn_sched_barrier(0);
         }
-        const float* ap = As + (wave * 32 + r) * LD + half * 32;
-        const float* bp = Bs + r * LD + half * 32;
+        const dbh_t* ap = As + (wave * 32 + r) * LH + half * 8;
+        const dbh_t* bp = Bs + r * LH + half * 8;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const f32x4 av = *(const f32x4*)(ap + 4 * m);
-            f32x4 bv[NT];
+        for (int m = 0; m < 4; ++m) {                         // four steps of 16 k: lane (r, half) holds k = 8 half .. 8 half + 7 of a step
+            const bf16x8 av = *(const bf16x8*)(ap + 16 * m);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = *(const f32x4*)(bp + nt * 32 * LD + 4 * m);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[nt][t], acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
+                const bf16x8 bv = *(const bf16x8*)(bp + nt * 32 * LH + 16 * m);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[nt], 0, 0, 0);
+            }
         }
     }
     // partial sums -> [part][query][row]: through LDS so that a half-wave writes 32 consecutive rows of one query
     __syncthreads();
-    float* tp = As + wave * (32 * 33);                        // wave-private [query column][row], 33 floats apart (one query tile at a time)
+    float* tp = (float*)As + wave * (32 * 33);                // wave-private [query column][row], 33 floats apart (4 x 4224 B <= the 18 KB of As)
     const int i = m0 + wave * 32 + r;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -1331,46 +1350,7 @@ __global__ __launch_bounds__(256) void k_db_gemm(const float* __restrict__ q, in
     }
 }
 
-// partial sums of the eight parts -> u = 1 - sqrt(|q|^2 + |d|^2 - 2 S), NOT yet clamped at 0 (the refinement below selects on
-// it); empty slots: -infinity.  One thread per (query, row), rows along the lanes; per-wave maxima for the refinement.
-__global__ __launch_bounds__(256) void k_db_combine(const float* __restrict__ partial, int qb, int n_queries, int q0, const float* __restrict__ qnorm,
-                                                    const float* __restrict__ dnorm, const unsigned char* __restrict__ occupied, int n,
-                                                    float* __restrict__ scores, float* __restrict__ umax_partial, int n_partials) {
-    const int i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, qi = q0 + c;
-    float u = -INFINITY;
-    if (i < n) {
-        float p[DBG_PARTS];
-#pragma unroll
-        for (int w = 0; w < DBG_PARTS; ++w) p[w] = partial[((long long)w * qb + c) * n + i];
-#pragma unroll
-        for (int m = DBG_PARTS; m > 1; m >>= 1)
-#pragma unroll
-            for (int w = 0; w < m / 2; ++w) p[w] = p[2 * w] + p[2 * w + 1];
-        const float s = p[0];
-        if (occupied[i]) {
-            const float t = qnorm[qi] + dnorm[i];
-            const float d2 = fmaxf(fmaf(-2.0f, s, t), 0.0f);
-            u = 1.0f - sqrtf(d2);
-        }
-        scores[(long long)qi * n + i] = u;
-    }
-    float best = u;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off, 64));
-    if ((threadIdx.x & 63) == 0) umax_partial[(long long)qi * n_partials + blockIdx.x * 4 + (threadIdx.x >> 6)] = best;
-}
-
-// ---- "screen on the matrix cores, decide with the exact arithmetic" (the rule of the matcher's rounding band): the inner-
-// product form above loses digits where it matters most -- near-identical descriptors, i.e. the revisit a loop closure is
-// about (5e-4 for a descriptor scanned against itself) -- so every slot whose value can decide something is re-scored with
-// the exact chain of k_db_scores (||q - d|| in tree256 order):
-//   pass A  the slots within 1e-3 of the largest screened value: the exact BEST score comes out of them (a slot further
-//           below cannot overtake: the screening error is <= 5e-4, include/hfnet_hip.h)
-//   pass B  the slots from 5e-5 below the candidate threshold (0.8 * best, resp. max(0.5, 0.8 * best): distance >= 0.2 there,
-//           screening error <= 5e-6) upwards that pass A has not done: every candidate's score is exact, and so is the
-//           candidate set.
-// What is left approximate are the scores of non-candidates (error <= 5e-6).  Pass B also clamps at 0, writes -1 for empty
-// slots and leaves the per-wave maxima k_db_filter reduces.
+// exact score of one (query, slot): ||q - d|| in tree256 order, the chain of k_db_scores
 __device__ __forceinline__ float db_exact_u(const float* __restrict__ q, const float* __restrict__ d, int dim, int lane) {
     f32x4 p = {0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < dim; k0 += 256) {                    // per (lane, component): one chain, k ascending -- k_db_scores' order
@@ -1381,91 +1361,62 @@ __device__ __forceinline__ float db_exact_u(const float* __restrict__ q, const f
     return 1 - sqrtf(tree256_wave4(p));
 }
 
-template <int PASS>
-__global__ __launch_bounds__(256) void k_db_refine(const float* __restrict__ q, const float* __restrict__ db, int n, int dim, int mode,
-                                                   float* __restrict__ scores, const float* __restrict__ part_in, float* __restrict__ part_out,
-                                                   unsigned int* __restrict__ best_bits, int n_partials) {
-    __shared__ float red[4];
+// partial sums of the eight parts -> d2~; decide; re-score what has to be; scores (clamped at 0, -1 for empty slots) and the per-wave
+// maxima k_db_filter reduces.  One workgroup = 256 slots of one query.
+__global__ __launch_bounds__(256) void k_db_decide(const float* __restrict__ partial, int qb, int q0, const float* __restrict__ q, const float* __restrict__ db,
+                                                   const float* __restrict__ qnorm, const float* __restrict__ dnorm, const unsigned char* __restrict__ occupied,
+                                                   int n, int dim, float* __restrict__ scores, unsigned int* __restrict__ best_bits, int n_partials) {
     __shared__ int list[256];
+    __shared__ float exact[256];
     __shared__ int n_list;
-    const int qi = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float m = -INFINITY;
-    for (int k = tid; k < n_partials; k += 256) m = fmaxf(m, part_in[(long long)qi * n_partials + k]);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if (lane == 0) red[wave] = m;
+    const int c = blockIdx.y, qi = q0 + c, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * 256 + tid;
     if (tid == 0) n_list = 0;
     __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    // pass A: part_in = screened maxima -> lo = max(m, 0) - 1e-3, no upper bound
-    // pass B: part_in = maxima after pass A (the exact best, m) -> threshold T; everything from T - 5e-5 up that lies below
-    //         pass A's bound (= what pass A re-scored: those values are already exact; re-scoring one again is harmless)
-    float lo, hi = INFINITY;
-    if (PASS == 0) {
-        lo = fmaxf(m, 0.0f) - 1e-3f;
-    } else {
-        const float best = fmaxf(m, 0.0f);
-        float thr = best * 0.8f;
-        if (mode == 1) thr = fmaxf(0.5f, thr);
-        lo = thr - 5e-5f;
-        hi = best - 1e-3f + 5e-4f;                              // (pass A covered >= screened best - 1e-3 >= exact best - 1.5e-3; overlap is fine)
-        if (hi < lo) hi = lo;
+    float u = -1.0f;                                           // empty slot
+    int mine = -1;
+    if (i < n && occupied[i]) {
+        float p[DBG_PARTS];
+#pragma unroll
+        for (int w = 0; w < DBG_PARTS; ++w) p[w] = partial[((long long)w * qb + c) * n + i];
+#pragma unroll
+        for (int m = DBG_PARTS; m > 1; m >>= 1)
+#pragma unroll
+            for (int w = 0; w < m / 2; ++w) p[w] = p[2 * w] + p[2 * w + 1];
+        const float t = qnorm[qi] + dnorm[i];
+        const float d2 = fmaf(-2.0f, p[0], t);
+        u = 0.0f;
+        if (!(d2 >= 1.0f + 9e-3f * t)) { mine = atomicAdd(&n_list, 1); list[mine] = i; }      // (NaN -- non-finite descriptors -- goes to the exact chain too)
     }
-    const int i = blockIdx.x * 256 + tid;
-    float u = i < n ? scores[(long long)qi * n + i] : -INFINITY;
-    if (u >= lo && u < hi && u > -INFINITY) { const int k = atomicAdd(&n_list, 1); list[k] = i; }
     __syncthreads();
     const int cnt = n_list;
     for (int k = wave; k < cnt; k += 4) {
-        const int slot = list[k];
-        const float e = db_exact_u(q + (long long)qi * dim, db + (long long)slot * dim, dim, lane);
-        if (lane == 0) scores[(long long)qi * n + slot] = e;
+        const float e = db_exact_u(q + (long long)qi * dim, db + (long long)list[k] * dim, dim, lane);
+        if (lane == 0) exact[k] = e;
     }
     __syncthreads();
-    if (i < n) u = scores[(long long)qi * n + i];
-    if (PASS == 1 && i < n) {
-        u = u == -INFINITY ? -1.0f : fmaxf(u, 0.0f);
-        scores[(long long)qi * n + i] = u;
-    }
-    float best = i < n ? u : -INFINITY;
+    if (mine >= 0) u = fmaxf(exact[mine], 0.0f);
+    if (i < n) scores[(long long)qi * n + i] = u;
+    float best = fmaxf(u, 0.0f);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off, 64));
-    if (lane == 0) {
-        const long long o = (long long)qi * n_partials + blockIdx.x * 4 + wave;
-        if (PASS == 0) part_out[o] = best;
-        else best_bits[o] = __float_as_uint(fmaxf(best, 0.0f));
-    }
+    if (lane == 0) best_bits[(long long)qi * n_partials + blockIdx.x * 4 + wave] = __float_as_uint(best);
 }
 
-// |x|^2 in tree256 order for n_rows vectors (one wave each): query norms per call, database norms when a row is added
-__global__ __launch_bounds__(256) void k_sumsq_rows(const float* __restrict__ x, int n_rows, int dim, float* __restrict__ out) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= n_rows) return;
-    const float* v = x + (long long)row * dim;
-    f32x4 p = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < dim; k += 256) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int i = k + lane * 4 + c;
-            if (i < dim) p[c] = fmaf(v[i], v[i], p[c]);
-        }
-    }
-    const float ss = tree256_wave4(p);
-    if (lane == 0) out[row] = ss;
-}
-
-hipError_t launch_sumsq_rows(const float* x, int n_rows, int dim, float* out, hipStream_t s) {
+hipError_t launch_db_prep_hi(const float* x, int n_rows, int dim, float* norm, void* hi, hipStream_t s) {
     if (n_rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_sumsq_rows, dim3((n_rows + 3) / 4), dim3(256), 0, s, x, n_rows, dim, out);
+    if (dim % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_db_prep_hi, dim3((n_rows + 3) / 4), dim3(256), 0, s, x, n_rows, dim, norm, (dbh_t*)hi);
     return hipGetLastError();
 }
 
 int db_gemm_partials(int n) { return 4 * ((n + 255) / 256); }
 size_t db_gemm_scratch_floats(int n, int n_queries) { return (size_t)DBG_PARTS * (size_t)std::min(128, (n_queries + 31) / 32 * 32) * (size_t)n; }
 
-hipError_t launch_db_gemm(const float* q, int n_queries, const float* qnorm, const float* db, const float* dnorm, const unsigned char* occupied,
-                          int n, int dim, int mode, float* scores, unsigned int* best_partial, float* scratch, float* umax_a, float* umax_b,
-                          hipStream_t s) {
+// scores of n_queries queries against the n slots of the database (see above): q / db: f32 rows, qh / dbh: their bf16 copies, qnorm / dnorm:
+// |.|^2 (launch_db_prep_hi); best_partial: [n_queries][db_gemm_partials(n)]; scratch: db_gemm_scratch_floats(n, n_queries) floats
+hipError_t launch_db_screen(const float* q, const void* qh, int n_queries, const float* qnorm, const float* db, const void* dbh, const float* dnorm,
+                            const unsigned char* occupied, int n, int dim, float* scores, unsigned int* best_partial, float* scratch, hipStream_t s) {
     if (n <= 0 || n_queries <= 0) return hipSuccess;
     if (dim % (DBG_PARTS * 64)) return hipErrorInvalidValue;
     const dim3 grid((n + 127) / 128, DBG_PARTS);
@@ -1473,17 +1424,14 @@ hipError_t launch_db_gemm(const float* q, int n_queries, const float* qnorm, con
     for (int q0 = 0; q0 < n_queries; q0 += 128) {
         const int nt = (std::min(128, n_queries - q0) + 31) / 32, qb = nt * 32, nq = std::min(qb, n_queries - q0);
         switch (nt) {
-            case 1: hipLaunchKernelGGL((k_db_gemm<1>), grid, dim3(256), 0, s, q, n_queries, q0, db, n, dim, scratch); break;
-            case 2: hipLaunchKernelGGL((k_db_gemm<2>), grid, dim3(256), 0, s, q, n_queries, q0, db, n, dim, scratch); break;
-            case 3: hipLaunchKernelGGL((k_db_gemm<3>), grid, dim3(256), 0, s, q, n_queries, q0, db, n, dim, scratch); break;
-            default: hipLaunchKernelGGL((k_db_gemm<4>), grid, dim3(256), 0, s, q, n_queries, q0, db, n, dim, scratch); break;
+            case 1: hipLaunchKernelGGL((k_db_screen<1>), grid, dim3(256), 0, s, (const dbh_t*)qh, n_queries, q0, (const dbh_t*)dbh, n, dim, scratch); break;
+            case 2: hipLaunchKernelGGL((k_db_screen<2>), grid, dim3(256), 0, s, (const dbh_t*)qh, n_queries, q0, (const dbh_t*)dbh, n, dim, scratch); break;
+            case 3: hipLaunchKernelGGL((k_db_screen<3>), grid, dim3(256), 0, s, (const dbh_t*)qh, n_queries, q0, (const dbh_t*)dbh, n, dim, scratch); break;
+            default: hipLaunchKernelGGL((k_db_screen<4>), grid, dim3(256), 0, s, (const dbh_t*)qh, n_queries, q0, (const dbh_t*)dbh, n, dim, scratch); break;
         }
-        hipLaunchKernelGGL(k_db_combine, dim3((n + 255) / 256, nq), dim3(256), 0, s, scratch, qb, n_queries, q0, qnorm, dnorm, occupied, n, scores,
-                           umax_a, parts);
+        hipLaunchKernelGGL(k_db_decide, dim3((n + 255) / 256, nq), dim3(256), 0, s, scratch, qb, q0, q, db, qnorm, dnorm, occupied, n, dim, scores,
+                           best_partial, parts);
     }
-    const dim3 rg((n + 255) / 256, n_queries);
-    hipLaunchKernelGGL((k_db_refine<0>), rg, dim3(256), 0, s, q, db, n, dim, mode, scores, umax_a, umax_b, best_partial, parts);
-    hipLaunchKernelGGL((k_db_refine<1>), rg, dim3(256), 0, s, q, db, n, dim, mode, scores, umax_b, umax_b, best_partial, parts);
     return hipGetLastError();
 }
 

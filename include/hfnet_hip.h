@@ -86,7 +86,7 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *   "two_streams" (3)   0 one stream; 1 fork after layer 7; 2 fork after the detector conv; 3 = 2 + deferred join
  *   "conv_wlds" (1)     3x3 head convolutions: weights staged through LDS once per workgroup (0: every wave reads them)
  *   "graph" (1), "pinned_frames" (4): host-pointer extractor calls
- *   "db_gemm_min_queries" (8): hfnet_db_query_batch switches to the MFMA form of the scores from this many queries on
+ *   "db_gemm_min_queries" (8): hfnet_db_query_batch screens on the bf16 matrix pipe from this many queries on (same bits either way)
  *   "tail_fuse" (4)     calls of up to this many frames run layers 8-18 with the single-frame kernels (depthwise + projection
  *                       in one launch, short-latency MFMA chains); 0: never
  *   "pyramid_fuse" (1)  calls of up to four frames: the pyramid resize chain as one launch
@@ -302,13 +302,13 @@ int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slo
  * entries); best_score: [n_queries] or NULL; scores_all: [n_queries][capacity] or NULL.
  *  - fewer than "db_gemm_min_queries" (8) queries: the exact scan, the database crosses HBM once per 8 queries; per query
  *    EVERY result equals hfnet_db_query's bit for bit (dim <= 4096);
- *  - otherwise (dim % 512 == 0): S = DB * Q^T on the matrix cores (the database crosses HBM once per 128 queries) screens
- *    max(0, 1 - sqrt(max(0, |q|^2 + |d|^2 - 2 S))) for every slot -- the same quantity in its inner-product form, which
- *    loses digits exactly where a loop closure looks (up to 5e-4 for a descriptor scanned against itself) -- and every
- *    slot whose value can decide something is then re-scored with hfnet_db_query's exact chain: the slots within 1e-3
- *    of the largest screened value (-> the exact best score), and the slots from 5e-5 below the candidate threshold
- *    upwards (-> every candidate).  best_score, the candidate set and cand_score equal hfnet_db_query's bit for bit
- *    whatever the burst size; what stays approximate are the entries of scores_all of NON-candidates (|error| <= 5e-6). */
+ *  - otherwise (dim % 512 == 0): the score is EXACTLY 0 for every keyframe at distance >= 1 from the query, so a crude product on
+ *    the bf16 matrix pipe (the database keeps a bf16 copy of its rows, + 2 bytes per element, refreshed with the first batched
+ *    query after an add) only has to find the slots that can be closer: d2~ = |q|^2 + |d|^2 - 2 bf16(q).bf16(d) deviates from the
+ *    true squared distance by at most 8.1e-3 (|q|^2 + |d|^2) (2^-8 per rounded operand + fp32 accumulation in any order), a slot with
+ *    d2~ >= 1 + 9e-3 (|q|^2 + |d|^2) is written as 0, every other occupied slot is scored with hfnet_db_query's exact chain.
+ *    EVERY result -- scores_all of every slot, best_score, the candidate set, cand_score -- equals hfnet_db_query's bit for bit,
+ *    whatever the burst size.  Cost: one pass over the bf16 copy per 128 queries + 16 KB per (query, keyframe closer than ~1.01). */
 int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int mode, int32_t* cand_slot,
                          float* cand_score, int32_t* n_cand, float* best_score, float* scores_all);
 

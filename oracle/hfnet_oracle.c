@@ -925,34 +925,6 @@ void hfo_db_scores(const float* query, const float* db, int n, int dim, float* s
     }
 }
 
-/* The same scores in their inner-product form, in the summation order of the MFMA kernel (k_db_gemm):
- *   S = sum_k q[k] d[k]: the descriptor is cut in eight parts, inside a part the fma chain runs over k ascending from 0,
- *   the parts are added as a binary tree ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7));
- *   score = max(0, 1 - sqrt(max(0, fma(-2, S, |q|^2 + |d|^2)))), the squared norms in tree256 order.
- * Equals hfo_db_scores up to rounding (tests state the tolerance); dim % 512 == 0. */
-void hfo_db_scores_gemm(const float* queries, int nq, const float* db, int n, int dim, float* scores) {
-    const int kw = dim / 8;
-#pragma omp parallel for schedule(static)
-    for (int i = 0; i < n; ++i) {
-        const float* d = db + (size_t)i * dim;
-        const float dn = hfo_sumsq_tree256(d, dim);
-        for (int qi = 0; qi < nq; ++qi) {
-            const float* q = queries + (size_t)qi * dim;
-            float p[8];
-            for (int w = 0; w < 8; ++w) {
-                float acc = 0.0f;
-                for (int k = w * kw; k < (w + 1) * kw; ++k) acc = fmaf(d[k], q[k], acc);
-                p[w] = acc;
-            }
-            const float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-            const float t = hfo_sumsq_tree256(q, dim) + dn;
-            const float d2 = fmaxf(fmaf(-2.0f, s, t), 0.0f);
-            const float sc = 1.0f - sqrtf(d2);
-            scores[(size_t)qi * n + i] = sc > 0.f ? sc : 0.f;
-        }
-    }
-}
-
 /* KeyFrameDatabase.cc:94-104 (mode 0) / 188-197 (mode 1) */
 int hfo_db_candidates(const float* scores, int n, int mode, int32_t* idx, float* best_out) {
     float best = 0;

@@ -135,8 +135,6 @@ void hfo_distinctive_descriptors(const float* desc, const int32_t* set_offsets, 
 
 /* --- place recognition (KeyFrameDatabase.cc:86-104,178-197) --- */
 void hfo_db_scores(const float* query, const float* db, int n, int dim, float* scores);
-/* the inner-product form of the same scores in the summation order of the MFMA kernel; scores: [nq][n] */
-void hfo_db_scores_gemm(const float* queries, int nq, const float* db, int n, int dim, float* scores);
 /* mode 0: DetectNBestCandidates filter (> 0.8 best); mode 1: relocalisation (> max(0.5, 0.8 best)) */
 int hfo_db_candidates(const float* scores, int n, int mode, int32_t* idx, float* best);
 

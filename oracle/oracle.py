@@ -302,14 +302,6 @@ def db_scores(query: np.ndarray, db: np.ndarray) -> np.ndarray:
     return s
 
 
-def db_scores_gemm(queries: np.ndarray, db: np.ndarray) -> np.ndarray:
-    """scores [Q, n] in the inner-product form / summation order of the MFMA kernel (hfo_db_scores_gemm)"""
-    q = np.ascontiguousarray(queries, np.float32); d = np.ascontiguousarray(db, np.float32)
-    s = np.empty((q.shape[0], d.shape[0]), np.float32)
-    lib().hfo_db_scores_gemm(_p(q), q.shape[0], _p(d), d.shape[0], d.shape[1], _p(s))
-    return s
-
-
 def db_candidates(scores: np.ndarray, mode: int = 0):
     s = np.ascontiguousarray(scores, np.float32)
     idx = np.empty((max(len(s), 1),), np.int32)

@@ -272,41 +272,46 @@ def test_loop_closure_stress_10k_database(engine):
         ref = O.db_scores(qs[5], rows)
         ref[17] = -1.0
         assert np.array_equal(scores[5], ref)
-    # (b) the default for >= 8 queries: S = DB * Q^T on the matrix cores screens every slot, the slots that can decide
-    #     something are re-scored with the exact chain.  Contract: best score, candidate set and candidate scores equal the
-    #     exact scan's (== the oracle's) bit for bit; every other slot is within 5e-6 of it (and -1 for the erased slot).
+    # (b) the default for >= 8 queries: a crude product on the bf16 matrix pipe screens every slot (one bf16 piece per operand, rigorous
+    #     band: a slot it rules out is at distance >= 1, score exactly 0), every other occupied slot is scored with the exact chain.
+    #     Contract: EVERY output equals the exact scan's (== the oracle's) bit for bit -- the scores of all slots (-1 for the erased one),
+    #     best, candidate set, candidate scores.
     engine.set_option("db_gemm_min_queries", 8)
     exact_all = np.stack([O.db_scores(qs[i], rows) for i in range(67)])
     exact_all[:, 17] = -1.0
     for mode in (0, 1):
         cands, best, scores = db.query_batch(qs, mode, want_scores=True)
+        assert np.array_equal(scores, exact_all)
         for i in range(67):
             eidx, ebest = O.db_candidates(exact_all[i], mode)
             assert best[i] == ebest, (i, best[i], ebest)
             assert np.array_equal(cands[i][0], eidx) and np.array_equal(cands[i][1], exact_all[i][eidx])
-            assert np.array_equal(scores[i][eidx], exact_all[i][eidx])
-        assert scores[:, 17].tolist() == [-1.0] * 67
-        assert np.max(np.abs(scores.astype(np.float64) - exact_all)) <= 5e-6
-    # the revisit case the inner-product form is worst at: queries that ARE database rows (distance 0, screening error up to
-    # 5e-4), near-duplicates a few ulp apart, and rows planted right at the 0.8 * best candidate threshold
+    # the revisit case (queries that ARE database rows, near-duplicates a few ulp apart), rows planted right at the 0.8 * best candidate
+    # threshold, rows planted around distance 1 -- where the screen decides between "exactly 0" and the exact chain: 0.99 .. 1.02, the
+    # band ends at 1.009 for unit vectors --, scaled (non-unit) rows, and a row of zeros
     rows2 = rows[:2048].copy()
     rows2[100] = rows2[7]; rows2[101] = np.nextafter(rows2[7], np.float32(1)); rows2[102] = rows2[7] * np.float32(1.0 + 2e-7)
     base = rows2[300]
-    for k, eps in enumerate((0.1995, 0.19999, 0.2, 0.20001, 0.2005)):          # distance ~eps from row 300: score ~ 1 - eps
+    plant = [(400 + k, eps) for k, eps in enumerate((0.1995, 0.19999, 0.2, 0.20001, 0.2005))]          # distance ~eps from row 300: score ~ 1 - eps
+    plant += [(420 + k, eps) for k, eps in enumerate((0.99, 0.999, 0.9999, 1.0, 1.0001, 1.001, 1.005, 1.0085, 1.0095, 1.02))]
+    for slot, eps in plant:
         v = rng.standard_normal(dim).astype(np.float32); v -= v.dot(base) * base; v /= np.linalg.norm(v)
-        rows2[400 + k] = (base * np.float32(np.sqrt(1 - eps * eps)) + v * np.float32(eps)).astype(np.float32)
+        c = 1.0 - eps * eps / 2.0                                                       # unit vector at distance eps: cos = 1 - eps^2 / 2
+        rows2[slot] = (base * np.float32(c) + v * np.float32(np.sqrt(max(1 - c * c, 0.0)))).astype(np.float32)
+    rows2[500] = rows2[300] * np.float32(1.7); rows2[501] = rows2[300] * np.float32(0.45); rows2[502] = 0.0
     db2 = capi.Database(engine, 2048, dim)
     for i in range(2048):
         db2.add(i, rows2[i])
-    qs2 = np.stack([rows2[7], rows2[300], rows2[101], rows2[1500]] + [rows2[i] for i in range(600, 612)]).astype(np.float32)
+    qs2 = np.stack([rows2[7], rows2[300], rows2[101], rows2[1500], rows2[300] * np.float32(1.3), rows2[502]] + [rows2[i] for i in range(600, 610)]).astype(np.float32)
     ex2 = np.stack([O.db_scores(q, rows2) for q in qs2])
     for mode in (0, 1):
         cands, best, scores = db2.query_batch(qs2, mode, want_scores=True)
+        assert np.array_equal(scores, ex2), np.argwhere(scores != ex2)[:8]
         for i in range(len(qs2)):
             eidx, ebest = O.db_candidates(ex2[i], mode)
-            assert best[i] == ebest == np.float32(1.0), (i, best[i], ebest)
+            assert best[i] == ebest, (i, best[i], ebest)
             assert np.array_equal(cands[i][0], eidx) and np.array_equal(cands[i][1], ex2[i][eidx]), (mode, i)
         assert set(cands[0][0].tolist()) >= {7, 100, 101, 102} and 300 in cands[1][0].tolist()
-        assert np.max(np.abs(scores.astype(np.float64) - ex2)) <= 5e-6
+    assert 0 < ex2[1][421] < 2e-3 and ex2[1][425] == 0.0                               # (the plants straddle distance 1)
     db2.close()
     db.close()

@@ -196,26 +196,6 @@ def test_db_scores_and_filters():
     assert list(O.db_candidates(low, 0)[0]) == [0, 1] and list(O.db_candidates(low, 1)[0]) == []   # reloc needs > 0.5
 
 
-def test_db_scores_gemm_form_agrees_with_the_scan():
-    """the inner-product form of the place-recognition score (what the MFMA kernel computes for >= 8 queries) against the
-    difference form of KeyFrameDatabase.cc:93 -- within 1e-6 / max(||q - d||, 2e-3), near duplicates included"""
-    rng = np.random.default_rng(21)
-    db = _unit(rng, 400, 4096)
-    qs = []
-    for i, sig in enumerate((0.0, 1e-4, 1e-3, 0.003, 0.01, 0.05)):
-        q = db[10 * i] + sig * rng.standard_normal(4096).astype(np.float32)
-        qs.append(q / np.linalg.norm(q))
-    qs = np.asarray(qs, np.float32)
-    g = O.db_scores_gemm(qs, db)
-    for i in range(len(qs)):
-        e = O.db_scores(qs[i], db)
-        exact = np.maximum(0, 1 - np.linalg.norm(db.astype(np.float64) - qs[i].astype(np.float64), axis=1))
-        dist = np.maximum(1.0 - exact, 2e-3)
-        assert np.all(np.abs(g[i] - exact) <= 1e-6 / dist), (i, np.max(np.abs(g[i] - exact) * dist))
-        assert np.all(np.abs(e - exact) <= 2e-6)
-        assert g[i].argmax() == 10 * i or g[i].max() == 0.0      # (sigma 0.05: every distance is >= 1, every score 0)
-
-
 def test_expf_and_tree_reduction():
     xs = np.linspace(-30, 0, 301).astype(np.float32)
     got = np.array([O.expf(float(x)) for x in xs], np.float64)
