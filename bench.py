@@ -544,8 +544,8 @@ def config_host_io(capi, eng, chunk, chunks_per_call=16, reps=3):
         def match_call(i):
             base = (i & 1) * n
             pr = [((base + f - 1) % (2 * n), base + f) for f in range(0 if i else 1, n)]
-            for p0 in range(0, len(pr), chunk):
-                store.search_by_bow(pr[p0:p0 + chunk], TH_LOW)
+            for p0 in range(0, len(pr), 4 * chunk):              # (512 pairs per call: a call's uploads, downloads and host synchronisation amortise)
+                store.search_by_bow(pr[p0:p0 + 4 * chunk], TH_LOW)
             done.append(i)
 
         worker = None
