@@ -12,11 +12,11 @@ LAUNCHES = {
     "conv3x3_det": ("void hfnet::k_conv3x3_wlds<4, false", 0),
     "conv3x3_desc_taps": ("void hfnet::k_conv3x3_wlds<4, true", 0),
     "stem_block_L02": ("void hfnet::k_stem_block2<24, 16>", 0),
-    "block_L03": ("void hfnet::k_block_fused4<2, 1, 2, false", 0),
+    "block_L03": ("void hfnet::k_block_fused8<2, 1, 2, false", 0),
     "block_L04": ("void hfnet::k_block_fused4<1, 1, 3, true", 0),
-    "block_L05": ("void hfnet::k_block_fused4<2, 1, 3, false", 0),
+    "block_L05": ("void hfnet::k_block_fused8<2, 1, 3, false", 0),
     "block_L06": ("void hfnet::k_block_fused6<6, 3, false", 0),
-    "block_L07": ("void hfnet::k_block_fused6<12, 6, false", 0),
+    "block_L07": ("void hfnet::k_block_fused8<1, 3, 6, false", 0),
     "block_L08": ("void hfnet::k_block_fused2<2, 2, 12, true, 8>", 0),
     "pointwise_desc_taps": ("void hfnet::k_pointwise_wlds<4>", 0),
     "det_tail": ("hfnet::k_det_tail", 0),
@@ -29,7 +29,7 @@ LAUNCHES = {
     "sample": ("hfnet::k_sample", 0),
     "pyramid_resize": ("hfnet::k_resize_u8", 0),
     "depthwise_L16": ("void hfnet::k_depthwise<1, 5>", 0),
-    "vlad_aggregate": ("hfnet::k_vlad_aggregate", 0),
+    "vlad_aggregate": ("void hfnet::k_vlad_aggregate<16>", 0),
     "match_gemm": ("hfnet::k_bow_gemm_cand", 0),
     "match_candidates": ("hfnet::k_bow_candidates", 0),
 }
