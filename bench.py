@@ -698,7 +698,7 @@ def windowed_inputs():
 
 
 def config_windowed_candidates(capi, eng, reps=30):
-    """SURVEY.md 8f rank 4, the question DESIGN.md section 7 answers with this number: is the candidate loop of the windowed
+    """SURVEY.md 8f rank 4, the question NOTEBOOK.md 4.3 answers with this number: is the candidate loop of the windowed
     matchers worth a device call?  hfnet_match_candidates through the host-pointer entry point (queries, train descriptors and
     the ragged candidate lists go up, five result arrays come down); the CPU side of the comparison -- the oracle's restatement
     of the reference loop on 8 host threads, same inputs -- is cpu_baseline.variants.windowed_candidates_8_threads_us."""

@@ -421,7 +421,7 @@ static hipError_t launch_block_fused2_t(const FusedArgs& a, const Geom& g, hipSt
 //                    execute in order: all reads are issued before the first write)
 //   project  (MFMA)  A fragments from D, accumulate into the tile's 32 x (NTO*32) accumulators (k order = expansion channel
 //                    order: the oracle's chain)
-// f32 MFMA and VALU instructions share one issue port per SIMD, so what counts is that the port never
+// f32 MFMA and VALU instructions share one issue port per SIMD (NOTEBOOK.md 4.1), so what counts is that the port never
 // idles: v2 synchronises its four waves twice per chunk and its phases are too short to hide their start-up latencies
 // (measured: stage times add up exactly, expansion at 42 % of its MFMA rate).  Here nothing couples the 2-4 waves of a
 // SIMD, so one wave's LDS round trips, weight fetches and VALU stretches are covered by the others' MFMA chains.  Price:
