@@ -28,7 +28,7 @@ def run(budget_s: float, seed: int, big_share: float = 0.02):
 
     while time.time() < t_end:
         eng = capi.Engine(wpath, 0)
-        opts = {"fuse_blocks": int(rng.integers(0, 2)), "fused_variant": int(rng.choice([2, 4])), "fuse_stem": int(rng.integers(0, 2)),
+        opts = {"fuse_blocks": int(rng.integers(0, 2)), "fused_variant": int(rng.choice([2, 4, 6, 8])), "fuse_min_wgs": int(rng.choice([0, 256])), "fuse_stem": int(rng.integers(0, 2)),
                 "dense_desc": int(rng.integers(0, 2)), "two_streams": int(rng.integers(0, 4)), "conv_wlds": int(rng.integers(0, 2)),
                 "match_screen_bf16": int(rng.integers(0, 2)), "tri_screen_bf16": int(rng.integers(0, 2))}
         if rng.random() < 0.5:
