@@ -62,7 +62,7 @@ def layer_work(batch: int, width: int = W_IMG, height: int = H_IMG, n_feat: int 
         f, b, x = work.get(name, (0.0, 0.0, 0.0))
         work[name] = (f + flop, b + byts, x + (flop if executed is None else executed))
 
-    V4_SHAPES = {(1, 3, 1), (1, 3, 2), (1, 6, 2), (1, 6, 3), (1, 9, 3), (2, 2, 1), (2, 3, 1)}   # (stride, cin / 8, cout tiles): kernels_block.hip
+    V4_SHAPES = {(1, 3, 1), (1, 3, 2), (1, 6, 2), (1, 6, 3), (1, 9, 3), (2, 2, 1), (2, 3, 1), (2, 12, 2)}   # (stride, cin / 8, cout tiles): kernels_block.hip
     V6_SHAPES = {(1, 6, 3), (1, 12, 3), (1, 12, 5), (1, 18, 5)}                                  # (stride, cin / 4, 16-column tiles): k_block_fused6
     # (k_block_fused8 -- layers 3, 5, 7: the expanded tensor in registers -- issues k_block_fused4's MFMAs: same tiles, same M tiles)
 

@@ -784,9 +784,9 @@ template <int STRIDE> struct F8Geo {
     static constexpr int MT = STRIDE == 2 ? 5 : 2;                 // halo M tiles (accumulator slots per lane half = 16 MT)
     static constexpr int CEP = 36;
 };
-// (Layer 8 -- 96 input channels, 240 registers of A fragments -- was tried in this form with the A pieces re-read from L1 / L2 per
-// chunk through a ring of three k-steps: 254 registers, two waves per SIMD, bit-identical, 1389 us per 128 frames against the
-// barrier kernel's 1270: every wave then pulls 60 KB of A per chunk for its own 4 x 8 tile, ~37 B/clk per CU from L2.  Not kept.)
+// Layer 8 (96 input channels: 240 registers of A fragments) runs at ONE wave per SIMD (OCC = 1) with everything resident: 1064 us per
+// 128 frames against the barrier kernel's 1273.  (With the A pieces re-read from L1 / L2 per chunk through a ring of three k-steps it
+// fitted two waves per SIMD and took 1389 us: every wave then pulls 60 KB of A per chunk, ~37 B/clk per CU from L2.  Not kept.)
 template <int STRIDE, int NTO, int KQT, bool RES, int OCC>
 __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
     using G = F8Geo<STRIDE>;
@@ -872,10 +872,13 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
         const int cn = min(chunk + 1, n_chunks - 1);
         const float enext = *(gf32_t)(sgpr_base(a.ex_bias, (unsigned)cn * 128u) + fresh(r4_));
         const unsigned dch4 = (unsigned)min(r, a.cexp - 1 - ch0) * 4u;      // (channels past cexp: clamped, never consumed)
-        float dwt[9];
+        float dwt[9], dwb;
+        auto load_dw = [&]() {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) dwt[t] = *(gf32_t)(sgpr_base(a.Wdw, (unsigned)(t * a.cexp + ch0) * 4u) + dch4);
-        const float dwb = *(gf32_t)(sgpr_base(a.dw_bias, (unsigned)ch0 * 4u) + dch4);
+            for (int t = 0; t < 9; ++t) dwt[t] = *(gf32_t)(sgpr_base(a.Wdw, (unsigned)(t * a.cexp + ch0) * 4u) + fresh(dch4));
+            dwb = *(gf32_t)(sgpr_base(a.dw_bias, (unsigned)ch0 * 4u) + fresh(dch4));
+        };
+        if constexpr (OCC > 1) load_dw();                          // (one wave per SIMD: requested behind the expansion, where its registers are free)
         // ---- expansion: MT independent chains, k outer, weights through the ring
         f32x16 acc[MT];
         {
@@ -910,6 +913,7 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if constexpr (OCC == 1) load_dw();
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -930,15 +934,20 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
                 E0[hy] = swp(a0, a4, 0);                           // local column 0: (own column 0, half 0's column 4)
             }
         }
-        // this chunk's projection weights: requested here, into registers the expansion has released
-        f32x4 pfrag[4][NTO];
-        {
+        // this chunk's projection weights: requested here, into registers the expansion has released (PJIT -- one wave per SIMD, every
+        // register counts: a k-group at a time, one group ahead of its MFMAs)
+        constexpr bool PJIT = OCC == 1;
+        f32x4 pfrag[PJIT ? 2 : 4][NTO];
+        auto load_p = [&](int kq, int slot) {
             const unsigned l16 = fresh(lane16_);
 #pragma unroll
-            for (int kq = 0; kq < 4; ++kq)
+            for (int nt = 0; nt < NTO; ++nt)
+                pfrag[slot][nt] = *(gvec4_t)(sgpr_base(a.Wpr, (unsigned)((chunk * 4 + min(kq, kqc - 1)) * a.pr_nt_total + nt) * 1024u) + l16);
+        };
+        if constexpr (PJIT) load_p(0, 0);
+        else {
 #pragma unroll
-                for (int nt = 0; nt < NTO; ++nt)
-                    pfrag[kq][nt] = *(gvec4_t)(sgpr_base(a.Wpr, (unsigned)((chunk * 4 + min(kq, kqc - 1)) * a.pr_nt_total + nt) * 1024u) + l16);
+            for (int kq = 0; kq < 4; ++kq) load_p(kq, kq);
         }
         // ---- depthwise: channel r, output columns 4 half .. 4 half + 3 of all four rows, taps in (ky, kx) order
 #pragma unroll
@@ -963,11 +972,12 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) {
             if (kq < kqc) {
+                if constexpr (PJIT) { if (kq + 1 < 4) load_p(kq + 1, (kq + 1) & 1); }
                 const f32x4 av = *(const f32x4*)(ET + r * CEP + kq * 8 + half * 4);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], pfrag[kq][nt][t], pacc[nt], 0, 0, 0);
+                    for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], pfrag[PJIT ? (kq & 1) : kq][nt][t], pacc[nt], 0, 0, 0);
             }
         }
         asm volatile("" ::: "memory");
@@ -1666,6 +1676,10 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
     }
     // v8 (stride 2, expansion kept in registers): what a launch of k_block_fused4's size runs for the stride-2 blocks (per 128
     // frames, v4 -> v8: layer 3 1803 -> 1599 us, layer 5 954 -> 833); variant 8: at any launch size (tests)
+    // layer 8 (96 -> 576 -> 48, stride 2) as a v8 tile at ONE wave per SIMD: the 240 registers of A fragments stay resident in the 512-entry
+    // file (the input crosses L2 once instead of once per chunk), five independent expansion chains keep the matrix pipe busy by
+    // themselves: 1273 -> 1064 us per 128 frames against the barrier kernel
+    if (st == 2 && kq == 12 && nto == 2 && (variant == 8 || (variant == 4 && !small_launch))) return launch_block_fused8_t<2, 2, 12, 1>(a, g, s);
     if (kind == FUSED_V4 && st == 2 && nto == 1 && (variant == 8 || (variant == 4 && !small_launch))) {
         if (kq == 2) return launch_block_fused8_t<2, 1, 2, 2>(a, g, s);
         if (kq == 3) return launch_block_fused8_t<2, 1, 3, 2>(a, g, s);

@@ -17,7 +17,7 @@ LAUNCHES = {
     "block_L05": ("void hfnet::k_block_fused8<2, 1, 3, false", 0),
     "block_L06": ("void hfnet::k_block_fused6<6, 3, false", 0),
     "block_L07": ("void hfnet::k_block_fused8<1, 3, 6, false", 0),
-    "block_L08": ("void hfnet::k_block_fused2<2, 2, 12, true, 8>", 0),
+    "block_L08": ("void hfnet::k_block_fused8<2, 2, 12, false, 1>", 0),
     "pointwise_desc_taps": ("void hfnet::k_pointwise_wlds<4>", 0),
     "det_tail": ("hfnet::k_det_tail", 0),
     "fc": ("void hfnet::k_fc_mfma<16>", 0),
