@@ -1664,6 +1664,8 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
     // per 128 frames; everywhere else it is 1-7 % slower than v4 / v6: the lanes' exchange is vector work on a saturated port)
     // (measured per 128 frames, v4 or v6 -> v8: layer 4 1710 -> 1732 us, layer 6 567 -> 602, layer 9 163 -> 165, layer 12 183 -> 188, layer 13
     // 325 -> 347: those instantiations are not kept)
+    // (one wave per SIMD for the other v8 shapes, per 128 frames: layer 3 1565 -> 2333 us, layer 5 834 -> 1077, layer 7 1798 -> 1831 -- a lone wave
+    //  needs long MFMA chains per chunk (layer 8: 272, layer 7: 96, layer 3: 56 next to ~290 vector instructions) to keep its SIMD busy)
     if (kind == FUSED_V4 && st == 1 && kq == 6 && nto == 3 && (variant == 8 || (variant == 4 && !small_launch))) return launch_block_fused8_t<1, 3, 6, 2>(a, g, s);
     if (kind == FUSED_V4 && st == 1 && a.Wex16 && a.Wpr16 && (variant == 6 || variant == 7 || (variant == 4 && !small_launch))) {
         const int kt = b.cin / 4, n16 = a.pr_n16;
