@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libhfnet_hip.so")
-SOURCES = ["weights.cpp", "kernels_conv.hip", "kernels_block.hip", "kernels_detect.hip", "kernels_global.hip", "kernels_match.hip", "kernels_tail.hip", "engine.hip"]
+SOURCES = ["weights.cpp", "kernels_conv.hip", "kernels_block.hip", "kernels_detect.hip", "kernels_global.hip", "kernels_match.hip", "kernels_tail.hip", "engine.hip", "api_extract.hip", "api_match.hip", "api_db.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", "engine.hpp", "device_util.hpp", os.path.join("..", "..", "include", "hfnet_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
          "-Wno-unused-result", "-x", "hip"]

@@ -1,0 +1,180 @@
+// api_db.hip -- C ABI: the global-descriptor store and scans of KeyFrameDatabase (src/KeyFrameDatabase.cc:36-104, 178-197).
+#include "engine.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+using namespace hfnet;
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------- KeyFrameDatabase
+int hfnet_db_create(hfnet_engine* eh, int capacity, int dim, hfnet_db** out) {
+    API_GUARD(out, "out");
+    *out = nullptr;
+    API_GUARD(eh, "engine");
+    if (capacity < 1 || dim < 256 || dim % 256) { set_error("db: capacity >= 1 and dim a multiple of 256 required"); return HFNET_ERR_INVALID_ARG; }
+    HF_HIP(hipSetDevice(eh->impl.device));
+    std::unique_ptr<hfnet_db> db(new hfnet_db());
+    db->eng = eh; db->capacity = capacity; db->dim = dim;
+    HF_HIP(hipMalloc((void**)&db->d_db, sizeof(float) * (size_t)capacity * dim));
+    HF_HIP(hipMalloc((void**)&db->d_occ, (size_t)capacity));
+    HF_HIP(hipMalloc((void**)&db->d_q, sizeof(float) * dim));
+    HF_HIP(hipMalloc((void**)&db->d_norm, sizeof(float) * capacity));
+    HF_HIP(hipMalloc(&db->d_hi, (size_t)2 * capacity * dim));
+    HF_HIP(hipMalloc((void**)&db->d_scores, sizeof(float) * capacity));
+    HF_HIP(hipMalloc((void**)&db->d_cand_score, sizeof(float) * capacity));
+    HF_HIP(hipMalloc((void**)&db->d_cand_slot, sizeof(int32_t) * capacity));
+    HF_HIP(hipMalloc((void**)&db->d_best, sizeof(float)));
+    HF_HIP(hipMalloc((void**)&db->d_n, sizeof(int)));
+    HF_HIP(hipMalloc((void**)&db->d_best_bits, sizeof(unsigned int) * 4 * (size_t)db_scan_workgroups(capacity)));   // per-wave partial maxima
+    {
+        // on the stream the adds and scans use: it is non-blocking, i.e. NOT ordered with the null stream, and a hipMemset there
+        // is not host-synchronous -- it could land after the first hfnet_db_add had set its occupancy byte
+        Engine& e = eh->impl;
+        std::lock_guard<std::mutex> lk(e.mu);
+        HF_HIP(hipMemsetAsync(db->d_occ, 0, (size_t)capacity, e.stream));
+        HF_HIP(hipMemsetAsync(db->d_norm, 0, sizeof(float) * capacity, e.stream));
+        HF_HIP(hipStreamSynchronize(e.stream));
+    }
+    *out = db.release();
+    return HFNET_OK;
+}
+
+void hfnet_db_destroy(hfnet_db* db) {
+    if (!db) return;
+    (void)hipSetDevice(db->eng->impl.device);
+    for (void* p : {(void*)db->d_db, (void*)db->d_occ, (void*)db->d_q, (void*)db->d_scores, (void*)db->d_cand_score, (void*)db->d_cand_slot,
+                    (void*)db->d_best, (void*)db->d_n, (void*)db->d_best_bits, (void*)db->d_norm, db->d_hi})
+        if (p) (void)hipFree(p);
+    delete db;
+}
+
+int hfnet_db_add(hfnet_db* db, int slot, const float* descriptor) {
+    API_GUARD(db, "db"); API_GUARD(descriptor, "descriptor");
+    if (slot < 0 || slot >= db->capacity) { set_error("db: slot %d outside [0, %d)", slot, db->capacity); return HFNET_ERR_CAPACITY; }
+    std::lock_guard<std::mutex> lk(db->mu);
+    Engine& e = db->eng->impl;
+    std::lock_guard<std::mutex> lk2(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    // on the stream the scans run on (created non-blocking: the null stream would not order with it)
+    HF_HIP(hipMemcpyAsync(db->d_db + (size_t)slot * db->dim, descriptor, sizeof(float) * db->dim, hipMemcpyHostToDevice, e.stream));
+    HF_HIP(hipMemsetAsync(db->d_occ + slot, 1, 1, e.stream));
+    db->norm_dirty = true;
+    HF_HIP(hipStreamSynchronize(e.stream));                          // the host buffer may go away
+    return HFNET_OK;
+}
+
+int hfnet_db_erase(hfnet_db* db, int slot) {
+    API_GUARD(db, "db");
+    if (slot < 0 || slot >= db->capacity) { set_error("db: slot %d outside [0, %d)", slot, db->capacity); return HFNET_ERR_CAPACITY; }
+    std::lock_guard<std::mutex> lk(db->mu);
+    Engine& e = db->eng->impl;
+    std::lock_guard<std::mutex> lk2(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    HF_HIP(hipMemsetAsync(db->d_occ + slot, 0, 1, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));
+    return HFNET_OK;
+}
+
+int hfnet_db_clear(hfnet_db* db) {
+    API_GUARD(db, "db");
+    std::lock_guard<std::mutex> lk(db->mu);
+    Engine& e = db->eng->impl;
+    std::lock_guard<std::mutex> lk2(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    HF_HIP(hipMemsetAsync(db->d_occ, 0, (size_t)db->capacity, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));
+    return HFNET_OK;
+}
+
+int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slot, float* cand_score, int* n_cand, float* best_score,
+                   float* scores_all) {
+    API_GUARD(db, "db"); API_GUARD(query, "query"); API_GUARD(cand_slot, "cand_slot"); API_GUARD(cand_score, "cand_score"); API_GUARD(n_cand, "n_cand");
+    if (mode != 0 && mode != 1) { set_error("db: mode must be 0 or 1"); return HFNET_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> lk(db->mu);   // KeyFrameDatabase.cc:82 holds mMutex over the scan
+    Engine& e = db->eng->impl;
+    std::lock_guard<std::mutex> lk2(e.mu);
+    HF_HIP(hipSetDevice(e.device));
+    HF_HIP(hipMemcpyAsync(db->d_q, query, sizeof(float) * db->dim, hipMemcpyHostToDevice, e.stream));
+    HF_LAUNCH(&e, e.stream, "db_scores", launch_db_scores(db->d_q, db->d_db, db->d_occ, db->capacity, db->dim, db->d_scores, db->d_best_bits, e.stream));
+    HF_LAUNCH(&e, e.stream, "db_filter", launch_db_filter(db->d_scores, db->capacity, mode, db->d_best_bits, 4 * db_scan_workgroups(db->capacity), db->d_cand_slot, db->d_cand_score, db->d_n, db->d_best, 1, e.stream));
+    int n = 0;
+    float best = 0.f;
+    HF_HIP(hipMemcpyAsync(&n, db->d_n, sizeof(int), hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipMemcpyAsync(&best, db->d_best, sizeof(float), hipMemcpyDeviceToHost, e.stream));
+    if (scores_all) HF_HIP(hipMemcpyAsync(scores_all, db->d_scores, sizeof(float) * db->capacity, hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));
+    if (n > 0) {
+        HF_HIP(hipMemcpyAsync(cand_slot, db->d_cand_slot, sizeof(int32_t) * n, hipMemcpyDeviceToHost, e.stream));
+        HF_HIP(hipMemcpyAsync(cand_score, db->d_cand_score, sizeof(float) * n, hipMemcpyDeviceToHost, e.stream));
+        HF_HIP(hipStreamSynchronize(e.stream));
+    }
+    *n_cand = n;
+    if (best_score) *best_score = best;
+    return HFNET_OK;
+}
+
+int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int mode, int32_t* cand_slot, float* cand_score, int32_t* n_cand,
+                         float* best_score, float* scores_all) {
+    API_GUARD(db, "db");
+    if (n_queries < 0) { set_error("db: n_queries < 0"); return HFNET_ERR_INVALID_ARG; }
+    if (n_queries == 0) return HFNET_OK;
+    API_GUARD(queries, "queries"); API_GUARD(cand_slot, "cand_slot"); API_GUARD(cand_score, "cand_score"); API_GUARD(n_cand, "n_cand");
+    if (mode != 0 && mode != 1) { set_error("db: mode must be 0 or 1"); return HFNET_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> lk(db->mu);
+    Engine& e = db->eng->impl;
+    std::lock_guard<std::mutex> lk2(e.mu);
+    const bool gemm = n_queries >= e.opt.db_gemm_min_queries && db->dim % 512 == 0;
+    if (!gemm && db->dim > 4096) { set_error("db: the exact batched scan supports dim <= 4096"); return HFNET_ERR_INVALID_ARG; }
+    HF_HIP(hipSetDevice(e.device));
+    const size_t Q = (size_t)n_queries, cap = (size_t)db->capacity;
+    // per-call scratch: [Q][dim] queries, [Q][cap] scores / candidates, [Q] best / counts
+    HF_TRY(e.m_a.ensure(sizeof(float) * Q * db->dim));
+    HF_TRY(e.m_s.ensure(sizeof(float) * Q * cap));
+    HF_TRY(e.m_f0.ensure(sizeof(float) * Q * cap));
+    HF_TRY(e.m_i0.ensure(sizeof(int32_t) * Q * cap));
+    HF_TRY(e.m_cnt.ensure(sizeof(int32_t) * Q));
+    HF_TRY(e.m_qn.ensure(sizeof(float) * Q));
+    const int parts = gemm ? db_gemm_partials(db->capacity) : 4 * db_batch_workgroups(db->capacity);
+    HF_TRY(e.m_key.ensure(sizeof(unsigned int) * Q * parts));
+    if (gemm) {
+        HF_TRY(e.m_tn.ensure(sizeof(float) * Q)); HF_TRY(e.m_b.ensure(sizeof(float) * db_gemm_scratch_floats(db->capacity, n_queries)));
+        HF_TRY(e.m_f1.ensure((size_t)2 * Q * db->dim));             // bf16 copies of the queries
+    }
+    float* d_q = e.m_a.as<float>(); float* d_scores = e.m_s.as<float>(); float* d_cs = e.m_f0.as<float>();
+    int32_t* d_slot = e.m_i0.as<int32_t>(); int* d_n = e.m_cnt.as<int>(); float* d_best = e.m_qn.as<float>();
+    unsigned int* d_bits = e.m_key.as<unsigned int>();
+    HF_HIP(hipMemcpyAsync(d_q, queries, sizeof(float) * Q * db->dim, hipMemcpyHostToDevice, e.stream));
+    if (gemm) {
+        if (db->norm_dirty) {
+            HF_LAUNCH(&e, e.stream, "db_norm", launch_db_prep_hi(db->d_db, db->capacity, db->dim, db->d_norm, db->d_hi, e.stream));
+            db->norm_dirty = false;
+        }
+        HF_LAUNCH(&e, e.stream, "db_qnorm", launch_db_prep_hi(d_q, n_queries, db->dim, e.m_tn.as<float>(), e.m_f1.p, e.stream));
+        HF_LAUNCH(&e, e.stream, "db_screen", launch_db_screen(d_q, e.m_f1.p, n_queries, e.m_tn.as<float>(), db->d_db, db->d_hi, db->d_norm, db->d_occ, db->capacity,
+                                                         db->dim, d_scores, d_bits, e.m_b.as<float>(), e.stream));
+    } else {
+        HF_LAUNCH(&e, e.stream, "db_scores_batch", launch_db_scores_batch(d_q, n_queries, db->d_db, db->d_occ, db->capacity, db->dim, d_scores, d_bits, e.stream));
+    }
+    HF_LAUNCH(&e, e.stream, "db_filter", launch_db_filter(d_scores, db->capacity, mode, d_bits, parts, d_slot, d_cs, d_n, d_best, n_queries, e.stream));
+    HF_HIP(hipMemcpyAsync(n_cand, d_n, sizeof(int32_t) * Q, hipMemcpyDeviceToHost, e.stream));
+    if (best_score) HF_HIP(hipMemcpyAsync(best_score, d_best, sizeof(float) * Q, hipMemcpyDeviceToHost, e.stream));
+    if (scores_all) HF_HIP(hipMemcpyAsync(scores_all, d_scores, sizeof(float) * Q * cap, hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipStreamSynchronize(e.stream));
+    for (size_t qi = 0; qi < Q; ++qi) {
+        const int n = n_cand[qi];
+        if (n <= 0) continue;
+        HF_HIP(hipMemcpyAsync(cand_slot + qi * cap, d_slot + qi * cap, sizeof(int32_t) * n, hipMemcpyDeviceToHost, e.stream));
+        HF_HIP(hipMemcpyAsync(cand_score + qi * cap, d_cs + qi * cap, sizeof(float) * n, hipMemcpyDeviceToHost, e.stream));
+    }
+    HF_HIP(hipStreamSynchronize(e.stream));
+    return HFNET_OK;
+}
+
+}  // extern "C"

@@ -2,6 +2,7 @@
 #pragma once
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -235,6 +236,57 @@ struct Net {
     const float* sample_source() const { return last_sparse ? rows_raw : desc_norm; }   // sparse rows are normalised by k_sample
     ~Net() { release(); }
 };
+
+// ---- internals shared by the translation units of the host side (engine.hip, api_extract.hip, api_match.hip, api_db.hip)
+// one polite spin iteration of the host waits on the pinned flags (the pause intrinsic is x86-only)
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
+
+template <class T>
+inline int dalloc(std::vector<void*>& allocs, T** out, size_t count) {
+    void* p = nullptr;
+    HF_HIP(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    allocs.push_back(p);
+    *out = (T*)p;
+    return HFNET_OK;
+}
+
+#define HF_LAUNCH(eng, strm, name, call)                                                   \
+    do {                                                                                   \
+        hipError_t er__;                                                                   \
+        if ((eng)->prof.enabled) {                                                         \
+            std::lock_guard<std::mutex> lk__((eng)->prof_mu);                              \
+            (eng)->prof.begin(name, strm);                                                 \
+            er__ = (call);                                                                 \
+            (eng)->prof.end(strm);                                                         \
+        } else {                                                                           \
+            er__ = (call);                                                                 \
+        }                                                                                  \
+        if (er__ != hipSuccess) {                                                          \
+            set_error("launch %s failed: %s", name, hipGetErrorString(er__));              \
+            return HFNET_ERR_DEVICE;                                                       \
+        }                                                                                  \
+    } while (0)
+
+#define API_GUARD(ptr, what)                                               \
+    do {                                                                   \
+        if (!(ptr)) { ::hfnet::set_error(what " is null"); return HFNET_ERR_INVALID_ARG; } \
+    } while (0)
+
+// HFextractor's constructor tables (HFextractor.cc:82-139) and cv::resize's fixed-point tables (engine.hip)
+void extractor_tables(int nfeatures, int nlevels, float scale_factor, int width, int height, float* sf, int* fpl, int* lw, int* lh);
+void resize_tables(int sw, int sh, int dw, int dh, std::vector<int>& xofs, std::vector<short>& ialpha, std::vector<int>& yofs, std::vector<short>& ibeta);
+// tensor offsets of a Net for `batch` frames per level (engine.hip)
+void compute_offsets(Net& n, int batch);
+// host rows -> device scratch (or the caller's device pointer as it is)
+int stage_rows(Engine& e, DevMem& m, const float* src, size_t count, int on_device, const float** out);
 
 }  // namespace hfnet
 
