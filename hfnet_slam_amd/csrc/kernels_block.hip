@@ -1315,10 +1315,16 @@ static hipError_t launch_block_fused6_t(const FusedArgs& a, const Geom& g, hipSt
 // them to the top and spills them to VGPR lanes (v_writelane / v_readlane: more VALU work than the convolution itself), so
 // they are fetched one step ahead of their use and scheduling barriers keep each batch where it is.
 // depthwise 3x3 + folded BN + ReLU6 of one pixel from the LDS halo tile: d[physical channel]
+// Row pitch of the halo tile in floats: (T + 2) positions of CIN + 4 floats, rounded up to a multiple of 64.  A 16-byte LDS read is
+// serviced in groups of 16 lanes that mix two tile rows (lanes 0-3, 12-15 of one row with lanes 4-11 of the next): with the plain
+// pitch 18 * 28 = 504 the two rows' bank patterns collide in two places (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.40 for
+// k_stem_block2); a pitch that is 0 mod 64 makes the second row continue the first row's pattern.
+template <int CIN, int T>
+constexpr int halo_row_pitch() { return ((T + 2) * (CIN + 4) + 63) / 64 * 64; }
 template <int CIN, int T>
 __device__ __forceinline__ void depthwise_from_tile(const float* tile, int ty, int tx, const float* __restrict__ wd /*[9][CIN] phys, BN folded*/,
                                                     const float* __restrict__ dbias, float (&d)[CIN]) {
-    constexpr int SH = T + 2, CP = CIN + 4;
+    constexpr int CP = CIN + 4, RP = halo_row_pitch<CIN, T>();
 #pragma unroll
     for (int c = 0; c < CIN; ++c) d[c] = dbias[c];         // accumulators start at the folded bias
     float wc[CIN], wn[CIN];
@@ -1331,7 +1337,7 @@ __device__ __forceinline__ void depthwise_from_tile(const float* tile, int ty, i
             for (int c = 0; c < CIN; ++c) wn[c] = wd[(tap + 1) * CIN + c];
         }
         asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-        const float* xp = tile + ((ty + tap / 3) * SH + tx + tap % 3) * CP;
+        const float* xp = tile + (ty + tap / 3) * RP + (tx + tap % 3) * CP;
 #pragma unroll
         for (int c4 = 0; c4 < CIN / 4; ++c4) {
             const f32x4 xv = *(const f32x4*)(xp + c4 * 4);
@@ -1415,8 +1421,8 @@ __global__ __launch_bounds__(256) void k_block_noexpand(const float* __restrict_
                                                         const float* __restrict__ pbias, Geom g) {
     // 16x16 output tile per workgroup; the 18x18 input halo tile is staged through LDS with coalesced 96-byte
     // pixel rows, so every input byte crosses HBM ~1.27x instead of up to 9x.
-    constexpr int T = 16, SH = T + 2, CP = CIN + 4;
-    __shared__ __attribute__((aligned(16))) float tile[SH * SH * CP];
+    constexpr int T = 16, SH = T + 2, CP = CIN + 4, RP = halo_row_pitch<CIN, T>();
+    __shared__ __attribute__((aligned(16))) float tile[SH * RP];
     const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
     const LevelGeom lv = g.lv[level];
     const int tiles_x = (lv.Wo + T - 1) / T;
@@ -1442,7 +1448,7 @@ __global__ __launch_bounds__(256) void k_block_noexpand(const float* __restrict_
                 const int hy = r2 * 2 + rsel, iy = oy0 - lv.pt + hy;
                 const bool ok = xok && iy >= 0 && iy < lv.H;
                 const f32x4 v = *(const f32x4*)(colp + (long long)(ok ? iy : 0) * lv.W * CIN);
-                *(f32x4*)(tp + hy * SH * CP) = ok ? v : zero;
+                *(f32x4*)(tp + hy * RP) = ok ? v : zero;
             }
         }
     }
@@ -1465,9 +1471,9 @@ __global__ __launch_bounds__(256) void k_stem_block2(ImageSet imgs, const float*
                                                      const float* __restrict__ wd, const float* __restrict__ dbias, const float* __restrict__ wp,
                                                      const float* __restrict__ pbias, float* __restrict__ out,
                                                      Geom gs /*image -> stem*/, Geom gb /*stem -> layer_2*/) {
-    constexpr int T = 16, SH = T + 2, SP = SH * SH, CP = CS + 4, CH = CS / 2;
+    constexpr int T = 16, SH = T + 2, SP = SH * SH, CP = CS + 4, CH = CS / 2, RP = halo_row_pitch<CS, T>();
     static_assert(CS == 24 && COUT == 16, "written for the 0.75-width network");
-    __shared__ __attribute__((aligned(16))) float tile[SP * CP];
+    __shared__ __attribute__((aligned(16))) float tile[SH * RP];
     int level, frame, tile_id, tiles_x;
     decode_tile_grid<T, T>(gb, blockIdx.x, level, frame, tile_id, tiles_x);
     const LevelGeom ls = gs.lv[level], lb = gb.lv[level];     // ls: H,W image (cropped), Ho,Wo stem; lb: H,W stem, Ho,Wo out (same size)
@@ -1521,7 +1527,7 @@ __global__ __launch_bounds__(256) void k_stem_block2(ImageSet imgs, const float*
             // prefetched ahead does not fit next to the geometry without spilling to VGPR lanes)
             const f32x4* __restrict__ w4 = (const f32x4*)(stem_w + hsel * CH);    // uniform; row t is w4[t * CS / 4 + group]
             const f32x4* __restrict__ sh4 = (const f32x4*)(stem_bias + hsel * CH);
-            float* tp = tile + p * CP + hsel * CH;
+            float* tp = tile + hy * RP + hx * CP + hsel * CH;
 #pragma unroll
             for (int grp = 0; grp < CH / 4; ++grp) {
                 f32x4 wq[9];
