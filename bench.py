@@ -590,7 +590,7 @@ def config_bf16x3(torch, capi, eng, dev, frames, B, chunks_per_step, steps, weig
     operands, bf16 matrix pipe) -- what the ~25 % of the step that never touches an index buys on the faster pipe.  `value` stays the
     exact path.  Keypoints must equal the oracle's bit for bit; descriptors / global descriptor within the stated tolerance."""
     from oracle import oracle as O
-    TOL = 1e-5
+    TOL, TOL_G = 1e-5, 2e-5            # include/hfnet_hip.h: descriptors / global descriptor
     saved = {o: eng.get_option(o) for o in ("desc_bf16x3", "global_bf16x3")}
     eng.set_option("desc_bf16x3", 1); eng.set_option("global_bf16x3", 1)
     pipe = Pipeline(torch, capi, eng, dev, W_IMG, H_IMG, B)
@@ -633,11 +633,11 @@ def config_bf16x3(torch, capi, eng, dev, frames, B, chunks_per_step, steps, weig
                 dmax = max(dmax, float(np.abs(d[:n].astype(np.float64) - rd).max()))
             gmax = max(gmax, float(np.abs(g.astype(np.float64) - rg).max()))
         return {"workload": "the headline workload with engine options desc_bf16x3 = global_bf16x3 = 1 (descriptor head at the tap cells and the 1x1 convolutions of "
-                            "layers 15-18 on split-bf16 operands, three products, bf16 matrix pipe); keypoints exact, float outputs within the stated tolerance",
+                            "layers 9-18 on split-bf16 operands, three products, bf16 matrix pipe); keypoints exact, float outputs within the stated tolerance",
                 "frames_per_s": B * chunks_per_step * steps / elapsed, "steps": steps, "profiled_chunk_ms_single_stream": chunk_ms,
                 "bf16x3_launches": rows, "bf16x3_share_of_chunk": sum(r["share"] for r in rows),
                 "verified": {"frames": [0, B - 1], "keypoints_equal": bool(kp_equal), "descriptor_max_abs_dev": dmax, "global_max_abs_dev": gmax,
-                             "tolerance": TOL, "within_tolerance": bool(kp_equal and dmax <= TOL and gmax <= TOL)}}
+                             "tolerance": TOL, "tolerance_global": TOL_G, "within_tolerance": bool(kp_equal and dmax <= TOL and gmax <= TOL_G)}}
     finally:
         for o, v in saved.items():
             eng.set_option(o, v)

@@ -249,10 +249,12 @@ static int run_block(Net& n, int L, int n_used, hipStream_t st) {   // layer L =
     const long long p_out = n.pix[L][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
     const bool fuse = block_runs_fused(n, L);
     if (fuse) {
+        // option global_bf16x3 (layers past the index-deciding part of the network only): the block's 1x1 convolutions on split-bf16 operands
+        const bool bfb = n.global_bf16x3 && L > 7 && block_fused_bf16x3_supported(b);
         char fn[32];
-        snprintf(fn, sizeof fn, "block_L%02d", L);
+        snprintf(fn, sizeof fn, bfb ? "block_L%02d_bf16x3" : "block_L%02d", L);
         const Geom gf = n.geom(L - 1, L, 0, n_used);
-        HF_LAUNCH(e, st, fn, launch_block_fused(n.act[L - 1], b, n.act[L], gf, n.fused_variant, st));
+        HF_LAUNCH(e, st, fn, launch_block_fused(n.act[L - 1], b, n.act[L], gf, n.fused_variant, st, bfb ? 1 : 0));
         return HFNET_OK;
     }
     const float* src = n.act[L - 1];

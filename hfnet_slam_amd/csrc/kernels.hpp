@@ -50,7 +50,9 @@ hipError_t launch_depthwise(const float* in, const DwPack& dp, int stride, float
 // variant: 4 = wave-autonomous tiles where available (default), 3 = the same with the three-waves-per-SIMD instantiations at any
 // launch size, 2 = the barrier-phased kernel everywhere (A/B of the tests)
 bool block_fusable(const BlockPack& b, int variant);
-hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, const Geom& g, int variant, hipStream_t s);
+hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, const Geom& g, int variant, hipStream_t s, int bf16x3 = 0);
+// bf16x3 != 0 takes the split-bf16 form of the block (engine option global_bf16x3) where this says so
+bool block_fused_bf16x3_supported(const BlockPack& b);
 // stem conv + layer_2 (no-expansion block) in one launch: the stem tensor stays in LDS
 bool stem_block_fusable(int stem_out, const BlockPack& b);
 hipError_t launch_stem_block(const ImageSet& imgs, const float* stem_w, const float* stem_bias, const BlockPack& b, float* out,

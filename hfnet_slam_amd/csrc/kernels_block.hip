@@ -32,6 +32,7 @@ struct FusedArgs {
     const float* Wdw; const float* dw_bias;
     const f32x4* Wpr; const float* pr_bias; int pr_nt_total;
     const f32x4* Wex16; const f32x4* Wpr16; int ex_n16, pr_n16;  // ConvPack16 forms (k_block_fused6)
+    const void* Wex_bf; const void* Wpr_bf;                      // split-bf16 forms (launch_repack_bf16x3; k_block_fused8<..., BF = true>), or null
     float* out;
     int cin, cexp, cout, residual, has_expand;
     int level_wgs[HFNET_MAX_LEVELS];   // k_block_fused4: workgroups launched per image of each level (a multiple of 8; exact 1-D grid)
@@ -787,7 +788,21 @@ template <int STRIDE> struct F8Geo {
 // Layer 8 (96 input channels: 240 registers of A fragments) runs at ONE wave per SIMD (OCC = 1) with everything resident: 1064 us per
 // 128 frames against the barrier kernel's 1273.  (With the A pieces re-read from L1 / L2 per chunk through a ring of three k-steps it
 // fitted two waves per SIMD and took 1389 us: every wave then pulls 60 KB of A per chunk, ~37 B/clk per CU from L2.  Not kept.)
-template <int STRIDE, int NTO, int KQT, bool RES, int OCC>
+// BF (engine option global_bf16x3, layers 8-14 of calls that take the fused kernels): both 1x1 convolutions on split-bf16 operands (two
+// pieces, three products, v_mfma_f32_32x32x16_bf16 -- kernels_conv.hip k_conv_bf16x3 for the scheme and its error bound): the block
+// input is split once per tile, the depthwise results once per chunk on their way from LDS into the projection; the D fragment of the
+// bf16 MFMA has the f32 one's layout, so the register-resident depthwise stage is unchanged (and exact for its inputs).  NOT the
+// oracle's bits: within the tolerance stated in include/hfnet_hip.h.
+typedef __bf16 fb16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void fsplit8(const f32x4& v0, const f32x4& v1, fb16x8& hi, fb16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = e < 4 ? v0[e] : v1[e - 4];
+        hi[e] = (__bf16)v;
+        lo[e] = (__bf16)(v - (float)hi[e]);
+    }
+}
+template <int STRIDE, int NTO, int KQT, bool RES, int OCC, bool BF = false>
 __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
     using G = F8Geo<STRIDE>;
     constexpr int TH = G::TH, TW = G::TW, IH = G::IH, IW = G::IW, NC = G::NC, MT = G::MT, CEP = G::CEP;
@@ -817,7 +832,9 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
     const char* __restrict__ xb = (const char*)(a.X + in_base * a.cin);      // uniform; lane offsets are 32-bit
 
     // ---- block input: A row r of M tile m is accumulator slot 16 m + ir of lane half hr
-    f32x4 afrag[MT][KQT];
+    constexpr int KS = (KQT + 1) / 2;                             // BF: 16-k steps of the expansion (the last one may hold 8 channels)
+    f32x4 afrag[BF ? 1 : MT][BF ? 1 : KQT];
+    fb16x8 ah[BF ? MT : 1][BF ? KS : 1], al[BF ? MT : 1][BF ? KS : 1];
     float aflag[MT];                                              // 1 where this A row is an out-of-image position (k half 0 only)
     {
         const int hr = (r >> 2) & 1, ir = ((r >> 3) << 2) | (r & 3);
@@ -838,9 +855,22 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
             const bool outside = iyr < 0 || iyr >= lv.H || ixr < 0 || ixr >= lv.W;
             aflag[m] = (outside && half == 0) ? 1.0f : 0.0f;
             const int iy = min(max(iyr, 0), lv.H - 1), ix = min(max(ixr, 0), lv.W - 1);
-            const unsigned off = ((unsigned)(iy * lv.W + ix) * (unsigned)a.cin + (unsigned)(half * 4)) * 4u;
+            if constexpr (BF) {
+                // lane (row, half) of a 16-k step holds k = 8 half .. 8 half + 7: the physical slots of channel group 2 ks + half
+                const unsigned offp = (unsigned)(iy * lv.W + ix) * (unsigned)a.cin * 4u;
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kq = 0; kq < KQT; ++kq) afrag[m][kq] = *(const f32x4*)(xb + off + kq * 32);
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bool kok = ks * 16 + half * 8 < a.cin;       // (the upper half of a last step of 8 channels: zeros)
+                    const char* pa = xb + offp + (kok ? (ks * 16 + half * 8) * 4 : 0);
+                    const f32x4 v0 = *(const f32x4*)pa, v1 = *(const f32x4*)(pa + 16);
+                    fsplit8(kok ? v0 : z4, kok ? v1 : z4, ah[m][ks], al[m][ks]);
+                }
+            } else {
+                const unsigned off = ((unsigned)(iy * lv.W + ix) * (unsigned)a.cin + (unsigned)(half * 4)) * 4u;
+#pragma unroll
+                for (int kq = 0; kq < KQT; ++kq) afrag[m][kq] = *(const f32x4*)(xb + off + kq * 32);
+            }
         }
     }
     const float bneg = half == 0 ? -1.0e30f : 0.0f;
@@ -854,12 +884,25 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
     const int n_chunks = min(a.ex_nt_total, (a.cexp + 31) >> 5);
     const unsigned lane16_ = (unsigned)lane * 16u, r4_ = (unsigned)r * 4u;
     constexpr int PF = KQT < 3 ? KQT : 3;                          // pieces of expansion weights in flight
-    f32x4 bq[PF];
+    f32x4 bq[BF ? 1 : PF];
+    // BF: the chunk's expansion weights [step][hi | lo], requested for the NEXT chunk right behind this chunk's expansion
+    fb16x8 bfr[BF ? KS : 1][2];
+    const fb16x8* __restrict__ wexb = (const fb16x8*)a.Wex_bf;
+    const fb16x8* __restrict__ wprb = (const fb16x8*)a.Wpr_bf;
+    auto load_bfr = [&](int chunk) {
+#pragma unroll
+        for (int ks = 0; ks < (BF ? KS : 1); ++ks)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) bfr[ks][hl] = wexb[(((size_t)ks * a.ex_nt_total + chunk) * 2 + hl) * 64 + lane];
+    };
     float ebias;
     {
         const unsigned lane16 = fresh(lane16_), r4 = fresh(r4_);
+        if constexpr (BF) load_bfr(0);
+        else {
 #pragma unroll
-        for (int j = 0; j < PF; ++j) bq[j] = *(gvec4_t)(sgpr_base(a.Wex, (unsigned)(j * a.ex_nt_total) * 1024u) + lane16);
+            for (int j = 0; j < PF; ++j) bq[j] = *(gvec4_t)(sgpr_base(a.Wex, (unsigned)(j * a.ex_nt_total) * 1024u) + lane16);
+        }
         ebias = *(gf32_t)(sgpr_base(a.ex_bias, 0u) + r4);
     }
     auto swp = [](float x, float y, int which) -> float {          // (x.lower, y.lower) [which = 0] / (x.upper, y.upper) [1] as (lower, upper) half
@@ -878,10 +921,36 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
             for (int t = 0; t < 9; ++t) dwt[t] = *(gf32_t)(sgpr_base(a.Wdw, (unsigned)(t * a.cexp + ch0) * 4u) + fresh(dch4));
             dwb = *(gf32_t)(sgpr_base(a.dw_bias, (unsigned)ch0 * 4u) + fresh(dch4));
         };
-        if constexpr (OCC > 1) load_dw();                          // (one wave per SIMD: requested behind the expansion, where its registers are free)
+        constexpr bool DW_LATE = OCC == 1 || (BF && KS >= 5);      // (tight on registers: requested behind the expansion, where its registers are free)
+        if constexpr (!DW_LATE) load_dw();
         // ---- expansion: MT independent chains, k outer, weights through the ring
         f32x16 acc[MT];
-        {
+        if constexpr (BF) {
+            if constexpr (KS >= 5) { if (chunk > 0) load_bfr(chunk); }
+            f32x16 bias16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bias16[i] = ebias;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                // (border tiles: the chain of an out-of-image row starts at -1e30, as in the f32 form)
+                const f32x16 c0 = interior ? bias16 : __builtin_amdgcn_mfma_f32_32x32x2f32(aflag[m], bneg, bias16, 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m][0], bfr[0][0], c0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks > 0) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m][ks], bfr[ks][0], acc[m], 0, 0, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m][ks], bfr[ks][1], acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m][ks], bfr[ks][0], acc[m], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (KS < 5) load_bfr(cn);                    // the next chunk's weights arrive during the depthwise / projection (72 input
+                                                                   // channels: 40 registers the depthwise needs -- requested at the chunk's top instead)
+        } else {
             f32x16 bias16;
 #pragma unroll
             for (int i = 0; i < 16; ++i) bias16[i] = ebias;
@@ -913,7 +982,7 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if constexpr (OCC == 1) load_dw();
+        if constexpr (DW_LATE) load_dw();
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -935,16 +1004,26 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
             }
         }
         // this chunk's projection weights: requested here, into registers the expansion has released (PJIT -- one wave per SIMD, every
-        // register counts: a k-group at a time, one group ahead of its MFMAs)
+        // register counts: a k-group at a time, one group ahead of its MFMAs).  BF: [16-k step][column tile][hi | lo], a step at a time.
         constexpr bool PJIT = OCC == 1;
-        f32x4 pfrag[PJIT ? 2 : 4][NTO];
+        f32x4 pfrag[BF ? 1 : (PJIT ? 2 : 4)][BF ? 1 : NTO];
+        constexpr int PBN = (KS >= 5 && NTO >= 3) ? 1 : 2;         // (72 -> 432 -> 72: no registers for a second step's fragments)
+        fb16x8 pbf[BF ? PBN : 1][BF ? NTO : 1][2];
         auto load_p = [&](int kq, int slot) {
             const unsigned l16 = fresh(lane16_);
 #pragma unroll
-            for (int nt = 0; nt < NTO; ++nt)
+            for (int nt = 0; nt < (BF ? 1 : NTO); ++nt)
                 pfrag[slot][nt] = *(gvec4_t)(sgpr_base(a.Wpr, (unsigned)((chunk * 4 + min(kq, kqc - 1)) * a.pr_nt_total + nt) * 1024u) + l16);
         };
-        if constexpr (PJIT) load_p(0, 0);
+        auto load_pbf = [&](int s16, int slot) {                  // s16: 16-k step of this chunk (0, 1)
+            const int step = min(chunk * 2 + s16, ((a.cexp + 15) >> 4) - 1);
+#pragma unroll
+            for (int nt = 0; nt < (BF ? NTO : 1); ++nt)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) pbf[slot][nt][hl] = wprb[(((size_t)step * a.pr_nt_total + nt) * 2 + hl) * 64 + lane];
+        };
+        if constexpr (BF) load_pbf(0, 0);
+        else if constexpr (PJIT) load_p(0, 0);
         else {
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) load_p(kq, kq);
@@ -969,6 +1048,27 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
             }
         asm volatile("" ::: "memory");
         // ---- projection of this chunk's channels
+        if constexpr (BF) {
+#pragma unroll
+            for (int s16 = 0; s16 < 2; ++s16) {
+                if (ch0 + s16 * 16 < a.cexp) {                     // (uniform)
+                    if (s16 == 0 && PBN == 2) load_pbf(1, 1);
+                    if (s16 == 1 && PBN == 1) load_pbf(1, 0);
+                    const bool kok = ch0 + s16 * 16 + half * 8 < a.cexp;      // (channels past cexp hold clamped garbage: zeros instead)
+                    const float* pa = ET + r * CEP + s16 * 16 + half * 8;
+                    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 v0 = *(const f32x4*)pa, v1 = *(const f32x4*)(pa + 4);
+                    fb16x8 dh, dl;
+                    fsplit8(kok ? v0 : z4, kok ? v1 : z4, dh, dl);
+#pragma unroll
+                    for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, pbf[s16 % PBN][nt][0], pacc[nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, pbf[s16 % PBN][nt][1], pacc[nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl, pbf[s16 % PBN][nt][0], pacc[nt], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) {
             if (kq < kqc) {
@@ -979,6 +1079,7 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
 #pragma unroll
                     for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], pfrag[PJIT ? (kq & 1) : kq][nt][t], pacc[nt], 0, 0, 0);
             }
+        }
         }
         asm volatile("" ::: "memory");
         ebias = enext;
@@ -1013,7 +1114,7 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
     }
 }
 
-template <int STRIDE, int NTO, int KQT, int OCC>
+template <int STRIDE, int NTO, int KQT, int OCC, bool BF = false>
 static hipError_t launch_block_fused8_t(const FusedArgs& a, const Geom& g, hipStream_t s) {
     if (a.residual && (STRIDE != 1 || a.cin != a.cout)) return hipErrorInvalidValue;
     FusedArgs b = a;
@@ -1026,8 +1127,9 @@ static hipError_t launch_block_fused8_t(const FusedArgs& a, const Geom& g, hipSt
         total += (long long)b.level_wgs[l] * g.batch;
     }
     if (total <= 0 || total > 0x7fffffffll) return hipErrorInvalidValue;
-    if (a.residual) hipLaunchKernelGGL((k_block_fused8<STRIDE, NTO, KQT, true, OCC>), dim3((unsigned)total), dim3(64), 0, s, b, g);
-    else hipLaunchKernelGGL((k_block_fused8<STRIDE, NTO, KQT, false, OCC>), dim3((unsigned)total), dim3(64), 0, s, b, g);
+    if (BF && (!a.Wex_bf || !a.Wpr_bf)) return hipErrorInvalidValue;
+    if (a.residual) hipLaunchKernelGGL((k_block_fused8<STRIDE, NTO, KQT, true, OCC, BF>), dim3((unsigned)total), dim3(64), 0, s, b, g);
+    else hipLaunchKernelGGL((k_block_fused8<STRIDE, NTO, KQT, false, OCC, BF>), dim3((unsigned)total), dim3(64), 0, s, b, g);
     return hipGetLastError();
 }
 
@@ -1646,9 +1748,16 @@ static FusedKind fused_kind(const BlockPack& b, int variant) {
 }
 bool block_fusable(const BlockPack& b, int variant) { return fused_kind(b, variant) != FUSED_NONE; }
 
-hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, const Geom& g, int variant, hipStream_t s) {
+bool block_fused_bf16x3_supported(const BlockPack& b) {
+    const int nto = (b.cout + 31) / 32, kq = b.cin / 8, st = b.stride;
+    return b.has_expand && b.ex_bf && b.pr_bf && b.cin % 8 == 0 && b.pr.nt_total == nto &&
+           ((st == 1 && kq == 6 && (nto == 2 || nto == 3)) || (st == 1 && kq == 9 && nto == 3));      // (layer 8: 240 + 48 fragment registers do not fit)
+}
+
+hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, const Geom& g, int variant, hipStream_t s, int bf16x3) {
     FusedArgs a;
     a.X = X;
+    a.Wex_bf = b.ex_bf; a.Wpr_bf = b.pr_bf;
     a.Wex = (const f32x4*)b.ex.w; a.ex_bias = b.ex.bias; a.ex_nt_total = b.ex.nt_total;
     a.Wdw = b.dw.w; a.dw_bias = b.dw.bias;
     a.Wpr = (const f32x4*)b.pr.w; a.pr_bias = b.pr.bias; a.pr_nt_total = b.pr.nt_total;
@@ -1662,6 +1771,11 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
     // (752x480, one frame: layer 5 49 -> 20 us, layers 3-7 together 200 -> 150 us).  Same bits either way.
     FusedKind kind = fused_kind(b, variant);
     const bool small_launch = n_tiles < 2048;
+    if (bf16x3 && block_fused_bf16x3_supported(b)) {              // engine option global_bf16x3: tolerance instead of the oracle's bits
+        if (kq == 6 && nto == 2) return launch_block_fused8_t<1, 2, 6, 2, true>(a, g, s);
+        if (kq == 6 && nto == 3) return launch_block_fused8_t<1, 3, 6, 2, true>(a, g, s);
+        if (kq == 9 && nto == 3) return launch_block_fused8_t<1, 3, 9, 2, true>(a, g, s);
+    }
     if (kind == FUSED_V4 && variant == 4 && small_launch && fused_kind(b, 2) == FUSED_V2) kind = FUSED_V2;
     // v6 (6 x 8 tiles on the 16x16x4 MFMA): what a launch of k_block_fused4's size runs for the stride-1 blocks from layer 6 on
     // (per 64 frames, v4 -> v6: layer 6 331 -> 303 us, 7 966 -> 957, 9-11 94 -> 87, 12 138 -> 98, 13 / 14 245 -> 168); layer 4 (four waves

@@ -279,7 +279,7 @@ int DeviceWeights::build(const WeightFile& wf) {
         };
         HF_TRY(split(desc1, &desc1_bf)); HF_TRY(split(desc2, &desc2_bf));
         if (!desc1_bf || !desc2_bf) desc1_bf = desc2_bf = nullptr;
-        for (int i = 13; i < 17; ++i) {                             // layers 15-18
+        for (int i = 6; i < 17; ++i) {                              // layers 8-18
             if (blocks[i].has_expand) HF_TRY(split(blocks[i].ex, &blocks[i].ex_bf));
             HF_TRY(split(blocks[i].pr, &blocks[i].pr_bf));
         }

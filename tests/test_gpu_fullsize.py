@@ -145,13 +145,13 @@ def test_mid_sized_call_every_frame_vs_oracle(engine, oracle_model, size):
 
 
 BF16X3_DESC_TOL = 1e-5        # abs, on unit-norm 256-D rows (include/hfnet_hip.h; observed <= 2e-6)
-BF16X3_GLOBAL_TOL = 1e-5      # abs, on the unit-norm global descriptor (observed <= 1.5e-6)
+BF16X3_GLOBAL_TOL = 2e-5      # abs, on the unit-norm global descriptor (observed <= 6e-6: ten layers of split-bf16 1x1 convolutions deep)
 
 
 @pytest.mark.parametrize("cfg", [(752, 480, 1000), (512, 512, 850)])
 def test_split_bf16_options_keep_indices_exact_and_floats_within_tolerance(engine, oracle_model, cfg):
     """engine options desc_bf16x3 / global_bf16x3 (default off): the stages that decide no index -- the descriptor head at the tap
-    cells, the 1x1 convolutions of layers 15-18 -- on split-bf16 operands (two pieces, three products on the bf16 matrix pipe).
+    cells, the 1x1 convolutions of layers 9-18 -- on split-bf16 operands (two pieces, three products on the bf16 matrix pipe).
     north_star's contract: keypoint indices bit-exact, descriptor tensors within a stated tolerance.  Against the ORACLE: counts,
     keypoints (x, y, response, octave) array_equal; descriptors and global descriptor within the stated tolerance; unit norms.  And the
     matcher's answers on the produced descriptors agree with its answers on the exact path's descriptors (frames that really match:
