@@ -119,8 +119,9 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *   "global_bf16x3" (0) the same for the 1x1 convolutions of the global branch's blocks: layers 9-14 inside their fused kernel (calls that take
  *                       the fused kernels, i.e. more than four frames; the depthwise stage between the two stays exact f32) and layers 15-18
  *                       (three launches per block).  STATED TOLERANCE: 2e-5 absolute per component of the (unit-norm) 4096-D global
- *                       descriptor (measured <= 6e-6 through the ten blocks).  Layer 8, the NetVLAD head and the dimensionality reduction
- *                       stay exact.
+ *                       descriptor (measured <= 6e-6 through the ten blocks; a model with a D-dimensional global descriptor: 2e-5 *
+ *                       sqrt(4096 / D) -- the components of a unit vector scale that way).  Layer 8, the NetVLAD head and the dimensionality
+ *                       reduction stay exact.
  * The matcher and the database are exact FOR THE DESCRIPTORS THEY ARE GIVEN in either mode. */
 int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value);
 int hfnet_engine_get_option(hfnet_engine* e, const char* name, int* value);

@@ -713,6 +713,76 @@ def test_other_network_widths(engine, tmp_path, mult, n_clusters, global_dim):
         e.close()
 
 
+@pytest.mark.parametrize("fuse_min_wgs", [0, None], ids=["fused_forms", "default_dispatch"])
+@pytest.mark.parametrize("mult", [0.75, 0.5, 1.4])
+def test_split_bf16_options_on_ragged_geometries_and_other_widths(engine, oracle_model, weights_path, tmp_path, mult, fuse_min_wgs):
+    """desc_bf16x3 / global_bf16x3 away from the two full-size configurations: level sizes that leave partial tiles on every border
+    (the split-bf16 forms of the fused blocks have their own border handling), single-frame calls and calls of three frames, the
+    fused forms forced onto launches this small (fuse_min_wgs = 0) and the default dispatch, and network widths whose layers only
+    the generic kernels cover.  Keypoints == oracle bit for bit; descriptors / global descriptor within the header's tolerances."""
+    from hfnet_slam_amd import capi, spec, weights
+    from oracle import oracle as O
+    if mult == 0.75:
+        e, m, own = engine, oracle_model, False
+    else:
+        p = str(tmp_path / "w.hfw")
+        weights.save(p, weights.synthetic_weights(13, spec.net_spec(mult, 32, 1024)))
+        e, m, own = capi.Engine(p, 0), O.Model(p), True
+    gdim = 4096 if mult == 0.75 else 1024
+    tol_g = 2e-5 * np.sqrt(4096 / gdim)         # (the header's tolerance is on the elements of a unit vector: they scale with 1 / sqrt(dimension))
+    opts = {"desc_bf16x3": 1, "global_bf16x3": 1}
+    if fuse_min_wgs is not None:
+        opts["fuse_min_wgs"] = fuse_min_wgs
+    saved = {o: e.get_option(o) for o in opts}
+    try:
+        for o, v in opts.items():
+            e.set_option(o, v)
+        for (w, h, nl, nf) in [(200, 152, 4, 500), (131, 121, 2, 150), (248, 168, 3, 300), (376, 240, 2, 400)]:
+            x = capi.Extractor(e, w, h, nf, 0.01, 1.2, nl, max_batch=3)
+            imgs = np.stack([synth_image(h, w, 71, "natural"), synth_image(h, w, 72), synth_image(h, w, 73, "natural")])
+            nb, kb, db, gb = x.extract_batch(imgs)
+            n1, k1, d1, g1, _ = x.extract(imgs[1])
+            for f in range(3):
+                rn, rk, rd, rg, _ = m.extract(imgs[f], nf, 0.01, nl, 1.2)
+                assert nb[f] == rn and np.array_equal(kb[f, :rn], rk), (mult, w, h, f)
+                assert np.abs(db[f, :rn].astype(np.float64) - rd).max() <= 1e-5, (mult, w, h, f)
+                assert np.abs(gb[f].astype(np.float64) - rg).max() <= tol_g, (mult, w, h, f)
+                if f == 1:
+                    assert n1 == rn and np.array_equal(k1, rk)
+                    assert np.abs(d1.astype(np.float64) - rd).max() <= 1e-5 and np.abs(g1.astype(np.float64) - rg).max() <= tol_g
+            x.close()
+    finally:
+        for o, v in saved.items():
+            e.set_option(o, v)
+        if own:
+            e.close()
+
+
+@pytest.mark.parametrize("B", [1, 4])
+def test_split_bf16_fused_forms_on_calls_of_few_frames(engine, oracle_model, engine_options, B):
+    """NOTEBOOK.md R4.8: with fuse_min_wgs lowered the split-bf16 forms of the fused blocks also run in calls of <= 4 frames, whose sampler
+    normally overlaps the global branch; in that combination the sampler read stale tap rows (wrong descriptors in a few rows per call, or
+    a GPU memory fault) until the branch was joined first.  One extractor, repeated calls on two alternating sets of frames (so that
+    anything left over from the previous call is wrong for this one), every frame of every call against the oracle."""
+    from hfnet_slam_amd import capi
+    engine_options({"global_bf16x3": 1, "fuse_min_wgs": 0})
+    w, h, nf, nl = 752, 480, 1000, 4
+    sets = [np.stack([synth_image(h, w, 8100 + 10 * s + i, "natural") for i in range(B)]) for s in range(2)]
+    refs = [[oracle_model.extract(im[i], nf, 0.01, nl, 1.2) for i in range(B)] for im in sets]
+    x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, nl, max_batch=B)
+    try:
+        for call in range(24):
+            s = call & 1
+            nb, kb, db, gb = x.extract_batch(sets[s])
+            for f in range(B):
+                rn, rk, rd, rg, _ = refs[s][f]
+                assert nb[f] == rn and np.array_equal(kb[f, :rn], rk), (call, f)
+                assert np.array_equal(db[f, :rn], rd), (call, f, int((np.abs(db[f, :rn] - rd).max(axis=1) > 0).sum()))      # (desc_bf16x3 is off: the oracle's bits)
+                assert np.abs(gb[f].astype(np.float64) - rg).max() <= 2e-5, (call, f)
+    finally:
+        x.close()
+
+
 def test_store_put_extracted_matches_host_round_trip(engine, oracle_model):
     """frame-to-frame tracking without the descriptors leaving the GPU: extract, keep the block in a store slot, match by slot"""
     from hfnet_slam_amd import capi
