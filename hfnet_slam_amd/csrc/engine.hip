@@ -251,7 +251,7 @@ static int run_block(Net& n, int L, int n_used, hipStream_t st) {   // layer L =
     if (fuse) {
         // option global_bf16x3 (layers past the index-deciding part of the network only): the block's 1x1 convolutions on split-bf16 operands
         const bool bfb = n.global_bf16x3 && L > 7 && block_fused_bf16x3_supported(b);
-        if (bfb) n.bf_fused_used = true;
+        if (L > 7) n.branch_fused_used = true;
         char fn[32];
         snprintf(fn, sizeof fn, bfb ? "block_L%02d_bf16x3" : "block_L%02d", L);
         const Geom gf = n.geom(L - 1, L, 0, n_used);
@@ -404,12 +404,13 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         HF_TRY(forward_global(stream_global, g_next, 1 << 20, nullptr));   // whatever is left of the branch
         HF_HIP(hipEventRecord(ev_join, stream_global));
     }
-    // OPEN ISSUE (NOTEBOOK.md R4.8): with the split-bf16 forms of the fused blocks in the global branch of a call of <= 4 frames (only reachable
-    // with fuse_min_wgs lowered: such calls take the exact single-frame kernels by default), a sampler that runs WHILE that branch is still
-    // going has read stale tap rows (tools/dev/latency_repro.py; never with the exact kernels, never when the branch is joined first).  Until
-    // that is understood the branch is joined before the sampler in exactly that case.
-    const bool early_join = caller_joins && bf_fused_used;
-    bf_fused_used = false;
+    // OPEN ISSUE (NOTEBOOK.md R4.8): with fused-block kernels in the global branch of a call of <= 4 frames (only reachable with fuse_min_wgs
+    // lowered: such calls take the single-frame kernels by default), a sampler that runs WHILE that branch is still going has read stale
+    // tap rows -- every few calls with the split-bf16 forms of k_block_fused8, once in 3 000 calls with its exact layer-8 form
+    // (tools/dev/latency_repro.py); never when the branch is joined first.  Until that is understood the branch is joined before the
+    // sampler in exactly that case.
+    const bool early_join = caller_joins && branch_fused_used;
+    branch_fused_used = false;
     if (cfg.global && fork_early && caller_joins && !early_join) join_pending = true;
     else if (cfg.global && fork && defer) join_pending = true;
     else if (cfg.global && fork) HF_HIP(hipStreamWaitEvent(stream, ev_join, 0));

@@ -229,7 +229,7 @@ struct Net {
     // join_pending is set, the caller finishes its work on the local results first and then waits for ev_join itself
     int forward(const ImageSet& imgs, float threshold, const TopkBudget& budget, bool defer_global = false, bool caller_joins = false);
     bool join_pending = false;
-    bool bf_fused_used = false;   // a split-bf16 fused block was enqueued by the forward() in progress (see the end of Net::forward)
+    bool branch_fused_used = false;   // a fused-block kernel was enqueued for a layer of the global branch by the forward() in progress (see its end)
     int tap(int id, std::vector<float>& out);
     int run_dense_desc();
     int forward_global(hipStream_t st, int first = 0, int count = 1 << 20, int* total = nullptr);   // launch groups [first, first + count)
