@@ -552,10 +552,14 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a, Geom g) {
         if (a.sparse && a.cell_row) {   // de-duplicated taps: the row of every cell is looked up
             const float* d = a.desc_map + ((long long)image * a.kps_stride * 4) * 256 + lane * 4;
             const int* cr = a.cell_row + (long long)image * a.cell_stride;
-            vff = (fxin && fyin) ? *(const f32x4*)(d + (long long)cr[fy * dw + fx] * 256) : zero;
-            vcc = (cxin && cyin) ? *(const f32x4*)(d + (long long)cr[cy * dw + cx] * 256) : zero;
-            vfc = (fxin && cyin) ? *(const f32x4*)(d + (long long)cr[cy * dw + fx] * 256) : zero;
-            vcf = (cxin && fyin) ? *(const f32x4*)(d + (long long)cr[fy * dw + cx] * 256) : zero;
+            // (a row number comes from device memory: kept inside the image's slot whatever it is -- a wrong descriptor is a test failure,
+            //  a wild address takes the process down; NOTEBOOK.md R4.8)
+            const int rmax = (int)a.kps_stride * 4 - 1;
+            auto row_of = [&](int cell) { return (long long)min(max(cr[cell], 0), rmax) * 256; };
+            vff = (fxin && fyin) ? *(const f32x4*)(d + row_of(fy * dw + fx)) : zero;
+            vcc = (cxin && cyin) ? *(const f32x4*)(d + row_of(cy * dw + cx)) : zero;
+            vfc = (fxin && cyin) ? *(const f32x4*)(d + row_of(cy * dw + fx)) : zero;
+            vcf = (cxin && fyin) ? *(const f32x4*)(d + row_of(fy * dw + cx)) : zero;
         } else if (a.sparse) {   // rows 4i..4i+3 of the image slot hold the taps (fx,fy) (cx,cy) (fx,cy) (cx,fy)
             const float* d = a.desc_map + (((long long)image * a.kps_stride + i) * 4) * 256 + lane * 4;
             vff = (fxin && fyin) ? *(const f32x4*)(d) : zero;
