@@ -21,7 +21,7 @@ int* Options::find(const char* name) {
     const struct { const char* n; int* p; } tab[] = {{"fuse_blocks", &fuse_blocks}, {"fuse_max_layer", &fuse_max_layer}, {"fused_variant", &fused_variant},
                                                        {"fuse_stem", &fuse_stem}, {"dense_desc", &dense_desc}, {"two_streams", &two_streams},
                                                        {"graph", &graph}, {"pinned_frames", &pinned_frames}, {"db_gemm_min_queries", &db_gemm_min_queries},
-                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}, {"interleave", &interleave}, {"host_global", &host_global}, {"det_fuse", &det_fuse}, {"match_screen_bf16", &match_screen_bf16}, {"tri_screen_bf16", &tri_screen_bf16}, {"desc_bf16x3", &desc_bf16x3}, {"global_bf16x3", &global_bf16x3}};
+                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}, {"interleave", &interleave}, {"host_global", &host_global}, {"det_fuse", &det_fuse}, {"match_screen_bf16", &match_screen_bf16}, {"tri_screen_bf16", &tri_screen_bf16}, {"desc_bf16x3", &desc_bf16x3}, {"global_bf16x3", &global_bf16x3}, {"join_fused_branch", &join_fused_branch}};
     for (const auto& t : tab) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -408,8 +408,8 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
     // lowered: such calls take the single-frame kernels by default), a sampler that runs WHILE that branch is still going has read stale
     // tap rows -- every few calls with the split-bf16 forms of k_block_fused8, once in 3 000 calls with its exact layer-8 form
     // (tools/dev/latency_repro.py); never when the branch is joined first.  Until that is understood the branch is joined before the
-    // sampler in exactly that case.
-    const bool early_join = caller_joins && branch_fused_used;
+    // sampler in exactly that case (engine option join_fused_branch = 0: not -- for whoever takes the issue up).
+    const bool early_join = caller_joins && branch_fused_used && e->opt.join_fused_branch;
     branch_fused_used = false;
     if (cfg.global && fork_early && caller_joins && !early_join) join_pending = true;
     else if (cfg.global && fork && defer) join_pending = true;

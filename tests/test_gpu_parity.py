@@ -766,6 +766,7 @@ def test_split_bf16_fused_forms_on_calls_of_few_frames(engine, oracle_model, eng
     anything left over from the previous call is wrong for this one), every frame of every call against the oracle."""
     from hfnet_slam_amd import capi
     engine_options({"global_bf16x3": 1, "fuse_min_wgs": 0})
+    assert engine.get_option("join_fused_branch") == 1         # (0 reproduces the issue: tools/dev/latency_repro.py ... join_fused_branch=0)
     w, h, nf, nl = 752, 480, 1000, 4
     sets = [np.stack([synth_image(h, w, 8100 + 10 * s + i, "natural") for i in range(B)]) for s in range(2)]
     refs = [[oracle_model.extract(im[i], nf, 0.01, nl, 1.2) for i in range(B)] for im in sets]

@@ -1,5 +1,5 @@
 # one extractor, many calls on two alternating sets of frames, every frame of every call against the oracle (needs the GPU):
-#   python tools/dev/latency_repro.py B option=value ...      e.g.  4 global_bf16x3=1 fuse_min_wgs=0   (NOTEBOOK.md R4.8)
+#   python tools/dev/latency_repro.py B option=value ...      e.g.  4 global_bf16x3=1 fuse_min_wgs=0 join_fused_branch=0   (NOTEBOOK.md R4.8)
 import sys, numpy as np, os, tempfile
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 from conftest import synth_image
