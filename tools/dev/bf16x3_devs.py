@@ -1,3 +1,5 @@
+# deviation of the split-bf16 options from the oracle over network widths, global dimensions and image sizes (needs the GPU):
+#   OPT_D=1 OPT_G=1 python tools/dev/bf16x3_devs.py
 import sys, numpy as np
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 from conftest import synth_image
