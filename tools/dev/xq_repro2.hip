@@ -63,6 +63,28 @@ __global__ __launch_bounds__(256) void k_sums(const float* rows, int n, unsigned
     tree_x4(sq, lane, s2);
     bool wrong = false;
     for (int t = 0; t < 4; ++t) wrong = wrong || __float_as_int(s1[t]) != __float_as_int(s2[t]);
+    // ... and the sampler's double-precision tail (cv::normalize: squares and tree in f64, sqrt, reciprocal), twice
+    auto tail = [&](const f32x4 (&q)[4]) -> float {
+        f32x4 o;
+        const float i0 = 1.0f / sqrtf(fmaxf(s1[0], 1e-12f)), i1 = 1.0f / sqrtf(fmaxf(s1[1], 1e-12f)), i2 = 1.0f / sqrtf(fmaxf(s1[2], 1e-12f)), i3 = 1.0f / sqrtf(fmaxf(s1[3], 1e-12f));
+        for (int j = 0; j < 4; ++j) o[j] = 0.3f * q[0][j] * i0 + 0.2f * q[1][j] * i1 + 0.4f * q[2][j] * i2 + 0.1f * q[3][j] * i3;
+        double pd[4];
+        for (int j = 0; j < 4; ++j) pd[j] = (double)o[j] * (double)o[j];
+        const bool b5 = lane & 32, b4 = lane & 16;
+        double v2[2];
+        for (int kk = 0; kk < 2; ++kk) v2[kk] = (b5 ? pd[2 + kk] : pd[kk]) + __shfl_xor(b5 ? pd[kk] : pd[2 + kk], 32, 64);
+        double v = (b4 ? v2[1] : v2[0]) + __shfl_xor(b4 ? v2[0] : v2[1], 16, 64);
+        for (int off = 8; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+        v = v + __shfl_xor(v, 32, 64);
+        v = v + __shfl_xor(v, 16, 64);
+        const double nrm = sqrt(v);
+        const float sc = (float)(nrm > 2.2e-16 ? 1.0 / nrm : 0.0);
+        return o[0] * sc + o[1] * sc + o[2] * sc + o[3] * sc;
+    };
+    const float t1 = tail(sq);
+    for (int t = 0; t < 4; ++t) for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(sq[t][j]));
+    const float t2 = tail(sq);
+    if (__ballot(__float_as_int(t1) != __float_as_int(t2)) && lane == 0) atomicAdd(bad + 1, 1000000u);
     // (and against the value every lane can compute alone: the four sums are equal by construction only for equal rows -- so just the repeat test)
     if (__ballot(wrong) && lane == 0) atomicAdd(bad + 1, 1u);
 }
