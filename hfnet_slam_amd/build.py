@@ -20,8 +20,14 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libhfnet_hip.so")
 SOURCES = ["weights.cpp", "kernels_conv.hip", "kernels_block.hip", "kernels_detect.hip", "kernels_global.hip", "kernels_match.hip", "kernels_tail.hip", "engine.hip", "api_extract.hip", "api_match.hip", "api_db.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", "engine.hpp", "device_util.hpp", os.path.join("..", "..", "include", "hfnet_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
-         "-Wno-unused-result", "-x", "hip"]
+# -fno-slp-vectorize: left on, clang packs neighbouring scalar f32 multiplies / adds into v_pk_mul_f32 / v_pk_add_f32, and on gfx950 those
+# returned WRONG values in lanes 48-63 of a wave that shared its SIMD with the split-bf16 fused-block kernels (NOTEBOOK.md R4.8:
+# tools/dev/xq_repro3.hip reproduces it outside the engine; without the packed instructions 8 000 iterations are clean).  Same bits
+# otherwise (the packed forms are two IEEE operations), and beside MFMAs they are slower than two plain ones anyway.
+# -target-feature -packed-fp32-ops takes the packed forms away from instruction selection altogether (explicit f32x2 / f32x4 arithmetic would
+# still become v_pk_*); the host pass of the compile answers "not a recognized feature for this target (ignoring feature)": filtered below.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
+         "-fPIC", "-Wall", "-Wno-unused-result", "-x", "hip"]
 
 
 def _hipcc() -> str:
@@ -79,7 +85,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout)
-        return r.stdout
+        return "\n".join(l for l in r.stdout.splitlines() if "'-packed-fp32-ops' is not a recognized feature" not in l)
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as ex:
         for out in ex.map(run, jobs):

@@ -404,11 +404,10 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         HF_TRY(forward_global(stream_global, g_next, 1 << 20, nullptr));   // whatever is left of the branch
         HF_HIP(hipEventRecord(ev_join, stream_global));
     }
-    // OPEN ISSUE (NOTEBOOK.md R4.8): with fused-block kernels in the global branch of a call of <= 4 frames (only reachable with fuse_min_wgs
-    // lowered: such calls take the single-frame kernels by default), a sampler that runs WHILE that branch is still going has read stale
-    // tap rows -- every few calls with the split-bf16 forms of k_block_fused8, once in 3 000 calls with its exact layer-8 form
-    // (tools/dev/latency_repro.py); never when the branch is joined first.  Until that is understood the branch is joined before the
-    // sampler in exactly that case (engine option join_fused_branch = 0: not -- for whoever takes the issue up).
+    // NOTEBOOK.md R4.8: with fused-block kernels in the global branch of a call of <= 4 frames (fuse_min_wgs lowered) the sampler, which runs while
+    // that branch is still going, returned wrong rows -- its compiler-packed v_pk_mul_f32 / v_pk_add_f32 gave wrong values in lanes 48-63
+    // beside those kernels.  The library is built without packed f32 instructions now (build.py); join_fused_branch = 1 brings back the stop-gap
+    // of joining the branch first.
     const bool early_join = caller_joins && branch_fused_used && e->opt.join_fused_branch;
     branch_fused_used = false;
     if (cfg.global && fork_early && caller_joins && !early_join) join_pending = true;

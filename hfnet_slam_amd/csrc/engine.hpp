@@ -109,7 +109,8 @@ struct Options {
     int tail_fuse = 4;        // calls of up to this many frames run layers 8-18 with the single-frame kernels (0: never)
     int global_bf16x3 = 0;    // 1: the 1x1 convolutions of layers 9-18 (fused blocks 9-14 of calls of more than four frames; the three-launch blocks
                               //    15-18) on split-bf16 operands: the global descriptor within the stated tolerance of the exact path (include/hfnet_hip.h)
-    int join_fused_branch = 1;   // 1: a global branch that contains fused-block kernels is joined before the sampler of a few-frame call (NOTEBOOK.md R4.8)
+    int join_fused_branch = 0;   // 1: a global branch that contains fused-block kernels is joined before the sampler of a few-frame call (the stop-gap of
+                                 // NOTEBOOK.md R4.8 before its cause -- packed f32 instructions, now compiled out -- was found; kept as a diagnostic)
     int desc_bf16x3 = 0;      // 1: the sparse descriptor head (3x3 + 1x1 at the distinct tap cells) on split-bf16 operands: descriptors within the stated
                               //    tolerance of the exact path instead of its bits; keypoints, scores and every index stay exact (include/hfnet_hip.h)
     int copy_threads = 64;    // helper threads of the host-pointer batch pipeline's staging copies (>= 64: chosen from the core count)

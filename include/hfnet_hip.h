@@ -122,8 +122,8 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *                       descriptor (measured <= 6e-6 through the ten blocks; a model with a D-dimensional global descriptor: 2e-5 *
  *                       sqrt(4096 / D) -- the components of a unit vector scale that way).  Layer 8, the NetVLAD head and the dimensionality
  *                       reduction stay exact.
- *   "join_fused_branch" (1) calls of <= 4 frames whose global branch contains fused-block kernels (only with "fuse_min_wgs" lowered): the
- *                       branch is joined before the sampler (NOTEBOOK.md R4.8, an open issue: with 0 the sampler has returned stale rows)
+ *   "join_fused_branch" (0) diagnostic: calls of <= 4 frames whose global branch contains fused-block kernels (only with "fuse_min_wgs"
+ *                       lowered) join the branch before the sampler instead of after it (NOTEBOOK.md R4.8)
  * The matcher and the database are exact FOR THE DESCRIPTORS THEY ARE GIVEN in either mode. */
 int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value);
 int hfnet_engine_get_option(hfnet_engine* e, const char* name, int* value);

@@ -67,3 +67,18 @@ def test_product_never_imports_the_oracle():
     timed = bench[bench.index("    t0 = time.perf_counter()\n    for _ in range(args.steps):"):bench.index("    elapsed = max_over_ranks(")]
     assert "oracle" not in timed and "verify" not in timed
     assert "from oracle" not in open(os.path.join(ROOT, "hfnet_slam_amd", "shard.py")).read()
+
+
+def test_library_is_built_without_packed_f32_instructions():
+    """gfx950: v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 returned wrong values in lanes 48-63 of a wave that shared its SIMD with the split-bf16
+    fused-block kernels (NOTEBOOK.md R4.8; tools/dev/xq_repro3.hip) -- clang forms them from neighbouring scalar operations (SLP) and from f32x2 /
+    f32x4 arithmetic.  The build flags must keep them out: two of the sources that had them, compiled to assembly with those flags."""
+    import subprocess
+    from hfnet_slam_amd import build
+    assert "-fno-slp-vectorize" in build.FLAGS and "-packed-fp32-ops" in build.FLAGS
+    for src in ("kernels_detect.hip", "kernels_global.hip"):
+        r = subprocess.run([build._hipcc()] + build.FLAGS + ["-S", "--cuda-device-only", os.path.join(build.CSRC, src), "-o", "-"],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600)
+        assert r.returncode == 0 and "s_endpgm" in r.stdout
+        packed = [l.strip() for l in r.stdout.splitlines() if re.search(r"\bv_pk_(mul|add|fma)_f32\b", l)]
+        assert not packed, (src, packed[:3])

@@ -761,12 +761,12 @@ def test_split_bf16_options_on_ragged_geometries_and_other_widths(engine, oracle
 @pytest.mark.parametrize("B", [1, 4])
 def test_split_bf16_fused_forms_on_calls_of_few_frames(engine, oracle_model, engine_options, B):
     """NOTEBOOK.md R4.8: with fuse_min_wgs lowered the split-bf16 forms of the fused blocks also run in calls of <= 4 frames, whose sampler
-    normally overlaps the global branch; in that combination the sampler read stale tap rows (wrong descriptors in a few rows per call, or
-    a GPU memory fault) until the branch was joined first.  One extractor, repeated calls on two alternating sets of frames (so that
-    anything left over from the previous call is wrong for this one), every frame of every call against the oracle."""
+    overlaps the global branch.  Built with clang's default SLP packing, k_sample's v_pk_mul_f32 / v_pk_add_f32 then returned wrong values in
+    lanes 48-63 (wrong descriptors in a few rows of nearly every call, or a GPU memory fault); the library is compiled without packed f32
+    instructions since (hfnet_slam_amd/build.py, tests/test_abi.py).  One extractor, repeated calls on two alternating sets of frames, every
+    frame of every call against the oracle."""
     from hfnet_slam_amd import capi
-    engine_options({"global_bf16x3": 1, "fuse_min_wgs": 0})
-    assert engine.get_option("join_fused_branch") == 1         # (0 reproduces the issue: tools/dev/latency_repro.py ... join_fused_branch=0)
+    engine_options({"global_bf16x3": 1, "fuse_min_wgs": 0, "join_fused_branch": 0})
     w, h, nf, nl = 752, 480, 1000, 4
     sets = [np.stack([synth_image(h, w, 8100 + 10 * s + i, "natural") for i in range(B)]) for s in range(2)]
     refs = [[oracle_model.extract(im[i], nf, 0.01, nl, 1.2) for i in range(B)] for im in sets]

@@ -1,0 +1,150 @@
+// xq_repro3.hip -- NOTEBOOK.md R4.8 outside the engine, third attempt: the REAL tail of the descriptor chain on stream A -- launch_tap_cells (k_tap_mark,
+// k_tap_compact) -> a producer that writes the tap rows of this iteration -> launch_sample (k_sample) -- on two alternating keypoint sets, with the
+// REAL split-bf16 fused blocks (layers 9-14, 4 frames) back to back on stream B.  The sampler's output of every iteration is compared with the
+// output of the same set computed with stream B idle.
+//   build: BB_MAIN=tools/dev/xq_repro3.hip BB_OUT=xq_repro3 BB_DEFS="hfnet_slam_amd/csrc/kernels_conv.hip hfnet_slam_amd/csrc/kernels_detect.hip" bash tools/dev/build_block_bench.sh
+//   run (GPU box): tools/dev/xq_repro3 <iterations> <burst> <bf16x3 0|1>
+#include "../../hfnet_slam_amd/csrc/kernels.hpp"
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+using namespace hfnet;
+namespace hfnet { void set_error(const char*, ...) {} const char* get_error() { return ""; } }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+static float* dev_rand(size_t n, float scale) {
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = scale * ((float)rand() / RAND_MAX - 0.5f);
+    float* d; hipMalloc(&d, n * 4); hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice); return d;
+}
+// the tap rows of one iteration: row r of image im = f(cell of the row, set): depends on the CELL, so that a row number from the wrong set reads the wrong data
+__global__ __launch_bounds__(256) void k_rows(float* rows, const int* cells, const int* n_rows, long long slot_rows, int set) {
+    const int im = blockIdx.y, r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n_rows[im]) return;
+    const int cell = cells[(long long)im * slot_rows + r];
+    f32x4 v;
+    for (int j = 0; j < 4; ++j) v[j] = 0.01f * (float)((cell * 31 + lane * 4 + j + set * 17) % 997) - 4.0f;
+    *(f32x4*)(rows + ((long long)im * slot_rows + r) * 256 + lane * 4) = v;
+}
+__global__ __launch_bounds__(256) void k_cmp_rows(const float* a, const float* b, const int* n_rows, long long slot_rows, unsigned* bad) {
+    const int im = blockIdx.y, r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n_rows[im]) return;
+    const long long o = ((long long)im * slot_rows + r) * 256 + lane * 4;
+    for (int j = 0; j < 4; ++j) if (__float_as_int(a[o + j]) != __float_as_int(b[o + j])) atomicAdd(bad, 1u);
+}
+__global__ void k_cmp(const float* a, const float* b, long long n, unsigned* bad) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && __float_as_int(a[i]) != __float_as_int(b[i])) atomicAdd(bad, 1u);
+}
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 1000, burst = argc > 2 ? atoi(argv[2]) : 12, bf = argc > 3 ? atoi(argv[3]) : 1;
+    const int frames = 4, NL = 4, images = NL * frames, KMAX = 1000;
+    const int lw[4] = {752, 624, 520, 432}, lh[4] = {480, 400, 328, 272}, budget[4] = {322, 268, 224, 186};
+    // ---- geometry of the sampler: H, W score map; Ho, Wo cell grid
+    Geom g{}; g.n_levels = NL; g.batch = frames;
+    long long cell_stride = 0;
+    for (int l = 0; l < NL; ++l) { g.lv[l].H = lh[l]; g.lv[l].W = lw[l]; g.lv[l].Ho = lh[l] / 8; g.lv[l].Wo = lw[l] / 8; cell_stride = std::max(cell_stride, (long long)(lh[l] / 8) * (lw[l] / 8)); }
+    // ---- two keypoint sets (integer level coordinates, at least 5 apart is not needed here), the per-level budget of keypoints each
+    std::vector<hfnet_keypoint> hk[2];
+    std::vector<int> hn(images);
+    for (int s = 0; s < 2; ++s) {
+        hk[s].assign((size_t)images * KMAX, hfnet_keypoint{0, 0, 0, 0});
+        srand(1234 + s);
+        for (int l = 0; l < NL; ++l) for (int f = 0; f < frames; ++f) for (int i = 0; i < budget[l]; ++i) {
+            hfnet_keypoint& k = hk[s][((size_t)(l * frames + f)) * KMAX + i];
+            k.x = (float)(rand() % lw[l]); k.y = (float)(rand() % lh[l]); k.response = 0.5f; k.octave = 0;
+        }
+    }
+    for (int l = 0; l < NL; ++l) for (int f = 0; f < frames; ++f) hn[l * frames + f] = budget[l];
+    hfnet_keypoint* dk[2]; int* dn;
+    for (int s = 0; s < 2; ++s) { CK(hipMalloc(&dk[s], hk[s].size() * sizeof(hfnet_keypoint))); CK(hipMemcpy(dk[s], hk[s].data(), hk[s].size() * sizeof(hfnet_keypoint), hipMemcpyHostToDevice)); }
+    CK(hipMalloc(&dn, images * 4)); CK(hipMemcpy(dn, hn.data(), images * 4, hipMemcpyHostToDevice));
+    unsigned char* flags; int *cell_row, *cells, *n_rows; float *rows, *out, *ref[2]; hfnet_keypoint* kout; int *nf, *nl; unsigned* bad;
+    const long long slot_rows = 4ll * KMAX;
+    CK(hipMalloc(&flags, images * cell_stride)); CK(hipMemset(flags, 0, images * cell_stride));
+    CK(hipMalloc(&cell_row, images * cell_stride * 4)); CK(hipMalloc(&cells, images * slot_rows * 4)); CK(hipMalloc(&n_rows, images * 4));
+    CK(hipMalloc(&rows, images * slot_rows * 256 * 4)); CK(hipMemset(rows, 0, images * slot_rows * 256 * 4));
+    const long long out_n = (long long)frames * KMAX * 256;
+    CK(hipMalloc(&out, out_n * 4)); CK(hipMalloc(&ref[0], out_n * 4)); CK(hipMalloc(&ref[1], out_n * 4));
+    CK(hipMalloc(&kout, frames * KMAX * sizeof(hfnet_keypoint))); CK(hipMalloc(&nf, frames * 4)); CK(hipMalloc(&nl, images * 4)); CK(hipMalloc(&bad, 4)); CK(hipMemset(bad, 0, 4));
+    // ---- the neighbours: layers 9 .. 14 as split-bf16 (or exact) fused blocks on 4 frames of 30 x 47
+    const int co[19] = {0, 24, 16, 24, 24, 24, 48, 96, 48, 48, 48, 48, 72, 72, 72, 120, 120, 120, 240};
+    BlockPack blk[6]; Geom gb{}; gb.n_levels = 1; gb.batch = frames;
+    gb.lv[0].H = 30; gb.lv[0].W = 47; gb.lv[0].Ho = 30; gb.lv[0].Wo = 47; gb.lv[0].pt = 1; gb.lv[0].pl = 1;
+    float* X = dev_rand((size_t)frames * 30 * 47 * 72, 2.0f); float* Y; CK(hipMalloc(&Y, (size_t)frames * 30 * 47 * 72 * 4));
+    hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    for (int q = 0; q < 6; ++q) {
+        const int L = 9 + q; BlockPack& b = blk[q]; b = BlockPack{};
+        b.cin = co[L - 1]; b.expand = b.cin * 6; b.stride = 1; b.cout = co[L]; b.residual = b.cin == b.cout; b.has_expand = 1;
+        b.ex.taps = 1; b.ex.cin = b.cin; b.ex.n = b.expand; b.ex.nt_total = (b.expand + 31) / 32;
+        b.ex.w = dev_rand((size_t)b.cin / 8 * b.ex.nt_total * 256, 0.2f); b.ex.bias = dev_rand(b.ex.nt_total * 32, 0.2f);
+        b.dw.c = b.expand; b.dw.w = dev_rand(9 * b.expand, 0.3f); b.dw.bias = dev_rand(b.expand, 0.2f);
+        b.pr.taps = 1; b.pr.cin = b.expand; b.pr.n = b.cout; b.pr.nt_total = (b.cout + 31) / 32;
+        b.pr.w = dev_rand((size_t)b.expand / 8 * b.pr.nt_total * 256, 0.1f); b.pr.bias = dev_rand(b.pr.nt_total * 32, 0.2f);
+        b.ex16.cin = b.cin; b.ex16.n = b.expand; b.ex16.n16 = (b.expand + 15) / 16; b.ex16.w = dev_rand((size_t)((b.cin + 15) / 16) * b.ex16.n16 * 256, 0.2f);
+        b.pr16.cin = b.expand; b.pr16.n = b.cout; b.pr16.n16 = (b.cout + 15) / 16; b.pr16.w = dev_rand((size_t)((b.expand + 15) / 16) * b.pr16.n16 * 256, 0.1f);
+        void *e, *p; CK(hipMalloc(&e, bf16x3_pack_bytes(b.ex))); CK(hipMalloc(&p, bf16x3_pack_bytes(b.pr)));
+        CK(launch_repack_bf16x3(b.ex, e, sb)); CK(launch_repack_bf16x3(b.pr, p, sb)); b.ex_bf = e; b.pr_bf = p;
+    }
+    CK(hipDeviceSynchronize());
+    SampleArgs sa_{}; memset(&sa_, 0, sizeof sa_);
+    sa_.desc_map = rows; sa_.cell_row = cell_row; sa_.cell_stride = cell_stride; sa_.sparse = 1; sa_.n_in = dn; sa_.kps_stride = KMAX;
+    sa_.kps_out = kout; sa_.n_out_frame = nf; sa_.n_out_level = nl; sa_.out_frame_stride = KMAX; sa_.set_octave = 1;
+    for (int l = 0; l < NL; ++l) sa_.scale_factor[l] = 1.0f;
+    hfnet_keypoint* dkc; if (hipMalloc(&dkc, hk[0].size() * sizeof(hfnet_keypoint)) != hipSuccess) return 1;
+    const bool const_args = getenv("XQ_CONST_ARGS") != nullptr;
+    auto chain = [&](int set, float* dst) -> hipError_t {
+        if (const_args) { hipError_t e0 = hipMemcpyAsync(dkc, dk[set], hk[0].size() * sizeof(hfnet_keypoint), hipMemcpyDeviceToDevice, sa); if (e0 != hipSuccess) return e0; }
+        hfnet_keypoint* kset = const_args ? dkc : dk[set];
+        hipError_t e = launch_tap_cells(kset, dn, KMAX, flags, cell_row, cells, n_rows, cell_stride, g, sa);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_rows, dim3((unsigned)(slot_rows / 4), images), dim3(256), 0, sa, rows, cells, n_rows, slot_rows, set);
+        SampleArgs a = sa_; a.kps_in = kset; a.desc_out = dst;
+        return launch_sample(a, g, sa);
+    };
+    int *rcr[2], *rcl[2], *rnr[2]; float* rrows[2];
+    for (int s = 0; s < 2; ++s) {
+        CK(chain(s, ref[s])); CK(hipStreamSynchronize(sa));
+        CK(hipMalloc(&rcr[s], images * cell_stride * 4)); CK(hipMalloc(&rcl[s], images * slot_rows * 4)); CK(hipMalloc(&rnr[s], images * 4)); CK(hipMalloc(&rrows[s], images * slot_rows * 256 * 4));
+        CK(hipMemcpy(rcr[s], cell_row, images * cell_stride * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(rcl[s], cells, images * slot_rows * 4, hipMemcpyDeviceToDevice));
+        CK(hipMemcpy(rnr[s], n_rows, images * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(rrows[s], rows, images * slot_rows * 256 * 4, hipMemcpyDeviceToDevice));
+    }
+    unsigned* bad4; CK(hipMalloc(&bad4, 16)); CK(hipMemset(bad4, 0, 16));
+    hipEvent_t fork, join; CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    unsigned total = 0; int bad_iters = 0;
+    for (int it = 0; it < iters; ++it) {
+        const int set = it & 1;
+        CK(hipEventRecord(fork, sa)); CK(hipStreamWaitEvent(sb, fork, 0));
+        for (int q = 0; q < burst; ++q) CK(launch_block_fused(X, blk[q % 6], Y, gb, 4, sb, bf));
+        CK(chain(set, out));
+        hipLaunchKernelGGL(k_cmp, dim3((unsigned)((out_n + 255) / 256)), dim3(256), 0, sa, out, ref[set], out_n, bad);
+        hipLaunchKernelGGL(k_cmp, dim3((unsigned)((out_n + 255) / 256)), dim3(256), 0, sa, out, ref[1 - set], out_n, bad4 + 3);
+        hipLaunchKernelGGL(k_cmp, dim3((unsigned)((images * cell_stride + 255) / 256)), dim3(256), 0, sa, (const float*)cell_row, (const float*)rcr[set], images * cell_stride, bad4);
+        hipLaunchKernelGGL(k_cmp, dim3((unsigned)((images + 255) / 256)), dim3(256), 0, sa, (const float*)n_rows, (const float*)rnr[set], (long long)images, bad4 + 1);
+        hipLaunchKernelGGL(k_cmp_rows, dim3((unsigned)(slot_rows / 4), images), dim3(256), 0, sa, rows, rrows[set], n_rows, slot_rows, bad4 + 2);
+        CK(hipEventRecord(join, sb)); CK(hipStreamWaitEvent(sa, join, 0));
+        unsigned hb = 0;
+        CK(hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, sa)); CK(hipStreamSynchronize(sa));
+        if (hb != total) {
+            ++bad_iters; total = hb;
+            if (bad_iters <= 2 && getenv("XQ_SHOW")) {
+                std::vector<float> ho(out_n), hr(out_n);
+                CK(hipMemcpy(ho.data(), out, out_n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hr.data(), ref[set], out_n * 4, hipMemcpyDeviceToHost));
+                int shown = 0;
+                for (long long r = 0; r < (long long)frames * KMAX && shown < 12; ++r) {
+                    bool d = false; int lanes = 0;
+                    for (int c = 0; c < 256; ++c) if (ho[r * 256 + c] != hr[r * 256 + c]) { d = true; ++lanes; }
+                    if (d) { int first = -1, last = -1; for (int c = 0; c < 256; ++c) if (ho[r * 256 + c] != hr[r * 256 + c]) { if (first < 0) first = c; last = c; }
+                             printf("      differing floats %d .. %d (lanes %d .. %d): got there %g %g %g %g | %g %g %g %g\n", first, last, first / 4, last / 4, ho[r * 256 + first], ho[r * 256 + first + 1], ho[r * 256 + first + 2], ho[r * 256 + first + 3],
+                                    ho[r * 256 + last - 3], ho[r * 256 + last - 2], ho[r * 256 + last - 1], ho[r * 256 + last]); }
+                    if (d) { ++shown; printf("   iteration %d set %d: frame %lld keypoint %lld: %d of 256 floats differ; got %g %g %g %g (lane 0) / %g %g %g %g (lane 40), want %g %g %g %g\n", it, set, r / KMAX, r % KMAX, lanes,
+                                       ho[r * 256], ho[r * 256 + 1], ho[r * 256 + 2], ho[r * 256 + 3], ho[r * 256 + 160], ho[r * 256 + 161], ho[r * 256 + 162], ho[r * 256 + 163], hr[r * 256], hr[r * 256 + 1], hr[r * 256 + 2], hr[r * 256 + 3]); }
+                }
+            }
+        }
+    }
+    unsigned h4[4]; CK(hipMemcpy(h4, bad4, 16, hipMemcpyDeviceToHost));
+    printf("   checked by kernels on the same stream right behind the sampler: cell_row words wrong %u, n_rows wrong %u, used tap-row floats wrong %u; output floats that differ from the OTHER set's reference %u (of %lld per iteration)\n", h4[0], h4[1], h4[2], h4[3], out_n);
+    printf("%d iterations, burst %d fused blocks (bf16x3 %d) beside tap_cells -> rows -> sample: %d iterations with a wrong sampler output (%u floats)\n", iters, burst, bf, bad_iters, total);
+    return 0;
+}

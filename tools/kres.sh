@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-kernel register / LDS / occupancy summary of one .hip file (compiler view):  tools/kres.sh hfnet_slam_amd/csrc/kernels_block.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -x hip -c "$1" -o /tmp/kres.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -Xclang -target-feature -Xclang -packed-fp32-ops -fPIC -x hip -c "$1" -o /tmp/kres.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -v "is not a recognized feature" | python3 -c '
 import sys,re,subprocess
 cur={}
 rows=[]
