@@ -1,0 +1,98 @@
+// pk_f32_hazard.hip -- NOTEBOOK.md R4.8 in its smallest form: a victim kernel whose waves do nothing but v_pk_mul_f32 (written as inline assembly) and
+// compare both halves with plain v_mul_f32 of the same operands, lane by lane, on stream A; on stream B either nothing, a synthetic bf16-MFMA
+// kernel, or the real split-bf16 fused block of layer 13 (kernels_block.hip), launched back to back.  Reports mismatches per 16-lane group.
+//   build: /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -w -I hfnet_slam_amd/csrc -I include -x hip \
+//            tools/micro/pk_f32_hazard.hip hfnet_slam_amd/csrc/kernels_block.hip hfnet_slam_amd/csrc/kernels_conv.hip -o tools/micro/pk_f32_hazard
+//   run (GPU box): tools/micro/pk_f32_hazard <neighbour 0 none | 1 synthetic | 2 split-bf16 fused block | 3 exact fused block> [iterations] [0 packed with op_sel | 1 two plain multiplies | 2 packed without op_sel]
+#include "../../hfnet_slam_amd/csrc/kernels.hpp"
+#include <cstdlib>
+#include <vector>
+using namespace hfnet;
+namespace hfnet { void set_error(const char*, ...) {} const char* get_error() { return ""; } }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__global__ __launch_bounds__(256) void k_victim(const float* src, unsigned* bad /* [4] per 16-lane group */, int rounds, int plain) {
+    const int lane = threadIdx.x & 63;
+    const f32x2 b = {1.0009765625f, 0.9990234375f};
+    unsigned mism = 0;
+    for (int r = 0; r < rounds; ++r) {
+        // as in k_sample: the operands arrive by a load, the packed multiply is the first instruction behind the s_waitcnt
+        const float* ptr = src + (((blockIdx.x * 7 + r * 13) & 2047) * 2);      // (wave-uniform address: every lane loads the same pair)
+        f32x2 a, p; float lo, hi;
+        if (plain == 0)
+            asm volatile("global_load_dwordx2 %0, %2, off\n\ts_waitcnt vmcnt(0)\n\tv_pk_mul_f32 %1, %3, %0 op_sel:[0,1] op_sel_hi:[1,0]"
+                         : "=&v"(a), "=&v"(p) : "v"(ptr), "v"(b) : "memory");
+        else if (plain == 1)      // the same position taken by two plain multiplies
+        {   float a0, a1, p0, p1;
+            asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %4, off offset:4\n\ts_waitcnt vmcnt(0)\n\tv_mul_f32 %2, %5, %1\n\tv_mul_f32 %3, %6, %0"
+                         : "=&v"(a0), "=&v"(a1), "=&v"(p0), "=&v"(p1) : "v"(ptr), "v"(b[0]), "v"(b[1]) : "memory");
+            a[0] = a0; a[1] = a1; p[0] = p0; p[1] = p1; }
+        else                       // the packed multiply without operand selection (p.lo = b.lo * a.lo, p.hi = b.hi * a.hi), results swapped below
+            asm volatile("global_load_dwordx2 %0, %2, off\n\ts_waitcnt vmcnt(0)\n\tv_pk_mul_f32 %1, %3, %0"
+                         : "=&v"(a), "=&v"(p) : "v"(ptr), "v"(b) : "memory");
+        if (plain == 2) { float q0, q1; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q0) : "v"(b[0]), "v"(a[0])); asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q1) : "v"(b[1]), "v"(a[1]));
+                          mism += (__float_as_int(p[0]) != __float_as_int(q0)) + (__float_as_int(p[1]) != __float_as_int(q1)); continue; }
+        // (op_sel:[0,1] op_sel_hi:[1,0]: p.lo = b.lo * a.hi, p.hi = b.hi * a.lo -- the operand selection the compiler produced in k_sample)
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(lo) : "v"(b[0]), "v"(a[1]));
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(hi) : "v"(b[1]), "v"(a[0]));
+        mism += (__float_as_int(p[0]) != __float_as_int(lo)) + (__float_as_int(p[1]) != __float_as_int(hi));
+    }
+    if (mism) atomicAdd(&bad[lane >> 4], mism);
+}
+__global__ __launch_bounds__(64, 2) void k_busy(const float* src, float* dst, int steps) {          // synthetic neighbour: bf16 MFMA back to back + a little LDS
+    __shared__ float tile[32 * 36];
+    const int lane = threadIdx.x;
+    f32x16 acc[12];
+    for (int m = 0; m < 12; ++m) for (int i = 0; i < 16; ++i) acc[m][i] = (float)(m + i);
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(src[(blockIdx.x * 64 + lane + e) & 4095]); b[e] = (__bf16)(0.001f * (float)(e + 1)); }
+    for (int s = 0; s < steps; ++s) {
+        for (int m = 0; m < 12; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m], 0, 0, 0);
+        tile[(s & 31) * 36 + (lane & 31)] = acc[s % 12][0];
+        asm volatile("" ::: "memory");
+        a[0] = (__bf16)tile[((s + 1) & 31) * 36 + (lane & 31)];
+    }
+    float sum = 0.f;
+    for (int m = 0; m < 12; ++m) for (int i = 0; i < 16; ++i) sum += acc[m][i];
+    dst[blockIdx.x * 64 + lane] = sum;
+}
+static float* dev_rand(size_t n, float scale) {
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = scale * ((float)rand() / RAND_MAX - 0.5f);
+    float* d; hipMalloc(&d, n * 4); hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice); return d;
+}
+int main(int argc, char** argv) {
+    const int neighbour = argc > 1 ? atoi(argv[1]) : 2, iters = argc > 2 ? atoi(argv[2]) : 500, plain = argc > 3 ? atoi(argv[3]) : 0;
+    float* src = dev_rand(4096, 4.0f); float* bdst; unsigned* bad;
+    CK(hipMalloc(&bdst, 4096 * 64 * 4)); CK(hipMalloc(&bad, 16)); CK(hipMemset(bad, 0, 16));
+    hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    // layer 13: 72 -> 432 -> 72, 4 frames of 30 x 47
+    BlockPack b{}; b.cin = 72; b.expand = 432; b.stride = 1; b.cout = 72; b.residual = 1; b.has_expand = 1;
+    b.ex.taps = 1; b.ex.cin = 72; b.ex.n = 432; b.ex.nt_total = 14; b.ex.w = dev_rand((size_t)9 * 14 * 256, 0.2f); b.ex.bias = dev_rand(14 * 32, 0.2f);
+    b.dw.c = 432; b.dw.w = dev_rand(9 * 432, 0.3f); b.dw.bias = dev_rand(432, 0.2f);
+    b.pr.taps = 1; b.pr.cin = 432; b.pr.n = 72; b.pr.nt_total = 3; b.pr.w = dev_rand((size_t)54 * 3 * 256, 0.1f); b.pr.bias = dev_rand(3 * 32, 0.2f);
+    b.ex16.cin = 72; b.ex16.n = 432; b.ex16.n16 = 27; b.ex16.w = dev_rand((size_t)5 * 27 * 256, 0.2f);
+    b.pr16.cin = 432; b.pr16.n = 72; b.pr16.n16 = 5; b.pr16.w = dev_rand((size_t)27 * 5 * 256, 0.1f);
+    void *e, *p; CK(hipMalloc(&e, bf16x3_pack_bytes(b.ex))); CK(hipMalloc(&p, bf16x3_pack_bytes(b.pr)));
+    CK(launch_repack_bf16x3(b.ex, e, sb)); CK(launch_repack_bf16x3(b.pr, p, sb)); b.ex_bf = e; b.pr_bf = p;
+    Geom g{}; g.n_levels = 1; g.batch = 4; g.lv[0].H = 30; g.lv[0].W = 47; g.lv[0].Ho = 30; g.lv[0].Wo = 47; g.lv[0].pt = 1; g.lv[0].pl = 1;
+    float* X = dev_rand((size_t)4 * 30 * 47 * 72, 2.0f); float* Y; CK(hipMalloc(&Y, (size_t)4 * 30 * 47 * 72 * 4));
+    CK(hipDeviceSynchronize());
+    for (int it = 0; it < iters; ++it) {
+        for (int q = 0; q < 12; ++q) {
+            if (neighbour == 1) hipLaunchKernelGGL(k_busy, dim3(192), dim3(64), 0, sb, src, bdst, 60);
+            if (neighbour == 2) CK(launch_block_fused(X, b, Y, g, 4, sb, 1));
+            if (neighbour == 3) CK(launch_block_fused(X, b, Y, g, 4, sb, 0));
+        }
+        hipLaunchKernelGGL(k_victim, dim3(1024), dim3(256), 0, sa, src, bad, 400, plain);
+        CK(hipStreamSynchronize(sa)); CK(hipStreamSynchronize(sb));
+    }
+    unsigned h[4]; CK(hipMemcpy(h, bad, 16, hipMemcpyDeviceToHost));
+    const char* names[4] = {"nothing", "a synthetic bf16-MFMA kernel", "the split-bf16 fused block (layer 13)", "the exact fused block (layer 13)"};
+    printf("%s right behind the load's s_waitcnt, checked against v_mul_f32 later; %d launches of 262144 lanes x 400 products beside %s: mismatching halves in lanes 0-15 / 16-31 / 32-47 / 48-63: %u / %u / %u / %u\n",
+           plain == 1 ? "two v_mul_f32" : plain == 2 ? "v_pk_mul_f32 (no op_sel)" : "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0]", iters, names[neighbour & 3], h[0], h[1], h[2], h[3]);
+    return 0;
+}
