@@ -2,7 +2,12 @@
 // k_tap_compact) -> a producer that writes the tap rows of this iteration -> launch_sample (k_sample) -- on two alternating keypoint sets, with the
 // REAL split-bf16 fused blocks (layers 9-14, 4 frames) back to back on stream B.  The sampler's output of every iteration is compared with the
 // output of the same set computed with stream B idle.
-//   build: BB_MAIN=tools/dev/xq_repro3.hip BB_OUT=xq_repro3 BB_DEFS="hfnet_slam_amd/csrc/kernels_conv.hip hfnet_slam_amd/csrc/kernels_detect.hip" bash tools/dev/build_block_bench.sh
+//   build, as the library WAS built (clang packs f32 pairs: fails in 40-95 % of the iterations, floats 192-255 of a row = lanes 48-63):
+//     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -I hfnet_slam_amd/csrc -I include -x hip tools/dev/xq_repro3.hip \
+//       hfnet_slam_amd/csrc/kernels_block.hip hfnet_slam_amd/csrc/kernels_conv.hip hfnet_slam_amd/csrc/kernels_detect.hip -o tools/dev/xq_repro3
+//   build, as the library IS built (add -fno-slp-vectorize -Xclang -target-feature -Xclang -packed-fp32-ops: 0 of 8 000 iterations):
+//     BB_MAIN=tools/dev/xq_repro3.hip BB_OUT=xq_repro3 BB_DEFS="hfnet_slam_amd/csrc/kernels_conv.hip hfnet_slam_amd/csrc/kernels_detect.hip" bash tools/dev/build_block_bench.sh
+//   (-DXQ_EXP=n staged the sampler's intermediate values into its output while the cause was being looked for; those hooks are gone from k_sample)
 //   run (GPU box): tools/dev/xq_repro3 <iterations> <burst> <bf16x3 0|1>
 #include "../../hfnet_slam_amd/csrc/kernels.hpp"
 #include <cstdlib>
