@@ -3,7 +3,7 @@
 // kernel, or the real split-bf16 fused block of layer 13 (kernels_block.hip), launched back to back.  Reports mismatches per 16-lane group.
 //   build: /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -w -I hfnet_slam_amd/csrc -I include -x hip \
 //            tools/micro/pk_f32_hazard.hip hfnet_slam_amd/csrc/kernels_block.hip hfnet_slam_amd/csrc/kernels_conv.hip -o tools/micro/pk_f32_hazard
-//   run (GPU box): tools/micro/pk_f32_hazard <neighbour 0 none | 1 synthetic | 2 split-bf16 fused block | 3 exact fused block> [iterations] [0 packed with op_sel | 1 two plain multiplies | 2 packed without op_sel]
+//   run (GPU box): tools/micro/pk_f32_hazard <neighbour 0 none | 1 synthetic | 2 split-bf16 fused block | 3 exact fused block> [iterations] [0 packed with op_sel | 1 two plain multiplies | 2 packed without op_sel | 10 + n: s_nop n in between | 30 a v_nop in between | 31 loaded pair as src0 | 32 no load | 33 what the wrong value is]
 #include "../../hfnet_slam_amd/csrc/kernels.hpp"
 #include <cstdlib>
 #include <vector>
@@ -17,12 +17,23 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void k_victim(const float* src, unsigned* bad /* [4] per 16-lane group */, int rounds, int plain) {
     const int lane = threadIdx.x & 63;
     const f32x2 b = {1.0009765625f, 0.9990234375f};
-    unsigned mism = 0;
+    unsigned mism = 0, other = 0;
     for (int r = 0; r < rounds; ++r) {
         // as in k_sample: the operands arrive by a load, the packed multiply is the first instruction behind the s_waitcnt
         const float* ptr = src + (((blockIdx.x * 7 + r * 13) & 2047) * 2);      // (wave-uniform address: every lane loads the same pair)
         f32x2 a, p; float lo, hi;
-        if (plain == 0)
+        if (plain >= 10 && plain < 30) {      // wait states between the s_waitcnt and the packed multiply: how many make it right?
+#define PKW(N) asm volatile("global_load_dwordx2 %0, %2, off\n\ts_waitcnt vmcnt(0)\n\ts_nop " #N "\n\tv_pk_mul_f32 %1, %3, %0 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(a), "=&v"(p) : "v"(ptr), "v"(b) : "memory")
+            switch (plain) { case 10: PKW(0); break; case 11: PKW(1); break; case 12: PKW(2); break; case 13: PKW(3); break; case 15: PKW(5); break; default: PKW(7); break; }
+#undef PKW
+        } else if (plain == 30)                 // an independent vector instruction in between instead of an s_nop
+            asm volatile("global_load_dwordx2 %0, %2, off\n\ts_waitcnt vmcnt(0)\n\tv_nop\n\tv_pk_mul_f32 %1, %3, %0 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(a), "=&v"(p) : "v"(ptr), "v"(b) : "memory");
+        else if (plain == 31)                   // the loaded pair as the FIRST source
+            asm volatile("global_load_dwordx2 %0, %2, off\n\ts_waitcnt vmcnt(0)\n\tv_pk_mul_f32 %1, %0, %3 op_sel:[1,0] op_sel_hi:[0,1]" : "=&v"(a), "=&v"(p) : "v"(ptr), "v"(b) : "memory");
+        else if (plain == 32) {                 // no load: the pair comes from vector instructions
+            a[0] = src[(r * 5 + lane) & 4095] + 1.0f; a[1] = src[(r * 3 + lane + 11) & 4095] - 1.0f;
+            asm volatile("s_nop 4\n\tv_pk_mul_f32 %0, %2, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(p) : "v"(a), "v"(b));
+        } else if (plain == 0 || plain == 33)
             asm volatile("global_load_dwordx2 %0, %2, off\n\ts_waitcnt vmcnt(0)\n\tv_pk_mul_f32 %1, %3, %0 op_sel:[0,1] op_sel_hi:[1,0]"
                          : "=&v"(a), "=&v"(p) : "v"(ptr), "v"(b) : "memory");
         else if (plain == 1)      // the same position taken by two plain multiplies
@@ -38,9 +49,18 @@ __global__ __launch_bounds__(256) void k_victim(const float* src, unsigned* bad 
         // (op_sel:[0,1] op_sel_hi:[1,0]: p.lo = b.lo * a.hi, p.hi = b.hi * a.lo -- the operand selection the compiler produced in k_sample)
         asm volatile("v_mul_f32 %0, %1, %2" : "=v"(lo) : "v"(b[0]), "v"(a[1]));
         asm volatile("v_mul_f32 %0, %1, %2" : "=v"(hi) : "v"(b[1]), "v"(a[0]));
+        if (plain == 33) {                      // what IS the wrong value?  count the halves that equal the product WITHOUT the operand selection
+            float ulo, uhi;
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ulo) : "v"(b[0]), "v"(a[0]));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(uhi) : "v"(b[1]), "v"(a[1]));
+            if (__float_as_int(p[0]) != __float_as_int(lo)) { if (__float_as_int(p[0]) == __float_as_int(ulo)) ++mism; else ++other; }
+            if (__float_as_int(p[1]) != __float_as_int(hi)) { if (__float_as_int(p[1]) == __float_as_int(uhi)) ++mism; else ++other; }
+            continue;
+        }
         mism += (__float_as_int(p[0]) != __float_as_int(lo)) + (__float_as_int(p[1]) != __float_as_int(hi));
     }
     if (mism) atomicAdd(&bad[lane >> 4], mism);
+    if (other) atomicAdd(&bad[4 + (lane >> 4)], other);
 }
 __global__ __launch_bounds__(64, 2) void k_busy(const float* src, float* dst, int steps) {          // synthetic neighbour: bf16 MFMA back to back + a little LDS
     __shared__ float tile[32 * 36];
@@ -67,7 +87,7 @@ static float* dev_rand(size_t n, float scale) {
 int main(int argc, char** argv) {
     const int neighbour = argc > 1 ? atoi(argv[1]) : 2, iters = argc > 2 ? atoi(argv[2]) : 500, plain = argc > 3 ? atoi(argv[3]) : 0;
     float* src = dev_rand(4096, 4.0f); float* bdst; unsigned* bad;
-    CK(hipMalloc(&bdst, 4096 * 64 * 4)); CK(hipMalloc(&bad, 16)); CK(hipMemset(bad, 0, 16));
+    CK(hipMalloc(&bdst, 4096 * 64 * 4)); CK(hipMalloc(&bad, 32)); CK(hipMemset(bad, 0, 32));
     hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
     // layer 13: 72 -> 432 -> 72, 4 frames of 30 x 47
     BlockPack b{}; b.cin = 72; b.expand = 432; b.stride = 1; b.cout = 72; b.residual = 1; b.has_expand = 1;
@@ -90,9 +110,10 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(k_victim, dim3(1024), dim3(256), 0, sa, src, bad, 400, plain);
         CK(hipStreamSynchronize(sa)); CK(hipStreamSynchronize(sb));
     }
-    unsigned h[4]; CK(hipMemcpy(h, bad, 16, hipMemcpyDeviceToHost));
+    unsigned h[8]; CK(hipMemcpy(h, bad, 32, hipMemcpyDeviceToHost));
+    if (plain == 33) printf("   wrong halves in lanes 48-63 that equal the product WITHOUT operand selection: %u; that are something else: %u\n", h[3], h[7]);
     const char* names[4] = {"nothing", "a synthetic bf16-MFMA kernel", "the split-bf16 fused block (layer 13)", "the exact fused block (layer 13)"};
     printf("%s right behind the load's s_waitcnt, checked against v_mul_f32 later; %d launches of 262144 lanes x 400 products beside %s: mismatching halves in lanes 0-15 / 16-31 / 32-47 / 48-63: %u / %u / %u / %u\n",
-           plain == 1 ? "two v_mul_f32" : plain == 2 ? "v_pk_mul_f32 (no op_sel)" : "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0]", iters, names[neighbour & 3], h[0], h[1], h[2], h[3]);
+           plain == 1 ? "two v_mul_f32" : plain == 2 ? "v_pk_mul_f32 (no op_sel)" : plain >= 10 && plain < 30 ? "s_nop (mode - 10), then v_pk_mul_f32 with op_sel," : plain == 30 ? "v_nop, then v_pk_mul_f32 with op_sel," : plain == 31 ? "v_pk_mul_f32 with op_sel, loaded pair as src0," : plain == 32 ? "v_pk_mul_f32 with op_sel on a pair computed by vector instructions (no load)," : plain == 33 ? "v_pk_mul_f32 with op_sel " : "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0]", iters, names[neighbour & 3], h[0], h[1], h[2], h[3]);
     return 0;
 }
