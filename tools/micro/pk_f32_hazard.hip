@@ -3,7 +3,7 @@
 // kernel, or the real split-bf16 fused block of layer 13 (kernels_block.hip), launched back to back.  Reports mismatches per 16-lane group.
 //   build: /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -w -I hfnet_slam_amd/csrc -I include -x hip \
 //            tools/micro/pk_f32_hazard.hip hfnet_slam_amd/csrc/kernels_block.hip hfnet_slam_amd/csrc/kernels_conv.hip -o tools/micro/pk_f32_hazard
-//   run (GPU box): tools/micro/pk_f32_hazard <neighbour 0 none | 1 synthetic | 2 split-bf16 fused block | 3 exact fused block> [iterations] [0 packed with op_sel | 1 two plain multiplies | 2 packed without op_sel | 10 + n: s_nop n in between | 30 a v_nop in between | 31 loaded pair as src0 | 32 no load | 33 what the wrong value is]
+//   run (GPU box): tools/micro/pk_f32_hazard <neighbour 0 none | 1 synthetic | 2 split-bf16 fused block | 3 exact fused block | 4 synthetic + bf16 split | 5 + 224 registers> [iterations] [0 packed with op_sel | 1 two plain multiplies | 2 packed without op_sel | 10 + n: s_nop n in between | 30 a v_nop in between | 31 loaded pair as src0 | 32 no load | 33 what the wrong value is]
 #include "../../hfnet_slam_amd/csrc/kernels.hpp"
 #include <cstdlib>
 #include <vector>
@@ -62,21 +62,29 @@ __global__ __launch_bounds__(256) void k_victim(const float* src, unsigned* bad 
     if (mism) atomicAdd(&bad[lane >> 4], mism);
     if (other) atomicAdd(&bad[4 + (lane >> 4)], other);
 }
-__global__ __launch_bounds__(64, 2) void k_busy(const float* src, float* dst, int steps) {          // synthetic neighbour: bf16 MFMA back to back + a little LDS
+template <int KIND>    // 0: bf16 MFMA + a little LDS; 1: + the split of f32 values into bf16 pieces per step (v_cvt_pk_bf16_f32, subtract, convert again); 2: + 224 accumulator registers
+__global__ __launch_bounds__(64, 2) void k_busy(const float* src, float* dst, int steps) {
+    constexpr int NA = KIND == 2 ? 14 : 12;
     __shared__ float tile[32 * 36];
     const int lane = threadIdx.x;
-    f32x16 acc[12];
-    for (int m = 0; m < 12; ++m) for (int i = 0; i < 16; ++i) acc[m][i] = (float)(m + i);
-    bf16x8 a, b;
-    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(src[(blockIdx.x * 64 + lane + e) & 4095]); b[e] = (__bf16)(0.001f * (float)(e + 1)); }
+    f32x16 acc[NA];
+    for (int m = 0; m < NA; ++m) for (int i = 0; i < 16; ++i) acc[m][i] = (float)(m + i);
+    bf16x8 a, b, al;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(src[(blockIdx.x * 64 + lane + e) & 4095]); b[e] = (__bf16)(0.001f * (float)(e + 1)); al[e] = a[e]; }
+    for (int i = 0; i < 36; ++i) tile[(lane & 31) * 36 + i] = src[(lane * 36 + i) & 4095];
     for (int s = 0; s < steps; ++s) {
-        for (int m = 0; m < 12; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m], 0, 0, 0);
-        tile[(s & 31) * 36 + (lane & 31)] = acc[s % 12][0];
+        if (KIND >= 1) {
+            const float* pa = tile + (lane & 31) * 36 + (s & 3) * 8;
+            for (int e = 0; e < 8; ++e) { const float v = pa[e]; a[e] = (__bf16)v; al[e] = (__bf16)(v - (float)a[e]); }
+        }
+        for (int m = 0; m < NA; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m], 0, 0, 0);
+        if (KIND >= 1) for (int m = 0; m < NA; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b, acc[m], 0, 0, 0);
+        tile[(s & 31) * 36 + (lane & 31)] = acc[s % NA][0] * 1e-6f;
         asm volatile("" ::: "memory");
-        a[0] = (__bf16)tile[((s + 1) & 31) * 36 + (lane & 31)];
+        if (KIND == 0) a[0] = (__bf16)tile[((s + 1) & 31) * 36 + (lane & 31)];
     }
     float sum = 0.f;
-    for (int m = 0; m < 12; ++m) for (int i = 0; i < 16; ++i) sum += acc[m][i];
+    for (int m = 0; m < NA; ++m) for (int i = 0; i < 16; ++i) sum += acc[m][i];
     dst[blockIdx.x * 64 + lane] = sum;
 }
 static float* dev_rand(size_t n, float scale) {
@@ -103,7 +111,9 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     for (int it = 0; it < iters; ++it) {
         for (int q = 0; q < 12; ++q) {
-            if (neighbour == 1) hipLaunchKernelGGL(k_busy, dim3(192), dim3(64), 0, sb, src, bdst, 60);
+            if (neighbour == 1) hipLaunchKernelGGL(k_busy<0>, dim3(192), dim3(64), 0, sb, src, bdst, 60);
+            if (neighbour == 4) hipLaunchKernelGGL(k_busy<1>, dim3(192), dim3(64), 0, sb, src, bdst, 40);
+            if (neighbour == 5) hipLaunchKernelGGL(k_busy<2>, dim3(192), dim3(64), 0, sb, src, bdst, 40);
             if (neighbour == 2) CK(launch_block_fused(X, b, Y, g, 4, sb, 1));
             if (neighbour == 3) CK(launch_block_fused(X, b, Y, g, 4, sb, 0));
         }
@@ -112,8 +122,8 @@ int main(int argc, char** argv) {
     }
     unsigned h[8]; CK(hipMemcpy(h, bad, 32, hipMemcpyDeviceToHost));
     if (plain == 33) printf("   wrong halves in lanes 48-63 that equal the product WITHOUT operand selection: %u; that are something else: %u\n", h[3], h[7]);
-    const char* names[4] = {"nothing", "a synthetic bf16-MFMA kernel", "the split-bf16 fused block (layer 13)", "the exact fused block (layer 13)"};
+    const char* names[8] = {"nothing", "a synthetic bf16-MFMA kernel", "the split-bf16 fused block (layer 13)", "the exact fused block (layer 13)", "a synthetic bf16-MFMA kernel that splits f32 into bf16 pieces", "the same with 224 accumulator registers", "", ""};
     printf("%s right behind the load's s_waitcnt, checked against v_mul_f32 later; %d launches of 262144 lanes x 400 products beside %s: mismatching halves in lanes 0-15 / 16-31 / 32-47 / 48-63: %u / %u / %u / %u\n",
-           plain == 1 ? "two v_mul_f32" : plain == 2 ? "v_pk_mul_f32 (no op_sel)" : plain >= 10 && plain < 30 ? "s_nop (mode - 10), then v_pk_mul_f32 with op_sel," : plain == 30 ? "v_nop, then v_pk_mul_f32 with op_sel," : plain == 31 ? "v_pk_mul_f32 with op_sel, loaded pair as src0," : plain == 32 ? "v_pk_mul_f32 with op_sel on a pair computed by vector instructions (no load)," : plain == 33 ? "v_pk_mul_f32 with op_sel " : "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0]", iters, names[neighbour & 3], h[0], h[1], h[2], h[3]);
+           plain == 1 ? "two v_mul_f32" : plain == 2 ? "v_pk_mul_f32 (no op_sel)" : plain >= 10 && plain < 30 ? "s_nop (mode - 10), then v_pk_mul_f32 with op_sel," : plain == 30 ? "v_nop, then v_pk_mul_f32 with op_sel," : plain == 31 ? "v_pk_mul_f32 with op_sel, loaded pair as src0," : plain == 32 ? "v_pk_mul_f32 with op_sel on a pair computed by vector instructions (no load)," : plain == 33 ? "v_pk_mul_f32 with op_sel " : "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0]", iters, names[neighbour & 7], h[0], h[1], h[2], h[3]);
     return 0;
 }
