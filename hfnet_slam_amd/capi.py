@@ -25,9 +25,9 @@ SYMBOLS = [
     "hfnet_engine_create", "hfnet_engine_destroy", "hfnet_engine_info", "hfnet_engine_set_option", "hfnet_engine_get_option",
     "hfnet_engine_synchronize", "hfnet_engine_fence",
     "hfnet_model_create", "hfnet_model_destroy", "hfnet_model_is_valid", "hfnet_model_mode",
-    "hfnet_model_detect", "hfnet_model_detect_global", "hfnet_model_tap",
+    "hfnet_model_detect", "hfnet_model_detect_global", "hfnet_model_tap", "hfnet_model_device_faults",
     "hfnet_extractor_create", "hfnet_extractor_destroy", "hfnet_extractor_tables",
-    "hfnet_extractor_extract", "hfnet_extractor_extract_batch", "hfnet_extractor_last_timing", "hfnet_host_register", "hfnet_host_unregister",
+    "hfnet_extractor_extract", "hfnet_extractor_extract_batch", "hfnet_extractor_last_timing", "hfnet_extractor_device_faults", "hfnet_host_register", "hfnet_host_unregister",
     "hfnet_descriptor_distance", "hfnet_resampler", "hfnet_match_search_by_bow", "hfnet_match_search_by_bow_batch", "hfnet_match_search_for_triangulation", "hfnet_match_search_for_triangulation_batch",
     "hfnet_match_candidates", "hfnet_distinctive_descriptors",
     "hfnet_extractor_attach_store", "hfnet_store_create", "hfnet_store_destroy", "hfnet_store_put", "hfnet_store_put_extracted", "hfnet_store_rows", "hfnet_store_set_flags", "hfnet_store_search_by_bow",
@@ -285,6 +285,12 @@ class Model:
         st = lib().hfnet_model_detect_global(self.h, _p(x), _p(g))
         return st, g
 
+    def device_faults(self) -> int:
+        """HFNET_DEVICE_FAULT_* bits (0 in a healthy run): a kernel had to bound an index it read from device memory"""
+        b = C.c_uint(0)
+        _chk(lib().hfnet_model_device_faults(self.h, C.byref(b)))
+        return int(b.value)
+
     def tap(self, tap_id: int, shape=None) -> np.ndarray:
         cap = 1 << 26
         buf = np.empty((cap,), np.float32)
@@ -321,6 +327,12 @@ class Extractor:
         fpl, lw, lh = (np.zeros(self.n_levels, np.int32) for _ in range(3))
         _chk(lib().hfnet_extractor_tables(self.h, _p(sf), _p(fpl), _p(lw), _p(lh)))
         return sf, fpl, lw, lh
+
+    def device_faults(self) -> int:
+        """see Model.device_faults"""
+        b = C.c_uint(0)
+        _chk(lib().hfnet_extractor_device_faults(self.h, C.byref(b)))
+        return int(b.value)
 
     def last_timing(self):
         """host-side stamps (us since entry) of the last latency-path call: image staged, enqueued, local results seen,

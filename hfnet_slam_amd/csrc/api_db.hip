@@ -20,19 +20,20 @@ int hfnet_db_create(hfnet_engine* eh, int capacity, int dim, hfnet_db** out) {
     API_GUARD(eh, "engine");
     if (capacity < 1 || dim < 256 || dim % 256) { set_error("db: capacity >= 1 and dim a multiple of 256 required"); return HFNET_ERR_INVALID_ARG; }
     HF_HIP(hipSetDevice(eh->impl.device));
-    std::unique_ptr<hfnet_db> db(new hfnet_db());
+    struct Cleanup { void operator()(hfnet_db* d) const { hfnet_db_destroy(d); } };      // (frees whatever had been allocated when a later step fails)
+    std::unique_ptr<hfnet_db, Cleanup> db(new hfnet_db());
     db->eng = eh; db->capacity = capacity; db->dim = dim;
-    HF_HIP(hipMalloc((void**)&db->d_db, sizeof(float) * (size_t)capacity * dim));
-    HF_HIP(hipMalloc((void**)&db->d_occ, (size_t)capacity));
-    HF_HIP(hipMalloc((void**)&db->d_q, sizeof(float) * dim));
-    HF_HIP(hipMalloc((void**)&db->d_norm, sizeof(float) * capacity));
-    HF_HIP(hipMalloc(&db->d_hi, (size_t)2 * capacity * dim));
-    HF_HIP(hipMalloc((void**)&db->d_scores, sizeof(float) * capacity));
-    HF_HIP(hipMalloc((void**)&db->d_cand_score, sizeof(float) * capacity));
-    HF_HIP(hipMalloc((void**)&db->d_cand_slot, sizeof(int32_t) * capacity));
-    HF_HIP(hipMalloc((void**)&db->d_best, sizeof(float)));
-    HF_HIP(hipMalloc((void**)&db->d_n, sizeof(int)));
-    HF_HIP(hipMalloc((void**)&db->d_best_bits, sizeof(unsigned int) * 4 * (size_t)db_scan_workgroups(capacity)));   // per-wave partial maxima
+    HF_HIP(dev_malloc((void**)&db->d_db, sizeof(float) * (size_t)capacity * dim));
+    HF_HIP(dev_malloc((void**)&db->d_occ, (size_t)capacity));
+    HF_HIP(dev_malloc((void**)&db->d_q, sizeof(float) * dim));
+    HF_HIP(dev_malloc((void**)&db->d_norm, sizeof(float) * capacity));
+    HF_HIP(dev_malloc(&db->d_hi, (size_t)2 * capacity * dim));
+    HF_HIP(dev_malloc((void**)&db->d_scores, sizeof(float) * capacity));
+    HF_HIP(dev_malloc((void**)&db->d_cand_score, sizeof(float) * capacity));
+    HF_HIP(dev_malloc((void**)&db->d_cand_slot, sizeof(int32_t) * capacity));
+    HF_HIP(dev_malloc((void**)&db->d_best, sizeof(float)));
+    HF_HIP(dev_malloc((void**)&db->d_n, sizeof(int)));
+    HF_HIP(dev_malloc((void**)&db->d_best_bits, sizeof(unsigned int) * 4 * (size_t)db_scan_workgroups(capacity)));   // per-wave partial maxima
     {
         // on the stream the adds and scans use: it is non-blocking, i.e. NOT ordered with the null stream, and a hipMemset there
         // is not host-synchronous -- it could land after the first hfnet_db_add had set its occupancy byte
@@ -51,7 +52,7 @@ void hfnet_db_destroy(hfnet_db* db) {
     (void)hipSetDevice(db->eng->impl.device);
     for (void* p : {(void*)db->d_db, (void*)db->d_occ, (void*)db->d_q, (void*)db->d_scores, (void*)db->d_cand_score, (void*)db->d_cand_slot,
                     (void*)db->d_best, (void*)db->d_n, (void*)db->d_best_bits, (void*)db->d_norm, db->d_hi})
-        if (p) (void)hipFree(p);
+        if (p) (void)dev_free(p);
     delete db;
 }
 

@@ -80,12 +80,15 @@ int hfnet_model_detect(hfnet_model* m, const uint8_t* image, int row_stride, int
     sa.desc_map = net.sample_source(); sa.sparse = net.last_sparse ? 1 : 0; sa.cell_row = net.last_sparse && net.last_dedupe ? net.tap_cell_row : nullptr; sa.cell_stride = net.cell_stride; sa.kps_in = net.kps_level; sa.n_in = net.n_level; sa.kps_stride = net.cfg.max_keypoints;
     sa.kps_out = m->d_kps; sa.desc_out = m->d_desc; sa.n_out_frame = m->d_n; sa.n_out_level = nullptr;
     sa.out_frame_stride = m->max_keypoints; sa.scale_factor[0] = 1.0f; sa.set_octave = 0;
+    sa.fault = net.dev_fault;
     Geom gs = net.geom(7, 7, 0, 1);
     gs.lv[0].H = net.lp[0].Hc; gs.lv[0].W = net.lp[0].Wc; gs.lv[0].Ho = net.lp[0].h[7]; gs.lv[0].Wo = net.lp[0].w[7];
     gs.lv[0].in_off = net.pix_cell[0];
     HF_LAUNCH(&m->eng->impl, net.stream, "sample", launch_sample(sa, gs, net.stream));
     int n = 0;
+    unsigned int faults = 0;
     HF_HIP(hipMemcpyAsync(&n, m->d_n, sizeof(int), hipMemcpyDeviceToHost, net.stream));
+    if (net.dev_fault) HF_HIP(hipMemcpyAsync(&faults, net.dev_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, net.stream));
     if (m->mode == HFNET_IMAGE_TO_LOCAL_AND_GLOBAL) {
         HF_HIP(hipMemcpyAsync(aux, net.global_out, sizeof(float) * m->eng->impl.w.global_dim, hipMemcpyDeviceToHost, net.stream));
     } else if (m->mode == HFNET_IMAGE_TO_LOCAL_AND_INTERMEDIATE) {
@@ -95,6 +98,7 @@ int hfnet_model_detect(hfnet_model* m, const uint8_t* image, int row_stride, int
         HF_HIP(hipMemcpyAsync(aux, net.inter_logical, sizeof(float) * P * C, hipMemcpyDeviceToHost, net.stream));
     }
     HF_HIP(hipStreamSynchronize(net.stream));
+    if (faults) { set_error("device-side bound hit (fault bits 0x%x): inconsistent device state, results discarded", faults); return HFNET_ERR_DEVICE; }
     if (n > 0) {
         HF_HIP(hipMemcpyAsync(kps, m->d_kps, sizeof(hfnet_keypoint) * n, hipMemcpyDeviceToHost, net.stream));
         HF_HIP(hipMemcpyAsync(local_desc, m->d_desc, sizeof(float) * HFNET_DESC_DIM * n, hipMemcpyDeviceToHost, net.stream));
@@ -125,6 +129,13 @@ int hfnet_model_detect_global(hfnet_model* m, const float* intermediate, float* 
     HF_HIP(hipMemcpyAsync(global_desc, net.global_out, sizeof(float) * eng.w.global_dim, hipMemcpyDeviceToHost, net.stream));
     HF_HIP(hipStreamSynchronize(net.stream));
     return HFNET_OK;
+}
+
+int hfnet_model_device_faults(hfnet_model* m, unsigned int* bits) {
+    API_GUARD(m, "model"); API_GUARD(bits, "bits");
+    std::lock_guard<std::mutex> lk(m->mu);
+    HF_HIP(hipSetDevice(m->eng->impl.device));
+    return m->net.read_faults(bits);
 }
 
 int hfnet_model_tap(hfnet_model* m, int tap, float* out, size_t capacity, size_t* count) {
@@ -202,7 +213,8 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
             off += 256;
             HF_TRY(dalloc(x->allocs, &x->d_blk, res_bytes));
             HF_TRY(dalloc(x->allocs, &x->d_seq, 3));
-            HF_HIP(hipMemset(x->d_seq, 0, 3 * sizeof(int)));
+            HF_HIP(hipMemsetAsync(x->d_seq, 0, 3 * sizeof(int), x->net.stream));   // (the stream its users run on; a null-stream clear is not ordered with it)
+            HF_HIP(hipStreamSynchronize(x->net.stream));
             void* hp = nullptr;
             // (coherent: kernels write results and the call's number into this block while the host spins on it mid-graph)
             if (hipHostMalloc(&hp, off, hipHostMallocCoherent) == hipSuccess) { x->h_pin = (unsigned char*)hp; x->pinned_frames = pf; *(volatile int*)(x->h_pin + x->pin_flag) = 0; *(volatile int*)(x->h_pin + x->pin_flag + 128) = 0; }
@@ -220,7 +232,7 @@ void hfnet_extractor_destroy(hfnet_extractor* x) {
     if (x->net.stream) (void)hipStreamSynchronize(x->net.stream);
     if (x->net.stream_global) (void)hipStreamSynchronize(x->net.stream_global);
     for (auto& kv : x->graphs) (void)hipGraphExecDestroy(kv.second);
-    for (void* p : x->allocs) (void)hipFree(p);
+    for (void* p : x->allocs) (void)dev_free(p);
     if (x->h_pin) (void)hipHostFree(x->h_pin);
     for (int s = 0; s < 2; ++s) {
         if (x->pipe.h_in[s]) (void)hipHostFree(x->pipe.h_in[s]);
@@ -285,6 +297,7 @@ static int extract_chunk(hfnet_extractor* x, int nb, const uint8_t* d_images, in
     sa.desc_map = net.sample_source(); sa.sparse = net.last_sparse ? 1 : 0; sa.cell_row = net.last_sparse && net.last_dedupe ? net.tap_cell_row : nullptr; sa.cell_stride = net.cell_stride; sa.kps_in = net.kps_level; sa.n_in = net.n_level; sa.kps_stride = net.cfg.max_keypoints;
     sa.kps_out = d_kps; sa.desc_out = d_desc; sa.n_out_frame = d_n; sa.n_out_level = d_n_level;
     sa.out_frame_stride = x->n_features; sa.set_octave = 1;
+    sa.fault = net.dev_fault;
     for (int l = 0; l < x->n_levels; ++l) sa.scale_factor[l] = x->scale_factors[l];
     Geom gs = net.geom(7, 7, 0, x->n_levels);
     for (int l = 0; l < x->n_levels; ++l) {
@@ -397,8 +410,8 @@ int hfnet_host_unregister(void* ptr) {
     std::lock_guard<std::mutex> lk(g_reg_mu);
     auto it = g_registered.find((uintptr_t)ptr);
     if (it == g_registered.end()) { set_error("hfnet_host_unregister: not a registered range"); return HFNET_ERR_INVALID_ARG; }
+    HF_HIP(hipHostUnregister(ptr));        // (first: on failure the range is still page-locked AND still known here, a retry can succeed)
     g_registered.erase(it);
-    HF_HIP(hipHostUnregister(ptr));
     return HFNET_OK;
 }
 
@@ -463,6 +476,13 @@ static int extract_host_pipelined(hfnet_extractor* x, int f0, int n_frames, cons
                         host_range_registered(n_out + f0, nf_all * sizeof(int)) &&
                         (!global_desc || host_range_registered(global_desc + (size_t)f0 * G, nf_all * G * sizeof(float)));
     if (direct) {
+        // The copy engines read the caller's images and write the caller's result buffers: no error return may leave such a copy in
+        // flight (the caller is free to unregister / free the buffers once the call has returned).  Whatever way the loop is left,
+        // the three streams are drained first.
+        struct Quiesce {
+            hipStream_t a, b, c; bool armed = true;
+            ~Quiesce() { if (armed) { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); (void)hipStreamSynchronize(c); } }
+        } quiesce{p.s_up, st, p.s_down};
         auto finish = [&](int c) -> int {                    // chunk c's results are in the caller's buffers
             const int s = c & 1, c0 = f0 + c * x->max_batch, nb = std::min(x->max_batch, n_frames - c0);
             HF_HIP(hipEventSynchronize(p.ev_down[s]));
@@ -498,6 +518,7 @@ static int extract_host_pipelined(hfnet_extractor* x, int f0, int n_frames, cons
             if (c >= 1) HF_TRY(finish(c - 1));
         }
         HF_TRY(finish(n_chunks - 1));
+        quiesce.armed = false;                                // (every download has been waited for)
         return HFNET_OK;
     }
     auto drain = [&](int c) -> int {
@@ -673,6 +694,13 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
     }
     if (on_device) HF_HIP(eng.note_extract(st));
     return HFNET_OK;
+}
+
+int hfnet_extractor_device_faults(hfnet_extractor* x, unsigned int* bits) {
+    API_GUARD(x, "extractor"); API_GUARD(bits, "bits");
+    std::lock_guard<std::mutex> lk(x->mu);
+    HF_HIP(hipSetDevice(x->eng->impl.device));
+    return x->net.read_faults(bits);
 }
 
 int hfnet_extractor_last_timing(hfnet_extractor* x, double* us, int n) {

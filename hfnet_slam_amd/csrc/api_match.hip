@@ -211,12 +211,13 @@ int hfnet_store_create(hfnet_engine* eh, int n_sets, int max_rows, int dim, hfne
     API_GUARD(eh, "engine");
     if (n_sets < 1 || max_rows < 1 || dim <= 0 || dim % 64) { set_error("store: n_sets, max_rows >= 1 and dim a multiple of 64 required"); return HFNET_ERR_INVALID_ARG; }
     HF_HIP(hipSetDevice(eh->impl.device));
-    std::unique_ptr<hfnet_store> st(new hfnet_store);
+    struct Cleanup { void operator()(hfnet_store* d) const { hfnet_store_destroy(d); } };     // (frees whatever had been allocated when a later step fails)
+    std::unique_ptr<hfnet_store, Cleanup> st(new hfnet_store);
     st->eng = eh; st->n_sets = n_sets; st->max_rows = max_rows; st->dim = dim;
     st->rows.assign(n_sets, 0);
-    HF_HIP(hipMalloc((void**)&st->d_desc, sizeof(float) * (size_t)n_sets * max_rows * dim));
-    if (hipMalloc((void**)&st->d_rows, sizeof(int32_t) * n_sets) != hipSuccess) { (void)hipFree(st->d_desc); set_error("store: out of device memory"); return HFNET_ERR_DEVICE; }
-    if (hipMalloc((void**)&st->d_flags, (size_t)n_sets * max_rows) != hipSuccess) { (void)hipFree(st->d_desc); (void)hipFree(st->d_rows); set_error("store: out of device memory"); return HFNET_ERR_DEVICE; }
+    HF_HIP(dev_malloc((void**)&st->d_desc, sizeof(float) * (size_t)n_sets * max_rows * dim));
+    HF_HIP(dev_malloc((void**)&st->d_rows, sizeof(int32_t) * n_sets));
+    HF_HIP(dev_malloc((void**)&st->d_flags, (size_t)n_sets * max_rows));
     {   // on the engine's (non-blocking) stream, which every later put / match uses: see hfnet_db_create
         Engine& e = eh->impl;
         std::lock_guard<std::mutex> lk(e.mu);
@@ -232,9 +233,9 @@ void hfnet_store_destroy(hfnet_store* st) {
     if (!st) return;
     (void)hipSetDevice(st->eng->impl.device);
     (void)hipDeviceSynchronize();
-    (void)hipFree(st->d_desc);
-    (void)hipFree(st->d_rows);
-    (void)hipFree(st->d_flags);
+    (void)dev_free(st->d_desc);
+    (void)dev_free(st->d_rows);
+    (void)dev_free(st->d_flags);
     delete st;
 }
 

@@ -28,6 +28,14 @@ const char* get_error();
         }                                                                                         \
     } while (0)
 
+// every device allocation of the library (devmem.cpp): hipMalloc / hipFree, or -- HFNET_GUARD_ALLOC / HFNET_GUARD_FILL in the
+// environment, diagnostics -- page-guarded and / or poisoned allocations that make an out-of-bounds access or a read of
+// never-written memory fail in the first test that has it
+hipError_t dev_malloc(void** out, size_t bytes);
+hipError_t dev_free(void* p);
+int dev_guard_mode();
+template <class T> inline hipError_t dev_malloc(T** out, size_t bytes) { return dev_malloc((void**)out, bytes); }
+
 #define HF_TRY(expr)                      \
     do {                                  \
         int s__ = (expr);                 \

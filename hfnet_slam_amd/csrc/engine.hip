@@ -29,13 +29,13 @@ int* Options::find(const char* name) {
 // ------------------------------------------------------------------------------------ memory
 int DevMem::ensure(size_t n) {
     if (n <= bytes) return HFNET_OK;
-    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-    HF_HIP(hipMalloc(&p, n));
+    if (p) { (void)dev_free(p); p = nullptr; bytes = 0; }
+    HF_HIP(dev_malloc(&p, n));
     bytes = n;
     return HFNET_OK;
 }
 void DevMem::release() {
-    if (p) (void)hipFree(p);
+    if (p) (void)dev_free(p);
     p = nullptr;
     bytes = 0;
 }
@@ -179,10 +179,20 @@ int Net::build(Engine* eng, const NetConfig& c) {
         cell_stride = 0;
         for (int l = 0; l < c.n_levels; ++l) cell_stride = std::max(cell_stride, (long long)lp[l].h[7] * lp[l].w[7]);
         HF_TRY(dalloc(allocs, &tap_flags, images * (size_t)cell_stride));
-        HF_HIP(hipMemset(tap_flags, 0, images * (size_t)cell_stride));
         HF_TRY(dalloc(allocs, &tap_cell_row, images * (size_t)cell_stride));
         HF_TRY(dalloc(allocs, &tap_cells, rows));
         HF_TRY(dalloc(allocs, &tap_nrows, images));
+        HF_TRY(dalloc(allocs, &dev_fault, 1));
+        // On the network's OWN stream, and waited for: every forward() runs on this (non-blocking) stream, which is not ordered with the
+        // null stream, and hipMemset is not host-synchronous on this runtime.  Until round 5 this was a null-stream hipMemset:
+        // hfnet_model_create returned with the clear possibly still queued, hfnet_model_detect's k_tap_compact could then see the
+        // allocation's previous contents, number up to H/8 * W/8 "marked" cells into a row list sized 4 * max_keypoints and hand that
+        // count to the gathered descriptor head -- writes past the end of three buffers, a GPU memory fault, the host process aborted
+        // (GPUTEST_r04; reproduced by tools/dev/null_stream_race.py, NOTEBOOK.md R5.1).  k_tap_compact also bounds its row numbers now.
+        HF_HIP(hipMemsetAsync(tap_flags, 0, images * (size_t)cell_stride, stream));
+        HF_HIP(hipMemsetAsync(tap_nrows, 0, sizeof(int) * images, stream));
+        HF_HIP(hipMemsetAsync(n_level, 0, sizeof(int) * images, stream));
+        HF_HIP(hipMemsetAsync(dev_fault, 0, sizeof(unsigned int), stream));
     }
     if (c.global) {
         const size_t pg = (size_t)c.batch * lp[0].h[18] * lp[0].w[18];
@@ -196,11 +206,12 @@ int Net::build(Engine* eng, const NetConfig& c) {
         HF_TRY(dalloc(allocs, &global_out, (size_t)c.batch * w.global_dim));
     }
     HF_TRY(dalloc(allocs, &inter_logical, (size_t)c.batch * lp[0].h[7] * lp[0].w[7] * w.c_local));
+    HF_HIP(hipStreamSynchronize(stream));                    // the clears above have landed when build() returns
     return HFNET_OK;
 }
 
 void Net::release() {
-    for (void* p : allocs) (void)hipFree(p);
+    for (void* p : allocs) (void)dev_free(p);
     allocs.clear();
     if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     if (stream_global) { (void)hipStreamDestroy(stream_global); stream_global = nullptr; }
@@ -380,7 +391,7 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
             last_dedupe = dedupe_taps != 0;
             if (last_dedupe) {
                 // taps shared by neighbouring keypoints are evaluated once: the rows of an image are its DISTINCT tap cells
-                HF_LAUNCH(e, stream, "tap_cells", launch_tap_cells(kps_level, n_level, cfg.max_keypoints, tap_flags, tap_cell_row, tap_cells, tap_nrows, cell_stride, gt, stream));
+                HF_LAUNCH(e, stream, "tap_cells", launch_tap_cells(kps_level, n_level, cfg.max_keypoints, tap_flags, tap_cell_row, tap_cells, tap_nrows, cell_stride, gt, stream, dev_fault));
                 HF_TRY(pump_global(1));
                 if (desc_bf16x3 && w.desc1_bf && w.desc2_bf) {
                     // option: the head on the bf16 matrix pipe (split operands, three products): tolerance instead of the oracle's bits
@@ -471,6 +482,14 @@ int Net::forward_global(hipStream_t st, int first, int count, int* total) {
     return HFNET_OK;
 }
 
+int Net::read_faults(unsigned int* out) {
+    *out = 0;
+    if (!dev_fault) return HFNET_OK;
+    HF_HIP(hipMemcpyAsync(out, dev_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    HF_HIP(hipStreamSynchronize(stream));
+    return HFNET_OK;
+}
+
 int Net::run_dense_desc() {
     const DeviceWeights& w = e->w;
     const long long pc = pix_cell[HFNET_MAX_LEVELS];
@@ -525,11 +544,11 @@ int Net::tap(int id, std::vector<float>& out) {
     out.resize(count);
     if (permute_c) {
         float* tmp = nullptr;
-        HF_HIP(hipMalloc((void**)&tmp, count * sizeof(float)));
+        HF_HIP(dev_malloc((void**)&tmp, count * sizeof(float)));
         hipError_t er = launch_permute_channels(src, tmp, (long long)(count / permute_c), permute_c, 1, stream);
         if (er == hipSuccess) er = hipMemcpyAsync(out.data(), tmp, count * sizeof(float), hipMemcpyDeviceToHost, stream);
         if (er == hipSuccess) er = hipStreamSynchronize(stream);
-        (void)hipFree(tmp);
+        (void)dev_free(tmp);
         if (er != hipSuccess) { set_error("tap copy failed: %s", hipGetErrorString(er)); return HFNET_ERR_DEVICE; }
     } else {
         HF_HIP(hipMemcpyAsync(out.data(), src, count * sizeof(float), hipMemcpyDeviceToHost, stream));

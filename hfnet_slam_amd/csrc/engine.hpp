@@ -192,6 +192,8 @@ struct Net {
     unsigned char* tap_flags = nullptr;        // [image][cell_stride] scratch of launch_tap_cells
     int *tap_cell_row = nullptr, *tap_cells = nullptr, *tap_nrows = nullptr;
     long long cell_stride = 0;
+    unsigned int* dev_fault = nullptr;         // HFNET_FAULT_* bits set by kernels that had to bound an index read from device memory (0 in a healthy run)
+    int read_faults(unsigned int* out);        // waits for the stream; hfnet_model_device_faults / hfnet_extractor_device_faults
     bool dense_valid = false;      // dense descriptor tensors match the last forward()
     bool nms_valid = false;        // the suppressed score map (tap 25) matches the last forward()
     float last_threshold = 0.f;
@@ -255,7 +257,7 @@ inline void cpu_relax() {
 template <class T>
 inline int dalloc(std::vector<void*>& allocs, T** out, size_t count) {
     void* p = nullptr;
-    HF_HIP(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    HF_HIP(dev_malloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
     allocs.push_back(p);
     *out = (T*)p;
     return HFNET_OK;

@@ -101,8 +101,11 @@ hipError_t launch_l2norm256(const float* in, float* out, long long P, hipStream_
 // the distinct tap cells of every image's selected keypoints, in ascending cell order (Geom as launch_conv3x3_taps):
 //   flags   [images][cell_stride] bytes, scratch     cell_row [images][cell_stride]: row of a cell in the image's slot (or -1)
 //   cells   [images][kps_stride * 4]: cell of a row   n_rows   [images]
+// fault (optional): device word that collects HFNET_FAULT_* bits -- an index from device memory that had to be bounded
+#define HFNET_FAULT_TAP_ROWS 1u     // k_tap_compact: more marked tap cells than rows in the image's slot (flags not clean)
+#define HFNET_FAULT_SAMPLE_ROW 2u   // k_sample: a tap cell of a selected keypoint has no row
 hipError_t launch_tap_cells(const hfnet_keypoint* kps, const int* n_in, long long kps_stride, unsigned char* flags, int* cell_row, int* cells,
-                            int* n_rows, long long cell_stride, const Geom& g, hipStream_t s);
+                            int* n_rows, long long cell_stride, const Geom& g, hipStream_t s, unsigned int* fault = nullptr);
 struct SampleArgs {
     const float* desc_map;        // dense: normalised [pixels x 256]; sparse: RAW tap rows [image][kps_stride*4][256] (normalised on the fly)
     const int* cell_row;          // sparse, de-duplicated taps: row of cell (y * Wo + x) in the image's slot; null: rows 4 i .. 4 i + 3
@@ -118,6 +121,7 @@ struct SampleArgs {
     long long out_frame_stride;
     float scale_factor[HFNET_MAX_LEVELS];  // pt *= scale_factor[level]; octave = level
     int set_octave;               // 0: single model (octave stays 0, no rescale)
+    unsigned int* fault;          // optional: HFNET_FAULT_* bits (see launch_tap_cells)
 };
 hipError_t launch_sample(const SampleArgs& a, const Geom& g, hipStream_t s);
 // free-standing Resampler (BaseModel.cc:491-562): out[b][p][c] for NHWC data and (x, y) warp points

@@ -727,7 +727,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a, Geom g, TapArgs 
     const int image = level * g.batch + frame;
     const LevelGeom lv = g.lv[level];
     const int Hc = GATHER ? lv.Ho : lv.H, Wc = GATHER ? lv.Wo : lv.W;
-    const int nrows = GATHER ? (ta.cells ? ta.n_rows[image] : ta.n_in[image] * 4) : Hc * Wc;
+    // (gathered rows: the count comes from device memory -- bounded by the image's slot of 4 * kps_stride rows)
+    const int nrows = GATHER ? min(ta.cells ? ta.n_rows[image] : ta.n_in[image] * 4, (int)ta.kps_stride * 4) : Hc * Wc;
     // (An XCD-aware order -- contiguous runs of row tiles per XCD, both column groups adjacent -- cut this kernel's HBM
     // fetches by 43 % but ran 5-50 % slower: the kernel is issue-bound, not HBM-bound.)
     const int T = (nrows + 127) >> 7;
@@ -898,7 +899,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wlds(ConvArgs a, Geom g, Tap
     const int image = level * g.batch + frame;
     const LevelGeom lv = g.lv[level];
     const int Hc = GATHER ? lv.Ho : lv.H, Wc = GATHER ? lv.Wo : lv.W;
-    const int nrows = GATHER ? (ta.cells ? ta.n_rows[image] : ta.n_in[image] * 4) : Hc * Wc;
+    // (gathered rows: the count comes from device memory -- bounded by the image's slot of 4 * kps_stride rows)
+    const int nrows = GATHER ? min(ta.cells ? ta.n_rows[image] : ta.n_in[image] * 4, (int)ta.kps_stride * 4) : Hc * Wc;
     const int T = (nrows + 127) >> 7;
     if (tile >= T) return;                                      // workgroup-uniform
     const int nt0 = grp * NT;
@@ -1236,7 +1238,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16x3(ConvArgs a, const bf16x8
         image = level * g.batch + frame;
         const LevelGeom lv = g.lv[level];
         Hc = lv.Ho; Wc = lv.Wo;
-        nrows = ta.n_rows[image];
+        nrows = min(ta.n_rows[image], (int)ta.kps_stride * 4);
         in_base = lv.in_off + (long long)frame * Hc * Wc;
         out_base = (long long)image * ta.kps_stride * 4;
     } else {

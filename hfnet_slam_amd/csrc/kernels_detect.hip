@@ -349,6 +349,7 @@ __global__ __launch_bounds__(1024) void k_topk(const unsigned long long* __restr
     const unsigned int n = counters[image * HFNET_COUNTER_STRIDE];
     int K = kmax_per_level.k[level];
     if (K > TOPK_CAP) K = TOPK_CAP;
+    if (K > (int)kps_stride) K = (int)kps_stride;              // (never past the image's keypoint slot, whatever the caller's budget)
     const int tid = threadIdx.x;
     unsigned int m;        // number of selected keys
     bool by_index;
@@ -526,11 +527,11 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a, Geom g) {
     const int i = blockIdx.x * 4 + wave;
     int base = 0, total = 0;
     for (int l = 0; l < g.n_levels; ++l) {
-        const int nl = a.n_in[l * g.batch + frame];
+        const int nl = min(a.n_in[l * g.batch + frame], (int)a.kps_stride);
         if (l < level) base += nl;
         total += nl;
     }
-    const int n = a.n_in[image];
+    const int n = min(a.n_in[image], (int)a.kps_stride);        // (a count comes from device memory: never past the image's slot)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (level == 0 && a.n_out_frame) a.n_out_frame[frame] = total;
         if (a.n_out_level) a.n_out_level[frame * g.n_levels + level] = n;
@@ -555,7 +556,12 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a, Geom g) {
             // (a row number comes from device memory: kept inside the image's slot whatever it is -- a wrong descriptor is a test failure,
             //  a wild address takes the process down; NOTEBOOK.md R4.8)
             const int rmax = (int)a.kps_stride * 4 - 1;
-            auto row_of = [&](int cell) { return (long long)min(max(cr[cell], 0), rmax) * 256; };
+            // ... and reported: a tap cell without a row means the row list and this keypoint disagree (HFNET_FAULT_SAMPLE_ROW)
+            auto row_of = [&](int cell) {
+                const int rw = cr[cell];
+                if ((rw < 0 || rw > rmax) && a.fault && lane == 0) atomicOr(a.fault, HFNET_FAULT_SAMPLE_ROW);
+                return (long long)min(max(rw, 0), rmax) * 256;
+            };
             vff = (fxin && fyin) ? *(const f32x4*)(d + row_of(fy * dw + fx)) : zero;
             vcc = (cxin && cyin) ? *(const f32x4*)(d + row_of(cy * dw + cx)) : zero;
             vfc = (fxin && cyin) ? *(const f32x4*)(d + row_of(cy * dw + fx)) : zero;
@@ -655,7 +661,7 @@ __global__ __launch_bounds__(256) void k_tap_mark(const hfnet_keypoint* __restri
     const int image = blockIdx.y, level = image / g.batch;
     const LevelGeom lv = g.lv[level];                            // H, W: score map; Ho, Wo: cell grid
     const int row = blockIdx.x * 256 + threadIdx.x, i = row >> 2, t = row & 3;
-    if (i >= n_in[image]) return;
+    if (i >= min(n_in[image], (int)kps_stride)) return;
     const hfnet_keypoint kp = kps[(long long)image * kps_stride + i];
     const int Wc = lv.Wo, Hc = lv.Ho;
     const float sw = ((float)Wc - 1.f) / (float)((float)lv.W - 1.f);
@@ -666,8 +672,12 @@ __global__ __launch_bounds__(256) void k_tap_mark(const hfnet_keypoint* __restri
     if (x >= 0 && x < Wc && y >= 0 && y < Hc) flags[(long long)image * cell_stride + y * Wc + x] = 1;
 }
 
+// The row list of an image holds 4 * kps_stride entries and k_tap_mark sets at most that many flags; the kernel nevertheless bounds
+// every row number it writes (a flag array that is not clean -- GPUTEST_r04: a creation-time clear that had not landed yet -- would
+// otherwise run the list, and the descriptor head's row buffers after it, past their ends) and reports the overflow.
 __global__ __launch_bounds__(1024) void k_tap_compact(unsigned char* __restrict__ flags, int* __restrict__ cell_row, int* __restrict__ cells,
-                                                      int* __restrict__ n_rows, long long cell_stride, long long kps_stride, Geom g) {
+                                                      int* __restrict__ n_rows, long long cell_stride, long long kps_stride, Geom g,
+                                                      unsigned int* __restrict__ fault) {
     __shared__ int wsum[16];
     __shared__ int base;
     const int image = blockIdx.x, level = image / g.batch;
@@ -676,6 +686,7 @@ __global__ __launch_bounds__(1024) void k_tap_compact(unsigned char* __restrict_
     int* cr = cell_row + (long long)image * cell_stride;
     int* cl = cells + (long long)image * kps_stride * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cap = (int)kps_stride * 4;
     if (tid == 0) base = 0;
     __syncthreads();
     for (int c0 = 0; c0 < ncell; c0 += 1024) {
@@ -689,20 +700,24 @@ __global__ __launch_bounds__(1024) void k_tap_compact(unsigned char* __restrict_
         int woff = 0;
         for (int w = 0; w < wave; ++w) woff += wsum[w];
         const int row = base + woff + prefix;
-        if (c < ncell) cr[c] = on ? row : -1;
-        if (on) cl[row] = c;
+        const bool fits = row < cap;
+        if (c < ncell) cr[c] = on && fits ? row : -1;
+        if (on && fits) cl[row] = c;
         __syncthreads();
         if (tid == 0) { int tot = 0; for (int w = 0; w < 16; ++w) tot += wsum[w]; base += tot; }
         __syncthreads();
     }
-    if (tid == 0) n_rows[image] = base;
+    if (tid == 0) {
+        n_rows[image] = min(base, cap);
+        if (base > cap && fault) atomicOr(fault, HFNET_FAULT_TAP_ROWS);
+    }
 }
 
 hipError_t launch_tap_cells(const hfnet_keypoint* kps, const int* n_in, long long kps_stride, unsigned char* flags, int* cell_row, int* cells,
-                            int* n_rows, long long cell_stride, const Geom& g, hipStream_t s) {
+                            int* n_rows, long long cell_stride, const Geom& g, hipStream_t s, unsigned int* fault) {
     const int images = g.n_levels * g.batch;
     hipLaunchKernelGGL(k_tap_mark, dim3((unsigned)((kps_stride * 4 + 255) / 256), images), dim3(256), 0, s, kps, n_in, kps_stride, flags, cell_stride, g);
-    hipLaunchKernelGGL(k_tap_compact, dim3(images), dim3(1024), 0, s, flags, cell_row, cells, n_rows, cell_stride, kps_stride, g);
+    hipLaunchKernelGGL(k_tap_compact, dim3(images), dim3(1024), 0, s, flags, cell_row, cells, n_rows, cell_stride, kps_stride, g, fault);
     return hipGetLastError();
 }
 

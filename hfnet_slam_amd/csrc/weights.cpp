@@ -112,7 +112,7 @@ int choose_nt(int tiles) {
 
 static int upload(DeviceWeights& dw, const std::vector<float>& h, float** out) {
     void* p = nullptr;
-    HF_HIP(hipMalloc(&p, h.size() * sizeof(float)));
+    HF_HIP(dev_malloc(&p, h.size() * sizeof(float)));
     dw.allocations.push_back(p);
     HF_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     *out = (float*)p;
@@ -271,7 +271,7 @@ int DeviceWeights::build(const WeightFile& wf) {
             *out = nullptr;
             if (!cp.w || !bf16x3_supported(cp)) return HFNET_OK;
             void* p = nullptr;
-            HF_HIP(hipMalloc(&p, bf16x3_pack_bytes(cp)));
+            HF_HIP(dev_malloc(&p, bf16x3_pack_bytes(cp)));
             allocations.push_back(p);
             HF_HIP(launch_repack_bf16x3(cp, p, nullptr));
             *out = p;
@@ -318,7 +318,7 @@ int DeviceWeights::build(const WeightFile& wf) {
 }
 
 void DeviceWeights::release() {
-    for (void* p : allocations) (void)hipFree(p);
+    for (void* p : allocations) (void)dev_free(p);
     allocations.clear();
 }
 

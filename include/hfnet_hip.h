@@ -160,6 +160,14 @@ int hfnet_model_detect_global(hfnet_model* m, const float* intermediate, float* 
  * order, NHWC).  tap ids as in oracle/hfnet_oracle.h (HFO_TAP_*), plus 25 = scores after NMS,
  * 26 = normalised dense descriptor map.  *count receives the number of floats written. */
 int hfnet_model_tap(hfnet_model* m, int tap, float* out, size_t capacity, size_t* count);
+/* Diagnostics: a word of HFNET_DEVICE_FAULT_* bits, 0 in a healthy run, sticky for the lifetime of the object.  The kernels
+ * bound every index they read from device memory before it becomes an address (a valid call can then never take the host
+ * process down through a GPU memory fault -- the reference's contract is `return false`, HFNetTFModelV2.cc:62-98, never an
+ * abort); a bit here says that such a bound was hit, i.e. that device state was inconsistent and results may be wrong.
+ * hfnet_model_detect also returns HFNET_ERR_DEVICE when the word is non-zero after its launches.  Waits for the object's stream. */
+#define HFNET_DEVICE_FAULT_TAP_ROWS 1u    /* more marked tap cells than rows in an image's slot of the sparse descriptor head */
+#define HFNET_DEVICE_FAULT_SAMPLE_ROW 2u  /* a bilinear tap of a selected keypoint had no descriptor row                      */
+int hfnet_model_device_faults(hfnet_model* m, unsigned int* bits);
 
 /* ---- HFextractor (include/Extractors/HFextractor.h:26-27; src/Extractors/HFextractor.cc:82-284;
  *      model set-up mirrors InitAllModels, BaseModel.cc:24-93) ----------------------------------- */
@@ -180,6 +188,8 @@ int hfnet_extractor_extract(hfnet_extractor* x, const uint8_t* image, int row_st
  * results seen on the host, [3] local results unpacked, [4] stream drained (global descriptor down), [5] return.
  * Writes min(n, 6) values; returns HFNET_ERR_INVALID_ARG before the first such call. */
 int hfnet_extractor_last_timing(hfnet_extractor* x, double* us, int n);
+/* see hfnet_model_device_faults */
+int hfnet_extractor_device_faults(hfnet_extractor* x, unsigned int* bits);
 /* Batched form (independent frames, BASELINE config 4): images are n_frames buffers of
  * height x row_stride bytes, `frame_stride` bytes apart; outputs are n_frames slots of n_features
  * rows each.  `on_device` != 0: every pointer is a device pointer on the engine's GPU and the call

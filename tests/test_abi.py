@@ -71,14 +71,23 @@ def test_product_never_imports_the_oracle():
 
 def test_library_is_built_without_packed_f32_instructions():
     """gfx950: v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 returned wrong values in lanes 48-63 of a wave that shared its SIMD with the split-bf16
-    fused-block kernels (NOTEBOOK.md R4.8; tools/dev/xq_repro3.hip) -- clang forms them from neighbouring scalar operations (SLP) and from f32x2 /
-    f32x4 arithmetic.  The build flags must keep them out: two of the sources that had them, compiled to assembly with those flags."""
-    import subprocess
+    fused-block kernels (NOTEBOOK.md R4.8; tools/micro/pk_f32_hazard_standalone.hip) -- clang forms them from neighbouring scalar operations
+    (SLP) and from f32x2 / f32x4 arithmetic.  The build flags must keep them out of EVERY kernel: all gfx950 code objects of the BUILT
+    libhfnet_hip.so are disassembled (build() runs the same check on every link and refuses to produce a library otherwise)."""
     from hfnet_slam_amd import build
     assert "-fno-slp-vectorize" in build.FLAGS and "-packed-fp32-ops" in build.FLAGS
-    for src in ("kernels_detect.hip", "kernels_global.hip"):
-        r = subprocess.run([build._hipcc()] + build.FLAGS + ["-S", "--cuda-device-only", os.path.join(build.CSRC, src), "-o", "-"],
-                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600)
-        assert r.returncode == 0 and "s_endpgm" in r.stdout
-        packed = [l.strip() for l in r.stdout.splitlines() if re.search(r"\bv_pk_(mul|add|fma)_f32\b", l)]
-        assert not packed, (src, packed[:3])
+    build.build()
+    n_obj, n_inst, packed = build.packed_f32_instructions()
+    assert n_obj >= 6, n_obj                    # one code object per .hip source that has kernels
+    assert n_inst > 100000, n_inst
+    assert not packed, packed[:3]
+
+
+def test_object_cache_is_keyed_on_the_compile_flags(tmp_path, monkeypatch):
+    """after a flag change only engine.o used to be rebuilt (time stamps alone) while the library was stamped with the new id"""
+    from hfnet_slam_amd import build
+    build.build()
+    stamp = os.path.join(build.OBJ, "flags.id")
+    assert open(stamp).read().strip() == build._flags_id()
+    monkeypatch.setattr(build, "FLAGS", build.FLAGS + ["-DHFNET_SOME_NEW_FLAG=1"])
+    assert open(stamp).read().strip() != build._flags_id()          # -> build() would schedule every source

@@ -11,9 +11,32 @@ from conftest import synth_image
 
 
 
-def run(budget_s: float, seed: int, big_share: float = 0.02):
-    """-> (cases, failures); big_share: fraction of full-size multi-frame cases"""
+class CaseLog:
+    """One line per case, written (flushed + fsync'd) BEFORE the case's first library call, so that a process abort
+    (a device fault takes the host process down through the HIP runtime's queue-error callback) names its case.
+    File: $HFNET_SOAK_LOG, else gpurun_out/soak_cases_<seed>.log under the repo root if that directory exists, else the
+    temporary directory.  The last line of the file after an abort is the case that died."""
+
+    def __init__(self, seed):
+        path = os.environ.get("HFNET_SOAK_LOG")
+        if not path:
+            d = os.path.join(ROOT, "gpurun_out")
+            path = os.path.join(d if os.path.isdir(d) else tempfile.gettempdir(), f"soak_cases_{seed}.log")
+        self.path = path
+        self.fh = open(path, "a")
+        self.note(f"# soak seed {seed} pid {os.getpid()} build {capi.build_id() if hasattr(capi, 'build_id') else '?'}")
+
+    def note(self, text):
+        self.fh.write(text + "\n")
+        self.fh.flush()
+        os.fsync(self.fh.fileno())
+
+
+def run(budget_s: float, seed: int, big_share: float = 0.02, max_cases: int = 0):
+    """-> (cases, failures); big_share: fraction of full-size multi-frame cases; max_cases > 0: stop after that many cases
+    whatever the clock says (the case sequence is a function of the seed alone: a replay of the first N cases is exact)"""
     rng = np.random.default_rng(seed)
+    log = CaseLog(seed)
     wpath = os.path.join(tempfile.gettempdir(), f"hfnet_soak_{seed}.hfw")
     weights.save(wpath, weights.synthetic_weights(100 + seed))
     model = O.Model(wpath)
@@ -26,7 +49,7 @@ def run(budget_s: float, seed: int, big_share: float = 0.02):
         return (a / np.maximum(np.linalg.norm(a, axis=1, keepdims=True), 1e-12)).astype(np.float32)
 
 
-    while time.time() < t_end:
+    while time.time() < t_end and not (max_cases and cases >= max_cases):
         eng = capi.Engine(wpath, 0)
         opts = {"fuse_blocks": int(rng.integers(0, 2)), "fused_variant": int(rng.choice([2, 4, 6, 8])), "fuse_min_wgs": int(rng.choice([0, 256])), "fuse_stem": int(rng.integers(0, 2)),
                 "dense_desc": int(rng.integers(0, 2)), "two_streams": int(rng.integers(0, 4)), "conv_wlds": int(rng.integers(0, 2)),
@@ -36,17 +59,20 @@ def run(budget_s: float, seed: int, big_share: float = 0.02):
         for k, v in opts.items():
             eng.set_option(k, v)
         for _ in range(6):
-            if time.time() >= t_end:
+            if time.time() >= t_end or (max_cases and cases >= max_cases):
                 break
             kind = rng.random()
             cases += 1
+            note = lambda what, *a: log.note(f"{cases} {what} {a} opts={opts}")      # noqa: E731
             try:
                 if kind < big_share:
                     # full-size frames at a random call size: the kernel choices (column tiles per wave, LDS-weight kernels,
                     # slot skipping, low-latency 1x1) switch with the number of tiles of a call
                     w, h = (752, 480) if rng.random() < 0.6 else (512, 512)
                     nf = int(rng.choice([1000, 850, 300])); B = int(rng.integers(1, 41))
-                    x = capi.Extractor(eng, w, h, nf, 0.01, 1.2, 4, max_batch=int(rng.choice([B, 8, 32])))
+                    mb = int(rng.choice([B, 8, 32]))
+                    note("extract_full", w, h, nf, B, mb)
+                    x = capi.Extractor(eng, w, h, nf, 0.01, 1.2, 4, max_batch=mb)
                     imgs = np.stack([synth_image(h, w, int(rng.integers(1 << 30)), "natural" if rng.random() < 0.5 else "uniform") for _ in range(B)])
                     nb, kb, db_, gb = x.extract_batch(imgs)
                     for i in sorted(set(int(v) for v in rng.integers(0, B, 2))):
@@ -54,6 +80,8 @@ def run(budget_s: float, seed: int, big_share: float = 0.02):
                         if not (nb[i] == rn and np.array_equal(kb[i, :rn], rk) and np.array_equal(db_[i, :rn], rd) and np.array_equal(gb[i], rg)):
                             fails.append(("extract_full", w, h, nf, B, i, opts))
                             break
+                    if x.device_faults():
+                        fails.append(("device_fault", x.device_faults(), cases, opts))
                     x.close()
                 elif kind < 0.5:
                     w, h = int(rng.integers(40, 420)), int(rng.integers(40, 340))
@@ -62,7 +90,9 @@ def run(budget_s: float, seed: int, big_share: float = 0.02):
                     while nl > 1 and min(w, h) / sf ** (nl - 1) < 24:
                         nl -= 1
                     B = int(rng.choice([1, 1, 2, 3, 5, 12]))
-                    x = capi.Extractor(eng, w, h, nf, thr, sf, nl, max_batch=int(rng.choice([1, 2, 4, 16])))
+                    mb = int(rng.choice([1, 2, 4, 16]))
+                    note("extract", w, h, nl, nf, thr, sf, B, mb)
+                    x = capi.Extractor(eng, w, h, nf, thr, sf, nl, max_batch=mb)
                     imgs = np.stack([synth_image(h, w, int(rng.integers(1 << 30)), "natural" if rng.random() < 0.5 else "uniform") for _ in range(B)])
                     nb, kb, db, gb = x.extract_batch(imgs)
                     for i in range(B):
@@ -71,6 +101,8 @@ def run(budget_s: float, seed: int, big_share: float = 0.02):
                         if not ok:
                             fails.append(("extract", w, h, nl, nf, thr, sf, B, i, opts))
                             break
+                    if x.device_faults():
+                        fails.append(("device_fault", x.device_faults(), cases, opts))
                     x.close()
                 elif kind < 0.62:
                     # one frame per call (graph path), twice with different images + the descriptor store fed from the extractor
@@ -78,7 +110,9 @@ def run(budget_s: float, seed: int, big_share: float = 0.02):
                     nl = int(rng.integers(1, 5)); nf = int(rng.integers(16, 1200))
                     while nl > 1 and min(w, h) / 1.2 ** (nl - 1) < 24:
                         nl -= 1
-                    x = capi.Extractor(eng, w, h, nf, 0.01, 1.2, nl, max_batch=int(rng.choice([1, 3])))
+                    mb = int(rng.choice([1, 3]))
+                    note("extract1", w, h, nl, nf, mb)
+                    x = capi.Extractor(eng, w, h, nf, 0.01, 1.2, nl, max_batch=mb)
                     for rep in range(3):
                         img = synth_image(h, w, int(rng.integers(1 << 30)), "natural" if rep % 2 else "uniform")
                         n, k, d, g, npl = x.extract(img)
@@ -86,10 +120,13 @@ def run(budget_s: float, seed: int, big_share: float = 0.02):
                         if n != rn or not np.array_equal(k, rk) or not np.array_equal(d, rd) or not np.array_equal(g, rg) or not np.array_equal(npl, rnpl):
                             fails.append(("extract1", w, h, nl, nf, rep, opts))
                             break
+                    if x.device_faults():
+                        fails.append(("device_fault", x.device_faults(), cases, opts))
                     x.close()
                 elif kind < 0.72:
                     # device-resident store with row filters
                     mr, S = int(rng.integers(1, 400)), int(rng.integers(2, 7))
+                    note("store", mr, S)
                     store = capi.Store(eng, S, mr)
                     base = unit(mr)
                     sets, flags = [], []
@@ -131,6 +168,7 @@ def run(budget_s: float, seed: int, big_share: float = 0.02):
                     h, w = 8 * int(rng.integers(5, 40)), 8 * int(rng.integers(5, 50))
                     nk = int(rng.integers(1, 800)); thr = float(rng.choice([0.0, 0.01]))
                     mode = int(rng.choice([capi.MODE_LOCAL_AND_GLOBAL, capi.MODE_LOCAL, capi.MODE_LOCAL_AND_INTERMEDIATE]))
+                    note("model", mode, h, w, nk, thr)
                     m = capi.Model(eng, mode, h, w, max_keypoints=nk)
                     img = synth_image(h, w, int(rng.integers(1 << 30)), "natural" if rng.random() < 0.5 else "uniform")
                     st, k, d, aux = m.detect(img, nk, thr)
@@ -142,12 +180,15 @@ def run(budget_s: float, seed: int, big_share: float = 0.02):
                         ok2, rg = model.detect_global(raux)
                         bad = (st2 == 0) != ok2 or not np.array_equal(g, rg)
                         m2.close()
+                    if m.device_faults():
+                        fails.append(("device_fault", m.device_faults(), cases, opts))
                     m.close()
                     if bad:
                         fails.append(("model", mode, h, w, nk, thr, opts))
                 elif kind < 0.81:
                     # candidate loop of the windowed matchers + distinctive descriptors
                     nq, nt = int(rng.integers(1, 600)), int(rng.integers(1, 900))
+                    note("candidates", nq, nt)
                     t = unit(nt)
                     q = t[rng.integers(0, nt, nq)] + float(rng.choice([0.0, 0.05])) * rng.standard_normal((nq, 256)).astype(np.float32)
                     q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
@@ -167,6 +208,7 @@ def run(budget_s: float, seed: int, big_share: float = 0.02):
                         fails.append(("distinctive", len(sizes)))
                 elif kind < 0.88:
                     n1, n2 = int(rng.integers(0, 1300)), int(rng.integers(0, 1300))
+                    note("bow_tri", n1, n2)
                     a = unit(max(n1, 1))[:n1]
                     if n1 and n2 and rng.random() < 0.7:
                         b = a[rng.integers(0, n1, n2)] + float(rng.choice([1e-5, 1e-3, 0.02, 0.05])) * rng.standard_normal((n2, 256)).astype(np.float32)
@@ -186,6 +228,7 @@ def run(budget_s: float, seed: int, big_share: float = 0.02):
                             fails.append(("tri", n1, n2))
                 else:
                     n, dim = int(rng.integers(1, 1500)), 4096
+                    note("db", n)
                     rows = unit(n, dim)
                     db = capi.Database(eng, n + 5, dim)
                     for i in range(n):
