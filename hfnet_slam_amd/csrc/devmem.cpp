@@ -48,7 +48,7 @@ hipError_t guarded_malloc(GuardState& s, void** out, size_t bytes) {
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = dev;
     size_t gran = 0;
-    r = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    r = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
     if (r != hipSuccess) return r;
     if (gran == 0) return hipErrorInvalidValue;
     const size_t user = (bytes + 15) / 16 * 16;
@@ -76,6 +76,17 @@ hipError_t guarded_malloc(GuardState& s, void** out, size_t bytes) {
 }  // namespace
 
 int dev_guard_mode() { return state().mode; }
+
+bool trace_launches() {
+    static const bool on = [] { const char* t = std::getenv("HFNET_TRACE_LAUNCHES"); return t && *t && *t != '0'; }();
+    return on;
+}
+void trace_launch(const char* name, hipStream_t s, bool after) {
+    if (!after) { std::fprintf(stderr, "[hfnet] launch %s\n", name); std::fflush(stderr); return; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (cs == hipStreamCaptureStatusNone) (void)hipStreamSynchronize(s);
+}
 
 hipError_t dev_malloc(void** out, size_t bytes) {
     GuardState& s = state();
@@ -105,8 +116,8 @@ hipError_t dev_free(void* p) {
     hipError_t q = hipMemUnmap(m.mapped, m.mapped_bytes);
     if (r == hipSuccess) r = q;
     q = hipMemRelease(m.handle);
-    if (r == hipSuccess) r = q;
-    q = hipMemAddressFree(m.va, m.reserved);
+    // The address range stays reserved for the rest of the process (never handed out again): an access through a stale pointer
+    // faults as well, and no later allocation can alias a range the GPU's translation caches have seen under another mapping.
     return r == hipSuccess ? q : r;
 }
 

@@ -263,9 +263,16 @@ inline int dalloc(std::vector<void*>& allocs, T** out, size_t count) {
     return HFNET_OK;
 }
 
+// HFNET_TRACE_LAUNCHES=1 in the environment (diagnostics, with the guarded allocator of devmem.cpp): every launch group is named on
+// stderr before it is enqueued and waited for afterwards (unless the stream is being captured into a graph), so that the last name
+// printed before a "Memory access fault" is the kernel that faulted.
+bool trace_launches();
+void trace_launch(const char* name, hipStream_t s, bool after);
+
 #define HF_LAUNCH(eng, strm, name, call)                                                   \
     do {                                                                                   \
         hipError_t er__;                                                                   \
+        if (::hfnet::trace_launches()) ::hfnet::trace_launch(name, strm, false);           \
         if ((eng)->prof.enabled) {                                                         \
             std::lock_guard<std::mutex> lk__((eng)->prof_mu);                              \
             (eng)->prof.begin(name, strm);                                                 \
@@ -278,6 +285,7 @@ inline int dalloc(std::vector<void*>& allocs, T** out, size_t count) {
             set_error("launch %s failed: %s", name, hipGetErrorString(er__));              \
             return HFNET_ERR_DEVICE;                                                       \
         }                                                                                  \
+        if (::hfnet::trace_launches()) ::hfnet::trace_launch(name, strm, true);            \
     } while (0)
 
 #define API_GUARD(ptr, what)                                               \

@@ -29,7 +29,10 @@ class CaseLog:
     def note(self, text):
         self.fh.write(text + "\n")
         self.fh.flush()
-        os.fsync(self.fh.fileno())
+        try:
+            os.fsync(self.fh.fileno())
+        except OSError:                      # (/dev/null and friends)
+            pass
 
 
 def run(budget_s: float, seed: int, big_share: float = 0.02, max_cases: int = 0):
