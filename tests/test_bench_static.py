@@ -104,3 +104,34 @@ def test_synthetic_frames_are_seeded():
         assert a.shape == (2, bench.H_IMG, bench.W_IMG) and a.dtype == np.uint8
         assert np.array_equal(a[1], b[0])                       # frame index -> seed, independent of the call
         assert a.std() > 20                                     # not degenerate
+
+
+def test_stdout_line_is_compact_and_parses(tmp_path):
+    """BENCH_r04.parsed was null: the line had grown to 21 KB of notes and tables and no longer fitted the ~8 KB stdout tail the
+    driver parses.  (a) the full round-4 record (profiles/r04_bench.json) compacts to < 8000 bytes with the contract's fields,
+    roofline and cpu_baseline in it; (b) a --dry-ranks 1 run of the real main(): the LAST stdout line is that compact JSON, the
+    full record goes to BENCH_DETAIL and stderr."""
+    import subprocess
+    import sys
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    line = json.dumps(bench.compact_line(full))
+    assert len(line.encode()) < bench.LINE_LIMIT == 8000
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "classes"}
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    assert set(d["roofline"]["classes"]) == {"fused_block", "head_gemm", "global_gemm", "hbm_stream", "match"}
+    assert set(d["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and d["verified"]["equal"] is True
+    assert "table" not in d["roofline"] and "dtype_note" not in d and "options" not in d
+    assert d["configs"]["4_frames_per_s"] > 0 and d["configs"]["5_db_q64_us"] > 0 and d["configs"]["2_extract_ms_median"] > 0
+    env = dict(os.environ); env.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "BENCH_DETAIL": str(tmp_path / "detail.json")})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-ranks", "1", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last.encode()) < 8000
+    d = json.loads(last)
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and "invalid" in d and d["detail"] == "bench_detail.json"
+    assert json.load(open(tmp_path / "detail.json"))["metric"] == d["metric"]

@@ -69,7 +69,8 @@ def test_bench_dry_ranks_runs_the_two_rank_control_flow(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   BENCH_DETAIL=str(tmp_path / "detail.json"))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-ranks", "2", "--steps", "2", "--warmup", "1",
                                        "--batch", "128", "--configs", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=240) for p in procs]
@@ -81,7 +82,8 @@ def test_bench_dry_ranks_runs_the_two_rank_control_flow(tmp_path):
     assert line["value"] > 0 and abs(line["value"] - 2 * 128 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
     pr = line["per_rank_frames_per_s"]                                                      # the first real SCALE run explains itself
     assert len(pr["all"]) == 2 and 0 < pr["min"] <= pr["max"] and pr["min"] * 2 >= line["value"] * 0.5
-    c4 = line["configs"]["4"]
+    assert len(json_lines(outs[0][0])[0].encode()) < 8000 and line["configs"]["4_frames_per_s"] > 0      # the compact line; the record in full:
+    c4 = json.load(open(tmp_path / "detail.json"))["configs"]["4"]
     assert c4["frames"] == 27049 and c4["gpus"] == 2 and c4["sequences"] == 11 and c4["frames_per_s"] > 0
     # a world size that does not match --gpus is refused before anything is initialised
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
@@ -97,7 +99,9 @@ def test_bench_rccl_path_with_one_rank():
     import json
     import subprocess
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, BENCH_FORCE_DIST="1")
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(), "detail.json")
+    env = dict(os.environ, BENCH_FORCE_DIST="1", BENCH_DETAIL=detail)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "256",
                         "--configs", "4", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
@@ -105,6 +109,7 @@ def test_bench_rccl_path_with_one_rank():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 1 and line["value"] > 0 and line["configs"]["4"]["frames"] == 27049
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["configs"]["4_frames_per_s"] > 0 and len(lines[0].encode()) < 8000
+    assert json.load(open(detail))["configs"]["4"]["frames"] == 27049
     v = line["verified"]                                       # the timed run checks its own last chunk against the oracle
     assert v["equal"] is True and v["equal_all_ranks"] is True and v["frames"] == [0, 1, 42, 85, 127] and line["value_natural"] > 0

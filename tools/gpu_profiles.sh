@@ -17,7 +17,8 @@ done
 python $GRAFT_REPO_ROOT/tools/make_traffic.py $(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) $CH $OUT/${TAG}_traffic_b${CH}.json > $OUT/traffic.log 2>&1
 cp $OUT/${TAG}_traffic_b${CH}.json $GRAFT_REPO_ROOT/profiles/
 cd $GRAFT_REPO_ROOT
-timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+# stdout: the compact line the driver parses; the record in full (tables, notes, sub-records) goes to BENCH_DETAIL
+BENCH_DETAIL=$OUT/${TAG}_bench_detail.json timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 cd /tmp
 rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --configs none --no-cpu-baseline > $OUT/kt.log 2>&1
 cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_bench_kernel_stats.csv
