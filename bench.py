@@ -184,6 +184,26 @@ def hbm_traffic(launch_name: str, batch: int):
 
 
 # ------------------------------------------------------------------------------------------------ synthetic data
+def host(t):
+    """device tensor -> numpy through PINNED host memory: a plain `.cpu()` has torch's HIP runtime pin the pageable destination in place -- the
+    mechanism behind the rare "Memory access fault ... <host heap page>" aborts of NOTEBOOK.md R5.4 (read-backs only: outside every timed region)"""
+    import torch
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    torch.cuda.synchronize()
+    return h.numpy().copy()
+
+
+def to_device(torch, a, dev):
+    """numpy -> device tensor through pinned host memory (see host())"""
+    src = torch.from_numpy(np.ascontiguousarray(a))
+    h = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+    h.copy_(src)
+    d = h.to(dev, non_blocking=True)
+    torch.cuda.synchronize()
+    return d
+
+
 def make_frames(count: int, first_index: int, kind: str = "uniform", w: int = W_IMG, h: int = H_IMG) -> np.ndarray:
     """seed 1000 + frame index; "uniform" = iid uniform u8, "natural" = sum of 6 octaves of bilinearly
     up-sampled uniform noise, clipped (smooth structures at several scales)"""
@@ -216,7 +236,7 @@ def make_natural_frames_device(torch, dev, count: int, first_index: int, w: int 
         acc = torch.zeros((h, w), dtype=torch.float64, device=dev)
         for o in range(6):
             gh, gw = 2 + (h >> (6 - o)), 2 + (w >> (6 - o))
-            g = torch.from_numpy(rng.random((gh, gw))).to(dev)
+            g = to_device(torch, rng.random((gh, gw)), dev)
             ys = torch.linspace(0, gh - 1.001, h, dtype=torch.float64, device=dev); xs = torch.linspace(0, gw - 1.001, w, dtype=torch.float64, device=dev)
             y0 = ys.long(); x0 = xs.long(); fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
             up = (g[y0][:, x0] * (1 - fy) * (1 - fx) + g[y0][:, x0 + 1] * (1 - fy) * fx + g[y0 + 1][:, x0] * fy * (1 - fx) + g[y0 + 1][:, x0 + 1] * fy * fx)
@@ -294,8 +314,8 @@ def verify_last_chunk(torch, pipe, weights_path, cur_frames, prev_frames, which,
     m = O.Model(weights_path)
     B, nb = pipe.B, pipe.n_buf
     s0 = ((pipe.cur - 1) % nb) * B                       # buffer block the last run_chunk wrote
-    imgs = cur_frames.cpu().numpy()
-    prev_last = prev_frames[B - 1].cpu().numpy()
+    imgs = host(cur_frames)
+    prev_last = host(prev_frames[B - 1])
     cache = {}
 
     def ref(f):                                            # f = -1: the previous chunk's last frame
@@ -308,7 +328,7 @@ def verify_last_chunk(torch, pipe, weights_path, cur_frames, prev_frames, which,
         rn, rk, rd, rg, _ = ref(f)
         slot = s0 + f
         n = int(pipe.n_rows[slot].item())
-        k = pipe.kps[slot].cpu().numpy(); d = pipe.desc[slot].cpu().numpy(); g = pipe.glob[f].cpu().numpy()
+        k = host(pipe.kps[slot]); d = host(pipe.desc[slot]); g = host(pipe.glob[f])
         ok = {"count": n == rn}
         if n == rn:
             ok["kps_xy_response"] = all(np.array_equal(k[:n, j], rk[name]) for j, name in enumerate(("x", "y", "response")))
@@ -318,8 +338,8 @@ def verify_last_chunk(torch, pipe, weights_path, cur_frames, prev_frames, which,
         qn, _, qd, _, _ = ref(f - 1)                       # query = the predecessor frame (Pipeline._default_pairs)
         rc, rm, rdist = O.search_by_bow(qd, rd, TH_LOW)
         ok["match_count"] = int(pipe.mcnt[f].item()) == rc
-        ok["matches"] = np.array_equal(pipe.match[f].cpu().numpy()[:qn], rm)
-        ok["distances"] = np.array_equal(pipe.mdist[f].cpu().numpy()[:qn], rdist)
+        ok["matches"] = np.array_equal(host(pipe.match[f])[:qn], rm)
+        ok["distances"] = np.array_equal(host(pipe.mdist[f])[:qn], rdist)
         bad += [f"frame {f}: {name}" for name, v in ok.items() if not v]
     return {"frames": list(which), "equal": not bad, "mismatch": bad,
             "checked": "keypoints (x, y, response, octave), descriptors, global descriptor, SearchByBoW matches + distances + count vs the predecessor "
@@ -621,13 +641,13 @@ def config_bf16x3(torch, capi, eng, dev, frames, B, chunks_per_step, steps, weig
         # the checker: frames spread over the last chunk against the oracle
         m = O.Model(weights_path)
         s0 = ((pipe.cur - 1) % pipe.n_buf) * B
-        imgs = frames[(i - 1) % n_sets].cpu().numpy()
+        imgs = host(frames[(i - 1) % n_sets])
         kp_equal, dmax, gmax = True, 0.0, 0.0
         checked = sorted(set([0, 1, B - 1] + list(range(0, B, max(1, B // 12)))))
         for f in checked:
             rn, rk, rd, rg, _ = m.extract(imgs[f], N_FEAT, THRESH, N_LEVELS, SCALE)
             n = int(pipe.n_rows[s0 + f].item())
-            k = pipe.kps[s0 + f].cpu().numpy(); d = pipe.desc[s0 + f].cpu().numpy(); g = pipe.glob[f].cpu().numpy()
+            k = host(pipe.kps[s0 + f]); d = host(pipe.desc[s0 + f]); g = host(pipe.glob[f])
             kp_equal = kp_equal and n == rn and all(np.array_equal(k[:n, j], rk[nm]) for j, nm in enumerate(("x", "y", "response"))) \
                 and np.array_equal(k[:n, 3].view(np.int32), rk["octave"])
             if n == rn:
@@ -720,7 +740,7 @@ def config_sequences(torch, pipe, dev, rank, world, dist, pool_frames=64, dry=Fa
     B = pipe.B
     plan = shard.assign_sequences(shard.EUROC_SEQUENCES, world)
     chunks = shard.sequence_chunks(plan[rank], shard.EUROC_SEQUENCES, B)
-    pool = None if dry else torch.from_numpy(make_frames(pool_frames + B, 10_000 * (rank + 1))).to(dev)
+    pool = None if dry else to_device(torch, make_frames(pool_frames + B, 10_000 * (rank + 1)), dev)
     # pair lists of every chunk, built before the timed region (slots rotate with the pipeline's buffers)
     cur, todo = pipe.cur, []
     for ci, (name, f0, n) in enumerate(chunks):
@@ -1009,7 +1029,7 @@ def main() -> None:
             eng.set_option(k, int(v))
         pipe = Pipeline(torch, capi, eng, dev, W_IMG, H_IMG, B)
         # rank r's frames: block r of the global frame index space (hfnet_slam_amd/shard.py: disjoint blocks, no collective)
-        frames = [torch.from_numpy(make_frames(B, (rank * n_sets + s) * B, args.frames)).to(dev) for s in range(n_sets)]
+        frames = [to_device(torch, make_frames(B, (rank * n_sets + s) * B, args.frames), dev) for s in range(n_sets)]
         dev_sync()
     state = {"i": 0}
 
@@ -1048,7 +1068,7 @@ def main() -> None:
     if not dry:
         n = pipe.run_chunk(frames[0], B)
         eng.synchronize()
-        n = n.cpu().numpy()
+        n = host(n)
         if int(n.min()) < N_FEAT and not os.environ.get("BENCH_NO_KP_CHECK"):
             raise SystemExit(f"synthetic frames gave only {int(n.min())} keypoints (< {N_FEAT}): budget not exercised")
     for _ in range(args.warmup):

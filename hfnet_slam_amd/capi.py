@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhfnet_hip.so")
 
 DESC_DIM = 256
-OK, ERR_INVALID_ARG, ERR_WRONG_MODE, ERR_SHAPE, ERR_DEVICE, ERR_IO, ERR_CAPACITY = range(7)
+OK, ERR_INVALID_ARG, ERR_WRONG_MODE, ERR_SHAPE, ERR_DEVICE, ERR_IO, ERR_CAPACITY, ERR_INTERNAL = range(8)
 MODE_LOCAL_AND_GLOBAL, MODE_LOCAL, MODE_LOCAL_AND_INTERMEDIATE, MODE_INTERMEDIATE_TO_GLOBAL = 0, 1, 2, 3
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4"), ("octave", "<i4")])
 

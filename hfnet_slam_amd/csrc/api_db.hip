@@ -14,7 +14,7 @@ using namespace hfnet;
 extern "C" {
 
 // ---------------------------------------------------------------------------------------- KeyFrameDatabase
-int hfnet_db_create(hfnet_engine* eh, int capacity, int dim, hfnet_db** out) {
+int hfnet_db_create(hfnet_engine* eh, int capacity, int dim, hfnet_db** out) try {
     API_GUARD(out, "out");
     *out = nullptr;
     API_GUARD(eh, "engine");
@@ -39,90 +39,95 @@ int hfnet_db_create(hfnet_engine* eh, int capacity, int dim, hfnet_db** out) {
         // is not host-synchronous -- it could land after the first hfnet_db_add had set its occupancy byte
         Engine& e = eh->impl;
         std::lock_guard<std::mutex> lk(e.mu);
+        e.bounce.discard();
         HF_HIP(hipMemsetAsync(db->d_occ, 0, (size_t)capacity, e.stream));
         HF_HIP(hipMemsetAsync(db->d_norm, 0, sizeof(float) * capacity, e.stream));
-        HF_HIP(hipStreamSynchronize(e.stream));
+        HF_TRY(e.sync_host());
     }
     *out = db.release();
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-void hfnet_db_destroy(hfnet_db* db) {
+void hfnet_db_destroy(hfnet_db* db) try {
     if (!db) return;
     (void)hipSetDevice(db->eng->impl.device);
     for (void* p : {(void*)db->d_db, (void*)db->d_occ, (void*)db->d_q, (void*)db->d_scores, (void*)db->d_cand_score, (void*)db->d_cand_slot,
                     (void*)db->d_best, (void*)db->d_n, (void*)db->d_best_bits, (void*)db->d_norm, db->d_hi})
         if (p) (void)dev_free(p);
     delete db;
-}
+} catch (...) { (void)::hfnet::api_exception(); }
 
-int hfnet_db_add(hfnet_db* db, int slot, const float* descriptor) {
+int hfnet_db_add(hfnet_db* db, int slot, const float* descriptor) try {
     API_GUARD(db, "db"); API_GUARD(descriptor, "descriptor");
     if (slot < 0 || slot >= db->capacity) { set_error("db: slot %d outside [0, %d)", slot, db->capacity); return HFNET_ERR_CAPACITY; }
     std::lock_guard<std::mutex> lk(db->mu);
     Engine& e = db->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
+    e.bounce.discard();
     HF_HIP(hipSetDevice(e.device));
     // on the stream the scans run on (created non-blocking: the null stream would not order with it)
-    HF_HIP(hipMemcpyAsync(db->d_db + (size_t)slot * db->dim, descriptor, sizeof(float) * db->dim, hipMemcpyHostToDevice, e.stream));
+    HF_TRY(e.h2d(db->d_db + (size_t)slot * db->dim, descriptor, sizeof(float) * db->dim));
     HF_HIP(hipMemsetAsync(db->d_occ + slot, 1, 1, e.stream));
     db->norm_dirty = true;
-    HF_HIP(hipStreamSynchronize(e.stream));                          // the host buffer may go away
+    HF_TRY(e.sync_host());                          // the host buffer may go away
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-int hfnet_db_erase(hfnet_db* db, int slot) {
+int hfnet_db_erase(hfnet_db* db, int slot) try {
     API_GUARD(db, "db");
     if (slot < 0 || slot >= db->capacity) { set_error("db: slot %d outside [0, %d)", slot, db->capacity); return HFNET_ERR_CAPACITY; }
     std::lock_guard<std::mutex> lk(db->mu);
     Engine& e = db->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
+    e.bounce.discard();
     HF_HIP(hipSetDevice(e.device));
     HF_HIP(hipMemsetAsync(db->d_occ + slot, 0, 1, e.stream));
-    HF_HIP(hipStreamSynchronize(e.stream));
+    HF_TRY(e.sync_host());
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-int hfnet_db_clear(hfnet_db* db) {
+int hfnet_db_clear(hfnet_db* db) try {
     API_GUARD(db, "db");
     std::lock_guard<std::mutex> lk(db->mu);
     Engine& e = db->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
+    e.bounce.discard();
     HF_HIP(hipSetDevice(e.device));
     HF_HIP(hipMemsetAsync(db->d_occ, 0, (size_t)db->capacity, e.stream));
-    HF_HIP(hipStreamSynchronize(e.stream));
+    HF_TRY(e.sync_host());
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slot, float* cand_score, int* n_cand, float* best_score,
-                   float* scores_all) {
+                   float* scores_all) try {
     API_GUARD(db, "db"); API_GUARD(query, "query"); API_GUARD(cand_slot, "cand_slot"); API_GUARD(cand_score, "cand_score"); API_GUARD(n_cand, "n_cand");
     if (mode != 0 && mode != 1) { set_error("db: mode must be 0 or 1"); return HFNET_ERR_INVALID_ARG; }
     std::lock_guard<std::mutex> lk(db->mu);   // KeyFrameDatabase.cc:82 holds mMutex over the scan
     Engine& e = db->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
+    e.bounce.discard();
     HF_HIP(hipSetDevice(e.device));
-    HF_HIP(hipMemcpyAsync(db->d_q, query, sizeof(float) * db->dim, hipMemcpyHostToDevice, e.stream));
+    HF_TRY(e.h2d(db->d_q, query, sizeof(float) * db->dim));
     HF_LAUNCH(&e, e.stream, "db_scores", launch_db_scores(db->d_q, db->d_db, db->d_occ, db->capacity, db->dim, db->d_scores, db->d_best_bits, e.stream));
     HF_LAUNCH(&e, e.stream, "db_filter", launch_db_filter(db->d_scores, db->capacity, mode, db->d_best_bits, 4 * db_scan_workgroups(db->capacity), db->d_cand_slot, db->d_cand_score, db->d_n, db->d_best, 1, e.stream));
     int n = 0;
     float best = 0.f;
-    HF_HIP(hipMemcpyAsync(&n, db->d_n, sizeof(int), hipMemcpyDeviceToHost, e.stream));
-    HF_HIP(hipMemcpyAsync(&best, db->d_best, sizeof(float), hipMemcpyDeviceToHost, e.stream));
-    if (scores_all) HF_HIP(hipMemcpyAsync(scores_all, db->d_scores, sizeof(float) * db->capacity, hipMemcpyDeviceToHost, e.stream));
-    HF_HIP(hipStreamSynchronize(e.stream));
+    HF_TRY(e.d2h(&n, db->d_n, sizeof(int)));
+    HF_TRY(e.d2h(&best, db->d_best, sizeof(float)));
+    if (scores_all) HF_TRY(e.d2h(scores_all, db->d_scores, sizeof(float) * db->capacity));
+    HF_TRY(e.sync_host());
     if (n > 0) {
-        HF_HIP(hipMemcpyAsync(cand_slot, db->d_cand_slot, sizeof(int32_t) * n, hipMemcpyDeviceToHost, e.stream));
-        HF_HIP(hipMemcpyAsync(cand_score, db->d_cand_score, sizeof(float) * n, hipMemcpyDeviceToHost, e.stream));
-        HF_HIP(hipStreamSynchronize(e.stream));
+        HF_TRY(e.d2h(cand_slot, db->d_cand_slot, sizeof(int32_t) * n));
+        HF_TRY(e.d2h(cand_score, db->d_cand_score, sizeof(float) * n));
+        HF_TRY(e.sync_host());
     }
     *n_cand = n;
     if (best_score) *best_score = best;
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int mode, int32_t* cand_slot, float* cand_score, int32_t* n_cand,
-                         float* best_score, float* scores_all) {
+                         float* best_score, float* scores_all) try {
     API_GUARD(db, "db");
     if (n_queries < 0) { set_error("db: n_queries < 0"); return HFNET_ERR_INVALID_ARG; }
     if (n_queries == 0) return HFNET_OK;
@@ -131,6 +136,7 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
     std::lock_guard<std::mutex> lk(db->mu);
     Engine& e = db->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
+    e.bounce.discard();
     const bool gemm = n_queries >= e.opt.db_gemm_min_queries && db->dim % 512 == 0;
     if (!gemm && db->dim > 4096) { set_error("db: the exact batched scan supports dim <= 4096"); return HFNET_ERR_INVALID_ARG; }
     HF_HIP(hipSetDevice(e.device));
@@ -151,7 +157,7 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
     float* d_q = e.m_a.as<float>(); float* d_scores = e.m_s.as<float>(); float* d_cs = e.m_f0.as<float>();
     int32_t* d_slot = e.m_i0.as<int32_t>(); int* d_n = e.m_cnt.as<int>(); float* d_best = e.m_qn.as<float>();
     unsigned int* d_bits = e.m_key.as<unsigned int>();
-    HF_HIP(hipMemcpyAsync(d_q, queries, sizeof(float) * Q * db->dim, hipMemcpyHostToDevice, e.stream));
+    HF_TRY(e.h2d(d_q, queries, sizeof(float) * Q * db->dim));
     if (gemm) {
         if (db->norm_dirty) {
             HF_LAUNCH(&e, e.stream, "db_norm", launch_db_prep_hi(db->d_db, db->capacity, db->dim, db->d_norm, db->d_hi, e.stream));
@@ -164,18 +170,18 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
         HF_LAUNCH(&e, e.stream, "db_scores_batch", launch_db_scores_batch(d_q, n_queries, db->d_db, db->d_occ, db->capacity, db->dim, d_scores, d_bits, e.stream));
     }
     HF_LAUNCH(&e, e.stream, "db_filter", launch_db_filter(d_scores, db->capacity, mode, d_bits, parts, d_slot, d_cs, d_n, d_best, n_queries, e.stream));
-    HF_HIP(hipMemcpyAsync(n_cand, d_n, sizeof(int32_t) * Q, hipMemcpyDeviceToHost, e.stream));
-    if (best_score) HF_HIP(hipMemcpyAsync(best_score, d_best, sizeof(float) * Q, hipMemcpyDeviceToHost, e.stream));
-    if (scores_all) HF_HIP(hipMemcpyAsync(scores_all, d_scores, sizeof(float) * Q * cap, hipMemcpyDeviceToHost, e.stream));
-    HF_HIP(hipStreamSynchronize(e.stream));
+    HF_TRY(e.d2h(n_cand, d_n, sizeof(int32_t) * Q));
+    if (best_score) HF_TRY(e.d2h(best_score, d_best, sizeof(float) * Q));
+    if (scores_all) HF_TRY(e.d2h(scores_all, d_scores, sizeof(float) * Q * cap));
+    HF_TRY(e.sync_host());
     for (size_t qi = 0; qi < Q; ++qi) {
         const int n = n_cand[qi];
         if (n <= 0) continue;
-        HF_HIP(hipMemcpyAsync(cand_slot + qi * cap, d_slot + qi * cap, sizeof(int32_t) * n, hipMemcpyDeviceToHost, e.stream));
-        HF_HIP(hipMemcpyAsync(cand_score + qi * cap, d_cs + qi * cap, sizeof(float) * n, hipMemcpyDeviceToHost, e.stream));
+        HF_TRY(e.d2h(cand_slot + qi * cap, d_slot + qi * cap, sizeof(int32_t) * n));
+        HF_TRY(e.d2h(cand_score + qi * cap, d_cs + qi * cap, sizeof(float) * n));
     }
-    HF_HIP(hipStreamSynchronize(e.stream));
+    HF_TRY(e.sync_host());
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 }  // extern "C"

@@ -15,7 +15,7 @@ using namespace hfnet;
 extern "C" {
 
 // ---------------------------------------------------------------------------------------- BaseModel
-int hfnet_model_create(hfnet_engine* e, hfnet_mode mode, int height, int width, int max_keypoints, hfnet_model** out) {
+int hfnet_model_create(hfnet_engine* e, hfnet_mode mode, int height, int width, int max_keypoints, hfnet_model** out) try {
     API_GUARD(out, "out");
     *out = nullptr;
     API_GUARD(e, "engine");
@@ -24,7 +24,8 @@ int hfnet_model_create(hfnet_engine* e, hfnet_mode mode, int height, int width, 
     if (max_keypoints < 1) max_keypoints = 1;
     if (max_keypoints > HFNET_MAX_KEYPOINTS) { set_error("max_keypoints %d > %d", max_keypoints, HFNET_MAX_KEYPOINTS); return HFNET_ERR_CAPACITY; }
     HF_HIP(hipSetDevice(e->impl.device));
-    std::unique_ptr<hfnet_model> m(new hfnet_model());
+    struct Cleanup { void operator()(hfnet_model* d) const { hfnet_model_destroy(d); } };      // (frees whatever had been allocated when a later step fails)
+    std::unique_ptr<hfnet_model, Cleanup> m(new hfnet_model());
     m->eng = e; m->mode = mode; m->height = height; m->width = width; m->max_keypoints = max_keypoints;
     NetConfig c;
     c.n_levels = 1; c.width[0] = width; c.height[0] = height; c.batch = 1; c.max_keypoints = max_keypoints;
@@ -38,22 +39,36 @@ int hfnet_model_create(hfnet_engine* e, hfnet_mode mode, int height, int width, 
         HF_TRY(dalloc(m->net.allocs, &m->d_desc, (size_t)max_keypoints * HFNET_DESC_DIM));
         HF_TRY(dalloc(m->net.allocs, &m->d_n, 2));
     }
+    {
+        auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+        const Engine& eng = e->impl;
+        const size_t img = c.local ? up((size_t)height * width) : 0;
+        const size_t inter = sizeof(float) * (size_t)(c.from_intermediate ? height * width : (height / 8) * (width / 8)) * eng.w.c_local;
+        const size_t aux = up(std::max(inter, sizeof(float) * (size_t)eng.w.global_dim));
+        m->o_n = img; m->o_aux = m->o_n + 256; m->o_kps = m->o_aux + aux;
+        m->o_desc = m->o_kps + up(sizeof(hfnet_keypoint) * (size_t)max_keypoints);
+        m->stage_bytes = m->o_desc + up(sizeof(float) * HFNET_DESC_DIM * (size_t)max_keypoints);
+        void* hp = nullptr;
+        HF_HIP(hipHostMalloc(&hp, m->stage_bytes, hipHostMallocDefault));
+        m->h_stage = (unsigned char*)hp;
+    }
     m->valid = true;
     *out = m.release();
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-void hfnet_model_destroy(hfnet_model* m) {
+void hfnet_model_destroy(hfnet_model* m) try {
     if (!m) return;
     (void)hipSetDevice(m->eng->impl.device);
+    if (m->h_stage) { if (m->net.stream) (void)hipStreamSynchronize(m->net.stream); (void)hipHostFree(m->h_stage); }
     delete m;
-}
+} catch (...) { (void)::hfnet::api_exception(); }
 
 int hfnet_model_is_valid(const hfnet_model* m) { return m && m->valid ? 1 : 0; }
 int hfnet_model_mode(const hfnet_model* m) { return m ? (int)m->mode : -1; }
 
 int hfnet_model_detect(hfnet_model* m, const uint8_t* image, int row_stride, int n_keypoints, float threshold, hfnet_keypoint* kps,
-                       float* local_desc, float* aux, int* n_out) {
+                       float* local_desc, float* aux, int* n_out) try {
     API_GUARD(m, "model");
     if (n_out) *n_out = 0;
     if (!m->valid) { set_error("model is not valid"); return HFNET_ERR_INVALID_ARG; }
@@ -67,7 +82,10 @@ int hfnet_model_detect(hfnet_model* m, const uint8_t* image, int row_stride, int
     std::lock_guard<std::mutex> lk(m->mu);
     Net& net = m->net;
     HF_HIP(hipSetDevice(m->eng->impl.device));
-    HF_HIP(hipMemcpy2DAsync(m->d_image, m->width, image, row_stride, m->width, m->height, hipMemcpyHostToDevice, net.stream));
+    // the image goes up through the model's pinned block (the caller's rows are read by the host only: see hfnet_model::h_stage)
+    if (row_stride == m->width) std::memcpy(m->h_stage, image, (size_t)m->width * m->height);
+    else for (int y = 0; y < m->height; ++y) std::memcpy(m->h_stage + (size_t)y * m->width, image + (size_t)y * row_stride, (size_t)m->width);
+    HF_HIP(hipMemcpyAsync(m->d_image, m->h_stage, (size_t)m->width * m->height, hipMemcpyHostToDevice, net.stream));
     ImageSet imgs;
     std::memset(&imgs, 0, sizeof imgs);
     imgs.ptr[0] = m->d_image; imgs.row_stride[0] = m->width; imgs.frame_stride[0] = (long long)m->width * m->height;
@@ -85,30 +103,39 @@ int hfnet_model_detect(hfnet_model* m, const uint8_t* image, int row_stride, int
     gs.lv[0].H = net.lp[0].Hc; gs.lv[0].W = net.lp[0].Wc; gs.lv[0].Ho = net.lp[0].h[7]; gs.lv[0].Wo = net.lp[0].w[7];
     gs.lv[0].in_off = net.pix_cell[0];
     HF_LAUNCH(&m->eng->impl, net.stream, "sample", launch_sample(sa, gs, net.stream));
-    int n = 0;
-    unsigned int faults = 0;
-    HF_HIP(hipMemcpyAsync(&n, m->d_n, sizeof(int), hipMemcpyDeviceToHost, net.stream));
-    if (net.dev_fault) HF_HIP(hipMemcpyAsync(&faults, net.dev_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, net.stream));
+    int* h_n = (int*)(m->h_stage + m->o_n);                      // [0] keypoints, [1] fault word
+    h_n[0] = 0; h_n[1] = 0;
+    float* h_aux = (float*)(m->h_stage + m->o_aux);
+    size_t aux_bytes = 0;
+    HF_HIP(hipMemcpyAsync(h_n, m->d_n, sizeof(int), hipMemcpyDeviceToHost, net.stream));
+    if (net.dev_fault) HF_HIP(hipMemcpyAsync(h_n + 1, net.dev_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, net.stream));
     if (m->mode == HFNET_IMAGE_TO_LOCAL_AND_GLOBAL) {
-        HF_HIP(hipMemcpyAsync(aux, net.global_out, sizeof(float) * m->eng->impl.w.global_dim, hipMemcpyDeviceToHost, net.stream));
+        aux_bytes = sizeof(float) * m->eng->impl.w.global_dim;
+        HF_HIP(hipMemcpyAsync(h_aux, net.global_out, aux_bytes, hipMemcpyDeviceToHost, net.stream));
     } else if (m->mode == HFNET_IMAGE_TO_LOCAL_AND_INTERMEDIATE) {
         const long long P = (long long)net.lp[0].h[7] * net.lp[0].w[7];
         const int C = m->eng->impl.w.c_local;
         HF_LAUNCH(&m->eng->impl, net.stream, "permute", launch_permute_channels(net.act[7], net.inter_logical, P, C, 1, net.stream));
-        HF_HIP(hipMemcpyAsync(aux, net.inter_logical, sizeof(float) * P * C, hipMemcpyDeviceToHost, net.stream));
+        aux_bytes = sizeof(float) * P * C;
+        HF_HIP(hipMemcpyAsync(h_aux, net.inter_logical, aux_bytes, hipMemcpyDeviceToHost, net.stream));
     }
     HF_HIP(hipStreamSynchronize(net.stream));
+    const int n = std::min(std::max(h_n[0], 0), n_keypoints);
+    const unsigned int faults = (unsigned int)h_n[1];
     if (faults) { set_error("device-side bound hit (fault bits 0x%x): inconsistent device state, results discarded", faults); return HFNET_ERR_DEVICE; }
+    if (aux_bytes) std::memcpy(aux, h_aux, aux_bytes);
     if (n > 0) {
-        HF_HIP(hipMemcpyAsync(kps, m->d_kps, sizeof(hfnet_keypoint) * n, hipMemcpyDeviceToHost, net.stream));
-        HF_HIP(hipMemcpyAsync(local_desc, m->d_desc, sizeof(float) * HFNET_DESC_DIM * n, hipMemcpyDeviceToHost, net.stream));
+        HF_HIP(hipMemcpyAsync(m->h_stage + m->o_kps, m->d_kps, sizeof(hfnet_keypoint) * n, hipMemcpyDeviceToHost, net.stream));
+        HF_HIP(hipMemcpyAsync(m->h_stage + m->o_desc, m->d_desc, sizeof(float) * HFNET_DESC_DIM * n, hipMemcpyDeviceToHost, net.stream));
         HF_HIP(hipStreamSynchronize(net.stream));
+        std::memcpy(kps, m->h_stage + m->o_kps, sizeof(hfnet_keypoint) * n);
+        std::memcpy(local_desc, m->h_stage + m->o_desc, sizeof(float) * HFNET_DESC_DIM * n);
     }
     *n_out = n;
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-int hfnet_model_detect_global(hfnet_model* m, const float* intermediate, float* global_desc) {
+int hfnet_model_detect_global(hfnet_model* m, const float* intermediate, float* global_desc) try {
     API_GUARD(m, "model");
     if (!m->valid) { set_error("model is not valid"); return HFNET_ERR_INVALID_ARG; }
     if (m->mode != HFNET_INTERMEDIATE_TO_GLOBAL) { set_error("Detect(intermediate, global) called on an image model"); return HFNET_ERR_WRONG_MODE; }
@@ -119,26 +146,30 @@ int hfnet_model_detect_global(hfnet_model* m, const float* intermediate, float* 
     HF_HIP(hipSetDevice(eng.device));
     const long long P = (long long)m->height * m->width;
     const int C = eng.w.c_local;
-    HF_HIP(hipMemcpyAsync(net.inter_logical, intermediate, sizeof(float) * P * C, hipMemcpyHostToDevice, net.stream));
+    float* h_aux = (float*)(m->h_stage + m->o_aux);               // (pinned block: see hfnet_model::h_stage)
+    std::memcpy(h_aux, intermediate, sizeof(float) * P * C);
+    HF_HIP(hipMemcpyAsync(net.inter_logical, h_aux, sizeof(float) * P * C, hipMemcpyHostToDevice, net.stream));
     HF_LAUNCH(&eng, net.stream, "permute", launch_permute_channels(net.inter_logical, net.act[7], P, C, 0, net.stream));
     ImageSet imgs;
     std::memset(&imgs, 0, sizeof imgs);
     TopkBudget budget;
     std::memset(&budget, 0, sizeof budget);
     HF_TRY(net.forward(imgs, 0.f, budget));
-    HF_HIP(hipMemcpyAsync(global_desc, net.global_out, sizeof(float) * eng.w.global_dim, hipMemcpyDeviceToHost, net.stream));
+    HF_HIP(hipStreamSynchronize(net.stream));                    // (the upload has left the block before the result overwrites it)
+    HF_HIP(hipMemcpyAsync(h_aux, net.global_out, sizeof(float) * eng.w.global_dim, hipMemcpyDeviceToHost, net.stream));
     HF_HIP(hipStreamSynchronize(net.stream));
+    std::memcpy(global_desc, h_aux, sizeof(float) * eng.w.global_dim);
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-int hfnet_model_device_faults(hfnet_model* m, unsigned int* bits) {
+int hfnet_model_device_faults(hfnet_model* m, unsigned int* bits) try {
     API_GUARD(m, "model"); API_GUARD(bits, "bits");
     std::lock_guard<std::mutex> lk(m->mu);
     HF_HIP(hipSetDevice(m->eng->impl.device));
     return m->net.read_faults(bits);
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-int hfnet_model_tap(hfnet_model* m, int tap, float* out, size_t capacity, size_t* count) {
+int hfnet_model_tap(hfnet_model* m, int tap, float* out, size_t capacity, size_t* count) try {
     API_GUARD(m, "model"); API_GUARD(out, "out"); API_GUARD(count, "count");
     std::lock_guard<std::mutex> lk(m->mu);
     HF_HIP(hipSetDevice(m->eng->impl.device));
@@ -148,11 +179,11 @@ int hfnet_model_tap(hfnet_model* m, int tap, float* out, size_t capacity, size_t
     if (v.size() > capacity) { set_error("tap %d needs %zu floats, buffer holds %zu", tap, v.size(), capacity); return HFNET_ERR_CAPACITY; }
     std::memcpy(out, v.data(), v.size() * sizeof(float));
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 // ---------------------------------------------------------------------------------------- HFextractor
 int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_features, float threshold, float scale_factor, int n_levels,
-                           int max_batch, hfnet_extractor** out) {
+                           int max_batch, hfnet_extractor** out) try {
     API_GUARD(out, "out");
     *out = nullptr;
     API_GUARD(e, "engine");
@@ -191,10 +222,10 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
         HF_TRY(dalloc(x->allocs, &x->d_ialpha[l], ia.size()));
         HF_TRY(dalloc(x->allocs, &x->d_yofs[l], yofs.size()));
         HF_TRY(dalloc(x->allocs, &x->d_ibeta[l], ib.size()));
-        HF_HIP(hipMemcpy(x->d_xofs[l], xofs.data(), xofs.size() * sizeof(int), hipMemcpyHostToDevice));
-        HF_HIP(hipMemcpy(x->d_ialpha[l], ia.data(), ia.size() * sizeof(short), hipMemcpyHostToDevice));
-        HF_HIP(hipMemcpy(x->d_yofs[l], yofs.data(), yofs.size() * sizeof(int), hipMemcpyHostToDevice));
-        HF_HIP(hipMemcpy(x->d_ibeta[l], ib.data(), ib.size() * sizeof(short), hipMemcpyHostToDevice));
+        HF_HIP(copy_h2d_blocking(x->d_xofs[l], xofs.data(), xofs.size() * sizeof(int)));
+        HF_HIP(copy_h2d_blocking(x->d_ialpha[l], ia.data(), ia.size() * sizeof(short)));
+        HF_HIP(copy_h2d_blocking(x->d_yofs[l], yofs.data(), yofs.size() * sizeof(int)));
+        HF_HIP(copy_h2d_blocking(x->d_ibeta[l], ib.data(), ib.size() * sizeof(short)));
     }
     HF_TRY(dalloc(x->allocs, &x->d_kps, (size_t)max_batch * n_features));
     HF_TRY(dalloc(x->allocs, &x->d_desc, (size_t)max_batch * n_features * HFNET_DESC_DIM));
@@ -223,9 +254,9 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
     }
     *out = x.release();
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-void hfnet_extractor_destroy(hfnet_extractor* x) {
+void hfnet_extractor_destroy(hfnet_extractor* x) try {
     if (!x) return;
     (void)hipSetDevice(x->eng->impl.device);
     // (a single-frame call returns when its results are in the caller's buffers, which is before its graph has retired)
@@ -242,9 +273,9 @@ void hfnet_extractor_destroy(hfnet_extractor* x) {
     if (x->pipe.s_up) (void)hipStreamDestroy(x->pipe.s_up);
     if (x->pipe.s_down) (void)hipStreamDestroy(x->pipe.s_down);
     delete x;
-}
+} catch (...) { (void)::hfnet::api_exception(); }
 
-int hfnet_extractor_tables(const hfnet_extractor* x, float* scale_factors, int* features_per_level, int* level_width, int* level_height) {
+int hfnet_extractor_tables(const hfnet_extractor* x, float* scale_factors, int* features_per_level, int* level_width, int* level_height) try {
     API_GUARD(x, "extractor");
     for (int l = 0; l < x->n_levels; ++l) {
         if (scale_factors) scale_factors[l] = x->scale_factors[l];
@@ -253,7 +284,7 @@ int hfnet_extractor_tables(const hfnet_extractor* x, float* scale_factors, int* 
         if (level_height) level_height[l] = x->level_h[l];
     }
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 // one chunk of nb <= max_batch frames; all pointers device pointers except when host_* is given
 static int extract_chunk(hfnet_extractor* x, int nb, const uint8_t* d_images, int row_stride, long long frame_stride, hfnet_keypoint* d_kps,
@@ -394,7 +425,7 @@ static bool host_range_registered(const void* p, size_t bytes) {
     --it;
     return (uintptr_t)p + bytes <= it->first + it->second;
 }
-int hfnet_host_register(void* ptr, size_t bytes) {
+int hfnet_host_register(void* ptr, size_t bytes) try {
     if (!ptr || !bytes) { set_error("hfnet_host_register: null range"); return HFNET_ERR_INVALID_ARG; }
     std::lock_guard<std::mutex> lk(g_reg_mu);
     auto it = g_registered.upper_bound((uintptr_t)ptr + bytes - 1);
@@ -405,15 +436,15 @@ int hfnet_host_register(void* ptr, size_t bytes) {
     HF_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
     g_registered[(uintptr_t)ptr] = bytes;
     return HFNET_OK;
-}
-int hfnet_host_unregister(void* ptr) {
+} catch (...) { return ::hfnet::api_exception(); }
+int hfnet_host_unregister(void* ptr) try {
     std::lock_guard<std::mutex> lk(g_reg_mu);
     auto it = g_registered.find((uintptr_t)ptr);
     if (it == g_registered.end()) { set_error("hfnet_host_unregister: not a registered range"); return HFNET_ERR_INVALID_ARG; }
     HF_HIP(hipHostUnregister(ptr));        // (first: on failure the range is still page-locked AND still known here, a retry can succeed)
     g_registered.erase(it);
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 static int host_pipe_init(hfnet_extractor* x) {
     hfnet_extractor::HostPipe& p = x->pipe;
@@ -578,7 +609,7 @@ static int extract_host_pipelined(hfnet_extractor* x, int f0, int n_frames, cons
     return HFNET_OK;
 }
 
-int hfnet_extractor_attach_store(hfnet_extractor* x, hfnet_store* s, int first_slot) {
+int hfnet_extractor_attach_store(hfnet_extractor* x, hfnet_store* s, int first_slot) try {
     API_GUARD(x, "extractor");
     std::lock_guard<std::mutex> lk(x->mu);
     if (s) {
@@ -589,10 +620,10 @@ int hfnet_extractor_attach_store(hfnet_extractor* x, hfnet_store* s, int first_s
     }
     x->att_store = s; x->att_first = s ? first_slot : 0;
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_t* images, int row_stride, size_t frame_stride,
-                                  hfnet_keypoint* kps, float* local_desc, float* global_desc, int* n_out, int on_device) {
+                                  hfnet_keypoint* kps, float* local_desc, float* global_desc, int* n_out, int on_device) try {
     API_GUARD(x, "extractor");
     if (n_frames < 0) { set_error("n_frames < 0"); return HFNET_ERR_INVALID_ARG; }
     if (n_frames == 0) return HFNET_OK;
@@ -694,25 +725,25 @@ int hfnet_extractor_extract_batch(hfnet_extractor* x, int n_frames, const uint8_
     }
     if (on_device) HF_HIP(eng.note_extract(st));
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-int hfnet_extractor_device_faults(hfnet_extractor* x, unsigned int* bits) {
+int hfnet_extractor_device_faults(hfnet_extractor* x, unsigned int* bits) try {
     API_GUARD(x, "extractor"); API_GUARD(bits, "bits");
     std::lock_guard<std::mutex> lk(x->mu);
     HF_HIP(hipSetDevice(x->eng->impl.device));
     return x->net.read_faults(bits);
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-int hfnet_extractor_last_timing(hfnet_extractor* x, double* us, int n) {
+int hfnet_extractor_last_timing(hfnet_extractor* x, double* us, int n) try {
     API_GUARD(x, "extractor"); API_GUARD(us, "us");
     std::lock_guard<std::mutex> lk(x->mu);
     if (x->t_last[5] < 0) { set_error("no latency-path call yet"); return HFNET_ERR_INVALID_ARG; }
     for (int i = 0; i < n && i < 6; ++i) us[i] = x->t_last[i];
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 int hfnet_extractor_extract(hfnet_extractor* x, const uint8_t* image, int row_stride, hfnet_keypoint* kps, float* local_desc,
-                            float* global_desc, int* n_out, int* n_per_level) {
+                            float* global_desc, int* n_out, int* n_per_level) try {
     if (n_out) *n_out = -1;
     API_GUARD(x, "extractor"); API_GUARD(n_out, "n_out");
     if (!image) { set_error("empty image"); return HFNET_ERR_INVALID_ARG; }   // HFextractor.cc:145 returns -1
@@ -722,9 +753,9 @@ int hfnet_extractor_extract(hfnet_extractor* x, const uint8_t* image, int row_st
     if (n_per_level) {
         std::lock_guard<std::mutex> lk(x->mu);
         if (x->h_pin && x->pinned_frames >= 1) std::memcpy(n_per_level, x->h_pin + x->pin_nl_last, sizeof(int) * x->n_levels);   // came down with the frame
-        else HF_HIP(hipMemcpy(n_per_level, x->d_n_level, sizeof(int) * x->n_levels, hipMemcpyDeviceToHost));
+        else HF_HIP(copy_d2h_blocking(n_per_level, x->d_n_level, sizeof(int) * x->n_levels));
     }
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 }  // extern "C"

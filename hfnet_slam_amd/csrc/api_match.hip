@@ -16,7 +16,7 @@ namespace hfnet {
 int stage_rows(Engine& e, DevMem& m, const float* src, size_t count, int on_device, const float** out) {
     if (on_device) { *out = src; return HFNET_OK; }
     HF_TRY(m.ensure(std::max<size_t>(count, 1) * sizeof(float)));
-    if (count) HF_HIP(hipMemcpyAsync(m.p, src, count * sizeof(float), hipMemcpyHostToDevice, e.stream));
+    if (count) HF_TRY(e.h2d(m.p, src, count * sizeof(float)));
     *out = m.as<float>();
     return HFNET_OK;
 }
@@ -26,21 +26,22 @@ extern "C" {
 
 // ---------------------------------------------------------------------------------------- Matcher
 
-int hfnet_descriptor_distance(hfnet_engine* eh, const float* a, const float* b, int dim, float* out) {
+int hfnet_descriptor_distance(hfnet_engine* eh, const float* a, const float* b, int dim, float* out) try {
     API_GUARD(eh, "engine"); API_GUARD(a, "a"); API_GUARD(b, "b"); API_GUARD(out, "out");
     if (dim <= 0) { set_error("dim <= 0"); return HFNET_ERR_INVALID_ARG; }
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
+    e.bounce.discard();
     HF_HIP(hipSetDevice(e.device));
     const float *da, *db;
     HF_TRY(stage_rows(e, e.m_a, a, dim, 0, &da));
     HF_TRY(stage_rows(e, e.m_b, b, dim, 0, &db));
     HF_TRY(e.m_f0.ensure(sizeof(float)));
     HF_LAUNCH(&e, e.stream, "descriptor_distance", launch_descriptor_distance(da, db, dim, e.m_f0.as<float>(), e.stream));
-    HF_HIP(hipMemcpyAsync(out, e.m_f0.p, sizeof(float), hipMemcpyDeviceToHost, e.stream));
-    HF_HIP(hipStreamSynchronize(e.stream));
+    HF_TRY(e.d2h(out, e.m_f0.p, sizeof(float)));
+    HF_TRY(e.sync_host());
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 // scratch for n_pairs x (max_rows x max_rows) similarity matrices, norms, keys and the pair descriptors
 // neither matcher stores an n x m matrix: SearchByBoW keeps candidate slots per train row, SearchForTriangulation
@@ -97,12 +98,13 @@ static int bow_scratch(Engine& e, int n_pairs, int max_rows, int dim, bool trian
 }
 
 int hfnet_match_search_by_bow(hfnet_engine* eh, const float* query, int n_query, const float* train, int n_train, int dim, float th_low,
-                              int32_t* match_q2t, float* dist, int* n_matches, int on_device) {
+                              int32_t* match_q2t, float* dist, int* n_matches, int on_device) try {
     API_GUARD(eh, "engine"); API_GUARD(match_q2t, "match_q2t"); API_GUARD(dist, "dist"); API_GUARD(n_matches, "n_matches");
     if (n_query < 0 || n_train < 0 || dim <= 0 || dim % 64) { set_error("bad matcher sizes (dim must be a multiple of 64)"); return HFNET_ERR_INVALID_ARG; }
     if ((n_query && !query) || (n_train && !train)) { set_error("null descriptor matrix"); return HFNET_ERR_INVALID_ARG; }
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
+    e.bounce.discard();
     HF_HIP(hipSetDevice(e.device));
     if (on_device) HF_HIP(e.wait_extract());
     if (n_query == 0) { if (!on_device) *n_matches = 0; else HF_HIP(hipMemsetAsync(n_matches, 0, sizeof(int), e.stream)); return HFNET_OK; }
@@ -119,17 +121,17 @@ int hfnet_match_search_by_bow(hfnet_engine* eh, const float* query, int n_query,
     BowPair P;
     P.q = dq; P.t = dt; P.St = e.m_s.as<float>(); P.qn = e.m_qn.as<float>(); P.tn = e.m_tn.as<float>(); P.qkey = e.m_key.as<unsigned long long>();
     P.match = d_match; P.dist = d_dist; P.cnt = d_cnt; P.nq = n_query; P.nt = n_train;
-    HF_HIP(hipMemcpyAsync(e.m_pairs.p, &P, sizeof P, hipMemcpyHostToDevice, e.stream));
-    HF_HIP(hipStreamSynchronize(e.stream));     // P lives on this stack frame
+    HF_TRY(e.h2d(e.m_pairs.p, &P, sizeof P));
+    HF_TRY(e.sync_host());     // P lives on this stack frame
     HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), 1, max_rows, dim, th_low, e.m_s.p, e.stream, e.opt.match_screen_bf16));
     if (!on_device) {
-        HF_HIP(hipMemcpyAsync(match_q2t, d_match, sizeof(int32_t) * n_query, hipMemcpyDeviceToHost, e.stream));
-        HF_HIP(hipMemcpyAsync(dist, d_dist, sizeof(float) * n_query, hipMemcpyDeviceToHost, e.stream));
-        HF_HIP(hipMemcpyAsync(n_matches, d_cnt, sizeof(int), hipMemcpyDeviceToHost, e.stream));
-        HF_HIP(hipStreamSynchronize(e.stream));
+        HF_TRY(e.d2h(match_q2t, d_match, sizeof(int32_t) * n_query));
+        HF_TRY(e.d2h(dist, d_dist, sizeof(float) * n_query));
+        HF_TRY(e.d2h(n_matches, d_cnt, sizeof(int)));
+        HF_TRY(e.sync_host());
     }
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 static int match_pairs_batch(hfnet_engine* eh, int n_pairs, const float* desc_base, size_t set_stride, const int32_t* n_rows, int n_sets,
                              const int32_t* query_set, const int32_t* train_set, int max_rows, int dim, float th, int32_t* match_q2t,
@@ -143,6 +145,7 @@ static int match_pairs_batch(hfnet_engine* eh, int n_pairs, const float* desc_ba
     if (!triangulation) API_GUARD(dist, "dist");
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
+    e.bounce.discard();
     HF_HIP(hipSetDevice(e.device));
     if (on_device) HF_HIP(e.wait_extract());
     HF_TRY(bow_scratch(e, n_pairs, max_rows, dim, triangulation));
@@ -157,11 +160,11 @@ static int match_pairs_batch(hfnet_engine* eh, int n_pairs, const float* desc_ba
         HF_TRY(e.m_b.ensure(sizeof(int32_t) * ((size_t)n_sets + 2 * (size_t)n_pairs)));
         HF_TRY(e.m_i0.ensure(sizeof(int32_t) * (size_t)n_pairs * max_rows)); HF_TRY(e.m_f0.ensure(sizeof(float) * (size_t)n_pairs * max_rows));
         HF_TRY(e.m_cnt.ensure(sizeof(int32_t) * n_pairs));
-        HF_HIP(hipMemcpyAsync(e.m_a.p, desc_base, sizeof(float) * (size_t)n_sets * set_stride, hipMemcpyHostToDevice, e.stream));
+        HF_TRY(e.h2d(e.m_a.p, desc_base, sizeof(float) * (size_t)n_sets * set_stride));
         int32_t* ib = e.m_b.as<int32_t>();
-        HF_HIP(hipMemcpyAsync(ib, n_rows, sizeof(int32_t) * n_sets, hipMemcpyHostToDevice, e.stream));
-        HF_HIP(hipMemcpyAsync(ib + n_sets, query_set, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, e.stream));
-        HF_HIP(hipMemcpyAsync(ib + n_sets + n_pairs, train_set, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, e.stream));
+        HF_TRY(e.h2d(ib, n_rows, sizeof(int32_t) * n_sets));
+        HF_TRY(e.h2d(ib + n_sets, query_set, sizeof(int32_t) * n_pairs));
+        HF_TRY(e.h2d(ib + n_sets + n_pairs, train_set, sizeof(int32_t) * n_pairs));
         d_base = e.m_a.as<float>(); d_rows = ib; d_qs = ib + n_sets; d_ts = ib + n_sets + n_pairs;
         d_match = e.m_i0.as<int32_t>(); d_dist = e.m_f0.as<float>(); d_cnt = e.m_cnt.as<int32_t>();
         // rows at or beyond a pair's query count are not written by the kernels: the caller gets -1 there (and 0xFF.. = NaN
@@ -182,30 +185,30 @@ static int match_pairs_batch(hfnet_engine* eh, int n_pairs, const float* desc_ba
         HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, th, e.m_s.p, e.stream, e.opt.match_screen_bf16));
     }
     if (!on_device) {
-        HF_HIP(hipMemcpyAsync(match_q2t, d_match, sizeof(int32_t) * (size_t)n_pairs * max_rows, hipMemcpyDeviceToHost, e.stream));
-        if (!triangulation) HF_HIP(hipMemcpyAsync(dist, d_dist, sizeof(float) * (size_t)n_pairs * max_rows, hipMemcpyDeviceToHost, e.stream));
-        HF_HIP(hipMemcpyAsync(n_matches, d_cnt, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToHost, e.stream));
-        HF_HIP(hipStreamSynchronize(e.stream));
+        HF_TRY(e.d2h(match_q2t, d_match, sizeof(int32_t) * (size_t)n_pairs * max_rows));
+        if (!triangulation) HF_TRY(e.d2h(dist, d_dist, sizeof(float) * (size_t)n_pairs * max_rows));
+        HF_TRY(e.d2h(n_matches, d_cnt, sizeof(int32_t) * n_pairs));
+        HF_TRY(e.sync_host());
     }
     return HFNET_OK;
 }
 
 int hfnet_match_search_by_bow_batch(hfnet_engine* eh, int n_pairs, const float* desc_base, size_t set_stride, const int32_t* n_rows, int n_sets,
                                     const int32_t* query_set, const int32_t* train_set, int max_rows, int dim, float th_low, int32_t* match_q2t,
-                                    float* dist, int32_t* n_matches, int on_device) {
+                                    float* dist, int32_t* n_matches, int on_device) try {
     return match_pairs_batch(eh, n_pairs, desc_base, set_stride, n_rows, n_sets, query_set, train_set, max_rows, dim, th_low, match_q2t, dist,
                              n_matches, on_device, false);
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 int hfnet_match_search_for_triangulation_batch(hfnet_engine* eh, int n_pairs, const float* desc_base, size_t set_stride, const int32_t* n_rows,
                                                int n_sets, const int32_t* set1, const int32_t* set2, int max_rows, int dim, float th_high,
-                                               int32_t* match12, int32_t* n_matches, int on_device) {
+                                               int32_t* match12, int32_t* n_matches, int on_device) try {
     return match_pairs_batch(eh, n_pairs, desc_base, set_stride, n_rows, n_sets, set1, set2, max_rows, dim, th_high, match12, nullptr, n_matches,
                              on_device, true);
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 // ---------------------------------------------------------------------------------------- descriptor store
-int hfnet_store_create(hfnet_engine* eh, int n_sets, int max_rows, int dim, hfnet_store** out) {
+int hfnet_store_create(hfnet_engine* eh, int n_sets, int max_rows, int dim, hfnet_store** out) try {
     API_GUARD(out, "out");
     *out = nullptr;
     API_GUARD(eh, "engine");
@@ -221,15 +224,16 @@ int hfnet_store_create(hfnet_engine* eh, int n_sets, int max_rows, int dim, hfne
     {   // on the engine's (non-blocking) stream, which every later put / match uses: see hfnet_db_create
         Engine& e = eh->impl;
         std::lock_guard<std::mutex> lk(e.mu);
+    e.bounce.discard();
         HF_HIP(hipMemsetAsync(st->d_rows, 0, sizeof(int32_t) * n_sets, e.stream));
         HF_HIP(hipMemsetAsync(st->d_flags, 0, (size_t)n_sets * max_rows, e.stream));
-        HF_HIP(hipStreamSynchronize(e.stream));
+        HF_TRY(e.sync_host());
     }
     *out = st.release();
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-void hfnet_store_destroy(hfnet_store* st) {
+void hfnet_store_destroy(hfnet_store* st) try {
     if (!st) return;
     (void)hipSetDevice(st->eng->impl.device);
     (void)hipDeviceSynchronize();
@@ -237,31 +241,32 @@ void hfnet_store_destroy(hfnet_store* st) {
     (void)dev_free(st->d_rows);
     (void)dev_free(st->d_flags);
     delete st;
-}
+} catch (...) { (void)::hfnet::api_exception(); }
 
-int hfnet_store_put(hfnet_store* st, int slot, const float* rows, int n_rows) {
+int hfnet_store_put(hfnet_store* st, int slot, const float* rows, int n_rows) try {
     API_GUARD(st, "store");
     if (slot < 0 || slot >= st->n_sets || n_rows < 0 || n_rows > st->max_rows) { set_error("store: slot %d / %d rows outside [0, %d) / [0, %d]", slot, n_rows, st->n_sets, st->max_rows); return HFNET_ERR_INVALID_ARG; }
     if (n_rows && !rows) { set_error("null descriptor matrix"); return HFNET_ERR_INVALID_ARG; }
     std::lock_guard<std::mutex> lk(st->mu);
     Engine& e = st->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
+    e.bounce.discard();
     HF_HIP(hipSetDevice(e.device));
     const int32_t n = n_rows;
-    if (n_rows) HF_HIP(hipMemcpyAsync(st->d_desc + (size_t)slot * st->max_rows * st->dim, rows, sizeof(float) * (size_t)n_rows * st->dim, hipMemcpyHostToDevice, e.stream));
-    HF_HIP(hipMemcpyAsync(st->d_rows + slot, &n, sizeof n, hipMemcpyHostToDevice, e.stream));
+    if (n_rows) HF_TRY(e.h2d(st->d_desc + (size_t)slot * st->max_rows * st->dim, rows, sizeof(float) * (size_t)n_rows * st->dim));
+    HF_TRY(e.h2d(st->d_rows + slot, &n, sizeof n));
     HF_HIP(hipMemsetAsync(st->d_flags + (size_t)slot * st->max_rows, 0, (size_t)st->max_rows, e.stream));
-    HF_HIP(hipStreamSynchronize(e.stream));                          // the host buffers may go away
+    HF_TRY(e.sync_host());                          // the host buffers may go away
     st->rows[slot] = n;
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-int hfnet_store_rows(const hfnet_store* st, int slot) {
+int hfnet_store_rows(const hfnet_store* st, int slot) try {
     if (!st || slot < 0 || slot >= st->n_sets) return -1;
     return st->rows[slot];
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-int hfnet_store_set_flags(hfnet_store* st, int slot, const uint8_t* flags, int n_rows) {
+int hfnet_store_set_flags(hfnet_store* st, int slot, const uint8_t* flags, int n_rows) try {
     API_GUARD(st, "store");
     if (slot < 0 || slot >= st->n_sets || n_rows < 0 || n_rows > st->max_rows) { set_error("store: slot %d / %d rows outside [0, %d) / [0, %d]", slot, n_rows, st->n_sets, st->max_rows); return HFNET_ERR_INVALID_ARG; }
     if (n_rows == 0) return HFNET_OK;
@@ -269,13 +274,14 @@ int hfnet_store_set_flags(hfnet_store* st, int slot, const uint8_t* flags, int n
     std::lock_guard<std::mutex> lk(st->mu);
     Engine& e = st->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
+    e.bounce.discard();
     HF_HIP(hipSetDevice(e.device));
-    HF_HIP(hipMemcpyAsync(st->d_flags + (size_t)slot * st->max_rows, flags, (size_t)n_rows, hipMemcpyHostToDevice, e.stream));
-    HF_HIP(hipStreamSynchronize(e.stream));
+    HF_TRY(e.h2d(st->d_flags + (size_t)slot * st->max_rows, flags, (size_t)n_rows));
+    HF_TRY(e.sync_host());
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-int hfnet_store_put_extracted(hfnet_store* st, int slot, hfnet_extractor* x, int frame) {
+int hfnet_store_put_extracted(hfnet_store* st, int slot, hfnet_extractor* x, int frame) try {
     API_GUARD(st, "store"); API_GUARD(x, "extractor");
     if (st->eng != x->eng) { set_error("store and extractor belong to different engines"); return HFNET_ERR_INVALID_ARG; }
     if (slot < 0 || slot >= st->n_sets || frame < 0 || frame >= x->max_batch) { set_error("store: slot %d / frame %d out of range", slot, frame); return HFNET_ERR_INVALID_ARG; }
@@ -287,6 +293,7 @@ int hfnet_store_put_extracted(hfnet_store* st, int slot, hfnet_extractor* x, int
     std::lock_guard<std::mutex> lk(st->mu);
     Engine& e = st->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
+    e.bounce.discard();
     HF_HIP(hipSetDevice(e.device));
     // Invariant relied on (no stream drain any more: with host_global the host-pointer call returns while the global branch may
     // still run): the LOCAL section of the extractor's device block (descriptors, counts) is complete once the host has seen the
@@ -310,7 +317,7 @@ int hfnet_store_put_extracted(hfnet_store* st, int slot, hfnet_extractor* x, int
     }
     st->rows[slot] = n;
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 // pairs of resident sets -> host results.  Only the pair lists go up and the matches come down.
 static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const int32_t* set2, int rows1, int rows2, float th, int32_t* match,
@@ -326,6 +333,7 @@ static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const 
     std::lock_guard<std::mutex> lks(st->mu);
     Engine& e = st->eng->impl;
     std::lock_guard<std::mutex> lk(e.mu);
+    e.bounce.discard();
     HF_HIP(hipSetDevice(e.device));
     const int mr = st->max_rows;
     const long long stride = (long long)mr * st->dim;
@@ -356,7 +364,7 @@ static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const 
     int32_t* ib = e.m_b.as<int32_t>();
     int32_t *d_qsel = ib, *d_tsel = ib + n_pairs, *d_cslot = ib + 2 * n_pairs, *d_cfilter = d_cslot + nc, *d_crows = d_cfilter + nc, *d_map = d_crows + nc,
             *d_inv = d_map + (size_t)nc * mr;
-    HF_HIP(hipMemcpyAsync(ib, host.data(), sizeof(int32_t) * host.size(), hipMemcpyHostToDevice, e.stream));
+    HF_TRY(e.h2d(ib, host.data(), sizeof(int32_t) * host.size()));
     int32_t* d_match = e.m_i0.as<int32_t>(); float* d_dist = e.m_f0.as<float>(); int32_t* d_cnt = e.m_cnt.as<int32_t>();
     int32_t* w_match = nc ? e.m_i1.as<int32_t>() : d_match; float* w_dist = nc ? e.m_f1.as<float>() : d_dist;   // results in compacted numbering
     if (nc)
@@ -388,36 +396,37 @@ static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const 
         HF_HIP(hipMemcpyAsync(hp, d_match, b_match, hipMemcpyDeviceToHost, e.stream));
         if (b_dist) HF_HIP(hipMemcpyAsync(hp + b_match, d_dist, b_dist, hipMemcpyDeviceToHost, e.stream));
         HF_HIP(hipMemcpyAsync(hp + b_match + b_dist, d_cnt, b_cnt, hipMemcpyDeviceToHost, e.stream));
-        HF_HIP(hipStreamSynchronize(e.stream));
+        HF_TRY(e.sync_host());
         std::memcpy(match, hp, b_match);
         if (b_dist) std::memcpy(dist, hp + b_match, b_dist);
         std::memcpy(n_matches, hp + b_match + b_dist, b_cnt);
         return HFNET_OK;
     }
-    HF_HIP(hipMemcpyAsync(match, d_match, b_match, hipMemcpyDeviceToHost, e.stream));
-    if (!triangulation) HF_HIP(hipMemcpyAsync(dist, d_dist, b_dist, hipMemcpyDeviceToHost, e.stream));
-    HF_HIP(hipMemcpyAsync(n_matches, d_cnt, b_cnt, hipMemcpyDeviceToHost, e.stream));
-    HF_HIP(hipStreamSynchronize(e.stream));
+    HF_TRY(e.d2h(match, d_match, b_match));
+    if (!triangulation) HF_TRY(e.d2h(dist, d_dist, b_dist));
+    HF_TRY(e.d2h(n_matches, d_cnt, b_cnt));
+    HF_TRY(e.sync_host());
     return HFNET_OK;
 }
 
 int hfnet_store_search_by_bow(hfnet_store* st, int n_pairs, const int32_t* query_set, const int32_t* train_set, int query_rows, int train_rows,
-                              float th_low, int32_t* match_q2t, float* dist, int32_t* n_matches) {
+                              float th_low, int32_t* match_q2t, float* dist, int32_t* n_matches) try {
     return match_store(st, n_pairs, query_set, train_set, query_rows, train_rows, th_low, match_q2t, dist, n_matches, false);
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 int hfnet_store_search_for_triangulation(hfnet_store* st, int n_pairs, const int32_t* set1, const int32_t* set2, int rows1, int rows2, float th_high,
-                                         int32_t* match12, int32_t* n_matches) {
+                                         int32_t* match12, int32_t* n_matches) try {
     return match_store(st, n_pairs, set1, set2, rows1, rows2, th_high, match12, nullptr, n_matches, true);
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 int hfnet_match_search_for_triangulation(hfnet_engine* eh, const float* d1, int n1, const float* d2, int n2, int dim, float th_high,
-                                         int32_t* match12, int* n_matches, int on_device) {
+                                         int32_t* match12, int* n_matches, int on_device) try {
     API_GUARD(eh, "engine"); API_GUARD(match12, "match12"); API_GUARD(n_matches, "n_matches");
     if (n1 < 0 || n2 < 0 || dim <= 0 || dim % 64) { set_error("bad matcher sizes (dim must be a multiple of 64)"); return HFNET_ERR_INVALID_ARG; }
     if ((n1 && !d1) || (n2 && !d2)) { set_error("null descriptor matrix"); return HFNET_ERR_INVALID_ARG; }
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
+    e.bounce.discard();
     HF_HIP(hipSetDevice(e.device));
     if (on_device) HF_HIP(e.wait_extract());
     if (n1 == 0) { if (!on_device) *n_matches = 0; else HF_HIP(hipMemsetAsync(n_matches, 0, sizeof(int), e.stream)); return HFNET_OK; }
@@ -434,21 +443,21 @@ int hfnet_match_search_for_triangulation(hfnet_engine* eh, const float* d1, int 
     BowPair P;
     P.q = da; P.t = db; P.St = e.m_s.as<float>(); P.qn = e.m_qn.as<float>(); P.tn = e.m_tn.as<float>(); P.qkey = e.m_key.as<unsigned long long>();
     P.match = d_match; P.dist = nullptr; P.cnt = d_cnt; P.nq = n1; P.nt = n2;
-    HF_HIP(hipMemcpyAsync(e.m_pairs.p, &P, sizeof P, hipMemcpyHostToDevice, e.stream));
-    HF_HIP(hipStreamSynchronize(e.stream));     // P lives on this stack frame
+    HF_TRY(e.h2d(e.m_pairs.p, &P, sizeof P));
+    HF_TRY(e.sync_host());     // P lives on this stack frame
     const float threshold = (float)(-0.5 * th_high * th_high + 1);   // Matcher.cc:851
     HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), 1, max_rows, dim, threshold, e.stream, nullptr, nullptr));
     if (!on_device) {
-        HF_HIP(hipMemcpyAsync(match12, d_match, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, e.stream));
-        HF_HIP(hipMemcpyAsync(n_matches, d_cnt, sizeof(int), hipMemcpyDeviceToHost, e.stream));
-        HF_HIP(hipStreamSynchronize(e.stream));
+        HF_TRY(e.d2h(match12, d_match, sizeof(int32_t) * n1));
+        HF_TRY(e.d2h(n_matches, d_cnt, sizeof(int)));
+        HF_TRY(e.sync_host());
     }
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 int hfnet_match_candidates(hfnet_engine* eh, const float* query, int n_query, const float* train, int n_train, const int32_t* train_level, int dim,
                            const int32_t* cand_offsets, const int32_t* cand_index, int32_t* best_idx, float* best_dist, int32_t* best_level,
-                           float* second_dist, int32_t* second_level, int on_device) {
+                           float* second_dist, int32_t* second_level, int on_device) try {
     API_GUARD(eh, "engine");
     if (n_query < 0 || n_train < 0 || dim <= 0 || dim % 4) { set_error("match_candidates: bad sizes (dim must be a multiple of 4)"); return HFNET_ERR_INVALID_ARG; }
     if (n_query == 0) return HFNET_OK;
@@ -456,6 +465,7 @@ int hfnet_match_candidates(hfnet_engine* eh, const float* query, int n_query, co
     API_GUARD(best_idx, "best_idx"); API_GUARD(best_dist, "best_dist"); API_GUARD(best_level, "best_level"); API_GUARD(second_dist, "second_dist"); API_GUARD(second_level, "second_level");
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
+    e.bounce.discard();
     HF_HIP(hipSetDevice(e.device));
     if (on_device) {
         HF_HIP(e.wait_extract());
@@ -475,23 +485,23 @@ int hfnet_match_candidates(hfnet_engine* eh, const float* query, int n_query, co
     HF_TRY(e.m_i0.ensure(sizeof(int32_t) * ((size_t)n_query + 1 + (size_t)total + (size_t)n_train)));
     HF_TRY(e.m_i1.ensure(sizeof(int32_t) * 3 * (size_t)n_query)); HF_TRY(e.m_f0.ensure(sizeof(float) * 2 * (size_t)n_query));
     int32_t* ib = e.m_i0.as<int32_t>();
-    HF_HIP(hipMemcpyAsync(ib, cand_offsets, sizeof(int32_t) * ((size_t)n_query + 1), hipMemcpyHostToDevice, e.stream));
-    if (total) HF_HIP(hipMemcpyAsync(ib + n_query + 1, cand_index, sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, e.stream));
+    HF_TRY(e.h2d(ib, cand_offsets, sizeof(int32_t) * ((size_t)n_query + 1)));
+    if (total) HF_TRY(e.h2d(ib + n_query + 1, cand_index, sizeof(int32_t) * (size_t)total));
     int32_t* d_level = nullptr;
-    if (train_level && n_train) { d_level = ib + n_query + 1 + total; HF_HIP(hipMemcpyAsync(d_level, train_level, sizeof(int32_t) * (size_t)n_train, hipMemcpyHostToDevice, e.stream)); }
+    if (train_level && n_train) { d_level = ib + n_query + 1 + total; HF_TRY(e.h2d(d_level, train_level, sizeof(int32_t) * (size_t)n_train)); }
     int32_t* oi = e.m_i1.as<int32_t>(); float* of = e.m_f0.as<float>();
     HF_LAUNCH(&e, e.stream, "match_candidates", launch_match_candidates(dq, n_query, dt, d_level, dim, ib, ib + n_query + 1, oi, of, oi + n_query, of + n_query,
                                                                    oi + 2 * (size_t)n_query, e.stream));
-    HF_HIP(hipMemcpyAsync(best_idx, oi, sizeof(int32_t) * n_query, hipMemcpyDeviceToHost, e.stream));
-    HF_HIP(hipMemcpyAsync(best_level, oi + n_query, sizeof(int32_t) * n_query, hipMemcpyDeviceToHost, e.stream));
-    HF_HIP(hipMemcpyAsync(second_level, oi + 2 * (size_t)n_query, sizeof(int32_t) * n_query, hipMemcpyDeviceToHost, e.stream));
-    HF_HIP(hipMemcpyAsync(best_dist, of, sizeof(float) * n_query, hipMemcpyDeviceToHost, e.stream));
-    HF_HIP(hipMemcpyAsync(second_dist, of + n_query, sizeof(float) * n_query, hipMemcpyDeviceToHost, e.stream));
-    HF_HIP(hipStreamSynchronize(e.stream));
+    HF_TRY(e.d2h(best_idx, oi, sizeof(int32_t) * n_query));
+    HF_TRY(e.d2h(best_level, oi + n_query, sizeof(int32_t) * n_query));
+    HF_TRY(e.d2h(second_level, oi + 2 * (size_t)n_query, sizeof(int32_t) * n_query));
+    HF_TRY(e.d2h(best_dist, of, sizeof(float) * n_query));
+    HF_TRY(e.d2h(second_dist, of + n_query, sizeof(float) * n_query));
+    HF_TRY(e.sync_host());
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-int hfnet_distinctive_descriptors(hfnet_engine* eh, const float* desc, const int32_t* set_offsets, int n_sets, int dim, int32_t* best) {
+int hfnet_distinctive_descriptors(hfnet_engine* eh, const float* desc, const int32_t* set_offsets, int n_sets, int dim, int32_t* best) try {
     API_GUARD(eh, "engine");
     if (n_sets < 0 || dim <= 0 || dim % 4) { set_error("distinctive_descriptors: bad sizes (dim must be a multiple of 4)"); return HFNET_ERR_INVALID_ARG; }
     if (n_sets == 0) return HFNET_OK;
@@ -506,36 +516,38 @@ int hfnet_distinctive_descriptors(hfnet_engine* eh, const float* desc, const int
     if (total) API_GUARD(desc, "desc");
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
+    e.bounce.discard();
     HF_HIP(hipSetDevice(e.device));
     const float* dd;
     HF_TRY(stage_rows(e, e.m_a, desc, (size_t)total * dim, 0, &dd));
     HF_TRY(e.m_i0.ensure(sizeof(int32_t) * ((size_t)n_sets + 1))); HF_TRY(e.m_i1.ensure(sizeof(int32_t) * (size_t)n_sets));
-    HF_HIP(hipMemcpyAsync(e.m_i0.p, set_offsets, sizeof(int32_t) * ((size_t)n_sets + 1), hipMemcpyHostToDevice, e.stream));
+    HF_TRY(e.h2d(e.m_i0.p, set_offsets, sizeof(int32_t) * ((size_t)n_sets + 1)));
     HF_LAUNCH(&e, e.stream, "distinctive", launch_distinctive(dd, e.m_i0.as<int>(), n_sets, dim, e.m_i1.as<int>(), e.stream));
-    HF_HIP(hipMemcpyAsync(best, e.m_i1.p, sizeof(int32_t) * (size_t)n_sets, hipMemcpyDeviceToHost, e.stream));
-    HF_HIP(hipStreamSynchronize(e.stream));
+    HF_TRY(e.d2h(best, e.m_i1.p, sizeof(int32_t) * (size_t)n_sets));
+    HF_TRY(e.sync_host());
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 int hfnet_resampler(hfnet_engine* eh, const float* data, const float* warp, float* output, int batch_size, int data_height, int data_width,
-                    int data_channels, int num_sampling_points) {
+                    int data_channels, int num_sampling_points) try {
     API_GUARD(eh, "engine"); API_GUARD(data, "data"); API_GUARD(output, "output");
     if (batch_size < 0 || data_height <= 0 || data_width <= 0 || data_channels <= 0 || num_sampling_points < 0) { set_error("resampler: bad sizes"); return HFNET_ERR_INVALID_ARG; }
     if (batch_size == 0 || num_sampling_points == 0) return HFNET_OK;
     API_GUARD(warp, "warp");
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
+    e.bounce.discard();
     HF_HIP(hipSetDevice(e.device));
     const size_t nd = (size_t)batch_size * data_height * data_width * data_channels, nw = (size_t)batch_size * num_sampling_points * 2;
     const size_t no = (size_t)batch_size * num_sampling_points * data_channels;
     HF_TRY(e.m_s.ensure(nd * sizeof(float))); HF_TRY(e.m_a.ensure(nw * sizeof(float))); HF_TRY(e.m_b.ensure(no * sizeof(float)));
-    HF_HIP(hipMemcpyAsync(e.m_s.p, data, nd * sizeof(float), hipMemcpyHostToDevice, e.stream));
-    HF_HIP(hipMemcpyAsync(e.m_a.p, warp, nw * sizeof(float), hipMemcpyHostToDevice, e.stream));
+    HF_TRY(e.h2d(e.m_s.p, data, nd * sizeof(float)));
+    HF_TRY(e.h2d(e.m_a.p, warp, nw * sizeof(float)));
     HF_LAUNCH(&e, e.stream, "resampler", launch_resampler(e.m_s.as<float>(), e.m_a.as<float>(), e.m_b.as<float>(), batch_size, data_height, data_width,
                                                          data_channels, num_sampling_points, e.stream));
-    HF_HIP(hipMemcpyAsync(output, e.m_b.p, no * sizeof(float), hipMemcpyDeviceToHost, e.stream));
-    HF_HIP(hipStreamSynchronize(e.stream));
+    HF_TRY(e.d2h(output, e.m_b.p, no * sizeof(float)));
+    HF_TRY(e.sync_host());
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 }  // extern "C"

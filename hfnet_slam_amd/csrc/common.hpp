@@ -18,6 +18,9 @@ namespace hfnet {
 
 void set_error(const char* fmt, ...);
 const char* get_error();
+// every extern "C" entry point is a function-try-block that ends in this (called inside the handler): the ABI's "nothing here throws"
+// (include/hfnet_hip.h) -- a std::bad_alloc or any other C++ exception becomes HFNET_ERR_INTERNAL with its text in hfnet_last_error()
+int api_exception() noexcept;
 
 #define HF_HIP(expr)                                                                              \
     do {                                                                                          \
@@ -34,6 +37,9 @@ const char* get_error();
 hipError_t dev_malloc(void** out, size_t bytes);
 hipError_t dev_free(void* p);
 int dev_guard_mode();
+// blocking copies between host memory of any kind and the device through a process-wide pinned block (set-up paths; devmem.cpp)
+hipError_t copy_h2d_blocking(void* dst_dev, const void* src_host, size_t bytes);
+hipError_t copy_d2h_blocking(void* dst_host, const void* src_dev, size_t bytes);
 template <class T> inline hipError_t dev_malloc(T** out, size_t bytes) { return dev_malloc((void**)out, bytes); }
 
 #define HF_TRY(expr)                      \

@@ -19,6 +19,7 @@
 #include "common.hpp"
 
 #include <cstdlib>
+#include <cstring>
 #include <unordered_map>
 
 namespace hfnet {
@@ -86,6 +87,37 @@ void trace_launch(const char* name, hipStream_t s, bool after) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); return; }
     if (cs == hipStreamCaptureStatusNone) (void)hipStreamSynchronize(s);
+}
+
+// Blocking copies between HOST memory of any kind and the device through one process-wide pinned block (8 MB pieces): set-up paths (weights,
+// resize tables) and odd small read-backs.  No pageable pointer reaches the runtime (HostBounce, engine.hpp, has the why).
+namespace {
+struct Staging { std::mutex mu; unsigned char* p = nullptr; static constexpr size_t cap = (size_t)8 << 20; };
+Staging& staging() { static Staging s; return s; }
+}  // namespace
+hipError_t copy_h2d_blocking(void* dst_dev, const void* src_host, size_t bytes) {
+    Staging& st = staging();
+    std::lock_guard<std::mutex> lk(st.mu);
+    if (!st.p) { void* hp = nullptr; const hipError_t r = hipHostMalloc(&hp, Staging::cap, hipHostMallocDefault); if (r != hipSuccess) return r; st.p = (unsigned char*)hp; }
+    for (size_t off = 0; off < bytes; off += Staging::cap) {
+        const size_t n = bytes - off < Staging::cap ? bytes - off : Staging::cap;
+        std::memcpy(st.p, (const unsigned char*)src_host + off, n);
+        const hipError_t r = hipMemcpy((unsigned char*)dst_dev + off, st.p, n, hipMemcpyHostToDevice);
+        if (r != hipSuccess) return r;
+    }
+    return hipSuccess;
+}
+hipError_t copy_d2h_blocking(void* dst_host, const void* src_dev, size_t bytes) {
+    Staging& st = staging();
+    std::lock_guard<std::mutex> lk(st.mu);
+    if (!st.p) { void* hp = nullptr; const hipError_t r = hipHostMalloc(&hp, Staging::cap, hipHostMallocDefault); if (r != hipSuccess) return r; st.p = (unsigned char*)hp; }
+    for (size_t off = 0; off < bytes; off += Staging::cap) {
+        const size_t n = bytes - off < Staging::cap ? bytes - off : Staging::cap;
+        const hipError_t r = hipMemcpy(st.p, (const unsigned char*)src_dev + off, n, hipMemcpyDeviceToHost);
+        if (r != hipSuccess) return r;
+        std::memcpy((unsigned char*)dst_host + off, st.p, n);
+    }
+    return hipSuccess;
 }
 
 hipError_t dev_malloc(void** out, size_t bytes) {

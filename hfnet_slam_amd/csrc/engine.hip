@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <thread>
 
 namespace hfnet {
@@ -48,11 +49,52 @@ Engine::~Engine() {
     for (DevMem* m : {&m_a, &m_b, &m_s, &m_qn, &m_tn, &m_key, &m_i0, &m_i1, &m_f0, &m_f1, &m_cnt, &m_pairs, &m_tri_stat}) m->release();
     w.release();
     if (h_res) (void)hipHostFree(h_res);
+    if (bounce.base) (void)hipHostFree(bounce.base);
     if (h_tri_stat) (void)hipHostFree(h_tri_stat);
     if (ev_extract) (void)hipEventDestroy(ev_extract);
     if (ev_match) (void)hipEventDestroy(ev_match);
     if (ev_tri_stat) (void)hipEventDestroy(ev_tri_stat);
     if (stream) (void)hipStreamDestroy(stream);
+}
+
+int Engine::sync_host() {
+    HF_HIP(hipStreamSynchronize(stream));
+    for (const HostBounce::Pending& p : bounce.pending) std::memcpy(p.dst, p.src, p.bytes);
+    bounce.pending.clear();
+    bounce.used = 0;
+    return HFNET_OK;
+}
+int Engine::bounce_take(size_t bytes, unsigned char** out) {
+    const size_t need = (bytes + 255) / 256 * 256;
+    if (bounce.used + need > bounce.cap) {
+        HF_TRY(sync_host());                                  // nothing is in flight through the block any more
+        if (need > bounce.cap) {
+            if (bounce.base) { (void)hipHostFree(bounce.base); bounce.base = nullptr; bounce.cap = 0; }
+            const size_t cap = std::max<size_t>(std::max(need, bounce.cap * 2), (size_t)1 << 20);
+            void* hp = nullptr;
+            HF_HIP(hipHostMalloc(&hp, cap, hipHostMallocDefault));
+            bounce.base = (unsigned char*)hp; bounce.cap = cap;
+        }
+    }
+    *out = bounce.base + bounce.used;
+    bounce.used += need;
+    return HFNET_OK;
+}
+int Engine::h2d(void* dst_dev, const void* src_host, size_t bytes) {
+    if (!bytes) return HFNET_OK;
+    unsigned char* b = nullptr;
+    HF_TRY(bounce_take(bytes, &b));
+    std::memcpy(b, src_host, bytes);
+    HF_HIP(hipMemcpyAsync(dst_dev, b, bytes, hipMemcpyHostToDevice, stream));
+    return HFNET_OK;
+}
+int Engine::d2h(void* dst_host, const void* src_dev, size_t bytes) {
+    if (!bytes) return HFNET_OK;
+    unsigned char* b = nullptr;
+    HF_TRY(bounce_take(bytes, &b));
+    HF_HIP(hipMemcpyAsync(b, src_dev, bytes, hipMemcpyDeviceToHost, stream));
+    bounce.pending.push_back({dst_host, b, bytes});
+    return HFNET_OK;
 }
 
 bool Engine::pinned_results(size_t bytes) {
@@ -485,8 +527,13 @@ int Net::forward_global(hipStream_t st, int first, int count, int* total) {
 int Net::read_faults(unsigned int* out) {
     *out = 0;
     if (!dev_fault) return HFNET_OK;
-    HF_HIP(hipMemcpyAsync(out, dev_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
-    HF_HIP(hipStreamSynchronize(stream));
+    void* hp = nullptr;                                       // (a pinned word: no pageable memory is handed to the runtime, see HostBounce)
+    HF_HIP(hipHostMalloc(&hp, 64, hipHostMallocDefault));
+    hipError_t er = hipMemcpyAsync(hp, dev_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, stream);
+    if (er == hipSuccess) er = hipStreamSynchronize(stream);
+    if (er == hipSuccess) *out = *(volatile unsigned int*)hp;
+    (void)hipHostFree(hp);
+    HF_HIP(er);
     return HFNET_OK;
 }
 
@@ -546,14 +593,18 @@ int Net::tap(int id, std::vector<float>& out) {
         float* tmp = nullptr;
         HF_HIP(dev_malloc((void**)&tmp, count * sizeof(float)));
         hipError_t er = launch_permute_channels(src, tmp, (long long)(count / permute_c), permute_c, 1, stream);
-        if (er == hipSuccess) er = hipMemcpyAsync(out.data(), tmp, count * sizeof(float), hipMemcpyDeviceToHost, stream);
-        if (er == hipSuccess) er = hipStreamSynchronize(stream);
-        (void)dev_free(tmp);
-        if (er != hipSuccess) { set_error("tap copy failed: %s", hipGetErrorString(er)); return HFNET_ERR_DEVICE; }
-    } else {
-        HF_HIP(hipMemcpyAsync(out.data(), src, count * sizeof(float), hipMemcpyDeviceToHost, stream));
-        HF_HIP(hipStreamSynchronize(stream));
+        if (er != hipSuccess) { (void)dev_free(tmp); set_error("tap permute failed: %s", hipGetErrorString(er)); return HFNET_ERR_DEVICE; }
+        src = tmp;
     }
+    // (diagnostics: through a pinned block of its own -- no pageable memory is handed to the runtime anywhere, see HostBounce)
+    void* hp = nullptr;
+    hipError_t er = hipHostMalloc(&hp, std::max<size_t>(count, 1) * sizeof(float), hipHostMallocDefault);
+    if (er == hipSuccess) er = hipMemcpyAsync(hp, src, count * sizeof(float), hipMemcpyDeviceToHost, stream);
+    if (er == hipSuccess) er = hipStreamSynchronize(stream);
+    if (er == hipSuccess) std::memcpy(out.data(), hp, count * sizeof(float));
+    if (hp) (void)hipHostFree(hp);
+    if (permute_c) (void)dev_free((void*)src);
+    if (er != hipSuccess) { set_error("tap copy failed: %s", hipGetErrorString(er)); return HFNET_ERR_DEVICE; }
     return HFNET_OK;
 }
 
@@ -622,14 +673,14 @@ int hfnet_abi_version(void) { return HFNET_ABI_VERSION; }
 // (the marker prefix lets hfnet_slam_amd/build.py read the id from the file without loading it)
 const char* hfnet_build_id(void) { static const char id[] = HFNET_BUILD_ID; return &id[sizeof("hfnet-build-id:") - 1]; }
 
-int hfnet_device_count(void) {
+int hfnet_device_count(void) try {
     int n = 0;
     const hipError_t er = hipGetDeviceCount(&n);
     if (er != hipSuccess || n <= 0) { set_error("no HIP device visible (%s)", hipGetErrorString(er)); return 0; }
     return n;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-int hfnet_engine_create(int device, const char* weights_path, hfnet_engine** out) {
+int hfnet_engine_create(int device, const char* weights_path, hfnet_engine** out) try {
     API_GUARD(out, "out");
     *out = nullptr;
     API_GUARD(weights_path, "weights_path");
@@ -646,11 +697,11 @@ int hfnet_engine_create(int device, const char* weights_path, hfnet_engine** out
     HF_HIP(hipDeviceSynchronize());
     *out = e.release();
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 void hfnet_engine_destroy(hfnet_engine* e) { delete e; }
 
-int hfnet_engine_info(const hfnet_engine* e, int what) {
+int hfnet_engine_info(const hfnet_engine* e, int what) try {
     if (!e) return -1;
     const DeviceWeights& w = e->impl.w;
     switch (what) {
@@ -662,9 +713,11 @@ int hfnet_engine_info(const hfnet_engine* e, int what) {
         case 5: return e->impl.device;
         default: return -1;
     }
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value) {
+int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value) try {
+    // test hook of the exception barrier every entry point ends in (tests/test_abi.py; needs no engine and no GPU): name "debug_throw"
+    if (name && std::strcmp(name, "debug_throw") == 0) { if (value == 1) throw std::bad_alloc(); throw std::runtime_error("debug_throw"); }
     API_GUARD(e, "engine");
     std::lock_guard<std::mutex> lk(e->impl.mu);              // (the database / matcher entry points read options under this lock)
     int* p = e->impl.opt.find(name);
@@ -676,24 +729,24 @@ int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value) {
         if (e->impl.h_tri_stat) { (void)hipStreamSynchronize(e->impl.stream); e->impl.tri_stat_pending = false; }
     }
     return HFNET_OK;
-}
-int hfnet_engine_get_option(hfnet_engine* e, const char* name, int* value) {
+} catch (...) { return ::hfnet::api_exception(); }
+int hfnet_engine_get_option(hfnet_engine* e, const char* name, int* value) try {
     API_GUARD(e, "engine"); API_GUARD(value, "value");
     std::lock_guard<std::mutex> lk(e->impl.mu);
     const int* p = e->impl.opt.find(name);
     if (!p) { set_error("unknown engine option '%s'", name ? name : "(null)"); return HFNET_ERR_INVALID_ARG; }
     *value = *p;
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-int hfnet_engine_synchronize(hfnet_engine* e) {
+int hfnet_engine_synchronize(hfnet_engine* e) try {
     API_GUARD(e, "engine");
     HF_HIP(hipSetDevice(e->impl.device));
     HF_HIP(hipDeviceSynchronize());
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
-int hfnet_engine_fence(hfnet_engine* eh) {
+int hfnet_engine_fence(hfnet_engine* eh) try {
     API_GUARD(eh, "engine");
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
@@ -703,35 +756,35 @@ int hfnet_engine_fence(hfnet_engine* eh) {
     HF_HIP(hipEventRecord(e.ev_match, e.stream));
     e.ev_match_set = true;
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 // ---------------------------------------------------------------------------------------- profiling
-int hfnet_profile_enable(hfnet_engine* e, int on) {
+int hfnet_profile_enable(hfnet_engine* e, int on) try {
     API_GUARD(e, "engine");
     std::lock_guard<std::mutex> lk(e->impl.prof_mu);
     if (!on) e->impl.prof.flush();
     e->impl.prof.enabled = on != 0;
     return HFNET_OK;
-}
-int hfnet_profile_reset(hfnet_engine* e) {
+} catch (...) { return ::hfnet::api_exception(); }
+int hfnet_profile_reset(hfnet_engine* e) try {
     API_GUARD(e, "engine");
     std::lock_guard<std::mutex> lk(e->impl.prof_mu);
     e->impl.prof.reset();
     return HFNET_OK;
-}
-int hfnet_profile_filter(hfnet_engine* e, const char* name) {
+} catch (...) { return ::hfnet::api_exception(); }
+int hfnet_profile_filter(hfnet_engine* e, const char* name) try {
     API_GUARD(e, "engine");
     std::lock_guard<std::mutex> lk(e->impl.prof_mu);
     e->impl.prof.filter = name ? name : "";
     return HFNET_OK;
-}
-int hfnet_profile_count(hfnet_engine* e) {
+} catch (...) { return ::hfnet::api_exception(); }
+int hfnet_profile_count(hfnet_engine* e) try {
     if (!e) return 0;
     std::lock_guard<std::mutex> lk(e->impl.prof_mu);
     e->impl.prof.flush();
     return (int)e->impl.prof.names.size();
-}
-int hfnet_profile_get(hfnet_engine* e, int i, char* name, int name_cap, int* launches, double* total_ms) {
+} catch (...) { return ::hfnet::api_exception(); }
+int hfnet_profile_get(hfnet_engine* e, int i, char* name, int name_cap, int* launches, double* total_ms) try {
     API_GUARD(e, "engine");
     std::lock_guard<std::mutex> lk(e->impl.prof_mu);
     Profiler& p = e->impl.prof;
@@ -741,6 +794,6 @@ int hfnet_profile_get(hfnet_engine* e, int i, char* name, int name_cap, int* lau
     if (launches) *launches = p.launches[i];
     if (total_ms) *total_ms = p.total_ms[i];
     return HFNET_OK;
-}
+} catch (...) { return ::hfnet::api_exception(); }
 
 }  // extern "C"

@@ -118,8 +118,26 @@ struct Options {
     int* find(const char* name);
 };
 
+// Every byte a host-pointer entry point of the matcher / store / database moves across the PCIe boundary goes through this pinned block: the
+// caller's (pageable) arrays are only ever touched by host memcpy.  Handing pageable caller memory to hipMemcpy*Async makes the runtime pin
+// it in place for the GPU; with the BaseModel path that ended in "Memory access fault by GPU ... on address <a page of the host heap>" once
+// in ~15 runs of the GPU suite (NOTEBOOK.md R5.4).  Uploads are copied into the block at once; downloads land in the block and are handed
+// to the caller's buffers by Engine::sync_host() (which every such entry point ends with).  Grow-only; all under Engine::mu.
+struct HostBounce {
+    unsigned char* base = nullptr;
+    size_t cap = 0, used = 0;
+    struct Pending { void* dst; const unsigned char* src; size_t bytes; };
+    std::vector<Pending> pending;
+    void discard() { pending.clear(); }     // an earlier call that returned an error half-way must not deliver into buffers that may be gone
+};
+
 struct Engine {
     int device = 0;
+    HostBounce bounce;
+    int bounce_take(size_t bytes, unsigned char** out);     // room in the block (drains the stream and grows the block when it is full)
+    int h2d(void* dst_dev, const void* src_host, size_t bytes);    // on `stream`
+    int d2h(void* dst_host, const void* src_dev, size_t bytes);    // on `stream`; dst_host is written by sync_host()
+    int sync_host();                                        // hipStreamSynchronize(stream) + the pending downloads' memcpys
     Options opt;
     hipStream_t stream = nullptr;   // matcher / database work
     DeviceWeights w;
@@ -316,6 +334,12 @@ struct hfnet_model {
     hfnet_keypoint* d_kps = nullptr;     // [max_keypoints]
     float* d_desc = nullptr;             // [max_keypoints x 256]
     int* d_n = nullptr;
+    // Pinned block every byte of a call crosses the PCIe boundary through: [image | n, fault word | aux | keypoints | descriptors].
+    // The caller's (pageable) buffers are only touched by host memcpy.  Until round 5 they were handed to hipMemcpy2DAsync / hipMemcpyAsync
+    // directly; the runtime pins such memory in place for the GPU, and once in ~15 runs of the GPU suite a call died with "Memory access
+    // fault by GPU ... on address <a page of the host heap>" (GPUTEST_r04, NOTEBOOK.md R5.4).
+    unsigned char* h_stage = nullptr;
+    size_t o_n = 0, o_aux = 0, o_kps = 0, o_desc = 0, stage_bytes = 0;
     std::mutex mu;
 };
 

@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <new>
+#include <stdexcept>
 
 namespace hfnet {
 
@@ -22,6 +24,13 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 const char* get_error() { return g_err; }
+int api_exception() noexcept {
+    try { throw; }                                            // (called inside a handler: the exception in flight)
+    catch (const std::bad_alloc&) { set_error("out of host memory"); }
+    catch (const std::exception& e) { set_error("internal error: %s", e.what()); }
+    catch (...) { set_error("internal error: unknown C++ exception"); }
+    return HFNET_ERR_INTERNAL;
+}
 
 // ------------------------------------------------------------------------------------ container
 #pragma pack(push, 1)
@@ -33,6 +42,8 @@ int WeightFile::load(const char* path) {
     std::ifstream f(path, std::ios::binary | std::ios::ate);
     if (!f) { set_error("cannot open weight container '%s'", path ? path : "(null)"); return HFNET_ERR_IO; }
     const std::streamsize sz = f.tellg();
+    if (sz < 16 || sz > ((std::streamsize)1 << 36)) {         // (a directory opens and reports -1 or LONG_MAX here)
+        set_error("'%s' is not an HFNETW1 container (size %lld)", path, (long long)sz); return HFNET_ERR_IO; }
     f.seekg(0);
     blob.resize((size_t)sz);
     if (!f.read((char*)blob.data(), sz)) { set_error("short read on '%s'", path); return HFNET_ERR_IO; }
@@ -114,7 +125,7 @@ static int upload(DeviceWeights& dw, const std::vector<float>& h, float** out) {
     void* p = nullptr;
     HF_HIP(dev_malloc(&p, h.size() * sizeof(float)));
     dw.allocations.push_back(p);
-    HF_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    HF_HIP(copy_h2d_blocking(p, h.data(), h.size() * sizeof(float)));
     *out = (float*)p;
     return HFNET_OK;
 }

@@ -39,7 +39,8 @@ typedef enum {
     HFNET_ERR_SHAPE = 3,            /* input size differs from the size given at construction (HFNetTFModelV2.cc:103)  */
     HFNET_ERR_DEVICE = 4,           /* HIP runtime error / no gfx950 device                                           */
     HFNET_ERR_IO = 5,               /* weight container missing or malformed                                           */
-    HFNET_ERR_CAPACITY = 6
+    HFNET_ERR_CAPACITY = 6,
+    HFNET_ERR_INTERNAL = 7          /* out of host memory / a C++ exception inside the library, caught at this boundary        */
 } hfnet_status;
 
 /* include/Extractors/BaseModel.h:16-21 */

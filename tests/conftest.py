@@ -70,3 +70,25 @@ def synth_image(h, w, seed, kind="uniform"):
         acc += (a * (1 - fy) * (1 - fx) + b * (1 - fy) * fx + c * fy * (1 - fx) + d * fy * fx) * (0.5 ** (5 - o))
     acc = (acc - acc.min()) / (acc.max() - acc.min())
     return np.clip(acc * 255.0, 0, 255).astype(np.uint8)
+
+
+def torch_to_host(t):
+    """device tensor -> numpy array through PINNED host memory (torch's own HIP runtime would otherwise pin the pageable destination in place:
+    the same mechanism behind the rare "Memory access fault ... on address <host heap page>" of NOTEBOOK.md R5.4 -- one abort of the GPU
+    suite happened inside a plain `.cpu()` of this file's callers)"""
+    import torch
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    torch.cuda.synchronize()
+    return h.numpy().copy()
+
+
+def torch_to_device(a, dev):
+    """numpy array -> device tensor through pinned host memory (see torch_to_host)"""
+    import torch
+    src = torch.from_numpy(np.ascontiguousarray(a))
+    h = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+    h.copy_(src)
+    d = h.to(dev, non_blocking=True)
+    torch.cuda.synchronize()
+    return d

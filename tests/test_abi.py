@@ -91,3 +91,38 @@ def test_object_cache_is_keyed_on_the_compile_flags(tmp_path, monkeypatch):
     assert open(stamp).read().strip() == build._flags_id()
     monkeypatch.setattr(build, "FLAGS", build.FLAGS + ["-DHFNET_SOME_NEW_FLAG=1"])
     assert open(stamp).read().strip() != build._flags_id()          # -> build() would schedule every source
+
+
+def test_no_exception_crosses_the_c_abi():
+    """include/hfnet_hip.h: "nothing here throws or exits".  Every extern "C" entry point is a function-try-block whose handler turns a
+    C++ exception into HFNET_ERR_INTERNAL (an exception that left an extern "C" function would std::terminate the host process -- the
+    SLAM system).  (a) the sources: every `int hfnet_*` / `void hfnet_*` definition with a body of its own ends in that handler;
+    (b) the built library: the test hook of hfnet_engine_set_option throws std::bad_alloc / std::runtime_error behind the boundary
+    (no engine, no GPU needed) and the call returns status 7 with the text in hfnet_last_error()."""
+    import ctypes as C
+    from hfnet_slam_amd import build, capi
+    n = 0
+    for f in ("api_db.hip", "api_extract.hip", "api_match.hip", "engine.hip"):
+        lines = open(os.path.join(build.CSRC, f)).read().split("\n")
+        for i, l in enumerate(lines):
+            m = re.match(r"^(int|void) (hfnet_\w+)\(", l)
+            if not m or l.rstrip().endswith("}"):                 # (one-line accessors: no call that can throw)
+                continue
+            j = i
+            while not lines[j].rstrip().endswith("{"):
+                j += 1
+            assert lines[j].rstrip().endswith(") try {"), (f, m.group(2))
+            k = j + 1
+            while not lines[k].startswith("}"):
+                k += 1
+            assert lines[k].startswith("} catch (...) {") and "api_exception()" in lines[k], (f, m.group(2))
+            assert ("return" in lines[k]) == (m.group(1) == "int"), (f, m.group(2))
+            n += 1
+    assert n >= 50, n
+    L = capi.lib()
+    L.hfnet_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    assert L.hfnet_engine_set_option(None, b"debug_throw", 1) == capi.ERR_INTERNAL == 7
+    assert "out of host memory" in capi.last_error()
+    assert L.hfnet_engine_set_option(None, b"debug_throw", 2) == capi.ERR_INTERNAL
+    assert "debug_throw" in capi.last_error()
+    assert L.hfnet_engine_set_option(None, b"fuse_blocks", 1) == capi.ERR_INVALID_ARG       # (the ordinary null-engine answer)

@@ -6,7 +6,7 @@ shows up as a failure rather than hiding inside a tolerance."""
 import numpy as np
 import pytest
 
-from conftest import synth_image
+from conftest import synth_image, torch_to_device, torch_to_host
 
 pytestmark = pytest.mark.gpu
 
@@ -481,7 +481,7 @@ def test_device_resident_pipeline_matches_host_path(engine, streams, engine_opti
     x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, 3, max_batch=B)
     xh = capi.Extractor(engine, w, h, nf, 0.01, 1.2, 3, max_batch=B)          # reference: host-pointer calls
     imgs = np.stack([synth_image(h, w, 900 + i, "natural" if i % 2 else "uniform") for i in range(B * steps)])
-    d_img = torch.from_numpy(imgs).to(dev)
+    d_img = torch_to_device(imgs, dev)
     kps = torch.zeros((steps * B, nf, 4), dtype=torch.float32, device=dev)
     desc = torch.zeros((steps * B, nf, 256), dtype=torch.float32, device=dev)
     glob = torch.zeros((steps * B, engine.global_dim), dtype=torch.float32, device=dev)
@@ -502,8 +502,8 @@ def test_device_resident_pipeline_matches_host_path(engine, streams, engine_opti
                                                C.c_void_p(match[o].data_ptr()), C.c_void_p(mdist[o].data_ptr()), C.c_void_p(mcnt[o:].data_ptr()), 1)
         assert st == capi.OK, capi.last_error()
     engine.synchronize(); torch.cuda.synchronize()
-    n_d = n_rows.cpu().numpy(); k_d = kps.cpu().numpy(); d_d = desc.cpu().numpy(); g_d = glob.cpu().numpy()
-    m_d = match.cpu().numpy(); c_d = mcnt.cpu().numpy()
+    n_d = torch_to_host(n_rows); k_d = torch_to_host(kps); d_d = torch_to_host(desc); g_d = torch_to_host(glob)
+    m_d = torch_to_host(match); c_d = torch_to_host(mcnt)
     prev = None
     for i in range(steps * B):
         n, k, d, g, _ = xh.extract(imgs[i])

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from hfnet_slam_amd import capi, weights
 from oracle import oracle as O
-from conftest import synth_image
+from conftest import synth_image, torch_to_host as H, torch_to_device
 
 
 def run(budget_s, seed):
@@ -35,7 +35,7 @@ def run(budget_s, seed):
         sizes = [int(rng.integers(1, 2 * MB + 1)) for _ in range(n_calls)]          # calls may span several chunks
         total = sum(sizes)
         imgs = np.stack([synth_image(h, w, int(rng.integers(1 << 30)), "natural" if rng.random() < 0.5 else "uniform") for _ in range(total)])
-        d_imgs = torch.from_numpy(imgs).to(dev)
+        d_imgs = torch_to_device(imgs, dev)
         kps = torch.zeros((total, nf, 4), dtype=torch.float32, device=dev)
         desc = torch.zeros((total, nf, 256), dtype=torch.float32, device=dev)
         glob = torch.zeros((total, eng.global_dim), dtype=torch.float32, device=dev)
@@ -67,8 +67,8 @@ def run(budget_s, seed):
                     fails.append(("status", st, capi.last_error()))
             f0 += n
         eng.synchronize(); torch.cuda.synchronize()
-        nr = nrow.cpu().numpy(); K = kps.cpu().numpy(); D = desc.cpu().numpy(); G = glob.cpu().numpy()
-        M = match.cpu().numpy(); MD = mdist.cpu().numpy(); MC = mcnt.cpu().numpy()
+        nr = H(nrow); K = H(kps); D = H(desc); G = H(glob)
+        M = H(match); MD = H(mdist); MC = H(mcnt)
         refs = [model.extract(imgs[i], nf, 0.01, nl, 1.2) for i in range(total)]
         for i, (rn, rk, rd, rg, _) in enumerate(refs):
             kk = K[i, :rn].view(capi.KP_DTYPE).reshape(-1) if hasattr(capi, "KP_DTYPE") else None
