@@ -69,8 +69,8 @@ int Engine::bounce_take(size_t bytes, unsigned char** out) {
     if (bounce.used + need > bounce.cap) {
         HF_TRY(sync_host());                                  // nothing is in flight through the block any more
         if (need > bounce.cap) {
-            if (bounce.base) { (void)hipHostFree(bounce.base); bounce.base = nullptr; bounce.cap = 0; }
             const size_t cap = std::max<size_t>(std::max(need, bounce.cap * 2), (size_t)1 << 20);
+            if (bounce.base) { (void)hipHostFree(bounce.base); bounce.base = nullptr; bounce.cap = 0; }
             void* hp = nullptr;
             HF_HIP(hipHostMalloc(&hp, cap, hipHostMallocDefault));
             bounce.base = (unsigned char*)hp; bounce.cap = cap;

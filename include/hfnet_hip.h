@@ -6,6 +6,9 @@
  * pointers and sizes only; caller-owned buffers; no memory owned by the library crosses the
  * boundary; nothing here throws or exits (the reference's factory exit(-1)s on a bad model,
  * src/Extractors/BaseModel.cc:119-125 -- the caller of this ABI decides instead).
+ * Host buffers handed to an entry point are only read / written by host code of the library (the bytes move through pinned blocks the
+ * library owns); the GPU never accesses caller memory, except arrays the caller registered with hfnet_host_register.  A C++ exception
+ * inside the library (out of host memory, ...) is caught at the boundary and returned as HFNET_ERR_INTERNAL.
  *
  * All entry points return HFNET_OK (0) or an error code; hfnet_last_error() gives the text for
  * the calling thread.  Objects are internally serialised per object (the reference enters its

@@ -51,3 +51,22 @@ def test_suite_slice_is_clean_under_the_allocator_modes(engine, mode):
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + SLICE, cwd=ROOT, env=e,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_bad_inputs_and_healthy_runs_report_status(engine, tmp_path):
+    """a directory as weight container used to reach blob.resize((size_t)-1) -- std::length_error, std::terminate in the host process; a healthy
+    model / extractor reports no device-side fault bits"""
+    import numpy as np
+    from conftest import synth_image
+    from hfnet_slam_amd import capi
+    with pytest.raises(capi.HfnetError) as ei:
+        capi.Engine(str(tmp_path), 0)
+    assert ei.value.status in (capi.ERR_IO, capi.ERR_INTERNAL)
+    m = capi.Model(engine, capi.MODE_LOCAL_AND_GLOBAL, 88, 80, max_keypoints=2)          # (few keypoints on a large cell grid: the R5.1 shape)
+    st, k, d, g = m.detect(synth_image(88, 80, 3), 2, 0.0)
+    assert st == capi.OK and len(k) == 2 and m.device_faults() == 0
+    m.close()
+    x = capi.Extractor(engine, 160, 120, 50, 0.0, 1.2, 2, max_batch=2)
+    x.extract_batch(np.stack([synth_image(120, 160, 5), synth_image(120, 160, 6)]))
+    assert x.device_faults() == 0
+    x.close()
