@@ -42,7 +42,7 @@ W_IMG, H_IMG, N_FEAT, N_LEVELS, SCALE, THRESH, TH_LOW, TH_HIGH = 752, 480, 1000,
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4)
 MFMA_BF16_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense bf16 MFMA (16 x the f32 rate); only the matcher's screening GEMM runs there
-TRAFFIC_FILES = [os.path.join("profiles", r + "_traffic_b{batch}.json") for r in ("r04", "r03", "r02")]     # newest first; one file per frames-per-call value
+TRAFFIC_FILES = [os.path.join("profiles", r + "_traffic_b{batch}.json") for r in ("r05", "r04", "r03", "r02")]     # newest first; one file per frames-per-call value
 ALL_CONFIGS = ["2-latency", "2-host-io", "2-bf16x3", "3", "4", "5"]
 DEFAULT_CHUNK = 128            # frames per extract / match call of the headline (tests/test_gpu_fullsize.py checks THIS size against the oracle)
 DEFAULT_BATCH = 768            # frames per step and GPU
