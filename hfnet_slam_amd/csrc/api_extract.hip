@@ -296,7 +296,7 @@ static int extract_chunk(hfnet_extractor* x, int nb, const uint8_t* d_images, in
     std::memset(&imgs, 0, sizeof imgs);
     imgs.ptr[0] = d_images; imgs.row_stride[0] = row_stride; imgs.frame_stride[0] = frame_stride;
     // calls of a few frames: the pyramid chain as ONE launch (three dependent 7 us launches otherwise)
-    const bool chain = nb <= 4 && eng.opt.pyramid_fuse && x->n_levels >= 2 && pyramid_chain_supported(x->n_levels - 1, x->level_w, x->level_h);
+    const bool chain = nb <= eng.opt.pyramid_fuse && x->n_levels >= 2 && pyramid_chain_supported(x->n_levels - 1, x->level_w, x->level_h);
     if (chain) {
         uint8_t* dst[HFNET_MAX_LEVELS] = {nullptr};
         int d_row[HFNET_MAX_LEVELS] = {0};

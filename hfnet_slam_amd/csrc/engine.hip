@@ -414,26 +414,33 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         HF_HIP(hipMemsetAsync(counters, 0, sizeof(unsigned int) * (size_t)NL * cfg.batch * HFNET_COUNTER_STRIDE, stream));
         HF_LAUNCH(e, stream, "nms", launch_nms(dense, nullptr, nms_mask, nms_flags, cand, counters, cand_stride, threshold, gn, stream));
         HF_TRY(pump_global(2));
-        HF_LAUNCH(e, stream, "topk", launch_topk(cand, counters, cand_stride, budget, kps_level, cfg.max_keypoints, n_level, gn, stream));
+        // Descriptor head: sparse or dense is a function of the budget alone (known here), see below
+        long long tap_rows = 0;
+        for (int l = 0; l < NL; ++l) tap_rows += 4ll * std::min(budget.k[l], cfg.max_keypoints) * cfg.batch;
+        last_sparse = !force_dense && tap_rows * 5 < pc * 4;
+        last_dedupe = last_sparse && dedupe_taps != 0;
+        Geom gt = gn;   // H, W: score map; Ho, Wo: cell grid; in_off: first cell of the level
+        for (int l = 0; l < NL; ++l) { gt.lv[l].Ho = lp[l].h[7]; gt.lv[l].Wo = lp[l].w[7]; gt.lv[l].in_off = pix_cell[l]; }
+        if (last_dedupe) {
+            // top-K and the distinct tap cells of its keypoints in one launch (both are one workgroup per image)
+            HF_LAUNCH(e, stream, "topk", launch_topk_taps(cand, counters, cand_stride, budget, kps_level, cfg.max_keypoints, n_level, tap_flags, tap_cell_row, tap_cells,
+                                                          tap_nrows, cell_stride, gt, stream, dev_fault));
+        } else {
+            HF_LAUNCH(e, stream, "topk", launch_topk(cand, counters, cand_stride, budget, kps_level, cfg.max_keypoints, n_level, gn, stream));
+        }
         HF_TRY(pump_global(1));
         // Descriptor head.  Only the 4 bilinear taps of every selected keypoint are ever read
         // (HFNetTFModelV2.cc:153-167), so unless the budget covers most of the cell grid the head is
         // evaluated at those taps only (same arithmetic per cell -> bit-identical descriptors).
-        long long tap_rows = 0;
-        for (int l = 0; l < NL; ++l) tap_rows += 4ll * std::min(budget.k[l], cfg.max_keypoints) * cfg.batch;
-        last_sparse = !force_dense && tap_rows * 5 < pc * 4;
         dense_valid = false;
         nms_valid = false; last_threshold = threshold;
         if (last_sparse) {
-            Geom gt = gn;   // H, W: score map; Ho, Wo: cell grid; in_off: first cell of the level
-            for (int l = 0; l < NL; ++l) { gt.lv[l].Ho = lp[l].h[7]; gt.lv[l].Wo = lp[l].w[7]; gt.lv[l].in_off = pix_cell[l]; }
             int kmaxb = 0;
             for (int l = 0; l < NL; ++l) kmaxb = std::max(kmaxb, std::min(budget.k[l], cfg.max_keypoints));
             const long long rows = ((long long)(NL * cfg.batch - 1) * cfg.max_keypoints + kmaxb) * 4;
-            last_dedupe = dedupe_taps != 0;
             if (last_dedupe) {
-                // taps shared by neighbouring keypoints are evaluated once: the rows of an image are its DISTINCT tap cells
-                HF_LAUNCH(e, stream, "tap_cells", launch_tap_cells(kps_level, n_level, cfg.max_keypoints, tap_flags, tap_cell_row, tap_cells, tap_nrows, cell_stride, gt, stream, dev_fault));
+                // taps shared by neighbouring keypoints are evaluated once: the rows of an image are its DISTINCT tap cells (numbered by the
+                // top-K launch above)
                 HF_TRY(pump_global(1));
                 if (desc_bf16x3 && w.desc1_bf && w.desc2_bf) {
                     // option: the head on the bf16 matrix pipe (split operands, three products): tolerance instead of the oracle's bits

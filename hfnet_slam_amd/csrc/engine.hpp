@@ -98,7 +98,7 @@ struct Options {
     int pinned_frames = 4;    // chunks up to this many frames move through one pinned block inside that graph
     int conv_wlds = 1;        // 3x3 heads: weights staged through LDS once per workgroup (0: every wave reads them from L1 / L2)
     int db_gemm_min_queries = 8;   // hfnet_db_query_batch: from this many queries on, the scores come from the MFMA GEMM form
-    int pyramid_fuse = 1;     // calls of up to four frames: the pyramid chain as one launch
+    int pyramid_fuse = 4;     // calls of up to this many frames: the pyramid chain as one launch (0: never)
     int det_fuse = 1;         // detector tail (1x1 conv, softmax, depth_to_space) as one launch
     int host_global = 1;      // host-pointer calls of up to four frames: the global descriptors are written into the pinned block by the branch's last kernel
     int interleave = 3;       // calls of up to four frames: launch groups of the global branch enqueued between the local heads' launches,

@@ -106,6 +106,10 @@ hipError_t launch_l2norm256(const float* in, float* out, long long P, hipStream_
 #define HFNET_FAULT_SAMPLE_ROW 2u   // k_sample: a tap cell of a selected keypoint has no row
 hipError_t launch_tap_cells(const hfnet_keypoint* kps, const int* n_in, long long kps_stride, unsigned char* flags, int* cell_row, int* cells,
                             int* n_rows, long long cell_stride, const Geom& g, hipStream_t s, unsigned int* fault = nullptr);
+// launch_topk + launch_tap_cells in one launch (g: launch_tap_cells' geometry)
+hipError_t launch_topk_taps(const unsigned long long* cand, const unsigned int* counters, long long cand_stride, const TopkBudget& kmax_per_level,
+                            hfnet_keypoint* kps, long long kps_stride, int* n_out, unsigned char* flags, int* cell_row, int* cells, int* n_rows,
+                            long long cell_stride, const Geom& g, hipStream_t s, unsigned int* fault = nullptr);
 struct SampleArgs {
     const float* desc_map;        // dense: normalised [pixels x 256]; sparse: RAW tap rows [image][kps_stride*4][256] (normalised on the fly)
     const int* cell_row;          // sparse, de-duplicated taps: row of cell (y * Wo + x) in the image's slot; null: rows 4 i .. 4 i + 3

@@ -336,9 +336,10 @@ hipError_t launch_nms(const float* dense, float* nms, unsigned* mask0, unsigned*
 // (column-major) order.  n > K: exact radix select of the K smallest 64-bit keys (8 passes of 8 bits),
 // then a bitonic sort in LDS -> (response desc, column-major index asc).
 #define TOPK_CAP 8192
-__global__ __launch_bounds__(1024) void k_topk(const unsigned long long* __restrict__ cand, const unsigned int* __restrict__ counters,
-                                               long long cand_stride, TopkBudget kmax_per_level,
-                                               hfnet_keypoint* __restrict__ kps, long long kps_stride, int* __restrict__ n_out, Geom g) {
+// the body of k_topk / k_topk_taps: one 1024-thread workgroup per image; returns the number of keypoints written (workgroup-uniform)
+__device__ __forceinline__ unsigned int topk_image(const unsigned long long* __restrict__ cand, const unsigned int* __restrict__ counters,
+                                                   long long cand_stride, const TopkBudget& kmax_per_level,
+                                                   hfnet_keypoint* kps, long long kps_stride, int* __restrict__ n_out, const Geom& g) {
     __shared__ unsigned long long buf[TOPK_CAP];
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long sh_prefix;
@@ -431,6 +432,13 @@ __global__ __launch_bounds__(1024) void k_topk(const unsigned long long* __restr
         out[i] = kp;
     }
     if (tid == 0) n_out[image] = (int)m;
+    return m;
+}
+
+__global__ __launch_bounds__(1024) void k_topk(const unsigned long long* __restrict__ cand, const unsigned int* __restrict__ counters,
+                                               long long cand_stride, TopkBudget kmax_per_level,
+                                               hfnet_keypoint* __restrict__ kps, long long kps_stride, int* __restrict__ n_out, Geom g) {
+    (void)topk_image(cand, counters, cand_stride, kmax_per_level, kps, kps_stride, n_out, g);
 }
 
 hipError_t launch_topk(const unsigned long long* cand, const unsigned int* counters, long long cand_stride,
@@ -656,12 +664,13 @@ hipError_t launch_sample(const SampleArgs& a, const Geom& g, hipStream_t s) {
 // 4) on an 8-pixel cell grid, so neighbouring keypoints share bilinear taps; real scenes cluster them far more than noise.
 // Pass 1 marks the cells any keypoint samples (the same float expressions as k_sample / the gathered conv), pass 2 numbers
 // the marked cells of an image in ascending cell order (a spatially sorted row list: good for the conv's L2 reuse too).
-__global__ __launch_bounds__(256) void k_tap_mark(const hfnet_keypoint* __restrict__ kps, const int* __restrict__ n_in, long long kps_stride,
-                                                  unsigned char* __restrict__ flags, long long cell_stride, Geom g) {
-    const int image = blockIdx.y, level = image / g.batch;
+// tap `row & 3` of keypoint `row >> 2` of `image`: marks its cell
+__device__ __forceinline__ void tap_mark_row(const hfnet_keypoint* kps, int n, long long kps_stride, unsigned char* flags, long long cell_stride,
+                                             const Geom& g, int image, int row) {
+    const int level = image / g.batch;
     const LevelGeom lv = g.lv[level];                            // H, W: score map; Ho, Wo: cell grid
-    const int row = blockIdx.x * 256 + threadIdx.x, i = row >> 2, t = row & 3;
-    if (i >= min(n_in[image], (int)kps_stride)) return;
+    const int i = row >> 2, t = row & 3;
+    if (i >= min(n, (int)kps_stride)) return;
     const hfnet_keypoint kp = kps[(long long)image * kps_stride + i];
     const int Wc = lv.Wo, Hc = lv.Ho;
     const float sw = ((float)Wc - 1.f) / (float)((float)lv.W - 1.f);
@@ -671,16 +680,20 @@ __global__ __launch_bounds__(256) void k_tap_mark(const hfnet_keypoint* __restri
     const int x = fx + ((t == 1 || t == 3) ? 1 : 0), y = fy + ((t == 1 || t == 2) ? 1 : 0);
     if (x >= 0 && x < Wc && y >= 0 && y < Hc) flags[(long long)image * cell_stride + y * Wc + x] = 1;
 }
+__global__ __launch_bounds__(256) void k_tap_mark(const hfnet_keypoint* __restrict__ kps, const int* __restrict__ n_in, long long kps_stride,
+                                                  unsigned char* __restrict__ flags, long long cell_stride, Geom g) {
+    tap_mark_row(kps, n_in[blockIdx.y], kps_stride, flags, cell_stride, g, blockIdx.y, blockIdx.x * 256 + threadIdx.x);
+}
 
 // The row list of an image holds 4 * kps_stride entries and k_tap_mark sets at most that many flags; the kernel nevertheless bounds
 // every row number it writes (a flag array that is not clean -- GPUTEST_r04: a creation-time clear that had not landed yet -- would
 // otherwise run the list, and the descriptor head's row buffers after it, past their ends) and reports the overflow.
-__global__ __launch_bounds__(1024) void k_tap_compact(unsigned char* __restrict__ flags, int* __restrict__ cell_row, int* __restrict__ cells,
-                                                      int* __restrict__ n_rows, long long cell_stride, long long kps_stride, Geom g,
-                                                      unsigned int* __restrict__ fault) {
+__device__ __forceinline__ void tap_compact_image(unsigned char* flags, int* __restrict__ cell_row, int* __restrict__ cells,
+                                                  int* __restrict__ n_rows, long long cell_stride, long long kps_stride, const Geom& g,
+                                                  unsigned int* __restrict__ fault, int image) {
     __shared__ int wsum[16];
     __shared__ int base;
-    const int image = blockIdx.x, level = image / g.batch;
+    const int level = image / g.batch;
     const int ncell = g.lv[level].Ho * g.lv[level].Wo;
     unsigned char* f = flags + (long long)image * cell_stride;
     int* cr = cell_row + (long long)image * cell_stride;
@@ -712,12 +725,39 @@ __global__ __launch_bounds__(1024) void k_tap_compact(unsigned char* __restrict_
         if (base > cap && fault) atomicOr(fault, HFNET_FAULT_TAP_ROWS);
     }
 }
+__global__ __launch_bounds__(1024) void k_tap_compact(unsigned char* __restrict__ flags, int* __restrict__ cell_row, int* __restrict__ cells,
+                                                      int* __restrict__ n_rows, long long cell_stride, long long kps_stride, Geom g,
+                                                      unsigned int* __restrict__ fault) {
+    tap_compact_image(flags, cell_row, cells, n_rows, cell_stride, kps_stride, g, fault, blockIdx.x);
+}
+// top-K + the distinct tap cells of the selected keypoints in ONE launch (both are one 1024-thread workgroup per image; asked for since round 3:
+// two launches and a dependent hop less per call).  g: H, W = score map, Ho, Wo = cell grid (launch_tap_cells' geometry; top-K reads H only).
+__global__ __launch_bounds__(1024) void k_topk_taps(const unsigned long long* __restrict__ cand, const unsigned int* __restrict__ counters,
+                                                    long long cand_stride, TopkBudget kmax_per_level, hfnet_keypoint* kps, long long kps_stride,
+                                                    int* __restrict__ n_out, unsigned char* flags, int* __restrict__ cell_row, int* __restrict__ cells,
+                                                    int* __restrict__ n_rows, long long cell_stride, Geom g, unsigned int* __restrict__ fault) {
+    const int m = (int)topk_image(cand, counters, cand_stride, kmax_per_level, kps, kps_stride, n_out, g);
+    __threadfence_block();
+    __syncthreads();                                              // the keypoints written above are read back by other waves below
+    for (int row = threadIdx.x; row < 4 * m; row += 1024) tap_mark_row(kps, m, kps_stride, flags, cell_stride, g, blockIdx.x, row);
+    __threadfence_block();
+    __syncthreads();
+    tap_compact_image(flags, cell_row, cells, n_rows, cell_stride, kps_stride, g, fault, blockIdx.x);
+}
 
 hipError_t launch_tap_cells(const hfnet_keypoint* kps, const int* n_in, long long kps_stride, unsigned char* flags, int* cell_row, int* cells,
                             int* n_rows, long long cell_stride, const Geom& g, hipStream_t s, unsigned int* fault) {
     const int images = g.n_levels * g.batch;
     hipLaunchKernelGGL(k_tap_mark, dim3((unsigned)((kps_stride * 4 + 255) / 256), images), dim3(256), 0, s, kps, n_in, kps_stride, flags, cell_stride, g);
     hipLaunchKernelGGL(k_tap_compact, dim3(images), dim3(1024), 0, s, flags, cell_row, cells, n_rows, cell_stride, kps_stride, g, fault);
+    return hipGetLastError();
+}
+
+hipError_t launch_topk_taps(const unsigned long long* cand, const unsigned int* counters, long long cand_stride, const TopkBudget& kmax_per_level,
+                            hfnet_keypoint* kps, long long kps_stride, int* n_out, unsigned char* flags, int* cell_row, int* cells, int* n_rows,
+                            long long cell_stride, const Geom& g, hipStream_t s, unsigned int* fault) {
+    hipLaunchKernelGGL(k_topk_taps, dim3(g.n_levels * g.batch), dim3(1024), 0, s, cand, counters, cand_stride, kmax_per_level, kps, kps_stride, n_out,
+                       flags, cell_row, cells, n_rows, cell_stride, g, fault);
     return hipGetLastError();
 }
 
