@@ -44,7 +44,9 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA (v_mfma_f32
 MFMA_BF16_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense bf16 MFMA (16 x the f32 rate); only the matcher's screening GEMM runs there
 TRAFFIC_FILES = [os.path.join("profiles", r + "_traffic_b{batch}.json") for r in ("r05", "r04", "r03", "r02")]     # newest first; one file per frames-per-call value
 ALL_CONFIGS = ["2-latency", "2-host-io", "2-bf16x3", "3", "4", "5"]
-DEFAULT_CHUNK = 128            # frames per extract / match call of the headline (tests/test_gpu_fullsize.py checks THIS size against the oracle)
+DEFAULT_CHUNK = 256            # frames per extract / match call of the headline (tests/test_gpu_fullsize.py checks THIS size against the oracle);
+                               # measured 96 / 128 / 160 / 192 / 256 frames per call: 7012 / 7131 / 7124 / 7229 / 7245 frames/s on one box (NOTEBOOK.md R5.6);
+                               # the gain flattens there (tests cover calls up to this size)
 DEFAULT_BATCH = 768            # frames per step and GPU
 
 

@@ -226,6 +226,7 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
         HF_HIP(copy_h2d_blocking(x->d_ialpha[l], ia.data(), ia.size() * sizeof(short)));
         HF_HIP(copy_h2d_blocking(x->d_yofs[l], yofs.data(), yofs.size() * sizeof(int)));
         HF_HIP(copy_h2d_blocking(x->d_ibeta[l], ib.data(), ib.size() * sizeof(short)));
+        x->pyr_band_rows[l] = e->impl.opt.resize_band ? resize_band_rows(yofs.data(), x->level_h[l], x->level_h[l - 1]) : 0;
     }
     HF_TRY(dalloc(x->allocs, &x->d_kps, (size_t)max_batch * n_features));
     HF_TRY(dalloc(x->allocs, &x->d_desc, (size_t)max_batch * n_features * HFNET_DESC_DIM));
@@ -315,7 +316,7 @@ static int extract_chunk(hfnet_extractor* x, int nb, const uint8_t* d_images, in
         const int dwp = (dw + 3) & ~3;              // pyramid rows are padded to 4 bytes (packed stores)
         HF_LAUNCH(&eng, net.stream, "pyramid_resize",
                   launch_resize_u8(imgs.ptr[l - 1], sw, sh, imgs.row_stride[l - 1], imgs.frame_stride[l - 1], x->d_pyr[l], dw, dh, dwp,
-                                   (long long)dwp * dh, x->d_xofs[l], x->d_ialpha[l], x->d_yofs[l], x->d_ibeta[l], nb, net.stream));
+                                   (long long)dwp * dh, x->d_xofs[l], x->d_ialpha[l], x->d_yofs[l], x->d_ibeta[l], nb, net.stream, x->pyr_band_rows[l]));
         imgs.ptr[l] = x->d_pyr[l]; imgs.row_stride[l] = dwp; imgs.frame_stride[l] = (long long)dwp * dh;
     }
     TopkBudget budget;

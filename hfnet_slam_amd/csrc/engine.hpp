@@ -99,6 +99,7 @@ struct Options {
     int conv_wlds = 1;        // 3x3 heads: weights staged through LDS once per workgroup (0: every wave reads them from L1 / L2)
     int db_gemm_min_queries = 8;   // hfnet_db_query_batch: from this many queries on, the scores come from the MFMA GEMM form
     int pyramid_fuse = 4;     // calls of up to this many frames: the pyramid chain as one launch (0: never)
+    int resize_band = 1;      // level-to-level resize of larger calls: source band of a workgroup staged through LDS (0: thread-per-column gathers from L2 / HBM)
     int det_fuse = 1;         // detector tail (1x1 conv, softmax, depth_to_space) as one launch
     int host_global = 1;      // host-pointer calls of up to four frames: the global descriptors are written into the pinned block by the branch's last kernel
     int interleave = 3;       // calls of up to four frames: launch groups of the global branch enqueued between the local heads' launches,
@@ -355,6 +356,7 @@ struct hfnet_extractor {
     int* d_xofs[HFNET_MAX_LEVELS] = {nullptr};
     short* d_ialpha[HFNET_MAX_LEVELS] = {nullptr};
     int* d_yofs[HFNET_MAX_LEVELS] = {nullptr};
+    int pyr_band_rows[HFNET_MAX_LEVELS] = {0};      // level l >= 1: resize_band_rows of its table (0: engine option resize_band off)
     short* d_ibeta[HFNET_MAX_LEVELS] = {nullptr};
     hfnet_keypoint* d_kps = nullptr;     // [max_batch][n_features]
     float* d_desc = nullptr;             // [max_batch][n_features][256]

@@ -10,7 +10,10 @@ namespace hfnet {
 hipError_t launch_resize_u8(const uint8_t* src, int sw, int sh, int s_row, long long s_frame,
                             uint8_t* dst, int dw, int dh, int d_row, long long d_frame,
                             const int* xofs, const short* ialpha, const int* yofs, const short* ibeta,
-                            int batch, hipStream_t s);
+                            int batch, hipStream_t s, int band_rows = 0);
+// band_rows > 0: the form that stages a workgroup's source band through LDS (each source row read once, as 16-byte pieces);
+// band_rows = resize_band_rows(host yofs table, dh, sh), the largest band of the level.  0: the thread-per-column form.
+int resize_band_rows(const int* yofs, int dh, int sh);
 // the whole chain level 0 -> 1 -> .. -> n (n <= 3) in one launch, same bytes (arrays indexed by level, [0] of dst / tables unused);
 // d_row: padded row length of a produced level (the padding repeats the last column, as launch_resize_u8 leaves it)
 bool pyramid_chain_supported(int n, const int* w, const int* h);

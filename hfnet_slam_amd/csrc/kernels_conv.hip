@@ -78,10 +78,140 @@ __global__ __launch_bounds__(256) void k_resize_u8(const uint8_t* __restrict__ s
     }
 }
 
+// ---- the same resize with the source band of a workgroup staged through LDS (calls of many frames).  k_resize_u8 is
+// latency-bound: a thread's eight output rows are eight dependent rounds of byte gathers from L2 / HBM (48 us per 128
+// frames for 57 MB: 0.15 of the HBM rate).  Here a workgroup owns RESIZE_ROWS output rows over the whole width: the source
+// rows they descend from (yofs is non-decreasing: rows clamp(yofs[first]) .. clamp(yofs[last] + 1), ~1.2 x 8 + 2 of them at
+// scale 1.2) are read ONCE, as aligned 16-byte pieces issued together -- a piece of a row keeps its offset inside its
+// 16-byte line, so that an aligned piece of memory is an aligned piece of LDS; only the bytes [0, sw) of a row are ever
+// read: the two partial pieces at a row's ends go byte by byte -- and the gathers come out of LDS.  Per pixel the arithmetic
+// is k_resize_u8's.  `pitch` (bytes per band row, a multiple of 16, >= sw + 30) and `cap_rows` (the largest band of the
+// level) size the LDS block; both come from the host, which has the tables.
+__global__ __launch_bounds__(256) void k_resize_u8_band(const uint8_t* __restrict__ src, int sw, int sh, int s_row, long long s_frame,
+                                                        uint8_t* __restrict__ dst, int dw, int dh, int d_row, long long d_frame,
+                                                        const int* __restrict__ xofs, const short* __restrict__ ialpha,
+                                                        const int* __restrict__ yofs, const short* __restrict__ ibeta, int pitch, int cap_rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char band[];
+    const int tid = threadIdx.x;
+    const int dx4 = tid * 4;                                   // (dw <= 1024: launch check)
+    const bool active = dx4 < dw;
+    const int dy0 = blockIdx.x * RESIZE_ROWS, dyl = min(dy0 + RESIZE_ROWS, dh) - 1;
+    const uint8_t* sp = src + (long long)blockIdx.y * s_frame;
+    // column tables first: their latency passes behind the band's
+    int sx[4], sx1[4], a0[4], a1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int dx = min(dx4 + c, dw - 1);
+        sx[c] = xofs[dx]; sx1[c] = min(sx[c] + 1, sw - 1);
+        a0[c] = ialpha[2 * dx]; a1[c] = ialpha[2 * dx + 1];
+    }
+    // ... and the row tables of all RESIZE_ROWS rows (k_resize_u8 fetches them row by row: eight dependent round trips to L2 per
+    // workgroup, which -- not the gathers -- is most of its time); ibeta's pair of shorts as one 4-byte load
+    int syv[RESIZE_ROWS], bwv[RESIZE_ROWS];
+#pragma unroll
+    for (int i = 0; i < RESIZE_ROWS; ++i) {
+        const int dyc = min(dy0 + i, dh - 1);
+        syv[i] = yofs[dyc];
+        bwv[i] = *(const int*)(ibeta + 2 * dyc);
+    }
+    const int ylo = min(max(syv[0], 0), sh - 1), yhi = min(max(yofs[dyl] + 1, 0), sh - 1);
+    const int nrows = min(yhi - ylo + 1, cap_rows);            // (the capacity is the level's largest band: this never cuts)
+    const int CH = pitch >> 4;                                 // 16-byte pieces per band row
+    const int total = nrows * CH;
+    for (int it0 = 0; it0 < total; it0 += 4 * 256) {           // four pieces per thread in flight (a band is ~600 pieces: one pass)
+        const uint8_t* rp[4];
+        int b0[4], lo[4];
+        bool whole[4];
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                           // straight-line loads: every thread reads SOME whole piece of its row
+            const int it = it0 + u * 256 + tid;
+            const int r = it / CH, c = it - r * CH;
+            rp[u] = sp + (long long)(ylo + min(r, nrows - 1)) * s_row;
+            const int mis = (int)((size_t)rp[u] & 15);
+            b0[u] = c * 16 - mis;                               // row byte of the piece's first byte; rp + b0 is 16-byte aligned
+            lo[u] = r * pitch + c * 16;
+            const int fw = (16 - mis) & 15, lw = fw + ((sw - fw) & ~15) - 16;      // first / last whole piece of the row (sw >= 32: launch check)
+            const int bc = min(max(b0[u], fw), lw);
+            whole[u] = it < total && bc == b0[u];
+            v[u] = *(const uint4*)(rp[u] + bc);
+            if (it >= total) b0[u] = sw;                        // (no piece)
+        }
+        // (the values are "used" here, all at once: left alone the optimiser sinks each load into the branch that stores it,
+        //  where it is waited for on the spot -- four dependent round trips instead of one)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (whole[u]) *(uint4*)(band + lo[u]) = v[u];
+            else if (b0[u] < sw && b0[u] > -16) {              // the partial pieces at a row's two ends: 16 clamped byte loads in flight,
+                unsigned char t[16];                            // the bytes inside [0, sw) kept
+#pragma unroll
+                for (int b = 0; b < 16; ++b) t[b] = rp[u][min(max(b0[u] + b, 0), sw - 1)];
+#pragma unroll
+                for (int b = 0; b < 16; ++b)
+                    if (b0[u] + b >= 0 && b0[u] + b < sw) band[lo[u] + b] = t[b];
+            }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    unsigned* dp = (unsigned*)(dst + (long long)blockIdx.y * d_frame + dx4);
+    struct H4 { int v[4]; };
+    auto hrow = [&](int y) {                                   // horizontal pass of source row y, out of the band
+        const unsigned char* lp = band + (y - ylo) * pitch + (int)((size_t)(sp + (long long)y * s_row) & 15);
+        H4 h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) h.v[c] = lp[sx[c]] * a0[c] + lp[sx1[c]] * a1[c];
+        return h;
+    };
+    int cache_y = -1;
+    H4 cache_v = {{0, 0, 0, 0}};
+#pragma unroll
+    for (int i = 0; i < RESIZE_ROWS; ++i) {
+        const int dy = dy0 + i;
+        if (dy >= dh) break;                                   // uniform
+        const int sy = syv[i];
+        const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
+        const int b0 = (short)(bwv[i] & 0xffff), b1 = bwv[i] >> 16;
+        const H4 r0 = y0 == cache_y ? cache_v : hrow(y0);      // uniform condition
+        const H4 r1 = y1 == y0 ? r0 : hrow(y1);
+        cache_y = y1; cache_v = r1;
+        unsigned packed = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int v = (((b0 * (r0.v[c] >> 4)) >> 16) + ((b1 * (r1.v[c] >> 4)) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+            packed |= (unsigned)v << (8 * c);
+        }
+        dp[((long long)dy * d_row) >> 2] = packed;
+    }
+}
+
+// largest number of source rows a band of RESIZE_ROWS output rows descends from (host table of the level)
+int resize_band_rows(const int* yofs, int dh, int sh) {
+    int cap = 1;
+    for (int dy0 = 0; dy0 < dh; dy0 += RESIZE_ROWS) {
+        const int dyl = std::min(dy0 + RESIZE_ROWS, dh) - 1;
+        const int ylo = std::min(std::max(yofs[dy0], 0), sh - 1), yhi = std::min(std::max(yofs[dyl] + 1, 0), sh - 1);
+        cap = std::max(cap, yhi - ylo + 1);
+    }
+    return cap;
+}
+
 hipError_t launch_resize_u8(const uint8_t* src, int sw, int sh, int s_row, long long s_frame, uint8_t* dst, int dw, int dh,
                             int d_row, long long d_frame, const int* xofs, const short* ialpha, const int* yofs,
-                            const short* ibeta, int batch, hipStream_t s) {
+                            const short* ibeta, int batch, hipStream_t s, int band_rows) {
     if ((d_row & 3) || (d_frame & 3) || ((size_t)dst & 3)) return hipErrorInvalidValue;      // packed 32-bit stores
+    if (band_rows > 0 && dw <= 1024 && sw >= 32) {
+        const int pitch = ((sw + 30) / 16 + 1) * 16;
+        const size_t lds = (size_t)band_rows * pitch;
+        if (lds <= 48 * 1024) {
+            hipLaunchKernelGGL(k_resize_u8_band, dim3((dh + RESIZE_ROWS - 1) / RESIZE_ROWS, batch), dim3(256), lds, s, src, sw, sh, s_row, s_frame,
+                               dst, dw, dh, d_row, d_frame, xofs, ialpha, yofs, ibeta, pitch, band_rows);
+            return hipGetLastError();
+        }
+    }
     dim3 grid(((dw + 3) / 4 + 255) / 256, (dh + RESIZE_ROWS - 1) / RESIZE_ROWS, batch);
     hipLaunchKernelGGL(k_resize_u8, grid, dim3(256), 0, s, src, sw, sh, s_row, s_frame, dst, dw, dh, d_row, d_frame, xofs, ialpha, yofs, ibeta);
     return hipGetLastError();

@@ -93,7 +93,9 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *   "db_gemm_min_queries" (8): hfnet_db_query_batch screens on the bf16 matrix pipe from this many queries on (same bits either way)
  *   "tail_fuse" (4)     calls of up to this many frames run layers 8-18 with the single-frame kernels (depthwise + projection
  *                       in one launch, short-latency MFMA chains); 0: never
- *   "pyramid_fuse" (1)  calls of up to four frames: the pyramid resize chain as one launch
+ *   "pyramid_fuse" (4)  calls of up to this many frames: the pyramid resize chain as one launch
+ *   "resize_band" (1)   larger calls: each level-to-level resize stages a workgroup's source rows through LDS once (0: per-thread
+ *                       byte gathers from L2 / HBM); same bytes either way
  *   "interleave" (3)    calls of up to four frames: the launch groups of the global branch are enqueued between the launches
  *                       of the local heads, this many right after the detector conv (0: the whole branch after the local heads)
  *   "det_fuse" (1)      detector tail (1x1 conv 128 -> 65, softmax, depth_to_space) as one launch: the logits stay in LDS

@@ -62,13 +62,13 @@ def test_bench_sized_call_vs_oracle(engine, oracle_model, B):
     """A full call of bench.py's size (`bench.DEFAULT_CHUNK` frames, and 64) in ONE extract_batch -- where the GEMM-shaped layers
     switch kernels (weight slabs through LDS for the 120 -> 720 expansions, skipped keypoint-slot tiles in the descriptor head), the
     tile lists of the fused blocks double and the XCD slot arithmetic runs at its largest -- against the oracle on the first two
-    frames, the frames either side of the 64-frame boundary and the last one; natural and uniform frames mixed."""
+    frames, the frames either side of the 64- and 128-frame boundaries and the last one; natural and uniform frames mixed."""
     from hfnet_slam_amd import capi
     w, h, nf = 752, 480, 1000
     x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, 4, max_batch=B)
     imgs = np.stack([synth_image(h, w, 3000 + i, "natural" if i % 5 == 0 else "uniform") for i in range(B)])
     nb, kb, db, gb = x.extract_batch(imgs)
-    for i in sorted({0, 1, 21, 63, 64, B - 1} & set(range(B))):
+    for i in sorted({0, 1, 21, 63, 64, 127, 128, B - 1} & set(range(B))):
         rn, rk, rd, rg, _ = oracle_model.extract(imgs[i], nf, 0.01, 4, 1.2)
         assert nb[i] == rn, i
         assert np.array_equal(kb[i, :rn], rk) and np.array_equal(db[i, :rn], rd) and np.array_equal(gb[i], rg), i

@@ -164,6 +164,7 @@ def test_response_ties(weights_ties_path):
 # the single-frame path's own pieces on and off: pyramid chain in one launch, distinct tap cells, one launch per block for layers
 # 8-18, and the caller-owned result buffers of the wrapper
 EXTRACTOR_VARIANTS = {"default": {}, "unfused_stem": {"fuse_stem": 0}, "separate_launches": {"pyramid_fuse": 0, "dedupe_taps": 0, "tail_fuse": 0},
+                      "resize_gather": {"pyramid_fuse": 0, "resize_band": 0},
                       "no_graph": {"graph": 0, "pinned_frames": 0}, "plain_launches": {"graph": 0},
                       "branch_after_heads": {"interleave": 0, "host_global": 0}}
 
@@ -464,6 +465,51 @@ def test_triangulation_screened_path(engine, tri_screen):
             _eq(f"pair {p} {(a, b)}", match[p, :n_rows[a]], rm)
     finally:
         engine.set_option("tri_screen_bf16", 1)
+
+
+@pytest.mark.parametrize("band", [1, 0])
+def test_pyramid_resize_of_misaligned_device_rois(engine, oracle_model, engine_options, band):
+    """Level-to-level resize of calls beyond pyramid_fuse (k_resize_u8_band: a workgroup's source rows through LDS as aligned 16-byte
+    pieces, the partial pieces at a row's ends byte by byte; resize_band = 0: the per-thread gathers).  Device-resident frames that are
+    ROIs of a larger buffer at odd offsets with an odd row stride give every piece alignment a turn; the buffer ENDS with the last
+    ROI row's last byte, so a read past a row's end is a read past the allocation (the guard modes of test_gpu_guard.py fault on it).
+    Widths that are not multiples of 4 / 16, one level wider than 1024 columns (the gather form's territory)."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    from hfnet_slam_amd import capi
+    engine_options({"resize_band": band, "pyramid_fuse": 0})
+    dev = torch.device("cuda", 0)
+    for (w, h, nl, F, ox, oy, pad) in [(203, 157, 4, 6, 5, 3, 13), (160, 120, 3, 5, 1, 0, 0), (1236, 72, 2, 5, 7, 2, 3)]:
+        nf = 200
+        x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, nl, max_batch=F)
+        imgs = np.stack([synth_image(h, w, 4100 + i, "natural" if i % 2 else "uniform") for i in range(F)])
+        rs = ox + w + pad                                       # odd row stride
+        fs = (oy + h) * rs + 11                                 # odd frame stride
+        flat = np.full(F * fs, 0xEE, np.uint8)
+        for i in range(F):
+            for r in range(h):
+                o = i * fs + (oy + r) * rs + ox
+                flat[o:o + w] = imgs[i, r]
+        last = (F - 1) * fs + (oy + h - 1) * rs + ox + w        # one past the last ROI byte: the allocation ends here
+        d_img = torch_to_device(flat[:last], dev)
+        kps = torch.zeros((F, nf, 4), dtype=torch.float32, device=dev)
+        desc = torch.zeros((F, nf, 256), dtype=torch.float32, device=dev)
+        glob = torch.zeros((F, engine.global_dim), dtype=torch.float32, device=dev)
+        n_rows = torch.zeros((F,), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        x.extract_batch_device(F, d_img.data_ptr() + oy * rs + ox, rs, fs, kps.data_ptr(), desc.data_ptr(), glob.data_ptr(), n_rows.data_ptr())
+        engine.synchronize(); torch.cuda.synchronize()
+        n_d = torch_to_host(n_rows); k_d = torch_to_host(kps); d_d = torch_to_host(desc); g_d = torch_to_host(glob)
+        for i in range(F):
+            rn, rk, rd, rg, _ = oracle_model.extract(imgs[i], nf, 0.01, nl, 1.2)
+            assert n_d[i] == rn, (w, h, i, n_d[i], rn)
+            for j, f in enumerate(("x", "y", "response")):
+                _eq(f"{w}x{h} frame {i} kps.{f}", k_d[i, :rn, j], rk[f])
+            _eq(f"{w}x{h} frame {i} desc", d_d[i, :rn], rd)
+            _eq(f"{w}x{h} frame {i} global", g_d[i], rg)
+        assert x.device_faults() == 0
+        x.close()
 
 
 @pytest.mark.parametrize("streams", [0, 1, 2, 3])

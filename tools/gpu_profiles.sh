@@ -3,7 +3,7 @@
 # FETCH_SIZE / WRITE_SIZE passes folded into <tag>_traffic_b<chunk>.json (chunk = bench.py's default frames per call).  Copy what is to be judged into profiles/.
 set -x
 TAG=$1
-CH=128   # bench.py default --chunk
+CH=$(cd $GRAFT_REPO_ROOT && python -c 'import bench; print(bench.DEFAULT_CHUNK)')   # bench.py default --chunk
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_profiles
 mkdir -p $OUT
