@@ -956,7 +956,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="frames per step and GPU")
-    ap.add_argument("--chunk", type=int, default=DEFAULT_CHUNK, help="frames per extract / match call (the extractor's batch)")
+    ap.add_argument("--chunk", type=int, default=None, help=f"frames per extract / match call (the extractor's batch); default {DEFAULT_CHUNK}, or --batch when that is smaller")
     ap.add_argument("--frames", choices=["uniform", "natural"], default="uniform", help="synthetic frame distribution (SURVEY.md 8d)")
     ap.add_argument("--configs", default="all", help="comma list of sub-records to measure besides the headline: " + ",".join(ALL_CONFIGS) + " | all | none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -969,7 +969,9 @@ def main() -> None:
                          "instead of the kernels; the line is marked invalid")
     args = ap.parse_args()
     want = ALL_CONFIGS if args.configs == "all" else [] if args.configs == "none" else [c.strip() for c in args.configs.split(",")]
-    if args.batch % args.chunk:
+    if args.chunk is None:
+        args.chunk = min(DEFAULT_CHUNK, args.batch)
+    if args.chunk < 1 or args.batch % args.chunk:
         raise SystemExit("--batch must be a multiple of --chunk")
     dry = args.dry_ranks > 0
     if dry and args.dry_ranks != args.gpus:
