@@ -99,6 +99,8 @@ struct Options {
     int conv_wlds = 1;        // 3x3 heads: weights staged through LDS once per workgroup (0: every wave reads them from L1 / L2)
     int db_gemm_min_queries = 8;   // hfnet_db_query_batch: from this many queries on, the scores come from the MFMA GEMM form
     int pyramid_fuse = 4;     // calls of up to this many frames: the pyramid chain as one launch (0: never)
+    int fc_tile = 1;          // FC 7680 -> 4096 of calls above 16 frames: 1 blocked kernel (weights shared through LDS, range partials in registers) when its
+                              // workgroups fill the chip, 2 / 4: that kernel with 32 / 64 columns per workgroup at any size (tests), 0: one column tile per wave
     int resize_band = 1;      // level-to-level resize of larger calls: source band of a workgroup staged through LDS (0: thread-per-column gathers from L2 / HBM)
     int det_fuse = 1;         // detector tail (1x1 conv, softmax, depth_to_space) as one launch
     int host_global = 1;      // host-pointer calls of up to four frames: the global descriptors are written into the pinned block by the branch's last kernel

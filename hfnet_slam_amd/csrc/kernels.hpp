@@ -151,7 +151,9 @@ size_t fc_scratch_floats(const FcPack& fc, int frames);
 // (seq[0], kept on the device; seq[1] counts the workgroups that are done) into `flag`; calls of up to four frames only
 struct FcHostOut { float* out = nullptr; int* flag = nullptr; int* seq = nullptr; };
 bool fc_host_out_supported(int frames);
-hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* partial, float* y_raw, float* out, int frames, hipStream_t s, FcHostOut host = FcHostOut());
+// fc_tile (engine option): 1 = the blocked kernel (k_fc_mfma_tile) for calls whose 64-frame workgroups fill the chip, 2 / 4 = that kernel with
+// 32 / 64 columns per workgroup at any size above 16 frames (tests), 0 = never
+hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* partial, float* y_raw, float* out, int frames, hipStream_t s, FcHostOut host = FcHostOut(), int fc_tile = 1);
 
 // ---- kernels_match.hip --------------------------------------------------------------------------
 // BFMatcher(NORM_L2, crossCheck) + distance < th_low (Matcher.cc:229-260), batched over descriptor-set pairs.

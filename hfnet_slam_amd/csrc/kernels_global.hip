@@ -335,6 +335,125 @@ __global__ __launch_bounds__(256) void k_fc_mfma_seq(const float* __restrict__ x
     }
 }
 
+// Many frames per call, blocked (calls that fill the chip with 64-frame x 16 NCT-column workgroups).  k_fc_mfma_seq runs at the OPERAND
+// rate: a wave fetches 1 KB of activations and 1 KB of weights per four MFMAs, the four waves of a workgroup fetch the SAME weights,
+// and two workgroups per CU ask the load path for 128 bytes per clock (0.34 of the f32 MFMA peak at 256 frames).  Here a wave owns 16
+// frames x NCT column tiles (its activations serve NCT tiles), the workgroup's weight pieces -- the same for its four row tiles -- are
+// fetched ONCE, one 16-byte piece per thread and k-group, and shared through a double-buffered LDS block of FC_S k-groups (one barrier
+// per round: a buffer is rewritten two rounds after it was read), and the 64 KB of range partials are gone: a completed range is merged
+// as a binary counter (range 1 joins range 0 when it completes, (2, 3) joins (0, 1) when 3 completes, ...), which adds exactly the
+// pairs of fc_combine_one's balanced tree in its order -- four pending levels in registers instead of sixteen LDS slots.  Per
+// (frame, output) the chain is k_fc_mfma_seq's: k-groups ascending, four MFMAs each, a fresh accumulator per input range.
+#define FC_S 6
+template <int NCT>
+__global__ __launch_bounds__(256) void k_fc_mfma_tile(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      float* __restrict__ y_raw, int frames, int n_in, int n_out) {
+    constexpr int PCS = NCT * 64;                                 // weight pieces of the workgroup per k-group
+    constexpr int PER_T = FC_S * PCS / 256;                       // pieces a thread stages per round
+    static_assert((FC_S * PCS) % 256 == 0, "whole pieces per thread");
+    __shared__ f32x4 wb[2][FC_S * PCS];                           // 2 x 6 x NCT KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ctiles = n_out >> 4, ct0 = blockIdx.x * NCT, rt = blockIdx.y * 4 + wave;
+    const bool live = rt * 16 < frames;                           // (a wave without frames still stages weights and meets the barriers)
+    const int row = min(rt * 16 + (lane & 15), frames - 1);
+    const f32x4* __restrict__ ap = (const f32x4*)(x + (long long)row * n_in) + (lane >> 4);
+    const f32x4* __restrict__ wp = (const f32x4*)w + (size_t)ct0 * 64;
+    const size_t wstep = (size_t)ctiles * 64;
+    const int KG_all = n_in >> 4, gp = (KG_all + FC_PARTS - 1) / FC_PARTS;
+    f32x4 acc[NCT], lvl[4][NCT], total[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) { acc[c] = f32x4{0.f, 0.f, 0.f, 0.f}; total[c] = acc[c]; }
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) lvl[l][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // rounds never straddle a range: a range is rpp rounds of FC_S k-groups (7680 inputs: 30 k-groups = 5 rounds of 6); the slots of a
+    // short last round get ZERO activations -- fma(0, w, acc) == acc, and an accumulator that started at +0 is never -0 -- so the MFMAs
+    // of a round are straight-line code (a branch per k-group makes the compiler park the accumulators in vector registers around it:
+    // 32 moves and a drained matrix pipe per k-group) and a range completes at ONE place in the code
+    const int rpp = (gp + FC_S - 1) / FC_S;
+    f32x4 an[FC_S], bs[PER_T];                                    // the next round's activations / this thread's weight pieces
+    int nv_next = 0;
+    auto fetch = [&](int q, int rr) {                             // round rr of range q -> registers
+        const int k0 = q * gp + rr * FC_S, kl = max(KG_all - 1, 0);
+        nv_next = min(min((q + 1) * gp, KG_all), k0 + FC_S) - k0;                  // slots of the round that exist (the others are zeroed when USED:
+#pragma unroll                                                                      //  a select right here would wait for the loads it is meant to hide)
+        for (int s = 0; s < FC_S; ++s) an[s] = ap[min(k0 + s, kl) * 4];
+#pragma unroll
+        for (int j = 0; j < PER_T; ++j) {
+            const int pc = j * 256 + tid, sl = pc / PCS, o = pc - sl * PCS;       // slot (uniform per wave: PCS is 128 or 256) and piece
+            const int kg = __builtin_amdgcn_readfirstlane(min(k0 + sl, kl));
+            bs[j] = wp[(size_t)kg * wstep + o];
+        }
+    };
+    fetch(0, 0);
+    int buf = 0;
+    for (int q = 0; q < FC_PARTS; ++q) {
+        for (int rr = 0; rr < rpp; ++rr) {
+            f32x4 av[FC_S];
+            const int nv = nv_next;
+#pragma unroll
+            for (int s = 0; s < FC_S; ++s) av[s] = s < nv ? an[s] : f32x4{0.f, 0.f, 0.f, 0.f};          // (uniform select)
+#pragma unroll
+            for (int j = 0; j < PER_T; ++j) wb[buf][j * 256 + tid] = bs[j];
+            __syncthreads();
+            {   // the next round, unconditionally (the last one re-reads itself; see k_pointwise_deep): in flight during this round's MFMAs
+                const bool last_rr = rr + 1 == rpp, last = last_rr && q + 1 == FC_PARTS;
+                fetch(last ? q : last_rr ? q + 1 : q, last ? rr : last_rr ? 0 : rr + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4* __restrict__ bp = wb[buf] + lane;
+#pragma unroll
+            for (int s = 0; s < FC_S; ++s) {
+                f32x4 bv[NCT];
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) bv[c] = bp[s * PCS + c * 64];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][t], bv[c][t], acc[c], 0, 0, 0);
+            }
+            buf ^= 1;
+        }
+        // range q is complete: merge it as a binary counter -- the pairs and the order of fc_combine_one's balanced tree (an empty range
+        // adds zeros, as there)
+        f32x4 v[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) { v[c] = acc[c]; acc[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        bool placed = false;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            if (!placed) {
+                if ((q >> l) & 1) {
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[c][e] = lvl[l][c][e] + v[c][e];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c) lvl[l][c] = v[c];
+                    placed = true;
+                }
+            }
+        }
+        if (!placed) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) total[c] = v[c];
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        const int col = (ct0 + c) * 16 + (lane & 15);
+        const float b = bias[col];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int rr = rt * 16 + (lane >> 4) * 4 + reg;
+            if (rr < frames) y_raw[(long long)rr * n_out + col] = total[c][reg] + b;
+        }
+    }
+}
+
 __device__ __forceinline__ float fc_combine_one(const float* __restrict__ partial, const float* __restrict__ bias, int frames, int n, int f, int i) {
     float p[FC_PARTS];
 #pragma unroll
@@ -390,12 +509,18 @@ size_t fc_scratch_floats(const FcPack& fc, int frames) { return (size_t)FC_PARTS
 
 bool fc_host_out_supported(int frames) { return frames >= 1 && frames <= 4; }
 
-hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* partial, float* y_raw, float* out, int frames, hipStream_t s, FcHostOut host) {
+hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* partial, float* y_raw, float* out, int frames, hipStream_t s, FcHostOut host, int fc_tile) {
     if (frames <= 0) return hipSuccess;
     if (fc.n_in % 16 || fc.n_out % 16) return hipErrorInvalidValue;
     const int waves = std::min(4, (frames + 15) / 16);
     if (host.out && !fc_host_out_supported(frames)) return hipErrorInvalidValue;
     if (frames > 16) {
+        // blocked form when its workgroups fill the chip (256 CUs): 64 frames x 64 columns each, 64 x 32 for fewer frames
+        const int rg = (frames + 63) / 64;
+        const int nct = fc_tile <= 0 ? 0 : fc_tile == 2 || fc_tile == 4 ? fc_tile : (fc.n_out / 64) * rg >= 256 ? 4 : (fc.n_out / 32) * rg >= 256 ? 2 : 0;
+        if (nct == 4 && fc.n_out % 64 == 0) hipLaunchKernelGGL(k_fc_mfma_tile<4>, dim3(fc.n_out / 64, rg), dim3(256), 0, s, x, fc.w, fc.bias, y_raw, frames, fc.n_in, fc.n_out);
+        else if (nct == 2 && fc.n_out % 32 == 0) hipLaunchKernelGGL(k_fc_mfma_tile<2>, dim3(fc.n_out / 32, rg), dim3(256), 0, s, x, fc.w, fc.bias, y_raw, frames, fc.n_in, fc.n_out);
+        else
         hipLaunchKernelGGL(k_fc_mfma_seq<16>, dim3(fc.n_out / 16, (frames + 63) / 64), dim3(64 * waves), 0, s, x, fc.w, fc.bias, y_raw, frames, fc.n_in, fc.n_out);
         hipLaunchKernelGGL(k_l2norm_vec, dim3(frames), dim3(256), 0, s, y_raw, out, fc.n_out);
         return hipGetLastError();

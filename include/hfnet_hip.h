@@ -94,6 +94,9 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *   "tail_fuse" (4)     calls of up to this many frames run layers 8-18 with the single-frame kernels (depthwise + projection
  *                       in one launch, short-latency MFMA chains); 0: never
  *   "pyramid_fuse" (4)  calls of up to this many frames: the pyramid resize chain as one launch
+ *   "fc_tile" (1)       dimensionality reduction of calls above 16 frames: blocked kernel (a workgroup's weight pieces shared through LDS, the 16
+ *                       range partials merged in registers in the balanced tree's order) when its workgroups fill the chip; 2 / 4: that kernel
+ *                       with 32 / 64 columns per workgroup at any size; 0: one column tile per wave.  Same bits either way
  *   "resize_band" (1)   larger calls: each level-to-level resize stages a workgroup's source rows through LDS once (0: per-thread
  *                       byte gathers from L2 / HBM); same bytes either way
  *   "interleave" (3)    calls of up to four frames: the launch groups of the global branch are enqueued between the launches

@@ -203,15 +203,20 @@ def test_extractor_matches_oracle(engine, oracle_model, cfg, variant, engine_opt
     x.close()
 
 
-def test_many_frames_per_call_global_descriptor(engine, oracle_model):
-    """calls of more than 16 frames take the FC form that walks the 16 input ranges as one stream (k_fc_mfma_seq), with a partial last
-    16-frame row tile here: every frame's global descriptor (and keypoints) must equal the oracle's"""
+@pytest.mark.parametrize("fc_tile,B", [(0, 21), (2, 21), (4, 21), (4, 70), (2, 130)])
+def test_many_frames_per_call_global_descriptor(engine, oracle_model, engine_options, fc_tile, B):
+    """calls of more than 16 frames take the FC form that walks the 16 input ranges as one stream (k_fc_mfma_seq, fc_tile = 0), or the
+    blocked form (k_fc_mfma_tile: weights shared through LDS, the range partials merged as a binary counter in registers; fc_tile = 2 / 4
+    force it with 32 / 64 columns per workgroup at sizes the default dispatch gives to the other kernel) -- with a partial last 16-frame
+    row tile, a second / third 64-frame row group and waves without frames here: every frame's global descriptor (and keypoints) must
+    equal the oracle's"""
     from hfnet_slam_amd import capi
-    w, h, nf, nl, B = 96, 96, 64, 2, 21
+    engine_options({"fc_tile": fc_tile})
+    w, h, nf, nl = 96, 96, 64, 2
     x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, nl, max_batch=B)
     imgs = np.stack([synth_image(h, w, 4100 + i, "natural" if i % 3 else "uniform") for i in range(B)])
     nb, kb, db, gb = x.extract_batch(imgs)
-    for i in range(B):
+    for i in sorted(set(range(B)) if B <= 21 else {0, 1, 15, 16, 63, 64, 65, B - 2, B - 1}):
         rn, rk, rd, rg, _ = oracle_model.extract(imgs[i], nf, 0.01, nl, 1.2)
         assert nb[i] == rn
         _eq(f"kps {i}", kb[i, :rn], rk); _eq(f"desc {i}", db[i, :rn], rd); _eq(f"global {i}", gb[i], rg)
