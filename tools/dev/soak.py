@@ -56,7 +56,8 @@ def run(budget_s: float, seed: int, big_share: float = 0.02, max_cases: int = 0)
         eng = capi.Engine(wpath, 0)
         opts = {"fuse_blocks": int(rng.integers(0, 2)), "fused_variant": int(rng.choice([2, 4, 6, 8])), "fuse_min_wgs": int(rng.choice([0, 256])), "fuse_stem": int(rng.integers(0, 2)),
                 "dense_desc": int(rng.integers(0, 2)), "two_streams": int(rng.integers(0, 4)), "conv_wlds": int(rng.integers(0, 2)),
-                "match_screen_bf16": int(rng.integers(0, 2)), "tri_screen_bf16": int(rng.integers(0, 2))}
+                "match_screen_bf16": int(rng.integers(0, 2)), "tri_screen_bf16": int(rng.integers(0, 2)),
+                "fc_tile": int(rng.choice([0, 1, 2, 4])), "resize_band": int(rng.integers(0, 2)), "pyramid_fuse": int(rng.choice([0, 4]))}
         if rng.random() < 0.5:
             opts = {}
         for k, v in opts.items():
