@@ -27,7 +27,7 @@ SYMBOLS = [
     "hfnet_model_create", "hfnet_model_destroy", "hfnet_model_is_valid", "hfnet_model_mode",
     "hfnet_model_detect", "hfnet_model_detect_global", "hfnet_model_tap", "hfnet_model_device_faults",
     "hfnet_extractor_create", "hfnet_extractor_destroy", "hfnet_extractor_tables",
-    "hfnet_extractor_extract", "hfnet_extractor_extract_batch", "hfnet_extractor_last_timing", "hfnet_extractor_device_faults", "hfnet_host_register", "hfnet_host_unregister",
+    "hfnet_extractor_extract", "hfnet_extractor_extract_batch", "hfnet_extractor_last_timing", "hfnet_extractor_device_faults", "hfnet_extractor_tap", "hfnet_host_register", "hfnet_host_unregister",
     "hfnet_descriptor_distance", "hfnet_resampler", "hfnet_match_search_by_bow", "hfnet_match_search_by_bow_batch", "hfnet_match_search_for_triangulation", "hfnet_match_search_for_triangulation_batch",
     "hfnet_match_candidates", "hfnet_distinctive_descriptors",
     "hfnet_extractor_attach_store", "hfnet_store_create", "hfnet_store_destroy", "hfnet_store_put", "hfnet_store_put_extracted", "hfnet_store_rows", "hfnet_store_set_flags", "hfnet_store_search_by_bow",
@@ -131,7 +131,7 @@ class Engine:
         _chk(lib().hfnet_engine_get_option(self.h, name.encode(), C.byref(v)))
         return v.value
 
-    OPTIONS = ("fuse_blocks", "fuse_max_layer", "fused_variant", "fuse_stem", "dense_desc", "conv_wlds", "two_streams", "graph", "pinned_frames", "db_gemm_min_queries", "fuse_min_wgs", "copy_threads", "tail_fuse", "dedupe_taps", "pyramid_fuse", "resize_band", "fc_tile", "interleave", "host_global", "det_fuse", "match_screen_bf16", "tri_screen_bf16", "desc_bf16x3", "global_bf16x3", "join_fused_branch")
+    OPTIONS = ("fuse_blocks", "fuse_max_layer", "fused_variant", "fuse_stem", "dense_desc", "conv_wlds", "two_streams", "graph", "pinned_frames", "db_gemm_min_queries", "fuse_min_wgs", "copy_threads", "tail_fuse", "dedupe_taps", "pyramid_fuse", "resize_band", "fc_tile", "interleave", "host_global", "det_fuse", "match_screen_bf16", "tri_screen_bf16", "desc_bf16x3", "global_bf16x3", "scores_bf16x3", "join_fused_branch")
 
     def options(self) -> dict:
         return {n: self.get_option(n) for n in self.OPTIONS}
@@ -333,6 +333,24 @@ class Extractor:
         b = C.c_uint(0)
         _chk(lib().hfnet_extractor_device_faults(self.h, C.byref(b)))
         return int(b.value)
+
+    def tap(self, tap_id: int, n_frames: int):
+        """Diagnostics: a tensor of the last call (of n_frames frames), per level: list of arrays [n_frames, H_l, W_l(, C)].  Only taps whose
+        per-level shapes the wrapper knows: 22 (dense scores) and 25 (scores after NMS), both at the cropped level size."""
+        assert tap_id in (22, 25)
+        cap = 1 << 28
+        buf = np.empty((cap,), np.float32)
+        cnt = C.c_size_t(0)
+        _chk(lib().hfnet_extractor_tap(self.h, tap_id, _p(buf), C.c_size_t(cap), C.byref(cnt)))
+        _, _, lw, lh = self.tables()
+        out, off = [], 0
+        for l in range(self.n_levels):
+            hc, wc = int(lh[l]) // 8 * 8, int(lw[l]) // 8 * 8
+            n = n_frames * hc * wc
+            out.append(buf[off:off + n].reshape(n_frames, hc, wc).copy())
+            off += n
+        assert off == cnt.value, (off, cnt.value)
+        return out
 
     def last_timing(self):
         """host-side stamps (us since entry) of the last latency-path call: image staged, enqueued, local results seen,

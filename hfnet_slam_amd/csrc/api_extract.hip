@@ -735,6 +735,18 @@ int hfnet_extractor_device_faults(hfnet_extractor* x, unsigned int* bits) try {
     return x->net.read_faults(bits);
 } catch (...) { return ::hfnet::api_exception(); }
 
+int hfnet_extractor_tap(hfnet_extractor* x, int tap, float* out, size_t capacity, size_t* count) try {
+    API_GUARD(x, "extractor"); API_GUARD(out, "out"); API_GUARD(count, "count");
+    std::lock_guard<std::mutex> lk(x->mu);
+    HF_HIP(hipSetDevice(x->eng->impl.device));
+    std::vector<float> v;
+    HF_TRY(x->net.tap(tap, v));
+    *count = v.size();
+    if (v.size() > capacity) { set_error("tap %d needs %zu floats, buffer holds %zu", tap, v.size(), capacity); return HFNET_ERR_CAPACITY; }
+    std::memcpy(out, v.data(), v.size() * sizeof(float));
+    return HFNET_OK;
+} catch (...) { return ::hfnet::api_exception(); }
+
 int hfnet_extractor_last_timing(hfnet_extractor* x, double* us, int n) try {
     API_GUARD(x, "extractor"); API_GUARD(us, "us");
     std::lock_guard<std::mutex> lk(x->mu);

@@ -129,8 +129,8 @@ struct BlockPack {
     ConvPack ex; DwPack dw; ConvPack pr;
     ConvPack16 pr16, ex16;         // projection / expansion for k_dwproject (layers 8-18 / 9-18)
     float* pr_logical = nullptr;   // projection weights [k logical][n physical] for the vector-ALU layer_2 kernel
-    void* ex_bf = nullptr;         // expansion / projection weights split into bf16 pieces (engine option global_bf16x3: the blocks that run as
-    void* pr_bf = nullptr;         // three launches, layers 15-18)
+    void* ex_bf = nullptr;         // expansion / projection weights split into bf16 pieces (engine options scores_bf16x3: layers 3-7,
+    void* pr_bf = nullptr;         // global_bf16x3: layers 8-18)
 };
 
 struct DeviceWeights {
@@ -141,6 +141,8 @@ struct DeviceWeights {
     ConvPack desc1, desc2, det1, det2, memb;
     void* desc1_bf = nullptr;     // the descriptor head's weights split into bf16 pieces (launch_repack_bf16x3; engine option desc_bf16x3),
     void* desc2_bf = nullptr;     // null where the shapes do not fit the split-bf16 kernels
+    void* det1_bf = nullptr;      // the detector head's (engine option scores_bf16x3)
+    void* det2_bf = nullptr;
     ConvPack16 memb16;            // the memberships conv as the "next 1x1" of layer 18's k_dwproject
     float* clusters = nullptr;    // [K][D] logical
     FcPack fc;                    // dimensionality reduction 7680 -> 4096

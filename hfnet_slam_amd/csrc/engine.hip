@@ -22,7 +22,7 @@ int* Options::find(const char* name) {
     const struct { const char* n; int* p; } tab[] = {{"fuse_blocks", &fuse_blocks}, {"fuse_max_layer", &fuse_max_layer}, {"fused_variant", &fused_variant},
                                                        {"fuse_stem", &fuse_stem}, {"dense_desc", &dense_desc}, {"two_streams", &two_streams},
                                                        {"graph", &graph}, {"pinned_frames", &pinned_frames}, {"db_gemm_min_queries", &db_gemm_min_queries},
-                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}, {"resize_band", &resize_band}, {"fc_tile", &fc_tile}, {"interleave", &interleave}, {"host_global", &host_global}, {"det_fuse", &det_fuse}, {"match_screen_bf16", &match_screen_bf16}, {"tri_screen_bf16", &tri_screen_bf16}, {"desc_bf16x3", &desc_bf16x3}, {"global_bf16x3", &global_bf16x3}, {"join_fused_branch", &join_fused_branch}};
+                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}, {"resize_band", &resize_band}, {"fc_tile", &fc_tile}, {"interleave", &interleave}, {"host_global", &host_global}, {"det_fuse", &det_fuse}, {"match_screen_bf16", &match_screen_bf16}, {"tri_screen_bf16", &tri_screen_bf16}, {"desc_bf16x3", &desc_bf16x3}, {"global_bf16x3", &global_bf16x3}, {"scores_bf16x3", &scores_bf16x3}, {"join_fused_branch", &join_fused_branch}};
     for (const auto& t : tab) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -146,7 +146,7 @@ int Net::build(Engine* eng, const NetConfig& c) {
     e = eng;
     cfg = c;
     // A/B and diagnostics switches of the engine (hfnet_engine_set_option), fixed for the lifetime of this network
-    fuse_blocks = e->opt.fuse_blocks; fuse_max_layer = e->opt.fuse_max_layer; fused_variant = e->opt.fused_variant; fuse_min_wgs = e->opt.fuse_min_wgs; tail_fuse = e->opt.tail_fuse; dedupe_taps = e->opt.dedupe_taps; interleave = e->opt.interleave; det_fuse = e->opt.det_fuse; desc_bf16x3 = e->opt.desc_bf16x3; global_bf16x3 = e->opt.global_bf16x3;
+    fuse_blocks = e->opt.fuse_blocks; fuse_max_layer = e->opt.fuse_max_layer; fused_variant = e->opt.fused_variant; fuse_min_wgs = e->opt.fuse_min_wgs; tail_fuse = e->opt.tail_fuse; dedupe_taps = e->opt.dedupe_taps; interleave = e->opt.interleave; det_fuse = e->opt.det_fuse; desc_bf16x3 = e->opt.desc_bf16x3; global_bf16x3 = e->opt.global_bf16x3; scores_bf16x3 = e->opt.scores_bf16x3;
     force_dense = e->opt.dense_desc; fuse_stem = e->opt.fuse_stem; conv_wlds = e->opt.conv_wlds;
     const DeviceWeights& w = e->w;
     if (c.n_levels < 1 || c.n_levels > HFNET_MAX_LEVELS || c.batch < 1) { set_error("net: bad level / batch count"); return HFNET_ERR_INVALID_ARG; }
@@ -303,7 +303,8 @@ static int run_block(Net& n, int L, int n_used, hipStream_t st) {   // layer L =
     const bool fuse = block_runs_fused(n, L);
     if (fuse) {
         // option global_bf16x3 (layers past the index-deciding part of the network only): the block's 1x1 convolutions on split-bf16 operands
-        const bool bfb = n.global_bf16x3 && L > 7 && block_fused_bf16x3_supported(b);
+        // option scores_bf16x3: the same for layers 3-7 -- the score map then moves within its stated tolerance, and NMS / top-K are exact ON IT
+        const bool bfb = ((n.global_bf16x3 && L > 7) || (n.scores_bf16x3 && L <= 7)) && block_fused_bf16x3_supported(b);
         if (L > 7) n.branch_fused_used = true;
         char fn[32];
         snprintf(fn, sizeof fn, bfb ? "block_L%02d_bf16x3" : "block_L%02d", L);

@@ -112,6 +112,8 @@ struct Options {
     int tail_fuse = 4;        // calls of up to this many frames run layers 8-18 with the single-frame kernels (0: never)
     int global_bf16x3 = 0;    // 1: the 1x1 convolutions of layers 9-18 (fused blocks 9-14 of calls of more than four frames; the three-launch blocks
                               //    15-18) on split-bf16 operands: the global descriptor within the stated tolerance of the exact path (include/hfnet_hip.h)
+    int scores_bf16x3 = 0;    // 1: the 1x1 convolutions of layers 3-7 and the detector head on split-bf16 operands: the SCORE MAP within the stated tolerance of
+                              //    the exact path; NMS, threshold scan and top-K run exactly on that map (include/hfnet_hip.h)
     int join_fused_branch = 0;   // 1: a global branch that contains fused-block kernels is joined before the sampler of a few-frame call (the stop-gap of
                                  // NOTEBOOK.md R4.8 before its cause -- packed f32 instructions, now compiled out -- was found; kept as a diagnostic)
     int desc_bf16x3 = 0;      // 1: the sparse descriptor head (3x3 + 1x1 at the distinct tap cells) on split-bf16 operands: descriptors within the stated
@@ -226,7 +228,7 @@ struct Net {
     int tail_fuse = 4;
     int interleave = 3;
     int det_fuse = 1;
-    int desc_bf16x3 = 0, global_bf16x3 = 0;
+    int desc_bf16x3 = 0, global_bf16x3 = 0, scores_bf16x3 = 0;
     bool logits_valid = false;     // the logits tensor holds the last forward's values (the fused detector tail does not write it)
     int fuse_stem = 1;             // stem + layer_2 in one launch: the stem tensor is not materialised (its tap recomputes it on demand)
     int conv_wlds = 1;             // 3x3 heads with LDS-staged weights

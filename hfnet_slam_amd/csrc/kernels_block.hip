@@ -1751,7 +1751,9 @@ bool block_fusable(const BlockPack& b, int variant) { return fused_kind(b, varia
 bool block_fused_bf16x3_supported(const BlockPack& b) {
     const int nto = (b.cout + 31) / 32, kq = b.cin / 8, st = b.stride;
     return b.has_expand && b.ex_bf && b.pr_bf && b.cin % 8 == 0 && b.pr.nt_total == nto &&
-           ((st == 1 && kq == 6 && (nto == 2 || nto == 3)) || (st == 1 && kq == 9 && nto == 3));      // (layer 8: 240 + 48 fragment registers do not fit)
+           ((st == 1 && kq == 6 && (nto == 2 || nto == 3)) || (st == 1 && kq == 9 && nto == 3) ||      // layers 7, 9-14
+            (st == 2 && (kq == 2 || kq == 3) && nto == 1) || (st == 1 && kq == 3 && nto <= 2));         // layers 3, 5 / 4, 6 (scores_bf16x3)
+            // (layer 8: 240 + 48 fragment registers do not fit)
 }
 
 hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, const Geom& g, int variant, hipStream_t s, int bf16x3) {
@@ -1772,9 +1774,13 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
     FusedKind kind = fused_kind(b, variant);
     const bool small_launch = n_tiles < 2048;
     if (bf16x3 && block_fused_bf16x3_supported(b)) {              // engine option global_bf16x3: tolerance instead of the oracle's bits
-        if (kq == 6 && nto == 2) return launch_block_fused8_t<1, 2, 6, 2, true>(a, g, s);
-        if (kq == 6 && nto == 3) return launch_block_fused8_t<1, 3, 6, 2, true>(a, g, s);
-        if (kq == 9 && nto == 3) return launch_block_fused8_t<1, 3, 9, 2, true>(a, g, s);
+        if (st == 1 && kq == 6 && nto == 2) return launch_block_fused8_t<1, 2, 6, 2, true>(a, g, s);
+        if (st == 1 && kq == 6 && nto == 3) return launch_block_fused8_t<1, 3, 6, 2, true>(a, g, s);
+        if (st == 1 && kq == 9 && nto == 3) return launch_block_fused8_t<1, 3, 9, 2, true>(a, g, s);
+        if (st == 2 && kq == 2 && nto == 1) return launch_block_fused8_t<2, 1, 2, 2, true>(a, g, s);
+        if (st == 2 && kq == 3 && nto == 1) return launch_block_fused8_t<2, 1, 3, 2, true>(a, g, s);
+        if (st == 1 && kq == 3 && nto == 1) return launch_block_fused8_t<1, 1, 3, 3, true>(a, g, s);
+        if (st == 1 && kq == 3 && nto == 2) return launch_block_fused8_t<1, 2, 3, 2, true>(a, g, s);
     }
     if (kind == FUSED_V4 && variant == 4 && small_launch && fused_kind(b, 2) == FUSED_V2) kind = FUSED_V2;
     // v6 (6 x 8 tiles on the 16x16x4 MFMA): what a launch of k_block_fused4's size runs for the stride-1 blocks from layer 6 on

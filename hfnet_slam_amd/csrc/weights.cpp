@@ -277,7 +277,10 @@ int DeviceWeights::build(const WeightFile& wf) {
     if (n != HFNET_DESC_DIM || desc1.cin != c_local) { set_error("descriptor head shape mismatch"); return HFNET_ERR_IO; }
     HF_TRY(pack_conv_bias(*this, wf, "local_head/descriptor/Conv_1", desc2, &n));
     if (n != HFNET_DESC_DIM) { set_error("descriptor dim %d != 256", n); return HFNET_ERR_IO; }
-    {   // engine options desc_bf16x3 / global_bf16x3: the same folded weights as bf16 hi / lo pieces
+    HF_TRY(pack_conv_bn(*this, wf, "local_head/detector/Conv", true, det1, &det_hidden));
+    HF_TRY(pack_conv_bias(*this, wf, "local_head/detector/Conv_1", det2, &n));
+    if (n != 65 || det2.cin != det_hidden) { set_error("detector head shape mismatch"); return HFNET_ERR_IO; }
+    {   // engine options desc_bf16x3 / global_bf16x3 / scores_bf16x3: the same folded weights as bf16 hi / lo pieces
         auto split = [&](const ConvPack& cp, void** out) -> int {
             *out = nullptr;
             if (!cp.w || !bf16x3_supported(cp)) return HFNET_OK;
@@ -290,15 +293,13 @@ int DeviceWeights::build(const WeightFile& wf) {
         };
         HF_TRY(split(desc1, &desc1_bf)); HF_TRY(split(desc2, &desc2_bf));
         if (!desc1_bf || !desc2_bf) desc1_bf = desc2_bf = nullptr;
-        for (int i = 6; i < 17; ++i) {                              // layers 8-18
+        HF_TRY(split(det1, &det1_bf)); HF_TRY(split(det2, &det2_bf));
+        for (int i = 1; i < 17; ++i) {                              // layers 3-18 (3-7: scores_bf16x3, 8-18: global_bf16x3)
             if (blocks[i].has_expand) HF_TRY(split(blocks[i].ex, &blocks[i].ex_bf));
             HF_TRY(split(blocks[i].pr, &blocks[i].pr_bf));
         }
         HF_HIP(hipStreamSynchronize(nullptr));
     }
-    HF_TRY(pack_conv_bn(*this, wf, "local_head/detector/Conv", true, det1, &det_hidden));
-    HF_TRY(pack_conv_bias(*this, wf, "local_head/detector/Conv_1", det2, &n));
-    if (n != 65 || det2.cin != det_hidden) { set_error("detector head shape mismatch"); return HFNET_ERR_IO; }
     HF_TRY(pack_conv_bn(*this, wf, "global_head/vlad/memberships", false, memb, &n_clusters, &memb16));
     if (memb.cin != c_global) { set_error("memberships conv width mismatch"); return HFNET_ERR_IO; }
     const HostTensor* cl = wf.find("global_head/vlad/clusters");

@@ -199,6 +199,10 @@ int hfnet_extractor_extract(hfnet_extractor* x, const uint8_t* image, int row_st
 int hfnet_extractor_last_timing(hfnet_extractor* x, double* us, int n);
 /* see hfnet_model_device_faults */
 int hfnet_extractor_device_faults(hfnet_extractor* x, unsigned int* bits);
+/* Diagnostics: hfnet_model_tap for the extractor's network -- the tensor of the LAST call (its last chunk of frames), all pyramid
+ * levels and frames concatenated in [level][frame][y][x][channel] order (levels have their own sizes).  Tap 22 (dense scores) is
+ * what the tolerance-mode tests run the oracle's NMS / top-K on (tests/test_gpu_scores_bf16x3.py). */
+int hfnet_extractor_tap(hfnet_extractor* x, int tap, float* out, size_t capacity, size_t* count);
 /* Batched form (independent frames, BASELINE config 4): images are n_frames buffers of
  * height x row_stride bytes, `frame_stride` bytes apart; outputs are n_frames slots of n_features
  * rows each.  `on_device` != 0: every pointer is a device pointer on the engine's GPU and the call

@@ -55,6 +55,19 @@ def engine(weights_path):
     e.close()
 
 
+@pytest.fixture
+def engine_options(engine):
+    """set engine options for the objects a test creates; the defaults come back afterwards"""
+    saved = engine.options()
+
+    def apply(opts):
+        for k, v in opts.items():
+            engine.set_option(k, v)
+    yield apply
+    for k, v in saved.items():
+        engine.set_option(k, v)
+
+
 def synth_image(h, w, seed, kind="uniform"):
     """(i) iid uniform; (ii) 'natural-ish' = 6 octaves of bilinear-upsampled noise"""
     rng = np.random.default_rng(seed)

@@ -33,19 +33,6 @@ VARIANTS = {"default": {}, "unfused_dense": {"fuse_blocks": 0, "dense_desc": 1},
             "fused_v4_all": {"fused_variant": 5, "fuse_min_wgs": 0}, "fused_v8": {"fused_variant": 8, "fuse_min_wgs": 0}}
 
 
-@pytest.fixture
-def engine_options(engine):
-    """set engine options for the objects a test creates; the defaults come back afterwards"""
-    saved = engine.options()
-
-    def apply(opts):
-        for k, v in opts.items():
-            engine.set_option(k, v)
-    yield apply
-    for k, v in saved.items():
-        engine.set_option(k, v)
-
-
 @pytest.mark.parametrize("variant", list(VARIANTS))
 @pytest.mark.parametrize("hw", SIZES)
 def test_layer_taps_bit_exact(engine, oracle_model, hw, variant, engine_options):
