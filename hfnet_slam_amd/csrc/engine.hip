@@ -387,7 +387,10 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         const long long pc = pix_cell[HFNET_MAX_LEVELS];
         Geom gh = geom(7, 7, 0, NL);
         for (int l = 0; l < NL; ++l) { gh.lv[l].pt = gh.lv[l].pl = 1; gh.lv[l].out_off = pix_cell[l]; }
-        HF_LAUNCH(e, stream, "conv3x3_det", launch_conv3x3(act[7], w.det1, det_hidden, 1, gh, conv_wlds, stream));
+        if (scores_bf16x3 && w.det1_bf && conv3x3_dense_bf16x3_supported(w.det1, gh))
+            HF_LAUNCH(e, stream, "conv3x3_det_bf16x3", launch_conv3x3_dense_bf16x3(act[7], w.det1, w.det1_bf, det_hidden, 1, gh, stream));
+        else
+            HF_LAUNCH(e, stream, "conv3x3_det", launch_conv3x3(act[7], w.det1, det_hidden, 1, gh, conv_wlds, stream));
         HF_TRY(pump_global(interleave));
         if (fork && !fork_early) {
             // the global branch starts after the (chip-filling, MFMA-bound) detector conv: it overlaps the long tail of

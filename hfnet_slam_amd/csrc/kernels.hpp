@@ -43,6 +43,9 @@ hipError_t launch_conv3x3_cells_bf16x3(const float* A, const ConvPack& cp, const
                                        const int* level_keypoints, const Geom& g, const int* cells, const int* n_rows, hipStream_t s);
 hipError_t launch_pointwise_bf16x3(const float* A, const ConvPack& cp, const void* Wb, const float* residual, float* out, long long P, int relu6,
                                    hipStream_t s, const int* slot_units = nullptr, int slot_rows = 0, int rows_per_unit = 0);
+// dense 3 x 3 convolution on split-bf16 operands with the halo staged through LDS (engine option scores_bf16x3: the detector head)
+bool conv3x3_dense_bf16x3_supported(const ConvPack& cp, const Geom& g);
+hipError_t launch_conv3x3_dense_bf16x3(const float* A, const ConvPack& cp, const void* Wb, float* out, int relu6, const Geom& g, hipStream_t s);
 hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, int relu6, const hfnet_keypoint* kps, const int* n_in,
                                long long kps_stride, const int* level_keypoints /* upper bound of n_in per level */, const Geom& g, int wlds,
                                hipStream_t s, const int* cells = nullptr, const int* n_rows = nullptr);

@@ -1548,6 +1548,229 @@ hipError_t launch_pointwise_bf16x3(const float* A, const ConvPack& cp, const voi
     return hipGetLastError();
 }
 
+// ---- dense 3 x 3 convolution on split bf16 operands (engine option scores_bf16x3: the detector head's 96 -> 128 conv, the launch a
+// call spends most of its time in).  k_conv_bf16x3<GATHER> above fetches every activation row from memory once per TAP and splits it
+// once per tap (nine times each), 32 bytes per lane and k-step straight from L1 / L2: it is bound by that gather.  A DENSE map has
+// what the gather lacks -- neighbours share their windows -- so here a workgroup stages the halo of its 256 consecutive pixels
+// through LDS, ALREADY SPLIT: every input value crosses L2 -> CU once per workgroup, is split once, and the nine taps of a k-step
+// read their A fragments from LDS.
+//   K order: chunk-major (16 input channels at a time: one 16-k step per tap), the tolerance mode's own order -- LDS holds one
+//     chunk of the halo ([cell][hi 16 | lo 16 | pad]: 80 bytes per cell, conflict-free ds_read_b128 for 32 consecutive cells).
+//   Halo in PADDED linear coordinates q = (y + 1) (W + 2) + (x + 1) of a map with a zero border: a tap is a uniform offset
+//     (ky - 1) (W + 2) + (kx - 1) for every pixel, border cells are written as zeros by the staging pass, the main loop has no
+//     per-lane mask or select at all; a tile of 256 pixels needs the cells q(first) - (W + 3) .. q(last) + (W + 3).
+//   Weights: launch_repack_bf16x3's pieces (step s = tap * steps_per_tap + chunk), two taps (16 KB) per slab through LDS, double
+//     buffered, one barrier per slab; the next chunk's activations are requested during the chunk's last slab into registers and
+//     split + written between the two barriers of the chunk boundary (the second workgroup of the CU computes meanwhile).
+//   Wave tile 64 pixels x 128 columns (eight 32 x 32 accumulators): 24 MFMAs per tap against 4 + 8 ds_read_b128.
+// CELLS: LDS capacity in halo cells (the launcher checks the geometry against it).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <int CELLS>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_dense_bf16x3(ConvArgs a, const bf16x8* __restrict__ Wb, Geom g) {
+    constexpr int NT = 4, MT = 2, REC = 80, TS = 2, NP = CELLS * 4 / 256;     // NP: 16-byte activation pieces per thread and chunk
+    __shared__ __attribute__((aligned(16))) unsigned char As[CELLS * REC];
+    __shared__ __attribute__((aligned(16))) bf16x8 wl[2][TS * NT * 2 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+    const int G = a.nt_total / NT;
+    // XCD mapping as k_conv3x3_wlds: every XCD takes one contiguous eighth of the tile list (vertical neighbours share an L2)
+    const int q8 = (int)gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int level = 0, rest = slot < q8 ? xcd * q8 + slot : 8 * q8 + xcd;
+    for (; level < g.n_levels - 1; ++level) {
+        const int per = g.batch * G * a.level_tiles[level];
+        if (rest < per) break;
+        rest -= per;
+    }
+    const int tl = a.level_tiles[level];
+    const int frame = rest / (G * tl);
+    rest -= frame * G * tl;
+    const int grp = rest / tl, tile = rest - grp * tl;
+    const LevelGeom lv = g.lv[level];
+    const int Hc = lv.H, Wc = lv.W, Wp = Wc + 2, nrows = Hc * Wc;
+    const int p0 = tile * 256;
+    if (p0 >= nrows) return;                                      // (workgroup-uniform)
+    const int nt0 = grp * NT;
+    const int y0 = p0 / Wc, x0 = p0 - y0 * Wc;
+    const int plast = min(p0 + 255, nrows - 1), yl = plast / Wc, xl = plast - yl * Wc;
+    const int qbase = y0 * Wp + x0;                               // padded index of the first staged cell: q(p0) - (Wp + 1)
+    const int ncell = (yl + 2) * Wp + xl + 2 - qbase + 1;         // ... up to q(plast) + Wp + 1   (<= CELLS: launcher)
+    const char* __restrict__ xb = (const char*)(a.A + (lv.in_off + (long long)frame * nrows) * a.cin);      // uniform; lane offsets are 32-bit
+    // ---- staging role: piece e = tid + 256 k is 16 bytes (4 channels) of cell e >> 2
+    unsigned aoff[NP];
+    unsigned okbits = 0, wrbits = 0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int e = tid + 256 * k, j = e >> 2, pc = e & 3;
+        const int q = qbase + j, yq = q / Wp, xq = q - yq * Wp;
+        const int y = yq - 1, x = xq - 1;
+        const bool in = j < ncell && y >= 0 && y < Hc && x >= 0 && x < Wc;
+        aoff[k] = in ? ((unsigned)(y * Wc + x) * (unsigned)a.cin + (unsigned)(pc * 4)) * 4u : 0u;
+        if (in) okbits |= 1u << k;
+        if (j < ncell) wrbits |= 1u << k;
+    }
+    f32x4 areg[NP];
+    auto load_a = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) areg[k] = *(const f32x4*)(xb + aoff[k] + chunk * 64);     // (outside cells re-read the image's first pixel: discarded)
+    };
+    auto write_a = [&]() {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            if ((wrbits >> k) & 1u) {
+                const int e = tid + 256 * k;
+                const bool ok = (okbits >> k) & 1u;
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = ok ? areg[k][c] : 0.0f;
+                    hi[c] = (__bf16)v;
+                    lo[c] = (__bf16)(v - (float)hi[c]);
+                }
+                unsigned char* dst = As + (e >> 2) * REC + (e & 3) * 8;
+                *(bf16x4*)dst = hi;
+                *(bf16x4*)(dst + 32) = lo;
+            }
+        }
+    };
+    // ---- this lane's two pixels: LDS offset of the window CENTRE's hi fragment
+    int abase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int p = min(p0 + wave * 64 + 32 * i + r, nrows - 1);
+        const int y = p / Wc, x = p - y * Wc;
+        abase[i] = ((y + 1) * Wp + (x + 1) - qbase) * REC + half * 16;
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float b = a.bias[(nt0 + nt) * 32 + r];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][nt][e] = b;
+    }
+    const int spt = a.cin >> 4;                                   // 16-k steps per tap == chunks
+    // weight pieces of one slab: TS taps x 4 column tiles x {hi, lo} = 16 pieces of 1 KB; wave w moves pieces j * 4 + w straight from
+    // memory into LDS (global_load_lds_dwordx4: destination = a wave-uniform base + 16 lane; no registers, no ds_write).  Ordering: a
+    // slab's pieces are requested at the top of the slab BEFORE it, into the buffer whose last readers passed the previous barrier; every
+    // wave waits for its own requests (vmcnt(0)) in front of the slab's closing barrier; the reads come after that barrier.
+    auto load_w = [&](int chunk, int tap0, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = j * 4 + wave, tt = piece >> 3, nt = (piece >> 1) & 3, hl = piece & 1;
+            const int s = min(tap0 + tt, 8) * spt + chunk;
+            const bf16x8* src = Wb + (((size_t)s * a.nt_total + nt0 + nt) * 2 + hl) * 64 + lane;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                             (void __attribute__((address_space(3)))*)(&wl[buf][piece * 64]), 16, 0, 0);
+        }
+    };
+    load_a(0);
+    load_w(0, 0, 0);
+    write_a();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (int chunk = 0; chunk < spt; ++chunk) {
+#pragma unroll
+        for (int sl = 0; sl < 5; ++sl) {                          // slabs of taps {0,1} {2,3} {4,5} {6,7} {8}
+            const bool last_slab = sl == 4;
+            const bool more = !(last_slab && chunk + 1 == spt);
+            if (more) load_w(last_slab ? chunk + 1 : chunk, last_slab ? 0 : 2 * sl + 2, buf ^ 1);
+            if (last_slab && chunk + 1 < spt) load_a(chunk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tt = 0; tt < TS; ++tt) {
+                const int tap = 2 * sl + tt;
+                if (tap < 9) {
+                    const int toff = ((tap / 3 - 1) * Wp + (tap % 3 - 1)) * REC;      // uniform
+                    bf16x8 ah[MT], al[MT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        ah[i] = *(const bf16x8*)(As + abase[i] + toff);
+                        al[i] = *(const bf16x8*)(As + abase[i] + toff + 32);
+                    }
+                    // two column tiles at a time (their hi / lo fragments: 16 registers): the three products of one accumulator are four
+                    // MFMAs apart
+#pragma unroll
+                    for (int np = 0; np < NT; np += 2) {
+                        bf16x8 bh[2], bl[2];
+#pragma unroll
+                        for (int n2 = 0; n2 < 2; ++n2) {
+                            bh[n2] = wl[buf][((tt * NT + np + n2) * 2 + 0) * 64 + lane];
+                            bl[n2] = wl[buf][((tt * NT + np + n2) * 2 + 1) * 64 + lane];
+                        }
+#pragma unroll
+                        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                            for (int i = 0; i < MT; ++i) acc[i][np + n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[n2], acc[i][np + n2], 0, 0, 0);
+#pragma unroll
+                        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                            for (int i = 0; i < MT; ++i) acc[i][np + n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[n2], acc[i][np + n2], 0, 0, 0);
+#pragma unroll
+                        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                            for (int i = 0; i < MT; ++i) acc[i][np + n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[n2], acc[i][np + n2], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's weight pieces (and, at a chunk's end, its activation pieces) have landed
+            __syncthreads();
+            if (last_slab && chunk + 1 < spt) {                    // every wave is done with this chunk's halo: the next one's goes in
+                write_a();
+                __syncthreads();
+            }
+            buf ^= 1;
+        }
+    }
+    // ---- (ReLU6) and store
+    const float lo6 = a.relu6 ? 0.0f : -INFINITY, hi6 = a.relu6 ? 6.0f : INFINITY;
+    float* __restrict__ ob = a.out + (lv.out_off + (long long)frame * nrows) * a.n;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row0 = p0 + wave * 64 + 32 * i + 4 * half;
+        const int left = nrows - row0;                             // rows of this lane's column that exist (may be <= 0)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = (nt0 + nt) * 32 + r;
+            if (col < a.n) {
+                float* __restrict__ op = ob + (long long)row0 * a.n + col;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rr = (reg & 3) + 8 * (reg >> 2);
+                    if (rr < left) op[rr * a.n] = __builtin_amdgcn_fmed3f(acc[i][nt][reg], lo6, hi6);
+                }
+            }
+        }
+    }
+}
+
+bool conv3x3_dense_bf16x3_supported(const ConvPack& cp, const Geom& g) {
+    if (cp.taps != 9 || cp.cin % 16 || cp.nt_total % 4) return false;
+    for (int l = 0; l < g.n_levels; ++l) {
+        const int Wc = g.lv[l].W, Wp = Wc + 2;
+        if (Wc < 1 || g.lv[l].H < 1) return false;
+        const int span = (255 + Wc - 1) / Wc;                       // image rows a tile's last pixel can lie below its first
+        if (255 + 2 * span + 2 * Wp + 3 > 512) return false;         // halo cells of the worst tile against the kernel's LDS block
+        if ((long long)g.lv[l].H * Wc * cp.cin * 4 > 0xffffffffll) return false;     // 32-bit lane offsets inside one image
+    }
+    return true;
+}
+
+// out[pixel][n] = act(3 x 3 conv of A) for every pixel of every level / frame, split-bf16 operands (Wb: launch_repack_bf16x3 of cp)
+hipError_t launch_conv3x3_dense_bf16x3(const float* A, const ConvPack& cp, const void* Wb, float* out, int relu6, const Geom& g, hipStream_t s) {
+    if (!Wb || !conv3x3_dense_bf16x3_supported(cp, g)) return hipErrorInvalidValue;
+    ConvArgs a = make_args(A, cp, nullptr, out, 0, relu6);
+    long long total = 0;
+    for (int l = 0; l < HFNET_MAX_LEVELS; ++l) {
+        a.level_tiles[l] = l < g.n_levels ? std::max((g.lv[l].H * g.lv[l].W + 255) / 256, 1) : 1;
+        if (l < g.n_levels) total += (long long)g.batch * (cp.nt_total / 4) * a.level_tiles[l];
+    }
+    if (total <= 0 || total > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_conv3x3_dense_bf16x3<512>), dim3((unsigned)total), dim3(256), 0, s, a, (const bf16x8*)Wb, g);
+    return hipGetLastError();
+}
+
 // =========================================================================== depthwise 3x3
 // One thread = 4 channels x a vertical strip of R output pixels of one column: the (R s + 2) x 3 input pieces and the nine
 // weight pieces are loaded once and serve R outputs (a thread per output re-read every input piece up to nine times

@@ -27,10 +27,10 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#endif
 
 #define HFO_FC_PARTS 16   /* partial chains of the dimensionality-reduction FC (see global_head) */
 #define HFO_VLAD_PARTS 8  /* partial chains of the NetVLAD pixel sum (see global_head) */
-#endif
 
 #define HFO_BN_EPS 1e-3f
 #define HFO_DESC_DIM 256
