@@ -1653,14 +1653,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dense_bf16x3(ConvArgs a, con
     // memory into LDS (global_load_lds_dwordx4: destination = a wave-uniform base + 16 lane; no registers, no ds_write).  Ordering: a
     // slab's pieces are requested at the top of the slab BEFORE it, into the buffer whose last readers passed the previous barrier; every
     // wave waits for its own requests (vmcnt(0)) in front of the slab's closing barrier; the reads come after that barrier.
+    // (The instruction is written as inline assembly: behind the compiler's own builtin every later ds_read of ANY LDS array waits for
+    //  vmcnt(0) -- the request that was just issued for the NEXT slab -- and the latency of the weight stream is exposed once per slab.
+    //  The compiler does not count these requests; its own vmcnt waits for the ordinary loads can then only be stricter than needed.)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned wl_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&wl[0][0];
+    const unsigned lane16 = (unsigned)lane * 16u;
     auto load_w = [&](int chunk, int tap0, int buf) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int piece = j * 4 + wave, tt = piece >> 3, nt = (piece >> 1) & 3, hl = piece & 1;
+            const int piece = j * 4 + wave_u, tt = piece >> 3, nt = (piece >> 1) & 3, hl = piece & 1;
             const int s = min(tap0 + tt, 8) * spt + chunk;
-            const bf16x8* src = Wb + (((size_t)s * a.nt_total + nt0 + nt) * 2 + hl) * 64 + lane;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                             (void __attribute__((address_space(3)))*)(&wl[buf][piece * 64]), 16, 0, 0);
+            const bf16x8* src = Wb + (((size_t)s * a.nt_total + nt0 + nt) * 2 + hl) * 64;      // uniform
+            const unsigned dst = wl_lds + (unsigned)((buf * TS * NT * 2 + piece) * 1024);       // uniform
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(src), "v"(lane16), "s"(dst) : "memory", "m0");
         }
     };
     load_a(0);
@@ -1674,8 +1680,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dense_bf16x3(ConvArgs a, con
         for (int sl = 0; sl < 5; ++sl) {                          // slabs of taps {0,1} {2,3} {4,5} {6,7} {8}
             const bool last_slab = sl == 4;
             const bool more = !(last_slab && chunk + 1 == spt);
-            if (more) load_w(last_slab ? chunk + 1 : chunk, last_slab ? 0 : 2 * sl + 2, buf ^ 1);
+            // (the activation requests first: the compiler guards their registers with vmcnt waits that would otherwise stall on the weight requests)
             if (last_slab && chunk + 1 < spt) load_a(chunk + 1);
+            if (more) load_w(last_slab ? chunk + 1 : chunk, last_slab ? 0 : 2 * sl + 2, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tt = 0; tt < TS; ++tt) {

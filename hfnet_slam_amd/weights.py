@@ -71,12 +71,17 @@ def tensor_shapes(spec: NetSpec) -> "OrderedDict[str, tuple]":
     return t
 
 
-def synthetic_weights(seed: int = 7, spec: NetSpec | None = None, detector_gain: float = 1.0
+def synthetic_weights(seed: int = 7, spec: NetSpec | None = None, detector_gain: float = 1.0, dustbin_bias: float = 0.0
                       ) -> "OrderedDict[str, np.ndarray]":
     """Seeded weights: He-normal convs, BN gamma~U[0.5,1.5], beta~N(0,0.1),
     mean~N(0,0.1), var~U[0.5,1.5], biases~N(0,0.01), Xavier for FC / memberships / clusters.
     `detector_gain` scales the last detector conv so the softmax is not flat (scores spread
-    around 1/65 and the threshold / top-K logic is genuinely exercised)."""
+    around 1/65 and the threshold / top-K logic is genuinely exercised).
+    `dustbin_bias` is added to the bias of the detector's 65th ("no keypoint") channel: with the default 0 every cell of a random-weight
+    network has candidates above the reference's threshold 0.01 and top-K is always saturated; 15 leaves the coarser pyramid levels of a
+    752x480 / 512x512 frame SHORT of their budget with the survivors clustered where the logits peak, 16 makes every level short on
+    smooth frames, 18 leaves whole levels without a single candidate -- the nearest stand-in for trained weights the data-dependent
+    kernels (candidate emission, top-K, tap de-duplication, the sparse descriptor head's row counts) can be given here."""
     spec = spec or net_spec()
     rng = np.random.Generator(np.random.PCG64(seed))
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
@@ -104,6 +109,9 @@ def synthetic_weights(seed: int = 7, spec: NetSpec | None = None, detector_gain:
             a = rng.normal(0.0, np.sqrt(2.0 / fan_in), shape)
             if name == "local_head/detector/Conv_1/weights":
                 a = a * detector_gain
+        if name == "local_head/detector/Conv_1/biases" and dustbin_bias:
+            a = a.copy()
+            a[-1] += dustbin_bias
         out[name] = np.ascontiguousarray(a, dtype=np.float32)
     return out
 

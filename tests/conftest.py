@@ -30,6 +30,20 @@ def weights_ties_path(tmp_path_factory):
     return p
 
 
+@pytest.fixture(scope="session", params=[15.0, 16.0, 18.0], ids=["dustbin15", "dustbin16", "dustbin18"])
+def sparse_pair(request, tmp_path_factory):
+    """(engine, oracle model) on weights whose detector leaves pyramid levels short of their budget (weights.synthetic_weights' dustbin_bias:
+    15 -- the coarse levels are short; 16 -- every level on smooth frames; 18 -- whole levels without a candidate)"""
+    from hfnet_slam_amd import capi, weights
+    from oracle import oracle as O
+    p = str(tmp_path_factory.mktemp("w") / f"synthetic_seed7_dustbin{int(request.param)}.hfw")
+    weights.save(p, weights.synthetic_weights(7, dustbin_bias=request.param))
+    O.build()
+    e = capi.Engine(p, 0)
+    yield e, O.Model(p), request.param
+    e.close()
+
+
 @pytest.fixture(scope="session")
 def oracle_model(weights_path):
     from oracle import oracle as O

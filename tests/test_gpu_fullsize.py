@@ -144,6 +144,37 @@ def test_mid_sized_call_every_frame_vs_oracle(engine, oracle_model, size):
     x.close()
 
 
+@pytest.mark.parametrize("cfg", [(752, 480, 1000), (512, 512, 850)])
+def test_sparse_score_regime_full_size(sparse_pair, cfg):
+    """The regime real weights live in and seeded random weights never reach (their scores sit near 1/65 > the threshold 0.01, so every NMS
+    survivor is a candidate and top-K is saturated at every level): weights whose detector lets FEW cells through -- pyramid levels that fall
+    short of their budget, candidates clustered where the logits peak (tap cells shared by neighbouring keypoints), levels with no candidate at
+    all.  Every frame of a call against the oracle, bit for bit; the call mixes frames with full and short levels."""
+    from hfnet_slam_amd import capi, spec
+    engine, om, bias = sparse_pair
+    w, h, nf = cfg
+    B = 6
+    imgs = np.stack([synth_image(h, w, 6400 + i, "natural" if i % 2 else "uniform") for i in range(B)])
+    budget = spec.features_per_level(nf, 4, 1.2)
+    x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, 4, max_batch=B)
+    nb, kb, db, gb = x.extract_batch(imgs)
+    short = empty = 0
+    for f in range(B):
+        rn, rk, rd, rg, rnpl = om.extract(imgs[f], nf, 0.01, 4, 1.2)
+        assert nb[f] == rn, (bias, f, nb[f], rn)
+        assert np.array_equal(kb[f, :rn], rk) and np.array_equal(db[f, :rn], rd) and np.array_equal(gb[f], rg), (bias, f)
+        short += sum(int(a) < b for a, b in zip(rnpl, budget)); empty += sum(int(a) == 0 for a in rnpl)
+    assert short >= B, "the fixture must produce short levels"
+    if bias >= 18:
+        assert empty > 0, "bias 18 must leave levels without a candidate"
+    # a single frame through the latency path (graph, two branches) sees the same short levels
+    n1, k1, d1, g1, npl1 = x.extract(imgs[1])
+    rn, rk, rd, rg, rnpl = om.extract(imgs[1], nf, 0.01, 4, 1.2)
+    assert n1 == rn and np.array_equal(npl1, rnpl) and np.array_equal(k1, rk) and np.array_equal(d1, rd) and np.array_equal(g1, rg)
+    assert x.device_faults() == 0
+    x.close()
+
+
 BF16X3_DESC_TOL = 1e-5        # abs, on unit-norm 256-D rows (include/hfnet_hip.h; observed <= 2e-6)
 BF16X3_GLOBAL_TOL = 2e-5      # abs, on the unit-norm global descriptor (observed <= 6e-6: ten layers of split-bf16 1x1 convolutions deep)
 
