@@ -39,7 +39,7 @@ int hfnet_db_create(hfnet_engine* eh, int capacity, int dim, hfnet_db** out) try
         // is not host-synchronous -- it could land after the first hfnet_db_add had set its occupancy byte
         Engine& e = eh->impl;
         std::lock_guard<std::mutex> lk(e.mu);
-        e.bounce.discard();
+        e.bounce_discard();
         HF_HIP(hipMemsetAsync(db->d_occ, 0, (size_t)capacity, e.stream));
         HF_HIP(hipMemsetAsync(db->d_norm, 0, sizeof(float) * capacity, e.stream));
         HF_TRY(e.sync_host());
@@ -63,7 +63,7 @@ int hfnet_db_add(hfnet_db* db, int slot, const float* descriptor) try {
     std::lock_guard<std::mutex> lk(db->mu);
     Engine& e = db->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
     HF_HIP(hipSetDevice(e.device));
     // on the stream the scans run on (created non-blocking: the null stream would not order with it)
     HF_TRY(e.h2d(db->d_db + (size_t)slot * db->dim, descriptor, sizeof(float) * db->dim));
@@ -79,7 +79,7 @@ int hfnet_db_erase(hfnet_db* db, int slot) try {
     std::lock_guard<std::mutex> lk(db->mu);
     Engine& e = db->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
     HF_HIP(hipSetDevice(e.device));
     HF_HIP(hipMemsetAsync(db->d_occ + slot, 0, 1, e.stream));
     HF_TRY(e.sync_host());
@@ -91,7 +91,7 @@ int hfnet_db_clear(hfnet_db* db) try {
     std::lock_guard<std::mutex> lk(db->mu);
     Engine& e = db->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
     HF_HIP(hipSetDevice(e.device));
     HF_HIP(hipMemsetAsync(db->d_occ, 0, (size_t)db->capacity, e.stream));
     HF_TRY(e.sync_host());
@@ -105,7 +105,7 @@ int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slo
     std::lock_guard<std::mutex> lk(db->mu);   // KeyFrameDatabase.cc:82 holds mMutex over the scan
     Engine& e = db->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
     HF_HIP(hipSetDevice(e.device));
     HF_TRY(e.h2d(db->d_q, query, sizeof(float) * db->dim));
     HF_LAUNCH(&e, e.stream, "db_scores", launch_db_scores(db->d_q, db->d_db, db->d_occ, db->capacity, db->dim, db->d_scores, db->d_best_bits, e.stream));
@@ -136,7 +136,7 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
     std::lock_guard<std::mutex> lk(db->mu);
     Engine& e = db->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
     const bool gemm = n_queries >= e.opt.db_gemm_min_queries && db->dim % 512 == 0;
     if (!gemm && db->dim > 4096) { set_error("db: the exact batched scan supports dim <= 4096"); return HFNET_ERR_INVALID_ARG; }
     HF_HIP(hipSetDevice(e.device));

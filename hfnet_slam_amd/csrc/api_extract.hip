@@ -122,7 +122,13 @@ int hfnet_model_detect(hfnet_model* m, const uint8_t* image, int row_stride, int
     HF_HIP(hipStreamSynchronize(net.stream));
     const int n = std::min(std::max(h_n[0], 0), n_keypoints);
     const unsigned int faults = (unsigned int)h_n[1];
-    if (faults) { set_error("device-side bound hit (fault bits 0x%x): inconsistent device state, results discarded", faults); return HFNET_ERR_DEVICE; }
+    if (faults) {
+        // the reference's contract is a per-call `return false` (HFNetTFModelV2.cc:62-98): THIS call fails, the word is cleared on the stream so that
+        // the next call (whose forward pass rebuilds every flag it reads) starts clean; hfnet_model_device_faults keeps the bits for the object's lifetime
+        HF_TRY(net.clear_faults(faults));
+        set_error("device-side bound hit (fault bits 0x%x): results of this call discarded", faults);
+        return HFNET_ERR_DEVICE;
+    }
     if (aux_bytes) std::memcpy(aux, h_aux, aux_bytes);
     if (n > 0) {
         HF_HIP(hipMemcpyAsync(m->h_stage + m->o_kps, m->d_kps, sizeof(hfnet_keypoint) * n, hipMemcpyDeviceToHost, net.stream));
@@ -207,8 +213,13 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
     }
     NetConfig c;
     c.n_levels = n_levels; c.batch = max_batch; c.local = true; c.global = true; c.from_intermediate = false;
-    x->use_graph = e->impl.opt.graph;
-    x->host_global = e->impl.opt.host_global;
+    int opt_resize_band;
+    {   // (the engine's option block is written under this lock: hfnet_engine_set_option)
+        std::lock_guard<std::mutex> lk(e->impl.mu);
+        x->use_graph = e->impl.opt.graph;
+        x->host_global = e->impl.opt.host_global;
+        opt_resize_band = e->impl.opt.resize_band;
+    }
     c.max_keypoints = 1;
     for (int l = 0; l < n_levels; ++l) { c.width[l] = x->level_w[l]; c.height[l] = x->level_h[l]; c.max_keypoints = std::max(c.max_keypoints, x->features_per_level[l]); }
     HF_TRY(x->net.build(&e->impl, c));
@@ -226,7 +237,7 @@ int hfnet_extractor_create(hfnet_engine* e, int width, int height, int n_feature
         HF_HIP(copy_h2d_blocking(x->d_ialpha[l], ia.data(), ia.size() * sizeof(short)));
         HF_HIP(copy_h2d_blocking(x->d_yofs[l], yofs.data(), yofs.size() * sizeof(int)));
         HF_HIP(copy_h2d_blocking(x->d_ibeta[l], ib.data(), ib.size() * sizeof(short)));
-        x->pyr_band_rows[l] = e->impl.opt.resize_band ? resize_band_rows(yofs.data(), x->level_h[l], x->level_h[l - 1]) : 0;
+        x->pyr_band_rows[l] = opt_resize_band ? resize_band_rows(yofs.data(), x->level_h[l], x->level_h[l - 1]) : 0;
     }
     HF_TRY(dalloc(x->allocs, &x->d_kps, (size_t)max_batch * n_features));
     HF_TRY(dalloc(x->allocs, &x->d_desc, (size_t)max_batch * n_features * HFNET_DESC_DIM));

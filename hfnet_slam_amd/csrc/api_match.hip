@@ -31,7 +31,7 @@ int hfnet_descriptor_distance(hfnet_engine* eh, const float* a, const float* b, 
     if (dim <= 0) { set_error("dim <= 0"); return HFNET_ERR_INVALID_ARG; }
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
     HF_HIP(hipSetDevice(e.device));
     const float *da, *db;
     HF_TRY(stage_rows(e, e.m_a, a, dim, 0, &da));
@@ -104,7 +104,7 @@ int hfnet_match_search_by_bow(hfnet_engine* eh, const float* query, int n_query,
     if ((n_query && !query) || (n_train && !train)) { set_error("null descriptor matrix"); return HFNET_ERR_INVALID_ARG; }
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
     HF_HIP(hipSetDevice(e.device));
     if (on_device) HF_HIP(e.wait_extract());
     if (n_query == 0) { if (!on_device) *n_matches = 0; else HF_HIP(hipMemsetAsync(n_matches, 0, sizeof(int), e.stream)); return HFNET_OK; }
@@ -145,7 +145,7 @@ static int match_pairs_batch(hfnet_engine* eh, int n_pairs, const float* desc_ba
     if (!triangulation) API_GUARD(dist, "dist");
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
     HF_HIP(hipSetDevice(e.device));
     if (on_device) HF_HIP(e.wait_extract());
     HF_TRY(bow_scratch(e, n_pairs, max_rows, dim, triangulation));
@@ -224,7 +224,7 @@ int hfnet_store_create(hfnet_engine* eh, int n_sets, int max_rows, int dim, hfne
     {   // on the engine's (non-blocking) stream, which every later put / match uses: see hfnet_db_create
         Engine& e = eh->impl;
         std::lock_guard<std::mutex> lk(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
         HF_HIP(hipMemsetAsync(st->d_rows, 0, sizeof(int32_t) * n_sets, e.stream));
         HF_HIP(hipMemsetAsync(st->d_flags, 0, (size_t)n_sets * max_rows, e.stream));
         HF_TRY(e.sync_host());
@@ -250,7 +250,7 @@ int hfnet_store_put(hfnet_store* st, int slot, const float* rows, int n_rows) tr
     std::lock_guard<std::mutex> lk(st->mu);
     Engine& e = st->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
     HF_HIP(hipSetDevice(e.device));
     const int32_t n = n_rows;
     if (n_rows) HF_TRY(e.h2d(st->d_desc + (size_t)slot * st->max_rows * st->dim, rows, sizeof(float) * (size_t)n_rows * st->dim));
@@ -274,7 +274,7 @@ int hfnet_store_set_flags(hfnet_store* st, int slot, const uint8_t* flags, int n
     std::lock_guard<std::mutex> lk(st->mu);
     Engine& e = st->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
     HF_HIP(hipSetDevice(e.device));
     HF_TRY(e.h2d(st->d_flags + (size_t)slot * st->max_rows, flags, (size_t)n_rows));
     HF_TRY(e.sync_host());
@@ -293,7 +293,7 @@ int hfnet_store_put_extracted(hfnet_store* st, int slot, hfnet_extractor* x, int
     std::lock_guard<std::mutex> lk(st->mu);
     Engine& e = st->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
     HF_HIP(hipSetDevice(e.device));
     // Invariant relied on (no stream drain any more: with host_global the host-pointer call returns while the global branch may
     // still run): the LOCAL section of the extractor's device block (descriptors, counts) is complete once the host has seen the
@@ -333,7 +333,7 @@ static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const 
     std::lock_guard<std::mutex> lks(st->mu);
     Engine& e = st->eng->impl;
     std::lock_guard<std::mutex> lk(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
     HF_HIP(hipSetDevice(e.device));
     const int mr = st->max_rows;
     const long long stride = (long long)mr * st->dim;
@@ -426,7 +426,7 @@ int hfnet_match_search_for_triangulation(hfnet_engine* eh, const float* d1, int 
     if ((n1 && !d1) || (n2 && !d2)) { set_error("null descriptor matrix"); return HFNET_ERR_INVALID_ARG; }
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
     HF_HIP(hipSetDevice(e.device));
     if (on_device) HF_HIP(e.wait_extract());
     if (n1 == 0) { if (!on_device) *n_matches = 0; else HF_HIP(hipMemsetAsync(n_matches, 0, sizeof(int), e.stream)); return HFNET_OK; }
@@ -465,7 +465,7 @@ int hfnet_match_candidates(hfnet_engine* eh, const float* query, int n_query, co
     API_GUARD(best_idx, "best_idx"); API_GUARD(best_dist, "best_dist"); API_GUARD(best_level, "best_level"); API_GUARD(second_dist, "second_dist"); API_GUARD(second_level, "second_level");
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
     HF_HIP(hipSetDevice(e.device));
     if (on_device) {
         HF_HIP(e.wait_extract());
@@ -516,7 +516,7 @@ int hfnet_distinctive_descriptors(hfnet_engine* eh, const float* desc, const int
     if (total) API_GUARD(desc, "desc");
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
     HF_HIP(hipSetDevice(e.device));
     const float* dd;
     HF_TRY(stage_rows(e, e.m_a, desc, (size_t)total * dim, 0, &dd));
@@ -536,7 +536,7 @@ int hfnet_resampler(hfnet_engine* eh, const float* data, const float* warp, floa
     API_GUARD(warp, "warp");
     Engine& e = eh->impl;
     std::lock_guard<std::mutex> lk(e.mu);
-    e.bounce.discard();
+    e.bounce_discard();
     HF_HIP(hipSetDevice(e.device));
     const size_t nd = (size_t)batch_size * data_height * data_width * data_channels, nw = (size_t)batch_size * num_sampling_points * 2;
     const size_t no = (size_t)batch_size * num_sampling_points * data_channels;

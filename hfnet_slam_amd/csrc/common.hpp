@@ -143,6 +143,7 @@ struct DeviceWeights {
     void* desc2_bf = nullptr;     // null where the shapes do not fit the split-bf16 kernels
     void* det1_bf = nullptr;      // the detector head's (engine option scores_bf16x3)
     void* det2_bf = nullptr;
+    void* memb_bf = nullptr;      // the NetVLAD memberships conv's (engine option global_bf16x3)
     ConvPack16 memb16;            // the memberships conv as the "next 1x1" of layer 18's k_dwproject
     float* clusters = nullptr;    // [K][D] logical
     FcPack fc;                    // dimensionality reduction 7680 -> 4096

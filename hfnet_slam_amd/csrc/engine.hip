@@ -66,10 +66,11 @@ int Engine::sync_host() {
 }
 int Engine::bounce_take(size_t bytes, unsigned char** out) {
     const size_t need = (bytes + 255) / 256 * 256;
+    if (need > HostBounce::kMaxBytes) { set_error("bounce_take: %zu bytes in one piece", bytes); return HFNET_ERR_INTERNAL; }
     if (bounce.used + need > bounce.cap) {
         HF_TRY(sync_host());                                  // nothing is in flight through the block any more
         if (need > bounce.cap) {
-            const size_t cap = std::max<size_t>(std::max(need, bounce.cap * 2), (size_t)1 << 20);
+            const size_t cap = std::min(std::max<size_t>(std::max(need, bounce.cap * 2), (size_t)1 << 20), HostBounce::kMaxBytes);
             if (bounce.base) { (void)hipHostFree(bounce.base); bounce.base = nullptr; bounce.cap = 0; }
             void* hp = nullptr;
             HF_HIP(hipHostMalloc(&hp, cap, hipHostMallocDefault));
@@ -80,20 +81,26 @@ int Engine::bounce_take(size_t bytes, unsigned char** out) {
     bounce.used += need;
     return HFNET_OK;
 }
+// (transfers above HostBounce::kPiece cross in pieces: the pinned block stays at <= kMaxBytes whatever a caller uploads -- a batch of
+//  descriptor sets can be hundreds of MB -- and a full block is drained, not grown)
 int Engine::h2d(void* dst_dev, const void* src_host, size_t bytes) {
-    if (!bytes) return HFNET_OK;
-    unsigned char* b = nullptr;
-    HF_TRY(bounce_take(bytes, &b));
-    std::memcpy(b, src_host, bytes);
-    HF_HIP(hipMemcpyAsync(dst_dev, b, bytes, hipMemcpyHostToDevice, stream));
+    for (size_t off = 0; off < bytes; off += HostBounce::kPiece) {
+        const size_t n = std::min(HostBounce::kPiece, bytes - off);
+        unsigned char* b = nullptr;
+        HF_TRY(bounce_take(n, &b));
+        std::memcpy(b, (const unsigned char*)src_host + off, n);
+        HF_HIP(hipMemcpyAsync((unsigned char*)dst_dev + off, b, n, hipMemcpyHostToDevice, stream));
+    }
     return HFNET_OK;
 }
 int Engine::d2h(void* dst_host, const void* src_dev, size_t bytes) {
-    if (!bytes) return HFNET_OK;
-    unsigned char* b = nullptr;
-    HF_TRY(bounce_take(bytes, &b));
-    HF_HIP(hipMemcpyAsync(b, src_dev, bytes, hipMemcpyDeviceToHost, stream));
-    bounce.pending.push_back({dst_host, b, bytes});
+    for (size_t off = 0; off < bytes; off += HostBounce::kPiece) {
+        const size_t n = std::min(HostBounce::kPiece, bytes - off);
+        unsigned char* b = nullptr;
+        HF_TRY(bounce_take(n, &b));
+        HF_HIP(hipMemcpyAsync(b, (const unsigned char*)src_dev + off, n, hipMemcpyDeviceToHost, stream));
+        bounce.pending.push_back({(unsigned char*)dst_host + off, b, n});
+    }
     return HFNET_OK;
 }
 
@@ -405,7 +412,10 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         logits_valid = !(det_fuse && det_tail_supported(w.det2));
         if (!logits_valid) {
             // 1x1 conv + softmax + depth_to_space in one launch: the logits never reach HBM (their tap recomputes them on demand)
-            HF_LAUNCH(e, stream, "det_tail", launch_det_tail(det_hidden, w.det2, dense, gd, stream));
+            if (scores_bf16x3 && w.det2_bf && det_tail_bf16x3_supported(w.det2))
+                HF_LAUNCH(e, stream, "det_tail_bf16x3", launch_det_tail_bf16x3(det_hidden, w.det2, w.det2_bf, dense, gd, stream));
+            else
+                HF_LAUNCH(e, stream, "det_tail", launch_det_tail(det_hidden, w.det2, dense, gd, stream));
             HF_TRY(pump_global(2));
         } else {
             HF_LAUNCH(e, stream, "pointwise_det", launch_pointwise(det_hidden, w.det2, nullptr, logits, pc, 0, stream));
@@ -425,7 +435,11 @@ int Net::forward(const ImageSet& imgs, float threshold, const TopkBudget& budget
         last_dedupe = last_sparse && dedupe_taps != 0;
         Geom gt = gn;   // H, W: score map; Ho, Wo: cell grid; in_off: first cell of the level
         for (int l = 0; l < NL; ++l) { gt.lv[l].Ho = lp[l].h[7]; gt.lv[l].Wo = lp[l].w[7]; gt.lv[l].in_off = pix_cell[l]; }
-        if (last_dedupe) {
+        if (last_dedupe && dedupe_taps == 2) {
+            // the two-launch form of the same row numbering (mark, then compact): kept reachable so that it cannot rot (tests' variant "dedupe_two_launch")
+            HF_LAUNCH(e, stream, "topk", launch_topk(cand, counters, cand_stride, budget, kps_level, cfg.max_keypoints, n_level, gn, stream));
+            HF_LAUNCH(e, stream, "tap_cells", launch_tap_cells(kps_level, n_level, cfg.max_keypoints, tap_flags, tap_cell_row, tap_cells, tap_nrows, cell_stride, gt, stream, dev_fault));
+        } else if (last_dedupe) {
             // top-K and the distinct tap cells of its keypoints in one launch (both are one workgroup per image)
             HF_LAUNCH(e, stream, "topk", launch_topk_taps(cand, counters, cand_stride, budget, kps_level, cfg.max_keypoints, n_level, tap_flags, tap_cell_row, tap_cells,
                                                           tap_nrows, cell_stride, gt, stream, dev_fault));
@@ -524,7 +538,10 @@ int Net::forward_global(hipStream_t st, int first, int count, int* total) {
         tail = true;                                             // (layer 18's launch leaves the SOFTMAXED memberships)
     } else {
         for (int L = 8; L <= 18; ++L) HF_GSTEP(HF_TRY(run_block(*this, L, 1, st)));
-        HF_GSTEP(HF_LAUNCH(e, st, "pointwise_memberships", launch_pointwise(act[18], w.memb, nullptr, memb, (long long)cfg.batch * P, 0, st)));
+        if (global_bf16x3 && w.memb_bf)
+            HF_GSTEP(HF_LAUNCH(e, st, "pointwise_memberships_bf16x3", launch_pointwise_bf16x3(act[18], w.memb, w.memb_bf, nullptr, memb, (long long)cfg.batch * P, 0, st)));
+        else
+            HF_GSTEP(HF_LAUNCH(e, st, "pointwise_memberships", launch_pointwise(act[18], w.memb, nullptr, memb, (long long)cfg.batch * P, 0, st)));
     }
     if (!tail) HF_GSTEP(HF_LAUNCH(e, st, "softmax_memberships", launch_softmax_rows(memb, (long long)cfg.batch * P, w.n_clusters, w.n_clusters, st)));
     HF_GSTEP(HF_LAUNCH(e, st, "vlad", launch_vlad_aggregate(act[18], memb, w.clusters, vlad_raw, cfg.batch, P, w.c_global, w.n_clusters, st));
@@ -535,14 +552,20 @@ int Net::forward_global(hipStream_t st, int first, int count, int* total) {
     return HFNET_OK;
 }
 
+int Net::clear_faults(unsigned int seen) {
+    sticky_faults |= seen;
+    if (dev_fault) HF_HIP(hipMemsetAsync(dev_fault, 0, sizeof(unsigned int), stream));
+    return HFNET_OK;
+}
+
 int Net::read_faults(unsigned int* out) {
-    *out = 0;
+    *out = sticky_faults;
     if (!dev_fault) return HFNET_OK;
     void* hp = nullptr;                                       // (a pinned word: no pageable memory is handed to the runtime, see HostBounce)
     HF_HIP(hipHostMalloc(&hp, 64, hipHostMallocDefault));
     hipError_t er = hipMemcpyAsync(hp, dev_fault, sizeof(unsigned int), hipMemcpyDeviceToHost, stream);
     if (er == hipSuccess) er = hipStreamSynchronize(stream);
-    if (er == hipSuccess) *out = *(volatile unsigned int*)hp;
+    if (er == hipSuccess) *out = *(volatile unsigned int*)hp | sticky_faults;
     (void)hipHostFree(hp);
     HF_HIP(er);
     return HFNET_OK;
@@ -728,7 +751,11 @@ int hfnet_engine_info(const hfnet_engine* e, int what) try {
 
 int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value) try {
     // test hook of the exception barrier every entry point ends in (tests/test_abi.py; needs no engine and no GPU): name "debug_throw"
-    if (name && std::strcmp(name, "debug_throw") == 0) { if (value == 1) throw std::bad_alloc(); throw std::runtime_error("debug_throw"); }
+    // -- only with HFNET_TEST_HOOKS=1 in the environment: a production caller that passes this name gets "unknown option" like any other
+    if (name && std::strcmp(name, "debug_throw") == 0 && std::getenv("HFNET_TEST_HOOKS") && std::strcmp(std::getenv("HFNET_TEST_HOOKS"), "1") == 0) {
+        if (value == 1) throw std::bad_alloc();
+        throw std::runtime_error("debug_throw");
+    }
     API_GUARD(e, "engine");
     std::lock_guard<std::mutex> lk(e->impl.mu);              // (the database / matcher entry points read options under this lock)
     int* p = e->impl.opt.find(name);

@@ -133,13 +133,19 @@ struct HostBounce {
     size_t cap = 0, used = 0;
     struct Pending { void* dst; const unsigned char* src; size_t bytes; };
     std::vector<Pending> pending;
-    void discard() { pending.clear(); }     // an earlier call that returned an error half-way must not deliver into buffers that may be gone
+    static constexpr size_t kMaxBytes = (size_t)64 << 20;    // the block never grows beyond this: larger transfers go through it in pieces
+    static constexpr size_t kPiece = (size_t)16 << 20;
 };
 
 struct Engine {
     int device = 0;
     HostBounce bounce;
-    int bounce_take(size_t bytes, unsigned char** out);     // room in the block (drains the stream and grows the block when it is full)
+    int bounce_take(size_t bytes, unsigned char** out);     // room in the block (drains the stream and grows the block, up to HostBounce::kMaxBytes, when it is full)
+    // at the top of every host-pointer entry point: an earlier call that returned an error half-way must not deliver into buffers that may be gone --
+    // its downloads are dropped, and (its copies may still be in flight through the block) the stream is drained before the block is reused
+    void bounce_discard() {
+        if (!bounce.pending.empty()) { (void)hipStreamSynchronize(stream); bounce.pending.clear(); bounce.used = 0; }
+    }
     int h2d(void* dst_dev, const void* src_host, size_t bytes);    // on `stream`
     int d2h(void* dst_host, const void* src_dev, size_t bytes);    // on `stream`; dst_host is written by sync_host()
     int sync_host();                                        // hipStreamSynchronize(stream) + the pending downloads' memcpys
@@ -216,7 +222,9 @@ struct Net {
     int *tap_cell_row = nullptr, *tap_cells = nullptr, *tap_nrows = nullptr;
     long long cell_stride = 0;
     unsigned int* dev_fault = nullptr;         // HFNET_FAULT_* bits set by kernels that had to bound an index read from device memory (0 in a healthy run)
-    int read_faults(unsigned int* out);        // waits for the stream; hfnet_model_device_faults / hfnet_extractor_device_faults
+    unsigned int sticky_faults = 0;            // every bit a call has reported so far (the device word itself is cleared once reported: per-call errors)
+    int read_faults(unsigned int* out);        // sticky bits | the device word; waits for the stream; hfnet_model_device_faults / hfnet_extractor_device_faults
+    int clear_faults(unsigned int seen);       // a call saw `seen` in the device word: remember it, clear the word on the stream (the next call starts clean)
     bool dense_valid = false;      // dense descriptor tensors match the last forward()
     bool nms_valid = false;        // the suppressed score map (tap 25) matches the last forward()
     float last_threshold = 0.f;

@@ -83,6 +83,9 @@ hipError_t launch_softmax_d2s(const float* logits, int ld, float* dense, const G
 // detector tail in one launch: 1x1 conv (65 outputs) + softmax + depth_to_space; same bits as launch_pointwise + launch_softmax_d2s
 bool det_tail_supported(const ConvPack& cp);
 hipError_t launch_det_tail(const float* hidden, const ConvPack& cp, float* dense, const Geom& g, hipStream_t s);
+// the same on split-bf16 operands (engine option scores_bf16x3; Wb: launch_repack_bf16x3 of cp): the scores within the stated tolerance
+bool det_tail_bf16x3_supported(const ConvPack& cp);
+hipError_t launch_det_tail_bf16x3(const float* hidden, const ConvPack& cp, const void* Wb, float* dense, const Geom& g, hipStream_t s);
 // simple_nms(radius 4, 2 iterations) (layers.py:10-32) + candidate emission (score >= threshold,
 // HFNetTFModelV2.cc:127-140).  counters: one uint per image, zeroed by the caller.
 // counters: one uint per image, HFNET_COUNTER_STRIDE words apart (a cache line each: atomics on neighbouring words

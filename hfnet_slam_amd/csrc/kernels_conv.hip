@@ -1300,6 +1300,7 @@ hipError_t launch_conv3x3_taps(const float* A, const ConvPack& cp, float* out, i
 // kernel.  K order of a 16-k step s: k = 8 half + p is PHYSICAL slot p of channel group 2 s + half (a lane's 32 consecutive
 // bytes of an activation row), so no permutation is needed on either side.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // f32 pack [kq][nt][lane][4 t] (logical channel 2 t + half of group kq) -> [s][nt][hi | lo][lane][8]: element e of lane (half, j)
 // is physical slot e of group 2 s + half = logical channel lop(e): e < 4 -> (t = e, half' = 0), else (t = e - 4, half' = 1)
@@ -1518,14 +1519,250 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16x3(ConvArgs a, const bf16x8
     }
 }
 
+// ---- k_conv_bf16x3 for outputs of 256 columns (the descriptor head: 3 x 3 96 -> 256 at the tap cells, 1 x 1 256 -> 256 on the tap rows).
+// There every activation row is gathered (and split) once per 128-column group, 32 bytes per lane and k-step straight into registers: the
+// kernel is bound by that per-lane gather (~16 B/clk per CU), not by the matrix pipe (0.35 of the bf16 roof).  Here a workgroup owns 128 rows x
+// 256 columns: its four waves are two row halves x two column groups, the rows' 16 channels of a k-step are gathered ONCE per workgroup (two
+// 16-byte pieces per thread), split ONCE and shared through LDS ([row][hi 16 | lo 16 | pad]: the dense kernel's record); the weight pieces of a
+// k-step (8 column tiles x {hi, lo} = 16 KB) arrive by LDS-DMA.  Both double buffered, one barrier per k-step (24 MFMAs per wave); per MFMA the
+// gather traffic and the split arithmetic are half of k_conv_bf16x3's.  cin % 16 == 0, nt_total % 8 == 0.
+template <bool GATHER>
+__global__ __launch_bounds__(256, 2) void k_conv_rows_bf16x3(ConvArgs a, const bf16x8* __restrict__ Wb, Geom g, TapArgs ta) {
+    constexpr int NT = 4, MT = 2, REC = 80, ROWS = 128, NTW = 8;   // NTW: column tiles per workgroup
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][ROWS * REC];
+    __shared__ __attribute__((aligned(16))) bf16x8 wl[2][NTW * 2 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int rh = wave_u & 1, cg = wave_u >> 1;
+    int grp, tile, Wc = 0, Hc = 0, image = 0;
+    int nrows;                                                   // (launcher: fewer than 2^31 rows, tensors below 4 GB)
+    long long in_base = 0, out_base = 0;
+    if (GATHER) {
+        const int G = a.nt_total / NTW;
+        int level = 0, rest = blockIdx.x;
+        for (; level < g.n_levels - 1; ++level) {
+            const int per = g.batch * G * a.level_tiles[level];
+            if (rest < per) break;
+            rest -= per;
+        }
+        const int tl = a.level_tiles[level];
+        const int frame = rest / (G * tl);
+        rest -= frame * G * tl;
+        grp = rest / tl; tile = rest - grp * tl;
+        image = level * g.batch + frame;
+        const LevelGeom lv = g.lv[level];
+        Hc = lv.Ho; Wc = lv.Wo;
+        nrows = min(ta.n_rows[image], (int)ta.kps_stride * 4);
+        in_base = lv.in_off + (long long)frame * Hc * Wc;
+        out_base = (long long)image * ta.kps_stride * 4;
+    } else {
+        tile = blockIdx.x; grp = blockIdx.y; nrows = (int)a.P;
+    }
+    const int p0 = tile * ROWS;
+    if (p0 >= nrows) return;                                     // (workgroup-uniform)
+    if (!GATHER && !tile_in_use(a, p0, ROWS)) return;            // (slotted rows: the whole tile lies in the unused part of a slot)
+    const int nt0 = grp * NTW;
+    const int spt = a.cin >> 4, n_steps = (GATHER ? 9 : 1) * spt;
+    unsigned store_tiles = 3u;                                   // which of this wave's two 32-row tiles are stored (slotted rows: decided here, not in the epilogue)
+    if (!GATHER) store_tiles = (tile_in_use(a, p0 + rh * 64, 32) ? 1u : 0u) | (tile_in_use(a, p0 + rh * 64 + 32, 32) ? 2u : 0u);
+    const char* __restrict__ xb = (const char*)(a.A + in_base * a.cin);      // uniform (plain rows: in_base = 0); lane offsets are 32-bit
+    // ---- staging role: this thread's two rows (tid >> 2 and + 64), piece tid & 3 (16 bytes = 4 channels of the k-step's 16).
+    // Buffer loads: the per-lane part of the address -- the row's centre cell + the piece, or an offset past the resource's range where the tap lies
+    // outside the image / the row does not exist (the load then returns zeros without touching memory) -- is computed ONCE per tap here and stays in
+    // registers for the whole K loop; the tap / k-step part moves the scalar base of the resource.  No vector address arithmetic inside the loop: the
+    // compiler guards a recycled load-destination register with a vmcnt wait, and such a wait would also wait for the weight requests it cannot see.
+    constexpr int NTAP = GATHER ? 9 : 1;
+    constexpr unsigned kOutOfRange = 0xffffff00u;
+    const unsigned img_bytes = GATHER ? (unsigned)Hc * (unsigned)Wc * (unsigned)a.cin * 4u : (unsigned)nrows * (unsigned)a.cin * 4u;
+    unsigned coff[2], okbits[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int row = (tid >> 2) + 64 * k;
+        const bool pvalid = p0 + row < nrows;
+        okbits[k] = 0;
+        if (GATHER) {
+            const int cell = pvalid ? ta.cells[(long long)image * ta.kps_stride * 4 + p0 + row] : 0;
+            const int y = cell / Wc, x = cell - y * Wc;
+            coff[k] = ((unsigned)(y * Wc + x) * (unsigned)a.cin + (unsigned)((tid & 3) * 4)) * 4u;
+#pragma unroll
+            for (int tap = 0; tap < NTAP; ++tap) {
+                const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+                if (pvalid && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc) okbits[k] |= 1u << tap;
+            }
+        } else {
+            okbits[k] = pvalid ? 1u : 0u;
+            coff[k] = ((unsigned)(pvalid ? p0 + row : p0) * (unsigned)a.cin + (unsigned)((tid & 3) * 4)) * 4u;     // (launcher: the tensor is < 4 GB)
+        }
+    }
+    // the offsets of one tap: computed once per tap, at the top of the tap BEFORE (in the K loop below), in front of that step's weight requests
+    auto tap_offsets = [&](int tap, unsigned (&vo)[2]) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) vo[k] = ((okbits[k] >> tap) & 1u) ? coff[k] : kOutOfRange;
+    };
+    // activation pieces are requested TWO k-steps ahead (two register sets that alternate; the K loop is unrolled so that they keep their names)
+    f32x4 aregX[2], aregY[2];
+    auto load_a = [&](int tap, int cs, const unsigned (&vo)[2], f32x4 (&areg)[2]) {
+        const int toff = GATHER ? ((tap / 3 - 1) * Wc + (tap % 3 - 1)) * a.cin * 4 : 0;      // uniform
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + toff + cs * 64), 0, img_bytes, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) areg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo[k], 0, 0));
+    };
+    auto write_a = [&](int s, int buf, const f32x4 (&areg)[2]) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float v = areg[k][c];                      // (zeros where the tap lies outside the image / the row does not exist)
+                hi[c] = (__bf16)v;
+                lo[c] = (__bf16)(v - (float)hi[c]);
+            }
+            unsigned char* dst = As[buf] + ((tid >> 2) + 64 * k) * REC + (tid & 3) * 8;
+            *(bf16x4*)dst = hi;
+            *(bf16x4*)(dst + 32) = lo;
+        }
+    };
+    // weight pieces of a k-step: 8 column tiles x {hi, lo} = 16 pieces of 1 KB; wave w moves pieces 4 j + w by LDS-DMA (k_conv3x3_dense_bf16x3)
+    const unsigned wl_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&wl[0][0];
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto load_w = [&](int s, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = j * 4 + wave_u, nt = piece >> 1, hl = piece & 1;
+            const bf16x8* src = Wb + (((size_t)s * a.nt_total + nt0 + nt) * 2 + hl) * 64;      // uniform
+            const unsigned dst = wl_lds + (unsigned)((buf * NTW * 2 + piece) * 1024);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(src), "v"(lane16), "s"(dst) : "memory", "m0");
+        }
+    };
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float b = a.bias[(nt0 + cg * NT + nt) * 32 + r];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][nt][e] = b;
+    }
+    const int abase = (rh * 64 + r) * REC + half * 16;
+    // Request order matters: the weight pieces are inline assembly the compiler does not count, and its own vmcnt waits for the activation registers
+    // assume only the loads it knows.  With the weight requests of a step issued BEFORE that step's activation requests, "at most the two newest
+    // requests outstanding" -- what the compiler emits in front of write_a, and what the explicit wait in front of the barrier says -- means exactly
+    // "everything but the activation pieces two steps ahead has landed".
+    unsigned vo_cur[2], vo_nxt[2];
+    tap_offsets(0, vo_cur);
+    load_w(0, 0);
+    load_a(0, 0, vo_cur, aregX);
+    load_a(0, 1, vo_cur, aregY);                                  // (spt is even: launcher)
+    write_a(0, 0, aregX);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __syncthreads();
+    // one k-step: cur is free (its pieces are in LDS) and takes the pieces of step s + 2 = (ltap, lcs) if there is one; nxt holds step s + 1
+    auto step = [&](int s, f32x4 (&cur)[2], f32x4 (&nxt)[2], bool load, int ltap, int lcs, const unsigned (&lvo)[2]) {
+        const int buf = s & 1;
+        if (s + 1 < n_steps) load_w(s + 1, buf ^ 1);
+        if (load) load_a(ltap, lcs, lvo, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 ah[MT], al[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            ah[i] = *(const bf16x8*)(As[buf] + abase + i * 32 * REC);
+            al[i] = *(const bf16x8*)(As[buf] + abase + i * 32 * REC + 32);
+        }
+#pragma unroll
+        for (int np = 0; np < NT; np += 2) {
+            bf16x8 bh[2], bl[2];
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) {
+                bh[n2] = wl[buf][((cg * NT + np + n2) * 2 + 0) * 64 + lane];
+                bl[n2] = wl[buf][((cg * NT + np + n2) * 2 + 1) * 64 + lane];
+            }
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][np + n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[n2], acc[i][np + n2], 0, 0, 0);
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][np + n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[n2], acc[i][np + n2], 0, 0, 0);
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][np + n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[n2], acc[i][np + n2], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < n_steps) write_a(s + 1, buf ^ 1, nxt);
+        // (the two newest requests are the activation pieces of step s + 2 -- when there is no such step, the newest are weight pieces: wait for all)
+        if (load) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    // (the tap loop stays a runtime loop: unrolled nine times the scalar registers spill into vector ones; the last tap is written out so that
+    //  "is there a step s + 2" is a compile-time fact in every copy of the step -- a run-time flag makes the compiler's vmcnt waits conservative)
+    auto tap_steps = [&](int tap, auto has_next) {
+        constexpr bool NEXT = decltype(has_next)::value;
+        const int s0 = tap * spt;
+        if (NEXT) tap_offsets(tap + 1, vo_nxt);
+#pragma unroll 1
+        for (int cs = 0; cs + 2 < spt; cs += 2) {                  // the steps whose look-ahead stays inside this tap
+            step(s0 + cs, aregX, aregY, true, tap, cs + 2, vo_cur);
+            step(s0 + cs + 1, aregY, aregX, true, tap, cs + 3, vo_cur);
+        }
+        step(s0 + spt - 2, aregX, aregY, NEXT, tap + 1, 0, vo_nxt);   // the tap's last two steps look ahead into the next tap
+        step(s0 + spt - 1, aregY, aregX, NEXT, tap + 1, 1, vo_nxt);
+        if (NEXT) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) vo_cur[k] = vo_nxt[k];
+        }
+    };
+    int ntap = NTAP;
+    asm volatile("" : "+s"(ntap));                                // (opaque: with the loop below folded away for the one-tap form the register allocator spills 37 registers)
+#pragma unroll 1
+    for (int tap = 0; tap + 1 < ntap; ++tap) tap_steps(tap, std::true_type{});
+    tap_steps(ntap - 1, std::false_type{});
+    // ---- (ReLU6) and store
+    const float lo6 = a.relu6 ? 0.0f : -INFINITY, hi6 = a.relu6 ? 6.0f : INFINITY;
+    const long long n = a.n;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row0 = p0 + rh * 64 + 32 * i + 4 * half;
+        const int left = min(32, nrows - row0);
+        if (!((store_tiles >> i) & 1u)) continue;                  // (uniform: rows in the unused part of a slot are left untouched)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = (nt0 + cg * NT + nt) * 32 + r;
+            if (col < a.n) {
+                float* __restrict__ op = a.out + (out_base + row0) * n + col;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rr = (reg & 3) + 8 * (reg >> 2);
+                    if (rr < left) op[rr * n] = __builtin_amdgcn_fmed3f(acc[i][nt][reg], lo6, hi6);      // (no residual form: launcher)
+                }
+            }
+        }
+    }
+}
+static bool conv_rows_bf16x3_supported(const ConvPack& cp) { return cp.cin % 32 == 0 && cp.nt_total % 8 == 0 && cp.nt_total * 32 == ((cp.n + 255) / 256) * 256; }
+
 // 3 x 3 convolution at the distinct tap cells (GATHER) / 1 x 1 convolution on rows, both on split bf16 operands.
 // Wb: launch_repack_bf16x3 of `cp`.  Shapes: cin % 16 == 0, nt_total % 4 == 0.
 hipError_t launch_conv3x3_cells_bf16x3(const float* A, const ConvPack& cp, const void* Wb, float* out, int relu6, long long kps_stride,
                                        const int* level_keypoints, const Geom& g, const int* cells, const int* n_rows, hipStream_t s) {
     if (cp.taps != 9 || cp.cin % 16 || !cells || !n_rows) return hipErrorInvalidValue;
     ConvArgs a = make_args(A, cp, nullptr, out, 0, relu6);
-    const int groups = (cp.nt_total + 3) / 4;
     const TapArgs ta = {nullptr, nullptr, kps_stride, cells, n_rows};
+    if (conv_rows_bf16x3_supported(cp)) {                         // 256-column outputs: rows gathered and split once per workgroup (k_conv_rows_bf16x3)
+        long long total = 0;
+        for (int l = 0; l < g.n_levels; ++l) {
+            if ((long long)g.lv[l].Ho * g.lv[l].Wo * cp.cin * 4 > 0xffffffffll) return hipErrorInvalidValue;
+            const int rows = 4 * (int)std::min<long long>(level_keypoints[l], kps_stride);
+            a.level_tiles[l] = std::max(1, (rows + 127) / 128);
+            total += (long long)g.batch * (cp.nt_total / 8) * a.level_tiles[l];
+        }
+        if (total <= 0 || total > 0x7fffffffll) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_conv_rows_bf16x3<true>), dim3((unsigned)total), dim3(256), 0, s, a, (const bf16x8*)Wb, g, ta);
+        return hipGetLastError();
+    }
+    const int groups = (cp.nt_total + 3) / 4;
     long long total = 0;
     for (int l = 0; l < g.n_levels; ++l) {
         const int rows = 4 * (int)std::min<long long>(level_keypoints[l], kps_stride);
@@ -1544,7 +1781,134 @@ hipError_t launch_pointwise_bf16x3(const float* A, const ConvPack& cp, const voi
     if (slot_units && slot_rows > 0) { a.slot_units = slot_units; a.slot_rows = slot_rows; a.rows_per_unit = rows_per_unit; }
     const Geom g0 = {};
     const TapArgs none = {nullptr, nullptr, 0, nullptr, nullptr};
+    if (conv_rows_bf16x3_supported(cp) && !residual && (long long)P * cp.cin * 4 <= 0xffffffffll && (long long)P * cp.n * 4 <= 0xffffffffll && P >= 4096) {
+        hipLaunchKernelGGL((k_conv_rows_bf16x3<false>), dim3((unsigned)((P + 127) / 128), cp.nt_total / 8), dim3(256), 0, s, a, (const bf16x8*)Wb, g0, none);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((k_conv_bf16x3<false>), dim3((unsigned)((P + 255) / 256), (cp.nt_total + 3) / 4), dim3(256), 0, s, a, (const bf16x8*)Wb, g0, none);
+    return hipGetLastError();
+}
+
+// ---- detector tail on split bf16 operands (engine option scores_bf16x3): k_det_tail with the 1 x 1 conv 128 -> 65 as three products on the
+// bf16 matrix pipe.  All of the conv's weight pieces (8 steps x 3 column tiles x {hi, lo} = 48 KB) arrive by LDS-DMA once per workgroup; the
+// dustbin column is simply column 0 of the third tile (an MFMA more per step is cheaper here than the vector-ALU chain of the exact form);
+// the logits then overlay the weight block in LDS and go through k_det_tail's softmax / depth_to_space, expression for expression.
+__global__ __launch_bounds__(256, 2) void k_det_tail_bf16x3(ConvArgs a, const bf16x8* __restrict__ Wb, float* __restrict__ dense, Geom g) {
+    constexpr int NTW = 3, STEPS = 8, LP = 65;                 // cin == 128 (launcher)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STEPS * NTW * 2 * 1024];
+    const bf16x8* wl = (const bf16x8*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int image = blockIdx.y, level = image / g.batch, frame = image - level * g.batch;
+    const LevelGeom lv = g.lv[level];                           // H, W: cell grid; Ho, Wo: dense map (8H, 8W)
+    const int ncells = lv.H * lv.W;
+    if ((int)blockIdx.x * 128 >= ncells) return;                // workgroup-uniform
+    const int c0 = blockIdx.x * 128 + wave * 32;
+    const bool active = c0 < ncells;
+    {   // 48 pieces of 1 KB, twelve per wave
+        const unsigned wl_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+        const unsigned lane16 = (unsigned)lane * 16u;
+#pragma unroll
+        for (int j = 0; j < STEPS * NTW * 2 / 4; ++j) {
+            const int piece = j * 4 + wave_u;
+            const bf16x8* src = Wb + (size_t)piece * 64;
+            const unsigned dst = wl_lds + (unsigned)(piece * 1024);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(src), "v"(lane16), "s"(dst) : "memory", "m0");
+        }
+    }
+    const long long row_base = lv.in_off + (long long)frame * ncells;
+    const float* ap = a.A + (row_base + min(c0 + r, ncells - 1)) * a.cin + half * 8;
+    f32x4 av[STEPS][2];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) { av[s][0] = *(const f32x4*)(ap + s * 16); av[s][1] = *(const f32x4*)(ap + s * 16 + 4); }
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const float b = a.bias[nt * 32 + r];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nt][e] = b;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            bf16x8 ah, al;
+            split8(av[s][0], av[s][1], ah, al);
+            bf16x8 bh[NTW], bl[NTW];
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                bh[nt] = wl[((s * NTW + nt) * 2 + 0) * 64 + lane];
+                bl[nt] = wl[((s * NTW + nt) * 2 + 1) * 64 + lane];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[nt], acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[nt], acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[nt], acc[nt], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                            // every wave is done with the weights: the logits take their place
+    if (!active) return;
+    float* L = (float*)smem + wave * (32 * LP);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = nt * 32 + r;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) L[((reg & 3) + 8 * (reg >> 2) + 4 * half) * LP + col] = acc[nt][reg];
+    }
+    if (r == 0) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) L[((reg & 3) + 8 * (reg >> 2) + 4 * half) * LP + 64] = acc[2][reg];
+    }
+    asm volatile("" ::: "memory");
+    // ---- k_det_tail's softmax / depth_to_space: lane (r, half): cell c0 + r, channels 32 half .. 32 half + 31 (+ the dustbin with the upper half)
+    const float* row = L + r * LP + 32 * half;
+    float e[33];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) e[k] = row[k];
+    e[32] = half ? row[32] : e[31];
+    float mx = e[0];
+#pragma unroll
+    for (int k = 1; k < 33; ++k) mx = fmaxf(mx, e[k]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+    for (int k = 0; k < 33; ++k) e[k] = hf_expf_c(e[k] - mx);
+    float sum = 0.0f;
+    if (!half) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) sum = sum + e[k];
+    }
+    sum = __shfl(sum, r, 64);
+    if (half) {
+#pragma unroll
+        for (int k = 0; k < 33; ++k) sum = sum + e[k];
+    }
+    sum = __shfl(sum, r + 32, 64);
+    const int cell = c0 + r;
+    if (cell < ncells) {
+        const int cy = cell / lv.W, cx = cell - cy * lv.W;
+        float* d = dense + lv.out_off + (long long)frame * lv.Ho * lv.Wo + (long long)(cy * 8 + 4 * half) * lv.Wo + cx * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 u, v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { u[j] = e[i * 8 + j] / sum; v[j] = e[i * 8 + 4 + j] / sum; }
+            *(f32x4*)(d + (long long)i * lv.Wo) = u;
+            *(f32x4*)(d + (long long)i * lv.Wo + 4) = v;
+        }
+    }
+}
+
+bool det_tail_bf16x3_supported(const ConvPack& cp) { return det_tail_supported(cp) && cp.cin == 128; }
+hipError_t launch_det_tail_bf16x3(const float* hidden, const ConvPack& cp, const void* Wb, float* dense, const Geom& g, hipStream_t s) {
+    if (!Wb || !det_tail_bf16x3_supported(cp)) return hipErrorInvalidValue;
+    int maxcells = 0;
+    for (int l = 0; l < g.n_levels; ++l) maxcells = max(maxcells, g.lv[l].H * g.lv[l].W);
+    if (maxcells <= 0) return hipSuccess;
+    ConvArgs a = make_args(hidden, cp, nullptr, nullptr, 0, 0);
+    hipLaunchKernelGGL(k_det_tail_bf16x3, dim3((unsigned)((maxcells + 127) / 128), (unsigned)(g.n_levels * g.batch)), dim3(256), 0, s, a, (const bf16x8*)Wb, dense, g);
     return hipGetLastError();
 }
 
@@ -1564,7 +1928,6 @@ hipError_t launch_pointwise_bf16x3(const float* A, const ConvPack& cp, const voi
 //     split + written between the two barriers of the chunk boundary (the second workgroup of the CU computes meanwhile).
 //   Wave tile 64 pixels x 128 columns (eight 32 x 32 accumulators): 24 MFMAs per tap against 4 + 8 ds_read_b128.
 // CELLS: LDS capacity in halo cells (the launcher checks the geometry against it).
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 template <int CELLS>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_dense_bf16x3(ConvArgs a, const bf16x8* __restrict__ Wb, Geom g) {
     constexpr int NT = 4, MT = 2, REC = 80, TS = 2, NP = CELLS * 4 / 256;     // NP: 16-byte activation pieces per thread and chunk

@@ -302,6 +302,12 @@ int DeviceWeights::build(const WeightFile& wf) {
     }
     HF_TRY(pack_conv_bn(*this, wf, "global_head/vlad/memberships", false, memb, &n_clusters, &memb16));
     if (memb.cin != c_global) { set_error("memberships conv width mismatch"); return HFNET_ERR_IO; }
+    if (memb.w && bf16x3_supported(memb)) {
+        HF_HIP(dev_malloc(&memb_bf, bf16x3_pack_bytes(memb)));
+        allocations.push_back(memb_bf);
+        HF_HIP(launch_repack_bf16x3(memb, memb_bf, nullptr));
+        HF_HIP(hipStreamSynchronize(nullptr));
+    }
     const HostTensor* cl = wf.find("global_head/vlad/clusters");
     const HostTensor* fw = wf.find("global_head/dimensionality_reduction/weights");
     const HostTensor* fb = wf.find("global_head/dimensionality_reduction/biases");

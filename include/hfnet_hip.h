@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define HFNET_ABI_VERSION 1
+#define HFNET_ABI_VERSION 2          /* 2 (round 6): HFNET_ERR_INTERNAL, hfnet_*_device_faults, hfnet_extractor_tap, option "scores_bf16x3",
+                                       "pyramid_fuse" is a frame limit (was on / off); 1: rounds 1-5 */
 #define HFNET_DESC_DIM 256          /* local descriptor length  (HFNetTFModelV2.cc:153)            */
 #define HFNET_MAX_LEVELS 8
 #define HFNET_MAX_KEYPOINTS 8192    /* per image and call; mono init asks for 5*nFeatures (Tracking.cc:693) */
@@ -86,7 +87,8 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *                       kernel), "fuse_stem" (1)
  *   "fuse_min_wgs" (256) layers 8-14 take their fused kernel from this many 128-pixel tiles per launch on (0: always)
  *   "dense_desc" (0)    1: dense descriptor head instead of the taps of the selected keypoints
- *   "dedupe_taps" (1)   sparse descriptor head: taps shared by neighbouring keypoints are evaluated once
+ *   "dedupe_taps" (1)   sparse descriptor head: taps shared by neighbouring keypoints are evaluated once (2: the row numbering as two launches,
+ *                       mark + compact, instead of inside the top-K launch; same rows)
  *   "two_streams" (3)   0 one stream; 1 fork after layer 7; 2 fork after the detector conv; 3 = 2 + deferred join
  *   "conv_wlds" (1)     3x3 head convolutions: weights staged through LDS once per workgroup (0: every wave reads them)
  *   "graph" (1), "pinned_frames" (4): host-pointer extractor calls
@@ -173,7 +175,8 @@ int hfnet_model_tap(hfnet_model* m, int tap, float* out, size_t capacity, size_t
  * bound every index they read from device memory before it becomes an address (a valid call can then never take the host
  * process down through a GPU memory fault -- the reference's contract is `return false`, HFNetTFModelV2.cc:62-98, never an
  * abort); a bit here says that such a bound was hit, i.e. that device state was inconsistent and results may be wrong.
- * hfnet_model_detect also returns HFNET_ERR_DEVICE when the word is non-zero after its launches.  Waits for the object's stream. */
+ * hfnet_model_detect returns HFNET_ERR_DEVICE for THE CALL whose launches set a bit (the reference's per-call `return false`) and clears
+ * the device word behind it, so the object stays usable; this function keeps reporting every bit ever seen.  Waits for the object's stream. */
 #define HFNET_DEVICE_FAULT_TAP_ROWS 1u    /* more marked tap cells than rows in an image's slot of the sparse descriptor head */
 #define HFNET_DEVICE_FAULT_SAMPLE_ROW 2u  /* a bilinear tap of a selected keypoint had no descriptor row                      */
 int hfnet_model_device_faults(hfnet_model* m, unsigned int* bits);

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/hfnet_hip.h but not exported"
     assert sorted(capi.SYMBOLS) == declared, "capi.SYMBOLS out of sync with the header"
-    assert lib.hfnet_abi_version() == 1
+    assert lib.hfnet_abi_version() == 2
 
 
 def test_header_cites_reference_for_every_group():
@@ -121,8 +121,13 @@ def test_no_exception_crosses_the_c_abi():
     assert n >= 50, n
     L = capi.lib()
     L.hfnet_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    # the throwing hook exists only with HFNET_TEST_HOOKS=1: without it the name is an ordinary (null-engine) call
+    os.environ.pop("HFNET_TEST_HOOKS", None)
+    assert L.hfnet_engine_set_option(None, b"debug_throw", 1) == capi.ERR_INVALID_ARG
+    os.environ["HFNET_TEST_HOOKS"] = "1"
     assert L.hfnet_engine_set_option(None, b"debug_throw", 1) == capi.ERR_INTERNAL == 7
     assert "out of host memory" in capi.last_error()
     assert L.hfnet_engine_set_option(None, b"debug_throw", 2) == capi.ERR_INTERNAL
     assert "debug_throw" in capi.last_error()
+    os.environ.pop("HFNET_TEST_HOOKS", None)
     assert L.hfnet_engine_set_option(None, b"fuse_blocks", 1) == capi.ERR_INVALID_ARG       # (the ordinary null-engine answer)

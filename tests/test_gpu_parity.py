@@ -28,7 +28,7 @@ SIZES = [(64, 96), (120, 160), (133, 171)]   # the last one exercises the crop t
 # fused kernel for every block shape it covers
 # (fuse_min_wgs 0: layers 8-14 take their fused kernels even for the few tiles of a single small frame)
 VARIANTS = {"default": {}, "unfused_dense": {"fuse_blocks": 0, "dense_desc": 1}, "fused_v2": {"fused_variant": 2},
-            "no_tail_fuse": {"tail_fuse": 0}, "no_dedupe": {"dedupe_taps": 0}, "fused_all": {"fuse_min_wgs": 0}, "fused_occ3_all": {"fused_variant": 3, "fuse_min_wgs": 0}, "fused_v2_all": {"fused_variant": 2, "fuse_min_wgs": 0},
+            "no_tail_fuse": {"tail_fuse": 0}, "no_dedupe": {"dedupe_taps": 0}, "dedupe_two_launch": {"dedupe_taps": 2}, "fused_all": {"fuse_min_wgs": 0}, "fused_occ3_all": {"fused_variant": 3, "fuse_min_wgs": 0}, "fused_v2_all": {"fused_variant": 2, "fuse_min_wgs": 0},
             "separate_det_tail": {"det_fuse": 0}, "fused_v6": {"fused_variant": 6, "fuse_min_wgs": 0}, "fused_v6_all": {"fused_variant": 7, "fuse_min_wgs": 0},
             "fused_v4_all": {"fused_variant": 5, "fuse_min_wgs": 0}, "fused_v8": {"fused_variant": 8, "fuse_min_wgs": 0}}
 
