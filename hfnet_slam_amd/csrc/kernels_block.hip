@@ -834,7 +834,13 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
     // ---- block input: A row r of M tile m is accumulator slot 16 m + ir of lane half hr
     constexpr int KS = (KQT + 1) / 2;                             // BF: 16-k steps of the expansion (the last one may hold 8 channels)
     f32x4 afrag[BF ? 1 : MT][BF ? 1 : KQT];
-    fb16x8 ah[BF ? MT : 1][BF ? KS : 1], al[BF ? MT : 1][BF ? KS : 1];
+    // 96 input channels (KS = 6): five M tiles of hi / lo fragments are 240 registers, and with the projection's accumulators next to them the
+    // accumulator half of the register file overflows (28 fragment registers lived in scratch memory and came back once per chunk).  The LAST
+    // M tile's fragments live in the wave's LDS instead (12 KB; a lone wave per SIMD leaves LDS mostly idle) and are read a step ahead.
+    constexpr bool ALDS = BF && KS >= 5 && OCC == 1;
+    constexpr int MR = ALDS ? MT - 1 : MT;                        // M tiles whose fragments stay in registers
+    __shared__ __attribute__((aligned(16))) fb16x8 AL[ALDS ? KS : 1][2][64];
+    fb16x8 ah[BF ? MT : 1][BF ? (ALDS ? KS : KS) : 1], al[BF ? MT : 1][BF ? KS : 1];
     float aflag[MT];                                              // 1 where this A row is an out-of-image position (k half 0 only)
     {
         const int hr = (r >> 2) & 1, ir = ((r >> 3) << 2) | (r & 3);
@@ -865,7 +871,9 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
                     const char* pa = xb + offp + (kok ? (ks * 16 + half * 8) * 4 : 0);
                     const f32x4 v0 = *(const f32x4*)pa, v1 = *(const f32x4*)(pa + 16);
                     fsplit8(kok ? v0 : z4, kok ? v1 : z4, ah[m][ks], al[m][ks]);
+                    if constexpr (ALDS) { if (m == MT - 1) { AL[ks][0][lane] = ah[m][ks]; AL[ks][1][lane] = al[m][ks]; } }
                 }
+                if constexpr (KS >= 5) __builtin_amdgcn_sched_barrier(0);   // (one M tile's raw pieces at a time: all of them in flight next to the fragments is 2 x 8 KS MT registers)
             } else {
                 const unsigned off = ((unsigned)(iy * lv.W + ix) * (unsigned)a.cin + (unsigned)(half * 4)) * 4u;
 #pragma unroll
@@ -885,15 +893,21 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
     const unsigned lane16_ = (unsigned)lane * 16u, r4_ = (unsigned)r * 4u;
     constexpr int PF = KQT < 3 ? KQT : 3;                          // pieces of expansion weights in flight
     f32x4 bq[BF ? 1 : PF];
-    // BF: the chunk's expansion weights [step][hi | lo], requested for the NEXT chunk right behind this chunk's expansion
-    fb16x8 bfr[BF ? KS : 1][2];
+    // BF: the chunk's expansion weights [step][hi | lo], requested for the NEXT chunk right behind this chunk's expansion; from five steps on
+    // (72 / 96 input channels) a ring of three steps instead, requested two steps ahead: 24 registers instead of 8 KS
+    constexpr bool BRING = BF && KS >= 5;
+    fb16x8 bfr[BF ? (BRING ? 3 : KS) : 1][2];
     const fb16x8* __restrict__ wexb = (const fb16x8*)a.Wex_bf;
     const fb16x8* __restrict__ wprb = (const fb16x8*)a.Wpr_bf;
     auto load_bfr = [&](int chunk) {
 #pragma unroll
-        for (int ks = 0; ks < (BF ? KS : 1); ++ks)
+        for (int ks = 0; ks < (BF ? (BRING ? 2 : KS) : 1); ++ks)       // (ring: the chunk's first two steps)
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl) bfr[ks][hl] = wexb[(((size_t)ks * a.ex_nt_total + chunk) * 2 + hl) * 64 + lane];
+    };
+    auto load_bfr_step = [&](int chunk, int ks) {                      // ring slot ks % 3
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) bfr[ks % 3][hl] = wexb[(((size_t)ks * a.ex_nt_total + chunk) * 2 + hl) * 64 + lane];
     };
     float ebias;
     {
@@ -926,30 +940,47 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
         // ---- expansion: MT independent chains, k outer, weights through the ring
         f32x16 acc[MT];
         if constexpr (BF) {
-            if constexpr (KS >= 5) { if (chunk > 0) load_bfr(chunk); }
-            f32x16 bias16;
+            if constexpr (BRING) {
+                // (one wave per SIMD, every register counts: the accumulators start at the bias in place -- 16 registers of a broadcast bias tile less)
+                load_bfr_step(chunk, 2);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) bias16[i] = ebias;
+                for (int m = 0; m < MT; ++m) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                // (border tiles: the chain of an out-of-image row starts at -1e30, as in the f32 form)
-                const f32x16 c0 = interior ? bias16 : __builtin_amdgcn_mfma_f32_32x32x2f32(aflag[m], bneg, bias16, 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m][0], bfr[0][0], c0, 0, 0, 0);
+                    for (int i = 0; i < 16; ++i) acc[m][i] = ebias;
+                    if (!interior) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(aflag[m], bneg, acc[m], 0, 0, 0);
+                    const fb16x8 a0 = (ALDS && m == MT - 1) ? AL[0][0][lane] : ah[m][0];
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr[0][0], acc[m], 0, 0, 0);
+                }
+            } else {
+                f32x16 bias16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) bias16[i] = ebias;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    // (border tiles: the chain of an out-of-image row starts at -1e30, as in the f32 form)
+                    const f32x16 c0 = interior ? bias16 : __builtin_amdgcn_mfma_f32_32x32x2f32(aflag[m], bneg, bias16, 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m][0], bfr[0][0], c0, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
+                constexpr int dummy = 0; (void)dummy;
+                const int slot = BRING ? ks % 3 : ks;
+                fb16x8 lh, ll;                                      // (ALDS: the last M tile's fragments of this step)
+                if constexpr (ALDS) { lh = AL[ks][0][lane]; ll = AL[ks][1][lane]; }
                 if (ks > 0) {
+                    if constexpr (BRING) { if (ks + 2 < KS) load_bfr_step(chunk, ks + 2); }
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m][ks], bfr[ks][0], acc[m], 0, 0, 0);
+                    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((ALDS && m == MT - 1) ? lh : ah[m][ks], bfr[slot][0], acc[m], 0, 0, 0);
                 }
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m][ks], bfr[ks][1], acc[m], 0, 0, 0);
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((ALDS && m == MT - 1) ? lh : ah[m][ks], bfr[slot][1], acc[m], 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m][ks], bfr[ks][0], acc[m], 0, 0, 0);
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((ALDS && m == MT - 1) ? ll : al[m][ks], bfr[slot][0], acc[m], 0, 0, 0);
+                if constexpr (BRING) __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (KS < 5) load_bfr(cn);                    // the next chunk's weights arrive during the depthwise / projection (72 input
-                                                                   // channels: 40 registers the depthwise needs -- requested at the chunk's top instead)
+            load_bfr(cn);                                          // the next chunk's (first) weights arrive during the depthwise / projection
         } else {
             f32x16 bias16;
 #pragma unroll
@@ -1007,7 +1038,7 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
         // register counts: a k-group at a time, one group ahead of its MFMAs).  BF: [16-k step][column tile][hi | lo], a step at a time.
         constexpr bool PJIT = OCC == 1;
         f32x4 pfrag[BF ? 1 : (PJIT ? 2 : 4)][BF ? 1 : NTO];
-        constexpr int PBN = (KS >= 5 && NTO >= 3) ? 1 : 2;         // (72 -> 432 -> 72: no registers for a second step's fragments)
+        constexpr int PBN = (KS >= 5 && (NTO >= 3 || OCC == 1)) ? 1 : 2;   // (72 -> 432 -> 72, 96 -> 576 -> 48: no registers for a second step's fragments)
         fb16x8 pbf[BF ? PBN : 1][BF ? NTO : 1][2];
         auto load_p = [&](int kq, int slot) {
             const unsigned l16 = fresh(lane16_);
@@ -1752,8 +1783,8 @@ bool block_fused_bf16x3_supported(const BlockPack& b) {
     const int nto = (b.cout + 31) / 32, kq = b.cin / 8, st = b.stride;
     return b.has_expand && b.ex_bf && b.pr_bf && b.cin % 8 == 0 && b.pr.nt_total == nto &&
            ((st == 1 && kq == 6 && (nto == 2 || nto == 3)) || (st == 1 && kq == 9 && nto == 3) ||      // layers 7, 9-14
-            (st == 2 && (kq == 2 || kq == 3) && nto == 1) || (st == 1 && kq == 3 && nto <= 2));         // layers 3, 5 / 4, 6 (scores_bf16x3)
-            // (layer 8: 240 + 48 fragment registers do not fit)
+            (st == 2 && (kq == 2 || kq == 3) && nto == 1) || (st == 1 && kq == 3 && nto <= 2) ||        // layers 3, 5 / 4, 6 (scores_bf16x3)
+            (st == 2 && kq == 12 && nto == 2));                                                          // layer 8: one wave per SIMD, like its f32 form
 }
 
 hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, const Geom& g, int variant, hipStream_t s, int bf16x3) {
@@ -1781,6 +1812,7 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
         if (st == 2 && kq == 3 && nto == 1) return launch_block_fused8_t<2, 1, 3, 2, true>(a, g, s);
         if (st == 1 && kq == 3 && nto == 1) return launch_block_fused8_t<1, 1, 3, 3, true>(a, g, s);
         if (st == 1 && kq == 3 && nto == 2) return launch_block_fused8_t<1, 2, 3, 2, true>(a, g, s);
+        if (st == 2 && kq == 12 && nto == 2) return launch_block_fused8_t<2, 2, 12, 1, true>(a, g, s);
     }
     if (kind == FUSED_V4 && variant == 4 && small_launch && fused_kind(b, 2) == FUSED_V2) kind = FUSED_V2;
     // v6 (6 x 8 tiles on the 16x16x4 MFMA): what a launch of k_block_fused4's size runs for the stride-1 blocks from layer 6 on

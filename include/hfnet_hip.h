@@ -117,9 +117,9 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  * Values are >= 0.
  * Every setting of the extractor and matcher switches ABOVE produces the same bits (tests/test_gpu_parity.py).
  *
- * Two options trade the oracle's bits of FLOAT outputs for speed, within a stated tolerance; both default to 0, and neither
- * touches anything that decides an index -- backbone layers 1-7, detector head, NMS, threshold scan and top-K run the exact f32
- * chains whatever they say, so keypoint counts, positions, responses and octaves stay bit-identical:
+ * Three options trade the oracle's bits of FLOAT outputs for speed, within a stated tolerance; all default to 0.  The first two touch
+ * nothing that decides an index -- backbone layers 1-7, detector head, NMS, threshold scan and top-K run the exact f32 chains whatever
+ * they say, so keypoint counts, positions, responses and octaves stay bit-identical; the third ("scores_bf16x3") is the full tolerance mode:
  *   "desc_bf16x3" (0)   the sparse descriptor head (3x3 96 -> 256 + ReLU6, 1x1 256 -> 256 at the distinct tap cells) on the bf16 matrix
  *                       pipe: every f32 operand is split into two bf16 pieces x = hi + lo + e, |e| <= 2^-16 |x|, and a product
  *                       a.w is taken as ah.wh + ah.wl + al.wh (v_mfma_f32_32x32x16_bf16; exact products, fp32 accumulation in the
@@ -131,8 +131,22 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *                       the fused kernels, i.e. more than four frames; the depthwise stage between the two stays exact f32) and layers 15-18
  *                       (three launches per block).  STATED TOLERANCE: 2e-5 absolute per component of the (unit-norm) 4096-D global
  *                       descriptor (measured <= 6e-6 through the ten blocks; a model with a D-dimensional global descriptor: 2e-5 *
- *                       sqrt(4096 / D) -- the components of a unit vector scale that way).  Layer 8, the NetVLAD head and the dimensionality
- *                       reduction stay exact.
+ *                       sqrt(4096 / D) -- the components of a unit vector scale that way).  Also layer 8 (fused; calls that take the fused kernels)
+ *                       and the NetVLAD memberships conv; the NetVLAD aggregation and the dimensionality reduction stay exact f32.
+ *   "scores_bf16x3" (0) the rest of the network on the same split-bf16 products: the 1x1 convolutions of layers 3-7 inside their fused kernels (the
+ *                       depthwise stage between them stays exact f32), the detector head's 3x3 conv 96 -> 128 (halo staged through LDS already split,
+ *                       k_conv3x3_dense_bf16x3) and its 1x1 128 -> 65 (k_det_tail_bf16x3).  Stem + layer 2, every depthwise stage, softmax, NMS,
+ *                       threshold scan, top-K, sampler, NetVLAD aggregation and the FC stay f32.  With this option THE SCORE MAP IS A TOLERANCE TENSOR,
+ *                       and "bit-exact keypoints" changes meaning the way SURVEY.md section 7 spells it out: NMS / threshold / top-K are exact ON THE SCORE
+ *                       MAP THE DEVICE PRODUCED -- the oracle's hfo_simple_nms + hfo_select_keypoints run on the dense scores read back through
+ *                       hfnet_extractor_tap(22) give the device's keypoints, array_equal (tests/test_gpu_scores_bf16x3.py; bench.py checks it on the
+ *                       last timed chunk) -- while the map itself is within a stated tolerance of the oracle's.  STATED TOLERANCES (all three options on;
+ *                       752x480 and 512x512, 4 levels): dense scores 5e-4 absolute and 2e-3 relative to the score (measured 1.4e-4 / 5e-4: a softmax output
+ *                       moves by s |d logit|, the logits by <= 5e-4 after six layers), unit-norm descriptors of the keypoints both modes select 1e-5
+ *                       (measured 7e-6), global descriptor 2e-5 (measured 1.5e-5; images of a few hundred cells, where NetVLAD averages far fewer
+ *                       pixels: 6e-5, measured 3.1e-5).  Keypoint-set overlap with the exact mode: >= 99 % (measured 100 % on the synthetic weights,
+ *                       whose scores are the hard case: near 1/65 everywhere).  With "global_bf16x3" the option also moves layer 8 (fused, one wave per
+ *                       SIMD) and the NetVLAD memberships conv onto split-bf16 operands.
  *   "join_fused_branch" (0) diagnostic: calls of <= 4 frames whose global branch contains fused-block kernels (only with "fuse_min_wgs"
  *                       lowered) join the branch before the sampler instead of after it (NOTEBOOK.md R4.8)
  * The matcher and the database are exact FOR THE DESCRIPTORS THEY ARE GIVEN in either mode. */

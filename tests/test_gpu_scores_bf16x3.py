@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 SCORES_TOL = 5e-4             # abs, on softmax scores in [0, 1] (include/hfnet_hip.h; observed <= 1.2e-4, at scores near 1)
 SCORES_REL_TOL = 2e-3         # and relative to the score itself: |ds| <= 2e-3 s + 1e-7 (a softmax output moves by s * |d logit|; observed 4e-4)
 DESC_TOL = 1e-5
-GLOBAL_TOL = 2e-5
+GLOBAL_TOL = 2e-5             # at the reference's image sizes (752x480, 512x512)
+GLOBAL_TOL_SMALL = 6e-5       # images of a few hundred cells: NetVLAD averages the deviations of far fewer pixels (observed <= 3e-5)
 ALL_OPTS = ("scores_bf16x3", "desc_bf16x3", "global_bf16x3")
 
 
@@ -91,12 +92,16 @@ def test_scores_bf16x3_full_size(engine, oracle_model, engine_options, cfg, opts
     assert worst_g <= GLOBAL_TOL, worst_g
 
 
-def test_scores_bf16x3_single_model_all_overloads(engine, oracle_model, engine_options):
+@pytest.mark.parametrize("fuse_min_wgs", [None, 0], ids=["default_dispatch", "fused_forms"])
+def test_scores_bf16x3_single_model_all_overloads(engine, oracle_model, engine_options, fuse_min_wgs):
     """the BaseModel path (one level, one frame; hfnet_model_detect) with every tolerance option on: keypoints == the oracle's selection on
-    the device's score map, for a ragged size whose tiles are partial on every border"""
+    the device's score map, for ragged sizes whose tiles are partial on every border; fuse_min_wgs = 0 forces the fused split-bf16 forms of
+    layers 8-14 (layer 8: the one-wave-per-SIMD form with a tile of fragments in LDS) onto launches this small"""
     from hfnet_slam_amd import capi
     from oracle import oracle as O
     engine_options({o: 1 for o in ALL_OPTS})
+    if fuse_min_wgs is not None:
+        engine_options({"fuse_min_wgs": fuse_min_wgs, "tail_fuse": 0})
     for (w, h, nk) in [(200, 152, 300), (131, 121, 100), (752, 480, 1000)]:
         m = capi.Model(engine, capi.MODE_LOCAL_AND_GLOBAL, h, w, nk)
         img = synth_image(h, w, 6300 + w, "natural")
@@ -109,5 +114,52 @@ def test_scores_bf16x3_single_model_all_overloads(engine, oracle_model, engine_o
         assert np.array_equal(kps["x"], kp["x"]) and np.array_equal(kps["y"], kp["y"]) and np.array_equal(kps["response"], kp["response"])
         ok, rk, rd, rg = oracle_model.detect(img, capi.MODE_LOCAL_AND_GLOBAL, nk, 0.01)
         assert ok
-        assert np.abs(g.astype(np.float64).ravel() - np.asarray(rg, np.float64).ravel()).max() <= GLOBAL_TOL
+        dev = float(np.abs(g.astype(np.float64).ravel() - np.asarray(rg, np.float64).ravel()).max())
+        print(f"\nmodel {w}x{h} fuse_min_wgs {fuse_min_wgs}: global max |d| {dev:.3e}")
+        assert dev <= (GLOBAL_TOL if w * h >= 512 * 512 else GLOBAL_TOL_SMALL), (w, h, dev)
         m.close()
+
+
+@pytest.mark.parametrize("fuse_min_wgs", [None, 0], ids=["default_dispatch", "fused_forms"])
+def test_scores_bf16x3_ragged_pyramids(engine, oracle_model, engine_options, fuse_min_wgs):
+    """the extractor on level sizes that leave partial tiles on every border of every kernel of the tolerance pipeline (the LDS-staged detector conv's
+    256-pixel tiles straddle image rows differently at every width), calls of one and three frames"""
+    from hfnet_slam_amd import capi, spec
+    from oracle import oracle as O
+    engine_options({o: 1 for o in ALL_OPTS})
+    if fuse_min_wgs is not None:
+        engine_options({"fuse_min_wgs": fuse_min_wgs})
+    for (w, h, nl, nf) in [(200, 152, 4, 500), (131, 121, 2, 150), (248, 168, 3, 300), (376, 240, 2, 400), (1024, 96, 2, 300)]:
+        B = 3
+        imgs = np.stack([synth_image(h, w, 6500 + i, "natural" if i != 1 else "uniform") for i in range(B)])
+        budget = spec.features_per_level(nf, nl, 1.2)
+        x = capi.Extractor(engine, w, h, nf, 0.01, 1.2, nl, max_batch=B)
+        n1, k1, d1, g1 = x.extract_batch(imgs)
+        dense = x.tap(22, B)
+        sf = x.tables()[0]
+        worst_g = 0.0
+        for f in range(B):
+            parts = []
+            for l, kb in enumerate(budget):
+                kp = O.select_keypoints(O.simple_nms(dense[l][f], 4, 2), 0.01, kb)
+                e = np.zeros(len(kp), capi.KP_DTYPE)
+                e["x"] = kp["x"] * np.float32(sf[l]); e["y"] = kp["y"] * np.float32(sf[l]); e["response"] = kp["response"]; e["octave"] = l
+                parts.append(e)
+            want = np.concatenate(parts)
+            assert n1[f] == len(want) and np.array_equal(k1[f, :n1[f]], want), (w, h, f)
+            rn, rk, rd, rg, _ = oracle_model.extract(imgs[f], nf, 0.01, nl, 1.2)
+            worst_g = max(worst_g, float(np.abs(g1[f].astype(np.float64) - rg).max()))
+            pos = {(int(o), float(a), float(b)): i for i, (o, a, b) in enumerate(zip(rk["octave"], rk["x"], rk["y"]))}
+            common = 0
+            for j in range(n1[f]):
+                i = pos.get((int(k1[f, j]["octave"]), float(k1[f, j]["x"]), float(k1[f, j]["y"])))
+                if i is not None:
+                    common += 1
+                    assert np.abs(d1[f, j].astype(np.float64) - rd[i]).max() <= DESC_TOL, (w, h, f, j)
+            assert common >= 0.98 * rn, (w, h, f, common, rn)
+        print(f"\nextractor {w}x{h} x{nl} fuse_min_wgs {fuse_min_wgs}: global max |d| {worst_g:.3e}")
+        assert worst_g <= GLOBAL_TOL_SMALL, (w, h, worst_g)
+        # one frame alone == the same frame inside the call (batch invariance holds in tolerance mode too: same kernels, same tiles per image)
+        na, ka, da, ga, _ = x.extract(imgs[1])
+        assert na == n1[1] and np.array_equal(ka, k1[1, :na])
+        x.close()
