@@ -131,6 +131,7 @@ struct BlockPack {
     float* pr_logical = nullptr;   // projection weights [k logical][n physical] for the vector-ALU layer_2 kernel
     void* ex_bf = nullptr;         // expansion / projection weights split into bf16 pieces (engine options scores_bf16x3: layers 3-7,
     void* pr_bf = nullptr;         // global_bf16x3: layers 8-18)
+    void* ex_bfb = nullptr;        // ... the expansion's with the folded bias in the spare k slot (input widths of an odd number of channel groups: 24)
 };
 
 struct DeviceWeights {

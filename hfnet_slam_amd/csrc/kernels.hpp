@@ -37,7 +37,8 @@ hipError_t launch_conv3x3(const float* A, const ConvPack& cp, float* out, int re
 // image are then its n_rows[image] DISTINCT tap cells (row r of the slot is cell cells[image * kps_stride * 4 + r]).
 // split-bf16 forms (engine option desc_bf16x3; kernels_conv.hip): NOT the oracle's bits -- within the tolerance of include/hfnet_hip.h
 size_t bf16x3_pack_bytes(const ConvPack& cp);
-hipError_t launch_repack_bf16x3(const ConvPack& cp, void* out, hipStream_t s);
+// with_bias: the folded bias goes into the spare k slot of an odd channel-group count (1x1 only): see k_repack_bf16x3
+hipError_t launch_repack_bf16x3(const ConvPack& cp, void* out, hipStream_t s, int with_bias = 0);
 inline bool bf16x3_supported(const ConvPack& cp) { return (cp.taps == 1 && cp.cin % 8 == 0) || (cp.taps == 9 && cp.cin % 16 == 0); }
 hipError_t launch_conv3x3_cells_bf16x3(const float* A, const ConvPack& cp, const void* Wb, float* out, int relu6, long long kps_stride,
                                        const int* level_keypoints, const Geom& g, const int* cells, const int* n_rows, hipStream_t s);

@@ -32,6 +32,7 @@ struct FusedArgs {
     const float* Wdw; const float* dw_bias;
     const f32x4* Wpr; const float* pr_bias; int pr_nt_total;
     const f32x4* Wex16; const f32x4* Wpr16; int ex_n16, pr_n16;  // ConvPack16 forms (k_block_fused6)
+    const void* Wex_bfb;                                           // ... the expansion's with the bias in the spare k slot (odd cin / 8), or null
     const void* Wex_bf; const void* Wpr_bf;                      // split-bf16 forms (launch_repack_bf16x3; k_block_fused8<..., BF = true>), or null
     float* out;
     int cin, cexp, cout, residual, has_expand;
@@ -794,12 +795,21 @@ template <int STRIDE> struct F8Geo {
 // bf16 MFMA has the f32 one's layout, so the register-resident depthwise stage is unchanged (and exact for its inputs).  NOT the
 // oracle's bits: within the tolerance stated in include/hfnet_hip.h.
 typedef __bf16 fb16x8 __attribute__((ext_vector_type(8)));
+// (pairs: one v_cvt_pk_bf16_f32 rounds two values, the f32 of the hi pieces is a shift / a mask of the packed word: 3 vector instructions per value
+//  where the value-by-value form compiles to 4 -- these kernels run with the vector ALU saturated)
+typedef __bf16 fb16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void fsplit8(const f32x4& v0, const f32x4& v1, fb16x8& hi, fb16x8& lo) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float v = e < 4 ? v0[e] : v1[e - 4];
-        hi[e] = (__bf16)v;
-        lo[e] = (__bf16)(v - (float)hi[e]);
+    for (int j = 0; j < 4; ++j) {
+        const float x = j < 2 ? v0[2 * j] : v1[2 * j - 4], y = j < 2 ? v0[2 * j + 1] : v1[2 * j - 3];
+        fb16x2 p;
+        p[0] = (__bf16)x; p[1] = (__bf16)y;
+        const unsigned pu = __builtin_bit_cast(unsigned, p);
+        const float hx = __builtin_bit_cast(float, pu << 16), hy = __builtin_bit_cast(float, pu & 0xffff0000u);
+        fb16x2 q;
+        q[0] = (__bf16)(x - hx); q[1] = (__bf16)(y - hy);
+        hi[2 * j] = p[0]; hi[2 * j + 1] = p[1];
+        lo[2 * j] = q[0]; lo[2 * j + 1] = q[1];
     }
 }
 template <int STRIDE, int NTO, int KQT, bool RES, int OCC, bool BF = false>
@@ -833,6 +843,10 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
 
     // ---- block input: A row r of M tile m is accumulator slot 16 m + ir of lane half hr
     constexpr int KS = (KQT + 1) / 2;                             // BF: 16-k steps of the expansion (the last one may hold 8 channels)
+    // BIASK (an odd number of input channel groups: 24 channels): the last step's spare k slot carries a constant 1 against the folded bias in the
+    // weights (launch_repack_bf16x3 with_bias), the accumulators start at the inline constant 0 -- no bias tile, no moves (the vector ALU is what
+    // bounds these kernels).  The launcher passes the pack with the bias row as Wex_bf.
+    constexpr bool BIASK = BF && (KQT % 2 == 1);
     f32x4 afrag[BF ? 1 : MT][BF ? 1 : KQT];
     // 96 input channels (KS = 6): five M tiles of hi / lo fragments are 240 registers, and with the projection's accumulators next to them the
     // accumulator half of the register file overflows (28 fragment registers lived in scratch memory and came back once per chunk).  The LAST
@@ -867,10 +881,11 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
                 const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const bool kok = ks * 16 + half * 8 < a.cin;       // (the upper half of a last step of 8 channels: zeros)
+                    const bool kok = ks * 16 + half * 8 < a.cin;       // (the upper half of a last step of 8 channels: zeros -- BIASK: a one in slot 0)
                     const char* pa = xb + offp + (kok ? (ks * 16 + half * 8) * 4 : 0);
                     const f32x4 v0 = *(const f32x4*)pa, v1 = *(const f32x4*)(pa + 16);
-                    fsplit8(kok ? v0 : z4, kok ? v1 : z4, ah[m][ks], al[m][ks]);
+                    const f32x4 one4 = {1.f, 0.f, 0.f, 0.f};
+                    fsplit8(kok ? v0 : (BIASK ? one4 : z4), kok ? v1 : z4, ah[m][ks], al[m][ks]);
                     if constexpr (ALDS) { if (m == MT - 1) { AL[ks][0][lane] = ah[m][ks]; AL[ks][1][lane] = al[m][ks]; } }
                 }
                 if constexpr (KS >= 5) __builtin_amdgcn_sched_barrier(0);   // (one M tile's raw pieces at a time: all of them in flight next to the fragments is 2 x 8 KS MT registers)
@@ -946,7 +961,7 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[m][i] = ebias;
+                    for (int i = 0; i < 16; ++i) acc[m][i] = BIASK ? 0.0f : ebias;
                     if (!interior) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(aflag[m], bneg, acc[m], 0, 0, 0);
                     const fb16x8 a0 = (ALDS && m == MT - 1) ? AL[0][0][lane] : ah[m][0];
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr[0][0], acc[m], 0, 0, 0);
@@ -954,7 +969,7 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
             } else {
                 f32x16 bias16;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) bias16[i] = ebias;
+                for (int i = 0; i < 16; ++i) bias16[i] = BIASK ? 0.0f : ebias;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     // (border tiles: the chain of an out-of-image row starts at -1e30, as in the f32 form)
@@ -1085,12 +1100,15 @@ __global__ __launch_bounds__(64, OCC) void k_block_fused8(FusedArgs a, Geom g) {
                 if (ch0 + s16 * 16 < a.cexp) {                     // (uniform)
                     if (s16 == 0 && PBN == 2) load_pbf(1, 1);
                     if (s16 == 1 && PBN == 1) load_pbf(1, 0);
-                    const bool kok = ch0 + s16 * 16 + half * 8 < a.cexp;      // (channels past cexp hold clamped garbage: zeros instead)
                     const float* pa = ET + r * CEP + s16 * 16 + half * 8;
-                    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                    const f32x4 v0 = *(const f32x4*)pa, v1 = *(const f32x4*)(pa + 4);
+                    f32x4 v0 = *(const f32x4*)pa, v1 = *(const f32x4*)(pa + 4);
+                    if (a.cexp & 8) {                                  // (uniform; an expansion width with half a 16-k step: the channels past cexp hold clamped garbage -- zeros instead)
+                        const bool kok = ch0 + s16 * 16 + half * 8 < a.cexp;
+                        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                        v0 = kok ? v0 : z4; v1 = kok ? v1 : z4;
+                    }
                     fb16x8 dh, dl;
-                    fsplit8(kok ? v0 : z4, kok ? v1 : z4, dh, dl);
+                    fsplit8(v0, v1, dh, dl);
 #pragma unroll
                     for (int nt = 0; nt < NTO; ++nt) pacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, pbf[s16 % PBN][nt][0], pacc[nt], 0, 0, 0);
 #pragma unroll
@@ -1159,6 +1177,10 @@ static hipError_t launch_block_fused8_t(const FusedArgs& a, const Geom& g, hipSt
     }
     if (total <= 0 || total > 0x7fffffffll) return hipErrorInvalidValue;
     if (BF && (!a.Wex_bf || !a.Wpr_bf)) return hipErrorInvalidValue;
+    if (BF && KQT % 2 == 1) {                                      // the kernel's BIASK form: the expansion pack with the bias row
+        if (!a.Wex_bfb) return hipErrorInvalidValue;
+        b.Wex_bf = a.Wex_bfb;
+    }
     if (a.residual) hipLaunchKernelGGL((k_block_fused8<STRIDE, NTO, KQT, true, OCC, BF>), dim3((unsigned)total), dim3(64), 0, s, b, g);
     else hipLaunchKernelGGL((k_block_fused8<STRIDE, NTO, KQT, false, OCC, BF>), dim3((unsigned)total), dim3(64), 0, s, b, g);
     return hipGetLastError();
@@ -1790,7 +1812,7 @@ bool block_fused_bf16x3_supported(const BlockPack& b) {
 hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, const Geom& g, int variant, hipStream_t s, int bf16x3) {
     FusedArgs a;
     a.X = X;
-    a.Wex_bf = b.ex_bf; a.Wpr_bf = b.pr_bf;
+    a.Wex_bf = b.ex_bf; a.Wpr_bf = b.pr_bf; a.Wex_bfb = b.ex_bfb;
     a.Wex = (const f32x4*)b.ex.w; a.ex_bias = b.ex.bias; a.ex_nt_total = b.ex.nt_total;
     a.Wdw = b.dw.w; a.dw_bias = b.dw.bias;
     a.Wpr = (const f32x4*)b.pr.w; a.pr_bias = b.pr.bias; a.pr_nt_total = b.pr.nt_total;

@@ -1304,14 +1304,19 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // f32 pack [kq][nt][lane][4 t] (logical channel 2 t + half of group kq) -> [s][nt][hi | lo][lane][8]: element e of lane (half, j)
 // is physical slot e of group 2 s + half = logical channel lop(e): e < 4 -> (t = e, half' = 0), else (t = e - 4, half' = 1)
-__global__ __launch_bounds__(256) void k_repack_bf16x3(const f32x4* __restrict__ W, int kq_total, int nt_total, bf16x8* __restrict__ out) {
+// bias (optional; an odd number of channel groups only): the spare k slot cin of the last step -- element 0 of its upper half -- takes the layer's
+// folded bias, so that a kernel that feeds a constant 1 there gets bias + sum from accumulators that start at ZERO (an inline constant: no
+// registers, no moves; k_block_fused8's split-bf16 form of the 24-channel layers)
+__global__ __launch_bounds__(256) void k_repack_bf16x3(const f32x4* __restrict__ W, int kq_total, int nt_total, bf16x8* __restrict__ out, const float* __restrict__ bias) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const int steps = (kq_total + 1) / 2;                          // (an odd number of channel groups: the last step's upper half is zeros)
     if (idx >= (long long)steps * nt_total * 64) return;
     const int lane = (int)(idx & 63), nt = (int)((idx >> 6) % nt_total), s = (int)((idx >> 6) / nt_total);
     const int half = lane >> 5, j = lane & 31, kq = 2 * s + half;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 w0 = kq < kq_total ? W[((size_t)kq * nt_total + nt) * 64 + j] : z4, w1 = kq < kq_total ? W[((size_t)kq * nt_total + nt) * 64 + 32 + j] : z4;
+    f32x4 w0 = kq < kq_total ? W[((size_t)kq * nt_total + nt) * 64 + j] : z4;
+    const f32x4 w1 = kq < kq_total ? W[((size_t)kq * nt_total + nt) * 64 + 32 + j] : z4;
+    if (bias && kq == kq_total) w0[0] = bias[nt * 32 + j];
     bf16x8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -1323,21 +1328,42 @@ __global__ __launch_bounds__(256) void k_repack_bf16x3(const f32x4* __restrict__
     out[(((size_t)s * nt_total + nt) * 2 + 1) * 64 + lane] = lo;
 }
 
-hipError_t launch_repack_bf16x3(const ConvPack& cp, void* out, hipStream_t s) {
+hipError_t launch_repack_bf16x3(const ConvPack& cp, void* out, hipStream_t s, int with_bias) {
     const int kq_total = cp.taps * cp.cin / 8;
     if (cp.cin % 8 || (cp.taps != 1 && cp.cin % 16)) return hipErrorInvalidValue;
+    if (with_bias && (kq_total % 2 == 0 || cp.taps != 1)) return hipErrorInvalidValue;      // (no spare k slot)
     const long long n = (long long)((kq_total + 1) / 2) * cp.nt_total * 64;
-    hipLaunchKernelGGL(k_repack_bf16x3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const f32x4*)cp.w, kq_total, cp.nt_total, (bf16x8*)out);
+    hipLaunchKernelGGL(k_repack_bf16x3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const f32x4*)cp.w, kq_total, cp.nt_total, (bf16x8*)out,
+                       with_bias ? cp.bias : nullptr);
     return hipGetLastError();
 }
 size_t bf16x3_pack_bytes(const ConvPack& cp) { return (size_t)((cp.taps * cp.cin / 8 + 1) / 2) * cp.nt_total * 2 * 64 * 16; }
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// two values: hi = round to nearest even (one v_cvt_pk_bf16_f32 for the pair), lo = bf16(v - hi) (the difference is exact in fp32; the f32 of the hi
+// pieces is a shift / a mask of the packed word): 3 vector instructions per value
+__device__ __forceinline__ void split2(float x, float y, bf16x2& p, bf16x2& q) {
+    p[0] = (__bf16)x; p[1] = (__bf16)y;
+    const unsigned pu = __builtin_bit_cast(unsigned, p);
+    const float hx = __builtin_bit_cast(float, pu << 16), hy = __builtin_bit_cast(float, pu & 0xffff0000u);
+    q[0] = (__bf16)(x - hx); q[1] = (__bf16)(y - hy);
+}
 __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, bf16x8& hi, bf16x8& lo) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float v = e < 4 ? v0[e] : v1[e - 4];
-        hi[e] = (__bf16)v;                                     // (v_cvt_pk_bf16_f32: round to nearest even)
-        lo[e] = (__bf16)(v - (float)hi[e]);                    // (the difference is exact in fp32)
+    for (int j = 0; j < 4; ++j) {
+        bf16x2 p, q;
+        split2(j < 2 ? v0[2 * j] : v1[2 * j - 4], j < 2 ? v0[2 * j + 1] : v1[2 * j - 3], p, q);
+        hi[2 * j] = p[0]; hi[2 * j + 1] = p[1];
+        lo[2 * j] = q[0]; lo[2 * j + 1] = q[1];
+    }
+}
+__device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        bf16x2 p, q;
+        split2(v[2 * j], v[2 * j + 1], p, q);
+        hi[2 * j] = p[0]; hi[2 * j + 1] = p[1];
+        lo[2 * j] = q[0]; lo[2 * j + 1] = q[1];
     }
 }
 
@@ -1611,12 +1637,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_rows_bf16x3(ConvArgs a, const b
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             bf16x4 hi, lo;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float v = areg[k][c];                      // (zeros where the tap lies outside the image / the row does not exist)
-                hi[c] = (__bf16)v;
-                lo[c] = (__bf16)(v - (float)hi[c]);
-            }
+            split4(areg[k], hi, lo);                             // (zeros where the tap lies outside the image / the row does not exist)
             unsigned char* dst = As[buf] + ((tid >> 2) + 64 * k) * REC + (tid & 3) * 8;
             *(bf16x4*)dst = hi;
             *(bf16x4*)(dst + 32) = lo;
@@ -1982,12 +2003,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dense_bf16x3(ConvArgs a, con
                 const int e = tid + 256 * k;
                 const bool ok = (okbits >> k) & 1u;
                 bf16x4 hi, lo;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float v = ok ? areg[k][c] : 0.0f;
-                    hi[c] = (__bf16)v;
-                    lo[c] = (__bf16)(v - (float)hi[c]);
-                }
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                split4(ok ? areg[k] : z4, hi, lo);
                 unsigned char* dst = As + (e >> 2) * REC + (e & 3) * 8;
                 *(bf16x4*)dst = hi;
                 *(bf16x4*)(dst + 32) = lo;

@@ -296,6 +296,13 @@ int DeviceWeights::build(const WeightFile& wf) {
         HF_TRY(split(det1, &det1_bf)); HF_TRY(split(det2, &det2_bf));
         for (int i = 1; i < 17; ++i) {                              // layers 3-18 (3-7: scores_bf16x3, 8-18: global_bf16x3)
             if (blocks[i].has_expand) HF_TRY(split(blocks[i].ex, &blocks[i].ex_bf));
+            if (blocks[i].has_expand && blocks[i].ex_bf && (blocks[i].ex.cin / 8) % 2 == 1) {
+                void* p = nullptr;
+                HF_HIP(dev_malloc(&p, bf16x3_pack_bytes(blocks[i].ex)));
+                allocations.push_back(p);
+                HF_HIP(launch_repack_bf16x3(blocks[i].ex, p, nullptr, 1));
+                blocks[i].ex_bfb = p;
+            }
             HF_TRY(split(blocks[i].pr, &blocks[i].pr_bf));
         }
         HF_HIP(hipStreamSynchronize(nullptr));
