@@ -307,11 +307,20 @@ static int run_block(Net& n, int L, int n_used, hipStream_t st) {   // layer L =
     const BlockPack& b = e->w.blocks[L - 2];
     const long long p_in = n.pix[L - 1][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
     const long long p_out = n.pix[L][n_used == 1 ? 1 : HFNET_MAX_LEVELS];
-    const bool fuse = block_runs_fused(n, L);
+    bool fuse = block_runs_fused(n, L);
+    // blocks that only have a split-bf16 fused form (layers 16, 17: 120 -> 720 -> 120): with the option on and a launch that fills the chip they take
+    // it instead of three launches (the 720-channel expanded tensor then never reaches HBM)
+    bool bf_only = false;
+    if (!fuse && n.global_bf16x3 && n.fuse_blocks && L > 14 && block_fused_bf16x3_supported(b)) {
+        const LevelPlan& p0 = n.lp[0];
+        const long long wgs = (long long)((p0.w[L] + 15) / 16) * ((p0.h[L] + 7) / 8) * n.cfg.batch;
+        bf_only = wgs >= std::max(n.fuse_min_wgs, 1);            // (calls of <= tail_fuse frames never get here: Net::tail_chain)
+        fuse = bf_only;
+    }
     if (fuse) {
         // option global_bf16x3 (layers past the index-deciding part of the network only): the block's 1x1 convolutions on split-bf16 operands
         // option scores_bf16x3: the same for layers 3-7 -- the score map then moves within its stated tolerance, and NMS / top-K are exact ON IT
-        const bool bfb = ((n.global_bf16x3 && L > 7) || (n.scores_bf16x3 && L <= 7)) && block_fused_bf16x3_supported(b);
+        const bool bfb = bf_only || (((n.global_bf16x3 && L > 7) || (n.scores_bf16x3 && L <= 7)) && block_fused_bf16x3_supported(b));
         if (L > 7) n.branch_fused_used = true;
         char fn[32];
         snprintf(fn, sizeof fn, bfb ? "block_L%02d_bf16x3" : "block_L%02d", L);

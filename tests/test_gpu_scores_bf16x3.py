@@ -128,7 +128,7 @@ def test_scores_bf16x3_ragged_pyramids(engine, oracle_model, engine_options, fus
     from oracle import oracle as O
     engine_options({o: 1 for o in ALL_OPTS})
     if fuse_min_wgs is not None:
-        engine_options({"fuse_min_wgs": fuse_min_wgs})
+        engine_options({"fuse_min_wgs": fuse_min_wgs, "tail_fuse": 0})      # (tail_fuse 0: layers 8-18 as blocks, not the single-frame chain)
     for (w, h, nl, nf) in [(200, 152, 4, 500), (131, 121, 2, 150), (248, 168, 3, 300), (376, 240, 2, 400), (1024, 96, 2, 300)]:
         B = 3
         imgs = np.stack([synth_image(h, w, 6500 + i, "natural" if i != 1 else "uniform") for i in range(B)])
