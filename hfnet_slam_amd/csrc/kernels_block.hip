@@ -1807,7 +1807,7 @@ bool block_fused_bf16x3_supported(const BlockPack& b) {
            ((st == 1 && kq == 6 && (nto == 2 || nto == 3)) || (st == 1 && kq == 9 && nto == 3) ||      // layers 7, 9-14
             (st == 2 && (kq == 2 || kq == 3) && nto == 1) || (st == 1 && kq == 3 && nto <= 2) ||        // layers 3, 5 / 4, 6 (scores_bf16x3)
             (st == 2 && kq == 12 && nto == 2) ||                                                         // layer 8: one wave per SIMD, like its f32 form
-            (st == 1 && kq == 15 && nto == 4));                                                          // layers 16, 17 (no f32 fused form: split-bf16 only)
+            (st == 1 && kq == 15 && (nto == 4 || nto == 8)) || (st == 2 && kq == 9 && nto == 4));       // layers 16, 17 / 18 / 15 (no f32 fused form: split-bf16 only)
 }
 
 hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, const Geom& g, int variant, hipStream_t s, int bf16x3) {
@@ -1837,6 +1837,8 @@ hipError_t launch_block_fused(const float* X, const BlockPack& b, float* out, co
         if (st == 1 && kq == 3 && nto == 2) return launch_block_fused8_t<1, 2, 3, 2, true>(a, g, s);
         if (st == 2 && kq == 12 && nto == 2) return launch_block_fused8_t<2, 2, 12, 1, true>(a, g, s);
         if (st == 1 && kq == 15 && nto == 4) return launch_block_fused8_t<1, 4, 15, 1, true>(a, g, s);
+        if (st == 1 && kq == 15 && nto == 8) return launch_block_fused8_t<1, 8, 15, 1, true>(a, g, s);
+        if (st == 2 && kq == 9 && nto == 4) return launch_block_fused8_t<2, 4, 9, 1, true>(a, g, s);
     }
     if (kind == FUSED_V4 && variant == 4 && small_launch && fused_kind(b, 2) == FUSED_V2) kind = FUSED_V2;
     // v6 (6 x 8 tiles on the 16x16x4 MFMA): what a launch of k_block_fused4's size runs for the stride-1 blocks from layer 6 on
