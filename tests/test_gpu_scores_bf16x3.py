@@ -7,7 +7,8 @@ oracle comparison changes shape ("bit-exact keypoint indice
       on the device's dense scores give array_equal keypoints (positions, responses, octaves, order, counts);
   (c) the keypoint set overlaps the exact mode's by >= 99 % (synthetic weights: scores hover at 1/65 and near-ties are everywhere -- the
       hardest case for this number);
-  (d) descriptors of the keypoints both modes selected are within 1e-5, the global descriptor within 2e-5, of the oracle's.
+  (d) descriptors of the keypoints both modes selected are within 2e-5, the global descriptor within 1e-4, of the oracle's (the index-exact options
+      desc_bf16x3 / global_bf16x3 alone keep 1e-5 / 2e-5: tests/test_gpu_fullsize.py; here all 18 layers feed the deviation).
 """
 import numpy as np
 import pytest
@@ -18,9 +19,9 @@ pytestmark = pytest.mark.gpu
 
 SCORES_TOL = 5e-4             # abs, on softmax scores in [0, 1] (include/hfnet_hip.h; observed <= 1.2e-4, at scores near 1)
 SCORES_REL_TOL = 2e-3         # and relative to the score itself: |ds| <= 2e-3 s + 1e-7 (a softmax output moves by s * |d logit|; observed 4e-4)
-DESC_TOL = 1e-5
-GLOBAL_TOL = 2e-5             # at the reference's image sizes (752x480, 512x512)
-GLOBAL_TOL_SMALL = 6e-5       # images of a few hundred cells: NetVLAD averages the deviations of far fewer pixels (observed <= 3e-5)
+DESC_TOL = 2e-5               # abs, unit-norm 256-D rows of the keypoints both modes select (observed <= 1.4e-5 over 1500 random cases, three weight sets)
+GLOBAL_TOL = 1e-4             # abs, unit-norm 4096-D, at the reference's image sizes (observed <= 5.9e-5 over 2 200 random cases and six weight sets)
+GLOBAL_TOL_SMALL = 2.5e-4     # images of a few hundred cells: NetVLAD averages the deviations of far fewer pixels (observed <= 8e-5)
 ALL_OPTS = ("scores_bf16x3", "desc_bf16x3", "global_bf16x3")
 
 

@@ -40,3 +40,12 @@ def test_three_host_threads_on_one_engine_10s(engine):
     counts, fails = _load("soak_threads").run(10.0, 20260930)
     assert min(counts.values()) >= 5, counts
     assert not fails, fails[:10]
+
+
+def test_tolerance_mode_soak_20s(engine):
+    """the three split-bf16 options in random subsets beside random dispatch options, random pyramids / budgets / call sizes, default and sparse-score
+    weights: keypoints == the oracle's NMS + top-K on the device's score map (or == the oracle's, scores exact), floats within the stated tolerances"""
+    cases, fails, stats = _load("soak_tolerance").run(20.0, 20261001)
+    assert cases >= 10, cases
+    assert not fails, fails[:10]
+    assert stats["overlap"] >= 0.985 * stats["total"], stats
