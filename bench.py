@@ -42,7 +42,7 @@ W_IMG, H_IMG, N_FEAT, N_LEVELS, SCALE, THRESH, TH_LOW, TH_HIGH = 752, 480, 1000,
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4)
 MFMA_BF16_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense bf16 MFMA (16 x the f32 rate); only the matcher's screening GEMM runs there
-TRAFFIC_FILES = [os.path.join("profiles", r + "_traffic_b{batch}.json") for r in ("r05", "r04", "r03", "r02")]     # newest first; one file per frames-per-call value
+TRAFFIC_FILES = [os.path.join("profiles", r + "_traffic_b{batch}.json") for r in ("r06", "r05", "r04", "r03", "r02")]     # newest first; one file per frames-per-call value
 ALL_CONFIGS = ["2-latency", "2-host-io", "2-bf16x3", "2-sparse", "3", "4", "5"]
 DEFAULT_CHUNK = 256            # frames per extract / match call of the headline (tests/test_gpu_fullsize.py checks THIS size against the oracle);
                                # measured 96 / 128 / 160 / 192 / 256 frames per call: 7012 / 7131 / 7124 / 7229 / 7245 frames/s on one box (NOTEBOOK.md R5.6);
@@ -732,7 +732,12 @@ def config_bf16x3(torch, capi, eng, dev, frames, B, chunks_per_step, steps, weig
                         break
                     except (OSError, KeyError, ValueError):
                         continue
+                gemms = [r for r in rows if r["name"].startswith(("conv3x3_", "pointwise_", "det_tail"))]
+                lg = max(gemms, key=lambda r: r["us"]) if gemms else None
                 res["roofline_bf16x3"] = {"bound": "mfma_bf16", "kernel": dom, "achieved": 3.0 * flop / sec / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "largest_gemm": ({"kernel": lg["name"], "us": lg["us"], "frac": lg["frac_bf16_roof_3_products"]} if lg else None),
+                                          "kernel_note": "the largest launch of the mode is a fused inverted-residual block: its 1x1 convolutions are on the bf16 matrix pipe, what bounds it is the "
+                                                         "depthwise / ReLU6 / operand-split work on the vector ALU (profiles/: VALU-busy 0.9); largest_gemm is the largest GEMM-shaped launch",
                                           "frac": 3.0 * flop / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": sec * 1e6,
                                           "timing": "HIP events on the kernel's stream over a timed region of this mode" if live else "single-stream profiling pass",
                                           "note": "achieved = 3 bf16 products per f32 product x the launch's algorithmic FLOP / its average duration",
@@ -1024,6 +1029,8 @@ def compact_line(out: dict) -> dict:
     rb = cf.get("2-bf16x3", {}).get("roofline_bf16x3")
     if rb:
         line["roofline_bf16x3"] = {k: r3(rb[k]) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "chunk_hbm_gbs", "chunk_hbm_frac") if k in rb}
+        if rb.get("largest_gemm"):
+            line["roofline_bf16x3"]["largest_gemm"] = {k: r3(v) for k, v in rb["largest_gemm"].items()}
         line["roofline_bf16x3"]["within_tolerance"] = cf["2-bf16x3"].get("verified", {}).get("within_tolerance")
 
     def take(name, cfg, *path):
