@@ -137,7 +137,7 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
     Engine& e = db->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
     e.bounce_discard();
-    const bool gemm = n_queries >= e.opt.db_gemm_min_queries && db->dim % 512 == 0;
+    const bool gemm = n_queries >= e.opt.db_gemm_min_queries && db_screen_supported(db->dim);
     if (!gemm && db->dim > 4096) { set_error("db: the exact batched scan supports dim <= 4096"); return HFNET_ERR_INVALID_ARG; }
     HF_HIP(hipSetDevice(e.device));
     const size_t Q = (size_t)n_queries, cap = (size_t)db->capacity;

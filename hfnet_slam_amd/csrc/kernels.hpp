@@ -225,6 +225,7 @@ hipError_t launch_db_scores_batch(const float* q, int n_queries, const float* db
 // norm / hi: |x|^2 in tree256 order and the bf16 copy of every row (launch_db_prep_hi: the database's when rows were added, the queries' per
 // call); best_partial: [n_queries][db_gemm_partials(n)]; scratch: db_gemm_scratch_floats(n, n_queries) floats
 int db_gemm_partials(int n);
+bool db_screen_supported(int dim);     // descriptor lengths the screened batched query takes (others: the exact batched scan)
 size_t db_gemm_scratch_floats(int n, int n_queries);
 hipError_t launch_db_prep_hi(const float* x, int n_rows, int dim, float* norm, void* hi, hipStream_t s);
 hipError_t launch_db_screen(const float* q, const void* qh, int n_queries, const float* qnorm, const float* db, const void* dbh, const float* dnorm,

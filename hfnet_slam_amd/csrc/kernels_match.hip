@@ -1256,8 +1256,8 @@ __global__ __launch_bounds__(256) void k_db_scores_batch(const float* __restrict
 //  within 5e-6 -- took 89 us for 64 queries against 10 000 keyframes; it is deleted.)
 // The database keeps a bf16 copy of its rows for this (2 bytes per element, refreshed with the norms: k_db_prep_hi); the kernel below
 // is k_db_gemm's structure at half the bytes and a sixteenth of the matrix time: a workgroup owns 128 database rows x (NT * 32) queries
-// x one EIGHTH of the descriptor length, both operands staged through LDS in chunks of 64 k.
-#define DBG_PARTS 8
+// x one QUARTER (1 / DBG_PARTS) of the descriptor length, both operands staged through LDS in chunks of 64 k.
+#define DBG_PARTS 4        // (round 6: 8 -> 4 -- half the partial sums written and read back, 316 workgroups still cover the chip: screen 19.5 -> 18.3 us, decide 11.4 -> 10.5)
 typedef __bf16 dbh_t;
 // |x|^2 (tree256 order, as k_sumsq_rows) and the bf16 copy of n_rows vectors, one wave each
 __global__ __launch_bounds__(256) void k_db_prep_hi(const float* __restrict__ x, int n_rows, int dim, float* __restrict__ norm, dbh_t* __restrict__ hi) {
@@ -1302,6 +1302,8 @@ __global__ __launch_bounds__(256) void k_db_screen(const dbh_t* __restrict__ qh,
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
+    // (one chunk ahead.  A register ring of four chunks in flight was measured SLOWER, 22.8 against 18.3 us: the kernel is not waiting for its
+    //  own loads -- it streams the database's bf16 copy at 4.5 TB/s with one or two workgroups per CU)
     f32x4 sa[4], sb[NT];                                      // (16-byte pieces of bf16, moved as f32x4)
 #pragma unroll
     for (int j = 0; j < 4; ++j) sa[j] = *(gvec4_t)(sgpr_base(dbase, 0) + ag[j]);
@@ -1353,7 +1355,19 @@ __global__ __launch_bounds__(256) void k_db_screen(const dbh_t* __restrict__ qh,
 // exact score of one (query, slot): ||q - d|| in tree256 order, the chain of k_db_scores
 __device__ __forceinline__ float db_exact_u(const float* __restrict__ q, const float* __restrict__ d, int dim, int lane) {
     f32x4 p = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < dim; k0 += 256) {                    // per (lane, component): one chain, k ascending -- k_db_scores' order
+    // (eight steps' loads in flight: the handful of slots a batch re-scores decide how long k_db_decide runs -- one wave walking 32 KB with a memory
+    //  round trip per step was 8 of its 11 us; the chain per (lane, component) still runs k ascending)
+    int k0 = 0;
+    for (; k0 + 2048 <= dim; k0 += 2048) {
+        f32x4 dv[8], qv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dv[j] = *(const f32x4*)(d + k0 + j * 256 + lane * 4); qv[j] = *(const f32x4*)(q + k0 + j * 256 + lane * 4); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float df = qv[j][c] - dv[j][c]; p[c] = fmaf(df, df, p[c]); }
+    }
+    for (; k0 < dim; k0 += 256) {                              // per (lane, component): one chain, k ascending -- k_db_scores' order
         const f32x4 dv = *(const f32x4*)(d + k0 + lane * 4), qv = *(const f32x4*)(q + k0 + lane * 4);
 #pragma unroll
         for (int c = 0; c < 4; ++c) { const float df = qv[c] - dv[c]; p[c] = fmaf(df, df, p[c]); }
@@ -1361,7 +1375,7 @@ __device__ __forceinline__ float db_exact_u(const float* __restrict__ q, const f
     return 1 - sqrtf(tree256_wave4(p));
 }
 
-// partial sums of the eight parts -> d2~; decide; re-score what has to be; scores (clamped at 0, -1 for empty slots) and the per-wave
+// partial sums of the DBG_PARTS parts -> d2~; decide; re-score what has to be; scores (clamped at 0, -1 for empty slots) and the per-wave
 // maxima k_db_filter reduces.  One workgroup = 256 slots of one query.
 __global__ __launch_bounds__(256) void k_db_decide(const float* __restrict__ partial, int qb, int q0, const float* __restrict__ q, const float* __restrict__ db,
                                                    const float* __restrict__ qnorm, const float* __restrict__ dnorm, const unsigned char* __restrict__ occupied,
@@ -1411,6 +1425,7 @@ hipError_t launch_db_prep_hi(const float* x, int n_rows, int dim, float* norm, v
 }
 
 int db_gemm_partials(int n) { return 4 * ((n + 255) / 256); }
+bool db_screen_supported(int dim) { return dim > 0 && dim % (DBG_PARTS * 64) == 0; }     // DBG_PARTS parts of whole 64-k chunks
 size_t db_gemm_scratch_floats(int n, int n_queries) { return (size_t)DBG_PARTS * (size_t)std::min(128, (n_queries + 31) / 32 * 32) * (size_t)n; }
 
 // scores of n_queries queries against the n slots of the database (see above): q / db: f32 rows, qh / dbh: their bf16 copies, qnorm / dnorm:
@@ -1418,7 +1433,7 @@ size_t db_gemm_scratch_floats(int n, int n_queries) { return (size_t)DBG_PARTS *
 hipError_t launch_db_screen(const float* q, const void* qh, int n_queries, const float* qnorm, const float* db, const void* dbh, const float* dnorm,
                             const unsigned char* occupied, int n, int dim, float* scores, unsigned int* best_partial, float* scratch, hipStream_t s) {
     if (n <= 0 || n_queries <= 0) return hipSuccess;
-    if (dim % (DBG_PARTS * 64)) return hipErrorInvalidValue;
+    if (!db_screen_supported(dim)) return hipErrorInvalidValue;
     const dim3 grid((n + 127) / 128, DBG_PARTS);
     const int parts = db_gemm_partials(n);
     for (int q0 = 0; q0 < n_queries; q0 += 128) {
