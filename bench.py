@@ -608,7 +608,7 @@ def config_host_io(capi, eng, chunk, chunks_per_call=16, reps=3):
 
 
 TOLERANCE_OPTIONS = ("scores_bf16x3", "desc_bf16x3", "global_bf16x3")
-BF16X3_HBM_FILES = ["profiles/r06_traffic_bf16x3_b{batch}.json"]
+BF16X3_HBM_FILES = ["profiles/r06_chunk_traffic_bf16x3_b{batch}.json"]
 
 
 def _timed_steps(torch, pipe, eng, frames, chunks_per_step, steps):

@@ -16,7 +16,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python $GRAFT_REPO_ROOT/tools/make_traffic.py $(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) $CH $OUT/${TAG}_traffic_b${CH}.json > $OUT/traffic.log 2>&1
 cp $OUT/${TAG}_traffic_b${CH}.json $GRAFT_REPO_ROOT/profiles/
-bash $GRAFT_REPO_ROOT/tools/gpu_traffic_chunk.sh profiles/${TAG}_traffic_bf16x3_b${CH}.json "Tolerance mode: --opt scores_bf16x3=1 --opt desc_bf16x3=1 --opt global_bf16x3=1 --no-verify --no-natural." --opt scores_bf16x3=1 --opt desc_bf16x3=1 --opt global_bf16x3=1 > $OUT/traffic_bf16x3_pre.log 2>&1
+bash $GRAFT_REPO_ROOT/tools/gpu_traffic_chunk.sh profiles/${TAG}_chunk_traffic_bf16x3_b${CH}.json "Tolerance mode: --opt scores_bf16x3=1 --opt desc_bf16x3=1 --opt global_bf16x3=1 --no-verify --no-natural." --opt scores_bf16x3=1 --opt desc_bf16x3=1 --opt global_bf16x3=1 > $OUT/traffic_bf16x3_pre.log 2>&1
 cd $GRAFT_REPO_ROOT
 # stdout: the compact line the driver parses; the record in full (tables, notes, sub-records) goes to BENCH_DETAIL
 BENCH_DETAIL=$OUT/${TAG}_bench_detail.json timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
@@ -35,8 +35,8 @@ done
 # ---- the tolerance mode (engine options scores_bf16x3 + desc_bf16x3 + global_bf16x3): whole-call HBM bytes (bench.py's roofline_bf16x3 reads the file),
 #      kernel stats and the two SQ passes of the same command
 TOL="--opt scores_bf16x3=1 --opt desc_bf16x3=1 --opt global_bf16x3=1 --no-verify --no-natural"
-bash $GRAFT_REPO_ROOT/tools/gpu_traffic_chunk.sh gpurun_out/${TAG}_profiles/${TAG}_traffic_bf16x3_b${CH}.json "Tolerance mode: $TOL." $TOL > $OUT/traffic_bf16x3.log 2>&1
-bash $GRAFT_REPO_ROOT/tools/gpu_traffic_chunk.sh gpurun_out/${TAG}_profiles/${TAG}_traffic_chunk_b${CH}.json "Exact mode (defaults)." > $OUT/traffic_chunk.log 2>&1
+bash $GRAFT_REPO_ROOT/tools/gpu_traffic_chunk.sh gpurun_out/${TAG}_profiles/${TAG}_chunk_traffic_bf16x3_b${CH}.json "Tolerance mode: $TOL." $TOL > $OUT/traffic_bf16x3.log 2>&1
+bash $GRAFT_REPO_ROOT/tools/gpu_traffic_chunk.sh gpurun_out/${TAG}_profiles/${TAG}_chunk_traffic_b${CH}.json "Exact mode (defaults)." > $OUT/traffic_chunk.log 2>&1
 cd /tmp
 rm -rf /tmp/ktt && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktt -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --configs none --no-cpu-baseline $TOL > $OUT/ktt.log 2>&1
 cp $(find /tmp/ktt -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_bench_bf16x3_kernel_stats.csv
