@@ -35,6 +35,16 @@
 namespace ORB_SLAM3
 {
 
+// Tolerance mode of the HIP back end (include/hfnet_hip.h: engine options scores_bf16x3 / desc_bf16x3 / global_bf16x3 -- the network on the bf16
+// matrix pipe with split operands, 1.7 x the frames/s; NMS / top-K exact on the score map the device produced, float outputs within the stated
+// tolerances).  Off by default (the exact f32 chains); call before InitAllModels, i.e. before the engine exists -- the options are read when
+// models are created.  The reference's own fast back end runs the whole network in FP16 (HFNetRTModel.cc:231).
+inline bool& HIPToleranceMode(void)
+{
+    static bool bTolerance = false;
+    return bTolerance;
+}
+
 // one engine (weights resident on one GPU) per process, shared by all level models like gvpModels shares the TensorRT runtime
 inline hfnet_engine* GetHIPEngine(const std::string &strModelDir = std::string(), int device = 0)
 {
@@ -48,6 +58,12 @@ inline hfnet_engine* GetHIPEngine(const std::string &strModelDir = std::string()
         {
             std::cerr << "Failed to load HFNet HIP model " << path << ": " << hfnet_last_error() << std::endl;
             engine = nullptr;
+        }
+        else if (HIPToleranceMode())
+        {
+            for (const char* name : {"scores_bf16x3", "desc_bf16x3", "global_bf16x3"})
+                if (hfnet_engine_set_option(engine, name, 1) != HFNET_OK)
+                    std::cerr << "HFNet HIP: option " << name << ": " << hfnet_last_error() << std::endl;
         }
     }
     return engine;
