@@ -148,6 +148,7 @@ struct DeviceWeights {
     ConvPack16 memb16;            // the memberships conv as the "next 1x1" of layer 18's k_dwproject
     float* clusters = nullptr;    // [K][D] logical
     FcPack fc;                    // dimensionality reduction 7680 -> 4096
+    void* fc_bf = nullptr;        // its weights as split-bf16 pieces in the activations' memory order (launch_repack_fc_bf16x3; engine option global_bf16x3)
     std::vector<void*> allocations;
     int build(const WeightFile& wf);
     void release();

@@ -555,7 +555,10 @@ int Net::forward_global(hipStream_t st, int first, int count, int* total) {
     if (!tail) HF_GSTEP(HF_LAUNCH(e, st, "softmax_memberships", launch_softmax_rows(memb, (long long)cfg.batch * P, w.n_clusters, w.n_clusters, st)));
     HF_GSTEP(HF_LAUNCH(e, st, "vlad", launch_vlad_aggregate(act[18], memb, w.clusters, vlad_raw, cfg.batch, P, w.c_global, w.n_clusters, st));
              HF_LAUNCH(e, st, "vlad_norm", launch_vlad_norm(vlad_raw, vlad_tap, vlad_out, cfg.batch, w.c_global, w.n_clusters, st)));
-    HF_GSTEP(HF_LAUNCH(e, st, "fc_l2", launch_fc_l2(vlad_out, w.fc, fc_part, fc_raw, global_dst ? global_dst : global_out, cfg.batch, st, global_host, e->opt.fc_tile)));
+    if (global_bf16x3 && w.fc_bf && cfg.batch >= 64 && !global_host.out)
+        HF_GSTEP(HF_LAUNCH(e, st, "fc_l2_bf16x3", launch_fc_l2_bf16x3(vlad_out, w.fc, w.fc_bf, fc_part, fc_raw, global_dst ? global_dst : global_out, cfg.batch, st)));
+    else
+        HF_GSTEP(HF_LAUNCH(e, st, "fc_l2", launch_fc_l2(vlad_out, w.fc, fc_part, fc_raw, global_dst ? global_dst : global_out, cfg.batch, st, global_host, e->opt.fc_tile)));
 #undef HF_GSTEP
     if (total) *total = step;
     return HFNET_OK;

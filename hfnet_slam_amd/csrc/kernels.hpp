@@ -154,6 +154,14 @@ hipError_t launch_vlad_norm(const float* scratch, float* vlad_tap /*optional*/, 
 // cross HBM once, 4096 workgroups stream them) + L2 normalise (layers.py:98-108).  x: [frames][n_in] in the FC slot order
 // (fc_slot_of_logical), pack: FcPack of weights.cpp; partial: fc_scratch_floats() floats
 size_t fc_scratch_floats(const FcPack& fc, int frames);
+// the FC on split-bf16 operands (engine option global_bf16x3, calls of many frames): FC_BF_PARTS partial GEMMs over contiguous input ranges
+// (k_conv_rows_bf16x3 with K split over the grid's z) + a sum with the bias + the L2 normalisation; Wb: launch_repack_fc_bf16x3 of the FcPack
+#define FC_BF_PARTS 8
+size_t fc_bf16x3_pack_bytes(const FcPack& fc);
+bool fc_bf16x3_supported(const FcPack& fc);
+hipError_t launch_repack_fc_bf16x3(const FcPack& fc, void* out, hipStream_t s);
+hipError_t launch_fc_partials_bf16x3(const float* x, const FcPack& fc, const void* Wb, float* partial, int frames, hipStream_t s);
+hipError_t launch_fc_l2_bf16x3(const float* x, const FcPack& fc, const void* Wb, float* partial, float* y_raw, float* out, int frames, hipStream_t s);
 // optional second destination of the global descriptors in host-visible (pinned) memory: `out` rows, then the call number
 // (seq[0], kept on the device; seq[1] counts the workgroups that are done) into `flag`; calls of up to four frames only
 struct FcHostOut { float* out = nullptr; int* flag = nullptr; int* seq = nullptr; };

@@ -1588,10 +1588,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_rows_bf16x3(ConvArgs a, const b
     if (p0 >= nrows) return;                                     // (workgroup-uniform)
     if (!GATHER && !tile_in_use(a, p0, ROWS)) return;            // (slotted rows: the whole tile lies in the unused part of a slot)
     const int nt0 = grp * NTW;
-    const int spt = a.cin >> 4, n_steps = (GATHER ? 9 : 1) * spt;
+    int spt = a.cin >> 4;
+    // plain rows, gridDim.z > 1 (the dimensionality-reduction FC: few rows, a long K): part z takes the 16-k steps [z, z + 1) spt / parts and writes
+    // its sums (no bias: a.bias is null) to slab z of the output, [parts][P][n]; the caller adds the slabs
+    long long part_out = 0;
+    unsigned part_shift = 0;
+    if (!GATHER && gridDim.z > 1) {
+        const int spp = spt / (int)gridDim.z;                    // (launcher: divisible, even)
+        part_shift = (unsigned)(blockIdx.z * spp) * 64u;          // bytes into a row
+        Wb += (size_t)blockIdx.z * spp * a.nt_total * 2 * 64;
+        part_out = (long long)blockIdx.z * a.P * a.n;
+        spt = spp;
+    }
+    const int n_steps = (GATHER ? 9 : 1) * spt;
     unsigned store_tiles = 3u;                                   // which of this wave's two 32-row tiles are stored (slotted rows: decided here, not in the epilogue)
     if (!GATHER) store_tiles = (tile_in_use(a, p0 + rh * 64, 32) ? 1u : 0u) | (tile_in_use(a, p0 + rh * 64 + 32, 32) ? 2u : 0u);
-    const char* __restrict__ xb = (const char*)(a.A + in_base * a.cin);      // uniform (plain rows: in_base = 0); lane offsets are 32-bit
+    const char* __restrict__ xb = (const char*)(a.A + in_base * a.cin) + part_shift;      // uniform (plain rows: in_base = 0); lane offsets are 32-bit
     // ---- staging role: this thread's two rows (tid >> 2 and + 64), piece tid & 3 (16 bytes = 4 channels of the k-step's 16).
     // Buffer loads: the per-lane part of the address -- the row's centre cell + the piece, or an offset past the resource's range where the tap lies
     // outside the image / the row does not exist (the load then returns zeros without touching memory) -- is computed ONCE per tap here and stays in
@@ -1599,7 +1611,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_rows_bf16x3(ConvArgs a, const b
     // compiler guards a recycled load-destination register with a vmcnt wait, and such a wait would also wait for the weight requests it cannot see.
     constexpr int NTAP = GATHER ? 9 : 1;
     constexpr unsigned kOutOfRange = 0xffffff00u;
-    const unsigned img_bytes = GATHER ? (unsigned)Hc * (unsigned)Wc * (unsigned)a.cin * 4u : (unsigned)nrows * (unsigned)a.cin * 4u;
+    const unsigned img_bytes = (GATHER ? (unsigned)Hc * (unsigned)Wc * (unsigned)a.cin * 4u : (unsigned)nrows * (unsigned)a.cin * 4u) - part_shift;
     unsigned coff[2], okbits[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -1658,7 +1670,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_rows_bf16x3(ConvArgs a, const b
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const float b = a.bias[(nt0 + cg * NT + nt) * 32 + r];
+        const float b = a.bias ? a.bias[(nt0 + cg * NT + nt) * 32 + r] : 0.0f;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1752,7 +1764,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_rows_bf16x3(ConvArgs a, const b
         for (int nt = 0; nt < NT; ++nt) {
             const int col = (nt0 + cg * NT + nt) * 32 + r;
             if (col < a.n) {
-                float* __restrict__ op = a.out + (out_base + row0) * n + col;
+                float* __restrict__ op = a.out + part_out + (out_base + row0) * n + col;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int rr = (reg & 3) + 8 * (reg >> 2);
@@ -1763,6 +1775,48 @@ __global__ __launch_bounds__(256, 2) void k_conv_rows_bf16x3(ConvArgs a, const b
     }
 }
 static bool conv_rows_bf16x3_supported(const ConvPack& cp) { return cp.cin % 32 == 0 && cp.nt_total % 8 == 0 && cp.nt_total * 32 == ((cp.n + 255) / 256) * 256; }
+
+// ---- the dimensionality-reduction FC (layers.py:98-107; engine option global_bf16x3) as k_conv_rows_bf16x3<false> with K split over blockIdx.z.
+// Its activations are stored in the f32 FC kernel's slot order (fc_slot_of_logical: slot 4 g + t of a group of 16 holds logical input 4 t + g) and its
+// weights as FcPack [k / 16][n / 16][64 lanes][4]; this makes the split-bf16 pieces in the ROWS' memory order, so the activations need no
+// permutation: piece (s, nt, hi | lo, lane (half, j)) element e = W[logical input of memory position 16 s + 8 half + e][column 32 nt + j].
+__global__ __launch_bounds__(256) void k_repack_fc_bf16x3(const float* __restrict__ w, int n_in, int n_out, bf16x8* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int steps = n_in >> 4, nts = n_out >> 5, ctiles = n_out >> 4;
+    if (idx >= (long long)steps * nts * 64) return;
+    const int lane = (int)(idx & 63), nt = (int)((idx >> 6) % nts), s = (int)((idx >> 6) / nts);
+    const int half = lane >> 5, j = lane & 31, col = nt * 32 + j, ct = col >> 4, c16 = col & 15;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int m = 8 * half + e, g = m >> 2, t = m & 3;      // memory slot m of the group = logical input 4 t + g: FcPack lane 16 g + column, element t
+        const float v = w[((((size_t)s * ctiles + ct) * 64) + 16 * g + c16) * 4 + t];
+        hi[e] = (__bf16)v;
+        lo[e] = (__bf16)(v - (float)hi[e]);
+    }
+    out[(((size_t)s * nts + nt) * 2 + 0) * 64 + lane] = hi;
+    out[(((size_t)s * nts + nt) * 2 + 1) * 64 + lane] = lo;
+}
+size_t fc_bf16x3_pack_bytes(const FcPack& fc) { return (size_t)(fc.n_in / 16) * (fc.n_out / 32) * 2 * 64 * 16; }
+bool fc_bf16x3_supported(const FcPack& fc) { return fc.n_in % (16 * 2 * FC_BF_PARTS) == 0 && fc.n_out % 256 == 0; }
+hipError_t launch_repack_fc_bf16x3(const FcPack& fc, void* out, hipStream_t s) {
+    if (!fc_bf16x3_supported(fc)) return hipErrorInvalidValue;
+    const long long n = (long long)(fc.n_in / 16) * (fc.n_out / 32) * 64;
+    hipLaunchKernelGGL(k_repack_fc_bf16x3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fc.w, fc.n_in, fc.n_out, (bf16x8*)out);
+    return hipGetLastError();
+}
+// partial[part][frames][n_out] = x[frames][k range of the part] * W (no bias); FC_BF_PARTS parts
+hipError_t launch_fc_partials_bf16x3(const float* x, const FcPack& fc, const void* Wb, float* partial, int frames, hipStream_t s) {
+    if (!Wb || !fc_bf16x3_supported(fc) || frames <= 0 || (long long)frames * fc.n_in * 4 > 0xffffffffll) return hipErrorInvalidValue;
+    ConvArgs a;
+    a.A = x; a.W = nullptr; a.bias = nullptr; a.res = nullptr; a.out = partial; a.P = frames; a.cin = fc.n_in; a.n = fc.n_out; a.nt_total = fc.n_out / 32; a.relu6 = 0;
+    for (int l = 0; l < HFNET_MAX_LEVELS; ++l) a.level_tiles[l] = 1;
+    a.slot_units = nullptr; a.slot_rows = 0; a.rows_per_unit = 0;
+    const Geom g0 = {};
+    const TapArgs none = {nullptr, nullptr, 0, nullptr, nullptr};
+    hipLaunchKernelGGL((k_conv_rows_bf16x3<false>), dim3((unsigned)((frames + 127) / 128), a.nt_total / 8, FC_BF_PARTS), dim3(256), 0, s, a, (const bf16x8*)Wb, g0, none);
+    return hipGetLastError();
+}
 
 // 3 x 3 convolution at the distinct tap cells (GATHER) / 1 x 1 convolution on rows, both on split bf16 operands.
 // Wb: launch_repack_bf16x3 of `cp`.  Shapes: cin % 16 == 0, nt_total % 4 == 0.

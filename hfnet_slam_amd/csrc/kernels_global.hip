@@ -535,4 +535,20 @@ hipError_t launch_fc_l2(const float* x, const FcPack& fc, float* partial, float*
     return hipGetLastError();
 }
 
+// ---- the FC on split-bf16 operands: partial GEMMs (kernels_conv.hip) -> slabs summed in part order + bias -> L2 normalisation
+__global__ __launch_bounds__(256) void k_fc_combine_parts(const float* __restrict__ partial, int parts, const float* __restrict__ bias, float* __restrict__ y_raw, int frames, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (i >= n) return;
+    float v = bias[i];
+    for (int q = 0; q < parts; ++q) v += partial[((long long)q * frames + f) * n + i];
+    y_raw[(long long)f * n + i] = v;
+}
+hipError_t launch_fc_l2_bf16x3(const float* x, const FcPack& fc, const void* Wb, float* partial, float* y_raw, float* out, int frames, hipStream_t s) {
+    const hipError_t e = launch_fc_partials_bf16x3(x, fc, Wb, partial, frames, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fc_combine_parts, dim3((fc.n_out + 255) / 256, frames), dim3(256), 0, s, partial, FC_BF_PARTS, fc.bias, y_raw, frames, fc.n_out);
+    hipLaunchKernelGGL(k_l2norm_vec, dim3(frames), dim3(256), 0, s, y_raw, out, fc.n_out);
+    return hipGetLastError();
+}
+
 }  // namespace hfnet

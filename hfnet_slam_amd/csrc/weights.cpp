@@ -338,6 +338,12 @@ int DeviceWeights::build(const WeightFile& wf) {
         HF_TRY(upload(*this, t, &fc.w));
         std::vector<float> b(fb->data, fb->data + G);
         HF_TRY(upload(*this, b, &fc.bias));
+        if (fc_bf16x3_supported(fc)) {
+            HF_HIP(dev_malloc(&fc_bf, fc_bf16x3_pack_bytes(fc)));
+            allocations.push_back(fc_bf);
+            HF_HIP(launch_repack_fc_bf16x3(fc, fc_bf, nullptr));
+            HF_HIP(hipStreamSynchronize(nullptr));
+        }
     }
     return HFNET_OK;
 }

@@ -164,3 +164,28 @@ def test_scores_bf16x3_ragged_pyramids(engine, oracle_model, engine_options, fus
         na, ka, da, ga, _ = x.extract(imgs[1])
         assert na == n1[1] and np.array_equal(ka, k1[1, :na])
         x.close()
+
+
+def test_global_bf16x3_fc_many_frames(engine, oracle_model, engine_options):
+    """calls of >= 64 frames with global_bf16x3 run the dimensionality-reduction FC as partial split-bf16 GEMMs over input ranges (kernels_conv.hip
+    launch_fc_partials_bf16x3) + a sum with the bias + the L2 normalisation: global descriptors within the stated tolerance of the oracle's, unit norm,
+    and within 5e-6 of the same frames in a call below the threshold (the f32 FC on the same split-bf16 activations: the FC's own deviation);
+    65 and 130 frames leave a partial 128-row tile"""
+    from hfnet_slam_amd import capi
+    engine_options({o: 1 for o in ALL_OPTS})
+    for (w, h, B) in [(200, 152, 65), (131, 121, 130)]:
+        imgs = np.stack([synth_image(h, w, 7100 + i, "natural" if i % 3 else "uniform") for i in range(B)])
+        x = capi.Extractor(engine, w, h, 200, 0.01, 1.2, 2, max_batch=B)
+        n1, k1, d1, g1 = x.extract_batch(imgs)
+        assert np.allclose(np.linalg.norm(g1.astype(np.float64), axis=1), 1.0, atol=2e-6)
+        picks = [0, 1, 63, 64, B - 1]
+        small = x.extract_batch(imgs[picks])[3]
+        fc_dev = float(np.abs(g1[picks].astype(np.float64) - small).max())
+        worst = 0.0
+        for f in picks:
+            rn, rk, rd, rg, _ = oracle_model.extract(imgs[f], 200, 0.01, 2, 1.2)
+            worst = max(worst, float(np.abs(g1[f].astype(np.float64) - rg).max()))
+        print(f"\nFC on split bf16 {w}x{h} x{B}: max |dglobal| {worst:.3e}, FC alone {fc_dev:.3e}")
+        assert 0 < fc_dev <= 5e-6, fc_dev
+        assert worst <= GLOBAL_TOL_SMALL, worst
+        x.close()
