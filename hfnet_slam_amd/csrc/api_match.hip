@@ -123,7 +123,7 @@ int hfnet_match_search_by_bow(hfnet_engine* eh, const float* query, int n_query,
     P.match = d_match; P.dist = d_dist; P.cnt = d_cnt; P.nq = n_query; P.nt = n_train;
     HF_TRY(e.h2d(e.m_pairs.p, &P, sizeof P));
     HF_TRY(e.sync_host());     // P lives on this stack frame
-    HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), 1, max_rows, dim, th_low, e.m_s.p, e.stream, e.opt.match_screen_bf16));
+    HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), 1, max_rows, dim, th_low, e.m_s.p, e.stream, e.opt.match_screen_bf16, e.opt.match_stats ? e.bow_stat() : nullptr));
     if (!on_device) {
         HF_TRY(e.d2h(match_q2t, d_match, sizeof(int32_t) * n_query));
         HF_TRY(e.d2h(dist, d_dist, sizeof(float) * n_query));
@@ -182,7 +182,7 @@ static int match_pairs_batch(hfnet_engine* eh, int n_pairs, const float* desc_ba
         HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, threshold, e.stream, split, stat));
         HF_TRY(tri_screen_end(e, stat));
     } else {
-        HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, th, e.m_s.p, e.stream, e.opt.match_screen_bf16));
+        HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, max_rows, dim, th, e.m_s.p, e.stream, e.opt.match_screen_bf16, e.opt.match_stats ? e.bow_stat() : nullptr));
     }
     if (!on_device) {
         HF_TRY(e.d2h(match_q2t, d_match, sizeof(int32_t) * (size_t)n_pairs * max_rows));
@@ -382,7 +382,7 @@ static int match_store(hfnet_store* st, int n_pairs, const int32_t* set1, const 
         HF_LAUNCH(&e, e.stream, "match_tri", launch_tri_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, threshold, e.stream, split, stat));
         HF_TRY(tri_screen_end(e, stat));
     } else {
-        HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, th, e.m_s.p, e.stream, e.opt.match_screen_bf16));
+        HF_LAUNCH(&e, e.stream, "match_bow", launch_bow_pairs(e.m_pairs.as<BowPair>(), n_pairs, mr, st->dim, th, e.m_s.p, e.stream, e.opt.match_screen_bf16, e.opt.match_stats ? e.bow_stat() : nullptr));
     }
     if (nc)
         HF_LAUNCH(&e, e.stream, "store_remap",

@@ -22,7 +22,7 @@ int* Options::find(const char* name) {
     const struct { const char* n; int* p; } tab[] = {{"fuse_blocks", &fuse_blocks}, {"fuse_max_layer", &fuse_max_layer}, {"fused_variant", &fused_variant},
                                                        {"fuse_stem", &fuse_stem}, {"dense_desc", &dense_desc}, {"two_streams", &two_streams},
                                                        {"graph", &graph}, {"pinned_frames", &pinned_frames}, {"db_gemm_min_queries", &db_gemm_min_queries},
-                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}, {"resize_band", &resize_band}, {"fc_tile", &fc_tile}, {"interleave", &interleave}, {"host_global", &host_global}, {"det_fuse", &det_fuse}, {"match_screen_bf16", &match_screen_bf16}, {"tri_screen_bf16", &tri_screen_bf16}, {"desc_bf16x3", &desc_bf16x3}, {"global_bf16x3", &global_bf16x3}, {"scores_bf16x3", &scores_bf16x3}, {"join_fused_branch", &join_fused_branch}};
+                                                       {"conv_wlds", &conv_wlds}, {"fuse_min_wgs", &fuse_min_wgs}, {"copy_threads", &copy_threads}, {"tail_fuse", &tail_fuse}, {"dedupe_taps", &dedupe_taps}, {"pyramid_fuse", &pyramid_fuse}, {"resize_band", &resize_band}, {"fc_tile", &fc_tile}, {"interleave", &interleave}, {"host_global", &host_global}, {"det_fuse", &det_fuse}, {"match_screen_bf16", &match_screen_bf16}, {"tri_screen_bf16", &tri_screen_bf16}, {"desc_bf16x3", &desc_bf16x3}, {"global_bf16x3", &global_bf16x3}, {"scores_bf16x3", &scores_bf16x3}, {"join_fused_branch", &join_fused_branch}, {"match_stats", &match_stats}};
     for (const auto& t : tab) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -46,7 +46,7 @@ Engine::~Engine() {
     prof.flush();
     for (auto ev : prof.pool) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamSynchronize(stream);          // (the statistics copy of a screened SearchForTriangulation may still be in flight)
-    for (DevMem* m : {&m_a, &m_b, &m_s, &m_qn, &m_tn, &m_key, &m_i0, &m_i1, &m_f0, &m_f1, &m_cnt, &m_pairs, &m_tri_stat}) m->release();
+    for (DevMem* m : {&m_a, &m_b, &m_s, &m_qn, &m_tn, &m_key, &m_i0, &m_i1, &m_f0, &m_f1, &m_cnt, &m_pairs, &m_tri_stat, &m_bow_stat}) m->release();
     w.release();
     if (h_res) (void)hipHostFree(h_res);
     if (bounce.base) (void)hipHostFree(bounce.base);
@@ -92,6 +92,13 @@ int Engine::h2d(void* dst_dev, const void* src_host, size_t bytes) {
         HF_HIP(hipMemcpyAsync((unsigned char*)dst_dev + off, b, n, hipMemcpyHostToDevice, stream));
     }
     return HFNET_OK;
+}
+int* Engine::bow_stat() {
+    if (!m_bow_stat.p) {
+        if (m_bow_stat.ensure(sizeof(int)) != HFNET_OK) return nullptr;
+        if (hipMemsetAsync(m_bow_stat.p, 0, sizeof(int), stream) != hipSuccess) return nullptr;
+    }
+    return m_bow_stat.as<int>();
 }
 int Engine::d2h(void* dst_host, const void* src_dev, size_t bytes) {
     for (size_t off = 0; off < bytes; off += HostBounce::kPiece) {
@@ -783,6 +790,20 @@ int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value) try {
 int hfnet_engine_get_option(hfnet_engine* e, const char* name, int* value) try {
     API_GUARD(e, "engine"); API_GUARD(value, "value");
     std::lock_guard<std::mutex> lk(e->impl.mu);
+    if (name && std::strcmp(name, "stat_bow_exact") == 0) {
+        // read-only statistic: exact distance evaluations of the SearchByBoW calls since the last read (what the screening GEMM let through: a
+        // broken screen still returns the right matches -- everything is then evaluated exactly -- and this is where it shows); waits for the stream
+        Engine& en = e->impl;
+        HF_HIP(hipSetDevice(en.device));
+        int v = 0;
+        if (en.m_bow_stat.p) {
+            HF_TRY(en.d2h(&v, en.m_bow_stat.p, sizeof(int)));
+            HF_HIP(hipMemsetAsync(en.m_bow_stat.p, 0, sizeof(int), en.stream));
+            HF_TRY(en.sync_host());
+        }
+        *value = v;
+        return HFNET_OK;
+    }
     const int* p = e->impl.opt.find(name);
     if (!p) { set_error("unknown engine option '%s'", name ? name : "(null)"); return HFNET_ERR_INVALID_ARG; }
     *value = *p;

@@ -205,7 +205,8 @@ hipError_t launch_tri_pairs(const BowPair* pairs, int n_pairs, int max_rows, int
 // scratch: bow_scratch_bytes(n_pairs, max_rows, dim) bytes (candidate slots per train row and 64-query tile + the rows of every pair split
 // into bf16 pieces for the screening GEMM; no n x m matrix)
 size_t bow_scratch_bytes(int n_pairs, int max_rows, int dim);
-hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, void* scratch, hipStream_t s, int screen_bf16);
+// stat (may be null): += the number of exact distance evaluations (what the screen let through; engine read-only option stat_bow_exact)
+hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, void* scratch, hipStream_t s, int screen_bf16, int* stat = nullptr);
 hipError_t launch_descriptor_distance(const float* a, const float* b, int dim, float* out, hipStream_t s);
 // the candidate loop of the windowed matchers (Matcher.cc:74-110 and siblings): best / second best with levels per query
 hipError_t launch_match_candidates(const float* query, int nq, const float* train, const int* train_level, int dim, const int* cand_offsets,

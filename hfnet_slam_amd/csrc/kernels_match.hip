@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_tri_resolve(const BowPair* __restrict__
 // the rounding band, e.g. duplicates) are counted in a byte per half tile; k_bow_candidates then evaluates all 32 queries
 // of that half tile exactly -- if its smallest lower bound can compete at all.
 struct BowCand { unsigned int lo_bits; int q; };
-#define BOW_SLOTS 4
+#define BOW_SLOTS 2        // (round 6: 4 -> 2: half the slot traffic; more than two candidates in one half tile: the half tile is evaluated exactly)
 // SPLIT: the screening products on the bf16 matrix pipe.  S only pre-selects (every query inside the rounding band of a train
 // row's nearest is re-evaluated exactly), so it need not be the f32 chain: each f32 operand is split into two bf16 pieces
 // x = hi + lo + e, |e| <= 2^-18 |x| (both round-to-nearest-even), and q.t ~ qh.th + qh.tl + ql.th on v_mfma_f32_32x32x16_bf16 --
@@ -664,7 +664,7 @@ hipError_t launch_tri_pairs(const BowPair* pairs, int n_pairs, int max_rows, int
 // every train row: the candidates of all its query tiles -> exact OpenCV distances -> nearest query (first minimum in
 // query order: ties go to the smaller index) -> the per-query key, as k_bow_train_pass.  One wave per train row.
 __global__ __launch_bounds__(256) void k_bow_candidates(const BowPair* __restrict__ pairs, int dim, float band, const BowCand* __restrict__ cand,
-                                                        const unsigned char* __restrict__ overflow, int max_rows, int n_qt) {
+                                                        const unsigned char* __restrict__ overflow, int max_rows, int n_qt, int* __restrict__ stat) {
     const BowPair P = pairs[blockIdx.z];
     const float* __restrict__ q = P.q; const float* __restrict__ t = P.t;
     const int nq = P.nq, nt = P.nt;
@@ -676,7 +676,9 @@ __global__ __launch_bounds__(256) void k_bow_candidates(const BowPair* __restric
     const float tnj = P.tn[j];
     float bd = FLT_MAX;
     int bi = 0x7fffffff;
+    int evals = 0;                                            // (uniform) exact evaluations of this train row: the screen's efficiency (stat)
     auto exact = [&](int qi) {
+        ++evals;
         const float d = (dim == 256) ? cv_l2_wave256(trow, q + (long long)qi * dim, lane) : cv_l2_wave(trow, q + (long long)qi * dim, dim, lane);
         if (d < bd || (d == bd && qi < bi)) { bd = d; bi = qi; }
     };
@@ -723,6 +725,7 @@ __global__ __launch_bounds__(256) void k_bow_candidates(const BowPair* __restric
     }
     if (lane == 0 && bi != 0x7fffffff)
         atomicMin(&P.qkey[bi], ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned int)j);
+    if (stat && lane == 0 && evals) atomicAdd(stat, evals);
 }
 
 // dim == 256: the same selection with the exact distances evaluated in batches.  cv_l2_wave256 ends in a 64-step serial sum
@@ -734,7 +737,8 @@ __global__ __launch_bounds__(256) void k_bow_candidates(const BowPair* __restric
 #define BOWC_ROWS 8
 #define BOWC_EVALS 32
 __global__ __launch_bounds__(256) void k_bow_candidates256(const BowPair* __restrict__ pairs, float band, const BowCand* __restrict__ cand,
-                                                           const unsigned char* __restrict__ overflow, int max_rows, int n_qt, int rows_per_wave) {
+                                                           const unsigned char* __restrict__ overflow, int max_rows, int n_qt, int rows_per_wave,
+                                                           int* __restrict__ stat) {
     constexpr int dim = 256, GP = 65;
     __shared__ float gs_all[4][BOWC_EVALS * GP];
     __shared__ int meta_q_all[4][BOWC_EVALS], meta_r_all[4][BOWC_EVALS];
@@ -750,7 +754,9 @@ __global__ __launch_bounds__(256) void k_bow_candidates256(const BowPair* __rest
     unsigned long long* rowkey = rowkey_all[wave];
     if (lane < BOWC_ROWS) rowkey[lane] = ~0ull;
     int E = 0;                                                // pending evaluations (uniform)
+    int evals = 0;                                            // (uniform) exact evaluations of this wave's train rows: the screen's efficiency (stat)
     auto flush = [&]() {
+        evals += E;
         asm volatile("" ::: "memory");                        // (LDS operations of one wave execute in order)
         float s = 0.0f;
         const float* gp = gs + min(lane, BOWC_EVALS - 1) * GP;
@@ -820,6 +826,7 @@ __global__ __launch_bounds__(256) void k_bow_candidates256(const BowPair* __rest
         const unsigned long long k = rowkey[lane];
         if (k != ~0ull) atomicMin(&P.qkey[(unsigned int)k], (k & 0xffffffff00000000ull) | (unsigned int)(j0 + lane));
     }
+    if (stat && lane == 0 && evals) atomicAdd(stat, evals);
 }
 
 __global__ __launch_bounds__(256) void k_bow_finalize(const BowPair* __restrict__ pairs, float th_low) {
@@ -982,6 +989,271 @@ hipError_t launch_store_remap(int n_pairs, const int* qsel, const int* tsel, con
     return hipGetLastError();
 }
 
+// ---- SearchByBoW, launches of many pairs, dim == 256: the screening GEMM as a SWEEP (k_bow_sweep256).
+// k_bow_gemm_cand stages both operands of every 128 x 128 tile through LDS in 64-k chunks: per 16-k step a wave reads eight 1 KB fragments for
+// twelve MFMAs and the workgroup writes what it reads -- the LDS port is as busy as the matrix pipe (both ~100 % on paper; measured: the matrix
+// pipe 0.38 busy), the candidate epilogue (~10 vector instructions per product) runs on top, and two barriers frame every 48 MFMAs.
+// Here a wave keeps its 64 queries' fragments -- {hi, lo} x 16 k-steps x two 32-row tiles = 256 registers, the matrix-operand half of the register
+// file -- for the whole sweep over the train rows, so only the train side moves: 64 train rows x 16 k x {hi, lo} = 4 KB per step, brought
+// into a 128 KB LDS ring by LDS-DMA (one 1 KB piece per wave and step, requested six 4-step chunks ahead) and read by all four waves (four
+// fragment reads per twelve MFMAs: a third of the LDS port).  One barrier per 48 MFMAs.  Both sets are laid out in fragment order by
+// k_bow_prep_frag ([32-row tile][k-step][hi | lo][lane][8]: 1 KB pieces a wave loads / the DMA moves as they are).
+// The accumulators start at -|q|^2 / 2 (rows that do not exist: -3e38), so a product IS the ordering key s' = q.t - |q|^2 / 2 of its train
+// column: d^2 = |t|^2 - 2 s'.  The epilogue of a column group runs while the NEXT group's MFMAs are in flight (two accumulator sets), and needs
+// ~3.5 vector instructions per product: the register index goes into the five low mantissa bits (one v_and_or), the lane's maximum carries it
+// along, and "inside the band of the column's best" is one compare against max - W with
+//   W = band (max |q|^2 of the wave's queries + |t|^2) + 2^-16 |max|
+// -- at least as wide as k_bow_gemm_cand's per-product band (lo_e <= min_f hi_f  =>  s'_e >= s'_max - max_f band (|q_f|^2 + |t|^2)), the second
+// term covers the 2^-18 relative error of the cleared bits on both sides.  A superset of candidates only adds exact evaluations.  The slots
+// written are k_bow_gemm_cand's ({lower bound d^2 - band (|q|^2 + |t|^2) of the product, query}, slot 0 = the lane's best; a half tile with more
+// candidates than slots: slot 0 = {a lower bound of ALL its products, -1} -- k_bow_candidates* then evaluates its 32 queries exactly).
+__global__ __launch_bounds__(256) void k_bow_prep_frag(const BowPair* __restrict__ pairs, bf16x8* __restrict__ frag, int tiles32) {
+    // one workgroup = one 32-row tile of one set of one pair: rows -> |.|^2 (pre-filter only), {hi, lo} pieces through LDS -> 32 pieces of 1 KB
+    constexpr int PP = 1040;                                   // bytes between staged pieces (1 KB + 16: the 16 k-steps a row's lanes write go to different banks)
+    __shared__ __attribute__((aligned(16))) unsigned char st[32 * PP];
+    const BowPair P = pairs[blockIdx.z];
+    const int which = blockIdx.x >= tiles32 ? 1 : 0, tile = blockIdx.x - which * tiles32;
+    const float* __restrict__ x = which ? P.t : P.q;
+    const int n = which ? P.nt : P.nq;
+    float* __restrict__ norm = which ? P.tn : P.qn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x == 0 && tid == 0) *P.cnt = 0;
+    if (tile * 32 >= ((n + 63) & ~63)) return;                 // (uniform; the sweep reads whole 64-row groups: their second tile is written as zeros)
+    const int step = lane >> 2, khalf = (lane >> 1) & 1, e0 = (lane & 1) * 4;
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = wave * 8 + rr, row = tile * 32 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < n) v = *(const f32x4*)(x + (long long)row * 256 + lane * 4);
+        float p = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p = fmaf(v[j], v[j], p);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);
+        if (lane == 0 && row < n) {
+            norm[row] = p;
+            if (!which) P.qkey[row] = ~0ull;
+        }
+        bf16x4 h, l;
+        split_bf16(v, h, l);
+        *(bf16x4*)(st + (step * 2 + 0) * PP + (khalf * 32 + r) * 16 + e0 * 2) = h;
+        *(bf16x4*)(st + (step * 2 + 1) * PP + (khalf * 32 + r) * 16 + e0 * 2) = l;
+    }
+    __syncthreads();
+    bf16x8* __restrict__ dst = frag + ((long long)(blockIdx.z * 2 + which) * tiles32 + tile) * (32 * 64);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j * 256 + tid] = *(const bf16x8*)(st + (j * 4 + (tid >> 6)) * PP + (tid & 63) * 16);
+}
+
+#define BOWS_RING_BYTES 131072
+#define BOW_SWEEP_MIN_PAIRS 16                              // fewer pairs: k_bow_gemm_cand (a sweep workgroup loads 256 KB of query fragments before its first MFMA)
+#define BOWS_MAX_GROUPS 32                                  // column groups (64 train rows) one workgroup sweeps at most: |t|^2 of 2048 rows in LDS
+__global__ __launch_bounds__(256, 1) void k_bow_sweep256(const BowPair* __restrict__ pairs, float band, BowCand* __restrict__ cand, unsigned char* __restrict__ overflow,
+                                                         int max_rows, int n_qt, const bf16x8* __restrict__ frag, int tiles32, int groups_per_wg, int a_gx, int a_gy,
+                                                         int a_n_pairs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // ring (128 KB) | |q|^2 of the 256 queries | |t|^2 of the swept rows | accumulator start values
+    float* qns = (float*)(smem + BOWS_RING_BYTES);
+    float* tns = qns + 256;
+    // workgroup -> (pair, query block of 256, part of the sweep): the workgroups of a pair on ONE XCD (k_bow_gemm_cand: its rows meet in that L2)
+    const int gx = a_gx, gy = a_gy, per_pair = gx * gy, n_pairs = a_n_pairs;
+    int pair, rest;
+    {
+        const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+        const int full = n_pairs >> 3;
+        if (slot < full * per_pair) { pair = (slot / per_pair) * 8 + xcd; rest = slot - (slot / per_pair) * per_pair; }
+        else { const int q = b - full * per_pair * 8; pair = full * 8 + q / per_pair; rest = q - (q / per_pair) * per_pair; }
+    }
+    if (pair >= n_pairs) return;
+    pair = __builtin_amdgcn_readfirstlane(pair); rest = __builtin_amdgcn_readfirstlane(rest);
+    const int part = rest % gx, qblock = rest / gx;
+    const BowPair P = pairs[pair];
+    const int n1 = P.nq, n2 = P.nt;
+    const int g_begin = part * groups_per_wg, g_end = min((n2 + 63) >> 6, g_begin + groups_per_wg);
+    if (qblock * 256 >= n1 || g_begin >= g_end) return;        // (workgroup-uniform)
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, r = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q0w = qblock * 256 + wave * 64;
+    const bool live = q0w < n1;                                // (a wave without queries still moves its share of the train rows)
+    const bf16x8* __restrict__ fq = frag + (long long)(pair * 2) * tiles32 * (32 * 64);
+    const bf16x8* __restrict__ ft = frag + (long long)(pair * 2 + 1) * tiles32 * (32 * 64);
+    qns[tid] = qblock * 256 + tid < n1 ? P.qn[qblock * 256 + tid] : 0.0f;
+    for (int i = tid; i < (g_end - g_begin) * 64; i += 256) tns[i] = g_begin * 64 + i < n2 ? P.tn[g_begin * 64 + i] : 0.0f;
+    // this wave's queries: fragments of the two 32-row tiles, all 16 k-steps, hi and lo (a wave without queries loads the last tile: never stored).
+    // (Loading them by inline assembly straight into the accumulation half of the register file does NOT work: the register allocator gives every
+    //  such output the same scratch tuple and copies it out right behind the request, before any wait the source can place.)
+    bf16x8 ah[2][16], al[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const bf16x8* pc = fq + ((long long)(min((q0w >> 5) + i, tiles32 - 1) * 16 + s) * 2) * 64 + lane;
+            ah[i][s] = pc[0];
+            al[i][s] = pc[64];
+        }
+    __syncthreads();
+    // accumulator start per (tile, register) -- the same for every column -- and the band's |q|^2
+    // (kept in LDS, [wave][half][tile * 16 + register]: 32 registers would not fit beside the fragments)
+    float* ini = tns + groups_per_wg * 64 + (wave * 2 + half) * 32;
+    float qmax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int rr = wave * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            const bool ok = qblock * 256 + rr < n1;
+            if (r == 0) ini[i * 16 + reg] = ok ? -0.5f * qns[rr] : -3.0e38f;
+            qmax = fmaxf(qmax, qns[rr]);
+        }
+    qmax = fmaxf(qmax, __shfl_xor(qmax, 32, 64));
+    const unsigned ring = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    // chunk L of the sweep (4 k-steps of one column group): piece `wave` = (tile wave >> 1, hi | lo = wave & 1) of each step -> ring slot L % 4
+    const int n_chunks = (g_end - g_begin) * 4;
+    auto request = [&](int L) {
+        const int slot = L & 7;                                // (of the index asked for: the slot the last barrier has freed)
+        L = min(L, n_chunks - 1);                              // (past the end: the last chunk again, into a slot nobody reads any more: the waits stay constant)
+        const int g = g_begin + (L >> 2), c = L & 3;
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) {
+            const bf16x8* src = ft + ((long long)((g * 2 + (wave >> 1)) * 16 + c * 4 + ss) * 2 + (wave & 1)) * 64;      // uniform
+            const unsigned dst = ring + (unsigned)(((slot * 4 + ss) * 4 + wave) * 1024);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(src), "v"(lane16), "s"(dst) : "memory", "m0");
+        }
+    };
+    const long long pair_rows = (long long)pair * max_rows;
+    const int qt = q0w >> 6;
+    // ---- the epilogue of one column tile (32 train rows, this lane's row tj), cut into slices of eight products that go between the MFMAs of
+    // one k-step each: eight steps per column tile, sixteen per column group -- the length of the next group's MFMA work.
+    // mark (steps 0-3 / 8-11): the register index into the low mantissa bits; the lane's largest and second largest (med3 of {largest, second,
+    // new} is the new second).  emit (steps 4-7 / 12-15): the band, the count, the slots -- straight-line: a lane's candidates ARE its largest
+    // (and second largest) when there are at most two, a half tile with more is flagged (its 32 queries are evaluated exactly if its bound can
+    // compete at all).  Among 64 unrelated queries the two best are inside the band for one train row in twenty: a scan of the 32 registers for
+    // "the other candidates" would run in most waves.
+    struct Epi { float m, m2, tnj, W, thr; int count; };
+    auto lower = [&](float u, float tnj) {                     // the product's lower bound of d^2 (k_bow_gemm_cand's, minus the cleared bits' share)
+        const int idx = (int)(__float_as_uint(u) & 31u);
+        const int rr = wave * 64 + (idx >> 4) * 32 + (idx & 3) + 8 * ((idx & 15) >> 2) + 4 * half;
+        const float nn = qns[rr] + tnj;
+        return BowCand{__float_as_uint(fmaf(-2.0f, u, tnj) - fmaf(band, nn, 1.52587890625e-5f * fabsf(u))), qblock * 256 + rr};
+    };
+    auto epi_slice = [&](f32x16 (&acc)[2][2], int s, int g, Epi& E) {      // s: k-step 0..15 of the group whose MFMAs run meanwhile; g: the group of acc
+        const int j = s >> 3, ph = (s >> 2) & 1, k = s & 3, i = k >> 1, r0 = (k & 1) * 8;
+        if (!ph) {
+            if (k == 0) { E.m = -3.4e38f; E.m2 = -3.4e38f; }
+#pragma unroll
+            for (int reg = r0; reg < r0 + 8; ++reg) {
+                const float u = __uint_as_float((__float_as_uint(acc[i][j][reg]) & ~31u) | (unsigned)(i * 16 + reg));
+                acc[i][j][reg] = u;
+                E.m2 = __builtin_amdgcn_fmed3f(E.m, E.m2, u);
+                E.m = fmaxf(E.m, u);
+            }
+        } else {
+            if (k == 0) {
+                E.tnj = tns[(g - g_begin) * 64 + j * 32 + r];
+                const float hm = fmaxf(E.m, __shfl_xor(E.m, 32, 64));      // the column's best over the wave's 64 queries
+                E.W = fmaf(band, qmax + E.tnj, 1.52587890625e-5f * fabsf(hm));
+                E.thr = hm - E.W;
+                E.count = 0;
+            }
+#pragma unroll
+            for (int reg = r0; reg < r0 + 8; ++reg) E.count += acc[i][j][reg] >= E.thr ? 1 : 0;
+            if (k == 3) {
+                const int tj = g * 64 + j * 32 + r;
+                BowCand c0 = BowCand{0x7f800000u, -1}, c1 = c0;
+                if (E.count > BOW_SLOTS) c0 = BowCand{__float_as_uint(fmaf(-2.0f, E.m, E.tnj) - E.W - E.W), -1};      // below every product's bound of this half tile, no query
+                else if (E.count > 0) {
+                    c0 = lower(E.m, E.tnj);
+                    if (E.count > 1) c1 = lower(E.m2, E.tnj);
+                }
+                if (tj < n2 && live) {
+                    const long long hs = ((pair_rows + tj) * n_qt + qt) * 2 + half;
+                    BowCand* dst = cand + hs * BOW_SLOTS;
+                    dst[0] = c0; dst[1] = c1;
+                    overflow[hs] = (unsigned char)min(E.count, 255);
+                }
+            }
+        }
+    };
+    // the train fragments of k-step s of the group of parity par (the ring holds two groups), one step ahead of the MFMAs that use them
+    bf16x8 bq[2][4];
+    auto read_b = [&](int par, int s, bf16x8 (&b)[4]) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) b[x] = *(const bf16x8*)(smem + (((par * 16 + s) * 4 + x) * 64 + lane) * 16);
+    };
+    // the barrier that makes chunk L readable stands in front of the LAST k-step of chunk L - 1 (so that the first fragments of L are read one
+    // step ahead like all others): behind it every wave has finished chunk L - 2, whose slot takes chunk L + 6.  My pieces of chunk L have landed
+    // when at most the five chunks requested after it (20 pieces) are on their way.  (The epilogue's stores count too and may complete before
+    // older loads: they can only make this wait longer than needed, never shorter.)
+    auto open_chunk = [&](int L) {
+        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        __syncthreads();
+        request(L + 6);
+    };
+    // ---- one column group: MFMAs into `cur`, the epilogue of the group before (in `prv`) between them
+    auto group = [&](int g, f32x16 (&cur)[2][2], f32x16 (&prv)[2][2], bool have_prev, int par) {      // par: parity of g - g_begin
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 v = *(const f32x4*)(ini + i * 16 + q4 * 4);      // (written before the first barrier of the sweep)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cur[i][j][q4 * 4 + e] = v[e];
+            }
+        Epi E;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if ((s & 3) == 3) open_chunk((g - g_begin) * 4 + (s >> 2) + 1);
+            if (s < 15) read_b(par, s + 1, bq[(s + 1) & 1]);
+            else read_b(par ^ 1, 0, bq[0]);                    // (the next group's first step; after the last group: stale bytes nobody uses)
+            const bf16x8 (&b)[4] = bq[s & 1];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) cur[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i][s], b[j * 2], cur[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) cur[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i][s], b[j * 2 + 1], cur[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) cur[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i][s], b[j * 2], cur[i][j], 0, 0, 0);
+            // (a wave without queries runs the epilogue too -- straight-line code -- and stores nothing)
+            if (have_prev) epi_slice(prv, s, g - 1, E);
+            // the slice's vector instructions BETWEEN the MFMAs (left alone the scheduler appends them, and with one wave per SIMD nobody else
+            // fills the gaps); nothing crosses the end of the step
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    f32x16 accA[2][2], accB[2][2];
+#pragma unroll
+    for (int L = 0; L < 6; ++L) request(L);
+    open_chunk(0);
+    read_b(0, 0, bq[0]);
+    int g = g_begin;
+    group(g, accA, accB, false, 0);
+    for (++g; g + 1 < g_end; g += 2) {
+        group(g, accB, accA, true, 1);
+        group(g + 1, accA, accB, true, 0);
+    }
+    auto tail = [&](f32x16 (&acc)[2][2], int gl) {
+        Epi E;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) epi_slice(acc, s, gl, E);
+    };
+    if (g < g_end) {
+        group(g, accB, accA, true, 1);
+        tail(accB, g);
+    } else tail(accA, g - 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (no LDS-DMA may land after the workgroup has given its LDS back)
+}
+
 // all pairs in four launches (prep, GEMM, train pass, finalize); grids are sized for max_rows, workgroups
 // beyond a pair's row counts exit at once
 static size_t bow_cand_bytes(int n_pairs, int max_rows) {      // candidate slots + counts, rounded up to 16 bytes
@@ -992,11 +1264,11 @@ size_t tri_split_offset_bytes(int n_pairs, int max_rows) { return ((size_t)n_pai
 size_t tri_scratch_bytes(int n_pairs, int max_rows, int dim) {   // partial maxima / candidate lists + the split rows of the screened path
     return tri_split_offset_bytes(n_pairs, max_rows) + (size_t)n_pairs * 2 * max_rows * dim * sizeof(float);
 }
-size_t bow_scratch_bytes(int n_pairs, int max_rows, int dim) {  // + the split rows of both sets of every pair (split-bf16 screening)
-    return bow_cand_bytes(n_pairs, max_rows) + (size_t)n_pairs * 2 * max_rows * dim * sizeof(float);
+size_t bow_scratch_bytes(int n_pairs, int max_rows, int dim) {  // + the split rows of both sets of every pair (split-bf16 screening; whole 64-row groups: k_bow_prep_frag)
+    return bow_cand_bytes(n_pairs, max_rows) + (size_t)n_pairs * 2 * ((max_rows + 63) & ~63) * dim * sizeof(float);
 }
 
-hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, void* scratch, hipStream_t s, int screen_bf16) {
+hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int dim, float th_low, void* scratch, hipStream_t s, int screen_bf16, int* stat) {
     if (n_pairs <= 0 || max_rows <= 0) return hipSuccess;
     if (dim % 64 || (long long)max_rows * dim * 4 >= (1ll << 32)) return hipErrorInvalidValue;   // (32-bit lane offsets inside a descriptor set)
     // G = |q|^2 + |t|^2 - 2 q.t (norms and the MFMA chain in fp32) against the exactly evaluated form X (OpenCV's order): with
@@ -1015,6 +1287,26 @@ hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int
     BowCand* cand = (BowCand*)scratch;
     unsigned char* overflow = (unsigned char*)scratch + (size_t)n_pairs * max_rows * n_qt * 2 * BOW_SLOTS * sizeof(BowCand);   // candidate counts per half tile
     bf16x8* split = screen_bf16 ? (bf16x8*)((unsigned char*)scratch + bow_cand_bytes(n_pairs, max_rows)) : nullptr;
+    const int t64 = (max_rows + 63) / 64;
+    if (screen_bf16 && dim == 256 && n_pairs >= BOW_SWEEP_MIN_PAIRS && t64 <= 4 * BOWS_MAX_GROUPS) {
+        // the sweep (k_bow_sweep256): query blocks of 256 x parts of the train rows, split only as far as the chip needs workgroups
+        const int tiles32 = t64 * 2, gy = (max_rows + 255) / 256;
+        int gx = 1;
+        while ((long long)n_pairs * gy * gx < 256 && (t64 + 2 * gx - 1) / (2 * gx) >= 4) gx *= 2;
+        while ((t64 + gx - 1) / gx > BOWS_MAX_GROUPS) gx *= 2;
+        const int gpw = (t64 + gx - 1) / gx;
+        if ((long long)gx * gy * n_pairs > 0x7fffffffll) return hipErrorInvalidValue;
+        const size_t lds = BOWS_RING_BYTES + (256 + (size_t)gpw * 64 + 256) * sizeof(float);
+        static std::once_flag attr_once;                        // > 64 KB of dynamic LDS has to be requested once
+        std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)k_bow_sweep256, hipFuncAttributeMaxDynamicSharedMemorySize, BOWS_RING_BYTES + (512 + BOWS_MAX_GROUPS * 64) * 4); });
+        hipLaunchKernelGGL(k_bow_prep_frag, dim3(2 * tiles32, 1, n_pairs), dim3(256), 0, s, pairs, split, tiles32);
+        hipLaunchKernelGGL(k_bow_sweep256, dim3((unsigned)(gx * gy * n_pairs)), dim3(256), lds, s, pairs, band, cand, overflow, max_rows, n_qt, split, tiles32, gpw, gx, gy, n_pairs);
+        int rpw = BOWC_ROWS;
+        while (rpw > 1 && (long long)((max_rows + 4 * rpw - 1) / (4 * rpw)) * n_pairs < 512) rpw >>= 1;
+        hipLaunchKernelGGL(k_bow_candidates256, dim3((max_rows + 4 * rpw - 1) / (4 * rpw), 1, n_pairs), dim3(256), 0, s, pairs, band, cand, overflow, max_rows, n_qt, rpw, stat);
+        hipLaunchKernelGGL(k_bow_finalize, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, th_low);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_bow_prep, dim3((2 * max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim, split, max_rows);
     // column tiles per workgroup: as many (up to 4) as still leave the launch two workgroups per CU
     const int t128 = (max_rows + 127) / 128;
@@ -1030,10 +1322,10 @@ hipError_t launch_bow_pairs(const BowPair* pairs, int n_pairs, int max_rows, int
     if (dim == 256) {
         int rpw = BOWC_ROWS;                                  // train rows per wave: 8 when the launch has waves to spare (measured: 32 pairs of 1000 rows 16 / 8 / 4 / 2 -> 30 / 20 / 23 / 25 us)
         while (rpw > 1 && (long long)((max_rows + 4 * rpw - 1) / (4 * rpw)) * n_pairs < 512) rpw >>= 1;
-        hipLaunchKernelGGL(k_bow_candidates256, dim3((max_rows + 4 * rpw - 1) / (4 * rpw), 1, n_pairs), dim3(256), 0, s, pairs, band, cand, overflow, max_rows, n_qt, rpw);
+        hipLaunchKernelGGL(k_bow_candidates256, dim3((max_rows + 4 * rpw - 1) / (4 * rpw), 1, n_pairs), dim3(256), 0, s, pairs, band, cand, overflow, max_rows, n_qt, rpw, stat);
     }
     else
-        hipLaunchKernelGGL(k_bow_candidates, dim3((max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim, band, cand, overflow, max_rows, n_qt);
+        hipLaunchKernelGGL(k_bow_candidates, dim3((max_rows + 3) / 4, 1, n_pairs), dim3(256), 0, s, pairs, dim, band, cand, overflow, max_rows, n_qt, stat);
     hipLaunchKernelGGL(k_bow_finalize, dim3((max_rows + 255) / 256, 1, n_pairs), dim3(256), 0, s, pairs, th_low);
     return hipGetLastError();
 }
@@ -1455,7 +1747,6 @@ __global__ __launch_bounds__(1024) void k_db_filter(const float* __restrict__ sc
                                                     int n_partials, int32_t* __restrict__ cand_slot, float* __restrict__ cand_score,
                                                     int* __restrict__ n_cand, float* __restrict__ best_out) {
     __shared__ int wsum[16];
-    __shared__ int base;
     // one workgroup per query (blockIdx.x): rows of n scores / candidates
     scores += (long long)blockIdx.x * n; cand_slot += (long long)blockIdx.x * n; cand_score += (long long)blockIdx.x * n;
     best_bits += (long long)blockIdx.x * n_partials; n_cand += blockIdx.x; best_out += blockIdx.x;
@@ -1468,28 +1759,38 @@ __global__ __launch_bounds__(1024) void k_db_filter(const float* __restrict__ sc
     __syncthreads();
     float best = wbest[0];
     for (int w = 1; w < 16; ++w) best = fmaxf(best, wbest[w]);
-    __syncthreads();
     float min_score = best * 0.8f;
     if (mode == 1) min_score = fmaxf(0.5f, min_score);
+    // ascending slot order without a barrier per 1024 slots: wave w owns the contiguous range [w, w + 1) per_wave, counts its survivors (ballots, the
+    // loads of four 64-slot pieces in flight), one barrier hands every wave its offset, and a second pass over the same range (L2 hits) writes them out
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) base = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += 1024) {
-        const int i = i0 + tid;
-        const float sc = i < n ? scores[i] : -1.0f;
-        const bool keep = i < n && sc > min_score;
-        const unsigned long long mask = __ballot(keep);
-        const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wave] = __popcll(mask);
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wsum[w];
-        if (keep) { const int o = base + woff + prefix; cand_slot[o] = i; cand_score[o] = sc; }
-        __syncthreads();
-        if (tid == 0) { int tot = 0; for (int w = 0; w < 16; ++w) tot += wsum[w]; base += tot; }
-        __syncthreads();
+    const int per_wave = (((n + 15) >> 4) + 63) & ~63;
+    const int w0 = wave * per_wave, w1 = min(n, w0 + per_wave);
+    int cnt = 0;                                              // (wave-uniform)
+    for (int i0 = w0; i0 < w1; i0 += 256) {
+        float sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * 64 + lane; sc[u] = i < w1 ? scores[i] : -1.0f; }      // (-1 never passes: min_score >= 0)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cnt += __popcll(__ballot(sc[u] > min_score));
     }
-    if (tid == 0) { *n_cand = base; *best_out = best; }
+    if (lane == 0) wsum[wave] = cnt;
+    __syncthreads();
+    int o = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) { const int c = wsum[w]; if (w < wave) o += c; tot += c; }
+    for (int i0 = w0; i0 < w1 && cnt > 0; i0 += 256) {
+        float sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * 64 + lane; sc[u] = i < w1 ? scores[i] : -1.0f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool keep = sc[u] > min_score;
+            const unsigned long long mask = __ballot(keep);
+            if (keep) { const int at = o + __popcll(mask & ((1ull << lane) - 1ull)); cand_slot[at] = i0 + u * 64 + lane; cand_score[at] = sc[u]; }
+            o += __popcll(mask);
+        }
+    }
+    if (tid == 0) { *n_cand = tot; *best_out = best; }
 }
 
 // workgroups of the scan kernels (4 waves each); the per-wave best scores are the filter kernel's partials

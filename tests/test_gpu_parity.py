@@ -397,6 +397,65 @@ def test_batched_bow_matches_per_pair_calls(engine):
             _eq("single", m1, rm)
 
 
+@pytest.mark.parametrize("scale", [1.0, 3.0])
+def test_bow_sweep_many_pairs(engine, engine_options, scale):
+    """launches of >= 16 pairs of 256-D sets take the sweep form of the screening GEMM (kernels_match.hip k_bow_sweep256: query fragments resident
+    in registers, train rows through an LDS ring): ragged row counts around its 32 / 64 / 256-row granules incl. an empty and a one-row set, clustered
+    descriptors with near-ties and exact duplicates (more candidates than slots in a half tile), unnormalised rows (the band scales with |q|^2):
+    every pair == the oracle.  And the screen has to SCREEN: a wrong product only costs exact evaluations, never a wrong match, so the number of
+    exact evaluations (engine statistic stat_bow_exact) is checked too."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(41)
+    mr = 300
+    n_rows = np.array([300, 257, 256, 255, 64, 65, 63, 1, 0, 200, 129, 300], np.int32)
+    S = len(n_rows)
+    centres = _unit_rows(rng, 9)
+    sets = np.zeros((S, mr, 256), np.float32)
+    for s_ in range(S):
+        v = np.repeat(centres, 34, axis=0)[:mr] + (0.004 if s_ % 3 == 0 else 0.05) * rng.standard_normal((mr, 256)).astype(np.float32)
+        v = v[rng.permutation(mr)]
+        sets[s_] = (scale * v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    sets[1, 5] = sets[0, 9]; sets[1, 200] = sets[0, 9]; sets[0, 77] = sets[0, 9]; sets[2, :6] = sets[0, 9]      # duplicates on both sides
+    pairs = [(a, (a * 5 + 1) % S) for a in range(S)] + [(0, 0), (1, 0), (0, 1), (8, 0), (0, 8), (7, 7), (11, 2), (2, 11)]
+    assert len(pairs) >= 16
+    engine_options({"match_stats": 1})
+    engine.get_option("stat_bow_exact")                                      # (reads and clears)
+    cnt, match, dist = engine.search_by_bow_batch(sets, n_rows, pairs, 0.6 * scale)
+    for p, (qs, ts) in enumerate(pairs):
+        q, t = sets[qs, :n_rows[qs]], sets[ts, :n_rows[ts]]
+        rn, rm, rd = O.search_by_bow(q, t, 0.6 * scale)
+        assert cnt[p] == rn, (p, qs, ts, cnt[p], rn)
+        _eq(f"pair {p} ({qs}, {ts}) match", match[p, :n_rows[qs]], rm); _eq(f"pair {p} ({qs}, {ts}) dist", dist[p, :n_rows[qs]], rd)
+    evals = engine.get_option("stat_bow_exact")
+    products = sum(int(n_rows[a]) * int(n_rows[b]) for a, b in pairs)
+    print(f"\nclustered sets x {len(pairs)} pairs, scale {scale}: {evals} exact evaluations of {products} products")
+    assert 0 < evals < 0.25 * products, (evals, products)               # (nine tight clusters: many true near-ties; a broken screen evaluates everything)
+
+
+def test_bow_sweep_screens(engine, engine_options):
+    """the sweep on distinct descriptors (1000 x 1000 x 256, a planted permutation, 16 pairs): matches == the oracle's for one pair, and about one
+    exact evaluation per train row and competitive query tile -- not 1000"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(42)
+    a = _unit_rows(rng, 1000)
+    perm = rng.permutation(1000)
+    b = a[perm] + 0.02 * rng.standard_normal((1000, 256)).astype(np.float32)
+    b = (b / np.linalg.norm(b, axis=1, keepdims=True)).astype(np.float32)
+    sets = np.stack([a, b]).astype(np.float32)
+    nr = np.array([1000, 1000], np.int32)
+    engine_options({"match_stats": 1})
+    engine.get_option("stat_bow_exact")
+    for n_pairs in (16, 4):                                                 # the sweep / k_bow_gemm_cand (fewer pairs)
+        cnt, match, dist = engine.search_by_bow_batch(sets, nr, [(0, 1)] * n_pairs, 0.6)
+        evals = engine.get_option("stat_bow_exact")
+        rn, rm, rd = O.search_by_bow(a, b, 0.6)
+        for p in (0, n_pairs - 1):
+            assert cnt[p] == rn
+            _eq("planted match", match[p], rm); _eq("planted dist", dist[p], rd)
+        print(f"\nplanted permutation x {n_pairs} pairs: {evals / (n_pairs * 1000):.2f} exact evaluations per train row")
+        assert n_pairs * 1000 <= evals <= 4 * n_pairs * 1000, evals
+
+
 def test_batched_triangulation_matches_per_pair_calls(engine):
     """hfnet_match_search_for_triangulation_batch == the single-pair entry point == the oracle (30 neighbours, ragged)"""
     from oracle import oracle as O
