@@ -27,7 +27,7 @@ int hfnet_db_create(hfnet_engine* eh, int capacity, int dim, hfnet_db** out) try
     HF_HIP(dev_malloc((void**)&db->d_occ, (size_t)capacity));
     HF_HIP(dev_malloc((void**)&db->d_q, sizeof(float) * dim));
     HF_HIP(dev_malloc((void**)&db->d_norm, sizeof(float) * capacity));
-    HF_HIP(dev_malloc(&db->d_hi, (size_t)2 * capacity * dim));
+    HF_HIP(dev_malloc(&db->d_hi, db_hi_bytes(capacity, dim)));
     HF_HIP(dev_malloc((void**)&db->d_scores, sizeof(float) * capacity));
     HF_HIP(dev_malloc((void**)&db->d_cand_score, sizeof(float) * capacity));
     HF_HIP(dev_malloc((void**)&db->d_cand_slot, sizeof(int32_t) * capacity));
@@ -151,8 +151,8 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
     const int parts = gemm ? db_gemm_partials(db->capacity) : 4 * db_batch_workgroups(db->capacity);
     HF_TRY(e.m_key.ensure(sizeof(unsigned int) * Q * parts));
     if (gemm) {
-        HF_TRY(e.m_tn.ensure(sizeof(float) * Q)); HF_TRY(e.m_b.ensure(sizeof(float) * db_gemm_scratch_floats(db->capacity, n_queries)));
-        HF_TRY(e.m_f1.ensure((size_t)2 * Q * db->dim));             // bf16 copies of the queries
+        HF_TRY(e.m_tn.ensure(sizeof(float) * Q)); HF_TRY(e.m_b.ensure(sizeof(float) * db_gemm_scratch_floats(db->capacity, n_queries, db->dim)));
+        HF_TRY(e.m_f1.ensure(db_hi_bytes(n_queries, db->dim)));      // bf16 copies of the queries
     }
     float* d_q = e.m_a.as<float>(); float* d_scores = e.m_s.as<float>(); float* d_cs = e.m_f0.as<float>();
     int32_t* d_slot = e.m_i0.as<int32_t>(); int* d_n = e.m_cnt.as<int>(); float* d_best = e.m_qn.as<float>();

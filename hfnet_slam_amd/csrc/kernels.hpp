@@ -231,11 +231,12 @@ hipError_t launch_db_scores_batch(const float* q, int n_queries, const float* db
 // the same scan for many queries (n_queries >= 8), screened on the bf16 matrix pipe: a slot whose crude squared distance (bf16 copies of both
 // vectors, one product) is >= 1 + 9e-3 (|q|^2 + |d|^2) is at distance >= 1 whatever the rounding -- score exactly 0 --, every other occupied
 // slot is scored with launch_db_scores' exact chain: ALL outputs equal the exact scan's bit for bit (kernels_match.hip).
-// norm / hi: |x|^2 in tree256 order and the bf16 copy of every row (launch_db_prep_hi: the database's when rows were added, the queries' per
+// norm / hi: |x|^2 in tree256 order and the bf16 copy of every row in the matrix unit's fragment order, db_hi_bytes (launch_db_prep_hi: the database's when rows were added, the queries' per
 // call); best_partial: [n_queries][db_gemm_partials(n)]; scratch: db_gemm_scratch_floats(n, n_queries) floats
 int db_gemm_partials(int n);
 bool db_screen_supported(int dim);     // descriptor lengths the screened batched query takes (others: the exact batched scan)
-size_t db_gemm_scratch_floats(int n, int n_queries);
+size_t db_gemm_scratch_floats(int n, int n_queries, int dim);
+size_t db_hi_bytes(int n_rows, int dim);   // the bf16 copy of n_rows vectors: whole 32-row tiles in fragment order
 hipError_t launch_db_prep_hi(const float* x, int n_rows, int dim, float* norm, void* hi, hipStream_t s);
 hipError_t launch_db_screen(const float* q, const void* qh, int n_queries, const float* qnorm, const float* db, const void* dbh, const float* dnorm,
                             const unsigned char* occupied, int n, int dim, float* scores, unsigned int* best_partial, float* scratch, hipStream_t s);

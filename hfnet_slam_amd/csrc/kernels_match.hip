@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 
 #include <cfloat>
 
@@ -1546,101 +1547,148 @@ __global__ __launch_bounds__(256) void k_db_scores_batch(const float* __restrict
 //    exact chain.  All outputs of hfnet_db_query_batch are therefore the exact scan's bits: scores of EVERY slot, best, candidates.
 // (Round 2-3's f32 MFMA form -- S on v_mfma_f32_32x32x2_f32, two exact re-scoring passes around the candidate threshold, non-candidates
 //  within 5e-6 -- took 89 us for 64 queries against 10 000 keyframes; it is deleted.)
-// The database keeps a bf16 copy of its rows for this (2 bytes per element, refreshed with the norms: k_db_prep_hi); the kernel below
-// is k_db_gemm's structure at half the bytes and a sixteenth of the matrix time: a workgroup owns 128 database rows x (NT * 32) queries
-// x one QUARTER (1 / DBG_PARTS) of the descriptor length, both operands staged through LDS in chunks of 64 k.
-#define DBG_PARTS 4        // (round 6: 8 -> 4 -- half the partial sums written and read back, 316 workgroups still cover the chip: screen 19.5 -> 18.3 us, decide 11.4 -> 10.5)
+// The database keeps a bf16 copy of its rows for this (2 bytes per element, refreshed with the norms: k_db_prep_frag), and keeps it in the
+// matrix unit's FRAGMENT ORDER -- [32-row tile][16-k step][lane = row & 31 | k-half << 5][8 bf16]: the 1 KB a wave's 64 lanes hand to one
+// v_mfma_f32_32x32x16_bf16 is 1 KB of consecutive memory.  Round 5's k_db_screen (k_db_gemm's structure: 128 rows x 128 queries x a
+// quarter of k per workgroup, both operands through LDS in 64-k chunks, one chunk ahead, two barriers per chunk) streamed the copy at
+// 4.5 TB/s: 24 KB in flight per workgroup, a third of every workgroup's fetches were the QUERIES again (128 KB per workgroup from L2), and
+// a memory round trip per chunk.  k_db_sweep: a workgroup brings its k-part of the queries' fragments into LDS ONCE (by LDS-DMA, <= 128 KB),
+// then every wave streams 32-row tiles of the database straight from memory into registers -- no LDS, no barrier on the database's way,
+// sixteen 1 KB requests in flight per wave -- and multiplies them against the resident fragments.  Queries are the M side, database rows
+// the N side of the product: a lane ends up with ONE row's products, so [part][query][row] is written in 128-byte runs without a transpose.
 typedef __bf16 dbh_t;
-// |x|^2 (tree256 order, as k_sumsq_rows) and the bf16 copy of n_rows vectors, one wave each
-__global__ __launch_bounds__(256) void k_db_prep_hi(const float* __restrict__ x, int n_rows, int dim, float* __restrict__ norm, dbh_t* __restrict__ hi) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= n_rows) return;
-    const float* v = x + (long long)row * dim;
-    dbh_t* h = hi + (long long)row * dim;
-    f32x4 p = {0.f, 0.f, 0.f, 0.f};
-    for (int k = lane * 4; k < dim; k += 256) {
-        const f32x4 xv = *(const f32x4*)(v + k);
+// |x|^2 (tree256 order, as k_sumsq_rows) and the bf16 copy of a 32-row tile in fragment order; rows >= n_rows of the last tile: zeros
+__global__ __launch_bounds__(256) void k_db_prep_frag(const float* __restrict__ x, int n_rows, int dim, float* __restrict__ norm, bf16x8* __restrict__ frag) {
+    constexpr int PP = 1040;                                   // bytes between staged pieces (k_bow_prep_frag)
+    __shared__ __attribute__((aligned(16))) unsigned char st[16 * PP];
+    const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int step = lane >> 2, khalf = (lane >> 1) & 1, e0 = (lane & 1) * 4;
+    const int ks = dim >> 4;
+    f32x4 p[8];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) p[c] = fmaf(xv[c], xv[c], p[c]);
-        bf16x4 hv;
+    for (int rr = 0; rr < 8; ++rr) p[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < dim; k0 += 256) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) hv[c] = (__bf16)xv[c];
-        *(bf16x4*)(h + k) = hv;
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = wave * 8 + rr, row = tile * 32 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < n_rows) v = *(const f32x4*)(x + (long long)row * dim + k0 + lane * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p[rr][c] = fmaf(v[c], v[c], p[rr][c]);
+            bf16x4 hv;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hv[c] = (__bf16)v[c];
+            *(bf16x4*)(st + step * PP + (khalf * 32 + r) * 16 + e0 * 2) = hv;
+        }
+        __syncthreads();
+        bf16x8* __restrict__ dst = frag + ((long long)tile * ks + (k0 >> 4)) * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[(j * 4 + wave) * 64 + lane] = *(const bf16x8*)(st + (j * 4 + wave) * PP + lane * 16);
+        __syncthreads();
     }
-    const float ss = tree256_wave4(p);
-    if (lane == 0) norm[row] = ss;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = tile * 32 + wave * 8 + rr;
+        const float ss = tree256_wave4(p[rr]);
+        if (lane == 0 && row < n_rows) norm[row] = ss;
+    }
 }
 
+#define DBS_WAVES 8
+#define DBS_RING 16                                           // 1 KB requests a wave keeps in flight, and the unit of the k loop (three / four query tiles: 8 -- registers)
+// k-steps per part for NT query tiles: NT * ksp KB of LDS (<= 128 KB), parts * NT <= 8 slabs of partial sums where the descriptor length allows
+__host__ __device__ static inline int dbs_ksp(int nt, int dim) {
+    const int cap = nt == 2 ? 64 : 32, units = dim >> 8;     // (units of 16 k-steps: dim is a multiple of 256)
+    int d = 1;
+    for (int c = 1; c <= units && 16 * c <= cap; ++c)
+        if (units % c == 0) d = c;
+    return 16 * d;
+}
 template <int NT>
-__global__ __launch_bounds__(256) void k_db_screen(const dbh_t* __restrict__ qh, int n_queries, int q0, const dbh_t* __restrict__ dbh, int n, int dim,
-                                                   float* __restrict__ partial /* [DBG_PARTS][NT*32][n] */) {
-    constexpr int LH = 72, QB = NT * 32;                      // bf16 per LDS row (64 k + 16 bytes: conflict-free 16-byte reads of 16 consecutive rows)
-    __shared__ __attribute__((aligned(16))) dbh_t As[128 * LH];
-    __shared__ __attribute__((aligned(16))) dbh_t Bs[QB * LH];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
-    const int m0 = blockIdx.x * 128, part = blockIdx.y;
-    const int kw = dim / DBG_PARTS, kbase = part * kw;
-    // staging: a row's 64-k chunk is 128 bytes = 8 pieces of 16 bytes; thread (row = tid >> 3 (+ 32 j), piece = tid & 7)
-    const int pc = tid & 7, prow = tid >> 3;
-    const dbh_t* dbase = dbh + (long long)m0 * dim + kbase;
-    const dbh_t* qbase = qh + (long long)q0 * dim + kbase;
-    unsigned ag[4], bg[NT];
+__global__ __launch_bounds__(DBS_WAVES * 64, 1) void k_db_sweep(const bf16x8* __restrict__ qfrag, int n_queries, int q0, const bf16x8* __restrict__ dbfrag, int n_tiles,
+                                                                int ks /* dim / 16 */, int ksp, int parts, int groups,
+                                                                float* __restrict__ partial /* [parts][NT * 32][n_tiles * 32] */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [NT][ksp][64 lanes][16 B]: the queries' fragments of this part
+    constexpr int RING = NT <= 2 ? DBS_RING : DBS_RING / 2;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, r = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int part = blockIdx.x % parts, g = blockIdx.x / parts;           // (parts of one k range share an XCD's L2 when parts divides 8)
+    {
+        const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+        const unsigned lane16 = (unsigned)lane * 16u;
+        const bf16x8* qb = qfrag + ((long long)(q0 >> 5) * ks + (long long)part * ksp) * 64;
+        for (int pc = wave; pc < NT * ksp; pc += DBS_WAVES) {
+            const int nt = pc / ksp, s = pc - nt * ksp;
+            const bf16x8* src = qb + ((long long)nt * ks + s) * 64;       // uniform
+            const unsigned dst = ldsb + (unsigned)pc * 1024u;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(src), "v"(lane16), "s"(dst) : "memory", "m0");
+        }
+    }
+    const int stride = groups * DBS_WAVES;
+    int t = g + groups * wave;
+    const bool have = t < n_tiles;
+    bf16x8 b[RING];
+    const bf16x8* cur = dbfrag + ((long long)(have ? t : 0) * ks + (long long)part * ksp) * 64 + lane;
+    if (have) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ag[j] = ((unsigned)min(prow + 32 * j, n - 1 - m0) * (unsigned)dim + (unsigned)pc * 8u) * 2u;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) bg[j] = ((unsigned)min(prow + 32 * j, n_queries - 1 - q0) * (unsigned)dim + (unsigned)pc * 8u) * 2u;
+        for (int j = 0; j < RING; ++j) {                       // (in this order: the waits of the loop below count requests)
+            b[j] = cur[j * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // (everything of this wave, the first database pieces included: the count does not depend on where the compiler puts them)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!have) return;
+    int pt = t, ps = RING;                                // the next batch to request: k-steps ps .. ps + 15 of tile pt
+    if (ps == ksp) { ps = 0; pt += stride; }
     f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
-    // (one chunk ahead.  A register ring of four chunks in flight was measured SLOWER, 22.8 against 18.3 us: the kernel is not waiting for its
-    //  own loads -- it streams the database's bf16 copy at 4.5 TB/s with one or two workgroups per CU)
-    f32x4 sa[4], sb[NT];                                      // (16-byte pieces of bf16, moved as f32x4)
+    int sb = 0;
+    const long long npad = (long long)n_tiles * 32;
+    for (;;) {
+        // the queries' fragments of a step are read one step ahead of its MFMAs; nothing else moves across a step (left alone the scheduler reads
+        // a whole batch's fragments first: 128 registers for four query tiles)
+        const unsigned char* ap = smem + ((size_t)sb * 64 + lane) * 16;
+        bf16x8 a[2][NT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sa[j] = *(gvec4_t)(sgpr_base(dbase, 0) + ag[j]);
+        for (int nt = 0; nt < NT; ++nt) a[0][nt] = *(const bf16x8*)(ap + (size_t)nt * ksp * 1024);
+        const bool more = pt < n_tiles;                       // (wave-uniform)
+        const bf16x8* nx = dbfrag + ((long long)(more ? pt : t) * ks + (long long)part * ksp + ps) * 64 + lane;
+        auto batch = [&](auto pf) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) sb[j] = *(gvec4_t)(sgpr_base(qbase, 0) + bg[j]);
-    for (int k0 = 0; k0 < kw; k0 += 64) {
-        __syncthreads();                                     // previous chunk fully consumed
+            for (int j = 0; j < RING; ++j) {
+                if (j + 1 < RING) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *(f32x4*)(As + (prow + 32 * j) * LH + pc * 8) = sa[j];
+                    for (int nt = 0; nt < NT; ++nt) a[(j + 1) & 1][nt] = *(const bf16x8*)(ap + ((size_t)nt * ksp + j + 1) * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
-        for (int j = 0; j < NT; ++j) *(f32x4*)(Bs + (prow + 32 * j) * LH + pc * 8) = sb[j];
-        __syncthreads();
-        {   // (unconditional: see k_tri_gemm_argmax)
-            const unsigned kn = (unsigned)min(k0 + 64, kw - 64) * 2u;
-            const gbase_t pa = sgpr_base(dbase, kn), pb = sgpr_base(qbase, kn);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sa[j] = *(gvec4_t)(pa + fresh(ag[j]));
-#pragma unroll
-            for (int j = 0; j < NT; ++j) sb[j] = *(gvec4_t)(pb + fresh(bg[j]));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const dbh_t* ap = As + (wave * 32 + r) * LH + half * 8;
-        const dbh_t* bp = Bs + r * LH + half * 8;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {                         // four steps of 16 k: lane (r, half) holds k = 8 half .. 8 half + 7 of a step
-            const bf16x8 av = *(const bf16x8*)(ap + 16 * m);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const bf16x8 bv = *(const bf16x8*)(bp + nt * 32 * LH + 16 * m);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j & 1][nt], b[j], acc[nt], 0, 0, 0);
+                if (decltype(pf)::value) b[j] = nx[j * 64];
+                __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        if (more) batch(std::true_type{}); else batch(std::false_type{});
+        sb += RING; ps += RING;
+        if (ps == ksp) { ps = 0; pt += stride; }
+        if (sb == ksp) {
+            // lane (r, half), register reg of tile nt: query nt * 32 + (reg & 3) + 8 (reg >> 2) + 4 half, database row t * 32 + r
+            float* out = partial + ((long long)part * (NT * 32)) * npad + (long long)t * 32 + r;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int m = nt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    out[(long long)m * npad] = acc[nt][reg];   // (rows of queries that do not exist: zeros times the database, never read)
+                    acc[nt][reg] = 0.0f;
+                }
+            sb = 0; t += stride;
+            if (t >= n_tiles) break;
         }
-    }
-    // partial sums -> [part][query][row]: through LDS so that a half-wave writes 32 consecutive rows of one query
-    __syncthreads();
-    float* tp = (float*)As + wave * (32 * 33);                // wave-private [query column][row], 33 floats apart (4 x 4224 B <= the 18 KB of As)
-    const int i = m0 + wave * 32 + r;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) tp[r * 33 + (reg & 3) + 8 * (reg >> 2) + 4 * half] = acc[nt][reg];
-        asm volatile("" ::: "memory");                        // (LDS operations of one wave execute in order)
-        for (int c = half; c < 32; c += 2)
-            if (i < n) partial[((long long)part * QB + nt * 32 + c) * n + i] = tp[c * 33 + r];
-        asm volatile("" ::: "memory");
     }
 }
 
@@ -1667,11 +1715,11 @@ __device__ __forceinline__ float db_exact_u(const float* __restrict__ q, const f
     return 1 - sqrtf(tree256_wave4(p));
 }
 
-// partial sums of the DBG_PARTS parts -> d2~; decide; re-score what has to be; scores (clamped at 0, -1 for empty slots) and the per-wave
+// partial sums of the k-parts -> d2~; decide; re-score what has to be; scores (clamped at 0, -1 for empty slots) and the per-wave
 // maxima k_db_filter reduces.  One workgroup = 256 slots of one query.
 __global__ __launch_bounds__(256) void k_db_decide(const float* __restrict__ partial, int qb, int q0, const float* __restrict__ q, const float* __restrict__ db,
                                                    const float* __restrict__ qnorm, const float* __restrict__ dnorm, const unsigned char* __restrict__ occupied,
-                                                   int n, int dim, float* __restrict__ scores, unsigned int* __restrict__ best_bits, int n_partials) {
+                                                   int n, int dim, float* __restrict__ scores, unsigned int* __restrict__ best_bits, int n_partials, int parts, long long npad) {
     __shared__ int list[256];
     __shared__ float exact[256];
     __shared__ int n_list;
@@ -1682,15 +1730,10 @@ __global__ __launch_bounds__(256) void k_db_decide(const float* __restrict__ par
     float u = -1.0f;                                           // empty slot
     int mine = -1;
     if (i < n && occupied[i]) {
-        float p[DBG_PARTS];
-#pragma unroll
-        for (int w = 0; w < DBG_PARTS; ++w) p[w] = partial[((long long)w * qb + c) * n + i];
-#pragma unroll
-        for (int m = DBG_PARTS; m > 1; m >>= 1)
-#pragma unroll
-            for (int w = 0; w < m / 2; ++w) p[w] = p[2 * w] + p[2 * w + 1];
+        float p = 0.0f;                                        // (any order of faithful additions: the band's bound does not care)
+        for (int w = 0; w < parts; ++w) p += partial[((long long)w * qb + c) * npad + i];
         const float t = qnorm[qi] + dnorm[i];
-        const float d2 = fmaf(-2.0f, p[0], t);
+        const float d2 = fmaf(-2.0f, p, t);
         u = 0.0f;
         if (!(d2 >= 1.0f + 9e-3f * t)) { mine = atomicAdd(&n_list, 1); list[mine] = i; }      // (NaN -- non-finite descriptors -- goes to the exact chain too)
     }
@@ -1711,33 +1754,51 @@ __global__ __launch_bounds__(256) void k_db_decide(const float* __restrict__ par
 
 hipError_t launch_db_prep_hi(const float* x, int n_rows, int dim, float* norm, void* hi, hipStream_t s) {
     if (n_rows <= 0) return hipSuccess;
-    if (dim % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_db_prep_hi, dim3((n_rows + 3) / 4), dim3(256), 0, s, x, n_rows, dim, norm, (dbh_t*)hi);
+    if (dim % 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_db_prep_frag, dim3((n_rows + 31) / 32), dim3(256), 0, s, x, n_rows, dim, norm, (bf16x8*)hi);
     return hipGetLastError();
 }
 
 int db_gemm_partials(int n) { return 4 * ((n + 255) / 256); }
-bool db_screen_supported(int dim) { return dim > 0 && dim % (DBG_PARTS * 64) == 0; }     // DBG_PARTS parts of whole 64-k chunks
-size_t db_gemm_scratch_floats(int n, int n_queries) { return (size_t)DBG_PARTS * (size_t)std::min(128, (n_queries + 31) / 32 * 32) * (size_t)n; }
+bool db_screen_supported(int dim) { return dim > 0 && dim % 256 == 0; }
+size_t db_hi_bytes(int n_rows, int dim) { return (size_t)2 * (size_t)((n_rows + 31) & ~31) * (size_t)dim; }     // whole 32-row tiles
+size_t db_gemm_scratch_floats(int n, int n_queries, int dim) {
+    const int nt = (std::min(128, n_queries) + 31) / 32;
+    return (size_t)((dim >> 4) / dbs_ksp(nt, dim)) * (size_t)(nt * 32) * (size_t)((n + 31) & ~31);
+}
 
-// scores of n_queries queries against the n slots of the database (see above): q / db: f32 rows, qh / dbh: their bf16 copies, qnorm / dnorm:
-// |.|^2 (launch_db_prep_hi); best_partial: [n_queries][db_gemm_partials(n)]; scratch: db_gemm_scratch_floats(n, n_queries) floats
+// scores of n_queries queries against the n slots of the database (see above): q / db: f32 rows, qh / dbh: their bf16 copies in fragment
+// order, qnorm / dnorm: |.|^2 (launch_db_prep_hi); best_partial: [n_queries][db_gemm_partials(n)]; scratch: db_gemm_scratch_floats floats
 hipError_t launch_db_screen(const float* q, const void* qh, int n_queries, const float* qnorm, const float* db, const void* dbh, const float* dnorm,
                             const unsigned char* occupied, int n, int dim, float* scores, unsigned int* best_partial, float* scratch, hipStream_t s) {
     if (n <= 0 || n_queries <= 0) return hipSuccess;
     if (!db_screen_supported(dim)) return hipErrorInvalidValue;
-    const dim3 grid((n + 127) / 128, DBG_PARTS);
-    const int parts = db_gemm_partials(n);
+    static std::once_flag attr_once;                                    // > 64 KB of dynamic LDS has to be requested once
+    std::call_once(attr_once, []() {
+        (void)hipFuncSetAttribute((const void*)k_db_sweep<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)k_db_sweep<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)k_db_sweep<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)k_db_sweep<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    });
+    const int n_tiles = (n + 31) / 32, ks = dim >> 4;
+    const long long npad = (long long)n_tiles * 32;
+    const int n_bp = db_gemm_partials(n);
     for (int q0 = 0; q0 < n_queries; q0 += 128) {
         const int nt = (std::min(128, n_queries - q0) + 31) / 32, qb = nt * 32, nq = std::min(qb, n_queries - q0);
+        const int ksp = dbs_ksp(nt, dim), parts = ks / ksp;
+        // one workgroup per CU where the database has the tiles for it: 256 / parts groups, a group's wave w takes tiles g + groups (w + 8 j)
+        const int groups = std::max(1, std::min(n_tiles, 256 / parts));
+        const dim3 grid((unsigned)(groups * parts));
+        const size_t lds = (size_t)nt * ksp * 1024;
+        const bf16x8* qf = (const bf16x8*)qh; const bf16x8* df = (const bf16x8*)dbh;
         switch (nt) {
-            case 1: hipLaunchKernelGGL((k_db_screen<1>), grid, dim3(256), 0, s, (const dbh_t*)qh, n_queries, q0, (const dbh_t*)dbh, n, dim, scratch); break;
-            case 2: hipLaunchKernelGGL((k_db_screen<2>), grid, dim3(256), 0, s, (const dbh_t*)qh, n_queries, q0, (const dbh_t*)dbh, n, dim, scratch); break;
-            case 3: hipLaunchKernelGGL((k_db_screen<3>), grid, dim3(256), 0, s, (const dbh_t*)qh, n_queries, q0, (const dbh_t*)dbh, n, dim, scratch); break;
-            default: hipLaunchKernelGGL((k_db_screen<4>), grid, dim3(256), 0, s, (const dbh_t*)qh, n_queries, q0, (const dbh_t*)dbh, n, dim, scratch); break;
+            case 1: hipLaunchKernelGGL((k_db_sweep<1>), grid, dim3(DBS_WAVES * 64), lds, s, qf, n_queries, q0, df, n_tiles, ks, ksp, parts, groups, scratch); break;
+            case 2: hipLaunchKernelGGL((k_db_sweep<2>), grid, dim3(DBS_WAVES * 64), lds, s, qf, n_queries, q0, df, n_tiles, ks, ksp, parts, groups, scratch); break;
+            case 3: hipLaunchKernelGGL((k_db_sweep<3>), grid, dim3(DBS_WAVES * 64), lds, s, qf, n_queries, q0, df, n_tiles, ks, ksp, parts, groups, scratch); break;
+            default: hipLaunchKernelGGL((k_db_sweep<4>), grid, dim3(DBS_WAVES * 64), lds, s, qf, n_queries, q0, df, n_tiles, ks, ksp, parts, groups, scratch); break;
         }
         hipLaunchKernelGGL(k_db_decide, dim3((n + 255) / 256, nq), dim3(256), 0, s, scratch, qb, q0, q, db, qnorm, dnorm, occupied, n, dim, scores,
-                           best_partial, parts);
+                           best_partial, n_bp, parts, npad);
     }
     return hipGetLastError();
 }

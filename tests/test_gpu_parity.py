@@ -325,6 +325,53 @@ def test_database(engine):
     db.close()
 
 
+@pytest.mark.parametrize("cap,dim,n_q", [(700, 4096, 9), (33, 256, 8), (257, 512, 31), (1000, 768, 33), (95, 1024, 64), (3001, 4096, 97),
+                                          (1500, 2048, 129), (64, 4096, 200), (31, 256, 40)])
+def test_database_batched_screen_geometries(engine, cap, dim, n_q):
+    """hfnet_db_query_batch, >= 8 queries: the screen on the bf16 matrix pipe (k_db_sweep: the database's bf16 copy in fragment order, whole
+    32-row tiles; 1-4 query tiles, 1-8 k-parts, a second launch past 128 queries) + the exact chain -- every output equals the exact batched
+    scan's bits (KeyFrameDatabase.cc:86-104), for capacities / descriptor lengths / query counts that fill no tile, with empty slots, near-
+    duplicates and rows around distance 1 from a query."""
+    from hfnet_slam_amd import capi
+    from oracle import oracle as O
+    rng = np.random.default_rng(cap * 7 + n_q)
+    n = max(1, cap - cap // 5)
+    rows = _unit_rows(rng, n, dim)
+    slots = np.random.default_rng(cap).permutation(cap)[:n]
+    base = rows[0]
+    for k, eps in enumerate((0.2, 0.99, 0.9999, 1.0, 1.0001, 1.005, 1.0085, 1.0095, 1.02)):
+        if 1 + k >= n: break
+        v = rng.standard_normal(dim).astype(np.float32); v -= v.dot(base) * base; v /= np.linalg.norm(v)
+        c = 1.0 - eps * eps / 2.0
+        rows[1 + k] = (base * np.float32(c) + v * np.float32(np.sqrt(max(1 - c * c, 0.0)))).astype(np.float32)
+    if n > 12: rows[11] = rows[0]; rows[12] = rows[0] * np.float32(1.5)
+    db = capi.Database(engine, cap, dim)
+    for s, r in zip(slots, rows):
+        db.add(int(s), r)
+    qs = rows[rng.integers(0, n, n_q)] + 0.01 * rng.standard_normal((n_q, dim)).astype(np.float32)
+    qs = (qs / np.linalg.norm(qs, axis=1, keepdims=True)).astype(np.float32)
+    qs[0] = rows[0]
+    if n_q > 2: qs[2] = 0.0
+    try:
+        for mode in (0, 1):
+            engine.set_option("db_gemm_min_queries", 1 << 20)
+            ce, be, se = db.query_batch(qs, mode, want_scores=True)
+            engine.set_option("db_gemm_min_queries", 8)
+            cs, bs, ss = db.query_batch(qs, mode, want_scores=True)
+            assert np.array_equal(ss, se), np.argwhere(ss != se)[:8]
+            assert np.array_equal(bs, be)
+            for i in range(n_q):
+                assert np.array_equal(cs[i][0], ce[i][0]) and np.array_equal(cs[i][1], ce[i][1]), (mode, i)
+        dense = np.zeros((cap, dim), np.float32); dense[slots] = rows
+        occ = np.zeros(cap, bool); occ[slots] = True
+        for i in (0, n_q - 1):
+            ref = np.where(occ, O.db_scores(qs[i], dense), -1.0).astype(np.float32)
+            assert np.array_equal(ss[i], ref)
+    finally:
+        engine.set_option("db_gemm_min_queries", 8)
+        db.close()
+
+
 def test_resampler_entry_point(engine):
     """free-standing Resampler (BaseModel.h:78-80) vs the oracle, incl. border / outside points and batch > 1"""
     from oracle import oracle as O
