@@ -26,7 +26,7 @@ int hfnet_db_create(hfnet_engine* eh, int capacity, int dim, hfnet_db** out) try
     HF_HIP(dev_malloc((void**)&db->d_db, sizeof(float) * (size_t)capacity * dim));
     HF_HIP(dev_malloc((void**)&db->d_occ, (size_t)capacity));
     HF_HIP(dev_malloc((void**)&db->d_q, sizeof(float) * dim));
-    HF_HIP(dev_malloc((void**)&db->d_norm, sizeof(float) * capacity));
+    HF_HIP(dev_malloc((void**)&db->d_norm, sizeof(float) * db_stat_floats(capacity)));
     HF_HIP(dev_malloc(&db->d_hi, db_hi_bytes(capacity, dim)));
     HF_HIP(dev_malloc((void**)&db->d_scores, sizeof(float) * capacity));
     HF_HIP(dev_malloc((void**)&db->d_cand_score, sizeof(float) * capacity));
@@ -41,7 +41,7 @@ int hfnet_db_create(hfnet_engine* eh, int capacity, int dim, hfnet_db** out) try
         std::lock_guard<std::mutex> lk(e.mu);
         e.bounce_discard();
         HF_HIP(hipMemsetAsync(db->d_occ, 0, (size_t)capacity, e.stream));
-        HF_HIP(hipMemsetAsync(db->d_norm, 0, sizeof(float) * capacity, e.stream));
+        HF_HIP(hipMemsetAsync(db->d_norm, 0, sizeof(float) * db_stat_floats(capacity), e.stream));
         HF_TRY(e.sync_host());
     }
     *out = db.release();
@@ -151,21 +151,34 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
     const int parts = gemm ? db_gemm_partials(db->capacity) : 4 * db_batch_workgroups(db->capacity);
     HF_TRY(e.m_key.ensure(sizeof(unsigned int) * Q * parts));
     if (gemm) {
-        HF_TRY(e.m_tn.ensure(sizeof(float) * Q)); HF_TRY(e.m_b.ensure(sizeof(float) * db_gemm_scratch_floats(db->capacity, n_queries, db->dim)));
-        HF_TRY(e.m_f1.ensure(db_hi_bytes(n_queries, db->dim)));      // bf16 copies of the queries
+        HF_TRY(e.m_tn.ensure(sizeof(float) * db_stat_floats(n_queries))); HF_TRY(e.m_b.ensure(sizeof(float) * db_gemm_scratch_floats(db->capacity, n_queries, db->dim)));
+        HF_TRY(e.m_f1.ensure(db_hi_bytes(n_queries, db->dim)));      // 8-bit copies of the queries
     }
     float* d_q = e.m_a.as<float>(); float* d_scores = e.m_s.as<float>(); float* d_cs = e.m_f0.as<float>();
     int32_t* d_slot = e.m_i0.as<int32_t>(); int* d_n = e.m_cnt.as<int>(); float* d_best = e.m_qn.as<float>();
     unsigned int* d_bits = e.m_key.as<unsigned int>();
     HF_TRY(e.h2d(d_q, queries, sizeof(float) * Q * db->dim));
     if (gemm) {
+        int* db_stat = e.opt.match_stats && e.bow_stat() ? e.bow_stat() + 1 : nullptr;
         if (db->norm_dirty) {
             HF_LAUNCH(&e, e.stream, "db_norm", launch_db_prep_hi(db->d_db, db->capacity, db->dim, db->d_norm, db->d_hi, e.stream));
             db->norm_dirty = false;
         }
         HF_LAUNCH(&e, e.stream, "db_qnorm", launch_db_prep_hi(d_q, n_queries, db->dim, e.m_tn.as<float>(), e.m_f1.p, e.stream));
-        HF_LAUNCH(&e, e.stream, "db_screen", launch_db_screen(d_q, e.m_f1.p, n_queries, e.m_tn.as<float>(), db->d_db, db->d_hi, db->d_norm, db->d_occ, db->capacity,
-                                                         db->dim, d_scores, d_bits, e.m_b.as<float>(), e.stream));
+        // (one profiler entry for both launches -- "db_screen", as in every earlier round's figures: an entry costs ~2.5 us of event handling --;
+        //  with "match_stats" set the two are timed apart: "db_sweep" + "db_decide")
+        auto both = [&](int q0) -> hipError_t {
+            hipError_t er = launch_db_sweep(e.m_f1.p, n_queries, q0, db->d_hi, db->capacity, db->dim, e.m_b.as<float>(), e.stream);
+            if (er != hipSuccess) return er;
+            return launch_db_decide(d_q, n_queries, q0, e.m_tn.as<float>(), db->d_db, db->d_norm, db->d_occ, db->capacity, db->dim, d_scores, d_bits,
+                                    e.m_b.as<float>(), e.stream, db_stat);
+        };
+        for (int q0 = 0; q0 < n_queries; q0 += 128) {
+            if (!e.opt.match_stats) { HF_LAUNCH(&e, e.stream, "db_screen", both(q0)); continue; }
+            HF_LAUNCH(&e, e.stream, "db_sweep", launch_db_sweep(e.m_f1.p, n_queries, q0, db->d_hi, db->capacity, db->dim, e.m_b.as<float>(), e.stream));
+            HF_LAUNCH(&e, e.stream, "db_decide", launch_db_decide(d_q, n_queries, q0, e.m_tn.as<float>(), db->d_db, db->d_norm, db->d_occ, db->capacity, db->dim,
+                                                                 d_scores, d_bits, e.m_b.as<float>(), e.stream, db_stat));
+        }
     } else {
         HF_LAUNCH(&e, e.stream, "db_scores_batch", launch_db_scores_batch(d_q, n_queries, db->d_db, db->d_occ, db->capacity, db->dim, d_scores, d_bits, e.stream));
     }

@@ -95,8 +95,8 @@ int Engine::h2d(void* dst_dev, const void* src_host, size_t bytes) {
 }
 int* Engine::bow_stat() {
     if (!m_bow_stat.p) {
-        if (m_bow_stat.ensure(sizeof(int)) != HFNET_OK) return nullptr;
-        if (hipMemsetAsync(m_bow_stat.p, 0, sizeof(int), stream) != hipSuccess) return nullptr;
+        if (m_bow_stat.ensure(2 * sizeof(int)) != HFNET_OK) return nullptr;
+        if (hipMemsetAsync(m_bow_stat.p, 0, 2 * sizeof(int), stream) != hipSuccess) return nullptr;
     }
     return m_bow_stat.as<int>();
 }
@@ -790,15 +790,17 @@ int hfnet_engine_set_option(hfnet_engine* e, const char* name, int value) try {
 int hfnet_engine_get_option(hfnet_engine* e, const char* name, int* value) try {
     API_GUARD(e, "engine"); API_GUARD(value, "value");
     std::lock_guard<std::mutex> lk(e->impl.mu);
-    if (name && std::strcmp(name, "stat_bow_exact") == 0) {
-        // read-only statistic: exact distance evaluations of the SearchByBoW calls since the last read (what the screening GEMM let through: a
-        // broken screen still returns the right matches -- everything is then evaluated exactly -- and this is where it shows); waits for the stream
+    const int stat_ix = !name ? -1 : std::strcmp(name, "stat_bow_exact") == 0 ? 0 : std::strcmp(name, "stat_db_exact") == 0 ? 1 : -1;
+    if (stat_ix >= 0) {
+        // read-only statistics (engine option match_stats): exact distance evaluations of the SearchByBoW calls / exact scores of the screened
+        // batched database queries since the last read -- what the screens let through: a broken screen still returns the right results
+        // (everything is then evaluated exactly), and this is where it shows; waits for the stream
         Engine& en = e->impl;
         HF_HIP(hipSetDevice(en.device));
         int v = 0;
         if (en.m_bow_stat.p) {
-            HF_TRY(en.d2h(&v, en.m_bow_stat.p, sizeof(int)));
-            HF_HIP(hipMemsetAsync(en.m_bow_stat.p, 0, sizeof(int), en.stream));
+            HF_TRY(en.d2h(&v, en.m_bow_stat.as<int>() + stat_ix, sizeof(int)));
+            HF_HIP(hipMemsetAsync(en.m_bow_stat.as<int>() + stat_ix, 0, sizeof(int), en.stream));
             HF_TRY(en.sync_host());
         }
         *value = v;

@@ -114,7 +114,7 @@ struct Options {
                               //    15-18) on split-bf16 operands: the global descriptor within the stated tolerance of the exact path (include/hfnet_hip.h)
     int scores_bf16x3 = 0;    // 1: the 1x1 convolutions of layers 3-7 and the detector head on split-bf16 operands: the SCORE MAP within the stated tolerance of
                               //    the exact path; NMS, threshold scan and top-K run exactly on that map (include/hfnet_hip.h)
-    int match_stats = 0;      // 1: the SearchByBoW calls count their exact distance evaluations (read-only option stat_bow_exact; an atomic per wave: tests / diagnosis)
+    int match_stats = 0;      // 1: the SearchByBoW calls and the screened database queries count their exact evaluations (read-only options stat_bow_exact, stat_db_exact; an atomic per wave / workgroup: tests / diagnosis)
     int join_fused_branch = 0;   // 1: a global branch that contains fused-block kernels is joined before the sampler of a few-frame call (the stop-gap of
                                  // NOTEBOOK.md R4.8 before its cause -- packed f32 instructions, now compiled out -- was found; kept as a diagnostic)
     int desc_bf16x3 = 0;      // 1: the sparse descriptor head (3x3 + 1x1 at the distinct tap cells) on split-bf16 operands: descriptors within the stated
@@ -166,7 +166,7 @@ struct Engine {
     // overflows its list and runs the full path as well.  The screened path counts {overflowed pairs, pairs} on the device, the counts
     // come down behind the call (no synchronisation: whatever has arrived by the next call is used), and after a call in which a
     // quarter of the pairs overflowed the next tri_skip calls go straight to the full path.  The matches are the same either way.
-    DevMem m_bow_stat;                                      // one int: exact evaluations of the SearchByBoW calls since it was last read (bow_stat())
+    DevMem m_bow_stat;                                      // two ints: exact evaluations of the SearchByBoW calls / of the screened database queries since they were last read (bow_stat(), + 1)
     int* bow_stat();                                        // its device address (allocated and zeroed on first use; null if that fails)
     DevMem m_tri_stat;
     int* h_tri_stat = nullptr;                              // pinned {overflowed, pairs}
@@ -453,8 +453,8 @@ struct hfnet_db {
     float* d_db = nullptr;
     unsigned char* d_occ = nullptr;
     float *d_q = nullptr, *d_scores = nullptr, *d_cand_score = nullptr, *d_best = nullptr;
-    float* d_norm = nullptr;       // |d|^2 per slot (tree256 order) and
-    void* d_hi = nullptr;          // the bf16 copy of every row, for the screened batched query: both refreshed in one launch
+    float* d_norm = nullptr;       // per slot: |d|^2 (tree256 order), scale and scaled 1-norm of its 8-bit steps (db_stat_floats), and
+    void* d_hi = nullptr;          // the 8-bit copy of every row (fragment order), for the screened batched query: both refreshed in one launch
     bool norm_dirty = true;        // by the first batched query after rows were added
     int32_t* d_cand_slot = nullptr;
     int* d_n = nullptr;

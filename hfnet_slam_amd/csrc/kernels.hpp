@@ -228,17 +228,23 @@ hipError_t launch_db_filter(const float* scores, int n, int mode, const unsigned
 // scores[q][slot] for n_queries queries (dim <= 4096): the database is read once per 8 queries
 hipError_t launch_db_scores_batch(const float* q, int n_queries, const float* db, const unsigned char* occupied, int n, int dim,
                                   float* scores, unsigned int* best_partial, hipStream_t s);
-// the same scan for many queries (n_queries >= 8), screened on the bf16 matrix pipe: a slot whose crude squared distance (bf16 copies of both
-// vectors, one product) is >= 1 + 9e-3 (|q|^2 + |d|^2) is at distance >= 1 whatever the rounding -- score exactly 0 --, every other occupied
-// slot is scored with launch_db_scores' exact chain: ALL outputs equal the exact scan's bit for bit (kernels_match.hip).
-// norm / hi: |x|^2 in tree256 order and the bf16 copy of every row in the matrix unit's fragment order, db_hi_bytes (launch_db_prep_hi: the database's when rows were added, the queries' per
-// call); best_partial: [n_queries][db_gemm_partials(n)]; scratch: db_gemm_scratch_floats(n, n_queries) floats
+// the same scan for many queries (n_queries >= 8), screened on the integer matrix pipe: a slot whose crude squared distance (8-bit copies of
+// both vectors at their own scales, one exact int32 product, a rigorous bound of the quantisation error from the rows' scales and 1-norms) is
+// >= 1 + the bound is at distance >= 1 whatever the rounding -- score exactly 0 --, every other occupied slot is scored with launch_db_scores'
+// exact chain: ALL outputs equal the exact scan's bit for bit (kernels_match.hip).
+// stat / hi: per row |x|^2 in tree256 order, scale, scaled 1-norm (db_stat_floats) and the 8-bit copy of every row in the matrix unit's
+// fragment order (db_hi_bytes) -- launch_db_prep_hi: the database's when rows were added, the queries' per call; best_partial:
+// [n_queries][db_gemm_partials(n)]; scratch: db_gemm_scratch_floats(n, n_queries, dim) floats
 int db_gemm_partials(int n);
 bool db_screen_supported(int dim);     // descriptor lengths the screened batched query takes (others: the exact batched scan)
 size_t db_gemm_scratch_floats(int n, int n_queries, int dim);
-size_t db_hi_bytes(int n_rows, int dim);   // the bf16 copy of n_rows vectors: whole 32-row tiles in fragment order
-hipError_t launch_db_prep_hi(const float* x, int n_rows, int dim, float* norm, void* hi, hipStream_t s);
-hipError_t launch_db_screen(const float* q, const void* qh, int n_queries, const float* qnorm, const float* db, const void* dbh, const float* dnorm,
-                            const unsigned char* occupied, int n, int dim, float* scores, unsigned int* best_partial, float* scratch, hipStream_t s);
+size_t db_hi_bytes(int n_rows, int dim);   // the 8-bit copy of n_rows vectors: whole 32-row tiles in fragment order
+size_t db_stat_floats(int n_rows);         // |x|^2, scale, scaled 1-norm of the steps per row
+hipError_t launch_db_prep_hi(const float* x, int n_rows, int dim, float* stat, void* hi, hipStream_t s);
+// (up to 128 queries from q0 on per pair of launches)
+hipError_t launch_db_sweep(const void* qh, int n_queries, int q0, const void* dbh, int n, int dim, float* scratch, hipStream_t s);
+hipError_t launch_db_decide(const float* q, int n_queries, int q0, const float* qstat, const float* db, const float* dstat, const unsigned char* occupied,
+                            int n, int dim, float* scores, unsigned int* best_partial, const float* scratch, hipStream_t s,
+                            int* stat /* may be null: += the exact scores computed (engine read-only option stat_db_exact) */);
 
 }  // namespace hfnet

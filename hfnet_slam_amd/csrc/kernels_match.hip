@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <cstdlib>
 #include <type_traits>
 
 #include <cfloat>
@@ -1534,92 +1535,137 @@ __global__ __launch_bounds__(256) void k_db_scores_batch(const float* __restrict
     }
 }
 
-// ---- many queries at once (loop-closure bursts, BASELINE config 5): screen on the bf16 matrix pipe, decide with the exact chain.
+// ---- many queries at once (loop-closure bursts, BASELINE config 5): screen on the integer matrix pipe, decide with the exact chain.
 // The place-recognition score is max(0, 1 - ||q - d||) (KeyFrameDatabase.cc:93): EXACTLY 0 for every keyframe at distance >= 1 from
 // the query -- for descriptors of different places, nearly all of them.  So the batched query needs the exact chain of k_db_scores
-// only for the slots that can be closer than 1, and a crude product is enough to find those:
-//   d2~ = |q|^2 + |d|^2 - 2 q~.d~,   q~ = bf16(q), d~ = bf16(d) (round to nearest even: |x~ - x| <= 2^-8 |x|),
-//   |q~.d~ - q.d| <= (2^-7 + 2^-16) sum|q_i d_i| + 4096 * 2^-24 * 1.01 sum|q_i d_i|   (products of bf16 are exact in fp32; the second term
-//                    bounds the fp32 accumulation of <= 4096 of them in ANY order of merely faithful additions, the k split included)
-//                 <= 8.1e-3 |q||d| <= 4.05e-3 (|q|^2 + |d|^2)
-// => a slot with d2~ >= 1 + 9e-3 (|q|^2 + |d|^2) has a true squared distance >= 1 + 9e-4 (|q|^2 + |d|^2): the exact chain (relative error
-//    <= 2e-6) returns a distance >= 1 and the score 0 -- which is what is written for it.  Every other occupied slot is re-scored with the
-//    exact chain.  All outputs of hfnet_db_query_batch are therefore the exact scan's bits: scores of EVERY slot, best, candidates.
-// (Round 2-3's f32 MFMA form -- S on v_mfma_f32_32x32x2_f32, two exact re-scoring passes around the candidate threshold, non-candidates
-//  within 5e-6 -- took 89 us for 64 queries against 10 000 keyframes; it is deleted.)
-// The database keeps a bf16 copy of its rows for this (2 bytes per element, refreshed with the norms: k_db_prep_frag), and keeps it in the
-// matrix unit's FRAGMENT ORDER -- [32-row tile][16-k step][lane = row & 31 | k-half << 5][8 bf16]: the 1 KB a wave's 64 lanes hand to one
-// v_mfma_f32_32x32x16_bf16 is 1 KB of consecutive memory.  Round 5's k_db_screen (k_db_gemm's structure: 128 rows x 128 queries x a
-// quarter of k per workgroup, both operands through LDS in 64-k chunks, one chunk ahead, two barriers per chunk) streamed the copy at
-// 4.5 TB/s: 24 KB in flight per workgroup, a third of every workgroup's fetches were the QUERIES again (128 KB per workgroup from L2), and
-// a memory round trip per chunk.  k_db_sweep: a workgroup brings its k-part of the queries' fragments into LDS ONCE (by LDS-DMA, <= 128 KB),
-// then every wave streams 32-row tiles of the database straight from memory into registers -- no LDS, no barrier on the database's way,
-// sixteen 1 KB requests in flight per wave -- and multiplies them against the resident fragments.  Queries are the M side, database rows
-// the N side of the product: a lane ends up with ONE row's products, so [part][query][row] is written in 128-byte runs without a transpose.
-typedef __bf16 dbh_t;
-// |x|^2 (tree256 order, as k_sumsq_rows) and the bf16 copy of a 32-row tile in fragment order; rows >= n_rows of the last tile: zeros
-__global__ __launch_bounds__(256) void k_db_prep_frag(const float* __restrict__ x, int n_rows, int dim, float* __restrict__ norm, bf16x8* __restrict__ frag) {
-    constexpr int PP = 1040;                                   // bytes between staged pieces (k_bow_prep_frag)
-    __shared__ __attribute__((aligned(16))) unsigned char st[16 * PP];
-    const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int step = lane >> 2, khalf = (lane >> 1) & 1, e0 = (lane & 1) * 4;
-    const int ks = dim >> 4;
-    f32x4 p[8];
+// only for the slots that can be closer than 1, and a crude product is enough to find those.  The crude product is an INTEGER one: every
+// vector x is kept as 8-bit steps of its own scale,
+//   x_i = s a_i + r_i,   s = max|x| / 127,   a_i = rint(x_i / s) in [-127, 127],   |r_i| <= s / 2 (1 + 1e-4: the fp32 scaling),
+// and for a query (s_q, a) and a database row (s_d, b)
+//   q.d = s_q s_d sum a_i b_i  +  sum s_q a_i r'_i  +  sum r_i s_d b_i  +  sum r_i r'_i
+//   |q.d - s_q s_d sum a_i b_i| <= (s_d / 2) A1 + (s_q / 2) B1 + dim s_q s_d / 4 =: err,   A1 = s_q sum|a_i|,  B1 = s_d sum|b_i|
+// (sum|a_i|, sum|b_i| and the scales are stored with the squared norms: k_db_rowstat, k_db_quant).  sum a_i b_i is EXACT in int32 (<= 4096 * 127^2 per 4096 elements;
+// descriptor lengths up to 2^17 fit), so nothing depends on the order the matrix unit or the k-parts add in.  With
+//   d2~ = |q|^2 + |d|^2 - 2 s_q s_d sum a_i b_i
+// a slot with  d2~ >= 1 + 2.002 err + 1e-4 (|q|^2 + |d|^2)  has a true squared distance >= 1 + 5e-5 (|q|^2 + |d|^2) (the last term covers the
+// fp32 norms, <= 3e-6 relative in tree256 order, and the three roundings of the scaled product): the exact chain (relative error <= 2e-6) returns a
+// distance >= 1 and the score 0 -- which is what is written for it.  Every other occupied slot is re-scored with the exact chain (anything not
+// finite fails the comparison and goes there too).  All outputs of hfnet_db_query_batch are therefore the exact scan's bits: scores of EVERY
+// slot, best, candidates.  For unit vectors of 4096 roughly Gaussian components: s ~ 5e-4, A1 ~ 51, err ~ 0.027: slots beyond d2 = 1.055 are
+// ruled out (the bf16 screen of rounds 4-6a: 1.018, at twice the bytes).
+// History: round 2-3's f32 MFMA form (S on v_mfma_f32_32x32x2_f32, two exact re-scoring passes) took 89 us for 64 queries against 10 000
+// keyframes of 4096; the bf16 screen k_db_screen (k_db_gemm's structure: 128 rows x 128 queries x a quarter of k per workgroup, both operands
+// through LDS in 64-k chunks, two barriers per chunk) 18.3 us -- 24 KB in flight per workgroup, a third of every workgroup's fetches the QUERIES
+// again; the same product as a sweep over a bf16 copy in fragment order 17.4 us: 3.5 us of launch / prologue / epilogue + the copy's 82 MB at
+// 5.9 TB/s, which is what the memory system gives (half the descriptor length: 10.5 us).  What is left is the number of bytes: one byte per
+// element.
+// The copy is kept in the matrix unit's FRAGMENT ORDER -- [32-row tile][32-k step][lane = row & 31 | k-half << 5][16 x i8]: the 1 KB a wave's
+// 64 lanes hand to one v_mfma_i32_32x32x32_i8 is 1 KB of consecutive memory.  k_db_sweep: a workgroup brings its k-part of the queries'
+// fragments into LDS ONCE (by LDS-DMA, <= 128 KB), then every wave streams 32-row tiles of the database straight from memory into registers
+// -- no LDS, no barrier on the database's way, sixteen 1 KB requests in flight per wave -- and multiplies them against the resident fragments.
+// Queries are the M side, database rows the N side of the product: a lane ends up with ONE row's sums, so [part][query][row] is written in
+// 128-byte runs without a transpose.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+struct DbRowStat { float norm, scale; int l1; float pad; };   // |x|^2 (tree256 order, as k_sumsq_rows), s, sum|a_i|
+// a row's statistics: one wave per row, sixteen 1 KB requests in flight
+__global__ __launch_bounds__(256) void k_db_rowstat(const float* __restrict__ x, int n_rows, int dim, DbRowStat* __restrict__ stat) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    const float* __restrict__ xr = x + (long long)row * dim;
+    f32x4 p = {0.f, 0.f, 0.f, 0.f};
+    float m = 0.0f;
+#pragma unroll 1
+    for (int kseg = 0; kseg < dim; kseg += 4096) {
+        const int seg = min(4096, dim - kseg);
+        f32x4 v[16];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) p[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < dim; k0 += 256) {
+        for (int j = 0; j < 16; ++j) {                         // (no branch around a request: every join would wait for all of them)
+            const f32x4 t = *(const f32x4*)(xr + kseg + (j * 256 < seg ? j * 256 : 0) + lane * 4);
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int r = wave * 8 + rr, row = tile * 32 + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < n_rows) v = *(const f32x4*)(x + (long long)row * dim + k0 + lane * 4);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) p[rr][c] = fmaf(v[c], v[c], p[rr][c]);
-            bf16x4 hv;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) hv[c] = (__bf16)v[c];
-            *(bf16x4*)(st + step * PP + (khalf * 32 + r) * 16 + e0 * 2) = hv;
+            for (int c = 0; c < 4; ++c) v[j][c] = j * 256 < seg ? t[c] : 0.0f;
         }
-        __syncthreads();
-        bf16x8* __restrict__ dst = frag + ((long long)tile * ks + (k0 >> 4)) * 64;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dst[(j * 4 + wave) * 64 + lane] = *(const bf16x8*)(st + (j * 4 + wave) * PP + lane * 16);
-        __syncthreads();
+        for (int j = 0; j < 16; ++j)                           // (zeros beyond the row's end change neither the chain's value nor the maximum)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { p[c] = fmaf(v[j][c], v[j][c], p[c]); m = fmaxf(m, fabsf(v[j][c])); }
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    const float ss = tree256_wave4(p);
+    if (lane == 0) stat[row] = DbRowStat{ss, m / 127.0f, 0, 0.0f};
+}
+// the 8-bit steps of 32 rows x 512 elements (16 pieces of 1 KB) per workgroup, a wave: eight rows, all their requests in flight; sum|a_i| by
+// integer atomics (exact in any order).  Rows >= n_rows of the last tile: zeros.  (One workgroup per 32-row tile was 39 us for a call's 64
+// queries: a single CU's vector ALU walking 131 072 elements.)
+__global__ __launch_bounds__(256) void k_db_quant(const float* __restrict__ x, int n_rows, int dim, DbRowStat* __restrict__ stat, i32x4* __restrict__ frag) {
+    constexpr int PP = 1040;                                   // bytes between staged pieces (1 KB + 16: the eight k-steps a row's lanes write go to different banks)
+    __shared__ __attribute__((aligned(16))) unsigned char st[16 * PP];
+    const int tile = blockIdx.x, k0 = blockIdx.y * 512, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_half = min(2, (dim - k0) >> 8);               // (dim is a multiple of 256: the last chunk may be half)
+    f32x4 v[8][2];
+    float inv[8];
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
         const int row = tile * 32 + wave * 8 + rr;
-        const float ss = tree256_wave4(p[rr]);
-        if (lane == 0 && row < n_rows) norm[row] = ss;
+        const float* __restrict__ xr = x + (long long)min(row, n_rows - 1) * dim + k0 + lane * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) v[rr][h] = *(const f32x4*)(xr + (h < n_half ? h * 256 : 0));
+        const float sc = stat[min(row, n_rows - 1)].scale;
+        inv[rr] = row < n_rows && sc > 0.0f ? 1.0f / sc : 0.0f;     // (rows that do not exist: zeros)
     }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = wave * 8 + rr, row = tile * 32 + r;
+        float l1 = 0.0f;                                       // (<= 8 x 127 per lane: exact)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            unsigned w = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // |x| <= 127 s (1 + 2^-23), the reciprocal and the product add 2^-23: the nearest integer is within [-127, 127]; NaN -> 0
+                const float a = rintf(v[rr][h][c] * inv[rr]);
+                l1 += h < n_half ? fabsf(a) : 0.0f;            // (a half chunk's second half was read from the first half's address: not counted)
+                w |= ((unsigned)(int)a & 255u) << (8 * c);
+            }
+            // element 256 h + 4 lane + c of the chunk: step 8 h + (lane >> 3), k-half (lane >> 2) & 1, byte 4 (lane & 3) + c
+            if (h < n_half) *(unsigned*)(st + (8 * h + (lane >> 3)) * PP + ((((lane >> 2) & 1) * 32 + r) * 16) + (lane & 3) * 4) = w;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) l1 += __shfl_xor(l1, off, 64);
+        if (lane == 0 && row < n_rows) atomicAdd(&stat[row].l1, (int)l1);
+    }
+    __syncthreads();
+    i32x4* __restrict__ dst = frag + ((long long)tile * (dim >> 5) + (k0 >> 5)) * 64;
+    for (int pc = wave; pc < 8 * n_half; pc += 4) dst[pc * 64 + lane] = *(const i32x4*)(st + pc * PP + lane * 16);
 }
 
 #define DBS_WAVES 8
-#define DBS_RING 16                                           // 1 KB requests a wave keeps in flight, and the unit of the k loop (three / four query tiles: 8 -- registers)
-// k-steps per part for NT query tiles: NT * ksp KB of LDS (<= 128 KB), parts * NT <= 8 slabs of partial sums where the descriptor length allows
+// 32-k steps per part for NT query tiles: NT * ksp KB of LDS (<= 128 KB), as few parts as that allows (every part is a slab of partial sums
+// k_db_decide reads back: 1.1 us per 5 MB measured) -- HFNET's 4096: two parts for <= 64 queries, four beyond
 __host__ __device__ static inline int dbs_ksp(int nt, int dim) {
-    const int cap = nt == 2 ? 64 : 32, units = dim >> 8;     // (units of 16 k-steps: dim is a multiple of 256)
+    const int cap = nt <= 2 ? 64 : 32, units = dim >> 8;     // (units of eight steps: dim is a multiple of 256)
     int d = 1;
-    for (int c = 1; c <= units && 16 * c <= cap; ++c)
+    for (int c = 1; c <= units && 8 * c <= cap; ++c)
         if (units % c == 0) d = c;
-    return 16 * d;
+    return 8 * d;
 }
-template <int NT>
-__global__ __launch_bounds__(DBS_WAVES * 64, 1) void k_db_sweep(const bf16x8* __restrict__ qfrag, int n_queries, int q0, const bf16x8* __restrict__ dbfrag, int n_tiles,
-                                                                int ks /* dim / 16 */, int ksp, int parts, int groups,
-                                                                float* __restrict__ partial /* [parts][NT * 32][n_tiles * 32] */) {
+// RING: 1 KB requests a wave keeps in flight, and the unit of the k loop (ksp is a multiple of it)
+template <int NT, int RING>
+__global__ __launch_bounds__(DBS_WAVES * 64, 1) void k_db_sweep(const i32x4* __restrict__ qfrag, int q0, const i32x4* __restrict__ dbfrag, int n_tiles,
+                                                                int ks /* dim / 32 */, int ksp, int parts, int groups,
+                                                                int* __restrict__ partial /* [parts][NT * 32][n_tiles * 32] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [NT][ksp][64 lanes][16 B]: the queries' fragments of this part
-    constexpr int RING = NT <= 2 ? DBS_RING : DBS_RING / 2;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, r = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int part = blockIdx.x % parts, g = blockIdx.x / parts;           // (parts of one k range share an XCD's L2 when parts divides 8)
+    const int part = blockIdx.x % parts, g = blockIdx.x / parts;           // (the workgroups of one k range share an XCD's L2 when parts divides 8)
     {
         const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
         const unsigned lane16 = (unsigned)lane * 16u;
-        const bf16x8* qb = qfrag + ((long long)(q0 >> 5) * ks + (long long)part * ksp) * 64;
+        const i32x4* qb = qfrag + ((long long)(q0 >> 5) * ks + (long long)part * ksp) * 64;
         for (int pc = wave; pc < NT * ksp; pc += DBS_WAVES) {
             const int nt = pc / ksp, s = pc - nt * ksp;
-            const bf16x8* src = qb + ((long long)nt * ks + s) * 64;       // uniform
+            const i32x4* src = qb + ((long long)nt * ks + s) * 64;        // uniform
             const unsigned dst = ldsb + (unsigned)pc * 1024u;
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(src), "v"(lane16), "s"(dst) : "memory", "m0");
         }
@@ -1627,8 +1673,8 @@ __global__ __launch_bounds__(DBS_WAVES * 64, 1) void k_db_sweep(const bf16x8* __
     const int stride = groups * DBS_WAVES;
     int t = g + groups * wave;
     const bool have = t < n_tiles;
-    bf16x8 b[RING];
-    const bf16x8* cur = dbfrag + ((long long)(have ? t : 0) * ks + (long long)part * ksp) * 64 + lane;
+    i32x4 b[RING];
+    const i32x4* cur = dbfrag + ((long long)(have ? t : 0) * ks + (long long)part * ksp) * 64 + lane;
     if (have) {
 #pragma unroll
         for (int j = 0; j < RING; ++j) {                       // (in this order: the waits of the loop below count requests)
@@ -1640,34 +1686,34 @@ __global__ __launch_bounds__(DBS_WAVES * 64, 1) void k_db_sweep(const bf16x8* __
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!have) return;
-    int pt = t, ps = RING;                                // the next batch to request: k-steps ps .. ps + 15 of tile pt
+    int pt = t, ps = RING;                                    // the next batch to request: k-steps ps .. ps + RING - 1 of tile pt
     if (ps == ksp) { ps = 0; pt += stride; }
-    f32x16 acc[NT];
+    i32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0;
     int sb = 0;
     const long long npad = (long long)n_tiles * 32;
     for (;;) {
         // the queries' fragments of a step are read one step ahead of its MFMAs; nothing else moves across a step (left alone the scheduler reads
         // a whole batch's fragments first: 128 registers for four query tiles)
         const unsigned char* ap = smem + ((size_t)sb * 64 + lane) * 16;
-        bf16x8 a[2][NT];
+        i32x4 a[2][NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) a[0][nt] = *(const bf16x8*)(ap + (size_t)nt * ksp * 1024);
+        for (int nt = 0; nt < NT; ++nt) a[0][nt] = *(const i32x4*)(ap + (size_t)nt * ksp * 1024);
         const bool more = pt < n_tiles;                       // (wave-uniform)
-        const bf16x8* nx = dbfrag + ((long long)(more ? pt : t) * ks + (long long)part * ksp + ps) * 64 + lane;
+        const i32x4* nx = dbfrag + ((long long)(more ? pt : t) * ks + (long long)part * ksp + ps) * 64 + lane;
         auto batch = [&](auto pf) {
 #pragma unroll
             for (int j = 0; j < RING; ++j) {
                 if (j + 1 < RING) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) a[(j + 1) & 1][nt] = *(const bf16x8*)(ap + ((size_t)nt * ksp + j + 1) * 1024);
+                    for (int nt = 0; nt < NT; ++nt) a[(j + 1) & 1][nt] = *(const i32x4*)(ap + ((size_t)nt * ksp + j + 1) * 1024);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j & 1][nt], b[j], acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[j & 1][nt], b[j], acc[nt], 0, 0, 0);
                 if (decltype(pf)::value) b[j] = nx[j * 64];
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1677,14 +1723,16 @@ __global__ __launch_bounds__(DBS_WAVES * 64, 1) void k_db_sweep(const bf16x8* __
         if (ps == ksp) { ps = 0; pt += stride; }
         if (sb == ksp) {
             // lane (r, half), register reg of tile nt: query nt * 32 + (reg & 3) + 8 (reg >> 2) + 4 half, database row t * 32 + r
-            float* out = partial + ((long long)part * (NT * 32)) * npad + (long long)t * 32 + r;
+            long long np = npad;
+            asm volatile("" : "+s"(np));                       // (opaque: the 16 NT store addresses are NOT loop invariants to be kept in registers)
+            int* out = partial + ((long long)part * (NT * 32)) * np + (long long)t * 32 + r;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int m = nt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                    out[(long long)m * npad] = acc[nt][reg];   // (rows of queries that do not exist: zeros times the database, never read)
-                    acc[nt][reg] = 0.0f;
+                    out[(long long)m * np] = acc[nt][reg];     // (rows of queries that do not exist: zeros times the database, never read)
+                    acc[nt][reg] = 0;
                 }
             sb = 0; t += stride;
             if (t >= n_tiles) break;
@@ -1695,15 +1743,15 @@ __global__ __launch_bounds__(DBS_WAVES * 64, 1) void k_db_sweep(const bf16x8* __
 // exact score of one (query, slot): ||q - d|| in tree256 order, the chain of k_db_scores
 __device__ __forceinline__ float db_exact_u(const float* __restrict__ q, const float* __restrict__ d, int dim, int lane) {
     f32x4 p = {0.f, 0.f, 0.f, 0.f};
-    // (eight steps' loads in flight: the handful of slots a batch re-scores decide how long k_db_decide runs -- one wave walking 32 KB with a memory
-    //  round trip per step was 8 of its 11 us; the chain per (lane, component) still runs k ascending)
+    // (sixteen steps' loads in flight: the handful of slots a batch re-scores decide how long k_db_decide runs -- one wave walking 32 KB with a
+    //  memory round trip per step was 8 of its 11 us; the chain per (lane, component) still runs k ascending)
     int k0 = 0;
-    for (; k0 + 2048 <= dim; k0 += 2048) {
-        f32x4 dv[8], qv[8];
+    for (; k0 + 4096 <= dim; k0 += 4096) {
+        f32x4 dv[16], qv[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { dv[j] = *(const f32x4*)(d + k0 + j * 256 + lane * 4); qv[j] = *(const f32x4*)(q + k0 + j * 256 + lane * 4); }
+        for (int j = 0; j < 16; ++j) { dv[j] = *(const f32x4*)(d + k0 + j * 256 + lane * 4); qv[j] = *(const f32x4*)(q + k0 + j * 256 + lane * 4); }
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 16; ++j)
 #pragma unroll
             for (int c = 0; c < 4; ++c) { const float df = qv[j][c] - dv[j][c]; p[c] = fmaf(df, df, p[c]); }
     }
@@ -1715,91 +1763,140 @@ __device__ __forceinline__ float db_exact_u(const float* __restrict__ q, const f
     return 1 - sqrtf(tree256_wave4(p));
 }
 
-// partial sums of the k-parts -> d2~; decide; re-score what has to be; scores (clamped at 0, -1 for empty slots) and the per-wave
-// maxima k_db_filter reduces.  One workgroup = 256 slots of one query.
-__global__ __launch_bounds__(256) void k_db_decide(const float* __restrict__ partial, int qb, int q0, const float* __restrict__ q, const float* __restrict__ db,
-                                                   const float* __restrict__ qnorm, const float* __restrict__ dnorm, const unsigned char* __restrict__ occupied,
-                                                   int n, int dim, float* __restrict__ scores, unsigned int* __restrict__ best_bits, int n_partials, int parts, long long npad) {
-    __shared__ int list[256];
-    __shared__ float exact[256];
+// integer sums of the k-parts -> d2~; decide; re-score what has to be; scores (clamped at 0, -1 for empty slots) and the per-wave
+// maxima k_db_filter reduces.  One workgroup = 256 slots x DBD_Q queries: a slot's statistics are read once for eight queries and a thread has
+// all its partial sums in flight together (one workgroup per (256 slots, query): 2 560 of them for 64 queries x 10 000 slots, each reading the
+// slots' 16-byte statistics again -- 8.4 us).
+#define DBD_Q 8
+__global__ __launch_bounds__(256) void k_db_decide(const int* __restrict__ partial, int qb, int q0, int nq, const float* __restrict__ q, const float* __restrict__ db,
+                                                   const DbRowStat* __restrict__ qstat, const DbRowStat* __restrict__ dstat, const unsigned char* __restrict__ occupied,
+                                                   int n, int dim, float* __restrict__ scores, unsigned int* __restrict__ best_bits, int n_partials, int parts, long long npad, int* __restrict__ stat) {
+    __shared__ int list[DBD_Q * 256];                         // (query << 8 | thread) of the pairs the exact chain takes
+    __shared__ float exact[DBD_Q * 256];
     __shared__ int n_list;
-    const int c = blockIdx.y, qi = q0 + c, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.y * DBD_Q, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x * 256 + tid;
     if (tid == 0) n_list = 0;
     __syncthreads();
-    float u = -1.0f;                                           // empty slot
-    int mine = -1;
-    if (i < n && occupied[i]) {
-        float p = 0.0f;                                        // (any order of faithful additions: the band's bound does not care)
-        for (int w = 0; w < parts; ++w) p += partial[((long long)w * qb + c) * npad + i];
-        const float t = qnorm[qi] + dnorm[i];
-        const float d2 = fmaf(-2.0f, p, t);
-        u = 0.0f;
-        if (!(d2 >= 1.0f + 9e-3f * t)) { mine = atomicAdd(&n_list, 1); list[mine] = i; }      // (NaN -- non-finite descriptors -- goes to the exact chain too)
+    float u[DBD_Q];
+    int mine[DBD_Q];
+    const bool occ = i < n && occupied[i];
+    {
+        // (no branch around a request -- every join would wait for all of them: clamped addresses, four parts x eight queries in flight)
+        int dot[DBD_Q];
+#pragma unroll
+        for (int j = 0; j < DBD_Q; ++j) dot[j] = 0;
+        const int ic = min(i, n - 1);
+        for (int w0 = 0; w0 < parts; w0 += 4) {
+            int pv[4][DBD_Q];
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int j = 0; j < DBD_Q; ++j) pv[w][j] = partial[((long long)min(w0 + w, parts - 1) * qb + min(c0 + j, nq - 1)) * npad + ic];
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int j = 0; j < DBD_Q; ++j) dot[j] += w0 + w < parts ? pv[w][j] : 0;
+        }
+        const DbRowStat ds = dstat[ic];
+#pragma unroll
+        for (int j = 0; j < DBD_Q; ++j) {
+            u[j] = occ ? 0.0f : -1.0f;                         // (-1: empty slot)
+            mine[j] = -1;
+            if (occ && c0 + j < nq) {
+                const DbRowStat qs = qstat[q0 + c0 + j];       // (uniform)
+                const float t = qs.norm + ds.norm;
+                const float err = ds.scale * qs.scale * (0.5f * ((float)qs.l1 + (float)ds.l1) + 0.25f * (float)dim);      // (s_d / 2) A1 + (s_q / 2) B1 + dim s_q s_d / 4
+                const float d2 = fmaf(-2.0f, qs.scale * ds.scale * (float)dot[j], t);
+                if (!(d2 >= 1.0f + 2.002f * err + 1e-4f * t)) { mine[j] = atomicAdd(&n_list, 1); list[mine[j]] = j << 8 | tid; }      // (anything not finite goes to the exact chain too)
+            }
+        }
     }
     __syncthreads();
     const int cnt = n_list;
+    if (stat && tid == 0 && cnt) atomicAdd(stat, cnt);
     for (int k = wave; k < cnt; k += 4) {
-        const float e = db_exact_u(q + (long long)qi * dim, db + (long long)list[k] * dim, dim, lane);
-        if (lane == 0) exact[k] = e;
+        const int e = list[k], j = e >> 8, slot = blockIdx.x * 256 + (e & 255);
+        const float ex = db_exact_u(q + (long long)(q0 + c0 + j) * dim, db + (long long)slot * dim, dim, lane);
+        if (lane == 0) exact[k] = ex;
     }
     __syncthreads();
-    if (mine >= 0) u = fmaxf(exact[mine], 0.0f);
-    if (i < n) scores[(long long)qi * n + i] = u;
-    float best = fmaxf(u, 0.0f);
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off, 64));
-    if (lane == 0) best_bits[(long long)qi * n_partials + blockIdx.x * 4 + wave] = __float_as_uint(best);
+    for (int j = 0; j < DBD_Q; ++j) {
+        if (c0 + j >= nq) break;                               // (uniform)
+        if (mine[j] >= 0) u[j] = fmaxf(exact[mine[j]], 0.0f);
+        const int qi = q0 + c0 + j;
+        if (i < n) scores[(long long)qi * n + i] = u[j];
+        float best = fmaxf(u[j], 0.0f);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off, 64));
+        if (lane == 0) best_bits[(long long)qi * n_partials + blockIdx.x * 4 + wave] = __float_as_uint(best);
+    }
 }
 
-hipError_t launch_db_prep_hi(const float* x, int n_rows, int dim, float* norm, void* hi, hipStream_t s) {
+hipError_t launch_db_prep_hi(const float* x, int n_rows, int dim, float* stat, void* hi, hipStream_t s) {
     if (n_rows <= 0) return hipSuccess;
     if (dim % 256) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_db_prep_frag, dim3((n_rows + 31) / 32), dim3(256), 0, s, x, n_rows, dim, norm, (bf16x8*)hi);
+    hipLaunchKernelGGL(k_db_rowstat, dim3((n_rows + 3) / 4), dim3(256), 0, s, x, n_rows, dim, (DbRowStat*)stat);
+    hipLaunchKernelGGL(k_db_quant, dim3((n_rows + 31) / 32, (dim + 511) / 512), dim3(256), 0, s, x, n_rows, dim, (DbRowStat*)stat, (i32x4*)hi);
     return hipGetLastError();
 }
 
 int db_gemm_partials(int n) { return 4 * ((n + 255) / 256); }
-bool db_screen_supported(int dim) { return dim > 0 && dim % 256 == 0; }
-size_t db_hi_bytes(int n_rows, int dim) { return (size_t)2 * (size_t)((n_rows + 31) & ~31) * (size_t)dim; }     // whole 32-row tiles
+bool db_screen_supported(int dim) { return dim > 0 && dim % 256 == 0 && dim <= (1 << 17); }      // (int32 sums: dim * 127^2 < 2^31)
+size_t db_hi_bytes(int n_rows, int dim) { return (size_t)((n_rows + 31) & ~31) * (size_t)dim; }     // whole 32-row tiles, one byte per element
+size_t db_stat_floats(int n_rows) { return (size_t)4 * (size_t)n_rows; }
 size_t db_gemm_scratch_floats(int n, int n_queries, int dim) {
     const int nt = (std::min(128, n_queries) + 31) / 32;
-    return (size_t)((dim >> 4) / dbs_ksp(nt, dim)) * (size_t)(nt * 32) * (size_t)((n + 31) & ~31);
+    return (size_t)((dim >> 5) / dbs_ksp(nt, dim)) * (size_t)(nt * 32) * (size_t)((n + 31) & ~31);
 }
 
-// scores of n_queries queries against the n slots of the database (see above): q / db: f32 rows, qh / dbh: their bf16 copies in fragment
-// order, qnorm / dnorm: |.|^2 (launch_db_prep_hi); best_partial: [n_queries][db_gemm_partials(n)]; scratch: db_gemm_scratch_floats floats
-hipError_t launch_db_screen(const float* q, const void* qh, int n_queries, const float* qnorm, const float* db, const void* dbh, const float* dnorm,
-                            const unsigned char* occupied, int n, int dim, float* scores, unsigned int* best_partial, float* scratch, hipStream_t s) {
-    if (n <= 0 || n_queries <= 0) return hipSuccess;
+// scores of up to 128 queries q0 .. of n_queries against the n slots of the database (see above), in two launches: q / db: f32 rows, qh /
+// dbh: their 8-bit copies in fragment order, qstat / dstat: DbRowStat per row (launch_db_prep_hi); best_partial: [n_queries][db_gemm_partials(n)];
+// scratch: db_gemm_scratch_floats floats
+hipError_t launch_db_sweep(const void* qh, int n_queries, int q0, const void* dbh, int n, int dim, float* scratch, hipStream_t s) {
+    if (n <= 0 || q0 >= n_queries) return hipSuccess;
     if (!db_screen_supported(dim)) return hipErrorInvalidValue;
     static std::once_flag attr_once;                                    // > 64 KB of dynamic LDS has to be requested once
     std::call_once(attr_once, []() {
-        (void)hipFuncSetAttribute((const void*)k_db_sweep<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        (void)hipFuncSetAttribute((const void*)k_db_sweep<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        (void)hipFuncSetAttribute((const void*)k_db_sweep<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        (void)hipFuncSetAttribute((const void*)k_db_sweep<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)k_db_sweep<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)k_db_sweep<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)k_db_sweep<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)k_db_sweep<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)k_db_sweep<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)k_db_sweep<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     });
-    const int n_tiles = (n + 31) / 32, ks = dim >> 4;
-    const long long npad = (long long)n_tiles * 32;
-    const int n_bp = db_gemm_partials(n);
-    for (int q0 = 0; q0 < n_queries; q0 += 128) {
-        const int nt = (std::min(128, n_queries - q0) + 31) / 32, qb = nt * 32, nq = std::min(qb, n_queries - q0);
-        const int ksp = dbs_ksp(nt, dim), parts = ks / ksp;
-        // one workgroup per CU where the database has the tiles for it: 256 / parts groups, a group's wave w takes tiles g + groups (w + 8 j)
-        const int groups = std::max(1, std::min(n_tiles, 256 / parts));
-        const dim3 grid((unsigned)(groups * parts));
-        const size_t lds = (size_t)nt * ksp * 1024;
-        const bf16x8* qf = (const bf16x8*)qh; const bf16x8* df = (const bf16x8*)dbh;
-        switch (nt) {
-            case 1: hipLaunchKernelGGL((k_db_sweep<1>), grid, dim3(DBS_WAVES * 64), lds, s, qf, n_queries, q0, df, n_tiles, ks, ksp, parts, groups, scratch); break;
-            case 2: hipLaunchKernelGGL((k_db_sweep<2>), grid, dim3(DBS_WAVES * 64), lds, s, qf, n_queries, q0, df, n_tiles, ks, ksp, parts, groups, scratch); break;
-            case 3: hipLaunchKernelGGL((k_db_sweep<3>), grid, dim3(DBS_WAVES * 64), lds, s, qf, n_queries, q0, df, n_tiles, ks, ksp, parts, groups, scratch); break;
-            default: hipLaunchKernelGGL((k_db_sweep<4>), grid, dim3(DBS_WAVES * 64), lds, s, qf, n_queries, q0, df, n_tiles, ks, ksp, parts, groups, scratch); break;
-        }
-        hipLaunchKernelGGL(k_db_decide, dim3((n + 255) / 256, nq), dim3(256), 0, s, scratch, qb, q0, q, db, qnorm, dnorm, occupied, n, dim, scores,
-                           best_partial, n_bp, parts, npad);
+    const int n_tiles = (n + 31) / 32, ks = dim >> 5;
+    const int nt = (std::min(128, n_queries - q0) + 31) / 32;
+    const int ksp = dbs_ksp(nt, dim), parts = ks / ksp;
+    // one workgroup per CU where the database has the tiles for it: 256 / parts groups, a group's wave w takes tiles g + groups (w + 8 j)
+    const int groups = std::max(1, std::min(n_tiles, 256 / parts));
+    const dim3 grid((unsigned)(groups * parts)), block(DBS_WAVES * 64);
+    const size_t lds = (size_t)nt * ksp * 1024;
+    const i32x4* qf = (const i32x4*)qh; const i32x4* df = (const i32x4*)dbh;
+    int* part_sums = (int*)scratch;
+    const bool deep = ksp % 16 == 0;
+    switch (nt) {
+        case 1: if (deep) hipLaunchKernelGGL((k_db_sweep<1, 16>), grid, block, lds, s, qf, q0, df, n_tiles, ks, ksp, parts, groups, part_sums);
+                else hipLaunchKernelGGL((k_db_sweep<1, 8>), grid, block, lds, s, qf, q0, df, n_tiles, ks, ksp, parts, groups, part_sums);
+                break;
+        case 2: if (deep) hipLaunchKernelGGL((k_db_sweep<2, 16>), grid, block, lds, s, qf, q0, df, n_tiles, ks, ksp, parts, groups, part_sums);
+                else hipLaunchKernelGGL((k_db_sweep<2, 8>), grid, block, lds, s, qf, q0, df, n_tiles, ks, ksp, parts, groups, part_sums);
+                break;
+        case 3: hipLaunchKernelGGL((k_db_sweep<3, 8>), grid, block, lds, s, qf, q0, df, n_tiles, ks, ksp, parts, groups, part_sums); break;
+        default: hipLaunchKernelGGL((k_db_sweep<4, 8>), grid, block, lds, s, qf, q0, df, n_tiles, ks, ksp, parts, groups, part_sums); break;
     }
+    return hipGetLastError();
+}
+hipError_t launch_db_decide(const float* q, int n_queries, int q0, const float* qstat, const float* db, const float* dstat, const unsigned char* occupied,
+                            int n, int dim, float* scores, unsigned int* best_partial, const float* scratch, hipStream_t s, int* stat) {
+    if (n <= 0 || q0 >= n_queries) return hipSuccess;
+    if (!db_screen_supported(dim)) return hipErrorInvalidValue;
+    const int n_tiles = (n + 31) / 32, ks = dim >> 5;
+    const int nt = (std::min(128, n_queries - q0) + 31) / 32, qb = nt * 32, nq = std::min(qb, n_queries - q0);
+    const int parts = ks / dbs_ksp(nt, dim);
+    hipLaunchKernelGGL(k_db_decide, dim3((n + 255) / 256, (nq + DBD_Q - 1) / DBD_Q), dim3(256), 0, s, (const int*)scratch, qb, q0, nq, q, db, (const DbRowStat*)qstat,
+                       (const DbRowStat*)dstat, occupied, n, dim, scores, best_partial, db_gemm_partials(n), parts, (long long)n_tiles * 32, stat);
     return hipGetLastError();
 }
 

@@ -17,8 +17,8 @@
  *
  * Numeric contract: fp32 end to end (f32 MFMA, fused multiply-add chains in the order fixed by
  * the CPU oracle, oracle/hfnet_oracle.h) -- keypoint coordinates / match indices / candidate
- * indices are bit-exact against the oracle, float outputs are bit-exact; the one exception is the
- * scores of non-candidate slots of the batched database scan for >= 8 queries (hfnet_db_query_batch), stated there.
+ * indices are bit-exact against the oracle, float outputs are bit-exact (the tolerance mode -- engine options "scores_bf16x3",
+ * "desc_bf16x3", "global_bf16x3", all off by default -- states its own contract below).
  */
 #ifndef HFNET_HIP_H
 #define HFNET_HIP_H
@@ -92,7 +92,7 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *   "two_streams" (3)   0 one stream; 1 fork after layer 7; 2 fork after the detector conv; 3 = 2 + deferred join
  *   "conv_wlds" (1)     3x3 head convolutions: weights staged through LDS once per workgroup (0: every wave reads them)
  *   "graph" (1), "pinned_frames" (4): host-pointer extractor calls
- *   "db_gemm_min_queries" (8): hfnet_db_query_batch screens on the bf16 matrix pipe from this many queries on (same bits either way)
+ *   "db_gemm_min_queries" (8): hfnet_db_query_batch screens on the integer matrix pipe from this many queries on (same bits either way)
  *   "tail_fuse" (4)     calls of up to this many frames run layers 8-18 with the single-frame kernels (depthwise + projection
  *                       in one launch, short-latency MFMA chains); 0: never
  *   "pyramid_fuse" (4)  calls of up to this many frames: the pyramid resize chain as one launch
@@ -114,6 +114,10 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *                       with too many of them goes through the full f32 GEMM instead, and after a call in which a quarter of the
  *                       pairs did, the next 16 calls skip the screen (writing the option resets that).  Same matches, bit for bit
  *   "copy_threads" (64 = by core count): helper threads for the staging copies of host-pointer batch calls (replicas sharing a host)
+ *   "match_stats" (0)   1: the SearchByBoW calls and the screened batched database queries count what their screens let through -- exact
+ *                       distance evaluations / exactly scored (query, keyframe) pairs -- into the read-only options "stat_bow_exact" /
+ *                       "stat_db_exact" (hfnet_engine_get_option reads AND clears; waits for the stream).  A screen that lets everything
+ *                       through still returns the right results; this is where it shows (tests, diagnosis)
  * Values are >= 0.
  * Every setting of the extractor and matcher switches ABOVE produces the same bits (tests/test_gpu_parity.py).
  *
@@ -350,13 +354,17 @@ int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slo
  * entries); best_score: [n_queries] or NULL; scores_all: [n_queries][capacity] or NULL.
  *  - fewer than "db_gemm_min_queries" (8) queries: the exact scan, the database crosses HBM once per 8 queries; per query
  *    EVERY result equals hfnet_db_query's bit for bit (dim <= 4096);
- *  - otherwise (dim % 512 == 0): the score is EXACTLY 0 for every keyframe at distance >= 1 from the query, so a crude product on
- *    the bf16 matrix pipe (the database keeps a bf16 copy of its rows, + 2 bytes per element, refreshed with the first batched
- *    query after an add) only has to find the slots that can be closer: d2~ = |q|^2 + |d|^2 - 2 bf16(q).bf16(d) deviates from the
- *    true squared distance by at most 8.1e-3 (|q|^2 + |d|^2) (2^-8 per rounded operand + fp32 accumulation in any order), a slot with
- *    d2~ >= 1 + 9e-3 (|q|^2 + |d|^2) is written as 0, every other occupied slot is scored with hfnet_db_query's exact chain.
+ *  - otherwise (dim <= 131072): the score is EXACTLY 0 for every keyframe at distance >= 1 from the query, so a crude product on
+ *    the integer matrix pipe only has to find the slots that can be closer.  The database keeps an 8-bit copy of its rows (+ 1 byte per
+ *    element in the matrix unit's fragment order, + 16 bytes per row; refreshed with the first batched query after an add): every vector
+ *    as steps of its own scale s = max|x| / 127.  The int32 product of two step vectors is exact, so
+ *    d2~ = |q|^2 + |d|^2 - 2 s_q s_d sum a_i b_i deviates from the true squared distance by at most
+ *    2 err = s_d sum|s_q a_i| + s_q sum|s_d b_i| + dim s_q s_d / 2 (the quantisation error; both sums are stored per row); a slot with
+ *    d2~ >= 1 + 2.002 err + 1e-4 (|q|^2 + |d|^2) is written as 0, every other occupied slot is scored with hfnet_db_query's exact chain
+ *    (for unit vectors of 4096 roughly Gaussian components: everything beyond d^2 ~ 1.055).
  *    EVERY result -- scores_all of every slot, best_score, the candidate set, cand_score -- equals hfnet_db_query's bit for bit,
- *    whatever the burst size.  Cost: one pass over the bf16 copy per 128 queries + 16 KB per (query, keyframe closer than ~1.01). */
+ *    whatever the burst size.  Cost: one pass over the 8-bit copy per 64 queries (two per 128) + 32 KB per (query, keyframe the bound
+ *    cannot rule out).  Engine option "match_stats" = 1 counts those pairs (read-only option "stat_db_exact": read and cleared). */
 int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int mode, int32_t* cand_slot,
                          float* cand_score, int32_t* n_cand, float* best_score, float* scores_all);
 

@@ -303,8 +303,9 @@ def test_loop_closure_stress_10k_database(engine):
         ref = O.db_scores(qs[5], rows)
         ref[17] = -1.0
         assert np.array_equal(scores[5], ref)
-    # (b) the default for >= 8 queries: a crude product on the bf16 matrix pipe screens every slot (one bf16 piece per operand, rigorous
-    #     band: a slot it rules out is at distance >= 1, score exactly 0), every other occupied slot is scored with the exact chain.
+    # (b) the default for >= 8 queries: a crude product on the integer matrix pipe screens every slot (8-bit steps of every vector at its own
+    #     scale, exact int32 sums, a rigorous bound of the quantisation error: a slot it rules out is at distance >= 1, score exactly 0), every
+    #     other occupied slot is scored with the exact chain.
     #     Contract: EVERY output equals the exact scan's (== the oracle's) bit for bit -- the scores of all slots (-1 for the erased one),
     #     best, candidate set, candidate scores.
     engine.set_option("db_gemm_min_queries", 8)
@@ -318,13 +319,13 @@ def test_loop_closure_stress_10k_database(engine):
             assert best[i] == ebest, (i, best[i], ebest)
             assert np.array_equal(cands[i][0], eidx) and np.array_equal(cands[i][1], exact_all[i][eidx])
     # the revisit case (queries that ARE database rows, near-duplicates a few ulp apart), rows planted right at the 0.8 * best candidate
-    # threshold, rows planted around distance 1 -- where the screen decides between "exactly 0" and the exact chain: 0.99 .. 1.02, the
-    # band ends at 1.009 for unit vectors --, scaled (non-unit) rows, and a row of zeros
+    # threshold, rows planted around distance 1 and around the end of the screen's band -- where it decides between "exactly 0" and the exact
+    # chain: 0.99 .. 1.06, the band ends near d^2 = 1.055 (distance 1.027) for these unit vectors --, scaled (non-unit) rows, and a row of zeros
     rows2 = rows[:2048].copy()
     rows2[100] = rows2[7]; rows2[101] = np.nextafter(rows2[7], np.float32(1)); rows2[102] = rows2[7] * np.float32(1.0 + 2e-7)
     base = rows2[300]
     plant = [(400 + k, eps) for k, eps in enumerate((0.1995, 0.19999, 0.2, 0.20001, 0.2005))]          # distance ~eps from row 300: score ~ 1 - eps
-    plant += [(420 + k, eps) for k, eps in enumerate((0.99, 0.999, 0.9999, 1.0, 1.0001, 1.001, 1.005, 1.0085, 1.0095, 1.02))]
+    plant += [(420 + k, eps) for k, eps in enumerate((0.99, 0.999, 0.9999, 1.0, 1.0001, 1.001, 1.005, 1.0085, 1.0095, 1.02, 1.024, 1.027, 1.03, 1.04, 1.06))]
     for slot, eps in plant:
         v = rng.standard_normal(dim).astype(np.float32); v -= v.dot(base) * base; v /= np.linalg.norm(v)
         c = 1.0 - eps * eps / 2.0                                                       # unit vector at distance eps: cos = 1 - eps^2 / 2

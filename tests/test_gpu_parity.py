@@ -357,7 +357,14 @@ def test_database_batched_screen_geometries(engine, cap, dim, n_q):
             engine.set_option("db_gemm_min_queries", 1 << 20)
             ce, be, se = db.query_batch(qs, mode, want_scores=True)
             engine.set_option("db_gemm_min_queries", 8)
+            engine.set_option("match_stats", 1); engine.get_option("stat_db_exact")                 # (reads and clears)
             cs, bs, ss = db.query_batch(qs, mode, want_scores=True)
+            evals = engine.get_option("stat_db_exact")
+            # what the screen let through: every pair with a positive score, and only a small multiple of them (unrelated unit vectors are at
+            # d^2 ~ 2; the plants around distance 1 and the duplicates are the rest, and the all-zero query is at distance exactly 1 from every
+            # unit row: n pairs) -- a screen that rules out nothing would score n x n_q pairs
+            assert (se > 0).sum() <= evals <= (se > 0).sum() + 16 * n_q + n, (evals, int((se > 0).sum()))
+            assert n_q < 16 or evals < n * n_q // 4
             assert np.array_equal(ss, se), np.argwhere(ss != se)[:8]
             assert np.array_equal(bs, be)
             for i in range(n_q):
@@ -368,7 +375,7 @@ def test_database_batched_screen_geometries(engine, cap, dim, n_q):
             ref = np.where(occ, O.db_scores(qs[i], dense), -1.0).astype(np.float32)
             assert np.array_equal(ss[i], ref)
     finally:
-        engine.set_option("db_gemm_min_queries", 8)
+        engine.set_option("db_gemm_min_queries", 8); engine.set_option("match_stats", 0)
         db.close()
 
 

@@ -6,7 +6,7 @@ from hfnet_slam_amd import capi, weights
 wpath = os.path.join(tempfile.gettempdir(), "hfnet_synth_seed7_dev.hfw")
 weights.save(wpath, weights.synthetic_weights(7))
 eng = capi.Engine(wpath, 0)
-N, DIM, Q = 10000, 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 64
+N, DIM, Q = 10000, int(sys.argv[2]) if len(sys.argv) > 2 else 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 64
 rng = np.random.default_rng(13)
 rows = rng.standard_normal((N, DIM)).astype(np.float32); rows /= np.linalg.norm(rows, axis=1, keepdims=True)
 db = capi.Database(eng, N, DIM)
