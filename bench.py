@@ -928,21 +928,10 @@ def config_loop_closure(capi, eng, reps=10):
     prof = eng.profile(); eng.profile_enable(False)
     ms = lambda p, k: p[k][1] / max(p[k][0], 1) if k in p else float("nan")
     q64 = next((k for k in ("db_screen", "db_scores_batch") if k in prof), "db_scores_batch")
-    # the screened query = two launches under one profiler entry, "db_screen" (as in every earlier round): k_db_sweep (the 8-bit copy streamed once
-    # against all queries) + k_db_decide (bound test, exact chain for what is left); a second pass with "match_stats" times them apart (an entry of
-    # its own costs each ~2.5 us of event handling).  The queries' own preparation (db_qnorm) and the candidate filter (db_filter) are reported beside them
+    # the screened query = ONE launch, "db_screen" (k_db_sweep: the 8-bit copy streamed once against all queries, the bound test and the exact chain
+    # for what is left in the same kernel); the queries' own preparation (db_qnorm) and the candidate filter (db_filter) are reported beside it
     t_q64 = ms(prof, q64)
-    t_sweep = float("nan")
-    if q64 == "db_screen":
-        eng.set_option("match_stats", 1)
-        db.query_batch(qs); eng.synchronize()
-        eng.profile_reset(); eng.profile_enable(True)
-        for _ in range(reps):
-            db.query_batch(qs)
-        eng.synchronize()
-        prof_split = eng.profile(); eng.profile_enable(False)
-        eng.set_option("match_stats", 0)
-        t_sweep = ms(prof_split, "db_sweep")
+    t_sweep = t_q64
     db.close()
     out = {"workload": "10000 x 4096 f32 database resident in HBM; 1000 x 1000 x 256 SearchByBoW and SearchForTriangulation x 32 pairs",
            "db_q1_warm_us": ms(prof, "db_scores") * 1e3, "db_q1_warm_GBps": N * DIM * 4 / (ms(prof, "db_scores") * 1e-3) / 1e9,

@@ -151,8 +151,8 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
     const int parts = gemm ? db_gemm_partials(db->capacity) : 4 * db_batch_workgroups(db->capacity);
     HF_TRY(e.m_key.ensure(sizeof(unsigned int) * Q * parts));
     if (gemm) {
-        HF_TRY(e.m_tn.ensure(sizeof(float) * db_stat_floats(n_queries))); HF_TRY(e.m_b.ensure(sizeof(float) * db_gemm_scratch_floats(db->capacity, n_queries, db->dim)));
-        HF_TRY(e.m_f1.ensure(db_hi_bytes(n_queries, db->dim)));      // 8-bit copies of the queries
+        HF_TRY(e.m_tn.ensure(sizeof(float) * db_stat_floats(n_queries)));
+        HF_TRY(e.m_f1.ensure(db_hi_bytes((n_queries + 63) & ~63, db->dim)));      // 8-bit copies of the queries (a launch reads whole groups of 16 .. 64)
     }
     float* d_q = e.m_a.as<float>(); float* d_scores = e.m_s.as<float>(); float* d_cs = e.m_f0.as<float>();
     int32_t* d_slot = e.m_i0.as<int32_t>(); int* d_n = e.m_cnt.as<int>(); float* d_best = e.m_qn.as<float>();
@@ -165,20 +165,9 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
             db->norm_dirty = false;
         }
         HF_LAUNCH(&e, e.stream, "db_qnorm", launch_db_prep_hi(d_q, n_queries, db->dim, e.m_tn.as<float>(), e.m_f1.p, e.stream));
-        // (one profiler entry for both launches -- "db_screen", as in every earlier round's figures: an entry costs ~2.5 us of event handling --;
-        //  with "match_stats" set the two are timed apart: "db_sweep" + "db_decide")
-        auto both = [&](int q0) -> hipError_t {
-            hipError_t er = launch_db_sweep(e.m_f1.p, n_queries, q0, db->d_hi, db->capacity, db->dim, e.m_b.as<float>(), e.stream);
-            if (er != hipSuccess) return er;
-            return launch_db_decide(d_q, n_queries, q0, e.m_tn.as<float>(), db->d_db, db->d_norm, db->d_occ, db->capacity, db->dim, d_scores, d_bits,
-                                    e.m_b.as<float>(), e.stream, db_stat);
-        };
-        for (int q0 = 0; q0 < n_queries; q0 += 128) {
-            if (!e.opt.match_stats) { HF_LAUNCH(&e, e.stream, "db_screen", both(q0)); continue; }
-            HF_LAUNCH(&e, e.stream, "db_sweep", launch_db_sweep(e.m_f1.p, n_queries, q0, db->d_hi, db->capacity, db->dim, e.m_b.as<float>(), e.stream));
-            HF_LAUNCH(&e, e.stream, "db_decide", launch_db_decide(d_q, n_queries, q0, e.m_tn.as<float>(), db->d_db, db->d_norm, db->d_occ, db->capacity, db->dim,
-                                                                 d_scores, d_bits, e.m_b.as<float>(), e.stream, db_stat));
-        }
+        for (int q0 = 0; q0 < n_queries; q0 += 64)
+            HF_LAUNCH(&e, e.stream, "db_screen", launch_db_sweep(d_q, e.m_f1.p, n_queries, q0, e.m_tn.as<float>(), db->d_db, db->d_hi, db->d_norm, db->d_occ, db->capacity,
+                                                                db->dim, d_scores, d_bits, e.stream, db_stat));
     } else {
         HF_LAUNCH(&e, e.stream, "db_scores_batch", launch_db_scores_batch(d_q, n_queries, db->d_db, db->d_occ, db->capacity, db->dim, d_scores, d_bits, e.stream));
     }

@@ -234,17 +234,14 @@ hipError_t launch_db_scores_batch(const float* q, int n_queries, const float* db
 // exact chain: ALL outputs equal the exact scan's bit for bit (kernels_match.hip).
 // stat / hi: per row |x|^2 in tree256 order, scale, scaled 1-norm (db_stat_floats) and the 8-bit copy of every row in the matrix unit's
 // fragment order (db_hi_bytes) -- launch_db_prep_hi: the database's when rows were added, the queries' per call; best_partial:
-// [n_queries][db_gemm_partials(n)]; scratch: db_gemm_scratch_floats(n, n_queries, dim) floats
+// [n_queries][db_gemm_partials(n)]
 int db_gemm_partials(int n);
 bool db_screen_supported(int dim);     // descriptor lengths the screened batched query takes (others: the exact batched scan)
-size_t db_gemm_scratch_floats(int n, int n_queries, int dim);
 size_t db_hi_bytes(int n_rows, int dim);   // the 8-bit copy of n_rows vectors: whole 32-row tiles in fragment order
-size_t db_stat_floats(int n_rows);         // |x|^2, scale, scaled 1-norm of the steps per row
+size_t db_stat_floats(int n_rows);         // |x|^2, scale, 1-norm of the steps per row
 hipError_t launch_db_prep_hi(const float* x, int n_rows, int dim, float* stat, void* hi, hipStream_t s);
-// (up to 128 queries from q0 on per pair of launches)
-hipError_t launch_db_sweep(const void* qh, int n_queries, int q0, const void* dbh, int n, int dim, float* scratch, hipStream_t s);
-hipError_t launch_db_decide(const float* q, int n_queries, int q0, const float* qstat, const float* db, const float* dstat, const unsigned char* occupied,
-                            int n, int dim, float* scores, unsigned int* best_partial, const float* scratch, hipStream_t s,
-                            int* stat /* may be null: += the exact scores computed (engine read-only option stat_db_exact) */);
+// up to 64 queries from q0 on per launch; stat (may be null): += the pairs scored exactly (engine read-only option stat_db_exact)
+hipError_t launch_db_sweep(const float* q, const void* qh, int n_queries, int q0, const float* qstat, const float* db, const void* dbh, const float* dstat,
+                           const unsigned char* occupied, int n, int dim, float* scores, unsigned int* best_partial, hipStream_t s, int* stat);
 
 }  // namespace hfnet

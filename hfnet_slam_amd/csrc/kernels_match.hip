@@ -1553,18 +1553,22 @@ __global__ __launch_bounds__(256) void k_db_scores_batch(const float* __restrict
 // finite fails the comparison and goes there too).  All outputs of hfnet_db_query_batch are therefore the exact scan's bits: scores of EVERY
 // slot, best, candidates.  For unit vectors of 4096 roughly Gaussian components: s ~ 5e-4, A1 ~ 51, err ~ 0.027: slots beyond d2 = 1.055 are
 // ruled out (the bf16 screen of rounds 4-6a: 1.018, at twice the bytes).
-// History: round 2-3's f32 MFMA form (S on v_mfma_f32_32x32x2_f32, two exact re-scoring passes) took 89 us for 64 queries against 10 000
-// keyframes of 4096; the bf16 screen k_db_screen (k_db_gemm's structure: 128 rows x 128 queries x a quarter of k per workgroup, both operands
-// through LDS in 64-k chunks, two barriers per chunk) 18.3 us -- 24 KB in flight per workgroup, a third of every workgroup's fetches the QUERIES
-// again; the same product as a sweep over a bf16 copy in fragment order 17.4 us: 3.5 us of launch / prologue / epilogue + the copy's 82 MB at
-// 5.9 TB/s, which is what the memory system gives (half the descriptor length: 10.5 us).  What is left is the number of bytes: one byte per
-// element.
+// History, 64 queries against 10 000 keyframes of 4096 (rocprofv3 kernel times): round 2-3's f32 MFMA form (S on v_mfma_f32_32x32x2_f32, two
+// exact re-scoring passes) 89 us; the bf16 screen k_db_screen (k_db_gemm's structure: 128 rows x 128 queries x a quarter of k per workgroup,
+// both operands through LDS in 64-k chunks, two barriers per chunk) 18.3 us + 7.1 us for the decision kernel -- 24 KB in flight per workgroup,
+// a third of every workgroup's fetches the QUERIES again; the same product as a sweep over a bf16 copy in fragment order (the queries' k-part
+// resident in LDS, the rows straight into registers) 17.4 us: 3.5 us of launch / prologue / epilogue + the copy's 82 MB at 5.9 TB/s, which is
+// what the memory system gives (half the descriptor length: 10.5 us).  So the bytes had to go: one byte per element, 10.5 + 8.8 us.  Then the
+// second kernel: a dependent launch costs 4.7 us before its first instruction (k_db_decide with an empty body), more than the decision's own
+// 4 us -- the sums have to be complete inside ONE kernel, i.e. a workgroup needs all of k for its rows, i.e. ALL the queries' fragments (256 KB
+// for 64 queries; the LDS is 160 KB).  Through LDS in two k-parts, one after the other: 19.7 us (each refill is a barrier and 128 KB from L2
+// with the memory pipe running dry behind it).  In REGISTERS -- one wave per SIMD, 512 registers, a wave holds every query's fragments for its
+// quarter of k: 15.7 us (k_db_sweep below).  What this form costs is the broadcast: every CU fetches the same 256 KB, 64 MB of L2 reads at
+// ~6 TB/s (s_memtime: 5.5 us from a workgroup's start to its first MFMAs; 32 queries: 11.4 us); and the 57 of 313 tiles that are some
+// workgroup's second.
 // The copy is kept in the matrix unit's FRAGMENT ORDER -- [32-row tile][32-k step][lane = row & 31 | k-half << 5][16 x i8]: the 1 KB a wave's
-// 64 lanes hand to one v_mfma_i32_32x32x32_i8 is 1 KB of consecutive memory.  k_db_sweep: a workgroup brings its k-part of the queries'
-// fragments into LDS ONCE (by LDS-DMA, <= 128 KB), then every wave streams 32-row tiles of the database straight from memory into registers
-// -- no LDS, no barrier on the database's way, sixteen 1 KB requests in flight per wave -- and multiplies them against the resident fragments.
-// Queries are the M side, database rows the N side of the product: a lane ends up with ONE row's sums, so [part][query][row] is written in
-// 128-byte runs without a transpose.
+// 64 lanes hand to one v_mfma_i32_32x32x32_i8 is 1 KB of consecutive memory.  Queries are the M side, database rows the N side of the
+// product: a lane ends up with ONE row's sums, 32 consecutive slots of a query per store.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 struct DbRowStat { float norm, scale; int l1; float pad; };   // |x|^2 (tree256 order, as k_sumsq_rows), s, sum|a_i|
@@ -1640,118 +1644,19 @@ __global__ __launch_bounds__(256) void k_db_quant(const float* __restrict__ x, i
     for (int pc = wave; pc < 8 * n_half; pc += 4) dst[pc * 64 + lane] = *(const i32x4*)(st + pc * PP + lane * 16);
 }
 
-#define DBS_WAVES 8
-// 32-k steps per part for NT query tiles: NT * ksp KB of LDS (<= 128 KB), as few parts as that allows (every part is a slab of partial sums
-// k_db_decide reads back: 1.1 us per 5 MB measured) -- HFNET's 4096: two parts for <= 64 queries, four beyond
-__host__ __device__ static inline int dbs_ksp(int nt, int dim) {
-    const int cap = nt <= 2 ? 64 : 32, units = dim >> 8;     // (units of eight steps: dim is a multiple of 256)
-    int d = 1;
-    for (int c = 1; c <= units && 8 * c <= cap; ++c)
-        if (units % c == 0) d = c;
-    return 8 * d;
-}
-// RING: 1 KB requests a wave keeps in flight, and the unit of the k loop (ksp is a multiple of it)
-template <int NT, int RING>
-__global__ __launch_bounds__(DBS_WAVES * 64, 1) void k_db_sweep(const i32x4* __restrict__ qfrag, int q0, const i32x4* __restrict__ dbfrag, int n_tiles,
-                                                                int ks /* dim / 32 */, int ksp, int parts, int groups,
-                                                                int* __restrict__ partial /* [parts][NT * 32][n_tiles * 32] */) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [NT][ksp][64 lanes][16 B]: the queries' fragments of this part
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, r = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int part = blockIdx.x % parts, g = blockIdx.x / parts;           // (the workgroups of one k range share an XCD's L2 when parts divides 8)
-    {
-        const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
-        const unsigned lane16 = (unsigned)lane * 16u;
-        const i32x4* qb = qfrag + ((long long)(q0 >> 5) * ks + (long long)part * ksp) * 64;
-        for (int pc = wave; pc < NT * ksp; pc += DBS_WAVES) {
-            const int nt = pc / ksp, s = pc - nt * ksp;
-            const i32x4* src = qb + ((long long)nt * ks + s) * 64;        // uniform
-            const unsigned dst = ldsb + (unsigned)pc * 1024u;
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(src), "v"(lane16), "s"(dst) : "memory", "m0");
-        }
-    }
-    const int stride = groups * DBS_WAVES;
-    int t = g + groups * wave;
-    const bool have = t < n_tiles;
-    i32x4 b[RING];
-    const i32x4* cur = dbfrag + ((long long)(have ? t : 0) * ks + (long long)part * ksp) * 64 + lane;
-    if (have) {
-#pragma unroll
-        for (int j = 0; j < RING; ++j) {                       // (in this order: the waits of the loop below count requests)
-            b[j] = cur[j * 64];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    // (everything of this wave, the first database pieces included: the count does not depend on where the compiler puts them)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (!have) return;
-    int pt = t, ps = RING;                                    // the next batch to request: k-steps ps .. ps + RING - 1 of tile pt
-    if (ps == ksp) { ps = 0; pt += stride; }
-    i32x16 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nt][i] = 0;
-    int sb = 0;
-    const long long npad = (long long)n_tiles * 32;
-    for (;;) {
-        // the queries' fragments of a step are read one step ahead of its MFMAs; nothing else moves across a step (left alone the scheduler reads
-        // a whole batch's fragments first: 128 registers for four query tiles)
-        const unsigned char* ap = smem + ((size_t)sb * 64 + lane) * 16;
-        i32x4 a[2][NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) a[0][nt] = *(const i32x4*)(ap + (size_t)nt * ksp * 1024);
-        const bool more = pt < n_tiles;                       // (wave-uniform)
-        const i32x4* nx = dbfrag + ((long long)(more ? pt : t) * ks + (long long)part * ksp + ps) * 64 + lane;
-        auto batch = [&](auto pf) {
-#pragma unroll
-            for (int j = 0; j < RING; ++j) {
-                if (j + 1 < RING) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) a[(j + 1) & 1][nt] = *(const i32x4*)(ap + ((size_t)nt * ksp + j + 1) * 1024);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[j & 1][nt], b[j], acc[nt], 0, 0, 0);
-                if (decltype(pf)::value) b[j] = nx[j * 64];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        if (more) batch(std::true_type{}); else batch(std::false_type{});
-        sb += RING; ps += RING;
-        if (ps == ksp) { ps = 0; pt += stride; }
-        if (sb == ksp) {
-            // lane (r, half), register reg of tile nt: query nt * 32 + (reg & 3) + 8 (reg >> 2) + 4 half, database row t * 32 + r
-            long long np = npad;
-            asm volatile("" : "+s"(np));                       // (opaque: the 16 NT store addresses are NOT loop invariants to be kept in registers)
-            int* out = partial + ((long long)part * (NT * 32)) * np + (long long)t * 32 + r;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int m = nt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                    out[(long long)m * np] = acc[nt][reg];     // (rows of queries that do not exist: zeros times the database, never read)
-                    acc[nt][reg] = 0;
-                }
-            sb = 0; t += stride;
-            if (t >= n_tiles) break;
-        }
-    }
-}
-
 // exact score of one (query, slot): ||q - d|| in tree256 order, the chain of k_db_scores
+template <int DEPTH>
 __device__ __forceinline__ float db_exact_u(const float* __restrict__ q, const float* __restrict__ d, int dim, int lane) {
     f32x4 p = {0.f, 0.f, 0.f, 0.f};
-    // (sixteen steps' loads in flight: the handful of slots a batch re-scores decide how long k_db_decide runs -- one wave walking 32 KB with a
-    //  memory round trip per step was 8 of its 11 us; the chain per (lane, component) still runs k ascending)
+    // (DEPTH steps' loads in flight: the handful of pairs a batch re-scores decide how long the kernel's last waves run -- one wave walking 32 KB with
+    //  a memory round trip per step was 8 us; the chain per (lane, component) still runs k ascending)
     int k0 = 0;
-    for (; k0 + 4096 <= dim; k0 += 4096) {
-        f32x4 dv[16], qv[16];
+    for (; k0 + DEPTH * 256 <= dim; k0 += DEPTH * 256) {
+        f32x4 dv[DEPTH], qv[DEPTH];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { dv[j] = *(const f32x4*)(d + k0 + j * 256 + lane * 4); qv[j] = *(const f32x4*)(q + k0 + j * 256 + lane * 4); }
+        for (int j = 0; j < DEPTH; ++j) { dv[j] = *(const f32x4*)(d + k0 + j * 256 + lane * 4); qv[j] = *(const f32x4*)(q + k0 + j * 256 + lane * 4); }
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
+        for (int j = 0; j < DEPTH; ++j)
 #pragma unroll
             for (int c = 0; c < 4; ++c) { const float df = qv[j][c] - dv[j][c]; p[c] = fmaf(df, df, p[c]); }
     }
@@ -1763,74 +1668,178 @@ __device__ __forceinline__ float db_exact_u(const float* __restrict__ q, const f
     return 1 - sqrtf(tree256_wave4(p));
 }
 
-// integer sums of the k-parts -> d2~; decide; re-score what has to be; scores (clamped at 0, -1 for empty slots) and the per-wave
-// maxima k_db_filter reduces.  One workgroup = 256 slots x DBD_Q queries: a slot's statistics are read once for eight queries and a thread has
-// all its partial sums in flight together (one workgroup per (256 slots, query): 2 560 of them for 64 queries x 10 000 slots, each reading the
-// slots' 16-byte statistics again -- 8.4 us).
-#define DBD_Q 8
-__global__ __launch_bounds__(256) void k_db_decide(const int* __restrict__ partial, int qb, int q0, int nq, const float* __restrict__ q, const float* __restrict__ db,
-                                                   const DbRowStat* __restrict__ qstat, const DbRowStat* __restrict__ dstat, const unsigned char* __restrict__ occupied,
-                                                   int n, int dim, float* __restrict__ scores, unsigned int* __restrict__ best_bits, int n_partials, int parts, long long npad, int* __restrict__ stat) {
-    __shared__ int list[DBD_Q * 256];                         // (query << 8 | thread) of the pairs the exact chain takes
-    __shared__ float exact[DBD_Q * 256];
-    __shared__ int n_list;
-    const int c0 = blockIdx.y * DBD_Q, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = blockIdx.x * 256 + tid;
-    if (tid == 0) n_list = 0;
-    __syncthreads();
-    float u[DBD_Q];
-    int mine[DBD_Q];
-    const bool occ = i < n && occupied[i];
-    {
-        // (no branch around a request -- every join would wait for all of them: clamped addresses, four parts x eight queries in flight)
-        int dot[DBD_Q];
+#define DBS_WAVES 4
+// QT: query tiles of 32 (1, 2); FULL: dim == 4096 (thirty-two 32-k steps per wave; other lengths: the same code with every step guarded).
+// One workgroup per CU, one wave per SIMD -- 512 registers each: a wave keeps the fragments of ALL the launch's queries for ITS QUARTER of k
+// in registers (QT x 32 steps x 4 = 256 for 64 queries: the matrix-operand half of the file), so the queries cost no LDS traffic, no k-parts
+// and no refill; the four waves walk the workgroup's tiles together, each streaming its quarter of a tile's rows (32 KB) straight from memory
+// into a register ring (the next tile's piece requested as a piece is consumed), and meet once per tile: 16 QT accumulator registers per wave
+// through LDS, one barrier, then wave w decides the pairs of registers 4 w .. 4 w + 3 of every query tile -- bound test, exact chain for what
+// is left, scores, maxima.  The queries' fragments are requested step by step (all tiles of a step together), so the first tile's MFMAs start
+// when the first step has arrived, not the last: every CU fetching the same 256 KB is 4 us of L2 time (8 MB per XCD), the one cost of this
+// form -- measured (s_memtime) 10 us from the kernel's start to the end of the first tile's MFMAs when they waited for all of it.
+#define DBS_DEFER 512                                         // pairs a workgroup keeps for the exact chain behind its sweep
+template <int QT, bool FULL>
+__global__ __launch_bounds__(DBS_WAVES * 64, 1) void k_db_sweep(const i32x4* __restrict__ qfrag, int n_queries, int q0, const i32x4* __restrict__ dbfrag, int n, int dim,
+                                                                const float* __restrict__ q, const float* __restrict__ db,
+                                                                const DbRowStat* __restrict__ qstat, const DbRowStat* __restrict__ dstat,
+                                                                const unsigned char* __restrict__ occupied, float* __restrict__ scores,
+                                                                unsigned int* __restrict__ best_bits, int n_partials, int* __restrict__ stat) {
+    __shared__ __attribute__((aligned(16))) int s_acc[2][DBS_WAVES][QT * 16][64];     // [buffer][wave][16 qt + reg][lane]
+    __shared__ DbRowStat s_q[QT * 32];
+    __shared__ int s_list[DBS_WAVES][QT * 256];
+    __shared__ float s_res[DBS_WAVES][QT * 256];
+    __shared__ int s_cnt[DBS_WAVES];
+    __shared__ int s_defer[DBS_DEFER];                         // tile << 11 | wave << 9 | (4 qt + r4) << 6 | lane; -1: none
+    __shared__ int s_dn;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ks = dim >> 5, spw = FULL ? 32 : ks >> 2, n_tiles = (n + 31) >> 5;      // (dim is a multiple of 256: ks of eight)
+    const int G = gridDim.x;
+    if (tid < QT * 32) s_q[tid] = qstat[min(q0 + tid, n_queries - 1)];
+    for (int i = tid; i < DBS_DEFER; i += DBS_WAVES * 64) s_defer[i] = -1;
+    if (tid == 0) s_dn = 0;
+    int t = blockIdx.x;                                        // (the grid has at most n_tiles workgroups)
+    // the ring: this wave's quarter of tile t; the queries' fragments step by step (in this order: the waits of the loop below count requests)
+    i32x4 b[32];
+    i32x4 fq[QT][32];
+    const i32x4* dq = dbfrag + (long long)wave * spw * 64 + lane;      // (+ t ks 64: tile t)
+    const i32x4* qq = qfrag + ((long long)(q0 >> 5) * ks + wave * spw) * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < DBD_Q; ++j) dot[j] = 0;
-        const int ic = min(i, n - 1);
-        for (int w0 = 0; w0 < parts; w0 += 4) {
-            int pv[4][DBD_Q];
+    for (int j = 0; j < 32; ++j) {
+        if (FULL || j < spw) {
+            b[j] = dq[((long long)t * ks + j) * 64];
 #pragma unroll
-            for (int w = 0; w < 4; ++w)
-#pragma unroll
-                for (int j = 0; j < DBD_Q; ++j) pv[w][j] = partial[((long long)min(w0 + w, parts - 1) * qb + min(c0 + j, nq - 1)) * npad + ic];
-#pragma unroll
-            for (int w = 0; w < 4; ++w)
-#pragma unroll
-                for (int j = 0; j < DBD_Q; ++j) dot[j] += w0 + w < parts ? pv[w][j] : 0;
+            for (int qt = 0; qt < QT; ++qt) fq[qt][j] = qq[((long long)qt * ks + j) * 64];
         }
-        const DbRowStat ds = dstat[ic];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                           // s_q, s_defer
+    // (opaque copies: what the stores' addresses are computed from must not look loop invariant)
+    int n_o = n, np_o = n_partials, nq_o = n_queries, q0_o = q0;
+    for (int buf = 0; t < n_tiles; t += G, buf ^= 1) {
+        asm volatile("" : "+s"(n_o), "+s"(np_o), "+s"(nq_o), "+s"(q0_o));
+        const int slot = t * 32 + (lane & 31), half = lane >> 5;
+        const unsigned char occ_b = occupied[min(slot, n_o - 1)];      // (requested now, used behind the barrier)
+        const DbRowStat ds = dstat[min(slot, n_o - 1)];
+        i32x16 acc[QT];
 #pragma unroll
-        for (int j = 0; j < DBD_Q; ++j) {
-            u[j] = occ ? 0.0f : -1.0f;                         // (-1: empty slot)
-            mine[j] = -1;
-            if (occ && c0 + j < nq) {
-                const DbRowStat qs = qstat[q0 + c0 + j];       // (uniform)
-                const float t = qs.norm + ds.norm;
-                const float err = ds.scale * qs.scale * (0.5f * ((float)qs.l1 + (float)ds.l1) + 0.25f * (float)dim);      // (s_d / 2) A1 + (s_q / 2) B1 + dim s_q s_d / 4
-                const float d2 = fmaf(-2.0f, qs.scale * ds.scale * (float)dot[j], t);
-                if (!(d2 >= 1.0f + 2.002f * err + 1e-4f * t)) { mine[j] = atomicAdd(&n_list, 1); list[mine[j]] = j << 8 | tid; }      // (anything not finite goes to the exact chain too)
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[qt][i] = 0;
+        const int tn = t + G;
+        const bool more = tn < n_tiles;                        // (uniform)
+        const i32x4* nx = dq + (long long)(more ? tn : t) * ks * 64;
+        auto batch = [&](auto pf) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                if (FULL || j < spw) {
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[qt][j], b[j], acc[qt], 0, 0, 0);
+                    if (decltype(pf)::value) b[j] = nx[(long long)j * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        if (more) batch(std::true_type{}); else batch(std::false_type{});
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) s_acc[buf][wave][qt * 16 + reg][lane] = acc[qt][reg];
+        __syncthreads();
+        // ---- the tile's sums: lane (row = lane & 31, half = lane >> 5), register reg of tile qt: query qt * 32 + (reg & 3) + 8 (reg >> 2) + 4 half;
+        // wave w decides registers 4 w + r4.  The pairs the bound cannot rule out go to the wave's list ((4 qt + r4) << 6 | lane); a few of them
+        // (the usual case: a keyframe's handful of true neighbours) are left for the end of the sweep -- the exact chain is two memory round
+        // trips during which the other three waves would stand at the next barrier --, more are walked here (one inlined copy), a second pass
+        // picks the results up.
+        // (one wave per SIMD: nothing hides an LDS round trip but the wave's own independent requests -- all sums and all query statistics are
+        //  read before the first is used, the list is appended to afterwards, the maxima are reduced level by level for all pairs together:
+        //  written pair by pair the decision was 4 us per tile, a hundred dependent LDS round trips)
+        if (lane == 0) s_cnt[wave] = 0;
+        const bool occ = slot < n_o && occ_b;
+        int dot[QT * 4];
+        DbRowStat qsv[QT * 4];
+#pragma unroll
+        for (int p = 0; p < QT * 4; ++p) {
+            const int qt = p >> 2, r4 = p & 3;
+            int w4[DBS_WAVES];
+#pragma unroll
+            for (int w = 0; w < DBS_WAVES; ++w) w4[w] = s_acc[buf][w][qt * 16 + 4 * wave + r4][lane];
+            dot[p] = (w4[0] + w4[1]) + (w4[2] + w4[3]);
+            qsv[p] = s_q[qt * 32 + r4 + 8 * wave + 4 * half];
+        }
+        unsigned mine = 0;
+#pragma unroll
+        for (int p = 0; p < QT * 4; ++p) {
+            const int c = (p >> 2) * 32 + (p & 3) + 8 * wave + 4 * half;
+            const DbRowStat qs = qsv[p];
+            const float tt = qs.norm + ds.norm;
+            const float err = ds.scale * qs.scale * (0.5f * ((float)qs.l1 + (float)ds.l1) + 0.25f * (float)dim);      // (s_d / 2) A1 + (s_q / 2) B1 + dim s_q s_d / 4
+            const float d2 = fmaf(-2.0f, qs.scale * ds.scale * (float)dot[p], tt);
+            // (anything not finite fails the comparison and goes to the exact chain too)
+            if (occ && q0_o + c < nq_o && !(d2 >= 1.0f + 2.002f * err + 1e-4f * tt)) mine |= 1u << p;
+        }
+        if (__ballot(mine != 0)) {                             // (wave-uniform; rare)
+#pragma unroll
+            for (int p = 0; p < QT * 4; ++p)
+                if (mine >> p & 1) s_list[wave][atomicAdd(&s_cnt[wave], 1)] = p << 6 | lane;
+        }
+        const int cnt = s_cnt[wave];                           // (LDS operations of one wave execute in order)
+        bool deferred = false;
+        if (cnt) {                                             // (wave-uniform; rare)
+            if (stat && lane == 0) atomicAdd(stat, cnt);
+            if (cnt <= 4) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_dn, cnt);
+                base = __builtin_amdgcn_readfirstlane(base);
+                deferred = base + cnt <= DBS_DEFER;            // (a full list: its last slots stay -1)
+                if (deferred && lane < cnt) s_defer[base + lane] = t << 11 | wave << 9 | s_list[wave][lane];
+            }
+            if (!deferred)
+                for (int k = 0; k < cnt; ++k) {
+                    const int e = s_list[wave][k], el = e & 63;
+                    const int e_c = (e >> 8) * 32 + ((e >> 6) & 3) + 8 * wave + 4 * (el >> 5), e_slot = t * 32 + (el & 31);
+                    const float ex = db_exact_u<4>(q + (long long)(q0_o + e_c) * dim, db + (long long)e_slot * dim, dim, lane);
+                    if (lane == 0) s_res[wave][e] = ex;
+                }
+        }
+        float best[QT * 4];
+#pragma unroll
+        for (int p = 0; p < QT * 4; ++p) {
+            const int qi = q0_o + (p >> 2) * 32 + (p & 3) + 8 * wave + 4 * half;
+            float u = occ ? 0.0f : -1.0f;                      // (-1: empty slot)
+            if ((mine >> p & 1) && !deferred) u = fmaxf(s_res[wave][p << 6 | lane], 0.0f);      // (a deferred pair: 0 for now)
+            if (slot < n_o && qi < nq_o) scores[(long long)qi * n_o + slot] = u;
+            best[p] = fmaxf(u, 0.0f);
+        }
+        // the maximum of a half wave's 32 rows by data-parallel primitives (a max does not care about the order): within quads, within rows of
+        // 16 (half mirror, mirror), then lane 15 / 47 into the row above -- lanes 16-31 / 48-63 hold it; no LDS round trips
+#pragma unroll
+        for (int p = 0; p < QT * 4; ++p) {
+            int v = (int)__float_as_uint(best[p]);             // (scores >= 0: the bits order like the floats)
+            v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));      // quad_perm [1, 0, 3, 2]
+            v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));      // quad_perm [2, 3, 0, 1]
+            v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));     // row_half_mirror
+            v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));     // row_mirror
+            v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false));     // row_bcast15 into rows 1 and 3
+            const int qi = q0_o + (p >> 2) * 32 + (p & 3) + 8 * wave + 4 * half;
+            if ((lane & 31) == 31 && qi < nq_o) best_bits[(long long)qi * np_o + t] = (unsigned)v;
         }
     }
+    // ---- the deferred pairs: every wave takes its share; a score >= 0 as an unsigned integer orders like the float, so the tile's maximum is
+    // raised by an atomic (its store above is behind the barrier)
     __syncthreads();
-    const int cnt = n_list;
-    if (stat && tid == 0 && cnt) atomicAdd(stat, cnt);
-    for (int k = wave; k < cnt; k += 4) {
-        const int e = list[k], j = e >> 8, slot = blockIdx.x * 256 + (e & 255);
-        const float ex = db_exact_u(q + (long long)(q0 + c0 + j) * dim, db + (long long)slot * dim, dim, lane);
-        if (lane == 0) exact[k] = ex;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < DBD_Q; ++j) {
-        if (c0 + j >= nq) break;                               // (uniform)
-        if (mine[j] >= 0) u[j] = fmaxf(exact[mine[j]], 0.0f);
-        const int qi = q0 + c0 + j;
-        if (i < n) scores[(long long)qi * n + i] = u[j];
-        float best = fmaxf(u[j], 0.0f);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off, 64));
-        if (lane == 0) best_bits[(long long)qi * n_partials + blockIdx.x * 4 + wave] = __float_as_uint(best);
+    const int nd = min(s_dn, DBS_DEFER);
+    for (int k = wave; k < nd; k += DBS_WAVES) {
+        const int e = s_defer[k];
+        if (e < 0) continue;                                   // (uniform)
+        const int et = e >> 11, ew = (e >> 9) & 3, eqt = (e >> 8) & 1, er4 = (e >> 6) & 3, el = e & 63;
+        const int qi = q0 + eqt * 32 + er4 + 8 * ew + 4 * (el >> 5), e_slot = et * 32 + (el & 31);
+        const float u = fmaxf(db_exact_u<16>(q + (long long)qi * dim, db + (long long)e_slot * dim, dim, lane), 0.0f);
+        if (lane == 0) {
+            scores[(long long)qi * n + e_slot] = u;
+            atomicMax(best_bits + (long long)qi * n_partials + et, __float_as_uint(u));
+        }
     }
 }
 
@@ -1842,61 +1851,28 @@ hipError_t launch_db_prep_hi(const float* x, int n_rows, int dim, float* stat, v
     return hipGetLastError();
 }
 
-int db_gemm_partials(int n) { return 4 * ((n + 255) / 256); }
-bool db_screen_supported(int dim) { return dim > 0 && dim % 256 == 0 && dim <= (1 << 17); }      // (int32 sums: dim * 127^2 < 2^31)
-size_t db_hi_bytes(int n_rows, int dim) { return (size_t)((n_rows + 31) & ~31) * (size_t)dim; }     // whole 32-row tiles, one byte per element
+int db_gemm_partials(int n) { return (n + 31) / 32; }      // one maximum per 32-row tile and query
+bool db_screen_supported(int dim) { return dim > 0 && dim % 256 == 0 && dim <= 4096; }      // (a wave's quarter of k: <= thirty-two 32-k steps of fragments in registers)
+size_t db_hi_bytes(int n_rows, int dim) { return (size_t)((n_rows + 31) & ~31) * (size_t)dim; }     // whole 32-row tiles (k_db_quant's unit), one byte per element
 size_t db_stat_floats(int n_rows) { return (size_t)4 * (size_t)n_rows; }
-size_t db_gemm_scratch_floats(int n, int n_queries, int dim) {
-    const int nt = (std::min(128, n_queries) + 31) / 32;
-    return (size_t)((dim >> 5) / dbs_ksp(nt, dim)) * (size_t)(nt * 32) * (size_t)((n + 31) & ~31);
-}
 
-// scores of up to 128 queries q0 .. of n_queries against the n slots of the database (see above), in two launches: q / db: f32 rows, qh /
-// dbh: their 8-bit copies in fragment order, qstat / dstat: DbRowStat per row (launch_db_prep_hi); best_partial: [n_queries][db_gemm_partials(n)];
-// scratch: db_gemm_scratch_floats floats
-hipError_t launch_db_sweep(const void* qh, int n_queries, int q0, const void* dbh, int n, int dim, float* scratch, hipStream_t s) {
+// scores of up to 64 queries q0 .. of n_queries against the n slots of the database (see above), one launch: q / db: f32 rows, qh / dbh: their
+// 8-bit copies in fragment order, qstat / dstat: DbRowStat per row (launch_db_prep_hi); best_partial: [n_queries][db_gemm_partials(n)]
+hipError_t launch_db_sweep(const float* q, const void* qh, int n_queries, int q0, const float* qstat, const float* db, const void* dbh, const float* dstat,
+                           const unsigned char* occupied, int n, int dim, float* scores, unsigned int* best_partial, hipStream_t s, int* stat) {
     if (n <= 0 || q0 >= n_queries) return hipSuccess;
     if (!db_screen_supported(dim)) return hipErrorInvalidValue;
-    static std::once_flag attr_once;                                    // > 64 KB of dynamic LDS has to be requested once
-    std::call_once(attr_once, []() {
-        (void)hipFuncSetAttribute((const void*)k_db_sweep<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        (void)hipFuncSetAttribute((const void*)k_db_sweep<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        (void)hipFuncSetAttribute((const void*)k_db_sweep<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        (void)hipFuncSetAttribute((const void*)k_db_sweep<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        (void)hipFuncSetAttribute((const void*)k_db_sweep<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        (void)hipFuncSetAttribute((const void*)k_db_sweep<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    });
-    const int n_tiles = (n + 31) / 32, ks = dim >> 5;
-    const int nt = (std::min(128, n_queries - q0) + 31) / 32;
-    const int ksp = dbs_ksp(nt, dim), parts = ks / ksp;
-    // one workgroup per CU where the database has the tiles for it: 256 / parts groups, a group's wave w takes tiles g + groups (w + 8 j)
-    const int groups = std::max(1, std::min(n_tiles, 256 / parts));
-    const dim3 grid((unsigned)(groups * parts)), block(DBS_WAVES * 64);
-    const size_t lds = (size_t)nt * ksp * 1024;
+    const int n_tiles = (n + 31) / 32;
+    const int nq = std::min(64, n_queries - q0);
+    const int qt = nq <= 32 ? 1 : 2;
+    const dim3 grid((unsigned)std::min(256, n_tiles)), block(DBS_WAVES * 64);      // a workgroup per CU: tiles blockIdx.x, + 256, ...
     const i32x4* qf = (const i32x4*)qh; const i32x4* df = (const i32x4*)dbh;
-    int* part_sums = (int*)scratch;
-    const bool deep = ksp % 16 == 0;
-    switch (nt) {
-        case 1: if (deep) hipLaunchKernelGGL((k_db_sweep<1, 16>), grid, block, lds, s, qf, q0, df, n_tiles, ks, ksp, parts, groups, part_sums);
-                else hipLaunchKernelGGL((k_db_sweep<1, 8>), grid, block, lds, s, qf, q0, df, n_tiles, ks, ksp, parts, groups, part_sums);
-                break;
-        case 2: if (deep) hipLaunchKernelGGL((k_db_sweep<2, 16>), grid, block, lds, s, qf, q0, df, n_tiles, ks, ksp, parts, groups, part_sums);
-                else hipLaunchKernelGGL((k_db_sweep<2, 8>), grid, block, lds, s, qf, q0, df, n_tiles, ks, ksp, parts, groups, part_sums);
-                break;
-        case 3: hipLaunchKernelGGL((k_db_sweep<3, 8>), grid, block, lds, s, qf, q0, df, n_tiles, ks, ksp, parts, groups, part_sums); break;
-        default: hipLaunchKernelGGL((k_db_sweep<4, 8>), grid, block, lds, s, qf, q0, df, n_tiles, ks, ksp, parts, groups, part_sums); break;
-    }
-    return hipGetLastError();
-}
-hipError_t launch_db_decide(const float* q, int n_queries, int q0, const float* qstat, const float* db, const float* dstat, const unsigned char* occupied,
-                            int n, int dim, float* scores, unsigned int* best_partial, const float* scratch, hipStream_t s, int* stat) {
-    if (n <= 0 || q0 >= n_queries) return hipSuccess;
-    if (!db_screen_supported(dim)) return hipErrorInvalidValue;
-    const int n_tiles = (n + 31) / 32, ks = dim >> 5;
-    const int nt = (std::min(128, n_queries - q0) + 31) / 32, qb = nt * 32, nq = std::min(qb, n_queries - q0);
-    const int parts = ks / dbs_ksp(nt, dim);
-    hipLaunchKernelGGL(k_db_decide, dim3((n + 255) / 256, (nq + DBD_Q - 1) / DBD_Q), dim3(256), 0, s, (const int*)scratch, qb, q0, nq, q, db, (const DbRowStat*)qstat,
-                       (const DbRowStat*)dstat, occupied, n, dim, scores, best_partial, db_gemm_partials(n), parts, (long long)n_tiles * 32, stat);
+    const DbRowStat* qs = (const DbRowStat*)qstat; const DbRowStat* ds = (const DbRowStat*)dstat;
+    const int np = db_gemm_partials(n);
+#define DBS_LAUNCH(QT_, FULL_) hipLaunchKernelGGL((k_db_sweep<QT_, FULL_>), grid, block, 0, s, qf, n_queries, q0, df, n, dim, q, db, qs, ds, occupied, scores, best_partial, np, stat)
+    if (dim == 4096) { if (qt == 1) DBS_LAUNCH(1, true); else DBS_LAUNCH(2, true); }
+    else { if (qt == 1) DBS_LAUNCH(1, false); else DBS_LAUNCH(2, false); }
+#undef DBS_LAUNCH
     return hipGetLastError();
 }
 

@@ -354,7 +354,7 @@ int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slo
  * entries); best_score: [n_queries] or NULL; scores_all: [n_queries][capacity] or NULL.
  *  - fewer than "db_gemm_min_queries" (8) queries: the exact scan, the database crosses HBM once per 8 queries; per query
  *    EVERY result equals hfnet_db_query's bit for bit (dim <= 4096);
- *  - otherwise (dim <= 131072): the score is EXACTLY 0 for every keyframe at distance >= 1 from the query, so a crude product on
+ *  - otherwise (dim <= 4096): the score is EXACTLY 0 for every keyframe at distance >= 1 from the query, so a crude product on
  *    the integer matrix pipe only has to find the slots that can be closer.  The database keeps an 8-bit copy of its rows (+ 1 byte per
  *    element in the matrix unit's fragment order, + 16 bytes per row; refreshed with the first batched query after an add): every vector
  *    as steps of its own scale s = max|x| / 127.  The int32 product of two step vectors is exact, so
@@ -363,7 +363,7 @@ int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slo
  *    d2~ >= 1 + 2.002 err + 1e-4 (|q|^2 + |d|^2) is written as 0, every other occupied slot is scored with hfnet_db_query's exact chain
  *    (for unit vectors of 4096 roughly Gaussian components: everything beyond d^2 ~ 1.055).
  *    EVERY result -- scores_all of every slot, best_score, the candidate set, cand_score -- equals hfnet_db_query's bit for bit,
- *    whatever the burst size.  Cost: one pass over the 8-bit copy per 64 queries (two per 128) + 32 KB per (query, keyframe the bound
+ *    whatever the burst size.  Cost: one launch and one pass over the 8-bit copy per 64 queries + 32 KB per (query, keyframe the bound
  *    cannot rule out).  Engine option "match_stats" = 1 counts those pairs (read-only option "stat_db_exact": read and cleared). */
 int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int mode, int32_t* cand_slot,
                          float* cand_score, int32_t* n_cand, float* best_score, float* scores_all);

@@ -328,10 +328,11 @@ def test_database(engine):
 @pytest.mark.parametrize("cap,dim,n_q", [(700, 4096, 9), (33, 256, 8), (257, 512, 31), (1000, 768, 33), (95, 1024, 64), (3001, 4096, 97),
                                           (1500, 2048, 129), (64, 4096, 200), (31, 256, 40)])
 def test_database_batched_screen_geometries(engine, cap, dim, n_q):
-    """hfnet_db_query_batch, >= 8 queries: the screen on the bf16 matrix pipe (k_db_sweep: the database's bf16 copy in fragment order, whole
-    32-row tiles; 1-4 query tiles, 1-8 k-parts, a second launch past 128 queries) + the exact chain -- every output equals the exact batched
-    scan's bits (KeyFrameDatabase.cc:86-104), for capacities / descriptor lengths / query counts that fill no tile, with empty slots, near-
-    duplicates and rows around distance 1 from a query."""
+    """hfnet_db_query_batch, >= 8 queries: the screen on the integer matrix pipe (k_db_sweep: the database's 8-bit copy in fragment order, whole
+    32-row tiles; one or two query tiles of 32 in registers, every wave a quarter of k, a launch per 64 queries; descriptor lengths other than
+    4096 take the guarded form) + the exact chain in the same kernel -- every output equals the exact batched scan's bits
+    (KeyFrameDatabase.cc:86-104), for capacities / descriptor lengths / query counts that fill no tile, with empty slots, near-duplicates and
+    rows around distance 1 from a query."""
     from hfnet_slam_amd import capi
     from oracle import oracle as O
     rng = np.random.default_rng(cap * 7 + n_q)
