@@ -136,7 +136,8 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *                       (three launches per block).  STATED TOLERANCE: 2e-5 absolute per component of the (unit-norm) 4096-D global
  *                       descriptor (measured <= 6e-6 through the ten blocks; a model with a D-dimensional global descriptor: 2e-5 *
  *                       sqrt(4096 / D) -- the components of a unit vector scale that way).  Also layer 8 (fused; calls that take the fused kernels)
- *                       and the NetVLAD memberships conv; the NetVLAD aggregation and the dimensionality reduction stay exact f32.
+ *                       and the NetVLAD memberships conv, and -- calls of >= 64 frames -- the dimensionality reduction (7680 x 4096 on the same
+ *                       split products, K in eight parts; its own deviation ~1e-6); the NetVLAD aggregation stays exact f32.
  *   "scores_bf16x3" (0) the rest of the network on the same split-bf16 products: the 1x1 convolutions of layers 3-7 inside their fused kernels (the
  *                       depthwise stage between them stays exact f32), the detector head's 3x3 conv 96 -> 128 (halo staged through LDS already split,
  *                       k_conv3x3_dense_bf16x3) and its 1x1 128 -> 65 (k_det_tail_bf16x3).  Stem + layer 2, every depthwise stage, softmax, NMS,

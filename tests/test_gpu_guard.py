@@ -41,7 +41,8 @@ def test_guarded_allocations_fault_one_element_outside(engine, selftest):
 
 
 SLICE = ["tests/test_gpu_parity.py::test_random_geometries_match_oracle", "tests/test_gpu_parity.py::test_modes_and_overloads",
-         "tests/test_gpu_soak.py::test_randomised_soak_20s"]
+         "tests/test_gpu_parity.py::test_database", "tests/test_gpu_parity.py::test_database_batched_screen_geometries",
+         "tests/test_gpu_parity.py::test_bow_sweep_many_pairs", "tests/test_gpu_soak.py::test_randomised_soak_20s"]
 
 
 @pytest.mark.parametrize("mode", [{"HFNET_GUARD_ALLOC": "1"}, {"HFNET_GUARD_ALLOC": "2"}, {"HFNET_GUARD_FILL": "ff"}],
