@@ -68,7 +68,8 @@ int hfnet_db_add(hfnet_db* db, int slot, const float* descriptor) try {
     // on the stream the scans run on (created non-blocking: the null stream would not order with it)
     HF_TRY(e.h2d(db->d_db + (size_t)slot * db->dim, descriptor, sizeof(float) * db->dim));
     HF_HIP(hipMemsetAsync(db->d_occ + slot, 1, 1, e.stream));
-    db->norm_dirty = true;
+    if (db->dirty_lo >= db->dirty_hi) { db->dirty_lo = slot; db->dirty_hi = slot + 1; }
+    else { db->dirty_lo = std::min(db->dirty_lo, slot); db->dirty_hi = std::max(db->dirty_hi, slot + 1); }
     HF_TRY(e.sync_host());                          // the host buffer may go away
     return HFNET_OK;
 } catch (...) { return ::hfnet::api_exception(); }
@@ -160,9 +161,13 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
     HF_TRY(e.h2d(d_q, queries, sizeof(float) * Q * db->dim));
     if (gemm) {
         int* db_stat = e.opt.match_stats && e.bow_stat() ? e.bow_stat() + 1 : nullptr;
-        if (db->norm_dirty) {
-            HF_LAUNCH(&e, e.stream, "db_norm", launch_db_prep_hi(db->d_db, db->capacity, db->dim, db->d_norm, db->d_hi, e.stream));
-            db->norm_dirty = false;
+        if (db->dirty_lo < db->dirty_hi) {
+            // only the 32-row tiles the added slots fall into (keyframes arrive in slot order: usually one tile): a tile's 8-bit steps are
+            // contiguous in the copy, its rows' statistics in the array
+            const int r0 = db->dirty_lo & ~31, r1 = std::min(db->capacity, (db->dirty_hi + 31) & ~31);
+            HF_LAUNCH(&e, e.stream, "db_norm", launch_db_prep_hi(db->d_db + (size_t)r0 * db->dim, r1 - r0, db->dim, db->d_norm + db_stat_floats(r0),
+                                                            (unsigned char*)db->d_hi + db_hi_bytes(r0, db->dim), e.stream));
+            db->dirty_lo = db->dirty_hi = 0;
         }
         HF_LAUNCH(&e, e.stream, "db_qnorm", launch_db_prep_hi(d_q, n_queries, db->dim, e.m_tn.as<float>(), e.m_f1.p, e.stream));
         for (int q0 = 0; q0 < n_queries; q0 += 64)

@@ -455,7 +455,7 @@ struct hfnet_db {
     float *d_q = nullptr, *d_scores = nullptr, *d_cand_score = nullptr, *d_best = nullptr;
     float* d_norm = nullptr;       // per slot: |d|^2 (tree256 order), scale and scaled 1-norm of its 8-bit steps (db_stat_floats), and
     void* d_hi = nullptr;          // the 8-bit copy of every row (fragment order), for the screened batched query: both refreshed in one launch
-    bool norm_dirty = true;        // by the first batched query after rows were added
+    int dirty_lo = 0, dirty_hi = 0;   // by the first batched query after rows were added: the slots [dirty_lo, dirty_hi) (whole 32-row tiles of them)
     int32_t* d_cand_slot = nullptr;
     int* d_n = nullptr;
     unsigned int* d_best_bits = nullptr;

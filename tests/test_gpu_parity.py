@@ -380,6 +380,47 @@ def test_database_batched_screen_geometries(engine, cap, dim, n_q):
         db.close()
 
 
+def test_database_batched_query_between_adds(engine):
+    """the 8-bit copy and the row statistics of the screened batched query follow hfnet_db_add incrementally (only the 32-row tiles the added slots
+    fall into are prepared again): queries between adds -- new slots, overwritten slots, a slot erased and re-added, tiles far apart -- equal the
+    exact batched scan's bits every time"""
+    from hfnet_slam_amd import capi
+    rng = np.random.default_rng(77)
+    cap, dim, n_q = 333, 4096, 24
+    rows = _unit_rows(rng, cap, dim)
+    db = capi.Database(engine, cap, dim)
+    live = {}
+
+    def check():
+        qs = np.stack([rows[s] for s in list(live)[:n_q // 2]] + [r for r in _unit_rows(rng, n_q - min(len(live), n_q // 2), dim)]).astype(np.float32)
+        qs = qs + 0.003 * rng.standard_normal(qs.shape).astype(np.float32)              # (distance ~0.19 from its row: score ~0.8)
+        qs = (qs / np.linalg.norm(qs, axis=1, keepdims=True)).astype(np.float32)
+        engine.set_option("db_gemm_min_queries", 1 << 20)
+        ce, be, se = db.query_batch(qs, 0, want_scores=True)
+        engine.set_option("db_gemm_min_queries", 8)
+        cs, bs, ss = db.query_batch(qs, 0, want_scores=True)
+        assert np.array_equal(ss, se), np.argwhere(ss != se)[:8]
+        assert np.array_equal(bs, be) and all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(cs, ce))
+        assert (se > 0.5).sum() >= min(len(live), n_q // 2)                 # (the planted neighbours are found)
+
+    try:
+        for s in range(0, 40):
+            db.add(s, rows[s]); live[s] = True
+        check()
+        for s in (40, 41, 200, 332):                                      # the same tile again, two tiles far apart
+            db.add(s, rows[s]); live[s] = True
+        check()
+        rows[5] = rows[300]; db.add(5, rows[5])                             # overwritten
+        db.erase(7); live.pop(7); check()
+        db.add(7, rows[7]); live[7] = True
+        for s in range(100, 131):
+            db.add(s, rows[s]); live[s] = True
+        check()
+    finally:
+        engine.set_option("db_gemm_min_queries", 8)
+        db.close()
+
+
 def test_resampler_entry_point(engine):
     """free-standing Resampler (BaseModel.h:78-80) vs the oracle, incl. border / outside points and batch > 1"""
     from oracle import oracle as O
