@@ -131,7 +131,7 @@ class Engine:
         _chk(lib().hfnet_engine_get_option(self.h, name.encode(), C.byref(v)))
         return v.value
 
-    OPTIONS = ("fuse_blocks", "fuse_max_layer", "fused_variant", "fuse_stem", "dense_desc", "conv_wlds", "two_streams", "graph", "pinned_frames", "db_gemm_min_queries", "fuse_min_wgs", "copy_threads", "tail_fuse", "dedupe_taps", "pyramid_fuse", "resize_band", "fc_tile", "interleave", "host_global", "det_fuse", "match_screen_bf16", "tri_screen_bf16", "desc_bf16x3", "global_bf16x3", "scores_bf16x3", "join_fused_branch", "match_stats")
+    OPTIONS = ("fuse_blocks", "fuse_max_layer", "fused_variant", "fuse_stem", "dense_desc", "conv_wlds", "two_streams", "graph", "pinned_frames", "db_gemm_min_queries", "db_screen_min_rows", "fuse_min_wgs", "copy_threads", "tail_fuse", "dedupe_taps", "pyramid_fuse", "resize_band", "fc_tile", "interleave", "host_global", "det_fuse", "match_screen_bf16", "tri_screen_bf16", "desc_bf16x3", "global_bf16x3", "scores_bf16x3", "join_fused_branch", "match_stats")
 
     def options(self) -> dict:
         return {n: self.get_option(n) for n in self.OPTIONS}

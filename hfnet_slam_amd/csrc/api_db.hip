@@ -11,6 +11,28 @@
 
 using namespace hfnet;
 
+// The screened scan of n_queries device rows d_q (kernels_match.hip: the database's 8-bit copy streamed once per 64 queries, the bound test and
+// the exact chain for what is left in the same kernel): scores [n_queries][capacity], per-tile maxima [n_queries][db_gemm_partials(capacity)].
+// Brings the copy up to date for the slots added since the last screened scan.  Engine lock held by the caller.
+static int db_screened_scan(Engine& e, hfnet_db* db, const float* d_q, int n_queries, float* d_scores, unsigned int* d_bits) {
+    HF_TRY(e.m_tn.ensure(sizeof(float) * db_stat_floats(n_queries)));
+    HF_TRY(e.m_f1.ensure(db_hi_bytes((n_queries + 63) & ~63, db->dim)));      // 8-bit copies of the queries (a launch reads whole groups of 32 / 64)
+    int* db_stat = e.opt.match_stats && e.bow_stat() ? e.bow_stat() + 1 : nullptr;
+    if (db->dirty_lo < db->dirty_hi) {
+        // only the 32-row tiles the added slots fall into (keyframes arrive in slot order: usually one tile): a tile's 8-bit steps are
+        // contiguous in the copy, its rows' statistics in the array
+        const int r0 = db->dirty_lo & ~31, r1 = std::min(db->capacity, (db->dirty_hi + 31) & ~31);
+        HF_LAUNCH(&e, e.stream, "db_norm", launch_db_prep_hi(db->d_db + (size_t)r0 * db->dim, r1 - r0, db->dim, db->d_norm + db_stat_floats(r0),
+                                                        (unsigned char*)db->d_hi + db_hi_bytes(r0, db->dim), e.stream));
+        db->dirty_lo = db->dirty_hi = 0;
+    }
+    HF_LAUNCH(&e, e.stream, "db_qnorm", launch_db_prep_hi(d_q, n_queries, db->dim, e.m_tn.as<float>(), e.m_f1.p, e.stream));
+    for (int q0 = 0; q0 < n_queries; q0 += 64)
+        HF_LAUNCH(&e, e.stream, "db_screen", launch_db_sweep(d_q, e.m_f1.p, n_queries, q0, e.m_tn.as<float>(), db->d_db, db->d_hi, db->d_norm, db->d_occ, db->capacity,
+                                                            db->dim, d_scores, d_bits, e.stream, db_stat));
+    return HFNET_OK;
+}
+
 extern "C" {
 
 // ---------------------------------------------------------------------------------------- KeyFrameDatabase
@@ -33,7 +55,7 @@ int hfnet_db_create(hfnet_engine* eh, int capacity, int dim, hfnet_db** out) try
     HF_HIP(dev_malloc((void**)&db->d_cand_slot, sizeof(int32_t) * capacity));
     HF_HIP(dev_malloc((void**)&db->d_best, sizeof(float)));
     HF_HIP(dev_malloc((void**)&db->d_n, sizeof(int)));
-    HF_HIP(dev_malloc((void**)&db->d_best_bits, sizeof(unsigned int) * 4 * (size_t)db_scan_workgroups(capacity)));   // per-wave partial maxima
+    HF_HIP(dev_malloc((void**)&db->d_best_bits, sizeof(unsigned int) * std::max((size_t)4 * db_scan_workgroups(capacity), (size_t)db_gemm_partials(capacity))));   // per-wave / per-tile partial maxima
     {
         // on the stream the adds and scans use: it is non-blocking, i.e. NOT ordered with the null stream, and a hipMemset there
         // is not host-synchronous -- it could land after the first hfnet_db_add had set its occupancy byte
@@ -109,8 +131,12 @@ int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slo
     e.bounce_discard();
     HF_HIP(hipSetDevice(e.device));
     HF_TRY(e.h2d(db->d_q, query, sizeof(float) * db->dim));
-    HF_LAUNCH(&e, e.stream, "db_scores", launch_db_scores(db->d_q, db->d_db, db->d_occ, db->capacity, db->dim, db->d_scores, db->d_best_bits, e.stream));
-    HF_LAUNCH(&e, e.stream, "db_filter", launch_db_filter(db->d_scores, db->capacity, mode, db->d_best_bits, 4 * db_scan_workgroups(db->capacity), db->d_cand_slot, db->d_cand_score, db->d_n, db->d_best, 1, e.stream));
+    // a large database: the screened form reads a quarter of the bytes (the 8-bit copy + 32 KB per keyframe that can be closer than 1) for the same
+    // bits; below "db_screen_min_rows" its two extra launches (the query's fragments) cost what it saves
+    const bool screened = e.opt.db_screen_min_rows > 0 && db->capacity >= e.opt.db_screen_min_rows && db_screen_supported(db->dim);
+    if (screened) HF_TRY(db_screened_scan(e, db, db->d_q, 1, db->d_scores, db->d_best_bits));
+    else HF_LAUNCH(&e, e.stream, "db_scores", launch_db_scores(db->d_q, db->d_db, db->d_occ, db->capacity, db->dim, db->d_scores, db->d_best_bits, e.stream));
+    HF_LAUNCH(&e, e.stream, "db_filter", launch_db_filter(db->d_scores, db->capacity, mode, db->d_best_bits, screened ? db_gemm_partials(db->capacity) : 4 * db_scan_workgroups(db->capacity), db->d_cand_slot, db->d_cand_score, db->d_n, db->d_best, 1, e.stream));
     int n = 0;
     float best = 0.f;
     HF_TRY(e.d2h(&n, db->d_n, sizeof(int)));
@@ -151,28 +177,12 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
     HF_TRY(e.m_qn.ensure(sizeof(float) * Q));
     const int parts = gemm ? db_gemm_partials(db->capacity) : 4 * db_batch_workgroups(db->capacity);
     HF_TRY(e.m_key.ensure(sizeof(unsigned int) * Q * parts));
-    if (gemm) {
-        HF_TRY(e.m_tn.ensure(sizeof(float) * db_stat_floats(n_queries)));
-        HF_TRY(e.m_f1.ensure(db_hi_bytes((n_queries + 63) & ~63, db->dim)));      // 8-bit copies of the queries (a launch reads whole groups of 16 .. 64)
-    }
     float* d_q = e.m_a.as<float>(); float* d_scores = e.m_s.as<float>(); float* d_cs = e.m_f0.as<float>();
     int32_t* d_slot = e.m_i0.as<int32_t>(); int* d_n = e.m_cnt.as<int>(); float* d_best = e.m_qn.as<float>();
     unsigned int* d_bits = e.m_key.as<unsigned int>();
     HF_TRY(e.h2d(d_q, queries, sizeof(float) * Q * db->dim));
     if (gemm) {
-        int* db_stat = e.opt.match_stats && e.bow_stat() ? e.bow_stat() + 1 : nullptr;
-        if (db->dirty_lo < db->dirty_hi) {
-            // only the 32-row tiles the added slots fall into (keyframes arrive in slot order: usually one tile): a tile's 8-bit steps are
-            // contiguous in the copy, its rows' statistics in the array
-            const int r0 = db->dirty_lo & ~31, r1 = std::min(db->capacity, (db->dirty_hi + 31) & ~31);
-            HF_LAUNCH(&e, e.stream, "db_norm", launch_db_prep_hi(db->d_db + (size_t)r0 * db->dim, r1 - r0, db->dim, db->d_norm + db_stat_floats(r0),
-                                                            (unsigned char*)db->d_hi + db_hi_bytes(r0, db->dim), e.stream));
-            db->dirty_lo = db->dirty_hi = 0;
-        }
-        HF_LAUNCH(&e, e.stream, "db_qnorm", launch_db_prep_hi(d_q, n_queries, db->dim, e.m_tn.as<float>(), e.m_f1.p, e.stream));
-        for (int q0 = 0; q0 < n_queries; q0 += 64)
-            HF_LAUNCH(&e, e.stream, "db_screen", launch_db_sweep(d_q, e.m_f1.p, n_queries, q0, e.m_tn.as<float>(), db->d_db, db->d_hi, db->d_norm, db->d_occ, db->capacity,
-                                                                db->dim, d_scores, d_bits, e.stream, db_stat));
+        HF_TRY(db_screened_scan(e, db, d_q, n_queries, d_scores, d_bits));
     } else {
         HF_LAUNCH(&e, e.stream, "db_scores_batch", launch_db_scores_batch(d_q, n_queries, db->d_db, db->d_occ, db->capacity, db->dim, d_scores, d_bits, e.stream));
     }

@@ -293,9 +293,13 @@ def test_matcher_near_ties_inside_the_rounding_band(engine, seed, spread, scale,
     _eq("batched reverse match", mb[1][:420], rm2); _eq("batched reverse dist", db[1][:420], rd2)
 
 
-def test_database(engine):
+@pytest.mark.parametrize("screen_min_rows", [0, 1], ids=["scan", "screened"])
+def test_database(engine, screen_min_rows):
+    """hfnet_db_query (KeyFrameDatabase.cc:86-104, 178-197) vs the oracle: as the exact f32 scan, and in the screened form large databases take
+    (engine option db_screen_min_rows: the 8-bit copy + the exact chain, hfnet_db_query_batch's kernel with one query) -- the same bits"""
     from hfnet_slam_amd import capi
     from oracle import oracle as O
+    engine.set_option("db_screen_min_rows", screen_min_rows)
     rng = np.random.default_rng(13)
     cap, dim, n = 700, 4096, 520
     rows = _unit_rows(rng, n, dim)
@@ -323,6 +327,7 @@ def test_database(engine):
     cs, sc, best, _ = db.query(rows[1], 0)
     assert len(cs) == 0 and best == 0.0
     db.close()
+    engine.set_option("db_screen_min_rows", 8192)
 
 
 @pytest.mark.parametrize("cap,dim,n_q", [(700, 4096, 9), (33, 256, 8), (257, 512, 31), (1000, 768, 33), (95, 1024, 64), (3001, 4096, 97),
