@@ -1599,6 +1599,53 @@ __global__ __launch_bounds__(256) void k_db_rowstat(const float* __restrict__ x,
     const float ss = tree256_wave4(p);
     if (lane == 0) stat[row] = DbRowStat{ss, m / 127.0f, 0, 0.0f};
 }
+// both of the above for a FEW rows (a call's queries, the tiles of added slots) in one launch -- a dependent launch costs 4.7 us before its first
+// instruction: one workgroup per row of whole 32-row tiles (rows >= n_rows: zeros), a thread = one 16-byte piece of the row's steps; maximum,
+// |x|^2 and sum|a_i| over the workgroup.  (|x|^2 in another order than k_db_rowstat's: the bound's 1e-4 (|q|^2 + |d|^2) does not care.)
+__global__ __launch_bounds__(256) void k_db_prep_rows(const float* __restrict__ x, int n_rows, int dim, DbRowStat* __restrict__ stat, i32x4* __restrict__ frag) {
+    __shared__ float s_m[4], s_ss[4];
+    __shared__ int s_l1[4];
+    const int row = blockIdx.x, tile = row >> 5, r = row & 31, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ks = dim >> 5, k = tid * 16;                    // (dim <= 4096: one piece per thread)
+    const bool mine = k < dim;
+    i32x4* __restrict__ dst = frag + ((long long)tile * ks + (k >> 5)) * 64 + ((k >> 4) & 1) * 32 + r;
+    if (row >= n_rows) {                                       // (workgroup-uniform)
+        if (mine) *dst = i32x4{0, 0, 0, 0};
+        return;
+    }
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = mine ? *(const f32x4*)(x + (long long)row * dim + k + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = 0.0f, ss = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { m = fmaxf(m, fabsf(v[j][c])); ss = fmaf(v[j][c], v[j][c], ss); }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { m = fmaxf(m, __shfl_xor(m, off, 64)); ss += __shfl_xor(ss, off, 64); }
+    if (lane == 0) { s_m[wave] = m; s_ss[wave] = ss; }
+    __syncthreads();
+    m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    ss = (s_ss[0] + s_ss[1]) + (s_ss[2] + s_ss[3]);
+    const float sc = m / 127.0f, inv = sc > 0.0f ? 1.0f / sc : 0.0f;      // (k_db_quant's)
+    float l1 = 0.0f;
+    i32x4 w = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float a = rintf(v[j][c] * inv);              // within [-127, 127]; NaN -> 0 (k_db_quant)
+            l1 += fabsf(a);
+            w[j] |= (int)(((unsigned)(int)a & 255u) << (8 * c));
+        }
+    if (mine) *dst = w;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) l1 += __shfl_xor(l1, off, 64);
+    if (lane == 0) s_l1[wave] = (int)l1;
+    __syncthreads();
+    if (tid == 0) stat[row] = DbRowStat{ss, sc, (s_l1[0] + s_l1[1]) + (s_l1[2] + s_l1[3]), 0.0f};
+}
+
 // the 8-bit steps of 32 rows x 512 elements (16 pieces of 1 KB) per workgroup, a wave: eight rows, all their requests in flight; sum|a_i| by
 // integer atomics (exact in any order).  Rows >= n_rows of the last tile: zeros.  (One workgroup per 32-row tile was 39 us for a call's 64
 // queries: a single CU's vector ALU walking 131 072 elements.)
@@ -1846,6 +1893,10 @@ __global__ __launch_bounds__(DBS_WAVES * 64, 1) void k_db_sweep(const i32x4* __r
 hipError_t launch_db_prep_hi(const float* x, int n_rows, int dim, float* stat, void* hi, hipStream_t s) {
     if (n_rows <= 0) return hipSuccess;
     if (dim % 256) return hipErrorInvalidValue;
+    if (n_rows <= 256 && dim <= 4096) {                                  // a call's queries, the tiles of a few added slots: one launch
+        hipLaunchKernelGGL(k_db_prep_rows, dim3((n_rows + 31) & ~31), dim3(256), 0, s, x, n_rows, dim, (DbRowStat*)stat, (i32x4*)hi);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_db_rowstat, dim3((n_rows + 3) / 4), dim3(256), 0, s, x, n_rows, dim, (DbRowStat*)stat);
     hipLaunchKernelGGL(k_db_quant, dim3((n_rows + 31) / 32, (dim + 511) / 512), dim3(256), 0, s, x, n_rows, dim, (DbRowStat*)stat, (i32x4*)hi);
     return hipGetLastError();
