@@ -31,7 +31,8 @@ extern "C" {
 #endif
 
 #define HFNET_ABI_VERSION 2          /* 2 (round 6): HFNET_ERR_INTERNAL, hfnet_*_device_faults, hfnet_extractor_tap, option "scores_bf16x3",
-                                       "pyramid_fuse" is a frame limit (was on / off); 1: rounds 1-5 */
+                                       "pyramid_fuse" is a frame limit (was on / off), options "match_stats" / "stat_bow_exact" / "stat_db_exact" /
+                                       "db_screen_min_rows", the screened database queries take dim <= 4096 (was: any multiple of 512); 1: rounds 1-5 */
 #define HFNET_DESC_DIM 256          /* local descriptor length  (HFNetTFModelV2.cc:153)            */
 #define HFNET_MAX_LEVELS 8
 #define HFNET_MAX_KEYPOINTS 8192    /* per image and call; mono init asks for 5*nFeatures (Tracking.cc:693) */
