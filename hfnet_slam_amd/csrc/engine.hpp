@@ -98,7 +98,7 @@ struct Options {
     int pinned_frames = 4;    // chunks up to this many frames move through one pinned block inside that graph
     int conv_wlds = 1;        // 3x3 heads: weights staged through LDS once per workgroup (0: every wave reads them from L1 / L2)
     int db_gemm_min_queries = 8;   // hfnet_db_query_batch: from this many queries on, the scores come from the screened form (integer matrix pipe + exact chain)
-    int db_screen_min_rows = 4096;    // hfnet_db_query (ONE query): databases of this capacity or more take the screened form too (a quarter of the bytes; 0: never)
+    int db_screen_min_rows = 6144;    // hfnet_db_query (ONE query): databases of this capacity or more take the screened form too (a quarter of the bytes; 0: never)
     int pyramid_fuse = 4;     // calls of up to this many frames: the pyramid chain as one launch (0: never)
     int fc_tile = 1;          // FC 7680 -> 4096 of calls above 16 frames: 1 blocked kernel (weights shared through LDS, range partials in registers) when its
                               // workgroups fill the chip, 2 / 4: that kernel with 32 / 64 columns per workgroup at any size (tests), 0: one column tile per wave

@@ -94,7 +94,7 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *   "conv_wlds" (1)     3x3 head convolutions: weights staged through LDS once per workgroup (0: every wave reads them)
  *   "graph" (1), "pinned_frames" (4): host-pointer extractor calls
  *   "db_gemm_min_queries" (8): hfnet_db_query_batch screens on the integer matrix pipe from this many queries on (same bits either way)
- *   "db_screen_min_rows" (4096): hfnet_db_query (one query) screens too when the database has this many slots or more (0: never; same bits)
+ *   "db_screen_min_rows" (6144): hfnet_db_query (one query) screens too when the database has this many slots or more (0: never; same bits)
  *   "tail_fuse" (4)     calls of up to this many frames run layers 8-18 with the single-frame kernels (depthwise + projection
  *                       in one launch, short-latency MFMA chains); 0: never
  *   "pyramid_fuse" (4)  calls of up to this many frames: the pyramid resize chain as one launch
@@ -350,8 +350,8 @@ int hfnet_db_clear(hfnet_db* db);
  * mode 1: DetectRelocalizationCandidates filter (score > max(0.5, 0.8 * best)).
  * score = max(0, 1 - ||q - d||).  cand_slot / cand_score: caller buffers of `capacity` entries,
  * filled in ascending slot order; scores_all (may be NULL): one score per slot, -1 for empty.
- * A database of "db_screen_min_rows" (4096) slots or more takes the screened form of hfnet_db_query_batch below (dim <= 4096): a quarter of
- * the bytes per scan, the same bits (measured, host pointers in and out: 10 000 slots 74 -> 55 us per call, 40 000 slots 176 -> 80 us; below ~2 500
+ * A database of "db_screen_min_rows" (6144) slots or more takes the screened form of hfnet_db_query_batch below (dim <= 4096): a quarter of
+ * the bytes per scan, the same bits (measured, host pointers in and out: 10 000 slots 63 -> 52 us per call, 40 000 slots 164 -> 77 us; below ~5 000
  * slots the exact scan is the faster one). */
 int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slot, float* cand_score,
                    int* n_cand, float* best_score, float* scores_all);

@@ -327,7 +327,7 @@ def test_database(engine, screen_min_rows):
     cs, sc, best, _ = db.query(rows[1], 0)
     assert len(cs) == 0 and best == 0.0
     db.close()
-    engine.set_option("db_screen_min_rows", 4096)
+    engine.set_option("db_screen_min_rows", 6144)
 
 
 @pytest.mark.parametrize("cap,dim,n_q", [(700, 4096, 9), (33, 256, 8), (257, 512, 31), (1000, 768, 33), (95, 1024, 64), (3001, 4096, 97),

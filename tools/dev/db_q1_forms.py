@@ -31,4 +31,4 @@ for N in (1000, 2500, 5000, 10000, 20000, 40000):
         out.append((wall * 1e6, dev))
     print("N %6d  scan: call %.1f us, launches %.1f us   screened: call %.1f us, launches %.1f us" % (N, out[0][0], out[0][1], out[1][0], out[1][1]))
     db.close()
-eng.set_option("db_screen_min_rows", 4096)
+eng.set_option("db_screen_min_rows", 6144)

@@ -233,7 +233,7 @@ def run(budget_s: float, seed: int, big_share: float = 0.02, max_cases: int = 0)
                 else:
                     n, dim = int(rng.integers(1, 1500)), int(rng.choice([4096, 4096, 4096, 1024, 256]))
                     note("db", n)
-                    eng.set_option("db_screen_min_rows", int(rng.choice([0, 1, 4096])))      # (one query: exact scan / screened form)
+                    eng.set_option("db_screen_min_rows", int(rng.choice([0, 1, 6144])))      # (one query: exact scan / screened form)
                     rows = unit(n, dim)
                     db = capi.Database(eng, n + 5, dim)
                     for i in range(n):
