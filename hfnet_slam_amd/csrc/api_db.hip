@@ -197,17 +197,39 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
         HF_LAUNCH(&e, e.stream, "db_scores_batch", launch_db_scores_batch(d_q, n_queries, db->d_db, db->d_occ, db->capacity, db->dim, d_scores, d_bits, e.stream));
     }
     HF_LAUNCH(&e, e.stream, "db_filter", launch_db_filter(d_scores, db->capacity, mode, d_bits, parts, d_slot, d_cs, d_n, d_best, n_queries, e.stream));
+    // results: counts, best scores and the first candidates of EVERY query in one round trip -- two strided copies (the first kFirst entries of each
+    // query's row) instead of two small copies per query behind a first synchronisation (128 copies of a few bytes for 64 queries: a multiple of
+    // the scan's own time); a query with more candidates fetches its rest in a second one
+    constexpr size_t kFirst = 32;
+    const size_t first = std::min(cap, kFirst);
     HF_TRY(e.d2h(n_cand, d_n, sizeof(int32_t) * Q));
     if (best_score) HF_TRY(e.d2h(best_score, d_best, sizeof(float) * Q));
     if (scores_all) HF_TRY(e.d2h(scores_all, d_scores, sizeof(float) * Q * cap));
+    // (ONE piece of the pinned block, taken last: a later bounce_take may drain and reuse -- or replace -- the block)
+    unsigned char* b_slot = nullptr;
+    HF_TRY(e.bounce_take((sizeof(int32_t) + sizeof(float)) * Q * first, &b_slot));
+    unsigned char* b_score = b_slot + sizeof(int32_t) * Q * first;
+    HF_HIP(hipMemcpy2DAsync(b_slot, sizeof(int32_t) * first, d_slot, sizeof(int32_t) * cap, sizeof(int32_t) * first, Q, hipMemcpyDeviceToHost, e.stream));
+    HF_HIP(hipMemcpy2DAsync(b_score, sizeof(float) * first, d_cs, sizeof(float) * cap, sizeof(float) * first, Q, hipMemcpyDeviceToHost, e.stream));
     HF_TRY(e.sync_host());
+    bool more = false;
     for (size_t qi = 0; qi < Q; ++qi) {
         const int n = n_cand[qi];
-        if (n <= 0) continue;
-        HF_TRY(e.d2h(cand_slot + qi * cap, d_slot + qi * cap, sizeof(int32_t) * n));
-        HF_TRY(e.d2h(cand_score + qi * cap, d_cs + qi * cap, sizeof(float) * n));
+        if (n < 0 || (size_t)n > cap) { set_error("db: candidate count %d of query %zu outside [0, %zu]", n, qi, cap); return HFNET_ERR_DEVICE; }
+        const size_t n0 = std::min((size_t)n, first);
+        std::memcpy(cand_slot + qi * cap, b_slot + sizeof(int32_t) * qi * first, sizeof(int32_t) * n0);
+        std::memcpy(cand_score + qi * cap, b_score + sizeof(float) * qi * first, sizeof(float) * n0);
+        more = more || (size_t)n > first;
     }
-    HF_TRY(e.sync_host());
+    if (more) {
+        for (size_t qi = 0; qi < Q; ++qi) {
+            const size_t n = (size_t)n_cand[qi];
+            if (n <= first) continue;
+            HF_TRY(e.d2h(cand_slot + qi * cap + first, d_slot + qi * cap + first, sizeof(int32_t) * (n - first)));
+            HF_TRY(e.d2h(cand_score + qi * cap + first, d_cs + qi * cap + first, sizeof(float) * (n - first)));
+        }
+        HF_TRY(e.sync_host());
+    }
     return HFNET_OK;
 } catch (...) { return ::hfnet::api_exception(); }
 

@@ -32,3 +32,18 @@ for N in (1000, 2500, 5000, 10000, 20000, 40000):
     print("N %6d  scan: call %.1f us, launches %.1f us   screened: call %.1f us, launches %.1f us" % (N, out[0][0], out[0][1], out[1][0], out[1][1]))
     db.close()
 eng.set_option("db_screen_min_rows", 6144)
+# the batched query's call time (64 queries, 10 000 slots)
+N = 10000
+db = capi.Database(eng, N, DIM)
+for i in range(N):
+    db.add(i, blk[i & 2047] if i >= 2048 else blk[i])
+qs = blk[rng.integers(0, 2048, 64)] + 0.003 * rng.standard_normal((64, DIM)).astype(np.float32)
+qs = (qs / np.linalg.norm(qs, axis=1, keepdims=True)).astype(np.float32)
+import ctypes as C
+from hfnet_slam_amd.capi import lib, _p, _chk
+slot = np.zeros((64, N), np.int32); score = np.zeros((64, N), np.float32); n = np.zeros((64,), np.int32); best = np.zeros((64,), np.float32)
+for _ in range(5): _chk(lib().hfnet_db_query_batch(db.h, 64, _p(qs), 0, _p(slot), _p(score), _p(n), _p(best), None))
+t0 = time.perf_counter()
+for _ in range(50): _chk(lib().hfnet_db_query_batch(db.h, 64, _p(qs), 0, _p(slot), _p(score), _p(n), _p(best), None))
+print("64 queries x %d slots: call %.1f us (host pointers in and out, no scores_all); candidates per query %.1f" % (N, (time.perf_counter() - t0) / 50 * 1e6, n.mean()))
+db.close()
