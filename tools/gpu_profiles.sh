@@ -47,6 +47,13 @@ for P in "$P1" "$P2"; do
   python $GRAFT_REPO_ROOT/tools/pmc_summary.py $(find /tmp/pmct$i -name '*counter_collection.csv' | head -1) > $OUT/${TAG}_pmc_$( [ $i = 1 ] && echo sq || echo instmix )_bf16x3_b${CH}.txt
   i=$((i+1))
 done
+# ---- the two exact paths beside the extractor that changed in round 6, alone: kernel times of the batched database query (64 queries x 10 000
+#      keyframes x 4096) and of SearchByBoW at the headline call's 255 pairs
+cd /tmp
+rm -rf /tmp/ktd && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktd -- python $GRAFT_REPO_ROOT/tools/dev/db_only.py 64 4096 > $OUT/ktd.log 2>&1
+cp $(find /tmp/ktd -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_db_q64_kernel_stats.csv
+rm -rf /tmp/ktm && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktm -- python $GRAFT_REPO_ROOT/tools/dev/match_only.py 10 255 > $OUT/ktm.log 2>&1
+cp $(find /tmp/ktm -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_match_255_kernel_stats.csv
 rm -f $OUT/*.log
 ls -la $OUT
 head -c 1500 $OUT/${TAG}_bench.json
