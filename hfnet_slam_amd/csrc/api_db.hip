@@ -174,7 +174,10 @@ int hfnet_db_query_batch(hfnet_db* db, int n_queries, const float* queries, int 
     Engine& e = db->eng->impl;
     std::lock_guard<std::mutex> lk2(e.mu);
     e.bounce_discard();
-    const bool gemm = n_queries >= e.opt.db_gemm_min_queries && db_screen_supported(db->dim);
+    // the screened form: from "db_gemm_min_queries" queries on, and -- any number of queries -- against a database large enough that a quarter of the
+    // bytes pays for the queries' fragments ("db_screen_min_rows", as hfnet_db_query)
+    const bool gemm = db_screen_supported(db->dim) &&
+                      (n_queries >= e.opt.db_gemm_min_queries || (e.opt.db_screen_min_rows > 0 && db->capacity >= e.opt.db_screen_min_rows));
     if (!gemm && db->dim > 4096) { set_error("db: the exact batched scan supports dim <= 4096"); return HFNET_ERR_INVALID_ARG; }
     HF_HIP(hipSetDevice(e.device));
     const size_t Q = (size_t)n_queries, cap = (size_t)db->capacity;

@@ -94,7 +94,8 @@ int hfnet_engine_info(const hfnet_engine* e, int what);
  *   "conv_wlds" (1)     3x3 head convolutions: weights staged through LDS once per workgroup (0: every wave reads them)
  *   "graph" (1), "pinned_frames" (4): host-pointer extractor calls
  *   "db_gemm_min_queries" (8): hfnet_db_query_batch screens on the integer matrix pipe from this many queries on (same bits either way)
- *   "db_screen_min_rows" (6144): hfnet_db_query (one query) screens too when the database has this many slots or more (0: never; same bits)
+ *   "db_screen_min_rows" (6144): hfnet_db_query (one query) and hfnet_db_query_batch of fewer than "db_gemm_min_queries" queries screen too when the
+ *                       database has this many slots or more (0: never; same bits)
  *   "tail_fuse" (4)     calls of up to this many frames run layers 8-18 with the single-frame kernels (depthwise + projection
  *                       in one launch, short-latency MFMA chains); 0: never
  *   "pyramid_fuse" (4)  calls of up to this many frames: the pyramid resize chain as one launch
@@ -358,7 +359,8 @@ int hfnet_db_query(hfnet_db* db, const float* query, int mode, int32_t* cand_slo
 /* The same scan for n_queries descriptors at once (a burst of keyframes at loop closing / relocalisation,
  * BASELINE config 5).  queries: [n_queries][dim]; cand_slot / cand_score: [n_queries][capacity] (row q holds n_cand[q]
  * entries); best_score: [n_queries] or NULL; scores_all: [n_queries][capacity] or NULL.
- *  - fewer than "db_gemm_min_queries" (8) queries: the exact scan, the database crosses HBM once per 8 queries; per query
+ *  - fewer than "db_gemm_min_queries" (8) queries against a database of fewer than "db_screen_min_rows" slots: the exact scan, the database
+ *    crosses HBM once per 8 queries; per query
  *    EVERY result equals hfnet_db_query's bit for bit (dim <= 4096);
  *  - otherwise (dim <= 4096): the score is EXACTLY 0 for every keyframe at distance >= 1 from the query, so a crude product on
  *    the integer matrix pipe only has to find the slots that can be closer.  The database keeps an 8-bit copy of its rows (+ 1 byte per

@@ -293,7 +293,7 @@ def test_loop_closure_stress_10k_database(engine):
     qs = rows[planted] + 0.003 * rng.standard_normal((67, dim)).astype(np.float32)
     qs = (qs / np.linalg.norm(qs, axis=1, keepdims=True)).astype(np.float32)
     # (a) the exact batched scan (engine option db_gemm_min_queries above Q): batched == single-query == oracle, bit for bit
-    engine.set_option("db_gemm_min_queries", 1 << 20)
+    engine.set_option("db_gemm_min_queries", 1 << 20); engine.set_option("db_screen_min_rows", 0)
     for mode in (0, 1):
         cands, best, scores = db.query_batch(qs, mode, want_scores=True)
         for i in (0, 7, 8, 33, 66):
@@ -308,7 +308,7 @@ def test_loop_closure_stress_10k_database(engine):
     #     other occupied slot is scored with the exact chain.
     #     Contract: EVERY output equals the exact scan's (== the oracle's) bit for bit -- the scores of all slots (-1 for the erased one),
     #     best, candidate set, candidate scores.
-    engine.set_option("db_gemm_min_queries", 8)
+    engine.set_option("db_gemm_min_queries", 8); engine.set_option("db_screen_min_rows", 6144)
     exact_all = np.stack([O.db_scores(qs[i], rows) for i in range(67)])
     exact_all[:, 17] = -1.0
     for mode in (0, 1):

@@ -331,7 +331,7 @@ def test_database(engine, screen_min_rows):
 
 
 @pytest.mark.parametrize("cap,dim,n_q", [(700, 4096, 9), (33, 256, 8), (257, 512, 31), (1000, 768, 33), (95, 1024, 64), (3001, 4096, 97),
-                                          (1500, 2048, 129), (64, 4096, 200), (31, 256, 40)])
+                                          (1500, 2048, 129), (64, 4096, 200), (31, 256, 40), (700, 4096, 3), (90, 512, 1)])
 def test_database_batched_screen_geometries(engine, cap, dim, n_q):
     """hfnet_db_query_batch, >= 8 queries: the screen on the integer matrix pipe (k_db_sweep: the database's 8-bit copy in fragment order, whole
     32-row tiles; one or two query tiles of 32 in registers, every wave a quarter of k, a launch per 64 queries; descriptor lengths other than
@@ -360,9 +360,9 @@ def test_database_batched_screen_geometries(engine, cap, dim, n_q):
     if n_q > 2: qs[2] = 0.0
     try:
         for mode in (0, 1):
-            engine.set_option("db_gemm_min_queries", 1 << 20)
+            engine.set_option("db_gemm_min_queries", 1 << 20); engine.set_option("db_screen_min_rows", 0)
             ce, be, se = db.query_batch(qs, mode, want_scores=True)
-            engine.set_option("db_gemm_min_queries", 8)
+            engine.set_option("db_gemm_min_queries", 8); engine.set_option("db_screen_min_rows", 1)      # (the size rule on: a burst of fewer than 8 is screened too)
             engine.set_option("match_stats", 1); engine.get_option("stat_db_exact")                 # (reads and clears)
             cs, bs, ss = db.query_batch(qs, mode, want_scores=True)
             evals = engine.get_option("stat_db_exact")
@@ -381,7 +381,7 @@ def test_database_batched_screen_geometries(engine, cap, dim, n_q):
             ref = np.where(occ, O.db_scores(qs[i], dense), -1.0).astype(np.float32)
             assert np.array_equal(ss[i], ref)
     finally:
-        engine.set_option("db_gemm_min_queries", 8); engine.set_option("match_stats", 0)
+        engine.set_option("db_gemm_min_queries", 8); engine.set_option("db_screen_min_rows", 6144); engine.set_option("match_stats", 0)
         db.close()
 
 
@@ -400,9 +400,9 @@ def test_database_batched_query_between_adds(engine):
         qs = np.stack([rows[s] for s in list(live)[:n_q // 2]] + [r for r in _unit_rows(rng, n_q - min(len(live), n_q // 2), dim)]).astype(np.float32)
         qs = qs + 0.003 * rng.standard_normal(qs.shape).astype(np.float32)              # (distance ~0.19 from its row: score ~0.8)
         qs = (qs / np.linalg.norm(qs, axis=1, keepdims=True)).astype(np.float32)
-        engine.set_option("db_gemm_min_queries", 1 << 20)
+        engine.set_option("db_gemm_min_queries", 1 << 20); engine.set_option("db_screen_min_rows", 0)
         ce, be, se = db.query_batch(qs, 0, want_scores=True)
-        engine.set_option("db_gemm_min_queries", 8)
+        engine.set_option("db_gemm_min_queries", 8); engine.set_option("db_screen_min_rows", 6144)
         cs, bs, ss = db.query_batch(qs, 0, want_scores=True)
         assert np.array_equal(ss, se), np.argwhere(ss != se)[:8]
         assert np.array_equal(bs, be) and all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(cs, ce))
@@ -422,7 +422,7 @@ def test_database_batched_query_between_adds(engine):
             db.add(s, rows[s]); live[s] = True
         check()
     finally:
-        engine.set_option("db_gemm_min_queries", 8)
+        engine.set_option("db_gemm_min_queries", 8); engine.set_option("db_screen_min_rows", 6144)
         db.close()
 
 
